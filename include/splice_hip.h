@@ -1,0 +1,125 @@
+/* splice_hip.h -- C ABI of libsplice_hip.so: the MI355X (gfx950) implementation of the
+ * Splice per-pair optimisation hot path.
+ *
+ * The reference (omerbt/Splice) has NO native/FFI boundary: its hot path is the Python API
+ * of models/extractor.py, models/model.py, models/unet/skip.py, models/unet/common.py, util/losses.py, util/util.py
+ * and the loop of train.py:51-80, executed as stock ATen ops.  This header is the boundary
+ * a maintainer binds instead (ctypes stub: splice_amd/_lib.py).  Each
+ * entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.  All pointers are DEVICE
+ *     pointers owned by the caller unless stated otherwise; the library never frees them.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and returns 0 (SPLICE_OK) or a negative error code; the message
+ *     is available from splice_last_error() (thread-local).  No exception crosses the ABI.
+ *   - bf16 tensors are raw uint16 (splice_bf16).  "Tld" is the per-pass row stride of a
+ *     token matrix (multiple of 32, >= T); rows T..Tld-1 of a pass are padding.
+ *   - one handle <-> one device <-> one stream at a time; handles are not thread-safe;
+ *     handles on different GPUs are independent (one process per GPU, no collectives).
+ */
+#ifndef SPLICE_HIP_H
+#define SPLICE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t splice_bf16;
+typedef void* splice_stream_t;
+
+#define SPLICE_OK 0
+#define SPLICE_ERR_ARG -1
+#define SPLICE_ERR_HIP -2
+#define SPLICE_ERR_STATE -3
+#define SPLICE_ERR_NOMEM -4
+
+int splice_version(void);
+const char* splice_last_error(void);
+
+/* ------------------------------------------------------------------ op level: ViT GEMMs
+ * C[M][N] = sum_k A[m][k] * B[n][k]  (bf16 in, fp32 accumulate) + fused epilogue.
+ * Replaces the nn.Linear / Conv2d(patch-embed) call sites inside the DINO ViT that the
+ * reference reaches through self.model(input_img) (models/extractor.py:83,91,99) and their
+ * autograd dgrads (train.py:78).  K % 64 == 0, lda/ldb % 8 == 0. */
+typedef struct splice_gemm_epilogue {
+    const float* bias;        /* [N] */
+    const float* resid;       /* fp32 [*][ldr]; row = resid_mod ? row % resid_mod : row */
+    int ldr, resid_mod;
+    float* out_f32;           /* [M][ldo] */
+    int ldo;
+    splice_bf16* out_bf;      /* [M][ldbf] */
+    int ldbf;
+    splice_bf16* out_bf_t;    /* transposed [N][ldt] (ldt % 4 == 0) */
+    int ldt;
+    splice_bf16* out_pre;     /* [M][ldp] value before GELU (may be NULL) */
+    int ldp;
+    const splice_bf16* aux;   /* [M][ldaux] pre-GELU activations for SPLICE_EPI_GELU_GRAD */
+    int ldaux;
+    float* out_f32_cols;      /* fp32 copy of columns [col_lo, col_hi): [M][ld_cols] */
+    int ld_cols, col_lo, col_hi;
+    float alpha;
+} splice_gemm_epilogue;
+
+enum {
+    SPLICE_EPI_BIAS = 1, SPLICE_EPI_RESID = 2, SPLICE_EPI_OUT_F32 = 4, SPLICE_EPI_OUT_BF = 8,
+    SPLICE_EPI_OUT_T = 16, SPLICE_EPI_GELU = 32, SPLICE_EPI_GELU_GRAD = 64,
+    SPLICE_EPI_COLS_F32 = 128, SPLICE_EPI_ALPHA = 256
+};
+
+int splice_gemm_nt_bf16(unsigned flags, const splice_bf16* A, int lda, const splice_bf16* B, int ldb,
+                        int M, int N, int K, const splice_gemm_epilogue* epi, splice_stream_t stream);
+
+/* LayerNorm(D, eps) of the DINO blocks (eps 1e-6), fp32 in -> bf16 out, and its dgrad
+ * accumulated into the fp32 residual-gradient stream: g_out = g_in + dLN(dy). */
+int splice_layernorm_fwd(const float* x, const float* gamma, const float* beta, splice_bf16* y,
+                         float* mean, float* rstd, int rows, int D, float eps, splice_stream_t stream);
+int splice_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                         const float* rstd, const float* g_in, float* g_out, splice_bf16* g_out_bf,
+                         int rows, int D, splice_stream_t stream);
+
+/* Multi-head self-attention (head dim 64), DINO Attention.forward: softmax(q k^T d^-1/2) v.
+ * qkv [B*Tld][3D] bf16 (layout of models/extractor.py:136-151), qkvT its transpose [3D][ldt].
+ * out [B*Tld][D] bf16; lse [B][H][Tld] fp32 (saved for the backward). */
+int splice_attention_fwd(const splice_bf16* qkv, const splice_bf16* qkvT, int ldt, int B, int T, int Tld,
+                         int D, int H, float scale, splice_bf16* out, float* lse, splice_stream_t stream);
+/* dqkv [B*Tld][3D] bf16 from dout [B*Tld][D] (+ its transpose doutT [D][ldt]); delta is
+ * [B][H][Tld] fp32 scratch. */
+int splice_attention_bwd(const splice_bf16* qkv, const splice_bf16* qkvT, int ldt, int B, int T, int Tld,
+                         int D, int H, float scale, const splice_bf16* out, const float* lse,
+                         const splice_bf16* dout, const splice_bf16* doutT, float* delta,
+                         splice_bf16* dqkv, splice_stream_t stream);
+/* attention probabilities [B][H][T][T] fp32 (the tensors models/extractor.py:44-45 hooks). */
+int splice_attention_probs(const splice_bf16* qkv, int B, int T, int Tld, int D, int H, float scale,
+                           const float* lse, float* probs, splice_stream_t stream);
+
+/* attn_cosine_sim (models/extractor.py:4-9) on K fp32 [T][ldk] (D columns): S fp32 [T][T].
+ * `ws` is caller scratch of splice_keys_selfsim_ws_bytes(T, D) bytes; the backward needs the
+ * state the forward left in it. */
+size_t splice_keys_selfsim_ws_bytes(int T, int D);
+int splice_keys_selfsim_fwd(const float* K, int ldk, int T, int D, float eps, float* S, void* ws,
+                            splice_stream_t stream);
+int splice_keys_selfsim_bwd(const float* dS, const float* S, int T, int D, float eps, float* dK, int lddk,
+                            int accumulate, void* ws, splice_stream_t stream);
+
+/* F.mse_loss(a, b) (util/losses.py:82,93,104) on 2-D strided fp32 views:
+ * loss_accum[0] += weight * mean((a-b)^2); grad (optional) = weight * 2 (a-b) / (rows*cols). */
+int splice_mse(const float* a, int lda, const float* b, int ldb, int rows, int cols, float weight,
+               float* loss_accum, float* grad, int ldg, splice_stream_t stream);
+
+/* patch-embed operand builders (Conv2d(3,D,p,p) as a GEMM; optional fused ImageNet Normalize,
+ * util/losses.py:19) and helpers */
+int splice_patchify(const float* img, splice_bf16* patches, int B, int H, int W, int p, int Tld,
+                    int normalize, splice_stream_t stream);
+int splice_unpatchify(const float* dpatches, float* dimg, int B, int H, int W, int p, int Tld,
+                      int normalize, splice_stream_t stream);
+int splice_cast_f32_bf16(const float* x, splice_bf16* y, size_t n, splice_stream_t stream);
+int splice_cast_bf16_f32(const splice_bf16* x, float* y, size_t n, splice_stream_t stream);
+int splice_transpose_f32_bf16(const float* x, splice_bf16* y, int rows, int cols, int ldy, splice_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPLICE_HIP_H */

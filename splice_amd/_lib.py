@@ -1,0 +1,92 @@
+"""ctypes binding of libsplice_hip.so (the C ABI of include/splice_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call fails,
+a RuntimeError is raised.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C splice_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsplice_hip.so")
+
+_lib = None
+
+
+class GemmEpilogue(C.Structure):
+    _fields_ = [
+        ("bias", C.c_void_p), ("resid", C.c_void_p), ("ldr", C.c_int), ("resid_mod", C.c_int),
+        ("out_f32", C.c_void_p), ("ldo", C.c_int),
+        ("out_bf", C.c_void_p), ("ldbf", C.c_int),
+        ("out_bf_t", C.c_void_p), ("ldt", C.c_int),
+        ("out_pre", C.c_void_p), ("ldp", C.c_int),
+        ("aux", C.c_void_p), ("ldaux", C.c_int),
+        ("out_f32_cols", C.c_void_p), ("ld_cols", C.c_int), ("col_lo", C.c_int), ("col_hi", C.c_int),
+        ("alpha", C.c_float),
+    ]
+
+
+EPI_BIAS, EPI_RESID, EPI_OUT_F32, EPI_OUT_BF, EPI_OUT_T = 1, 2, 4, 8, 16
+EPI_GELU, EPI_GELU_GRAD, EPI_COLS_F32, EPI_ALPHA = 32, 64, 128, 256
+
+_vp, _i, _f, _sz, _u = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint
+
+_SIGNATURES = {
+    "splice_version": ([], C.c_int),
+    "splice_last_error": ([], C.c_char_p),
+    "splice_gemm_nt_bf16": ([_u, _vp, _i, _vp, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _vp], _i),
+    "splice_layernorm_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
+    "splice_layernorm_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
+    "splice_attention_fwd": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
+    "splice_attention_bwd": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
+    "splice_attention_probs": ([_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
+    "splice_keys_selfsim_ws_bytes": ([_i, _i], _sz),
+    "splice_keys_selfsim_fwd": ([_vp, _i, _i, _i, _f, _vp, _vp, _vp], _i),
+    "splice_keys_selfsim_bwd": ([_vp, _vp, _i, _i, _f, _vp, _i, _i, _vp, _vp], _i),
+    "splice_mse": ([_vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp], _i),
+    "splice_patchify": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "splice_unpatchify": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "splice_cast_f32_bf16": ([_vp, _vp, _sz, _vp], _i),
+    "splice_cast_bf16_f32": ([_vp, _vp, _sz, _vp], _i),
+    "splice_transpose_f32_bf16": ([_vp, _vp, _i, _i, _i, _vp], _i),
+}
+
+
+def exported_symbols():
+    """Names include/splice_hip.h declares (checked against the .so by the CPU tests)."""
+    return sorted(_SIGNATURES)
+
+
+def register(name, argtypes, restype):
+    _SIGNATURES[name] = (argtypes, restype)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built "
+                "(run __graft_entry__.build() or `make -C splice_amd/csrc`). There is no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().splice_last_error().decode(errors="replace")
+        raise RuntimeError(f"libsplice_hip {what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

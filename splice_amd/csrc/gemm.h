@@ -1,0 +1,201 @@
+// bf16 "NT" GEMM tile engine for gfx950:  C[M][N] = sum_k A[m][k] * B[n][k]   (fp32 accumulate)
+//
+// Both operands are K-contiguous (activations [rows][K]; weights pre-packed [N][K]), so
+// every MFMA fragment is one 16-byte LDS read.  Workgroup = 256 threads = 4 waves in a
+// 2x2 grid; each wave owns a (BM/2)x(BN/2) sub-tile built from 16x16x32 bf16 MFMAs.
+// K is consumed in BK=64 slices staged through LDS with an XOR swizzle of the 16-byte
+// chunks (chunk ^= row&7) that makes the ds_read_b128 fragment reads conflict-free;
+// the next slice is prefetched into registers while the current one feeds the MFMAs.
+//
+// Ragged M / N are handled by clamping the load row and predicating the epilogue, so any
+// M, N >= 1 works; K must be a multiple of 64 and lda/ldb multiples of 8 (16-byte rows).
+#pragma once
+#include "common.h"
+
+constexpr int GEMM_BK = 64;
+
+template <int BM, int BN>
+struct GemmTile {
+    static constexpr int FM = BM / 32;  // 16-row fragments per wave along M
+    static constexpr int FN = BN / 32;
+    static constexpr int A_LOADS = BM * 8 / 256;  // 16-byte chunks per thread per slice
+    static constexpr int B_LOADS = BN * 8 / 256;
+    static constexpr int LDS_ELEMS = (BM + BN) * GEMM_BK;
+    f32x4 acc[FM][FN];
+
+    __device__ __forceinline__ void run(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+                                        int M, int N, int K, int m0, int n0, bf16_t* smem) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave >> 1, wn = wave & 1;
+        bf16_t* As = smem;
+        bf16_t* Bs = smem + BM * GEMM_BK;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        const bf16_t* ag[A_LOADS];
+        const bf16_t* bg[B_LOADS];
+        int as_off[A_LOADS], bs_off[B_LOADS];
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
+            int gr = m0 + row;
+            gr = gr < M ? gr : M - 1;
+            ag[i] = A + (size_t)gr * lda + kc * 8;
+            as_off[i] = row * GEMM_BK + ((kc ^ (row & 7)) << 3);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
+            int gr = n0 + row;
+            gr = gr < N ? gr : N - 1;
+            bg[i] = B + (size_t)gr * ldb + kc * 8;
+            bs_off[i] = row * GEMM_BK + ((kc ^ (row & 7)) << 3);
+        }
+        uint4 ar[A_LOADS], br[B_LOADS];
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) ar[i] = *reinterpret_cast<const uint4*>(ag[i]);
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) br[i] = *reinterpret_cast<const uint4*>(bg[i]);
+
+        const int frow = lane & 15, fchunk = lane >> 4;
+        for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
+            __syncthreads();  // previous slice fully consumed
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) *reinterpret_cast<uint4*>(As + as_off[i]) = ar[i];
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) *reinterpret_cast<uint4*>(Bs + bs_off[i]) = br[i];
+            __syncthreads();
+            if (k0 + GEMM_BK < K) {
+#pragma unroll
+                for (int i = 0; i < A_LOADS; ++i) ar[i] = *reinterpret_cast<const uint4*>(ag[i] + k0 + GEMM_BK);
+#pragma unroll
+                for (int i = 0; i < B_LOADS; ++i) br[i] = *reinterpret_cast<const uint4*>(bg[i] + k0 + GEMM_BK);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                uint4 af[FM], bf[FN];
+                const int chunk = kk * 4 + fchunk;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int row = wm * (BM / 2) + i * 16 + frow;
+                    af[i] = *reinterpret_cast<const uint4*>(As + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int row = wn * (BN / 2) + j * 16 + frow;
+                    bf[j] = *reinterpret_cast<const uint4*>(Bs + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+            }
+        }
+    }
+
+    // Visit every accumulator fragment: f(row0, col, v) where v[r] is C[row0 + r][col].
+    template <class F>
+    __device__ __forceinline__ void for_each(int m0, int n0, F&& f) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                f(m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4, n0 + wn * (BN / 2) + j * 16 + (lane & 15), acc[i][j]);
+    }
+};
+
+// Fused epilogue description shared by every ViT GEMM: the public splice_gemm_epilogue.
+typedef splice_gemm_epilogue GemmEpi;
+enum : unsigned {
+    EPI_BIAS = SPLICE_EPI_BIAS, EPI_RESID = SPLICE_EPI_RESID, EPI_OUT_F32 = SPLICE_EPI_OUT_F32,
+    EPI_OUT_BF = SPLICE_EPI_OUT_BF, EPI_OUT_T = SPLICE_EPI_OUT_T, EPI_GELU = SPLICE_EPI_GELU,
+    EPI_GELU_GRAD = SPLICE_EPI_GELU_GRAD, EPI_COLS_F32 = SPLICE_EPI_COLS_F32, EPI_ALPHA = SPLICE_EPI_ALPHA
+};
+
+template <unsigned FLAGS>
+__device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, int M, int N, int row0, int col, f32x4 v) {
+    if (col >= N || row0 >= M) return;
+    float b = 0.f;
+    if (FLAGS & EPI_BIAS) b = e.bias[col];
+    float x[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        x[r] = v[r];
+        if (FLAGS & EPI_ALPHA) x[r] *= e.alpha;
+        x[r] += b;
+    }
+    if (FLAGS & EPI_RESID) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (row0 + r < M) {
+                const int rr = e.resid_mod ? (row0 + r) % e.resid_mod : (row0 + r);
+                x[r] += e.resid[(size_t)rr * e.ldr + col];
+            }
+    }
+    if (FLAGS & EPI_GELU_GRAD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (row0 + r < M) x[r] *= gelu_grad_f(bf2f(e.aux[(size_t)(row0 + r) * e.ldaux + col]));
+    }
+    if (FLAGS & EPI_GELU) {
+        if (e.out_pre) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (row0 + r < M) e.out_pre[(size_t)(row0 + r) * e.ldp + col] = f2bf(x[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = gelu_f(x[r]);
+    }
+    if (FLAGS & EPI_OUT_F32) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (row0 + r < M) e.out_f32[(size_t)(row0 + r) * e.ldo + col] = x[r];
+    }
+    if (FLAGS & EPI_OUT_BF) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (row0 + r < M) e.out_bf[(size_t)(row0 + r) * e.ldbf + col] = f2bf(x[r]);
+    }
+    if (FLAGS & EPI_OUT_T) {
+        bf16_t* p = e.out_bf_t + (size_t)col * e.ldt + row0;
+        if (row0 + 3 < M) {
+            uint2 pk = {pack2bf(x[0], x[1]), pack2bf(x[2], x[3])};
+            *reinterpret_cast<uint2*>(p) = pk;  // row0 % 4 == 0 and ldt % 4 == 0 -> 8-byte aligned
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (row0 + r < M) p[r] = f2bf(x[r]);
+        }
+    }
+    if (FLAGS & EPI_COLS_F32) {
+        if (col >= e.col_lo && col < e.col_hi) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (row0 + r < M) e.out_f32_cols[(size_t)(row0 + r) * e.ld_cols + (col - e.col_lo)] = x[r];
+        }
+    }
+}
+
+template <int BM, int BN, unsigned FLAGS>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
+                                                      int ldb, int M, int N, int K, GemmEpi e) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[GemmTile<BM, BN>::LDS_ELEMS];
+    const int tiles_n = (N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    const int t = xcd_remap(blockIdx.x, nwg);
+    const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+    GemmTile<BM, BN> tile;
+    tile.run(A, lda, B, ldb, M, N, K, m0, n0, smem);
+    tile.for_each(m0, n0, [&](int row0, int col, f32x4 v) { gemm_epilogue<FLAGS>(e, M, N, row0, col, v); });
+}
+
+template <int BM, int BN, unsigned FLAGS>
+static inline void launch_gemm_nt(hipStream_t s, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K,
+                                  const GemmEpi& e) {
+    const int grid = cdiv(M, BM) * cdiv(N, BN);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, FLAGS>), dim3(grid), dim3(256), 0, s, A, lda, B, ldb, M, N, K, e);
+}

@@ -1,0 +1,70 @@
+// Internal launcher declarations (one per hand-written gfx950 kernel family).
+// The public C ABI is include/splice_hip.h, implemented in capi.hip / engine.hip.
+#pragma once
+#include "common.h"
+#include "gemm.h"
+
+// ---- attention.hip -------------------------------------------------------------------
+struct AttnArgs {
+    const bf16_t* qkv;     // [B*Tld][3D]
+    const bf16_t* qkvT;    // [3D][ldt]
+    int ldt;
+    int B, T, Tld, D, H;
+    float scale;
+    bf16_t* out;           // [B*Tld][D]
+    float* lse;            // [B][H][Tld]
+    // backward only
+    const bf16_t* dout;    // [B*Tld][D]
+    const bf16_t* doutT;   // [D][ldt]
+    float* delta;          // [B][H][Tld]  rowsum(dO * O) (scratch, written by the bwd launcher)
+    bf16_t* dqkv;          // [B*Tld][3D]
+};
+int attn_fwd_launch(const AttnArgs* a, hipStream_t s);
+int attn_bwd_launch(const AttnArgs* a, hipStream_t s);
+int attn_probs_launch(const AttnArgs* a, float* probs, hipStream_t s);
+
+// ---- gemm.hip --------------------------------------------------------------------------
+// Runtime dispatch over the instantiated (tile, epilogue-flag) combinations.
+int gemm_nt_launch(unsigned flags, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K,
+                   const GemmEpi& e, hipStream_t s);
+
+// ---- vit_ops.hip -----------------------------------------------------------------------
+// LayerNorm over the last dim (D % 256 == 0 handled generally), one wave per row.
+int layernorm_fwd_launch(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
+                         int rows, int D, float eps, hipStream_t s);
+// g_out = g_in + LN_backward(dy); also emits bf16(g_out).  dy is fp32 [rows][D].
+int layernorm_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                         const float* g_in, float* g_out, bf16_t* g_out_bf, int rows, int D, hipStream_t s);
+// image [B][3][H][W] fp32 -> patch matrix bf16 [B*Tld][3*p*p] (row b*Tld+1+patch; row 0 and
+// rows >= T are zero), k index = c*p*p + py*p + px (Conv2d weight order).  Optional
+// ImageNet normalisation (x-mean)/std fused in.
+int patchify_launch(const float* img, bf16_t* patches, int B, int H, int W, int p, int Tld, int normalize, hipStream_t s);
+// d(patch matrix) fp32 [B*Tld][3*p*p] -> d(image) [B][3][H][W] (divides by std when normalize).
+int unpatchify_launch(const float* dpatches, float* dimg, int B, int H, int W, int p, int Tld, int normalize, hipStream_t s);
+int cast_f32_bf16_launch(const float* x, bf16_t* y, size_t n, hipStream_t s);
+int cast_bf16_f32_launch(const bf16_t* x, float* y, size_t n, hipStream_t s);
+int transpose_f32_to_bf16_launch(const float* x, bf16_t* y, int rows, int cols, int ldy, hipStream_t s);  // y[c][r]
+int fill_f32_launch(float* x, float v, size_t n, hipStream_t s);
+int add_f32_launch(float* y, const float* x, size_t n, hipStream_t s);  // y += x
+
+// ---- selfsim.hip -----------------------------------------------------------------------
+// Cosine self-similarity of the rows of K (fp32 [T][ldk], D columns), models/extractor.py:4-9.
+struct SelfSimWs {          // carved from caller-provided scratch (selfsim_ws_bytes)
+    bf16_t* kbf;            // [Tp][D]   bf16 keys (rows >= T zero), Tp = roundup(T, 64)
+    bf16_t* kbfT;           // [D][Tp]
+    float* norm;            // [Tp]      L2 norms of the bf16-rounded rows
+    bf16_t* wmat;           // [Tp][Tp]  backward weights  (dS + dS^T) / max(n_i n_j, eps)
+    float* rowdot;          // [Tp]      sum_j (dS+dS^T)_ij S_ij / n_i^2
+    int Tp;
+};
+size_t selfsim_ws_bytes(int T, int D);
+void selfsim_ws_carve(void* base, int T, int D, SelfSimWs* ws);
+// S = cos-sim(K) -> fp32 [T][T]; fills ws.kbf / kbfT / norm (needed by the backward).
+int selfsim_fwd_launch(const float* K, int ldk, int T, int D, float eps, float* S, const SelfSimWs& ws, hipStream_t s);
+// dK fp32 [T][lddk] (+= if accumulate) from dS fp32 [T][T] (any, not nec. symmetric); needs the
+// ws state left by selfsim_fwd_launch on the same K, and S.
+int selfsim_bwd_launch(const float* dS, const float* S, int T, int D, float eps, float* dK, int lddk, int accumulate,
+                       const SelfSimWs& ws, hipStream_t s);
+// 2-D strided MSE: loss_accum[0] += weight * mean((a-b)^2); grad (optional) = weight * 2 (a-b) / (rows*cols)
+int mse_launch(const float* a, int lda, const float* b, int ldb, int rows, int cols, float weight, float* loss_accum,
+               float* grad, int ldg, hipStream_t s);

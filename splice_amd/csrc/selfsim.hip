@@ -1,0 +1,160 @@
+// Key self-similarity (K11/K12 of SURVEY.md): S_ij = K_i.K_j / max(|K_i||K_j|, eps),
+// models/extractor.py:4-9 (attn_cosine_sim) applied to the concatenated layer-11 keys
+// (models/extractor.py:158-163), forward and backward, plus the strided MSE used by the
+// three losses (util/losses.py:82,93,104).
+//
+// Forward  = row prep (bf16 cast + norms + transposed copy) -> K K^T on the MFMA tile
+//            engine with the normalising epilogue.
+// Backward = E = dS + dS^T;  W_ij = E_ij / c_ij;  r_i = sum_j [n_i n_j > eps] E_ij S_ij / n_i^2;
+//            dK = W K - diag(r) K   (second MFMA GEMM, K-dim = tokens, via the transposed copy).
+#include "kernels.h"
+
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+size_t selfsim_ws_bytes(int T, int D) {
+    const size_t Tp = round_up(T, 64);
+    return Tp * D * 2 * 2 + Tp * 4 * 2 + Tp * Tp * 2 + 256;
+}
+void selfsim_ws_carve(void* base, int T, int D, SelfSimWs* ws) {
+    const size_t Tp = round_up(T, 64);
+    char* p = (char*)base;
+    ws->Tp = (int)Tp;
+    ws->kbf = (bf16_t*)p; p += Tp * D * 2;
+    ws->kbfT = (bf16_t*)p; p += Tp * D * 2;
+    ws->wmat = (bf16_t*)p; p += Tp * Tp * 2;
+    ws->norm = (float*)p; p += Tp * 4;
+    ws->rowdot = (float*)p;
+}
+
+// one wave per row: bf16 copy, norm of the ROUNDED row (so the diagonal is exactly cos=1)
+__global__ __launch_bounds__(256) void selfsim_prep_kernel(const float* __restrict__ K, int ldk, int T, int D, SelfSimWs ws) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= ws.Tp) return;
+    float sq = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const bf16_t h = row < T ? f2bf(K[(size_t)row * ldk + d]) : (bf16_t)0;
+        ws.kbf[(size_t)row * D + d] = h;
+        ws.kbfT[(size_t)d * ws.Tp + row] = h;
+        const float f = bf2f(h);
+        sq += f * f;
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) ws.norm[row] = sqrtf(sq);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void selfsim_gemm_kernel(const bf16_t* __restrict__ Kb, int T, int D, const float* __restrict__ norm,
+                                                           float eps, float* __restrict__ S) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[GemmTile<BM, BN>::LDS_ELEMS];
+    const int tiles_n = (T + BN - 1) / BN;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+    GemmTile<BM, BN> tile;
+    tile.run(Kb, D, Kb, D, T, T, D, m0, n0, smem);
+    tile.for_each(m0, n0, [&](int row0, int col, f32x4 v) {
+        if (col >= T) return;
+        const float nj = norm[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (row0 + r < T) S[(size_t)(row0 + r) * T + col] = v[r] / fmaxf(norm[row0 + r] * nj, eps);
+    });
+}
+
+int selfsim_fwd_launch(const float* K, int ldk, int T, int D, float eps, float* S, const SelfSimWs& ws, hipStream_t s) {
+    if (D % 64) return SPLICE_ERR_ARG;
+    hipLaunchKernelGGL(selfsim_prep_kernel, dim3(cdiv(ws.Tp, 4)), dim3(256), 0, s, K, ldk, T, D, ws);
+    const int grid = cdiv(T, 64) * cdiv(T, 64);
+    hipLaunchKernelGGL((selfsim_gemm_kernel<64, 64>), dim3(grid), dim3(256), 0, s, ws.kbf, T, D, ws.norm, eps, S);
+    return SPLICE_OK;
+}
+
+// one block per row i: W_i. = (dS_i. + dS_.i) / c_i. ; r_i
+__global__ __launch_bounds__(256) void selfsim_wmat_kernel(const float* __restrict__ dS, const float* __restrict__ S, int T, float eps,
+                                                           SelfSimWs ws) {
+    const int i = blockIdx.x;
+    __shared__ float red[4];
+    bf16_t* wrow = ws.wmat + (size_t)i * ws.Tp;
+    if (i >= T) {
+        for (int j = threadIdx.x; j < ws.Tp; j += 256) wrow[j] = 0;
+        if (threadIdx.x == 0) ws.rowdot[i] = 0.f;
+        return;
+    }
+    const float ni = ws.norm[i];
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < ws.Tp; j += 256) {
+        float w = 0.f;
+        if (j < T) {
+            const float e = dS[(size_t)i * T + j] + dS[(size_t)j * T + i];
+            const float nn = ni * ws.norm[j];
+            w = e / fmaxf(nn, eps);
+            if (nn > eps) acc += e * S[(size_t)i * T + j];
+        }
+        wrow[j] = f2bf(w);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) ws.rowdot[i] = (red[0] + red[1] + red[2] + red[3]) / fmaxf(ni * ni, 1e-30f);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void selfsim_bwd_gemm_kernel(SelfSimWs ws, int T, int D, float* __restrict__ dK, int lddk,
+                                                               int accumulate) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[GemmTile<BM, BN>::LDS_ELEMS];
+    const int tiles_n = (D + BN - 1) / BN;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+    GemmTile<BM, BN> tile;
+    tile.run(ws.wmat, ws.Tp, ws.kbfT, ws.Tp, T, D, ws.Tp, m0, n0, smem);
+    tile.for_each(m0, n0, [&](int row0, int col, f32x4 v) {
+        if (col >= D) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + r;
+            if (row < T) {
+                const float g = v[r] - ws.rowdot[row] * bf2f(ws.kbf[(size_t)row * D + col]);
+                float* p = dK + (size_t)row * lddk + col;
+                *p = accumulate ? *p + g : g;
+            }
+        }
+    });
+}
+
+int selfsim_bwd_launch(const float* dS, const float* S, int T, int D, float eps, float* dK, int lddk, int accumulate,
+                       const SelfSimWs& ws, hipStream_t s) {
+    if (D % 64) return SPLICE_ERR_ARG;
+    hipLaunchKernelGGL(selfsim_wmat_kernel, dim3(ws.Tp), dim3(256), 0, s, dS, S, T, eps, ws);
+    const int grid = cdiv(T, 64) * cdiv(D, 64);
+    hipLaunchKernelGGL((selfsim_bwd_gemm_kernel<64, 64>), dim3(grid), dim3(256), 0, s, ws, T, D, dK, lddk, accumulate);
+    return SPLICE_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int rows,
+                                                  int cols, float wmean, float* __restrict__ loss_accum, float* __restrict__ grad,
+                                                  int ldg) {
+    const size_t n = (size_t)rows * cols;
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int r = i / cols, c = i % cols;
+        const float d = a[(size_t)r * lda + c] - b[(size_t)r * ldb + c];
+        acc += d * d;
+        if (grad) grad[(size_t)r * ldg + c] = 2.0f * wmean * d;
+    }
+    __shared__ float red[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_accum, (red[0] + red[1] + red[2] + red[3]) * wmean);
+}
+
+int mse_launch(const float* a, int lda, const float* b, int ldb, int rows, int cols, float weight, float* loss_accum,
+               float* grad, int ldg, hipStream_t s) {
+    const size_t n = (size_t)rows * cols;
+    if (!n) return SPLICE_ERR_ARG;
+    size_t g = (n + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(mse_kernel, dim3((unsigned)g), dim3(256), 0, s, a, lda, b, ldb, rows, cols, weight / (float)n, loss_accum, grad, ldg);
+    return SPLICE_OK;
+}

@@ -1,0 +1,259 @@
+"""GPU parity of every hand-written HIP kernel family, called through the C ABI
+(include/splice_hip.h), against a plain fp32 torch / oracle reference of the same op.
+
+Tolerances: bf16 operands (8 mantissa bits) with fp32 accumulation -> inputs are rounded
+to bf16 first so the comparison isolates the kernel's own arithmetic; remaining error is
+output rounding (bf16 outputs: rel 2^-8) and accumulation order (fp32 outputs: ~1e-5 rel
+of the operand magnitude sum).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from splice_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _st():
+    return _lib.current_stream()
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _rand(*shape, seed=0, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * std).to(DEV)
+
+
+def _relerr(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+def _gemm(flags, A, B, M, N, K, **kw):
+    e = _lib.GemmEpilogue()
+    keep = []
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            keep.append(v)
+            setattr(e, k, v.data_ptr())
+        else:
+            setattr(e, k, v)
+    rc = _lib.lib().splice_gemm_nt_bf16(flags, _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), M, N, K, C.byref(e), _st())
+    _lib.check(rc, "gemm")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 16, 64), (100, 72, 128), (785, 768, 768), (3140, 2304, 768), (1570, 768, 3072),
+                                   (800, 192, 768), (130, 3072, 768)])
+def test_gemm_plain_f32(M, N, K):
+    A, B = _bf(_rand(M, K, seed=1)), _bf(_rand(N, K, seed=2))
+    out = torch.full((M, N), float("nan"), device=DEV)
+    _gemm(_lib.EPI_OUT_F32, A, B, M, N, K, out_f32=out, ldo=N)
+    ref = A.float() @ B.float().T
+    assert torch.isfinite(out).all()
+    assert _relerr(out, ref) < 2e-6, _relerr(out, ref)
+    # transpose / row-col swap detector: asymmetric operands, compare a few exact entries
+    assert torch.allclose(out[M - 1, 0], ref[M - 1, 0], rtol=1e-4, atol=1e-3)
+    assert torch.allclose(out[0, N - 1], ref[0, N - 1], rtol=1e-4, atol=1e-3)
+
+
+def test_gemm_epilogues():
+    M, N, K = 785, 768, 768
+    A, B = _bf(_rand(M, K, seed=3)), _bf(_rand(N, K, seed=4, std=0.05))
+    bias = _rand(N, seed=5)
+    resid = _rand(M, N, seed=6)
+    base = A.float() @ B.float().T
+    # bias + residual -> fp32
+    out = torch.empty(M, N, device=DEV)
+    _gemm(_lib.EPI_BIAS | _lib.EPI_RESID | _lib.EPI_OUT_F32, A, B, M, N, K, bias=bias, resid=resid, ldr=N, resid_mod=0,
+          out_f32=out, ldo=N)
+    assert _relerr(out, base + bias + resid) < 2e-6
+    # residual with row modulo (pos-embed style)
+    pos = _rand(200, N, seed=7)
+    _gemm(_lib.EPI_BIAS | _lib.EPI_RESID | _lib.EPI_OUT_F32, A, B, M, N, K, bias=bias, resid=pos, ldr=N, resid_mod=200,
+          out_f32=out, ldo=N)
+    ref = base + bias + pos[torch.arange(M, device=DEV) % 200]
+    assert _relerr(out, ref) < 2e-6
+    # bias -> bf16 + transposed bf16 + fp32 column window
+    ldt = 788
+    ob = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    obt = torch.zeros(N, ldt, device=DEV, dtype=torch.bfloat16)
+    oc = torch.zeros(M, 256, device=DEV)
+    _gemm(_lib.EPI_BIAS | _lib.EPI_OUT_BF | _lib.EPI_OUT_T | _lib.EPI_COLS_F32, A, B, M, N, K, bias=bias, out_bf=ob,
+          ldbf=N, out_bf_t=obt, ldt=ldt, out_f32_cols=oc, ld_cols=256, col_lo=256, col_hi=512)
+    ref = base + bias
+    assert _relerr(ob.float(), ref) < 3e-3
+    assert torch.equal(obt[:, :M].T.contiguous(), ob)
+    assert _relerr(oc, ref[:, 256:512]) < 2e-6
+    # GELU (+ saved pre-activation) and the GELU-grad epilogue
+    og = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    opre = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    _gemm(_lib.EPI_BIAS | _lib.EPI_GELU | _lib.EPI_OUT_BF, A, B, M, N, K, bias=bias, out_bf=og, ldbf=N, out_pre=opre, ldp=N)
+    assert _relerr(opre.float(), ref) < 3e-3
+    assert _relerr(og.float(), torch.nn.functional.gelu(ref)) < 4e-3
+    od = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    _gemm(_lib.EPI_GELU_GRAD | _lib.EPI_OUT_BF, A, B, M, N, K, aux=opre, ldaux=N, out_bf=od, ldbf=N)
+    x = opre.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).backward(base)
+    assert _relerr(od.float(), x.grad) < 4e-3
+
+
+def test_layernorm():
+    rows, D = 1571, 768
+    x = _rand(rows, D, seed=8, std=3.0) + 0.5
+    gamma, beta = 1 + 0.1 * _rand(D, seed=9), 0.1 * _rand(D, seed=10)
+    y = torch.empty(rows, D, device=DEV, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    L = _lib.lib()
+    _lib.check(L.splice_layernorm_fwd(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), _lib.ptr(mean),
+                                      _lib.ptr(rstd), rows, D, 1e-6, _st()))
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gamma, beta, 1e-6)
+    assert _relerr(y.float(), ref) < 3e-3
+    assert _relerr(mean, x.mean(1)) < 1e-5
+    dy = _rand(rows, D, seed=11)
+    g_in = _rand(rows, D, seed=12)
+    g_out = torch.empty(rows, D, device=DEV)
+    g_bf = torch.empty(rows, D, device=DEV, dtype=torch.bfloat16)
+    _lib.check(L.splice_layernorm_bwd(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(mean), _lib.ptr(rstd),
+                                      _lib.ptr(g_in), _lib.ptr(g_out), _lib.ptr(g_bf), rows, D, _st()))
+    ref.backward(dy)
+    assert _relerr(g_out, xr.grad + g_in) < 1e-5
+    assert _relerr(g_bf.float(), xr.grad + g_in) < 3e-3
+    # D = 384 (ViT-S)
+    x2 = _rand(70, 384, seed=13)
+    y2 = torch.empty(70, 384, device=DEV, dtype=torch.bfloat16)
+    _lib.check(L.splice_layernorm_fwd(_lib.ptr(x2), _lib.ptr(gamma[:384].contiguous()), _lib.ptr(beta[:384].contiguous()),
+                                      _lib.ptr(y2), None, None, 70, 384, 1e-6, _st()))
+    assert _relerr(y2.float(), torch.nn.functional.layer_norm(x2, (384,), gamma[:384], beta[:384], 1e-6)) < 3e-3
+
+
+def _attn_ref(qkv, B, T, Tld, D, H, scale):
+    """fp32 reference on the bf16-rounded qkv; returns out [B,T,D] and the leaf for autograd."""
+    x = qkv.float().reshape(B, Tld, 3, H, D // H)[:, :T].detach().clone().requires_grad_(True)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    p = ((q @ k.transpose(-1, -2)) * scale).softmax(-1)
+    o = (p @ v).transpose(1, 2).reshape(B, T, D)
+    return o, x, p
+
+
+@pytest.mark.parametrize("B,T,D,H,std", [(1, 17, 384, 6, 1.0), (2, 197, 768, 12, 1.0), (2, 785, 768, 12, 0.6), (1, 785, 768, 12, 2.5)])
+def test_attention_fwd_bwd(B, T, D, H, std):
+    Tld = (T + 31) // 32 * 32
+    rows = B * Tld
+    scale = (D // H) ** -0.5
+    qkv = _bf(_rand(rows, 3 * D, seed=20, std=std))
+    qkvT = qkv.T.contiguous()
+    out = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, Tld, device=DEV)
+    L = _lib.lib()
+    _lib.check(L.splice_attention_fwd(_lib.ptr(qkv), _lib.ptr(qkvT), rows, B, T, Tld, D, H, scale, _lib.ptr(out),
+                                      _lib.ptr(lse), _st()))
+    torch.cuda.synchronize()
+    ref, leaf, p = _attn_ref(qkv, B, T, Tld, D, H, scale)
+    got = out.float().reshape(B, Tld, D)[:, :T]
+    assert torch.isfinite(out.float()).all()
+    assert _relerr(got, ref) < 6e-3, _relerr(got, ref)
+    # probabilities API
+    probs = torch.empty(B, H, T, T, device=DEV)
+    _lib.check(L.splice_attention_probs(_lib.ptr(qkv), B, T, Tld, D, H, scale, _lib.ptr(lse), _lib.ptr(probs), _st()))
+    assert _relerr(probs, p) < 2e-3
+    # backward; padded query rows carry zero upstream gradient (engine invariant)
+    dout = _rand(B, Tld, D, seed=21)
+    dout[:, T:] = 0
+    dout = _bf(dout.reshape(rows, D))
+    doutT = dout.T.contiguous()
+    delta = torch.zeros(B, H, Tld, device=DEV)
+    dqkv = torch.zeros(rows, 3 * D, device=DEV, dtype=torch.bfloat16)
+    _lib.check(L.splice_attention_bwd(_lib.ptr(qkv), _lib.ptr(qkvT), rows, B, T, Tld, D, H, scale, _lib.ptr(out),
+                                      _lib.ptr(lse), _lib.ptr(dout), _lib.ptr(doutT), _lib.ptr(delta), _lib.ptr(dqkv), _st()))
+    torch.cuda.synchronize()
+    ref.backward(dout.float().reshape(B, Tld, D)[:, :T])
+    gref = leaf.grad  # [B,T,3,H,d]
+    ggot = dqkv.float().reshape(B, Tld, 3, H, D // H)
+    assert torch.isfinite(ggot).all()
+    for i, name in enumerate("qkv"):
+        e = _relerr(ggot[:, :T, i], gref[:, :, i])
+        assert e < 2e-2, (name, e)
+    assert ggot[:, T:, 1:].abs().max().item() == 0.0  # padded keys/values get exactly zero gradient
+
+
+def _selfsim(K, T, D, eps=1e-8):
+    L = _lib.lib()
+    ws = torch.empty(L.splice_keys_selfsim_ws_bytes(T, D), device=DEV, dtype=torch.uint8)
+    S = torch.empty(T, T, device=DEV)
+    _lib.check(L.splice_keys_selfsim_fwd(_lib.ptr(K), K.stride(0), T, D, eps, _lib.ptr(S), _lib.ptr(ws), _st()))
+    return S, ws
+
+
+def test_selfsim_golden(golden_dir):
+    """attn_cosine_sim against the vectors recorded from the reference function."""
+    g = np.load(os.path.join(golden_dir, "extractor.npz"))
+    for T, D, key in ((197, 64, "cos_T197_D64"),):
+        x = torch.from_numpy(synth.normal(11, f"cos/{T}", (1, 1, T, D)))[0, 0].to(DEV)
+        S, _ = _selfsim(x, T, D)
+        ref = torch.from_numpy(g[key])[0].to(DEV)
+        # bf16 operands: |err| <= ~2^-8 on values in [-1,1]
+        assert (S - ref).abs().max().item() < 8e-3
+        assert (S.diagonal() - 1).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("T,D", [(65, 384), (197, 768), (785, 768)])
+def test_selfsim_fwd_bwd(T, D):
+    from oracle.extractor import attn_cosine_sim
+    K = _rand(T, D, seed=30) * (1 + _rand(T, 1, seed=31).abs())
+    Kb = _bf(K).float()  # the kernel rounds K to bf16; compare on the rounded operand
+    S, ws = _selfsim(K, T, D)
+    leaf = Kb.clone().requires_grad_(True)
+    ref = attn_cosine_sim(leaf[None, None])[0]
+    assert (S - ref).abs().max().item() < 2e-5
+    dS = _rand(T, T, seed=32)  # deliberately NOT symmetric
+    dK = torch.full((T, D + 8), float("nan"), device=DEV)
+    L = _lib.lib()
+    _lib.check(L.splice_keys_selfsim_bwd(_lib.ptr(dS), _lib.ptr(S), T, D, 1e-8, _lib.ptr(dK), D + 8, 0, _lib.ptr(ws), _st()))
+    ref.backward(dS)
+    e = _relerr(dK[:, :D], leaf.grad)
+    assert e < 1e-2, e
+    # accumulate mode
+    _lib.check(L.splice_keys_selfsim_bwd(_lib.ptr(dS), _lib.ptr(S), T, D, 1e-8, _lib.ptr(dK), D + 8, 1, _lib.ptr(ws), _st()))
+    assert _relerr(dK[:, :D], 2 * leaf.grad) < 1e-2
+
+
+def test_mse():
+    a, b = _rand(785, 800, seed=40), _rand(785, 790, seed=41)
+    loss = torch.zeros(1, device=DEV)
+    grad = torch.zeros(785, 785, device=DEV)
+    _lib.check(_lib.lib().splice_mse(_lib.ptr(a), 800, _lib.ptr(b), 790, 785, 785, 10.0, _lib.ptr(loss), _lib.ptr(grad), 785, _st()))
+    d = a[:, :785] - b[:, :785]
+    assert abs(loss.item() - 10.0 * (d * d).mean().item()) < 1e-4 * loss.item()
+    assert _relerr(grad, 10.0 * 2 * d / d.numel()) < 1e-6
+
+
+@pytest.mark.parametrize("p,H,W", [(8, 32, 48), (16, 64, 64), (8, 224, 224)])
+def test_patchify_roundtrip(p, H, W):
+    B = 2
+    T = 1 + (H // p) * (W // p)
+    Tld = (T + 31) // 32 * 32
+    img = torch.rand(B, 3, H, W, device=DEV)
+    pat = torch.full((B * Tld, 3 * p * p), 7.0, device=DEV, dtype=torch.bfloat16)
+    L = _lib.lib()
+    _lib.check(L.splice_patchify(_lib.ptr(img), _lib.ptr(pat), B, H, W, p, Tld, 1, _st()))
+    mean = torch.tensor([0.485, 0.456, 0.406], device=DEV).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], device=DEV).view(1, 3, 1, 1)
+    ref = torch.nn.functional.unfold((img - mean) / std, p, stride=p).transpose(1, 2)  # [B, T-1, 3pp]
+    got = pat.float().reshape(B, Tld, -1)
+    assert _relerr(got[:, 1:T], ref) < 3e-3
+    assert got[:, 0].abs().max() == 0 and got[:, T:].abs().max() == 0
+    dp = torch.randn(B * Tld, 3 * p * p, device=DEV)
+    dimg = torch.empty(B, 3, H, W, device=DEV)
+    _lib.check(L.splice_unpatchify(_lib.ptr(dp), _lib.ptr(dimg), B, H, W, p, Tld, 1, _st()))
+    refd = torch.nn.functional.fold(dp.reshape(B, Tld, -1)[:, 1:T].transpose(1, 2).contiguous(), (H, W), p, stride=p) / std
+    assert _relerr(dimg, refd) < 1e-6
