@@ -119,6 +119,37 @@ int splice_cast_f32_bf16(const float* x, splice_bf16* y, size_t n, splice_stream
 int splice_cast_bf16_f32(const splice_bf16* x, float* y, size_t n, splice_stream_t stream);
 int splice_transpose_f32_bf16(const float* x, splice_bf16* y, int rows, int cols, int ldy, splice_stream_t stream);
 
+/* ------------------------------------------------------------------ ViT engine (handle level)
+ * Replaces VitExtractor.__init__ + the hooked self.model(img) forwards of
+ * models/extractor.py:19-103 and the autograd backward through them (train.py:78).
+ * Weights are the DINO state-dict entries (public checkpoint key names), frozen and
+ * re-packed to bf16 ([out][in] and [in][out]) inside the handle. */
+int splice_vit_create(int patch, int dim, int depth, int heads, void** out_handle);
+void splice_vit_destroy(void* vit);
+int splice_vit_set_param(void* vit, const char* name, const float* data, long long numel, splice_stream_t stream);
+int splice_vit_params_complete(void* vit);
+/* A context = one (batch, image shape): owns the activations of the last forward.
+ * pos_TD: position table for this token grid, fp32 [T][dim] (interpolate_pos_encoding done
+ * once per shape by the host). need_grad != 0 also allocates the backward workspace. */
+int splice_vit_ctx_create(void* vit, int B, int H, int W, const float* pos_TD, int need_grad,
+                          splice_stream_t stream, void** out_ctx);
+void splice_vit_ctx_destroy(void* ctx);
+int splice_vit_ctx_info(void* ctx, int* T, int* Tld, int* rows);
+/* img fp32 [B][3][H][W]; normalize != 0 fuses transforms.Normalize (util/losses.py:19). */
+int splice_vit_forward(void* ctx, const float* img, int normalize, splice_stream_t stream);
+/* kind 0: block output l fp32 [rows][D] (models/extractor.py:56-60) | 1: raw qkv l bf16
+ * [rows][3D] (:68-72) | 2: attention output l bf16 [rows][D] | 3: last-layer qkv fp32
+ * [rows][3D] | 4: lse l fp32 [B][H][Tld] | 5: embedded tokens fp32 [rows][D] */
+int splice_vit_get_tensor(void* ctx, int kind, int layer, void** out_ptr);
+int splice_vit_read_tensor(void* ctx, int kind, int layer, void* dst, size_t bytes, splice_stream_t stream);
+/* dgrad-only backward over passes [pass_begin, pass_end): gradients may be injected at
+ * any block output (d_block[l], fp32 [rows][D]), any raw qkv (d_qkv[l], fp32 [rows][3D])
+ * or its key columns only (d_keys[l], fp32 [rows][D]); arrays of `depth` pointers, NULL
+ * entries / NULL arrays allowed.  d_img fp32 [B][3][H][W] (selected passes written). */
+int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* const* d_block,
+                        const float* const* d_qkv, const float* const* d_keys, float* d_img,
+                        int normalize, splice_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

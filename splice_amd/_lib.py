@@ -49,6 +49,18 @@ _SIGNATURES = {
     "splice_cast_f32_bf16": ([_vp, _vp, _sz, _vp], _i),
     "splice_cast_bf16_f32": ([_vp, _vp, _sz, _vp], _i),
     "splice_transpose_f32_bf16": ([_vp, _vp, _i, _i, _i, _vp], _i),
+    # ViT engine
+    "splice_vit_create": ([_i, _i, _i, _i, C.POINTER(_vp)], _i),
+    "splice_vit_destroy": ([_vp], None),
+    "splice_vit_set_param": ([_vp, C.c_char_p, _vp, C.c_longlong, _vp], _i),
+    "splice_vit_params_complete": ([_vp], _i),
+    "splice_vit_ctx_create": ([_vp, _i, _i, _i, _vp, _i, _vp, C.POINTER(_vp)], _i),
+    "splice_vit_ctx_destroy": ([_vp], None),
+    "splice_vit_ctx_info": ([_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _i),
+    "splice_vit_forward": ([_vp, _vp, _i, _vp], _i),
+    "splice_vit_get_tensor": ([_vp, _i, _i, C.POINTER(_vp)], _i),
+    "splice_vit_read_tensor": ([_vp, _i, _i, _vp, _sz, _vp], _i),
+    "splice_vit_backward": ([_vp, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp, _i, _vp], _i),
 }
 
 

@@ -1,0 +1,469 @@
+// DINO-ViT feature-extraction engine: frozen pre-packed weights + batched forward and
+// dgrad-only backward, built from the kernels of gemm.h / attention.hip / vit_ops.hip.
+//
+// Replaces what the reference does with forward hooks on a torch.hub model
+// (models/extractor.py:19-103): one forward over a BATCH of images (the reference loops
+// batch-1 calls, util/losses.py:76-81) keeps, per layer, exactly the tensors its hooks
+// expose -- block output, raw qkv, attention output -- plus what the backward needs; the
+// backward propagates gradients injected at any block output / qkv back to the image and
+// never forms weight gradients (the reference accumulates and discards them).
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+void splice_set_error(const char* fmt, ...);
+
+#define HIPCHK(x)                                                                                 \
+    do {                                                                                          \
+        hipError_t e_ = (x);                                                                      \
+        if (e_ != hipSuccess) {                                                                   \
+            splice_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_));    \
+            return SPLICE_ERR_HIP;                                                                \
+        }                                                                                         \
+    } while (0)
+#define RC(x)                                                                                     \
+    do {                                                                                          \
+        int rc_ = (x);                                                                            \
+        if (rc_ != SPLICE_OK) {                                                                   \
+            splice_set_error("%s:%d %s failed (%d)", __FILE__, __LINE__, #x, rc_);                \
+            return rc_;                                                                           \
+        }                                                                                         \
+    } while (0)
+
+struct Linear {
+    bf16_t* w = nullptr;    // [out][in]
+    bf16_t* wT = nullptr;   // [in][out]
+    float* b = nullptr;     // [out]
+    int out = 0, in = 0;
+};
+struct LayerW {
+    float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+    Linear qkv, proj, fc1, fc2;
+};
+
+struct SpliceVit {
+    int patch = 0, dim = 0, depth = 0, heads = 0, hidden = 0;
+    int device = 0;
+    std::vector<LayerW> layers;
+    Linear pe;              // patch-embed as [dim][3*p*p]
+    float* cls = nullptr;   // [dim]
+    float* pos = nullptr;   // [pos_tokens][dim]  (trained grid, incl. cls row)
+    int pos_tokens = 0;
+    float *norm_g = nullptr, *norm_b = nullptr;
+    std::vector<void*> allocs;
+    int n_set = 0;
+};
+
+struct SpliceVitCtx {
+    SpliceVit* vit = nullptr;
+    int B = 0, H = 0, W = 0, T = 0, Tld = 0, rows = 0, need_grad = 0;
+    float* pos_eff = nullptr;              // [Tld][D]
+    bf16_t* patches = nullptr;             // [rows][3pp]
+    std::vector<float*> xs;                // depth+1 x [rows][D]   residual stream (block outputs)
+    std::vector<float*> xmid;              // depth   x [rows][D]
+    std::vector<float*> mean1, rstd1, mean2, rstd2;  // depth x [rows]
+    std::vector<bf16_t*> qkv, qkvT, attn_out, hpre;  // depth
+    std::vector<float*> lse;               // depth x [B][H][Tld]
+    float* qkv_last_f32 = nullptr;         // [rows][3D]
+    bf16_t* ln_out = nullptr;              // [rows][D]   transient
+    bf16_t* hact = nullptr;                // [rows][4D]  transient
+    // backward temporaries (sized for all rows)
+    float* g = nullptr;                    // [rows][D]
+    bf16_t* g_bf = nullptr;
+    bf16_t* dh = nullptr;                  // [rows][4D]
+    float* dln = nullptr;                  // [rows][D]
+    bf16_t *dout = nullptr, *doutT = nullptr, *dqkv = nullptr;
+    float* delta = nullptr;
+    float* dpatches = nullptr;             // [rows][3pp]
+    std::vector<void*> allocs;
+    int forward_done = 0;
+};
+
+template <class T>
+static int dev_alloc(std::vector<void*>& list, T** p, size_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, n * sizeof(T) + 256) != hipSuccess) {
+        splice_set_error("hipMalloc of %zu bytes failed", n * sizeof(T));
+        return SPLICE_ERR_NOMEM;
+    }
+    list.push_back(q);
+    *p = (T*)q;
+    return SPLICE_OK;
+}
+
+static int pack_linear(SpliceVit* v, Linear& L, const float* w, int out, int in, hipStream_t s) {
+    L.out = out; L.in = in;
+    RC(dev_alloc(v->allocs, &L.w, (size_t)out * in));
+    RC(dev_alloc(v->allocs, &L.wT, (size_t)out * in));
+    RC(cast_f32_bf16_launch(w, L.w, (size_t)out * in, s));
+    RC(transpose_f32_to_bf16_launch(w, L.wT, out, in, out, s));  // wT[in][out]
+    return SPLICE_OK;
+}
+static int copy_vec(SpliceVit* v, float** dst, const float* src, size_t n, hipStream_t s) {
+    RC(dev_alloc(v->allocs, dst, n));
+    HIPCHK(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return SPLICE_OK;
+}
+
+// add fp32 src[rows][lds] (cols columns) into bf16 dst[rows][ldd] columns [col0, col0+cols)
+__global__ void add_f32_into_bf16_kernel(bf16_t* dst, int ldd, int col0, const float* src, int lds, int rows, int cols) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = i / cols, c = i % cols;
+        bf16_t* p = dst + (size_t)r * ldd + col0 + c;
+        *p = f2bf(bf2f(*p) + src[(size_t)r * lds + c]);
+    }
+}
+// g (+)= add ; g_bf = bf16(g).  add may be null (then just refresh g_bf); init: g = add (or 0).
+__global__ void grad_stream_kernel(float* g, bf16_t* g_bf, const float* add, size_t n, int init) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = init ? 0.f : g[i];
+        if (add) v += add[i];
+        g[i] = v;
+        g_bf[i] = f2bf(v);
+    }
+}
+static inline unsigned grid_n(size_t n) { size_t b = (n + 255) / 256; return (unsigned)(b > 2048 ? 2048 : (b ? b : 1)); }
+
+extern "C" {
+
+int splice_vit_create(int patch, int dim, int depth, int heads, void** out) {
+    if (!out || (patch != 8 && patch != 16) || dim % 64 || dim / 64 != heads || depth < 1 || dim > 1024) {
+        splice_set_error("splice_vit_create: unsupported config patch=%d dim=%d depth=%d heads=%d (head dim must be 64)", patch, dim, depth, heads);
+        return SPLICE_ERR_ARG;
+    }
+    SpliceVit* v = new SpliceVit();
+    v->patch = patch; v->dim = dim; v->depth = depth; v->heads = heads; v->hidden = 4 * dim;
+    hipGetDevice(&v->device);
+    v->layers.resize(depth);
+    *out = v;
+    return SPLICE_OK;
+}
+
+void splice_vit_destroy(void* h) {
+    SpliceVit* v = (SpliceVit*)h;
+    if (!v) return;
+    for (void* p : v->allocs) hipFree(p);
+    delete v;
+}
+
+// One DINO state-dict entry (public checkpoint key names), fp32 on the device.
+int splice_vit_set_param(void* h, const char* name, const float* data, long long numel, splice_stream_t stream) {
+    SpliceVit* v = (SpliceVit*)h;
+    hipStream_t s = (hipStream_t)stream;
+    if (!v || !name || !data) return SPLICE_ERR_ARG;
+    const int D = v->dim, Hd = v->hidden, pp3 = 3 * v->patch * v->patch;
+    std::string n(name);
+    auto expect = [&](long long want) {
+        if (numel != want) { splice_set_error("splice_vit_set_param(%s): numel %lld, expected %lld", name, numel, want); return false; }
+        return true;
+    };
+    if (n == "cls_token") { if (!expect(D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &v->cls, data, D, s)); }
+    else if (n == "pos_embed") {
+        if (numel % D) return SPLICE_ERR_ARG;
+        v->pos_tokens = (int)(numel / D);
+        RC(copy_vec(v, &v->pos, data, numel, s));
+    }
+    else if (n == "patch_embed.proj.weight") { if (!expect((long long)D * pp3)) return SPLICE_ERR_ARG; RC(pack_linear(v, v->pe, data, D, pp3, s)); }
+    else if (n == "patch_embed.proj.bias") { if (!expect(D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &v->pe.b, data, D, s)); }
+    else if (n == "norm.weight") { if (!expect(D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &v->norm_g, data, D, s)); }
+    else if (n == "norm.bias") { if (!expect(D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &v->norm_b, data, D, s)); }
+    else if (n.rfind("blocks.", 0) == 0) {
+        const size_t dot = n.find('.', 7);
+        if (dot == std::string::npos) return SPLICE_ERR_ARG;
+        const int li = atoi(n.substr(7, dot - 7).c_str());
+        if (li < 0 || li >= v->depth) { splice_set_error("splice_vit_set_param: layer %d out of range", li); return SPLICE_ERR_ARG; }
+        LayerW& L = v->layers[li];
+        const std::string r = n.substr(dot + 1);
+        if (r == "norm1.weight") { if (!expect(D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &L.ln1_g, data, D, s)); }
+        else if (r == "norm1.bias") { if (!expect(D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &L.ln1_b, data, D, s)); }
+        else if (r == "norm2.weight") { if (!expect(D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &L.ln2_g, data, D, s)); }
+        else if (r == "norm2.bias") { if (!expect(D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &L.ln2_b, data, D, s)); }
+        else if (r == "attn.qkv.weight") { if (!expect(3LL * D * D)) return SPLICE_ERR_ARG; RC(pack_linear(v, L.qkv, data, 3 * D, D, s)); }
+        else if (r == "attn.qkv.bias") { if (!expect(3 * D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &L.qkv.b, data, 3 * D, s)); }
+        else if (r == "attn.proj.weight") { if (!expect((long long)D * D)) return SPLICE_ERR_ARG; RC(pack_linear(v, L.proj, data, D, D, s)); }
+        else if (r == "attn.proj.bias") { if (!expect(D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &L.proj.b, data, D, s)); }
+        else if (r == "mlp.fc1.weight") { if (!expect((long long)Hd * D)) return SPLICE_ERR_ARG; RC(pack_linear(v, L.fc1, data, Hd, D, s)); }
+        else if (r == "mlp.fc1.bias") { if (!expect(Hd)) return SPLICE_ERR_ARG; RC(copy_vec(v, &L.fc1.b, data, Hd, s)); }
+        else if (r == "mlp.fc2.weight") { if (!expect((long long)Hd * D)) return SPLICE_ERR_ARG; RC(pack_linear(v, L.fc2, data, D, Hd, s)); }
+        else if (r == "mlp.fc2.bias") { if (!expect(D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &L.fc2.b, data, D, s)); }
+        else { splice_set_error("splice_vit_set_param: unknown key %s", name); return SPLICE_ERR_ARG; }
+    } else { splice_set_error("splice_vit_set_param: unknown key %s", name); return SPLICE_ERR_ARG; }
+    v->n_set++;
+    return SPLICE_OK;
+}
+
+int splice_vit_params_complete(void* h) {
+    SpliceVit* v = (SpliceVit*)h;
+    if (!v) return 0;
+    bool ok = v->cls && v->pos && v->pe.w && v->pe.b;
+    for (auto& L : v->layers)
+        ok = ok && L.ln1_g && L.ln1_b && L.ln2_g && L.ln2_b && L.qkv.w && L.qkv.b && L.proj.w && L.proj.b && L.fc1.w &&
+             L.fc1.b && L.fc2.w && L.fc2.b;
+    return ok ? 1 : 0;
+}
+
+// pos_eff_host-independent: caller passes the (already interpolated) position table for this
+// image shape as fp32 [T][D] on the device (row 0 = cls position); K20 of SURVEY.md is done
+// once per shape by the host (splice_amd/extractor.py).
+int splice_vit_ctx_create(void* h, int B, int H, int W, const float* pos_TD, int need_grad, splice_stream_t stream, void** out);
+}
+
+__global__ void pos_eff_kernel(float* pos_eff, const float* pos, const float* cls, const float* pe_bias, int T, int Tld, int D) {
+    const size_t n = (size_t)Tld * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = i / D, d = i % D;
+        float v;
+        if (t == 0) v = cls[d] + pos[d] - pe_bias[d];          // GEMM adds the bias back on the zero patch row
+        else if (t < T) v = pos[(size_t)t * D + d];
+        else v = -pe_bias[d];                                  // padding tokens are exactly zero
+        pos_eff[i] = v;
+    }
+}
+
+extern "C" {
+
+int splice_vit_ctx_create(void* h, int B, int H, int W, const float* pos_TD, int need_grad, splice_stream_t stream, void** out) {
+    SpliceVit* v = (SpliceVit*)h;
+    hipStream_t s = (hipStream_t)stream;
+    if (!v || !out || B < 1 || !splice_vit_params_complete(h)) {
+        splice_set_error("splice_vit_ctx_create: bad handle / incomplete weights / B<1");
+        return SPLICE_ERR_STATE;
+    }
+    const int p = v->patch, D = v->dim, Hd = v->hidden, pp3 = 3 * p * p;
+    if (H < p || W < p) return SPLICE_ERR_ARG;
+    SpliceVitCtx* c = new SpliceVitCtx();
+    c->vit = v; c->B = B; c->H = H; c->W = W; c->need_grad = need_grad;
+    c->T = 1 + (H / p) * (W / p);
+    c->Tld = (c->T + 31) / 32 * 32;
+    c->rows = B * c->Tld;
+    const size_t rows = c->rows;
+    const int L = v->depth;
+    int rc = SPLICE_OK;
+#define A(ptr, n) if (rc == SPLICE_OK) rc = dev_alloc(c->allocs, &(ptr), (size_t)(n))
+    A(c->pos_eff, (size_t)c->Tld * D);
+    A(c->patches, rows * pp3);
+    c->xs.resize(L + 1); c->xmid.resize(L); c->mean1.resize(L); c->rstd1.resize(L); c->mean2.resize(L); c->rstd2.resize(L);
+    c->qkv.resize(L); c->qkvT.resize(L); c->attn_out.resize(L); c->hpre.resize(L); c->lse.resize(L);
+    for (int l = 0; l <= L; ++l) A(c->xs[l], rows * D);
+    for (int l = 0; l < L; ++l) {
+        A(c->xmid[l], rows * D);
+        A(c->mean1[l], rows); A(c->rstd1[l], rows); A(c->mean2[l], rows); A(c->rstd2[l], rows);
+        A(c->qkv[l], rows * 3 * D); A(c->qkvT[l], rows * 3 * D); A(c->attn_out[l], rows * D);
+        A(c->hpre[l], rows * Hd);
+        A(c->lse[l], (size_t)B * v->heads * c->Tld);
+    }
+    A(c->qkv_last_f32, rows * 3 * D);
+    A(c->ln_out, rows * D);
+    A(c->hact, rows * Hd);
+    if (need_grad) {
+        A(c->g, rows * D); A(c->g_bf, rows * D); A(c->dh, rows * Hd); A(c->dln, rows * D);
+        A(c->dout, rows * D); A(c->doutT, rows * D); A(c->dqkv, rows * 3 * D);
+        A(c->delta, (size_t)B * v->heads * c->Tld);
+        A(c->dpatches, rows * pp3);
+    }
+#undef A
+    if (rc != SPLICE_OK) {
+        for (void* q : c->allocs) hipFree(q);
+        delete c;
+        return rc;
+    }
+    hipLaunchKernelGGL(pos_eff_kernel, dim3(grid_n((size_t)c->Tld * D)), dim3(256), 0, s, c->pos_eff, pos_TD, v->cls, v->pe.b, c->T, c->Tld, D);
+    *out = c;
+    return SPLICE_OK;
+}
+
+void splice_vit_ctx_destroy(void* ctx) {
+    SpliceVitCtx* c = (SpliceVitCtx*)ctx;
+    if (!c) return;
+    for (void* p : c->allocs) hipFree(p);
+    delete c;
+}
+
+int splice_vit_ctx_info(void* ctx, int* T, int* Tld, int* rows) {
+    SpliceVitCtx* c = (SpliceVitCtx*)ctx;
+    if (!c) return SPLICE_ERR_ARG;
+    if (T) *T = c->T;
+    if (Tld) *Tld = c->Tld;
+    if (rows) *rows = c->rows;
+    return SPLICE_OK;
+}
+
+// Forward over the ctx's batch.  img: fp32 [B][3][H][W]; normalize != 0 applies the ImageNet
+// Normalize of util/losses.py:19 on the fly (input in [0,1]); == 0 expects a normalised image
+// (what VitExtractor receives, models/extractor.py:81).
+int splice_vit_forward(void* ctx, const float* img, int normalize, splice_stream_t stream) {
+    SpliceVitCtx* c = (SpliceVitCtx*)ctx;
+    if (!c || !img) return SPLICE_ERR_ARG;
+    SpliceVit* v = c->vit;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = v->dim, Hd = v->hidden, pp3 = 3 * v->patch * v->patch, rows = c->rows, L = v->depth;
+    RC(patchify_launch(img, c->patches, c->B, c->H, c->W, v->patch, c->Tld, normalize, s));
+    {
+        GemmEpi e = {};
+        e.bias = v->pe.b; e.resid = c->pos_eff; e.ldr = D; e.resid_mod = c->Tld; e.out_f32 = c->xs[0]; e.ldo = D;
+        RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, c->patches, pp3, v->pe.w, pp3, rows, D, pp3, e, s));
+    }
+    for (int l = 0; l < L; ++l) {
+        const LayerW& W = v->layers[l];
+        RC(layernorm_fwd_launch(c->xs[l], W.ln1_g, W.ln1_b, c->ln_out, c->mean1[l], c->rstd1[l], rows, D, 1e-6f, s));
+        {
+            GemmEpi e = {};
+            e.bias = W.qkv.b; e.out_bf = c->qkv[l]; e.ldbf = 3 * D; e.out_bf_t = c->qkvT[l]; e.ldt = rows;
+            unsigned fl = EPI_BIAS | EPI_OUT_BF | EPI_OUT_T;
+            if (l == L - 1) { fl |= EPI_COLS_F32; e.out_f32_cols = c->qkv_last_f32; e.ld_cols = 3 * D; e.col_lo = 0; e.col_hi = 3 * D; }
+            RC(gemm_nt_launch(fl, c->ln_out, D, W.qkv.w, D, rows, 3 * D, D, e, s));
+        }
+        {
+            AttnArgs a = {};
+            a.qkv = c->qkv[l]; a.qkvT = c->qkvT[l]; a.ldt = rows; a.B = c->B; a.T = c->T; a.Tld = c->Tld; a.D = D; a.H = v->heads;
+            a.scale = 0.125f; a.out = c->attn_out[l]; a.lse = c->lse[l];
+            RC(attn_fwd_launch(&a, s));
+        }
+        {
+            GemmEpi e = {};
+            e.bias = W.proj.b; e.resid = c->xs[l]; e.ldr = D; e.out_f32 = c->xmid[l]; e.ldo = D;
+            RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, c->attn_out[l], D, W.proj.w, D, rows, D, D, e, s));
+        }
+        RC(layernorm_fwd_launch(c->xmid[l], W.ln2_g, W.ln2_b, c->ln_out, c->mean2[l], c->rstd2[l], rows, D, 1e-6f, s));
+        {
+            GemmEpi e = {};
+            e.bias = W.fc1.b; e.out_bf = c->hact; e.ldbf = Hd; e.out_pre = c->hpre[l]; e.ldp = Hd;
+            RC(gemm_nt_launch(EPI_BIAS | EPI_GELU | EPI_OUT_BF, c->ln_out, D, W.fc1.w, D, rows, Hd, D, e, s));
+        }
+        {
+            GemmEpi e = {};
+            e.bias = W.fc2.b; e.resid = c->xmid[l]; e.ldr = D; e.out_f32 = c->xs[l + 1]; e.ldo = D;
+            RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, c->hact, Hd, W.fc2.w, Hd, rows, D, Hd, e, s));
+        }
+    }
+    c->forward_done = 1;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { splice_set_error("splice_vit_forward: %s", hipGetErrorString(e)); return SPLICE_ERR_HIP; }
+    return SPLICE_OK;
+}
+
+// Device pointers of the tensors the reference's hooks expose (valid until the next forward):
+// kind 0: block output l  fp32 [rows][D]      (models/extractor.py:56-60; l = depth-1 gives the CLS source)
+// kind 1: raw qkv      l  bf16 [rows][3D]     (models/extractor.py:68-72)
+// kind 2: attention out l bf16 [rows][D]      (pre-projection; the hooked 'patch_imd' is proj of it)
+// kind 3: last-layer qkv  fp32 [rows][3D]
+// kind 4: lse          l  fp32 [B][H][Tld]
+int splice_vit_get_tensor(void* ctx, int kind, int layer, void** out) {
+    SpliceVitCtx* c = (SpliceVitCtx*)ctx;
+    if (!c || !out || layer < 0 || layer >= c->vit->depth) return SPLICE_ERR_ARG;
+    switch (kind) {
+        case 0: *out = c->xs[layer + 1]; break;
+        case 1: *out = c->qkv[layer]; break;
+        case 2: *out = c->attn_out[layer]; break;
+        case 3: *out = c->qkv_last_f32; break;
+        case 4: *out = c->lse[layer]; break;
+        case 5: *out = c->xs[0]; break;
+        default: return SPLICE_ERR_ARG;
+    }
+    return SPLICE_OK;
+}
+
+// Copy one of the tensors above into caller memory (device to device), `bytes` from its start.
+int splice_vit_read_tensor(void* ctx, int kind, int layer, void* dst, size_t bytes, splice_stream_t stream) {
+    void* src = nullptr;
+    RC(splice_vit_get_tensor(ctx, kind, layer, &src));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SPLICE_OK;
+}
+
+// dgrad-only backward over passes [pass_begin, pass_end) of the last forward.
+//   d_block[l]  fp32 [rows][D]   (full-batch layout) or NULL : gradient w.r.t. block output l
+//   d_qkv[l]    fp32 [rows][3D]  or NULL                    : gradient w.r.t. the raw qkv of layer l
+//   d_keys[l]   fp32 [rows][D]   or NULL                    : gradient w.r.t. the key columns only
+// (arrays may be NULL as a whole).  d_img fp32 [B][3][H][W]: only the selected passes are written.
+// Rows of padding tokens must carry zero gradient.
+int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* const* d_block, const float* const* d_qkv,
+                        const float* const* d_keys, float* d_img, int normalize, splice_stream_t stream) {
+    SpliceVitCtx* c = (SpliceVitCtx*)ctx;
+    if (!c || !c->need_grad || !c->forward_done || pass_begin < 0 || pass_end > c->B || pass_begin >= pass_end || !d_img) {
+        splice_set_error("splice_vit_backward: bad ctx / range / no forward / ctx created without need_grad");
+        return SPLICE_ERR_STATE;
+    }
+    SpliceVit* v = c->vit;
+    hipStream_t s = (hipStream_t)stream;
+    const int D = v->dim, Hd = v->hidden, pp3 = 3 * v->patch * v->patch, L = v->depth;
+    const size_t r0 = (size_t)pass_begin * c->Tld;
+    const int R = (pass_end - pass_begin) * c->Tld;
+    const int Bp = pass_end - pass_begin;
+    float* g = c->g + r0 * D;
+    bf16_t* g_bf = c->g_bf + r0 * D;
+    bool g_live = false;  // gradient stream known non-zero
+    for (int l = L - 1; l >= 0; --l) {
+        const LayerW& W = v->layers[l];
+        const float* db = d_block ? d_block[l] : nullptr;
+        const float* dq = d_qkv ? d_qkv[l] : nullptr;
+        const float* dk = d_keys ? d_keys[l] : nullptr;
+        if (db) {
+            hipLaunchKernelGGL(grad_stream_kernel, dim3(grid_n((size_t)R * D)), dim3(256), 0, s, g, g_bf, db + r0 * D, (size_t)R * D, g_live ? 0 : 1);
+            g_live = true;
+        }
+        if (!g_live && !dq && !dk) continue;
+        bf16_t* dqkv = c->dqkv + r0 * 3 * D;
+        const float* g_after_mlp = nullptr;  // g_in for LN1 backward
+        if (g_live) {
+            // MLP branch
+            {
+                GemmEpi e = {};
+                e.aux = c->hpre[l] + r0 * Hd; e.ldaux = Hd; e.out_bf = c->dh + r0 * Hd; e.ldbf = Hd;
+                RC(gemm_nt_launch(EPI_GELU_GRAD | EPI_OUT_BF, g_bf, D, W.fc2.wT, D, R, Hd, D, e, s));
+            }
+            {
+                GemmEpi e = {};
+                e.out_f32 = c->dln + r0 * D; e.ldo = D;
+                RC(gemm_nt_launch(EPI_OUT_F32, c->dh + r0 * Hd, Hd, W.fc1.wT, Hd, R, D, Hd, e, s));
+            }
+            RC(layernorm_bwd_launch(c->dln + r0 * D, c->xmid[l] + r0 * D, W.ln2_g, c->mean2[l] + r0, c->rstd2[l] + r0, g, g, g_bf, R, D, s));
+            // attention branch
+            {
+                GemmEpi e = {};
+                e.out_bf = c->dout + r0 * D; e.ldbf = D; e.out_bf_t = c->doutT; e.ldt = c->rows;
+                // transposed output is addressed by GEMM row index (0..R) -> shift the base so column = global row
+                e.out_bf_t = c->doutT + r0;
+                RC(gemm_nt_launch(EPI_OUT_BF | EPI_OUT_T, g_bf, D, W.proj.wT, D, R, D, D, e, s));
+            }
+            {
+                AttnArgs a = {};
+                a.qkv = c->qkv[l] + r0 * 3 * D; a.qkvT = c->qkvT[l] + r0; a.ldt = c->rows; a.B = Bp; a.T = c->T; a.Tld = c->Tld;
+                a.D = D; a.H = v->heads; a.scale = 0.125f; a.out = c->attn_out[l] + r0 * D;
+                a.lse = c->lse[l] + (size_t)pass_begin * v->heads * c->Tld;
+                a.dout = c->dout + r0 * D; a.doutT = c->doutT + r0; a.delta = c->delta; a.dqkv = dqkv;
+                RC(attn_bwd_launch(&a, s));
+            }
+            g_after_mlp = g;
+        } else {
+            HIPCHK(hipMemsetAsync(dqkv, 0, (size_t)R * 3 * D * sizeof(bf16_t), s));
+        }
+        if (dq) hipLaunchKernelGGL(add_f32_into_bf16_kernel, dim3(grid_n((size_t)R * 3 * D)), dim3(256), 0, s, dqkv, 3 * D, 0, dq + r0 * 3 * D, 3 * D, R, 3 * D);
+        if (dk) hipLaunchKernelGGL(add_f32_into_bf16_kernel, dim3(grid_n((size_t)R * D)), dim3(256), 0, s, dqkv, 3 * D, D, dk + r0 * D, D, R, D);
+        {
+            GemmEpi e = {};
+            e.out_f32 = c->dln + r0 * D; e.ldo = D;
+            RC(gemm_nt_launch(EPI_OUT_F32, dqkv, 3 * D, W.qkv.wT, 3 * D, R, D, 3 * D, e, s));
+        }
+        RC(layernorm_bwd_launch(c->dln + r0 * D, c->xs[l] + r0 * D, W.ln1_g, c->mean1[l] + r0, c->rstd1[l] + r0, g_after_mlp, g, g_bf, R, D, s));
+        g_live = true;
+    }
+    if (!g_live) {
+        HIPCHK(hipMemsetAsync(d_img + (size_t)pass_begin * 3 * c->H * c->W, 0, (size_t)Bp * 3 * c->H * c->W * sizeof(float), s));
+        return SPLICE_OK;
+    }
+    {
+        GemmEpi e = {};
+        e.out_f32 = c->dpatches + r0 * pp3; e.ldo = pp3;
+        RC(gemm_nt_launch(EPI_OUT_F32, g_bf, D, v->pe.wT, D, R, pp3, D, e, s));
+    }
+    RC(unpatchify_launch(c->dpatches + r0 * pp3, d_img + (size_t)pass_begin * 3 * c->H * c->W, Bp, c->H, c->W, v->patch, c->Tld, normalize, s));
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { splice_set_error("splice_vit_backward: %s", hipGetErrorString(e)); return SPLICE_ERR_HIP; }
+    return SPLICE_OK;
+}
+}

@@ -1,0 +1,182 @@
+"""GPU parity of the DINO-ViT engine (C ABI splice_vit_*) against the fp32 CPU oracle and the
+fixtures recorded from the reference's VitExtractor.
+
+bf16 tolerance rationale: every GEMM operand is rounded to bf16 (rel 2^-9 per element, fp32
+accumulate), activations between kernels are bf16 except the fp32 residual stream; through 12
+blocks the relative L2 error of a block output stays ~3e-3 and of an input gradient ~1e-2.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from splice_amd import synth
+from splice_amd.vit import KIND_BLOCK, KIND_QKV, KIND_QKV_LAST_F32, VitEngine
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    e = ((a - b).norm() / (b.norm() + 1e-30)).item()
+    print(f"    relerr={e:.3e}")
+    return e
+
+
+def _cos(a, b):
+    a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
+    return (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+
+
+def _oracle_vit(name, img_size, seed=7, w_std=0.05):
+    from oracle import dino_vit
+    patch, dim, depth, heads = dino_vit.DINO_CONFIGS[name]
+    m = dino_vit.VisionTransformer(patch, dim, depth, heads, img_size=img_size).eval()
+    sd = synth.vit_params(seed, name, img_size=img_size, w_std=w_std)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    for p in m.parameters():
+        p.requires_grad_(False)
+    return m, sd
+
+
+def test_vits8_golden_features(golden_dir):
+    """Same seeded weights + image as oracle/make_golden.py fed to the REFERENCE VitExtractor."""
+    g = np.load(os.path.join(golden_dir, "extractor.npz"))
+    _, sd = _oracle_vit("dino_vits8", 32)
+    eng = VitEngine("dino_vits8").load_state_dict(sd)
+    img = torch.from_numpy(synth.normal(13, "img32", (1, 3, 32, 32))).to(DEV)
+    ctx = eng.context(1, 32, 32, need_grad=False)
+    ctx.forward(img, normalize=False)
+    T = ctx.T
+    assert T == 17
+    b0 = ctx.read(KIND_BLOCK, 0)[:, :T]
+    bl = ctx.read(KIND_BLOCK, 11)[:, :T]
+    assert _relerr(b0, torch.from_numpy(g["vits8_block0"])) < 8e-3
+    assert _relerr(bl, torch.from_numpy(g["vits8_block_last"])) < 2e-2
+    q11 = ctx.read(KIND_QKV_LAST_F32, 11)[:, :T]
+    assert _relerr(q11, torch.from_numpy(g["vits8_qkv11"])) < 2e-2
+    assert _relerr(ctx.read(KIND_QKV, 11)[:, :T].float(), torch.from_numpy(g["vits8_qkv11"])) < 2e-2
+    # padding tokens stay exactly zero at the embedding and finite afterwards
+    assert torch.isfinite(ctx.read(KIND_BLOCK, 11)).all()
+    # non-square 32x48 -> interpolated position grid
+    img2 = torch.from_numpy(synth.normal(13, "img32x48", (1, 3, 32, 48))).to(DEV)
+    ctx2 = eng.context(1, 32, 48, need_grad=False)
+    ctx2.forward(img2, normalize=False)
+    assert ctx2.T == 25
+    assert _relerr(ctx2.read(KIND_BLOCK, 11)[:, :25], torch.from_numpy(g["vits8_32x48_block_last"])) < 2e-2
+
+
+def _oracle_grad(model, imgs, wb, wq, layers_b, layers_q, normalize):
+    """d/d img of sum_l <wb[l], block_l> + <wq[l], qkv_l> with the oracle on CPU (per image)."""
+    from oracle import dino_vit
+    from oracle.losses import normalize as onorm
+    grads, feats_all = [], []
+    for i in range(imgs.shape[0]):
+        x = imgs[i:i + 1].clone().requires_grad_(True)
+        xin = onorm(x[0])[None] if normalize else x
+        f = dino_vit.forward_features(model, xin)
+        loss = 0
+        for l in layers_b:
+            loss = loss + (f["block"][l][0] * wb[l][i]).sum()
+        for l in layers_q:
+            loss = loss + (f["qkv"][l][0] * wq[l][i]).sum()
+        loss.backward()
+        grads.append(x.grad[0])
+        feats_all.append(f)
+    return torch.stack(grads), feats_all
+
+
+@pytest.mark.parametrize("name,H,W,B,rng", [("dino_vits8", 32, 48, 3, (1, 3)), ("dino_vitb16", 64, 64, 2, (0, 2))])
+def test_backward_injection(name, H, W, B, rng):
+    model, sd = _oracle_vit(name, 64, seed=5, w_std=0.04)
+    eng = VitEngine(name).load_state_dict(sd)
+    D, L = eng.dim, eng.depth
+    imgs = torch.from_numpy(synth.uniform(3, f"bk/{name}", (B, 3, H, W)))
+    ctx = eng.context(B, H, W, need_grad=True)
+    ctx.forward(imgs.to(DEV), normalize=True)
+    T, Tld = ctx.T, ctx.Tld
+    layers_b, layers_q = [L - 1, 4], [L - 1, 2]
+    wb = {l: torch.from_numpy(synth.normal(4, f"wb{l}", (B, T, D))) for l in layers_b}
+    wq = {l: torch.from_numpy(synth.normal(4, f"wq{l}", (B, T, 3 * D))) for l in layers_q}
+    gref, feats = _oracle_grad(model, imgs, wb, wq, layers_b, layers_q, True)
+    # forward parity on every pass
+    got_last = ctx.read(KIND_BLOCK, L - 1)[:, :T]
+    ref_last = torch.cat([f["block"][L - 1] for f in feats])
+    assert _relerr(got_last, ref_last) < 2e-2
+
+    def pad(t, width):
+        out = torch.zeros(B, Tld, width, device=DEV)
+        out[:, :T] = t.to(DEV)
+        return out.contiguous()
+
+    d_block = {l: pad(wb[l], D) for l in layers_b}
+    # layer L-1 qkv gradient: split into a keys-only part (d_keys) and the rest (d_qkv) to cover both paths
+    wq_last = wq[L - 1].clone()
+    keys_part = wq_last[:, :, D:2 * D].clone()
+    wq_last[:, :, D:2 * D] = 0
+    d_qkv = {L - 1: pad(wq_last, 3 * D), 2: pad(wq[2], 3 * D)}
+    d_keys = {L - 1: pad(keys_part, D)}
+    d_img = ctx.backward(rng[0], rng[1], d_block, d_qkv, d_keys, normalize=True).cpu()
+    for i in range(B):
+        if rng[0] <= i < rng[1]:
+            e, c = _relerr(d_img[i], gref[i]), _cos(d_img[i], gref[i])
+            assert e < 5e-2 and c > 0.998, (i, e, c)
+        else:
+            assert d_img[i].abs().max().item() == 0.0
+
+
+def test_keys_only_injection():
+    """Only d_keys at the last layer (the identity-loss pattern): upper half of the last block is skipped."""
+    name, H, W = "dino_vits8", 40, 40
+    model, sd = _oracle_vit(name, 40, seed=6, w_std=0.04)
+    eng = VitEngine(name).load_state_dict(sd)
+    D, L = eng.dim, eng.depth
+    imgs = torch.from_numpy(synth.uniform(8, "ko", (1, 3, H, W)))
+    ctx = eng.context(1, H, W, need_grad=True)
+    ctx.forward(imgs.to(DEV), normalize=False)
+    T, Tld = ctx.T, ctx.Tld
+    wk = torch.from_numpy(synth.normal(9, "wk", (1, T, D)))
+    wq = {L - 1: torch.zeros(1, T, 3 * D)}
+    wq[L - 1][:, :, D:2 * D] = wk
+    gref, _ = _oracle_grad(model, imgs, {}, wq, [], [L - 1], False)
+    dk = torch.zeros(1, Tld, D, device=DEV)
+    dk[:, :T] = wk.to(DEV)
+    d_img = ctx.backward(0, 1, None, None, {L - 1: dk.contiguous()}, normalize=False).cpu()
+    assert _relerr(d_img[0], gref[0]) < 5e-2 and _cos(d_img[0], gref[0]) > 0.998
+
+
+def test_vitb8_224_full_size():
+    """BASELINE config shape (ViT-B/8, 224x224, T=785): forward features and image gradient vs the
+    fp32 oracle run on the host cores."""
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    name = "dino_vitb8"
+    model, sd = _oracle_vit(name, 224, seed=1, w_std=0.02)
+    eng = VitEngine(name).load_state_dict(sd)
+    D, L = eng.dim, eng.depth
+    A, Bimg = synth.image_pair(1234, 0, 224, 224)
+    imgs = torch.from_numpy(np.stack([A, Bimg]))
+    ctx = eng.context(2, 224, 224, need_grad=True)
+    ctx.forward(imgs.to(DEV), normalize=True)
+    T, Tld = ctx.T, ctx.Tld
+    assert (T, Tld) == (785, 800)
+    wb = {L - 1: torch.zeros(2, T, D)}
+    wb[L - 1][:, 0] = torch.from_numpy(synth.normal(2, "cls", (2, D)))  # CLS-token gradient only
+    wq = {L - 1: torch.zeros(2, T, 3 * D)}
+    wq[L - 1][:, :, D:2 * D] = torch.from_numpy(synth.normal(2, "keys", (2, T, D))) * 0.05
+    gref, feats = _oracle_grad(model, imgs, wb, wq, [L - 1], [L - 1], True)
+    for l in (0, 5, 11):
+        ref = torch.cat([f["block"][l] for f in feats])
+        e = _relerr(ctx.read(KIND_BLOCK, l)[:, :T], ref)
+        assert e < 2e-2, (l, e)
+    refq = torch.cat([f["qkv"][11] for f in feats])
+    assert _relerr(ctx.read(KIND_QKV_LAST_F32, 11)[:, :T], refq) < 2e-2
+    db = torch.zeros(2, Tld, D, device=DEV)
+    db[:, :T] = wb[L - 1].to(DEV)
+    dk = torch.zeros(2, Tld, D, device=DEV)
+    dk[:, :T] = wq[L - 1][:, :, D:2 * D].to(DEV)
+    d_img = ctx.backward(0, 2, {L - 1: db}, None, {L - 1: dk}, normalize=True).cpu()
+    for i in range(2):
+        e, c = _relerr(d_img[i], gref[i]), _cos(d_img[i], gref[i])
+        assert e < 5e-2 and c > 0.998, (i, e, c)
