@@ -150,6 +150,29 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
                         const float* const* d_qkv, const float* const* d_keys, float* d_img,
                         int normalize, splice_stream_t stream);
 
+/* ------------------------------------------------------------------ generator engine
+ * The reference's define_G() -> skip() U-Net (models/networks.py:56-58, models/unet/skip.py:4-102,
+ * models/unet/common.py:11-124), forward + full backward, fp32.  Parameters / gradients are
+ * ONE flat fp32 arena in netG.parameters() order; splice_gen_tensor_info gives the per-tensor
+ * (state_dict name, offset, numel) table.  A plan = (N side-by-side generator calls, H, W). */
+int splice_gen_create(void** out_handle);
+void splice_gen_destroy(void* gen);
+long long splice_gen_param_count(void* gen);
+int splice_gen_num_tensors(void* gen);
+int splice_gen_tensor_info(void* gen, int i, const char** name, long long* offset, long long* numel);
+int splice_gen_plan_create(void* gen, int N, int H, int W, int need_grad, void** out_plan);
+void splice_gen_plan_destroy(void* plan);
+/* y = netG(x) per image (models/model.py:15-23): x,y fp32 [N][3][H][W] */
+int splice_gen_forward(void* plan, const float* params, const float* x, float* y, splice_stream_t stream);
+/* parameter gradients of the last forward from dy = dL/dy (autograd backward through netG,
+ * train.py:78); grads overwritten, or accumulated when accumulate != 0 */
+int splice_gen_backward(void* plan, const float* params, const float* dy, float* grads, int accumulate,
+                        splice_stream_t stream);
+/* torch.optim.Adam(lr, betas) step (util/util.py:28-32, train.py:79) fused over the arena;
+ * step counts from 1; zero_grad != 0 also clears grads (optimizer.zero_grad, train.py:56) */
+int splice_adam_step(float* params, float* grads, float* m, float* v, long long n, float lr, float beta1,
+                     float beta2, float eps, int step, int zero_grad, splice_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,17 @@ _SIGNATURES = {
     "splice_vit_get_tensor": ([_vp, _i, _i, C.POINTER(_vp)], _i),
     "splice_vit_read_tensor": ([_vp, _i, _i, _vp, _sz, _vp], _i),
     "splice_vit_backward": ([_vp, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp, _i, _vp], _i),
+    # generator engine
+    "splice_gen_create": ([C.POINTER(_vp)], _i),
+    "splice_gen_destroy": ([_vp], None),
+    "splice_gen_param_count": ([_vp], C.c_longlong),
+    "splice_gen_num_tensors": ([_vp], _i),
+    "splice_gen_tensor_info": ([_vp, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], _i),
+    "splice_gen_plan_create": ([_vp, _i, _i, _i, _i, C.POINTER(_vp)], _i),
+    "splice_gen_plan_destroy": ([_vp], None),
+    "splice_gen_forward": ([_vp, _vp, _vp, _vp, _vp], _i),
+    "splice_gen_backward": ([_vp, _vp, _vp, _vp, _i, _vp], _i),
+    "splice_adam_step": ([_vp, _vp, _vp, _vp, C.c_longlong, _f, _f, _f, _f, _i, _i, _vp], _i),
 }
 
 

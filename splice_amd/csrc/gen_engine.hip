@@ -1,0 +1,426 @@
+// Generator engine: the reference's define_G() -> skip() network (models/networks.py:56-58,
+// models/unet/skip.py:4-102) as a static plan of HIP kernel launches over pre-allocated
+// buffers, forward and full backward (dgrad + wgrad + bias/BN grads).  Parameters and
+// gradients live in ONE flat fp32 arena in the reference's parameters() order so the
+// optimiser is a single fused launch and the Python facade can expose per-tensor views.
+//
+// "N" is the number of independent generator calls processed side by side (e.g. G(A_crop)
+// and G(B_crop), models/model.py:15-23): BatchNorm statistics are per call (the reference
+// runs batch 1), parameter gradients are summed over calls.
+#include <string>
+#include <vector>
+
+#include "gen_kernels.h"
+
+void splice_set_error(const char* fmt, ...);
+
+#define RC(x)                                                                                     \
+    do {                                                                                          \
+        int rc_ = (x);                                                                            \
+        if (rc_ != SPLICE_OK) {                                                                   \
+            splice_set_error("%s:%d %s failed (%d)", __FILE__, __LINE__, #x, rc_);                \
+            return rc_;                                                                           \
+        }                                                                                         \
+    } while (0)
+
+static const int DOWN[5] = {16, 32, 64, 128, 128};
+static const int UP[5] = {16, 32, 64, 128, 128};
+static const int SKIPC = 4;
+static const float BN_EPS = 1e-5f;
+static const float LRELU = 0.2f;
+
+struct ParamTable {
+    struct Entry { std::string name; size_t off, numel; };
+    std::vector<Entry> entries;
+    size_t total = 0;
+    size_t add(const std::string& name, size_t numel) {
+        entries.push_back({name, total, numel});
+        total += numel;
+        return entries.back().off;
+    }
+};
+
+// conv(+bias) -> train-mode BN -> LeakyReLU unit (or BN alone when ks == 0)
+struct Unit {
+    int ks = 0, stride = 1, Cin = 0, Cout = 0, Hi = 0, Wi = 0, Ho = 0, Wo = 0;
+    size_t w_off = 0, b_off = 0, g_off = 0, be_off = 0;   // offsets into the parameter arena
+    bool has_bn = true;
+    float slope = LRELU;
+    // tensors (device): input, conv output y, activation output a (+ strides, may be channel slices)
+    const float* in = nullptr; size_t in_ns = 0;
+    float* y = nullptr; size_t y_ns = 0;
+    float* out = nullptr; size_t out_ns = 0;
+    float *mean = nullptr, *rstd = nullptr, *s1 = nullptr, *s2 = nullptr;
+    // gradients
+    float* d_out = nullptr; size_t d_out_ns = 0;   // grad w.r.t. `out` (provided by the consumer)
+    float* dy = nullptr;                            // grad w.r.t. y (same shape/stride as y)
+    float* d_in = nullptr; size_t d_in_ns = 0;      // grad w.r.t. `in` (null: not needed)
+    int d_in_accumulate = 0;
+};
+
+struct SpliceGen {
+    ParamTable table;
+};
+
+struct SpliceGenPlan {
+    SpliceGen* gen = nullptr;
+    int N = 0, H = 0, W = 0, need_grad = 0;
+    int h[6], w[6];                       // spatial size at scale i (h[0] = H)
+    std::vector<void*> allocs;
+    // per scale
+    Unit u_skip[5], u_da[5], u_db[5], u_cat[5], u_up3[5], u_up1[5];
+    float* cat[5]; float* d_cat[5];       // [N][4+k][h][w]
+    int kch[5];
+    float* head_y = nullptr;              // unused (sigmoid fused)
+    size_t head_w = 0, head_b = 0;
+    float* d_head_pre = nullptr;          // [N][3][H][W]
+    float* d_u0 = nullptr;                // grad w.r.t. u_0 (scale-0 output)
+    float* wgrad_ws = nullptr;
+    float* out_copy = nullptr;            // generator output kept for the sigmoid backward
+    float* x_copy = nullptr;              // private copy of the input (the caller may free x after forward)
+    int forward_saved = 0;
+};
+
+static void build_table(ParamTable& t, size_t* offs /* [5][6 units][4] */, size_t* head) {
+    auto conv = [&](const std::string& n, int co, int ci, int k, size_t* o) {
+        o[0] = t.add(n + ".weight", (size_t)co * ci * k * k);
+        o[1] = t.add(n + ".bias", co);
+    };
+    auto bn = [&](const std::string& n, int c, size_t* o) {
+        o[2] = t.add(n + ".weight", c);
+        o[3] = t.add(n + ".bias", c);
+    };
+    std::string prefix[5];
+    for (int i = 1; i < 5; ++i) prefix[i] = prefix[i - 1] + "1.1.7.";
+    // registration order is recursive (skip.py:46-99): skip, down-a, down-b of scale i, then all of scale
+    // i+1, then cat-BN, up3, up1 of scale i.
+    struct Rec {
+        static void go(int i, int cin, ParamTable& t, size_t* offs, std::string* prefix,
+                       decltype(conv)& conv, decltype(bn)& bn) {
+            const std::string p = prefix[i];
+            size_t* o = offs + (size_t)i * 6 * 4;
+            conv(p + "1.0.1.0", SKIPC, cin, 1, o + 0 * 4); bn(p + "1.0.2", SKIPC, o + 0 * 4);
+            conv(p + "1.1.1.0", DOWN[i], cin, 3, o + 1 * 4); bn(p + "1.1.2", DOWN[i], o + 1 * 4);
+            conv(p + "1.1.4.0", DOWN[i], DOWN[i], 3, o + 2 * 4); bn(p + "1.1.5", DOWN[i], o + 2 * 4);
+            int k = DOWN[i];
+            if (i < 4) { go(i + 1, DOWN[i], t, offs, prefix, conv, bn); k = UP[i + 1]; }
+            bn(p + "2", SKIPC + k, o + 3 * 4);
+            conv(p + "3.0", UP[i], SKIPC + k, 3, o + 4 * 4); bn(p + "4", UP[i], o + 4 * 4);
+            conv(p + "6.0", UP[i], UP[i], 1, o + 5 * 4); bn(p + "7", UP[i], o + 5 * 4);
+        }
+    };
+    Rec::go(0, 3, t, offs, prefix, conv, bn);
+    conv("9.0", 3, UP[0], 1, head);
+}
+
+template <class T>
+static int palloc(SpliceGenPlan* p, T** ptr, size_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, n * sizeof(T) + 256) != hipSuccess) {
+        splice_set_error("generator plan: hipMalloc of %zu bytes failed", n * sizeof(T));
+        return SPLICE_ERR_NOMEM;
+    }
+    p->allocs.push_back(q);
+    *ptr = (T*)q;
+    return SPLICE_OK;
+}
+
+static int unit_alloc(SpliceGenPlan* p, Unit& u, bool own_out) {
+    const size_t N = p->N;
+    if (u.ks) {
+        RC(palloc(p, &u.y, N * u.Cout * u.Ho * u.Wo));
+        u.y_ns = (size_t)u.Cout * u.Ho * u.Wo;
+    }
+    RC(palloc(p, &u.mean, N * u.Cout)); RC(palloc(p, &u.rstd, N * u.Cout));
+    RC(palloc(p, &u.s1, N * u.Cout)); RC(palloc(p, &u.s2, N * u.Cout));
+    if (own_out) {
+        RC(palloc(p, &u.out, N * u.Cout * u.Ho * u.Wo));
+        u.out_ns = (size_t)u.Cout * u.Ho * u.Wo;
+    }
+    if (p->need_grad) {
+        RC(palloc(p, &u.dy, N * u.Cout * u.Ho * u.Wo));
+        if (own_out) {
+            RC(palloc(p, &u.d_out, N * u.Cout * u.Ho * u.Wo));
+            u.d_out_ns = u.out_ns;
+        }
+    }
+    return SPLICE_OK;
+}
+
+static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* params, hipStream_t s) {
+    const int N = p->N;
+    const float* y = u.in;
+    size_t y_ns = u.in_ns;
+    if (u.ks) {
+        ConvArgs a = {};
+        a.in = u.in; a.w = params + u.w_off; a.bias = params + u.b_off; a.out = u.y;
+        a.in_nstride = u.in_ns; a.in_cstride = (size_t)u.Hi * u.Wi; a.out_nstride = u.y_ns; a.out_cstride = (size_t)u.Ho * u.Wo;
+        a.w_jstride = (size_t)u.Cin * u.ks * u.ks; a.w_cstride = (size_t)u.ks * u.ks;
+        a.N = N; a.Cin = u.Cin; a.Hi = u.Hi; a.Wi = u.Wi; a.Cout = u.Cout; a.Ho = u.Ho; a.Wo = u.Wo;
+        a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2;
+        RC(conv_launch(a, s));
+        y = u.y; y_ns = u.y_ns;
+    }
+    RC(bn_stats_launch(y, y_ns, N, u.Cout, u.Ho * u.Wo, BN_EPS, u.mean, u.rstd, s));
+    RC(bn_act_launch(y, y_ns, u.out, u.out_ns, N, u.Cout, u.Ho * u.Wo, params + u.g_off, params + u.be_off, u.mean, u.rstd, u.slope, s));
+    return SPLICE_OK;
+}
+
+// backward of one unit: consumes u.d_out, produces parameter grads and (optionally) u.d_in
+static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* params, float* grads, int acc, hipStream_t s) {
+    const int N = p->N, HW = u.Ho * u.Wo;
+    const float* y = u.ks ? u.y : u.in;
+    const size_t y_ns = u.ks ? u.y_ns : u.in_ns;
+    float* dy = u.ks ? u.dy : u.d_in;          // BN-only unit: dy IS the input gradient
+    const size_t dy_ns = u.ks ? u.y_ns : u.d_in_ns;
+    RC(bn_bwd_launch(u.d_out, u.d_out_ns, u.out, u.out_ns, y, y_ns, dy, dy_ns, N, u.Cout, HW, params + u.g_off, u.mean, u.rstd, u.slope,
+                     u.s1, u.s2, grads + u.g_off, grads + u.be_off, acc, s));
+    if (!u.ks) return SPLICE_OK;
+    RC(channel_sum_launch(u.dy, u.y_ns, N, u.Cout, HW, grads + u.b_off, acc, s));
+    {
+        WgradArgs a = {};
+        a.x = u.in; a.dy = u.dy; a.ws = p->wgrad_ws;
+        a.x_nstride = u.in_ns; a.x_cstride = (size_t)u.Hi * u.Wi; a.dy_nstride = u.y_ns; a.dy_cstride = (size_t)HW;
+        a.N = N; a.Cin = u.Cin; a.Hi = u.Hi; a.Wi = u.Wi; a.Cout = u.Cout; a.Ho = u.Ho; a.Wo = u.Wo;
+        a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2;
+        RC(conv_wgrad_launch(a, grads + u.w_off, acc, s));
+    }
+    if (u.d_in) {
+        ConvArgs a = {};
+        a.in = u.dy; a.w = params + u.w_off; a.bias = nullptr; a.out = u.d_in;
+        a.in_nstride = u.y_ns; a.in_cstride = (size_t)HW; a.out_nstride = u.d_in_ns; a.out_cstride = (size_t)u.Hi * u.Wi;
+        a.w_jstride = (size_t)u.ks * u.ks; a.w_cstride = (size_t)u.Cin * u.ks * u.ks;
+        a.N = N; a.Cin = u.Cout; a.Hi = u.Ho; a.Wi = u.Wo; a.Cout = u.Cin; a.Ho = u.Hi; a.Wo = u.Wi;
+        a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2; a.transposed = 1; a.accumulate = u.d_in_accumulate;
+        RC(conv_launch(a, s));
+    }
+    return SPLICE_OK;
+}
+
+static size_t wgrad_ws_need(const SpliceGenPlan* p, const Unit& u) {
+    if (!u.ks) return 0;
+    int ppc, cpi;
+    const int chunks = wgrad_chunks(p->N, u.Ho, u.Wo, &ppc, &cpi);
+    return (size_t)chunks * u.Cout * u.Cin * u.ks * u.ks;
+}
+
+extern "C" {
+
+int splice_gen_create(void** out) {
+    if (!out) return SPLICE_ERR_ARG;
+    SpliceGen* g = new SpliceGen();
+    size_t offs[5 * 6 * 4], head[4];
+    build_table(g->table, offs, head);
+    *out = g;
+    return SPLICE_OK;
+}
+void splice_gen_destroy(void* h) { delete (SpliceGen*)h; }
+
+long long splice_gen_param_count(void* h) { return h ? (long long)((SpliceGen*)h)->table.total : -1; }
+int splice_gen_num_tensors(void* h) { return h ? (int)((SpliceGen*)h)->table.entries.size() : -1; }
+// name / offset / numel of parameter tensor i, in the reference's netG.parameters() order
+int splice_gen_tensor_info(void* h, int i, const char** name, long long* offset, long long* numel) {
+    SpliceGen* g = (SpliceGen*)h;
+    if (!g || i < 0 || i >= (int)g->table.entries.size()) return SPLICE_ERR_ARG;
+    if (name) *name = g->table.entries[i].name.c_str();
+    if (offset) *offset = (long long)g->table.entries[i].off;
+    if (numel) *numel = (long long)g->table.entries[i].numel;
+    return SPLICE_OK;
+}
+
+int splice_gen_plan_create(void* h, int N, int H, int W, int need_grad, void** out) {
+    SpliceGen* g = (SpliceGen*)h;
+    if (!g || !out || N < 1 || H < 33 || W < 33) {
+        splice_set_error("splice_gen_plan_create: need N>=1 and H,W >= 33 (train-mode BatchNorm needs >1 value per channel at the 5th scale)");
+        return SPLICE_ERR_ARG;
+    }
+    SpliceGenPlan* p = new SpliceGenPlan();
+    p->gen = g; p->N = N; p->H = H; p->W = W; p->need_grad = need_grad;
+    p->h[0] = H; p->w[0] = W;
+    for (int i = 1; i <= 5; ++i) { p->h[i] = (p->h[i - 1] + 1) / 2; p->w[i] = (p->w[i - 1] + 1) / 2; }
+    size_t offs[5 * 6 * 4], head[4];
+    ParamTable tmp;
+    build_table(tmp, offs, head);
+    p->head_w = head[0]; p->head_b = head[1];
+    int rc = SPLICE_OK;
+    auto fail = [&]() { for (void* q : p->allocs) hipFree(q); delete p; return rc; };
+    size_t ws_need = 0;
+    for (int i = 0; i < 5 && rc == SPLICE_OK; ++i) {
+        const int cin = i == 0 ? 3 : DOWN[i - 1];
+        const int hi = p->h[i], wi = p->w[i], hd = p->h[i + 1], wd = p->w[i + 1];
+        const int k = i < 4 ? UP[i + 1] : DOWN[i];
+        p->kch[i] = k;
+        const size_t catC = SKIPC + k;
+        if ((rc = palloc(p, &p->cat[i], (size_t)N * catC * hi * wi)) != SPLICE_OK) break;
+        if (need_grad && (rc = palloc(p, &p->d_cat[i], (size_t)N * catC * hi * wi)) != SPLICE_OK) break;
+        const size_t cat_ns = catC * hi * wi;
+        size_t* o = offs + (size_t)i * 6 * 4;
+        auto setp = [&](Unit& u, int idx) { u.w_off = o[idx * 4 + 0]; u.b_off = o[idx * 4 + 1]; u.g_off = o[idx * 4 + 2]; u.be_off = o[idx * 4 + 3]; };
+        Unit& sk = p->u_skip[i];
+        sk.ks = 1; sk.stride = 1; sk.Cin = cin; sk.Cout = SKIPC; sk.Hi = hi; sk.Wi = wi; sk.Ho = hi; sk.Wo = wi; setp(sk, 0);
+        if ((rc = unit_alloc(p, sk, false)) != SPLICE_OK) break;
+        sk.out = p->cat[i]; sk.out_ns = cat_ns;
+        if (need_grad) { sk.d_out = p->d_cat[i]; sk.d_out_ns = cat_ns; }
+        Unit& da = p->u_da[i];
+        da.ks = 3; da.stride = 2; da.Cin = cin; da.Cout = DOWN[i]; da.Hi = hi; da.Wi = wi; da.Ho = hd; da.Wo = wd; setp(da, 1);
+        if ((rc = unit_alloc(p, da, true)) != SPLICE_OK) break;
+        Unit& db = p->u_db[i];
+        db.ks = 3; db.stride = 1; db.Cin = DOWN[i]; db.Cout = DOWN[i]; db.Hi = hd; db.Wi = wd; db.Ho = hd; db.Wo = wd; setp(db, 2);
+        if ((rc = unit_alloc(p, db, true)) != SPLICE_OK) break;
+        Unit& ct = p->u_cat[i];
+        ct.ks = 0; ct.Cin = (int)catC; ct.Cout = (int)catC; ct.Hi = hi; ct.Wi = wi; ct.Ho = hi; ct.Wo = wi; ct.slope = 1.0f; setp(ct, 3);
+        if ((rc = unit_alloc(p, ct, true)) != SPLICE_OK) break;
+        ct.in = p->cat[i]; ct.in_ns = cat_ns;
+        if (need_grad) { ct.d_in = p->d_cat[i]; ct.d_in_ns = cat_ns; }
+        Unit& u3 = p->u_up3[i];
+        u3.ks = 3; u3.stride = 1; u3.Cin = (int)catC; u3.Cout = UP[i]; u3.Hi = hi; u3.Wi = wi; u3.Ho = hi; u3.Wo = wi; setp(u3, 4);
+        if ((rc = unit_alloc(p, u3, true)) != SPLICE_OK) break;
+        Unit& u1 = p->u_up1[i];
+        u1.ks = 1; u1.stride = 1; u1.Cin = UP[i]; u1.Cout = UP[i]; u1.Hi = hi; u1.Wi = wi; u1.Ho = hi; u1.Wo = wi; setp(u1, 5);
+        if ((rc = unit_alloc(p, u1, true)) != SPLICE_OK) break;
+        // wiring (inputs / gradient sinks)
+        da.in_ns = (size_t)cin * hi * wi; sk.in_ns = da.in_ns;     // .in set at run time for scale 0 (the image)
+        db.in = da.out; db.in_ns = da.out_ns;
+        u3.in = ct.out; u3.in_ns = ct.out_ns;
+        u1.in = u3.out; u1.in_ns = u3.out_ns;
+        if (need_grad) {
+            db.d_in = da.d_out; db.d_in_ns = da.d_out_ns;
+            u3.d_in = ct.d_out; u3.d_in_ns = ct.d_out_ns;
+            u1.d_in = u3.d_out; u1.d_in_ns = u3.d_out_ns;
+        }
+        for (Unit* u : {&sk, &da, &db, &u3, &u1}) { const size_t n = wgrad_ws_need(p, *u); if (n > ws_need) ws_need = n; }
+    }
+    if (rc != SPLICE_OK) return fail();
+    // link scales: x_{i+1} = db_i.out ; d x_{i+1} = db_i.d_out
+    for (int i = 1; i < 5; ++i) {
+        p->u_skip[i].in = p->u_db[i - 1].out; p->u_da[i].in = p->u_db[i - 1].out;
+        if (need_grad) {
+            p->u_da[i].d_in = p->u_db[i - 1].d_out; p->u_da[i].d_in_ns = p->u_db[i - 1].d_out_ns; p->u_da[i].d_in_accumulate = 0;  // first writer
+            p->u_skip[i].d_in = p->u_db[i - 1].d_out; p->u_skip[i].d_in_ns = p->u_db[i - 1].d_out_ns; p->u_skip[i].d_in_accumulate = 1;
+        }
+    }
+    { const size_t n = (size_t)N * 3 * UP[0] * 16; if (n > ws_need) ws_need = n; }
+    {
+        int ppc, cpi;
+        const size_t n = (size_t)wgrad_chunks(N, H, W, &ppc, &cpi) * 3 * UP[0];
+        if (n > ws_need) ws_need = n;
+    }
+    if ((rc = palloc(p, &p->x_copy, (size_t)N * 3 * H * W)) != SPLICE_OK) return fail();
+    if (need_grad) {
+        if ((rc = palloc(p, &p->wgrad_ws, ws_need)) != SPLICE_OK) return fail();
+        if ((rc = palloc(p, &p->d_head_pre, (size_t)N * 3 * H * W)) != SPLICE_OK) return fail();
+        if ((rc = palloc(p, &p->out_copy, (size_t)N * 3 * H * W)) != SPLICE_OK) return fail();
+    }
+    *out = p;
+    return SPLICE_OK;
+}
+
+void splice_gen_plan_destroy(void* plan) {
+    SpliceGenPlan* p = (SpliceGenPlan*)plan;
+    if (!p) return;
+    for (void* q : p->allocs) hipFree(q);
+    delete p;
+}
+
+static int scale_forward(SpliceGenPlan* p, int i, const float* params, hipStream_t s) {
+    RC(unit_forward(p, p->u_skip[i], params, s));
+    RC(unit_forward(p, p->u_da[i], params, s));
+    RC(unit_forward(p, p->u_db[i], params, s));
+    const float* deep = p->u_db[i].out;
+    size_t deep_ns = p->u_db[i].out_ns;
+    if (i < 4) {
+        RC(scale_forward(p, i + 1, params, s));
+        deep = p->u_up1[i + 1].out; deep_ns = p->u_up1[i + 1].out_ns;
+    }
+    const int hi = p->h[i], wi = p->w[i];
+    RC(upsample2x_fwd_launch(deep, deep_ns, p->cat[i] + (size_t)SKIPC * hi * wi, p->u_skip[i].out_ns, p->N, p->kch[i], p->h[i + 1], p->w[i + 1], hi, wi, s));
+    RC(unit_forward(p, p->u_cat[i], params, s));
+    RC(unit_forward(p, p->u_up3[i], params, s));
+    RC(unit_forward(p, p->u_up1[i], params, s));
+    return SPLICE_OK;
+}
+
+// x [N][3][H][W] in [0,1] -> y [N][3][H][W] in (0,1)   (netG(input), models/model.py:15-23)
+int splice_gen_forward(void* plan, const float* params, const float* x, float* y, splice_stream_t stream) {
+    SpliceGenPlan* p = (SpliceGenPlan*)plan;
+    if (!p || !params || !x || !y) return SPLICE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(p->x_copy, x, (size_t)p->N * 3 * p->H * p->W * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return SPLICE_ERR_HIP;
+    p->u_skip[0].in = p->x_copy; p->u_da[0].in = p->x_copy;
+    RC(scale_forward(p, 0, params, s));
+    {
+        const Unit& u = p->u_up1[0];
+        ConvArgs a = {};
+        a.in = u.out; a.w = params + p->head_w; a.bias = params + p->head_b; a.out = y;
+        a.in_nstride = u.out_ns; a.in_cstride = (size_t)p->H * p->W; a.out_nstride = (size_t)3 * p->H * p->W; a.out_cstride = (size_t)p->H * p->W;
+        a.w_jstride = UP[0]; a.w_cstride = 1;
+        a.N = p->N; a.Cin = UP[0]; a.Hi = p->H; a.Wi = p->W; a.Cout = 3; a.Ho = p->H; a.Wo = p->W; a.ks = 1; a.stride = 1; a.pad = 0; a.act = 1;
+        RC(conv_launch(a, s));
+    }
+    if (p->need_grad) {
+        if (hipMemcpyAsync(p->out_copy, y, (size_t)p->N * 3 * p->H * p->W * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return SPLICE_ERR_HIP;
+        p->forward_saved = 1;
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { splice_set_error("splice_gen_forward: %s", hipGetErrorString(e)); return SPLICE_ERR_HIP; }
+    return SPLICE_OK;
+}
+
+static int scale_backward(SpliceGenPlan* p, int i, const float* params, float* grads, int acc, hipStream_t s) {
+    // u_up1[i].d_out holds d u_i
+    RC(unit_backward(p, p->u_up1[i], params, grads, acc, s));
+    RC(unit_backward(p, p->u_up3[i], params, grads, acc, s));
+    RC(unit_backward(p, p->u_cat[i], params, grads, acc, s));   // -> d_cat[i]
+    const int hi = p->h[i], wi = p->w[i];
+    Unit& deep = i < 4 ? p->u_up1[i + 1] : p->u_db[i];
+    RC(upsample2x_bwd_launch(p->d_cat[i] + (size_t)SKIPC * hi * wi, p->u_skip[i].d_out_ns, deep.d_out, deep.d_out_ns, p->N, p->kch[i],
+                             p->h[i + 1], p->w[i + 1], hi, wi, s));
+    if (i < 4) RC(scale_backward(p, i + 1, params, grads, acc, s));   // leaves d x_{i+1} in u_db[i].d_out
+    RC(unit_backward(p, p->u_db[i], params, grads, acc, s));
+    RC(unit_backward(p, p->u_da[i], params, grads, acc, s));
+    RC(unit_backward(p, p->u_skip[i], params, grads, acc, s));
+    return SPLICE_OK;
+}
+
+// dy: grad w.r.t. the generator output [N][3][H][W]; grads: flat arena (overwritten, or += when accumulate)
+int splice_gen_backward(void* plan, const float* params, const float* dy, float* grads, int accumulate, splice_stream_t stream) {
+    SpliceGenPlan* p = (SpliceGenPlan*)plan;
+    if (!p || !p->need_grad || !p->forward_saved || !params || !dy || !grads) {
+        splice_set_error("splice_gen_backward: plan without need_grad / no forward / null argument");
+        return SPLICE_ERR_STATE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t npix = (size_t)p->N * 3 * p->H * p->W;
+    RC(sigmoid_bwd_launch(dy, p->out_copy, p->d_head_pre, npix, s));
+    const Unit& u = p->u_up1[0];
+    const int HW = p->H * p->W;
+    RC(channel_sum_launch(p->d_head_pre, (size_t)3 * HW, p->N, 3, HW, grads + p->head_b, accumulate, s));
+    {
+        WgradArgs a = {};
+        a.x = u.out; a.dy = p->d_head_pre; a.ws = p->wgrad_ws;
+        a.x_nstride = u.out_ns; a.x_cstride = (size_t)HW; a.dy_nstride = (size_t)3 * HW; a.dy_cstride = (size_t)HW;
+        a.N = p->N; a.Cin = UP[0]; a.Hi = p->H; a.Wi = p->W; a.Cout = 3; a.Ho = p->H; a.Wo = p->W; a.ks = 1; a.stride = 1; a.pad = 0;
+        RC(conv_wgrad_launch(a, grads + p->head_w, accumulate, s));
+    }
+    {
+        ConvArgs a = {};
+        a.in = p->d_head_pre; a.w = params + p->head_w; a.out = u.d_out;
+        a.in_nstride = (size_t)3 * HW; a.in_cstride = (size_t)HW; a.out_nstride = u.d_out_ns; a.out_cstride = (size_t)HW;
+        a.w_jstride = 1; a.w_cstride = UP[0];
+        a.N = p->N; a.Cin = 3; a.Hi = p->H; a.Wi = p->W; a.Cout = UP[0]; a.Ho = p->H; a.Wo = p->W; a.ks = 1; a.stride = 1; a.pad = 0; a.transposed = 1;
+        RC(conv_launch(a, s));
+    }
+    RC(scale_backward(p, 0, params, grads, accumulate, s));
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { splice_set_error("splice_gen_backward: %s", hipGetErrorString(e)); return SPLICE_ERR_HIP; }
+    return SPLICE_OK;
+}
+
+// torch.optim.Adam step over a flat arena (util/util.py:28-32); zero_grad != 0 also clears g.
+int splice_adam_step(float* params, float* grads, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                     int step, int zero_grad, splice_stream_t stream) {
+    if (!params || !grads || !m || !v || n < 1) return SPLICE_ERR_ARG;
+    RC(adam_launch(params, grads, m, v, (size_t)n, lr, beta1, beta2, eps, step, zero_grad, (hipStream_t)stream));
+    return SPLICE_OK;
+}
+}

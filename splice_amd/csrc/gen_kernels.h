@@ -1,0 +1,41 @@
+// Launchers of the generator kernels (gen_kernels.hip).
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+    const float* in;      // [N][*][Hi][Wi]; channel c at in + img*in_nstride + c*in_cstride
+    const float* w;       // element (col n, red. channel c, tap) at n*w_jstride + c*w_cstride + tap
+    const float* bias;    // [Cout] or null
+    float* out;           // [N][*][Ho][Wo]; channel n at out + img*out_nstride + n*out_cstride
+    size_t in_nstride, in_cstride, out_nstride, out_cstride;
+    size_t w_jstride, w_cstride;
+    int N, Cin, Hi, Wi, Cout, Ho, Wo;   // Cin = reduction channels, Cout = output columns
+    int ks, stride, pad;
+    int act;          // 1 = sigmoid
+    int transposed;   // data-gradient form
+    int accumulate;   // out += result
+};
+int conv_launch(const ConvArgs& a, hipStream_t s);
+
+struct WgradArgs {
+    const float* x;       // layer input  [N][*][Hi][Wi]
+    const float* dy;      // grad of the conv output [N][*][Ho][Wo]
+    float* ws;            // scratch: chunks * Cout*Cin*ks*ks floats
+    size_t x_nstride, x_cstride, dy_nstride, dy_cstride;
+    int N, Cin, Hi, Wi, Cout, Ho, Wo, ks, stride, pad;
+    int pix_per_chunk, chunks_per_img;   // filled by the launcher
+};
+int wgrad_chunks(int N, int Ho, int Wo, int* pix_per_chunk, int* chunks_per_img);
+int conv_wgrad_launch(WgradArgs a, float* dw, int accumulate, hipStream_t s);
+
+int bn_stats_launch(const float* y, size_t nstride, int N, int C, int HW, float eps, float* mean, float* rstd, hipStream_t s);
+int bn_act_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
+                  const float* beta, const float* mean, const float* rstd, float slope, hipStream_t s);
+int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
+                  size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
+                  float* s1, float* s2, float* dgamma, float* dbeta, int accumulate, hipStream_t s);
+int channel_sum_launch(const float* dy, size_t nstride, int N, int C, int HW, float* db, int accumulate, hipStream_t s);
+int upsample2x_fwd_launch(const float* in, size_t in_nstride, float* out, size_t out_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s);
+int upsample2x_bwd_launch(const float* dout, size_t dout_nstride, float* din, size_t din_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s);
+int sigmoid_bwd_launch(const float* dout, const float* sout, float* dpre, size_t n, hipStream_t s);
+int adam_launch(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step, int zero_grad, hipStream_t s);

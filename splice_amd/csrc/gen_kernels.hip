@@ -1,0 +1,515 @@
+// Kernels of the skip-U-Net generator (K13-K18 of SURVEY.md; models/unet/skip.py:42-102,
+// models/unet/common.py:11-124): fp32 NCHW, convolutions as implicit GEMM on the exact-f32
+// matrix cores (v_mfma_f32_16x16x4_f32: bit-equal to an fmaf chain, so generator parity with
+// the fp32 oracle is rounding-order only), train-mode BatchNorm with per-instance statistics
+// (the reference calls netG once per image with batch 1), LeakyReLU(0.2), bilinear x2
+// up-sampling written straight into the concat buffer, sigmoid head.  Every reduction runs
+// in a fixed order (no float atomics): replicas are bit-reproducible.
+#include "gen_kernels.h"
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    // A: lane l holds A[i = l&15][k = l>>4];  B: lane l holds B[k = l>>4][n = l&15]
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------
+// Implicit-GEMM convolution.  M = output pixels of one image (64 per workgroup),
+// N = output channels (16*FN per workgroup), K = (channel, ky, kx) in the weight's own
+// memory order, consumed CK channels at a time.  TRANSPOSED = data-gradient form:
+// out[c][iy][ix] = sum_{n,ky,kx} in[n][oy][ox] w[n][c][ky][kx] with oy*stride + ky - pad = iy.
+template <int KS, bool TRANSPOSED, int FN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+    constexpr int T = KS * KS;
+    constexpr int CK = (KS == 3) ? 4 : 16;
+    constexpr int KT = CK * T;          // 36 or 16
+    constexpr int BM = 64;
+    constexpr int LDA = BM + 16;        // 80: k-rows 16 banks apart -> conflict-free ds_read_b32
+    constexpr int LDW = KT + 2;         // 38 / 18 = 2*odd -> conflict-free
+    constexpr int BN = 16 * FN;
+    __shared__ float As[KT * LDA];
+    __shared__ float Ws[BN * LDW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int img = blockIdx.z;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int HWo = a.Ho * a.Wo;
+    const float* in = a.in + (size_t)img * a.in_nstride;
+    // this thread gathers pixel pl for k = wave + 4*i
+    const int pl = tid & 63;
+    const int p = m0 + pl;
+    const bool pvalid = p < HWo;
+    const int oy = pvalid ? p / a.Wo : 0, ox = pvalid ? p % a.Wo : 0;
+    f32x4 acc[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int Kc = a.Cin;  // reduction channels
+    for (int c0 = 0; c0 < Kc; c0 += CK) {
+        __syncthreads();
+        // ---- gather A tile: As[k][pixel]
+#pragma unroll
+        for (int i = 0; i < KT / 4; ++i) {
+            const int k = wave + 4 * i;           // wave-uniform
+            const int cl = k / T, tap = k % T;
+            const int ky = tap / KS, kx = tap % KS;
+            const int c = c0 + cl;
+            float v = 0.f;
+            if (pvalid && c < Kc) {
+                int sy, sx;
+                bool ok;
+                if (!TRANSPOSED) {
+                    sy = oy * a.stride + ky - a.pad;
+                    sx = ox * a.stride + kx - a.pad;
+                    ok = sy >= 0 && sy < a.Hi && sx >= 0 && sx < a.Wi;
+                } else {
+                    const int ty = oy + a.pad - ky, tx = ox + a.pad - kx;
+                    ok = ty >= 0 && tx >= 0;
+                    if (a.stride == 2) {
+                        ok = ok && !(ty & 1) && !(tx & 1);
+                        sy = ty >> 1; sx = tx >> 1;
+                    } else {
+                        sy = ty; sx = tx;
+                    }
+                    ok = ok && sy < a.Hi && sx < a.Wi;
+                }
+                if (ok) v = in[(size_t)c * a.in_cstride + (size_t)sy * a.Wi + sx];
+            }
+            As[k * LDA + pl] = v;
+        }
+        // ---- weight tile: Ws[j][k] = w[(n0+j)*w_jstride + (c0+cl)*w_cstride + tap]
+        for (int e = tid; e < BN * KT; e += 256) {
+            const int j = e / KT, k = e % KT;
+            const int cl = k / T, tap = k % T;
+            const int n = n0 + j, c = c0 + cl;
+            float v = 0.f;
+            if (n < a.Cout && c < Kc) v = a.w[(size_t)n * a.w_jstride + (size_t)c * a.w_cstride + tap];
+            Ws[j * LDW + k] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KT / 4; ++kk) {
+            const float av = As[(kk * 4 + (lane >> 4)) * LDA + wave * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const float bv = Ws[(j * 16 + (lane & 15)) * LDW + kk * 4 + (lane >> 4)];
+                acc[j] = mfma4(av, bv, acc[j]);
+            }
+        }
+    }
+    // epilogue: acc[j][r] = out[n = n0 + j*16 + (lane&15)][pixel = m0 + wave*16 + (lane>>4)*4 + r]
+    float* out = a.out + (size_t)img * a.out_nstride;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + j * 16 + (lane & 15);
+        if (n >= a.Cout) continue;
+        const float b = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pp = m0 + wave * 16 + (lane >> 4) * 4 + r;
+            if (pp < HWo) {
+                float v = acc[j][r] + b;
+                if (a.act == 1) v = 1.0f / (1.0f + __expf(-v));
+                float* q = out + (size_t)n * a.out_cstride + pp;
+                *q = a.accumulate ? *q + v : v;
+            }
+        }
+    }
+}
+
+template <int KS, bool TR>
+static void conv_launch_fn(const ConvArgs& a, hipStream_t s) {
+    const int HWo = a.Ho * a.Wo;
+    if (a.Cout <= 16) {
+        hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1>), dim3(cdiv(HWo, 64), 1, a.N), dim3(256), 0, s, a);
+    } else if (a.Cout <= 32) {
+        hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 2>), dim3(cdiv(HWo, 64), 1, a.N), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 4>), dim3(cdiv(HWo, 64), cdiv(a.Cout, 64), a.N), dim3(256), 0, s, a);
+    }
+}
+
+int conv_launch(const ConvArgs& a, hipStream_t s) {
+    if (a.ks != 1 && a.ks != 3) return SPLICE_ERR_ARG;
+    if (a.stride != 1 && a.stride != 2) return SPLICE_ERR_ARG;
+    if (a.ks == 3) { if (a.transposed) conv_launch_fn<3, true>(a, s); else conv_launch_fn<3, false>(a, s); }
+    else { if (a.transposed) conv_launch_fn<1, true>(a, s); else conv_launch_fn<1, false>(a, s); }
+    return SPLICE_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Weight gradient: dW[n][c][tap] = sum_{img,pixel} dy[n][pixel] * x[c][tap-shifted pixel].
+// Workgroup = (pixel chunk, 4-or-16-channel K tile); MFMA reduces over pixels; the partial
+// tile goes to ws[chunk][n][k] and wgrad_reduce_kernel sums chunks in a fixed order.
+template <int KS, int NI>   // NI = 16-row fragments of output channels
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int T = KS * KS;
+    constexpr int CK = (KS == 3) ? 4 : 16;
+    constexpr int KT = CK * T;                 // 36 / 16
+    constexpr int NJ = (KT + 15) / 16;         // 3 / 1
+    constexpr int PC = 64;                     // pixels per LDS fill
+    constexpr int LD = PC + 2;                 // 66 = 2*33
+    constexpr int NQ = (NI * NJ + 3) / 4;      // fragment pairs per wave
+    __shared__ float Xs[NJ * 16 * LD];         // [k][pixel]
+    __shared__ float Ds[NI * 16 * LD];         // [n][pixel]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x, c0 = blockIdx.y * CK;
+    const int HWo = a.Ho * a.Wo;
+    const int chunks_per_img = a.chunks_per_img;
+    const int img = chunk / chunks_per_img, ch_in_img = chunk % chunks_per_img;
+    const float* x = a.x + (size_t)img * a.x_nstride;
+    const float* dy = a.dy + (size_t)img * a.dy_nstride;
+    f32x4 acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // zero the k-padding rows of Xs once (k in [KT, NJ*16))
+    for (int e = tid; e < (NJ * 16 - KT) * LD; e += 256) Xs[KT * LD + e] = 0.f;
+    const int pl = tid & 63;
+    const int p_begin = ch_in_img * a.pix_per_chunk;
+    const int p_end = min(p_begin + a.pix_per_chunk, HWo);
+    for (int pb = p_begin; pb < p_end; pb += PC) {
+        __syncthreads();
+        const int p = pb + pl;
+        const bool pvalid = p < p_end;
+        const int oy = pvalid ? p / a.Wo : 0, ox = pvalid ? p % a.Wo : 0;
+#pragma unroll
+        for (int i = 0; i < KT / 4; ++i) {
+            const int k = wave + 4 * i;
+            const int cl = k / T, tap = k % T;
+            const int ky = tap / KS, kx = tap % KS;
+            const int c = c0 + cl;
+            float v = 0.f;
+            if (pvalid && c < a.Cin) {
+                const int sy = oy * a.stride + ky - a.pad, sx = ox * a.stride + kx - a.pad;
+                if (sy >= 0 && sy < a.Hi && sx >= 0 && sx < a.Wi) v = x[(size_t)c * a.x_cstride + (size_t)sy * a.Wi + sx];
+            }
+            Xs[k * LD + pl] = v;
+        }
+        for (int e = tid; e < NI * 16 * PC; e += 256) {
+            const int n = e / PC, q = e % PC;
+            const int pp = pb + q;
+            Ds[n * LD + q] = (n < a.Cout && pp < p_end) ? dy[(size_t)n * a.dy_cstride + pp] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int pair = wave + 4 * q;
+            if (pair < NI * NJ) {
+                const int fi = pair / NJ, fj = pair % NJ;
+#pragma unroll
+                for (int s4 = 0; s4 < PC / 4; ++s4) {
+                    const float av = Ds[(fi * 16 + (lane & 15)) * LD + s4 * 4 + (lane >> 4)];
+                    const float bv = Xs[(fj * 16 + (lane & 15)) * LD + s4 * 4 + (lane >> 4)];
+                    acc[q] = mfma4(av, bv, acc[q]);
+                }
+            }
+        }
+    }
+    // partial[chunk][n][c][tap]: layout identical to the weight tensor
+    float* ws = a.ws + (size_t)chunk * a.Cout * a.Cin * T;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int pair = wave + 4 * q;
+        if (pair < NI * NJ) {
+            const int fi = pair / NJ, fj = pair % NJ;
+            const int k = fj * 16 + (lane & 15);
+            const int cl = k / T, tap = k % T;
+            if (k < KT && c0 + cl < a.Cin) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = fi * 16 + (lane >> 4) * 4 + r;
+                    if (n < a.Cout) ws[((size_t)n * a.Cin + c0 + cl) * T + tap] = acc[q][r];
+                }
+            }
+        }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int n, int chunks, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += ws[(size_t)c * n + i];
+    dw[i] = accumulate ? dw[i] + s : s;
+}
+
+template <int KS>
+static void wgrad_launch_fn(const WgradArgs& a, int chunks, int ktiles, hipStream_t s) {
+    const int ni = cdiv(a.Cout, 16);
+    dim3 grid(chunks, ktiles);
+    if (ni <= 1) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 1>), grid, dim3(256), 0, s, a);
+    else if (ni <= 2) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 2>), grid, dim3(256), 0, s, a);
+    else if (ni <= 4) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<KS, 8>), grid, dim3(256), 0, s, a);
+}
+
+int wgrad_chunks(int N, int Ho, int Wo, int* pix_per_chunk, int* chunks_per_img) {
+    const int HWo = Ho * Wo;
+    int ppc = 512;
+    if (HWo <= 1024) ppc = 128;
+    if (HWo <= 256) ppc = 64;
+    *pix_per_chunk = ppc;
+    *chunks_per_img = cdiv(HWo, ppc);
+    return N * *chunks_per_img;
+}
+
+int conv_wgrad_launch(WgradArgs a, float* dw, int accumulate, hipStream_t s) {
+    if (a.Cout > 128 || (a.ks != 1 && a.ks != 3)) return SPLICE_ERR_ARG;
+    const int chunks = wgrad_chunks(a.N, a.Ho, a.Wo, &a.pix_per_chunk, &a.chunks_per_img);
+    const int T = a.ks * a.ks, CK = a.ks == 3 ? 4 : 16;
+    if (a.ks == 3) wgrad_launch_fn<3>(a, chunks, cdiv(a.Cin, CK), s);
+    else wgrad_launch_fn<1>(a, chunks, cdiv(a.Cin, CK), s);
+    const int n = a.Cout * a.Cin * T;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a.ws, dw, n, chunks, accumulate);
+    return SPLICE_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// block-wide fixed-order sum of two values (256 threads)
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[w] = a; red[4 + w] = b; }
+    __syncthreads();
+    a = red[0] + red[1] + red[2] + red[3];
+    b = red[4] + red[5] + red[6] + red[7];
+}
+
+// per-(image, channel) mean / rstd over the H*W plane (biased variance, two-pass)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, size_t nstride, int C, int HW, float eps,
+                                                       float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ float red[8];
+    const int c = blockIdx.x, img = blockIdx.y;
+    const float* p = y + (size_t)img * nstride + (size_t)c * HW;
+    float s = 0.f, dummy = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    block_sum2(s, dummy, red);
+    const float m = s / (float)HW;
+    float sq = 0.f;
+    dummy = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) { const float d = p[i] - m; sq += d * d; }
+    block_sum2(sq, dummy, red);
+    if (threadIdx.x == 0) {
+        mean[img * C + c] = m;
+        rstd[img * C + c] = rsqrtf(sq / (float)HW + eps);
+    }
+}
+
+// a = act(gamma * (y - mean) * rstd + beta), written to a channel slice of `out`
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y, size_t y_nstride, float* __restrict__ out,
+                                                     size_t out_nstride, int C, int HW, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float slope) {
+    const int c = blockIdx.y, img = blockIdx.z;
+    const float sc = gamma[c] * rstd[img * C + c];
+    const float sh = beta[c] - mean[img * C + c] * sc;
+    const float* p = y + (size_t)img * y_nstride + (size_t)c * HW;
+    float* q = out + (size_t)img * out_nstride + (size_t)c * HW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        const float v = p[i] * sc + sh;
+        q[i] = v > 0.f ? v : v * slope;
+    }
+}
+
+// BN backward, reduction half: s1 = sum dz, s2 = sum dz * xhat, dz = da * act'(a)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ da, size_t da_nstride, const float* __restrict__ aout,
+                                                            size_t a_nstride, const float* __restrict__ y, size_t y_nstride, int C, int HW,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd, float slope,
+                                                            float* __restrict__ s1o, float* __restrict__ s2o) {
+    __shared__ float red[8];
+    const int c = blockIdx.x, img = blockIdx.y;
+    const float m = mean[img * C + c], r = rstd[img * C + c];
+    const float* pd = da + (size_t)img * da_nstride + (size_t)c * HW;
+    const float* pa = aout + (size_t)img * a_nstride + (size_t)c * HW;
+    const float* py = y + (size_t)img * y_nstride + (size_t)c * HW;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        float dz = pd[i];
+        if (slope != 1.0f && !(pa[i] > 0.f)) dz *= slope;
+        s1 += dz;
+        s2 += dz * (py[i] - m) * r;
+    }
+    block_sum2(s1, s2, red);
+    if (threadIdx.x == 0) { s1o[img * C + c] = s1; s2o[img * C + c] = s2; }
+}
+
+// apply half: dy = gamma * rstd * (dz - s1/HW - xhat * s2/HW); also dgamma/dbeta (sum over images)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ da, size_t da_nstride, const float* __restrict__ aout,
+                                                           size_t a_nstride, const float* __restrict__ y, size_t y_nstride,
+                                                           float* __restrict__ dy, size_t dy_nstride, int C, int HW, int N,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, float slope, const float* __restrict__ s1i,
+                                                           const float* __restrict__ s2i, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.y, img = blockIdx.z;
+    const float m = mean[img * C + c], r = rstd[img * C + c];
+    const float k1 = s1i[img * C + c] / (float)HW, k2 = s2i[img * C + c] / (float)HW;
+    const float gr = gamma[c] * r;
+    const float* pd = da + (size_t)img * da_nstride + (size_t)c * HW;
+    const float* pa = aout + (size_t)img * a_nstride + (size_t)c * HW;
+    const float* py = y + (size_t)img * y_nstride + (size_t)c * HW;
+    float* po = dy + (size_t)img * dy_nstride + (size_t)c * HW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        float dz = pd[i];
+        if (slope != 1.0f && !(pa[i] > 0.f)) dz *= slope;
+        po[i] = gr * (dz - k1 - (py[i] - m) * r * k2);
+    }
+    if (img == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        float g = 0.f, b = 0.f;
+        for (int n = 0; n < N; ++n) { g += s2i[n * C + c]; b += s1i[n * C + c]; }
+        dgamma[c] = accumulate ? dgamma[c] + g : g;
+        dbeta[c] = accumulate ? dbeta[c] + b : b;
+    }
+}
+
+// db[c] = sum over images and pixels of dy[c]
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ dy, size_t nstride, int HW, int N, float* __restrict__ db,
+                                                          int accumulate) {
+    __shared__ float red[8];
+    const int c = blockIdx.x;
+    float s = 0.f, dummy = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* p = dy + (size_t)n * nstride + (size_t)c * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    }
+    block_sum2(s, dummy, red);
+    if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;
+}
+
+int bn_stats_launch(const float* y, size_t nstride, int N, int C, int HW, float eps, float* mean, float* rstd, hipStream_t s) {
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, N), dim3(256), 0, s, y, nstride, C, HW, eps, mean, rstd);
+    return SPLICE_OK;
+}
+static inline int plane_blocks(int HW) { int b = cdiv(HW, 1024); return b < 1 ? 1 : (b > 64 ? 64 : b); }
+int bn_act_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
+                  const float* beta, const float* mean, const float* rstd, float slope, hipStream_t s) {
+    hipLaunchKernelGGL(bn_act_kernel, dim3(plane_blocks(HW), C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, gamma, beta, mean, rstd, slope);
+    return SPLICE_OK;
+}
+int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
+                  size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
+                  float* s1, float* s2, float* dgamma, float* dbeta, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, C, HW, mean, rstd, slope, s1, s2);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(plane_blocks(HW), C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy,
+                       dy_nstride, C, HW, N, gamma, mean, rstd, slope, s1, s2, dgamma, dbeta, accumulate);
+    return SPLICE_OK;
+}
+int channel_sum_launch(const float* dy, size_t nstride, int N, int C, int HW, float* db, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, s, dy, nstride, HW, N, db, accumulate);
+    return SPLICE_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// bilinear x2 (align_corners=False) of in[C][h][w] -> the top-left Ho x Wo window of the 2h x 2w
+// result (Concat's centre-crop offset is always 0 here: models/unet/common.py:24-37).
+__device__ __forceinline__ void up_coord(int o, int n, int& i0, int& i1, float& lam) {
+    float src = ((float)o + 0.5f) * 0.5f - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+    lam = src - (float)i0;
+}
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ in, size_t in_nstride, float* __restrict__ out,
+                                                             size_t out_nstride, int C, int h, int w, int Ho, int Wo) {
+    const int c = blockIdx.y, img = blockIdx.z;
+    const float* p = in + (size_t)img * in_nstride + (size_t)c * h * w;
+    float* q = out + (size_t)img * out_nstride + (size_t)c * Ho * Wo;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Ho * Wo; i += gridDim.x * 256) {
+        const int oy = i / Wo, ox = i % Wo;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        up_coord(oy, h, y0, y1, ly);
+        up_coord(ox, w, x0, x1, lx);
+        const float top = p[y0 * w + x0] * (1.f - lx) + p[y0 * w + x1] * lx;
+        const float bot = p[y1 * w + x0] * (1.f - lx) + p[y1 * w + x1] * lx;
+        q[i] = top * (1.f - ly) + bot * ly;
+    }
+}
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dout, size_t dout_nstride, float* __restrict__ din,
+                                                             size_t din_nstride, int C, int h, int w, int Ho, int Wo) {
+    const int c = blockIdx.y, img = blockIdx.z;
+    const float* p = dout + (size_t)img * dout_nstride + (size_t)c * Ho * Wo;
+    float* q = din + (size_t)img * din_nstride + (size_t)c * h * w;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < h * w; i += gridDim.x * 256) {
+        const int my = i / w, mx = i % w;
+        float wy[4], wx[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int oy = 2 * my - 1 + t, ox = 2 * mx - 1 + t;
+            wy[t] = 0.f; wx[t] = 0.f;
+            if (oy >= 0 && oy < Ho) {
+                int a0, a1; float l;
+                up_coord(oy, h, a0, a1, l);
+                if (a0 == my) wy[t] += 1.f - l;
+                if (a1 == my) wy[t] += l;
+            }
+            if (ox >= 0 && ox < Wo) {
+                int a0, a1; float l;
+                up_coord(ox, w, a0, a1, l);
+                if (a0 == mx) wx[t] += 1.f - l;
+                if (a1 == mx) wx[t] += l;
+            }
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int ty = 0; ty < 4; ++ty) {
+            if (wy[ty] == 0.f) continue;
+            const int oy = 2 * my - 1 + ty;
+            float row = 0.f;
+#pragma unroll
+            for (int tx = 0; tx < 4; ++tx)
+                if (wx[tx] != 0.f) row += wx[tx] * p[oy * Wo + 2 * mx - 1 + tx];
+            acc += wy[ty] * row;
+        }
+        q[i] = acc;
+    }
+}
+int upsample2x_fwd_launch(const float* in, size_t in_nstride, float* out, size_t out_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s) {
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(plane_blocks(Ho * Wo), C, N), dim3(256), 0, s, in, in_nstride, out, out_nstride, C, h, w, Ho, Wo);
+    return SPLICE_OK;
+}
+int upsample2x_bwd_launch(const float* dout, size_t dout_nstride, float* din, size_t din_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s) {
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(plane_blocks(h * w), C, N), dim3(256), 0, s, dout, dout_nstride, din, din_nstride, C, h, w, Ho, Wo);
+    return SPLICE_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// dpre = dout * s * (1 - s) for the sigmoid head (s = generator output)
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ sout, float* __restrict__ dpre, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float sv = sout[i];
+        dpre[i] = dout[i] * sv * (1.f - sv);
+    }
+}
+int sigmoid_bwd_launch(const float* dout, const float* sout, float* dpre, size_t n, hipStream_t s) {
+    size_t g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3((unsigned)g), dim3(256), 0, s, dout, sout, dpre, n);
+    return SPLICE_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused multi-tensor Adam over the flat parameter arena (K19; torch.optim.Adam as configured by
+// util/util.py:28-32: no weight decay / amsgrad, eps added after sqrt(v_hat)).  Also clears the
+// gradient (optimizer.zero_grad, train.py:56) when zero_grad != 0.
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
+                            float b1, float b2, float eps, float bc1, float bc2_sqrt, int zero_grad) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+int adam_launch(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step, int zero_grad, hipStream_t s) {
+    if (step < 1) return SPLICE_ERR_ARG;
+    const float bc1 = 1.0f - powf(b1, (float)step);
+    const float bc2 = 1.0f - powf(b2, (float)step);
+    size_t g_ = (n + 255) / 256;
+    if (g_ > 2048) g_ = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g_), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), zero_grad);
+    return SPLICE_OK;
+}
