@@ -173,6 +173,33 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
 int splice_adam_step(float* params, float* grads, float* m, float* v, long long n, float lr, float beta1,
                      float beta2, float eps, int step, int zero_grad, splice_stream_t stream);
 
+int splice_vit_ctx_dims(void* ctx, int* B, int* H, int* W, int* D, int* depth, int* heads, int* patch);
+int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams);
+
+/* ------------------------------------------------------------------ fused optimisation step
+ * train.py:51-80 for one image pair: Model.forward (models/model.py:12-25), LossG.forward incl.
+ * its lambda schedule (util/losses.py:34-72), loss.backward(), optimizer.step().
+ * Built on a B=4 ViT context [T(A_crop), T(B_crop), T(G(A_crop)), T(G(B_crop))] and an N=2
+ * generator plan (+ a B=2 context / N=1 plan for the every-75th-step entire-image branch). */
+typedef struct splice_step_config {
+    int crop_h, crop_w;          /* size of the global crops fed to G */
+    int vit_h, vit_w;            /* after global_transform's Resize (== crop when it is the identity) */
+    int ent_h, ent_w;            /* entire structure image (0 = branch disabled) */
+    int ent_vit_h, ent_vit_w;    /* its size after Resize */
+    float lambda_global_cls, lambda_global_ssim, lambda_global_identity, lambda_entire_cls, lambda_entire_ssim;
+    int entire_every, cls_warmup;
+    float lr, beta1, beta2, eps;
+} splice_step_config;
+int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void* vit_ctx_entire,
+                       void* gen_plan_global, void* gen_plan_entire, void** out_handle);
+void splice_step_destroy(void* step);
+/* losses_out: device fp32[8] = {loss, loss_global_ssim, loss_entire_ssim, loss_entire_cls,
+ * loss_global_cls, loss_global_id_B, 0, 0} -- the keys of the dict LossG.forward returns. */
+int splice_step_run(void* step, float* params, float* grads, float* m, float* v, const float* A_crop,
+                    const float* B_crop, const float* A_entire, int step_idx, float* losses_out,
+                    splice_stream_t stream);
+int splice_step_output(void* step, int which, float** out_ptr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,17 @@ class GemmEpilogue(C.Structure):
     ]
 
 
+class StepConfig(C.Structure):
+    _fields_ = [
+        ("crop_h", C.c_int), ("crop_w", C.c_int), ("vit_h", C.c_int), ("vit_w", C.c_int),
+        ("ent_h", C.c_int), ("ent_w", C.c_int), ("ent_vit_h", C.c_int), ("ent_vit_w", C.c_int),
+        ("lambda_global_cls", C.c_float), ("lambda_global_ssim", C.c_float), ("lambda_global_identity", C.c_float),
+        ("lambda_entire_cls", C.c_float), ("lambda_entire_ssim", C.c_float),
+        ("entire_every", C.c_int), ("cls_warmup", C.c_int),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+    ]
+
+
 EPI_BIAS, EPI_RESID, EPI_OUT_F32, EPI_OUT_BF, EPI_OUT_T = 1, 2, 4, 8, 16
 EPI_GELU, EPI_GELU_GRAD, EPI_COLS_F32, EPI_ALPHA = 32, 64, 128, 256
 
@@ -72,6 +83,13 @@ _SIGNATURES = {
     "splice_gen_forward": ([_vp, _vp, _vp, _vp, _vp], _i),
     "splice_gen_backward": ([_vp, _vp, _vp, _vp, _i, _vp], _i),
     "splice_adam_step": ([_vp, _vp, _vp, _vp, C.c_longlong, _f, _f, _f, _f, _i, _i, _vp], _i),
+    "splice_vit_ctx_dims": ([_vp] + [C.POINTER(_i)] * 7, _i),
+    "splice_gen_plan_dims": ([_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_longlong)], _i),
+    # fused step
+    "splice_step_create": ([C.POINTER(StepConfig), _vp, _vp, _vp, _vp, C.POINTER(_vp)], _i),
+    "splice_step_destroy": ([_vp], None),
+    "splice_step_run": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp], _i),
+    "splice_step_output": ([_vp, _i, C.POINTER(_vp)], _i),
 }
 
 

@@ -315,6 +315,16 @@ int splice_gen_plan_create(void* h, int N, int H, int W, int need_grad, void** o
     return SPLICE_OK;
 }
 
+int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams) {
+    SpliceGenPlan* p = (SpliceGenPlan*)plan;
+    if (!p) return SPLICE_ERR_ARG;
+    if (N) *N = p->N;
+    if (H) *H = p->H;
+    if (W) *W = p->W;
+    if (nparams) *nparams = (long long)p->gen->table.total;
+    return SPLICE_OK;
+}
+
 void splice_gen_plan_destroy(void* plan) {
     SpliceGenPlan* p = (SpliceGenPlan*)plan;
     if (!p) return;

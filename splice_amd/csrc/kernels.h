@@ -45,6 +45,10 @@ int cast_f32_bf16_launch(const float* x, bf16_t* y, size_t n, hipStream_t s);
 int cast_bf16_f32_launch(const bf16_t* x, float* y, size_t n, hipStream_t s);
 int transpose_f32_to_bf16_launch(const float* x, bf16_t* y, int rows, int cols, int ldy, hipStream_t s);  // y[c][r]
 int fill_f32_launch(float* x, float v, size_t n, hipStream_t s);
+// torchvision-0.10 tensor Resize = F.interpolate(bilinear, align_corners=False, no antialias) on [N][C][h][w]
+// (util/losses.py:20,77-78); backward is the exact adjoint in gather form (deterministic).
+int resize_bilinear_fwd_launch(const float* in, float* out, int planes, int h, int w, int oh, int ow, hipStream_t s);
+int resize_bilinear_bwd_launch(const float* dout, float* din, int planes, int h, int w, int oh, int ow, hipStream_t s);
 int add_f32_launch(float* y, const float* x, size_t n, hipStream_t s);  // y += x
 
 // ---- selfsim.hip -----------------------------------------------------------------------
@@ -68,3 +72,6 @@ int selfsim_bwd_launch(const float* dS, const float* S, int T, int D, float eps,
 // 2-D strided MSE: loss_accum[0] += weight * mean((a-b)^2); grad (optional) = weight * 2 (a-b) / (rows*cols)
 int mse_launch(const float* a, int lda, const float* b, int ldb, int rows, int cols, float weight, float* loss_accum,
                float* grad, int ldg, hipStream_t s);
+// same with separate scales: loss_accum[0] += loss_weight * mean(d^2); grad = grad_weight * 2 d / n
+int mse2_launch(const float* a, int lda, const float* b, int ldb, int rows, int cols, float loss_weight, float grad_weight,
+                float* loss_accum, float* grad, int ldg, hipStream_t s);

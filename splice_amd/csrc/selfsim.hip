@@ -132,7 +132,7 @@ int selfsim_bwd_launch(const float* dS, const float* S, int T, int D, float eps,
 
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int rows,
-                                                  int cols, float wmean, float* __restrict__ loss_accum, float* __restrict__ grad,
+                                                  int cols, float wmean, float gmean, float* __restrict__ loss_accum, float* __restrict__ grad,
                                                   int ldg) {
     const size_t n = (size_t)rows * cols;
     float acc = 0.f;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, i
         const int r = i / cols, c = i % cols;
         const float d = a[(size_t)r * lda + c] - b[(size_t)r * ldb + c];
         acc += d * d;
-        if (grad) grad[(size_t)r * ldg + c] = 2.0f * wmean * d;
+        if (grad) grad[(size_t)r * ldg + c] = 2.0f * gmean * d;
     }
     __shared__ float red[4];
     acc = wave_sum(acc);
@@ -149,12 +149,17 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, i
     if (threadIdx.x == 0) atomicAdd(loss_accum, (red[0] + red[1] + red[2] + red[3]) * wmean);
 }
 
-int mse_launch(const float* a, int lda, const float* b, int ldb, int rows, int cols, float weight, float* loss_accum,
-               float* grad, int ldg, hipStream_t s) {
+int mse2_launch(const float* a, int lda, const float* b, int ldb, int rows, int cols, float loss_weight, float grad_weight,
+                float* loss_accum, float* grad, int ldg, hipStream_t s) {
     const size_t n = (size_t)rows * cols;
     if (!n) return SPLICE_ERR_ARG;
     size_t g = (n + 255) / 256;
     if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(mse_kernel, dim3((unsigned)g), dim3(256), 0, s, a, lda, b, ldb, rows, cols, weight / (float)n, loss_accum, grad, ldg);
+    hipLaunchKernelGGL(mse_kernel, dim3((unsigned)g), dim3(256), 0, s, a, lda, b, ldb, rows, cols, loss_weight / (float)n,
+                       grad_weight / (float)n, loss_accum, grad, ldg);
     return SPLICE_OK;
+}
+int mse_launch(const float* a, int lda, const float* b, int ldb, int rows, int cols, float weight, float* loss_accum,
+               float* grad, int ldg, hipStream_t s) {
+    return mse2_launch(a, lda, b, ldb, rows, cols, weight, weight, loss_accum, grad, ldg, s);
 }

@@ -1,0 +1,275 @@
+// One Splice optimisation step (train.py:51-80) as a single host call: zero_grad, Model.forward
+// (models/model.py:12-25), LossG.forward with its lambda schedule (util/losses.py:34-72),
+// backward and Adam -- with the de-duplicated ViT plan of SURVEY.md section 7: the four global
+// passes [T(A_crop), T(B_crop), T(G(A_crop)), T(G(B_crop))] run as ONE batched forward (the
+// reference runs six batch-1 forwards, x' and B' twice), the backward covers only the two
+// generated images and only data gradients.  Nothing is cached across steps.
+#include <vector>
+
+#include "kernels.h"
+
+void splice_set_error(const char* fmt, ...);
+extern "C" {
+int splice_vit_ctx_info(void* ctx, int* T, int* Tld, int* rows);
+int splice_vit_ctx_dims(void* ctx, int* B, int* H, int* W, int* D, int* depth, int* heads, int* patch);
+int splice_vit_forward(void* ctx, const float* img, int normalize, splice_stream_t stream);
+int splice_vit_get_tensor(void* ctx, int kind, int layer, void** out);
+int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* const* d_block, const float* const* d_qkv,
+                        const float* const* d_keys, float* d_img, int normalize, splice_stream_t stream);
+int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams);
+int splice_gen_forward(void* plan, const float* params, const float* x, float* y, splice_stream_t stream);
+int splice_gen_backward(void* plan, const float* params, const float* dy, float* grads, int accumulate, splice_stream_t stream);
+int splice_adam_step(float* params, float* grads, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                     int step, int zero_grad, splice_stream_t stream);
+}
+
+#define RC(x)                                                                                     \
+    do {                                                                                          \
+        int rc_ = (x);                                                                            \
+        if (rc_ != SPLICE_OK) {                                                                   \
+            splice_set_error("%s:%d %s failed (%d)", __FILE__, __LINE__, #x, rc_);                \
+            return rc_;                                                                           \
+        }                                                                                         \
+    } while (0)
+#define HIPCHK(x)                                                                                 \
+    do {                                                                                          \
+        hipError_t e_ = (x);                                                                      \
+        if (e_ != hipSuccess) {                                                                   \
+            splice_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(e_));    \
+            return SPLICE_ERR_HIP;                                                                \
+        }                                                                                         \
+    } while (0)
+
+enum { L_TOTAL = 0, L_GLOBAL_SSIM = 1, L_ENTIRE_SSIM = 2, L_ENTIRE_CLS = 3, L_GLOBAL_CLS = 4, L_GLOBAL_ID = 5 };
+
+struct VitView {
+    void* ctx = nullptr;
+    int B = 0, H = 0, W = 0, D = 0, depth = 0, heads = 0, patch = 0, T = 0, Tld = 0, rows = 0;
+    float* d_block = nullptr;   // [rows][D]
+    float* d_keys = nullptr;    // [rows][D]
+    float* imgs = nullptr;      // [B][3][H][W]
+    float* d_imgs = nullptr;    // [B][3][H][W]
+    std::vector<const float*> pb, pk;   // per-layer pointer tables
+};
+
+struct SpliceStep {
+    splice_step_config cfg;
+    VitView vg, ve;
+    void *plan_g = nullptr, *plan_e = nullptr;
+    long long nparams = 0;
+    float* gen_in = nullptr;     // [2][3][s][s]   A_crop | B_crop
+    float* gen_out = nullptr;    // [2][3][s][s]   x_global | y_global
+    float* d_gen_out = nullptr;
+    float* ent_out = nullptr;    // [1][3][He][We]
+    float* d_ent_out = nullptr;
+    float *S = nullptr, *S_tgt = nullptr, *dS = nullptr;   // [Tmax][Tmax]
+    void* ssim_ws = nullptr;
+    float* losses = nullptr;     // [8] raw per-term losses of the current step
+    std::vector<void*> allocs;
+    int ssim_id_on = 0;          // lambda_global_ssim / lambda_global_identity switched on (util/losses.py:35-37)
+};
+
+template <class T>
+static int salloc(SpliceStep* st, T** p, size_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, n * sizeof(T) + 256) != hipSuccess) {
+        splice_set_error("splice_step: hipMalloc of %zu bytes failed", n * sizeof(T));
+        return SPLICE_ERR_NOMEM;
+    }
+    st->allocs.push_back(q);
+    *p = (T*)q;
+    return SPLICE_OK;
+}
+
+static int view_init(SpliceStep* st, VitView& v, void* ctx, int want_B) {
+    v.ctx = ctx;
+    RC(splice_vit_ctx_dims(ctx, &v.B, &v.H, &v.W, &v.D, &v.depth, &v.heads, &v.patch));
+    RC(splice_vit_ctx_info(ctx, &v.T, &v.Tld, &v.rows));
+    if (v.B != want_B) { splice_set_error("splice_step_create: ViT context has batch %d, need %d", v.B, want_B); return SPLICE_ERR_ARG; }
+    RC(salloc(st, &v.d_block, (size_t)v.rows * v.D));
+    RC(salloc(st, &v.d_keys, (size_t)v.rows * v.D));
+    RC(salloc(st, &v.imgs, (size_t)v.B * 3 * v.H * v.W));
+    RC(salloc(st, &v.d_imgs, (size_t)v.B * 3 * v.H * v.W));
+    v.pb.assign(v.depth, nullptr);
+    v.pk.assign(v.depth, nullptr);
+    v.pb[v.depth - 1] = v.d_block;
+    v.pk[v.depth - 1] = v.d_keys;
+    return SPLICE_OK;
+}
+
+// total = sum_k lambda_k * raw_k   (util/losses.py:53-71)
+__global__ void total_loss_kernel(float* l, float w_ssim, float w_essim, float w_ecls, float w_cls, float w_id) {
+    if (threadIdx.x == 0)
+        l[L_TOTAL] = w_ssim * l[L_GLOBAL_SSIM] + w_essim * l[L_ENTIRE_SSIM] + w_ecls * l[L_ENTIRE_CLS] + w_cls * l[L_GLOBAL_CLS] + w_id * l[L_GLOBAL_ID];
+}
+
+static int place_image(const float* src, int h, int w, float* dst, int oh, int ow, hipStream_t s) {
+    if (h == oh && w == ow) {   // Resize returns its input when the shorter edge already matches
+        HIPCHK(hipMemcpyAsync(dst, src, (size_t)3 * h * w * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return SPLICE_OK;
+    }
+    return resize_bilinear_fwd_launch(src, dst, 3, h, w, oh, ow, s);
+}
+static int unplace_grad(const float* dsrc, int oh, int ow, float* ddst, int h, int w, hipStream_t s) {
+    if (h == oh && w == ow) {
+        HIPCHK(hipMemcpyAsync(ddst, dsrc, (size_t)3 * h * w * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return SPLICE_OK;
+    }
+    return resize_bilinear_bwd_launch(dsrc, ddst, 3, h, w, oh, ow, s);
+}
+
+// keys of pass b (fp32 view into the last layer's raw qkv): pointer + leading dimension 3D
+static const float* keys_ptr(const VitView& v, const float* qkv_last, int pass) { return qkv_last + (size_t)pass * v.Tld * 3 * v.D + v.D; }
+
+// self-sim structure loss of `pass_x` against `pass_tgt` (util/losses.py:74-83): raw loss into slot, d_keys rows of pass_x
+static int ssim_term(SpliceStep* st, VitView& v, const float* qkv_last, int pass_tgt, int pass_x, float lambda, int slot, hipStream_t s) {
+    SelfSimWs ws;
+    selfsim_ws_carve(st->ssim_ws, v.T, v.D, &ws);
+    RC(selfsim_fwd_launch(keys_ptr(v, qkv_last, pass_tgt), 3 * v.D, v.T, v.D, 1e-8f, st->S_tgt, ws, s));
+    RC(selfsim_fwd_launch(keys_ptr(v, qkv_last, pass_x), 3 * v.D, v.T, v.D, 1e-8f, st->S, ws, s));
+    RC(mse2_launch(st->S, v.T, st->S_tgt, v.T, v.T, v.T, 1.0f, lambda, st->losses + slot, st->dS, v.T, s));
+    RC(selfsim_bwd_launch(st->dS, st->S, v.T, v.D, 1e-8f, v.d_keys + (size_t)pass_x * v.Tld * v.D, v.D, 0, ws, s));
+    return SPLICE_OK;
+}
+
+extern "C" {
+
+int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void* vit_ctx_entire, void* gen_plan_global,
+                       void* gen_plan_entire, void** out) {
+    if (!cfg || !vit_ctx_global || !gen_plan_global || !out) return SPLICE_ERR_ARG;
+    SpliceStep* st = new SpliceStep();
+    st->cfg = *cfg;
+    int rc = SPLICE_OK;
+    auto fail = [&](int code) { for (void* q : st->allocs) hipFree(q); delete st; return code; };
+    if ((rc = view_init(st, st->vg, vit_ctx_global, 4)) != SPLICE_OK) return fail(rc);
+    if (st->vg.H != cfg->vit_h || st->vg.W != cfg->vit_w) { splice_set_error("splice_step_create: global ViT context shape mismatch"); return fail(SPLICE_ERR_ARG); }
+    int n, h, w;
+    if ((rc = splice_gen_plan_dims(gen_plan_global, &n, &h, &w, &st->nparams)) != SPLICE_OK) return fail(rc);
+    if (n != 2 || h != cfg->crop_h || w != cfg->crop_w) { splice_set_error("splice_step_create: global generator plan must be N=2 at the crop size"); return fail(SPLICE_ERR_ARG); }
+    st->plan_g = gen_plan_global;
+    const size_t crop = (size_t)3 * cfg->crop_h * cfg->crop_w;
+    if ((rc = salloc(st, &st->gen_in, 2 * crop)) != SPLICE_OK) return fail(rc);
+    if ((rc = salloc(st, &st->gen_out, 2 * crop)) != SPLICE_OK) return fail(rc);
+    if ((rc = salloc(st, &st->d_gen_out, 2 * crop)) != SPLICE_OK) return fail(rc);
+    int Tmax = st->vg.T;
+    if (cfg->ent_h > 0) {
+        if (!vit_ctx_entire || !gen_plan_entire) { splice_set_error("splice_step_create: entire-image branch needs its ViT context and generator plan"); return fail(SPLICE_ERR_ARG); }
+        if ((rc = view_init(st, st->ve, vit_ctx_entire, 2)) != SPLICE_OK) return fail(rc);
+        if (st->ve.H != cfg->ent_vit_h || st->ve.W != cfg->ent_vit_w) { splice_set_error("splice_step_create: entire ViT context shape mismatch"); return fail(SPLICE_ERR_ARG); }
+        if ((rc = splice_gen_plan_dims(gen_plan_entire, &n, &h, &w, nullptr)) != SPLICE_OK) return fail(rc);
+        if (n != 1 || h != cfg->ent_h || w != cfg->ent_w) { splice_set_error("splice_step_create: entire generator plan must be N=1 at the entire-image size"); return fail(SPLICE_ERR_ARG); }
+        st->plan_e = gen_plan_entire;
+        const size_t ent = (size_t)3 * cfg->ent_h * cfg->ent_w;
+        if ((rc = salloc(st, &st->ent_out, ent)) != SPLICE_OK) return fail(rc);
+        if ((rc = salloc(st, &st->d_ent_out, ent)) != SPLICE_OK) return fail(rc);
+        if (st->ve.T > Tmax) Tmax = st->ve.T;
+    }
+    if ((rc = salloc(st, &st->S, (size_t)Tmax * Tmax)) != SPLICE_OK) return fail(rc);
+    if ((rc = salloc(st, &st->S_tgt, (size_t)Tmax * Tmax)) != SPLICE_OK) return fail(rc);
+    if ((rc = salloc(st, &st->dS, (size_t)Tmax * Tmax)) != SPLICE_OK) return fail(rc);
+    char* wsb = nullptr;
+    if ((rc = salloc(st, &wsb, selfsim_ws_bytes(Tmax, st->vg.D))) != SPLICE_OK) return fail(rc);
+    st->ssim_ws = wsb;
+    if ((rc = salloc(st, &st->losses, 8)) != SPLICE_OK) return fail(rc);
+    *out = st;
+    return SPLICE_OK;
+}
+
+void splice_step_destroy(void* h) {
+    SpliceStep* st = (SpliceStep*)h;
+    if (!st) return;
+    for (void* q : st->allocs) hipFree(q);
+    delete st;
+}
+
+// Pointers to the generator outputs of the last step (device, valid until the next run):
+// which 0: x_global|y_global [2][3][crop_h][crop_w], 1: x_entire [1][3][ent_h][ent_w]
+int splice_step_output(void* h, int which, float** out) {
+    SpliceStep* st = (SpliceStep*)h;
+    if (!st || !out) return SPLICE_ERR_ARG;
+    *out = which == 0 ? st->gen_out : st->ent_out;
+    return *out ? SPLICE_OK : SPLICE_ERR_STATE;
+}
+
+// One step.  step_idx is the reference's data step counter (0-based, data/Dataset.py:57,63).
+// params/grads/m/v: flat generator arenas.  losses_out: device fp32[8] =
+// {loss, loss_global_ssim, loss_entire_ssim, loss_entire_cls, loss_global_cls, loss_global_id_B, 0, 0}
+// (inactive terms are 0).  A_entire may be NULL on steps where step_idx % entire_every != 0.
+int splice_step_run(void* h, float* params, float* grads, float* m, float* v, const float* A_crop, const float* B_crop,
+                    const float* A_entire, int step_idx, float* losses_out, splice_stream_t stream) {
+    SpliceStep* st = (SpliceStep*)h;
+    if (!st || !params || !grads || !m || !v || !A_crop || !B_crop || step_idx < 0) return SPLICE_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const splice_step_config& c = st->cfg;
+    VitView& vg = st->vg;
+    // ---- lambda schedule (util/losses.py:34-44)
+    if (step_idx == c.cls_warmup) st->ssim_id_on = 1;
+    const bool entire = c.ent_h > 0 && c.entire_every > 0 && (step_idx % c.entire_every == 0);
+    if (entire && !A_entire) { splice_set_error("splice_step_run: step %d needs the entire structure image", step_idx); return SPLICE_ERR_ARG; }
+    const float l_ssim = st->ssim_id_on ? c.lambda_global_ssim : 0.f, l_id = st->ssim_id_on ? c.lambda_global_identity : 0.f;
+    const float l_cls = c.lambda_global_cls;
+    const float l_essim = entire ? c.lambda_entire_ssim : 0.f, l_ecls = entire ? c.lambda_entire_cls : 0.f;
+    const size_t crop = (size_t)3 * c.crop_h * c.crop_w, vimg = (size_t)3 * vg.H * vg.W;
+    // ---- Model.forward: x_global = G(A_crop), y_global = G(B_crop) [, x_entire = G(A)]
+    HIPCHK(hipMemcpyAsync(st->gen_in, A_crop, crop * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(st->gen_in + crop, B_crop, crop * sizeof(float), hipMemcpyDeviceToDevice, s));
+    RC(splice_gen_forward(st->plan_g, params, st->gen_in, st->gen_out, s));
+    // ---- global_transform (Resize -> Normalize; the Normalize is fused into the ViT patch gather)
+    RC(place_image(A_crop, c.crop_h, c.crop_w, vg.imgs + 0 * vimg, vg.H, vg.W, s));
+    RC(place_image(B_crop, c.crop_h, c.crop_w, vg.imgs + 1 * vimg, vg.H, vg.W, s));
+    RC(place_image(st->gen_out, c.crop_h, c.crop_w, vg.imgs + 2 * vimg, vg.H, vg.W, s));
+    RC(place_image(st->gen_out + crop, c.crop_h, c.crop_w, vg.imgs + 3 * vimg, vg.H, vg.W, s));
+    RC(splice_vit_forward(vg.ctx, vg.imgs, 1, s));
+    float *blk_g = nullptr, *qkv_g = nullptr;
+    RC(splice_vit_get_tensor(vg.ctx, 0, vg.depth - 1, (void**)&blk_g));
+    RC(splice_vit_get_tensor(vg.ctx, 3, vg.depth - 1, (void**)&qkv_g));
+    HIPCHK(hipMemsetAsync(st->losses, 0, 8 * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(vg.d_block, 0, (size_t)vg.rows * vg.D * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(vg.d_keys, 0, (size_t)vg.rows * vg.D * sizeof(float), s));
+    const size_t passD = (size_t)vg.Tld * vg.D;
+    // ---- losses on the global batch: passes 0 A', 1 B', 2 x', 3 y'
+    if (l_ssim > 0.f) RC(ssim_term(st, vg, qkv_g, 0, 2, l_ssim, L_GLOBAL_SSIM, s));
+    if (l_cls > 0.f)   // [CLS] of block 11, before the final LayerNorm (util/losses.py:90-93)
+        RC(mse2_launch(blk_g + 2 * passD, vg.D, blk_g + 1 * passD, vg.D, 1, vg.D, 1.0f, l_cls, st->losses + L_GLOBAL_CLS, vg.d_block + 2 * passD, vg.D, s));
+    if (l_id > 0.f)    // keys of y' against keys of B' (util/losses.py:96-105): mean over h*T*d = T*D
+        RC(mse2_launch(keys_ptr(vg, qkv_g, 3), 3 * vg.D, keys_ptr(vg, qkv_g, 1), 3 * vg.D, vg.T, vg.D, 1.0f, l_id, st->losses + L_GLOBAL_ID,
+                       vg.d_keys + 3 * passD, vg.D, s));
+    // ---- entire-image branch (every entire_every-th step)
+    if (entire) {
+        VitView& ve = st->ve;
+        const size_t eimg = (size_t)3 * ve.H * ve.W;
+        RC(splice_gen_forward(st->plan_e, params, A_entire, st->ent_out, s));
+        RC(place_image(A_entire, c.ent_h, c.ent_w, ve.imgs, ve.H, ve.W, s));
+        RC(place_image(st->ent_out, c.ent_h, c.ent_w, ve.imgs + eimg, ve.H, ve.W, s));
+        RC(splice_vit_forward(ve.ctx, ve.imgs, 1, s));
+        float *blk_e = nullptr, *qkv_e = nullptr;
+        RC(splice_vit_get_tensor(ve.ctx, 0, ve.depth - 1, (void**)&blk_e));
+        RC(splice_vit_get_tensor(ve.ctx, 3, ve.depth - 1, (void**)&qkv_e));
+        HIPCHK(hipMemsetAsync(ve.d_block, 0, (size_t)ve.rows * ve.D * sizeof(float), s));
+        HIPCHK(hipMemsetAsync(ve.d_keys, 0, (size_t)ve.rows * ve.D * sizeof(float), s));
+        const size_t epassD = (size_t)ve.Tld * ve.D;
+        if (l_essim > 0.f) RC(ssim_term(st, ve, qkv_e, 0, 1, l_essim, L_ENTIRE_SSIM, s));
+        if (l_ecls > 0.f)   // target is the B_global crop's CLS (util/losses.py:60)
+            RC(mse2_launch(blk_e + 1 * epassD, ve.D, blk_g + 1 * passD, vg.D, 1, ve.D, 1.0f, l_ecls, st->losses + L_ENTIRE_CLS, ve.d_block + 1 * epassD, ve.D, s));
+    }
+    // ---- backward (train.py:78): ViT dgrad for the generated images only, then the generator
+    RC(splice_vit_backward(vg.ctx, 2, 4, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
+    RC(unplace_grad(vg.d_imgs + 2 * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, s));
+    RC(unplace_grad(vg.d_imgs + 3 * vimg, vg.H, vg.W, st->d_gen_out + crop, c.crop_h, c.crop_w, s));
+    RC(splice_gen_backward(st->plan_g, params, st->d_gen_out, grads, 0, s));
+    if (entire) {
+        VitView& ve = st->ve;
+        const size_t eimg = (size_t)3 * ve.H * ve.W;
+        RC(splice_vit_backward(ve.ctx, 1, 2, ve.pb.data(), nullptr, ve.pk.data(), ve.d_imgs, 1, s));
+        RC(unplace_grad(ve.d_imgs + eimg, ve.H, ve.W, st->d_ent_out, c.ent_h, c.ent_w, s));
+        RC(splice_gen_backward(st->plan_e, params, st->d_ent_out, grads, 1, s));
+    }
+    hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(64), 0, s, st->losses, l_ssim, l_essim, l_ecls, l_cls, l_id);
+    if (losses_out) HIPCHK(hipMemcpyAsync(losses_out, st->losses, 8 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // ---- optimizer.step() (train.py:79); Adam's own step counter starts at 1
+    RC(splice_adam_step(params, grads, m, v, st->nparams, c.lr, c.beta1, c.beta2, c.eps, step_idx + 1, 0, s));
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { splice_set_error("splice_step_run: %s", hipGetErrorString(e)); return SPLICE_ERR_HIP; }
+    return SPLICE_OK;
+}
+}

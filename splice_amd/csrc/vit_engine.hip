@@ -292,6 +292,19 @@ int splice_vit_ctx_info(void* ctx, int* T, int* Tld, int* rows) {
     return SPLICE_OK;
 }
 
+int splice_vit_ctx_dims(void* ctx, int* B, int* H, int* W, int* D, int* depth, int* heads, int* patch) {
+    SpliceVitCtx* c = (SpliceVitCtx*)ctx;
+    if (!c) return SPLICE_ERR_ARG;
+    if (B) *B = c->B;
+    if (H) *H = c->H;
+    if (W) *W = c->W;
+    if (D) *D = c->vit->dim;
+    if (depth) *depth = c->vit->depth;
+    if (heads) *heads = c->vit->heads;
+    if (patch) *patch = c->vit->patch;
+    return SPLICE_OK;
+}
+
 // Forward over the ctx's batch.  img: fp32 [B][3][H][W]; normalize != 0 applies the ImageNet
 // Normalize of util/losses.py:19 on the fly (input in [0,1]); == 0 expects a normalised image
 // (what VitExtractor receives, models/extractor.py:81).

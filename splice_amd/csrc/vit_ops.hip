@@ -225,3 +225,78 @@ int transpose_f32_to_bf16_launch(const float* x, bf16_t* y, int rows, int cols, 
     hipLaunchKernelGGL(transpose_f32_to_bf16_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, s, x, y, rows, cols, ldy);
     return SPLICE_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// K1: bilinear resize (align_corners=False, no antialias) and its adjoint.
+__device__ __forceinline__ void rs_coord(int o, float scale, int n, int& i0, int& i1, float& lam) {
+    float src = ((float)o + 0.5f) * scale - 0.5f;   // scale = in / out
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i0 = i0 < n - 1 ? i0 : n - 1;
+    i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+    lam = src - (float)i0;
+    lam = lam > 1.f ? 1.f : lam;
+}
+__global__ void resize_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int h, int w, int oh, int ow,
+                                  float sy, float sx) {
+    const size_t n = (size_t)planes * oh * ow;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int ox = i % ow, oy = (i / ow) % oh;
+        const size_t pl = i / ((size_t)ow * oh);
+        const float* p = in + pl * h * w;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        rs_coord(oy, sy, h, y0, y1, ly);
+        rs_coord(ox, sx, w, x0, x1, lx);
+        const float top = p[y0 * w + x0] * (1.f - lx) + p[y0 * w + x1] * lx;
+        const float bot = p[y1 * w + x0] * (1.f - lx) + p[y1 * w + x1] * lx;
+        out[i] = top * (1.f - ly) + bot * ly;
+    }
+}
+// gather adjoint: input pixel m receives from the output pixels whose (i0, i1) include m
+__global__ void resize_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int planes, int h, int w, int oh, int ow,
+                                  float sy, float sx) {
+    const size_t n = (size_t)planes * h * w;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int mx = i % w, my = (i / w) % h;
+        const size_t pl = i / ((size_t)w * h);
+        const float* p = dout + pl * oh * ow;
+        // candidate output range: src(o) in (m-1, m+1)  ->  o in ((m-1+0.5)/s - 0.5, (m+1+0.5)/s - 0.5)
+        int oy_lo = (int)floorf(((float)my - 0.5f) / sy - 0.5f) - 1, oy_hi = (int)ceilf(((float)my + 1.5f) / sy - 0.5f) + 1;
+        int ox_lo = (int)floorf(((float)mx - 0.5f) / sx - 0.5f) - 1, ox_hi = (int)ceilf(((float)mx + 1.5f) / sx - 0.5f) + 1;
+        oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+        oy_hi = oy_hi > oh - 1 ? oh - 1 : oy_hi; ox_hi = ox_hi > ow - 1 ? ow - 1 : ox_hi;
+        if (my == 0) oy_lo = 0;           // clamped sources (src < 0) all land on row/col 0
+        if (mx == 0) ox_lo = 0;
+        float acc = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int a0, a1; float l;
+            rs_coord(oy, sy, h, a0, a1, l);
+            float wy = 0.f;
+            if (a0 == my) wy += 1.f - l;
+            if (a1 == my) wy += l;
+            if (wy == 0.f) continue;
+            float row = 0.f;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int b0, b1; float lx;
+                rs_coord(ox, sx, w, b0, b1, lx);
+                float wx = 0.f;
+                if (b0 == mx) wx += 1.f - lx;
+                if (b1 == mx) wx += lx;
+                if (wx != 0.f) row += wx * p[oy * ow + ox];
+            }
+            acc += wy * row;
+        }
+        din[i] = acc;
+    }
+}
+int resize_bilinear_fwd_launch(const float* in, float* out, int planes, int h, int w, int oh, int ow, hipStream_t s) {
+    const size_t n = (size_t)planes * oh * ow;
+    hipLaunchKernelGGL(resize_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, planes, h, w, oh, ow, (float)h / (float)oh, (float)w / (float)ow);
+    return SPLICE_OK;
+}
+int resize_bilinear_bwd_launch(const float* dout, float* din, int planes, int h, int w, int oh, int ow, hipStream_t s) {
+    const size_t n = (size_t)planes * h * w;
+    hipLaunchKernelGGL(resize_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, dout, din, planes, h, w, oh, ow, (float)h / (float)oh, (float)w / (float)ow);
+    return SPLICE_OK;
+}

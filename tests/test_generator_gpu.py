@@ -61,7 +61,6 @@ def test_generator_batch_vs_fp64_oracle_and_accumulate(N, h, w):
     """N side-by-side calls == N independent oracle calls (per-call BN statistics); parameter
     gradients sum over calls; accumulate adds.  Gradients vs the fp64 oracle (see module docstring)."""
     from oracle import generator as ogen
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
     eng = GeneratorEngine()
     raw = synth.generator_params(5, 0.02, perturb_bias=0.03)
     params = eng.flatten(raw)

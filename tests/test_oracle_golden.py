@@ -10,7 +10,6 @@ from oracle import dino_vit, extractor as oex, generator as ogen, losses as olos
 from oracle.step import SpliceOracle
 from splice_amd import synth
 
-torch.set_num_threads(8)
 
 
 def _load(golden_dir, name):

@@ -1,0 +1,131 @@
+"""GPU parity of the fused optimisation step (C ABI splice_step_*) against the loss trajectories
+recorded from the REFERENCE loop (Model + LossG + Adam, oracle/make_golden.py) and the fp32 oracle.
+
+Tolerances (bf16 ViT, fp32 generator/losses/Adam): every entry of the loss dict within 3e-2
+relative at steps 0-2 (identical parameters on both sides up to one or two updates).  After that
+the trajectory is CHAOTIC in the optimiser itself: Adam with beta1=0 takes ~lr-sized steps along
+sign(g), so any gradient perturbation re-routes it.  Measured with the fp32 CPU oracle (DESIGN.md
+"trajectory sensitivity"): 2 % multiplicative gradient noise moves the loss at step 72 of this very
+fixture from 99.8 to 58..84, i.e. pointwise agreement beyond ~10 steps is not a property the
+reference itself has.  So: 6-step window means within 25 % up to step 30, and the optimisation must
+end at least as low as 1.25x the reference's level.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from splice_amd import synth
+from splice_amd.engine import LOSS_KEYS, SpliceEngine
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _engine(cfg_over, A, B, gen_seed, img_size):
+    cfg = dict(dino_model_name="dino_vits8", dino_global_patch_size=img_size, **cfg_over)
+    vit_state = synth.vit_params(7, "dino_vits8", img_size=img_size, w_std=0.05)
+    gen_state = synth.generator_params(gen_seed, 0.02)
+    return SpliceEngine(cfg, vit_state, gen_state, A.shape[-2:], A.shape[-2:])
+
+
+def _run(eng, A, B, n):
+    rows = []
+    A, B = torch.from_numpy(A).to(DEV), torch.from_numpy(B).to(DEV)
+    for _ in range(n):
+        eng.step(A, B, A)
+        rows.append(eng.losses())
+    return rows
+
+
+def _check(rows, gl, keys, lo, hi, rtol):
+    worst = 0.0
+    for i in range(lo, hi):
+        for j, k in enumerate(keys):
+            if np.isnan(gl[i, j]):
+                assert k not in rows[i], (i, k)
+            else:
+                rel = abs(rows[i][k] - gl[i, j]) / abs(gl[i, j])
+                worst = max(worst, rel)
+                assert rel < rtol, (i, k, rows[i][k], gl[i, j])
+    print(f"    steps {lo}..{hi - 1}: worst rel loss deviation {worst:.3e}")
+
+
+def test_trajectory_a_identity_resize(golden_dir):
+    g = np.load(os.path.join(golden_dir, "steps.npz"))
+    keys = [str(k) for k in g["loss_keys"]]
+    assert keys == LOSS_KEYS
+    A, B = synth.smooth_image_pair(32, 0, 64, 64)
+    eng = _engine({}, A, B, 31, 64)
+    rows = _run(eng, A, B, 78)
+    _check(rows, g["a/losses"], keys, 0, 3, 3e-2)
+    mine = np.array([r["loss"] for r in rows])
+    ref = g["a/losses"][:, 0]
+    for lo in range(1, 31, 6):     # window means (step 0 excluded: 3x larger, checked exactly above)
+        a, b = mine[lo:lo + 6].mean(), ref[lo:lo + 6].mean()
+        print(f"    steps {lo}..{lo + 5}: mean loss {a:.1f} vs reference {b:.1f}")
+        assert abs(a - b) / b < 0.25, (lo, a, b)
+    tail_mine, tail_ref = np.sort(mine[60:75])[:5].mean(), np.sort(ref[60:75])[:5].mean()
+    print(f"    level reached (steps 60..74): {tail_mine:.1f} vs reference {tail_ref:.1f}")
+    assert tail_mine < 1.25 * tail_ref
+    assert np.isfinite(mine).all()
+    out = eng.generate(torch.from_numpy(A)[None].to(DEV)).cpu().numpy()
+    refimg = g["a/final_out"]
+    mse = float(((out - refimg) ** 2).mean())
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-12))
+    print(f"    final image PSNR(HIP engine vs reference CPU fp32) after 78 steps: {psnr:.1f} dB (reported, chaotic)")
+    assert out.shape == refimg.shape and np.isfinite(out).all() and 0.0 <= out.min() and out.max() <= 1.0
+
+
+def test_trajectory_b_resize_nonsquare(golden_dir):
+    """48x80 pair: Resize 48->64 (non-identity, differentiable) and an 8x13 token grid (interpolated
+    position embedding)."""
+    g = np.load(os.path.join(golden_dir, "steps.npz"))
+    keys = [str(k) for k in g["loss_keys"]]
+    A, B = synth.smooth_image_pair(34, 1, 48, 80)
+    eng = _engine({}, A, B, 33, 64)
+    assert eng.vit_hw == (64, 106)
+    rows = _run(eng, A, B, 4)
+    _check(rows, g["b/losses"], keys, 0, 2, 3e-2)
+    _check(rows, g["b/losses"], keys, 2, 4, 2.5e-1)
+
+
+def test_step_gradients_vs_oracle_teacher_forced():
+    """Steps 0..4 (all lambda regimes: step 0 = entire + cls, steps >= 1 = ssim + cls + id) with the
+    engine's parameters re-synchronised to the oracle's before every step, so both sides evaluate
+    the SAME point: every loss entry within 3e-2 and the whole generator gradient within 5e-2
+    (relative L2, bf16 ViT) of the fp32 oracle's autograd through the reference-shaped graph
+    (6 ViT forwards / 3 backwards per step).  Without the re-sync the first Adam steps (lr 2e-3 on
+    weights initialised at ~1e-3) already make the two parameter sets differ in a few % of the
+    signs, and gradients at those two points are no longer comparable (cos ~0.3, measured)."""
+    from oracle import dino_vit
+    from oracle.step import SpliceOracle
+    A, B = synth.smooth_image_pair(40, 2, 64, 64)
+    cfg = dict(dino_model_name="dino_vits8", dino_global_patch_size=64)
+    vit_state = synth.vit_params(7, "dino_vits8", img_size=64, w_std=0.05)
+    gen_state = synth.generator_params(41, 0.02)
+    eng = SpliceEngine(cfg, vit_state, gen_state, (64, 64), (64, 64))
+    m = dino_vit.VisionTransformer(8, 384, 12, 6, img_size=64).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in vit_state.items()})
+    orc = SpliceOracle(m, {k: torch.from_numpy(v) for k, v in gen_state.items()}, cfg)
+    At, Bt = torch.from_numpy(A), torch.from_numpy(B)
+    Ad, Bd = At.to(DEV), Bt.to(DEV)
+    for step in range(5):
+        eng.params.copy_(eng.gen.flatten({k: v.detach() for k, v in orc.params.items()}))
+        lo, _, og = orc.step(At[None], Bt[None], At[None])
+        eng.step(Ad, Bd, Ad)
+        le = eng.losses()
+        assert set(le) == set(lo), (le.keys(), lo.keys())
+        for k in lo:
+            assert abs(le[k] - lo[k]) / abs(lo[k]) < 3e-2, (step, k, le[k], lo[k])
+        got = eng.gen.unflatten(eng.grads)
+        num = den = 0.0
+        for (name, gt), go in zip(got.items(), og):
+            if name.endswith("0.bias") and name != "9.0.bias":
+                continue  # zero-gradient conv biases (feed a BatchNorm)
+            d = (gt.cpu().double() - go.reshape(-1).double()).norm().item()
+            num, den = num + d * d, den + go.double().norm().item() ** 2
+        rel = (num / den) ** 0.5
+        print(f"    step {step}: loss {le['loss']:.3f} vs {lo['loss']:.3f}; generator-gradient rel err vs oracle {rel:.3e}")
+        assert rel < 5e-2, rel

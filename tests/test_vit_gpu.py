@@ -150,7 +150,6 @@ def test_keys_only_injection():
 def test_vitb8_224_full_size():
     """BASELINE config shape (ViT-B/8, 224x224, T=785): forward features and image gradient vs the
     fp32 oracle run on the host cores."""
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
     name = "dino_vitb8"
     model, sd = _oracle_vit(name, 224, seed=1, w_std=0.02)
     eng = VitEngine(name).load_state_dict(sd)
