@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Benchmark of the Splice per-pair optimisation step on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload): BASELINE.json configs[1] -- one 224x224 structure/appearance pair,
+DINO ViT-B/8 (T = 785 tokens), bf16 ViT / fp32 generator, reference hyper-parameters
+(conf/default/config.yaml), entire-image branch every 75th step, synthetic U[0,1) images and
+seeded synthetic weights (no network for checkpoints).  One "step" = zero_grad, Model.forward,
+LossG.forward, backward, Adam (train.py:56-80), nothing cached between steps.  Each rank
+optimises its OWN pair on its own GPU (independent units, no data-path collective): weak scaling;
+value = total steps of all ranks / max-over-ranks time.
+
+Printed JSON (one line, rank 0) additionally carries
+  roofline     : the dominant kernel (fc1 bf16 MFMA GEMM of the batched ViT forward): algorithmic
+                 FLOPs per launch / live HIP-event duration of its launches inside the timed region
+  cpu_baseline : the fp32 CPU oracle (a port of the reference-shaped loop: 6 ViT forwards + 3
+                 backwards per step) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def host_threads():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(cfg, hw, seed, budget_s=25.0):
+    """Reference-shaped fp32 loop (oracle/step.py) on the host cores; bounded sample."""
+    import torch
+    from oracle import dino_vit
+    from oracle.step import SpliceOracle
+    from splice_amd import synth
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    name = cfg["dino_model_name"]
+    patch, dim, depth, heads = dino_vit.DINO_CONFIGS[name]
+    m = dino_vit.VisionTransformer(patch, dim, depth, heads, img_size=cfg["dino_global_patch_size"]).eval()
+    sd = synth.vit_params(seed, name, img_size=cfg["dino_global_patch_size"])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    orc = SpliceOracle(m, {k: torch.from_numpy(v) for k, v in synth.generator_params(seed + 1, 0.02).items()}, cfg)
+    A, B = synth.image_pair(seed, 0, hw[0], hw[1])
+    A, B = torch.from_numpy(A)[None], torch.from_numpy(B)[None]
+    orc.step(A, B, A)          # step 0 (entire branch, cls only): warm-up, untimed
+    n, t0 = 0, time.time()
+    while True:
+        orc.step(A, B, A)      # ordinary steps (ssim + cls + id)
+        n += 1
+        el = time.time() - t0
+        if el > budget_s or n >= 8:
+            break
+    return {"value": n / el, "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"{n} ordinary steps (after 1 warm-up step) of the same 224x224 ViT-B/8 pair, fp32, "
+                      f"reference-shaped 6-forward/3-backward loop, torch {torch.__version__} CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, default=224, help="pair height = width (configs[1]: 224)")
+    ap.add_argument("--model", default="dino_vitb8")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-kernel", type=int, default=1, help="1 fc1 GEMM, 2 qkv GEMM, 3 attention fwd, 0 off")
+    args = ap.parse_args()
+
+    import torch
+    from splice_amd import _lib
+    from splice_amd.engine import synthetic_engine
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(dev))   # RCCL; used for barrier + max only
+
+    cfg = dict(dino_model_name=args.model, dino_global_patch_size=args.size)
+    hw = (args.size, args.size)
+    eng, A, B = synthetic_engine(cfg, pair_id=rank, hw=hw, seed=1234, device=dev)
+    K, W = args.steps, args.warmup
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(W):
+        eng.step(A, B, A)
+    barrier()
+    if args.prof_kernel:
+        _lib.check(_lib.lib().splice_prof_begin(args.prof_kernel))
+    t0 = time.perf_counter()
+    for _ in range(K):
+        eng.step(A, B, A)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof_ms, prof_n = C.c_float(0), C.c_int(0)
+    if args.prof_kernel:
+        _lib.check(_lib.lib().splice_prof_end(C.byref(prof_ms), C.byref(prof_n)))
+    losses = eng.losses()
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    T = eng.ctx_g.T
+    D, hidden = eng.vit.dim, 4 * eng.vit.dim
+    n_entire = sum(1 for s in range(W, W + K) if s % eng.cfg["entire_A_every"] == 0)
+    roof = None
+    if args.prof_kernel and prof_n.value:
+        # algorithmic FLOPs of ONE launch of the timed kernel on the global batch (4 passes x T tokens)
+        shapes = {1: ("gemm_nt_kernel<128,128,BIAS|GELU|OUT_BF> (fc1 fwd)", 2.0 * 4 * T * hidden * D),
+                  2: ("gemm_nt_kernel<128,128,BIAS|OUT_BF|OUT_T> (qkv fwd)", 2.0 * 4 * T * 3 * D * D),
+                  3: ("attn_fwd_kernel<2>", 4.0 * 4 * T * T * D)}
+        kname, flops = shapes[args.prof_kernel]
+        avg_ms = prof_ms.value / prof_n.value
+        ach = flops / (avg_ms * 1e-3) / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(str(args.prof_kernel))
+            except Exception:
+                traffic = None
+        roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": round(ach / 2500.0, 4), "traffic": traffic, "avg_launch_us": round(avg_ms * 1e3, 2),
+                "launches": prof_n.value,
+                "note": "algorithmic FLOPs of one launch on the 4x785-token batch / mean HIP-event duration of the launches "
+                        "in the timed region (includes the 12 smaller launches of each entire-image step)"}
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            cpu = cpu_baseline(dict(eng.cfg), hw, 1234)
+        except Exception as e:  # the baseline must never take the product number down
+            cpu = {"value": None, "unit": "steps/s", "cores": host_threads(), "kind": "port", "sample": f"failed: {e}"}
+    steps_total = K * world
+    value = steps_total / elapsed
+    out = {
+        "metric": "opt_steps_per_sec", "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"Splice pair {hw[0]}x{hw[1]}, {args.model} (T={T}), 1 pair per GPU, "
+                               f"{n_entire} of {K} timed steps include the entire-image branch",
+                   "pairs": world, "pairs_per_hour_at_2000_steps": round(value * 3600 / 2000, 2),
+                   "generator_dtype": "f32", "last_loss": round(losses["loss"], 5)},
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

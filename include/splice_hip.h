@@ -173,6 +173,10 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
 int splice_adam_step(float* params, float* grads, float* m, float* v, long long n, float lr, float beta1,
                      float beta2, float eps, int step, int zero_grad, splice_stream_t stream);
 
+/* live HIP-event timing of one kernel family on its launch stream (bench.py roofline leg):
+ * which 1 = fc1 GEMM fwd, 2 = qkv GEMM fwd (layers 0..depth-2), 3 = attention fwd */
+int splice_prof_begin(int which);
+int splice_prof_end(float* total_ms, int* launches);
 int splice_vit_ctx_dims(void* ctx, int* B, int* H, int* W, int* D, int* depth, int* heads, int* patch);
 int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams);
 

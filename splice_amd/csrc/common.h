@@ -7,6 +7,7 @@
 typedef uint16_t bf16_t;  // raw bf16 storage
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 
@@ -44,6 +45,9 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 //   B: lane l holds B[k = (l>>4)*8 .. +7][n = l&15]
 //   C/D: lane l, reg r holds C[row = (l>>4)*4 + r][col = l&15]
 __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 

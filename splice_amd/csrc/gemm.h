@@ -53,39 +53,40 @@ struct GemmTile {
             bg[i] = B + (size_t)gr * ldb + kc * 8;
             bs_off[i] = row * GEMM_BK + ((kc ^ (row & 7)) << 3);
         }
-        uint4 ar[A_LOADS], br[B_LOADS];
+        u32x4 ar[A_LOADS], br[B_LOADS];   // native vectors: HIP's uint4 (a union struct) defeats SROA here -> scratch
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) ar[i] = *reinterpret_cast<const uint4*>(ag[i]);
+        for (int i = 0; i < A_LOADS; ++i) ar[i] = *reinterpret_cast<const u32x4*>(ag[i]);
 #pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) br[i] = *reinterpret_cast<const uint4*>(bg[i]);
+        for (int i = 0; i < B_LOADS; ++i) br[i] = *reinterpret_cast<const u32x4*>(bg[i]);
 
         const int frow = lane & 15, fchunk = lane >> 4;
         for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
             __syncthreads();  // previous slice fully consumed
 #pragma unroll
-            for (int i = 0; i < A_LOADS; ++i) *reinterpret_cast<uint4*>(As + as_off[i]) = ar[i];
+            for (int i = 0; i < A_LOADS; ++i) *reinterpret_cast<u32x4*>(As + as_off[i]) = ar[i];
 #pragma unroll
-            for (int i = 0; i < B_LOADS; ++i) *reinterpret_cast<uint4*>(Bs + bs_off[i]) = br[i];
+            for (int i = 0; i < B_LOADS; ++i) *reinterpret_cast<u32x4*>(Bs + bs_off[i]) = br[i];
             __syncthreads();
-            if (k0 + GEMM_BK < K) {
+            // unconditional prefetch (the last iteration re-reads its own slice): a branch here makes
+            // hipcc park ar/br in scratch and wait for every load at once
+            const int kn = (k0 + GEMM_BK < K) ? k0 + GEMM_BK : k0;
 #pragma unroll
-                for (int i = 0; i < A_LOADS; ++i) ar[i] = *reinterpret_cast<const uint4*>(ag[i] + k0 + GEMM_BK);
+            for (int i = 0; i < A_LOADS; ++i) ar[i] = *reinterpret_cast<const u32x4*>(ag[i] + kn);
 #pragma unroll
-                for (int i = 0; i < B_LOADS; ++i) br[i] = *reinterpret_cast<const uint4*>(bg[i] + k0 + GEMM_BK);
-            }
+            for (int i = 0; i < B_LOADS; ++i) br[i] = *reinterpret_cast<const u32x4*>(bg[i] + kn);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                uint4 af[FM], bf[FN];
+                u32x4 af[FM], bf[FN];
                 const int chunk = kk * 4 + fchunk;
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const int row = wm * (BM / 2) + i * 16 + frow;
-                    af[i] = *reinterpret_cast<const uint4*>(As + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
+                    af[i] = *reinterpret_cast<const u32x4*>(As + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
                 }
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
                     const int row = wn * (BN / 2) + j * 16 + frow;
-                    bf[j] = *reinterpret_cast<const uint4*>(Bs + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
+                    bf[j] = *reinterpret_cast<const u32x4*>(Bs + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
                 }
 #pragma unroll
                 for (int i = 0; i < FM; ++i)

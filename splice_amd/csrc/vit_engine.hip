@@ -33,6 +33,31 @@ void splice_set_error(const char* fmt, ...);
         }                                                                                         \
     } while (0)
 
+// ---- optional live timing of ONE kernel family with HIP events on the launch stream (bench.py's
+// roofline leg).  which: 1 = fc1 GEMM (forward), 2 = qkv GEMM (forward), 3 = attention forward.
+struct ProfState {
+    int which = 0;
+    std::vector<hipEvent_t> ev;   // start/stop pairs
+    size_t used = 0;
+};
+static ProfState g_prof;
+struct ProfScope {
+    bool on;
+    hipStream_t s;
+    ProfScope(int which, hipStream_t st) : on(g_prof.which == which), s(st) {
+        if (!on) return;
+        if (g_prof.used + 2 > g_prof.ev.size()) {
+            for (int i = 0; i < 256; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } g_prof.ev.push_back(e); }
+        }
+        (void)hipEventRecord(g_prof.ev[g_prof.used], s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s);
+        g_prof.used += 2;
+    }
+};
+
 struct Linear {
     bf16_t* w = nullptr;    // [out][in]
     bf16_t* wT = nullptr;   // [in][out]
@@ -292,6 +317,29 @@ int splice_vit_ctx_info(void* ctx, int* T, int* Tld, int* rows) {
     return SPLICE_OK;
 }
 
+// Live kernel timing for the roofline report: begin(which) arms HIP-event pairs around every launch
+// of the chosen kernel family on its own stream; end() synchronises those events and returns the
+// summed duration and the launch count.
+int splice_prof_begin(int which) {
+    g_prof.which = which;
+    g_prof.used = 0;
+    return SPLICE_OK;
+}
+int splice_prof_end(float* total_ms, int* launches) {
+    float tot = 0.f;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) return SPLICE_ERR_HIP;
+        if (hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) != hipSuccess) return SPLICE_ERR_HIP;
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int)(g_prof.used / 2);
+    g_prof.which = 0;
+    g_prof.used = 0;
+    return SPLICE_OK;
+}
+
 int splice_vit_ctx_dims(void* ctx, int* B, int* H, int* W, int* D, int* depth, int* heads, int* patch) {
     SpliceVitCtx* c = (SpliceVitCtx*)ctx;
     if (!c) return SPLICE_ERR_ARG;
@@ -328,12 +376,14 @@ int splice_vit_forward(void* ctx, const float* img, int normalize, splice_stream
             e.bias = W.qkv.b; e.out_bf = c->qkv[l]; e.ldbf = 3 * D; e.out_bf_t = c->qkvT[l]; e.ldt = rows;
             unsigned fl = EPI_BIAS | EPI_OUT_BF | EPI_OUT_T;
             if (l == L - 1) { fl |= EPI_COLS_F32; e.out_f32_cols = c->qkv_last_f32; e.ld_cols = 3 * D; e.col_lo = 0; e.col_hi = 3 * D; }
+            ProfScope ps(l == L - 1 ? 0 : 2, s);
             RC(gemm_nt_launch(fl, c->ln_out, D, W.qkv.w, D, rows, 3 * D, D, e, s));
         }
         {
             AttnArgs a = {};
             a.qkv = c->qkv[l]; a.qkvT = c->qkvT[l]; a.ldt = rows; a.B = c->B; a.T = c->T; a.Tld = c->Tld; a.D = D; a.H = v->heads;
             a.scale = 0.125f; a.out = c->attn_out[l]; a.lse = c->lse[l];
+            ProfScope ps(3, s);
             RC(attn_fwd_launch(&a, s));
         }
         {
@@ -345,6 +395,7 @@ int splice_vit_forward(void* ctx, const float* img, int normalize, splice_stream
         {
             GemmEpi e = {};
             e.bias = W.fc1.b; e.out_bf = c->hact; e.ldbf = Hd; e.out_pre = c->hpre[l]; e.ldp = Hd;
+            ProfScope ps(1, s);
             RC(gemm_nt_launch(EPI_BIAS | EPI_GELU | EPI_OUT_BF, c->ln_out, D, W.fc1.w, D, rows, Hd, D, e, s));
         }
         {
