@@ -84,7 +84,7 @@ def main():
     from splice_amd import _lib
     from splice_amd.engine import synthetic_engine
 
-    rank = int(os.environ.get("RANK", "0"))
+    from splice_amd.dist import Replicas, aggregate_throughput
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
@@ -93,20 +93,17 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(dev))   # RCCL; used for barrier + max only
+    rep = Replicas(backend="nccl", device=dev)   # RCCL; used for the barrier + max-over-ranks only
+    rank = rep.rank
 
     cfg = dict(dino_model_name=args.model, dino_global_patch_size=args.size)
     hw = (args.size, args.size)
-    eng, A, B = synthetic_engine(cfg, pair_id=rank, hw=hw, seed=1234, device=dev)
+    eng, A, B = synthetic_engine(cfg, pair_id=rep.pair_id(), hw=hw, seed=1234, device=dev)
     K, W = args.steps, args.warmup
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        rep.barrier()
         torch.cuda.synchronize()
 
     for _ in range(W):
@@ -123,13 +120,9 @@ def main():
     if args.prof_kernel:
         _lib.check(_lib.lib().splice_prof_end(C.byref(prof_ms), C.byref(prof_n)))
     losses = eng.losses()
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed = rep.max_over_ranks(elapsed)
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        rep.close()
         return
 
     T = eng.ctx_g.T
@@ -162,8 +155,7 @@ def main():
             cpu = cpu_baseline(dict(eng.cfg), hw, 1234)
         except Exception as e:  # the baseline must never take the product number down
             cpu = {"value": None, "unit": "steps/s", "cores": host_threads(), "kind": "port", "sample": f"failed: {e}"}
-    steps_total = K * world
-    value = steps_total / elapsed
+    value = aggregate_throughput(K, world, elapsed)
     out = {
         "metric": "opt_steps_per_sec", "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -175,8 +167,7 @@ def main():
         "roofline": roof, "cpu_baseline": cpu,
     }
     print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    rep.close()
 
 
 if __name__ == "__main__":

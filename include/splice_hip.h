@@ -118,6 +118,10 @@ int splice_unpatchify(const float* dpatches, float* dimg, int B, int H, int W, i
 int splice_cast_f32_bf16(const float* x, splice_bf16* y, size_t n, splice_stream_t stream);
 int splice_cast_bf16_f32(const splice_bf16* x, float* y, size_t n, splice_stream_t stream);
 int splice_transpose_f32_bf16(const float* x, splice_bf16* y, int rows, int cols, int ldy, splice_stream_t stream);
+/* transforms.Resize on tensors (util/losses.py:20; torchvision 0.10: bilinear, align_corners=False,
+ * no antialias) on `planes` images [h][w] -> [oh][ow], and its exact adjoint (deterministic gather). */
+int splice_resize_bilinear_fwd(const float* in, float* out, int planes, int h, int w, int oh, int ow, splice_stream_t stream);
+int splice_resize_bilinear_bwd(const float* dout, float* din, int planes, int h, int w, int oh, int ow, splice_stream_t stream);
 
 /* ------------------------------------------------------------------ ViT engine (handle level)
  * Replaces VitExtractor.__init__ + the hooked self.model(img) forwards of
@@ -179,6 +183,9 @@ int splice_prof_begin(int which);
 int splice_prof_end(float* total_ms, int* launches);
 int splice_vit_ctx_dims(void* ctx, int* B, int* H, int* W, int* D, int* depth, int* heads, int* patch);
 int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams);
+/* re-target a plan to a smaller input without reallocating (per-step random crop sizes,
+ * data/transforms.py:21-22) */
+int splice_gen_plan_resize(void* plan, int H, int W);
 
 /* ------------------------------------------------------------------ fused optimisation step
  * train.py:51-80 for one image pair: Model.forward (models/model.py:12-25), LossG.forward incl.
@@ -203,6 +210,12 @@ int splice_step_run(void* step, float* params, float* grads, float* m, float* v,
                     const float* B_crop, const float* A_entire, int step_idx, float* losses_out,
                     splice_stream_t stream);
 int splice_step_output(void* step, int which, float** out_ptr);
+/* per-step crop sizes (<= creation size).  Equal A/B sizes run the N=2 plan; different sizes
+ * (the reference draws them independently, data/Dataset.py:66-67) run two N=1 plans that must
+ * have been attached once with splice_step_attach_split_plans. */
+int splice_step_set_crop(void* step, int crop_h, int crop_w);
+int splice_step_attach_split_plans(void* step, void* gen_plan_a, void* gen_plan_b);
+int splice_step_set_crops(void* step, int a_h, int a_w, int b_h, int b_w);
 
 #ifdef __cplusplus
 }

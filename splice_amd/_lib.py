@@ -60,6 +60,8 @@ _SIGNATURES = {
     "splice_cast_f32_bf16": ([_vp, _vp, _sz, _vp], _i),
     "splice_cast_bf16_f32": ([_vp, _vp, _sz, _vp], _i),
     "splice_transpose_f32_bf16": ([_vp, _vp, _i, _i, _i, _vp], _i),
+    "splice_resize_bilinear_fwd": ([_vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
+    "splice_resize_bilinear_bwd": ([_vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     # ViT engine
     "splice_vit_create": ([_i, _i, _i, _i, C.POINTER(_vp)], _i),
     "splice_vit_destroy": ([_vp], None),
@@ -92,6 +94,10 @@ _SIGNATURES = {
     "splice_step_destroy": ([_vp], None),
     "splice_step_run": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp], _i),
     "splice_step_output": ([_vp, _i, C.POINTER(_vp)], _i),
+    "splice_step_set_crop": ([_vp, _i, _i], _i),
+    "splice_step_attach_split_plans": ([_vp, _vp, _vp], _i),
+    "splice_step_set_crops": ([_vp, _i, _i, _i, _i], _i),
+    "splice_gen_plan_resize": ([_vp, _i, _i], _i),
 }
 
 

@@ -102,6 +102,12 @@ int splice_cast_f32_bf16(const float* x, splice_bf16* y, size_t n, splice_stream
 int splice_cast_bf16_f32(const splice_bf16* x, float* y, size_t n, splice_stream_t stream) {
     return finish(cast_bf16_f32_launch(x, y, n, ST(stream)), "splice_cast_bf16_f32");
 }
+int splice_resize_bilinear_fwd(const float* in, float* out, int planes, int h, int w, int oh, int ow, splice_stream_t stream) {
+    return finish(resize_bilinear_fwd_launch(in, out, planes, h, w, oh, ow, ST(stream)), "splice_resize_bilinear_fwd");
+}
+int splice_resize_bilinear_bwd(const float* dout, float* din, int planes, int h, int w, int oh, int ow, splice_stream_t stream) {
+    return finish(resize_bilinear_bwd_launch(dout, din, planes, h, w, oh, ow, ST(stream)), "splice_resize_bilinear_bwd");
+}
 int splice_transpose_f32_bf16(const float* x, splice_bf16* y, int rows, int cols, int ldy, splice_stream_t stream) {
     return finish(transpose_f32_to_bf16_launch(x, y, rows, cols, ldy, ST(stream)), "splice_transpose_f32_bf16");
 }

@@ -56,6 +56,7 @@ struct Unit {
     float* dy = nullptr;                            // grad w.r.t. y (same shape/stride as y)
     float* d_in = nullptr; size_t d_in_ns = 0;      // grad w.r.t. `in` (null: not needed)
     int d_in_accumulate = 0;
+    bool own_out = false;
 };
 
 struct SpliceGen {
@@ -64,7 +65,7 @@ struct SpliceGen {
 
 struct SpliceGenPlan {
     SpliceGen* gen = nullptr;
-    int N = 0, H = 0, W = 0, need_grad = 0;
+    int N = 0, H = 0, W = 0, need_grad = 0, maxH = 0, maxW = 0;
     int h[6], w[6];                       // spatial size at scale i (h[0] = H)
     std::vector<void*> allocs;
     // per scale
@@ -125,26 +126,64 @@ static int palloc(SpliceGenPlan* p, T** ptr, size_t n) {
     return SPLICE_OK;
 }
 
+// allocate a unit's tensors for the plan's MAXIMUM size (dims currently set on the unit)
 static int unit_alloc(SpliceGenPlan* p, Unit& u, bool own_out) {
     const size_t N = p->N;
-    if (u.ks) {
-        RC(palloc(p, &u.y, N * u.Cout * u.Ho * u.Wo));
-        u.y_ns = (size_t)u.Cout * u.Ho * u.Wo;
-    }
+    const size_t plane = (size_t)u.Cout * u.Ho * u.Wo;
+    if (u.ks) RC(palloc(p, &u.y, N * plane));
     RC(palloc(p, &u.mean, N * u.Cout)); RC(palloc(p, &u.rstd, N * u.Cout));
     RC(palloc(p, &u.s1, N * u.Cout)); RC(palloc(p, &u.s2, N * u.Cout));
-    if (own_out) {
-        RC(palloc(p, &u.out, N * u.Cout * u.Ho * u.Wo));
-        u.out_ns = (size_t)u.Cout * u.Ho * u.Wo;
-    }
+    if (own_out) RC(palloc(p, &u.out, N * plane));
     if (p->need_grad) {
-        RC(palloc(p, &u.dy, N * u.Cout * u.Ho * u.Wo));
-        if (own_out) {
-            RC(palloc(p, &u.d_out, N * u.Cout * u.Ho * u.Wo));
-            u.d_out_ns = u.out_ns;
+        RC(palloc(p, &u.dy, N * plane));
+        if (own_out) RC(palloc(p, &u.d_out, N * plane));
+    }
+    u.own_out = own_out;
+    return SPLICE_OK;
+}
+
+// (re)derive every size-dependent field for an H x W input (<= the size the plan was created for);
+// buffers are laid out compactly inside their maximum-size allocations.
+static void plan_configure(SpliceGenPlan* p, int H, int W) {
+    p->H = H; p->W = W;
+    p->h[0] = H; p->w[0] = W;
+    for (int i = 1; i <= 5; ++i) { p->h[i] = (p->h[i - 1] + 1) / 2; p->w[i] = (p->w[i - 1] + 1) / 2; }
+    const bool ng = p->need_grad;
+    for (int i = 0; i < 5; ++i) {
+        const int cin = i == 0 ? 3 : DOWN[i - 1];
+        const int hi = p->h[i], wi = p->w[i], hd = p->h[i + 1], wd = p->w[i + 1];
+        const size_t catC = SKIPC + p->kch[i];
+        const size_t cat_ns = catC * hi * wi;
+        Unit &sk = p->u_skip[i], &da = p->u_da[i], &db = p->u_db[i], &ct = p->u_cat[i], &u3 = p->u_up3[i], &u1 = p->u_up1[i];
+        auto dims = [](Unit& u, int Hi, int Wi, int Ho, int Wo) {
+            u.Hi = Hi; u.Wi = Wi; u.Ho = Ho; u.Wo = Wo;
+            u.y_ns = (size_t)u.Cout * Ho * Wo;
+            if (u.own_out) { u.out_ns = u.y_ns; u.d_out_ns = u.y_ns; }
+        };
+        dims(sk, hi, wi, hi, wi); dims(da, hi, wi, hd, wd); dims(db, hd, wd, hd, wd);
+        dims(ct, hi, wi, hi, wi); dims(u3, hi, wi, hi, wi); dims(u1, hi, wi, hi, wi);
+        sk.out = p->cat[i]; sk.out_ns = cat_ns;
+        if (ng) { sk.d_out = p->d_cat[i]; sk.d_out_ns = cat_ns; }
+        ct.in = p->cat[i]; ct.in_ns = cat_ns;
+        if (ng) { ct.d_in = p->d_cat[i]; ct.d_in_ns = cat_ns; }
+        da.in_ns = (size_t)cin * hi * wi; sk.in_ns = da.in_ns;
+        db.in = da.out; db.in_ns = da.out_ns;
+        u3.in = ct.out; u3.in_ns = ct.out_ns;
+        u1.in = u3.out; u1.in_ns = u3.out_ns;
+        if (ng) {
+            db.d_in = da.d_out; db.d_in_ns = da.d_out_ns;
+            u3.d_in = ct.d_out; u3.d_in_ns = ct.d_out_ns;
+            u1.d_in = u3.d_out; u1.d_in_ns = u3.d_out_ns;
         }
     }
-    return SPLICE_OK;
+    for (int i = 1; i < 5; ++i) {   // x_{i+1} = db_i.out ; d x_{i+1} = db_i.d_out
+        p->u_skip[i].in = p->u_db[i - 1].out; p->u_da[i].in = p->u_db[i - 1].out;
+        if (ng) {
+            p->u_da[i].d_in = p->u_db[i - 1].d_out; p->u_da[i].d_in_ns = p->u_db[i - 1].d_out_ns; p->u_da[i].d_in_accumulate = 0;  // first writer
+            p->u_skip[i].d_in = p->u_db[i - 1].d_out; p->u_skip[i].d_in_ns = p->u_db[i - 1].d_out_ns; p->u_skip[i].d_in_accumulate = 1;
+        }
+    }
+    p->forward_saved = 0;
 }
 
 static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* params, hipStream_t s) {
@@ -199,9 +238,9 @@ static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* par
 
 static size_t wgrad_ws_need(const SpliceGenPlan* p, const Unit& u) {
     if (!u.ks) return 0;
-    int ppc, cpi;
-    const int chunks = wgrad_chunks(p->N, u.Ho, u.Wo, &ppc, &cpi);
-    return (size_t)chunks * u.Cout * u.Cin * u.ks * u.ks;
+    // upper bound over every size <= the plan maximum (the pixels-per-chunk choice is not monotone in size)
+    const size_t chunks = (size_t)p->N * ((u.Ho * u.Wo + 63) / 64);
+    return chunks * u.Cout * u.Cin * u.ks * u.ks;
 }
 
 extern "C" {
@@ -235,7 +274,7 @@ int splice_gen_plan_create(void* h, int N, int H, int W, int need_grad, void** o
         return SPLICE_ERR_ARG;
     }
     SpliceGenPlan* p = new SpliceGenPlan();
-    p->gen = g; p->N = N; p->H = H; p->W = W; p->need_grad = need_grad;
+    p->gen = g; p->N = N; p->H = H; p->W = W; p->maxH = H; p->maxW = W; p->need_grad = need_grad;
     p->h[0] = H; p->w[0] = W;
     for (int i = 1; i <= 5; ++i) { p->h[i] = (p->h[i - 1] + 1) / 2; p->w[i] = (p->w[i - 1] + 1) / 2; }
     size_t offs[5 * 6 * 4], head[4];
@@ -253,56 +292,25 @@ int splice_gen_plan_create(void* h, int N, int H, int W, int need_grad, void** o
         const size_t catC = SKIPC + k;
         if ((rc = palloc(p, &p->cat[i], (size_t)N * catC * hi * wi)) != SPLICE_OK) break;
         if (need_grad && (rc = palloc(p, &p->d_cat[i], (size_t)N * catC * hi * wi)) != SPLICE_OK) break;
-        const size_t cat_ns = catC * hi * wi;
         size_t* o = offs + (size_t)i * 6 * 4;
         auto setp = [&](Unit& u, int idx) { u.w_off = o[idx * 4 + 0]; u.b_off = o[idx * 4 + 1]; u.g_off = o[idx * 4 + 2]; u.be_off = o[idx * 4 + 3]; };
-        Unit& sk = p->u_skip[i];
-        sk.ks = 1; sk.stride = 1; sk.Cin = cin; sk.Cout = SKIPC; sk.Hi = hi; sk.Wi = wi; sk.Ho = hi; sk.Wo = wi; setp(sk, 0);
-        if ((rc = unit_alloc(p, sk, false)) != SPLICE_OK) break;
-        sk.out = p->cat[i]; sk.out_ns = cat_ns;
-        if (need_grad) { sk.d_out = p->d_cat[i]; sk.d_out_ns = cat_ns; }
-        Unit& da = p->u_da[i];
-        da.ks = 3; da.stride = 2; da.Cin = cin; da.Cout = DOWN[i]; da.Hi = hi; da.Wi = wi; da.Ho = hd; da.Wo = wd; setp(da, 1);
-        if ((rc = unit_alloc(p, da, true)) != SPLICE_OK) break;
-        Unit& db = p->u_db[i];
-        db.ks = 3; db.stride = 1; db.Cin = DOWN[i]; db.Cout = DOWN[i]; db.Hi = hd; db.Wi = wd; db.Ho = hd; db.Wo = wd; setp(db, 2);
-        if ((rc = unit_alloc(p, db, true)) != SPLICE_OK) break;
-        Unit& ct = p->u_cat[i];
-        ct.ks = 0; ct.Cin = (int)catC; ct.Cout = (int)catC; ct.Hi = hi; ct.Wi = wi; ct.Ho = hi; ct.Wo = wi; ct.slope = 1.0f; setp(ct, 3);
-        if ((rc = unit_alloc(p, ct, true)) != SPLICE_OK) break;
-        ct.in = p->cat[i]; ct.in_ns = cat_ns;
-        if (need_grad) { ct.d_in = p->d_cat[i]; ct.d_in_ns = cat_ns; }
-        Unit& u3 = p->u_up3[i];
-        u3.ks = 3; u3.stride = 1; u3.Cin = (int)catC; u3.Cout = UP[i]; u3.Hi = hi; u3.Wi = wi; u3.Ho = hi; u3.Wo = wi; setp(u3, 4);
-        if ((rc = unit_alloc(p, u3, true)) != SPLICE_OK) break;
-        Unit& u1 = p->u_up1[i];
-        u1.ks = 1; u1.stride = 1; u1.Cin = UP[i]; u1.Cout = UP[i]; u1.Hi = hi; u1.Wi = wi; u1.Ho = hi; u1.Wo = wi; setp(u1, 5);
-        if ((rc = unit_alloc(p, u1, true)) != SPLICE_OK) break;
-        // wiring (inputs / gradient sinks)
-        da.in_ns = (size_t)cin * hi * wi; sk.in_ns = da.in_ns;     // .in set at run time for scale 0 (the image)
-        db.in = da.out; db.in_ns = da.out_ns;
-        u3.in = ct.out; u3.in_ns = ct.out_ns;
-        u1.in = u3.out; u1.in_ns = u3.out_ns;
-        if (need_grad) {
-            db.d_in = da.d_out; db.d_in_ns = da.d_out_ns;
-            u3.d_in = ct.d_out; u3.d_in_ns = ct.d_out_ns;
-            u1.d_in = u3.d_out; u1.d_in_ns = u3.d_out_ns;
-        }
-        for (Unit* u : {&sk, &da, &db, &u3, &u1}) { const size_t n = wgrad_ws_need(p, *u); if (n > ws_need) ws_need = n; }
+        auto mk = [&](Unit& u, int idx, int ks, int stride, int ci, int co, int Hi, int Wi, int Ho, int Wo, bool own) {
+            u.ks = ks; u.stride = stride; u.Cin = ci; u.Cout = co; u.Hi = Hi; u.Wi = Wi; u.Ho = Ho; u.Wo = Wo;
+            setp(u, idx);
+            return unit_alloc(p, u, own);
+        };
+        if ((rc = mk(p->u_skip[i], 0, 1, 1, cin, SKIPC, hi, wi, hi, wi, false)) != SPLICE_OK) break;
+        if ((rc = mk(p->u_da[i], 1, 3, 2, cin, DOWN[i], hi, wi, hd, wd, true)) != SPLICE_OK) break;
+        if ((rc = mk(p->u_db[i], 2, 3, 1, DOWN[i], DOWN[i], hd, wd, hd, wd, true)) != SPLICE_OK) break;
+        p->u_cat[i].slope = 1.0f;
+        if ((rc = mk(p->u_cat[i], 3, 0, 1, (int)catC, (int)catC, hi, wi, hi, wi, true)) != SPLICE_OK) break;
+        if ((rc = mk(p->u_up3[i], 4, 3, 1, (int)catC, UP[i], hi, wi, hi, wi, true)) != SPLICE_OK) break;
+        if ((rc = mk(p->u_up1[i], 5, 1, 1, UP[i], UP[i], hi, wi, hi, wi, true)) != SPLICE_OK) break;
+        for (Unit* u : {&p->u_skip[i], &p->u_da[i], &p->u_db[i], &p->u_up3[i], &p->u_up1[i]}) { const size_t n = wgrad_ws_need(p, *u); if (n > ws_need) ws_need = n; }
     }
     if (rc != SPLICE_OK) return fail();
-    // link scales: x_{i+1} = db_i.out ; d x_{i+1} = db_i.d_out
-    for (int i = 1; i < 5; ++i) {
-        p->u_skip[i].in = p->u_db[i - 1].out; p->u_da[i].in = p->u_db[i - 1].out;
-        if (need_grad) {
-            p->u_da[i].d_in = p->u_db[i - 1].d_out; p->u_da[i].d_in_ns = p->u_db[i - 1].d_out_ns; p->u_da[i].d_in_accumulate = 0;  // first writer
-            p->u_skip[i].d_in = p->u_db[i - 1].d_out; p->u_skip[i].d_in_ns = p->u_db[i - 1].d_out_ns; p->u_skip[i].d_in_accumulate = 1;
-        }
-    }
-    { const size_t n = (size_t)N * 3 * UP[0] * 16; if (n > ws_need) ws_need = n; }
     {
-        int ppc, cpi;
-        const size_t n = (size_t)wgrad_chunks(N, H, W, &ppc, &cpi) * 3 * UP[0];
+        const size_t n = (size_t)N * ((H * W + 63) / 64) * 3 * UP[0];
         if (n > ws_need) ws_need = n;
     }
     if ((rc = palloc(p, &p->x_copy, (size_t)N * 3 * H * W)) != SPLICE_OK) return fail();
@@ -311,7 +319,20 @@ int splice_gen_plan_create(void* h, int N, int H, int W, int need_grad, void** o
         if ((rc = palloc(p, &p->d_head_pre, (size_t)N * 3 * H * W)) != SPLICE_OK) return fail();
         if ((rc = palloc(p, &p->out_copy, (size_t)N * 3 * H * W)) != SPLICE_OK) return fail();
     }
+    plan_configure(p, H, W);
     *out = p;
+    return SPLICE_OK;
+}
+
+// Re-target a plan to a smaller input (H, W <= the creation size) without reallocating: the data
+// feed draws a different crop size every step (data/transforms.py:21-22).
+int splice_gen_plan_resize(void* plan, int H, int W) {
+    SpliceGenPlan* p = (SpliceGenPlan*)plan;
+    if (!p || H < 33 || W < 33 || H > p->maxH || W > p->maxW) {
+        splice_set_error("splice_gen_plan_resize: %dx%d outside [33, plan maximum]", H, W);
+        return SPLICE_ERR_ARG;
+    }
+    if (H != p->H || W != p->W) plan_configure(p, H, W);
     return SPLICE_OK;
 }
 

@@ -17,6 +17,7 @@ int splice_vit_get_tensor(void* ctx, int kind, int layer, void** out);
 int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* const* d_block, const float* const* d_qkv,
                         const float* const* d_keys, float* d_img, int normalize, splice_stream_t stream);
 int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams);
+int splice_gen_plan_resize(void* plan, int H, int W);
 int splice_gen_forward(void* plan, const float* params, const float* x, float* y, splice_stream_t stream);
 int splice_gen_backward(void* plan, const float* params, const float* dy, float* grads, int accumulate, splice_stream_t stream);
 int splice_adam_step(float* params, float* grads, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
@@ -56,6 +57,8 @@ struct SpliceStep {
     splice_step_config cfg;
     VitView vg, ve;
     void *plan_g = nullptr, *plan_e = nullptr;
+    void *plan_a = nullptr, *plan_b = nullptr;   // N=1 plans used when the A and B crops differ in size
+    int cropb_h = 0, cropb_w = 0, max_cropb_h = 0, max_cropb_w = 0;
     long long nparams = 0;
     float* gen_in = nullptr;     // [2][3][s][s]   A_crop | B_crop
     float* gen_out = nullptr;    // [2][3][s][s]   x_global | y_global
@@ -66,6 +69,7 @@ struct SpliceStep {
     void* ssim_ws = nullptr;
     float* losses = nullptr;     // [8] raw per-term losses of the current step
     std::vector<void*> allocs;
+    int max_crop_h = 0, max_crop_w = 0;
     int ssim_id_on = 0;          // lambda_global_ssim / lambda_global_identity switched on (util/losses.py:35-37)
 };
 
@@ -139,6 +143,8 @@ int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void
     if (!cfg || !vit_ctx_global || !gen_plan_global || !out) return SPLICE_ERR_ARG;
     SpliceStep* st = new SpliceStep();
     st->cfg = *cfg;
+    st->max_crop_h = cfg->crop_h; st->max_crop_w = cfg->crop_w;
+    st->cropb_h = st->max_cropb_h = cfg->crop_h; st->cropb_w = st->max_cropb_w = cfg->crop_w;
     int rc = SPLICE_OK;
     auto fail = [&](int code) { for (void* q : st->allocs) hipFree(q); delete st; return code; };
     if ((rc = view_init(st, st->vg, vit_ctx_global, 4)) != SPLICE_OK) return fail(rc);
@@ -191,6 +197,48 @@ int splice_step_output(void* h, int which, float** out) {
     return *out ? SPLICE_OK : SPLICE_ERR_STATE;
 }
 
+// Crop size of the NEXT steps (<= the size the step was created for): the reference's data feed
+// draws size ~ U(min_cover*h, h) per step (data/transforms.py:21-22); the ViT input size
+// (after Resize) is unchanged for square crops.
+int splice_step_set_crop(void* h, int crop_h, int crop_w) {
+    SpliceStep* st = (SpliceStep*)h;
+    if (!st) return SPLICE_ERR_ARG;
+    if (crop_h > st->max_crop_h || crop_w > st->max_crop_w) { splice_set_error("splice_step_set_crop: larger than the creation size"); return SPLICE_ERR_ARG; }
+    RC(splice_gen_plan_resize(st->plan_g, crop_h, crop_w));
+    st->cfg.crop_h = st->cropb_h = crop_h;
+    st->cfg.crop_w = st->cropb_w = crop_w;
+    return SPLICE_OK;
+}
+
+// Independent crop sizes for the structure and the appearance image (the reference draws them
+// separately, data/Dataset.py:66-67): needs the two N=1 plans given here (created for the maxima).
+int splice_step_attach_split_plans(void* h, void* plan_a, void* plan_b) {
+    SpliceStep* st = (SpliceStep*)h;
+    if (!st || !plan_a || !plan_b) return SPLICE_ERR_ARG;
+    int n, ha, wa, hb, wb;
+    RC(splice_gen_plan_dims(plan_a, &n, &ha, &wa, nullptr));
+    if (n != 1) return SPLICE_ERR_ARG;
+    RC(splice_gen_plan_dims(plan_b, &n, &hb, &wb, nullptr));
+    if (n != 1) return SPLICE_ERR_ARG;
+    if (ha > st->max_crop_h || wa > st->max_crop_w || hb > st->max_crop_h || wb > st->max_crop_w) {
+        splice_set_error("splice_step_attach_split_plans: plans larger than the step's buffers");
+        return SPLICE_ERR_ARG;
+    }
+    st->plan_a = plan_a; st->plan_b = plan_b;
+    return SPLICE_OK;
+}
+int splice_step_set_crops(void* h, int a_h, int a_w, int b_h, int b_w) {
+    SpliceStep* st = (SpliceStep*)h;
+    if (!st) return SPLICE_ERR_ARG;
+    if (a_h == b_h && a_w == b_w) return splice_step_set_crop(h, a_h, a_w);
+    if (!st->plan_a || !st->plan_b) { splice_set_error("splice_step_set_crops: different A/B crop sizes need splice_step_attach_split_plans"); return SPLICE_ERR_STATE; }
+    if (a_h > st->max_crop_h || a_w > st->max_crop_w || b_h > st->max_crop_h || b_w > st->max_crop_w) return SPLICE_ERR_ARG;
+    RC(splice_gen_plan_resize(st->plan_a, a_h, a_w));
+    RC(splice_gen_plan_resize(st->plan_b, b_h, b_w));
+    st->cfg.crop_h = a_h; st->cfg.crop_w = a_w; st->cropb_h = b_h; st->cropb_w = b_w;
+    return SPLICE_OK;
+}
+
 // One step.  step_idx is the reference's data step counter (0-based, data/Dataset.py:57,63).
 // params/grads/m/v: flat generator arenas.  losses_out: device fp32[8] =
 // {loss, loss_global_ssim, loss_entire_ssim, loss_entire_cls, loss_global_cls, loss_global_id_B, 0, 0}
@@ -210,15 +258,21 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
     const float l_cls = c.lambda_global_cls;
     const float l_essim = entire ? c.lambda_entire_ssim : 0.f, l_ecls = entire ? c.lambda_entire_cls : 0.f;
     const size_t crop = (size_t)3 * c.crop_h * c.crop_w, vimg = (size_t)3 * vg.H * vg.W;
+    const bool split = c.crop_h != st->cropb_h || c.crop_w != st->cropb_w;
     // ---- Model.forward: x_global = G(A_crop), y_global = G(B_crop) [, x_entire = G(A)]
-    HIPCHK(hipMemcpyAsync(st->gen_in, A_crop, crop * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(st->gen_in + crop, B_crop, crop * sizeof(float), hipMemcpyDeviceToDevice, s));
-    RC(splice_gen_forward(st->plan_g, params, st->gen_in, st->gen_out, s));
+    if (!split) {
+        HIPCHK(hipMemcpyAsync(st->gen_in, A_crop, crop * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(st->gen_in + crop, B_crop, crop * sizeof(float), hipMemcpyDeviceToDevice, s));
+        RC(splice_gen_forward(st->plan_g, params, st->gen_in, st->gen_out, s));
+    } else {
+        RC(splice_gen_forward(st->plan_a, params, A_crop, st->gen_out, s));
+        RC(splice_gen_forward(st->plan_b, params, B_crop, st->gen_out + crop, s));
+    }
     // ---- global_transform (Resize -> Normalize; the Normalize is fused into the ViT patch gather)
     RC(place_image(A_crop, c.crop_h, c.crop_w, vg.imgs + 0 * vimg, vg.H, vg.W, s));
-    RC(place_image(B_crop, c.crop_h, c.crop_w, vg.imgs + 1 * vimg, vg.H, vg.W, s));
+    RC(place_image(B_crop, st->cropb_h, st->cropb_w, vg.imgs + 1 * vimg, vg.H, vg.W, s));
     RC(place_image(st->gen_out, c.crop_h, c.crop_w, vg.imgs + 2 * vimg, vg.H, vg.W, s));
-    RC(place_image(st->gen_out + crop, c.crop_h, c.crop_w, vg.imgs + 3 * vimg, vg.H, vg.W, s));
+    RC(place_image(st->gen_out + crop, st->cropb_h, st->cropb_w, vg.imgs + 3 * vimg, vg.H, vg.W, s));
     RC(splice_vit_forward(vg.ctx, vg.imgs, 1, s));
     float *blk_g = nullptr, *qkv_g = nullptr;
     RC(splice_vit_get_tensor(vg.ctx, 0, vg.depth - 1, (void**)&blk_g));
@@ -255,8 +309,13 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
     // ---- backward (train.py:78): ViT dgrad for the generated images only, then the generator
     RC(splice_vit_backward(vg.ctx, 2, 4, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
     RC(unplace_grad(vg.d_imgs + 2 * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, s));
-    RC(unplace_grad(vg.d_imgs + 3 * vimg, vg.H, vg.W, st->d_gen_out + crop, c.crop_h, c.crop_w, s));
-    RC(splice_gen_backward(st->plan_g, params, st->d_gen_out, grads, 0, s));
+    RC(unplace_grad(vg.d_imgs + 3 * vimg, vg.H, vg.W, st->d_gen_out + crop, st->cropb_h, st->cropb_w, s));
+    if (!split) {
+        RC(splice_gen_backward(st->plan_g, params, st->d_gen_out, grads, 0, s));
+    } else {
+        RC(splice_gen_backward(st->plan_a, params, st->d_gen_out, grads, 0, s));
+        RC(splice_gen_backward(st->plan_b, params, st->d_gen_out + crop, grads, 1, s));
+    }
     if (entire) {
         VitView& ve = st->ve;
         const size_t eimg = (size_t)3 * ve.H * ve.W;

@@ -83,6 +83,8 @@ class SpliceEngine:
         self.handle = h
         self.losses_dev = torch.zeros(8, device=self.device)
         self.step_idx = -1  # data/Dataset.py:57 -- the first step is 0
+        self._cur_crops = (ch, cw, ch, cw)
+        self._split_plans = None
 
     def __del__(self):
         try:
@@ -98,7 +100,16 @@ class SpliceEngine:
         (see LOSS_KEYS); call ``losses()`` to sync and read them."""
         self.step_idx += 1
         for t in (A_crop, B_crop):
-            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == 3 * self.crop_hw[0] * self.crop_hw[1]
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        crops = tuple(A_crop.shape[-2:]) + tuple(B_crop.shape[-2:])
+        if crops != self._cur_crops:   # per-step random crop sizes (data/transforms.py:21-22)
+            if crops[:2] != crops[2:] and self._split_plans is None:
+                self._split_plans = (self.gen.plan(1, self.crop_hw[0], self.crop_hw[1], need_grad=True),
+                                     GeneratorPlanAlias(self.gen, self.crop_hw))
+                _lib.check(_lib.lib().splice_step_attach_split_plans(self.handle, self._split_plans[0].handle,
+                                                                      self._split_plans[1].handle), "step_attach_split_plans")
+            _lib.check(_lib.lib().splice_step_set_crops(self.handle, *crops), "step_set_crops")
+            self._cur_crops = crops
         if A_entire is not None:
             assert A_entire.is_cuda and A_entire.is_contiguous() and A_entire.numel() == 3 * self.entire_hw[0] * self.entire_hw[1]
         _lib.check(_lib.lib().splice_step_run(self.handle, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.m), _lib.ptr(self.v),
@@ -124,6 +135,12 @@ class SpliceEngine:
 
     def state_dict(self):
         return {k: v.clone() for k, v in self.gen.unflatten(self.params).items()}
+
+
+def GeneratorPlanAlias(gen, hw):
+    """A second, independent N=1 plan of the same maximum size (the plan cache is keyed by shape)."""
+    from .generator import GeneratorPlan
+    return GeneratorPlan(gen, 1, hw[0], hw[1], True)
 
 
 def synthetic_engine(cfg, pair_id=0, hw=(224, 224), seed=1234, device="cuda", vit_engine=None, entire=True):

@@ -1,0 +1,151 @@
+"""Drop-in for ``models/networks.py`` + ``models/unet/skip.py`` (``define_G``, ``init_weights``,
+``init_net``, ``skip``) on the HIP generator engine.
+
+``netG`` is an ``nn.Module`` whose 112 parameters carry the reference's ``state_dict`` names
+(``1.0.1.0.weight`` ... ``9.0.bias``, the numbering of ``models/unet/common.py:6-9``) and are
+VIEWS into one flat fp32 arena, so ``torch.optim`` / ``state_dict`` / ``load_state_dict`` work
+unchanged while the engine reads and writes the arena directly.  Only the reference's default
+architecture (``skip()`` with its default arguments, which is all ``define_G`` ever builds) is
+implemented; other ``skip(...)`` arguments raise NotImplementedError.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .generator import GeneratorEngine
+
+
+class _Node(nn.Module):
+    """Container mirroring one level of the reference's dotted module path."""
+
+
+class _GenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, net, need_grad, *params):
+        plan = net._acquire(x.shape[0], x.shape[2], x.shape[3], need_grad)
+        y = plan.forward(net.flat, x.contiguous().float())
+        ctx.net, ctx.plan, ctx.need_grad = net, plan, need_grad
+        if not need_grad:
+            net._release(plan)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        net, plan = ctx.net, ctx.plan
+        if not ctx.need_grad:
+            return (None, None, None) + (None,) * len(net._plist)
+        g = plan.backward(net.flat, dy.contiguous().float())
+        net._release(plan)
+        grads = tuple(g[off:off + n].view(p.shape) for (off, n), p in zip(net._slices, net._plist))
+        return (None, None, None) + grads
+
+
+class SkipGenerator(nn.Module):
+    """The reference generator (``skip()`` defaults) backed by ``splice_gen_*``."""
+
+    def __init__(self, device="cuda"):
+        super().__init__()
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("SkipGenerator (HIP engine) needs a GPU device; there is no CPU fallback")
+        self.engine = GeneratorEngine(device=dev)
+        from .synth import generator_param_specs
+        self.flat = torch.zeros(self.engine.numel, device=dev)
+        self._plist, self._slices, self._kinds = [], [], {}
+        for name, shape, kind in generator_param_specs():
+            off, n = self.engine.table[name]
+            p = nn.Parameter(self.flat[off:off + n].view(shape))
+            self._register(name, p)
+            self._plist.append(p)
+            self._slices.append((off, n))
+            self._kinds[name] = kind
+            if kind == "bn_w":   # BatchNorm buffers exist in the reference state_dict (never consumed: train mode)
+                base = name[:-len(".weight")]
+                self._register_buffer(base + ".running_mean", torch.zeros(shape, device=dev))
+                self._register_buffer(base + ".running_var", torch.ones(shape, device=dev))
+                self._register_buffer(base + ".num_batches_tracked", torch.zeros((), dtype=torch.long, device=dev))
+        self._free = {}
+
+    def _walk(self, dotted):
+        parts = dotted.split(".")
+        node = self
+        for part in parts[:-1]:
+            if part not in node._modules:
+                node.add_module(part, _Node())
+            node = node._modules[part]
+        return node, parts[-1]
+
+    def _register(self, dotted, param):
+        node, leaf = self._walk(dotted)
+        node.register_parameter(leaf, param)
+
+    def _register_buffer(self, dotted, buf):
+        node, leaf = self._walk(dotted)
+        node.register_buffer(leaf, buf)
+
+    def _acquire(self, N, H, W, need_grad):
+        pool = self._free.setdefault((N, H, W, need_grad), [])
+        if pool:
+            return pool.pop()
+        from .generator import GeneratorPlan
+        return GeneratorPlan(self.engine, N, H, W, need_grad)
+
+    def _release(self, plan):
+        self._free.setdefault((plan.N, plan.H, plan.W, bool(plan.need_grad)), []).append(plan)
+
+    def forward(self, x):
+        """x ``[N,3,H,W]`` in [0,1]; each image is an independent batch-1 call (per-image BN statistics),
+        exactly what the reference does by calling netG once per crop."""
+        if not x.is_cuda:
+            raise RuntimeError("SkipGenerator: input must be on the GPU")
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._plist)
+        return _GenFn.apply(x, self, need_grad, *self._plist)
+
+
+def skip(num_input_channels=3, num_output_channels=3, num_channels_down=[16, 32, 64, 128, 128],
+         num_channels_up=[16, 32, 64, 128, 128], num_channels_skip=[4, 4, 4, 4, 4], filter_size_down=3, filter_size_up=3,
+         filter_skip_size=1, need_sigmoid=True, need_tanh=False, need_bias=True, pad='zero', upsample_mode='bilinear',
+         downsample_mode='stride', act_fun='LeakyReLU', need1x1_up=True, device="cuda"):
+    """``models/unet/skip.py:4-11`` -- only the default arguments are supported by the HIP engine."""
+    default = (3, 3, [16, 32, 64, 128, 128], [16, 32, 64, 128, 128], [4, 4, 4, 4, 4], 3, 3, 1, True, False, True, 'zero',
+               'bilinear', 'stride', 'LeakyReLU', True)
+    given = (num_input_channels, num_output_channels, list(num_channels_down), list(num_channels_up), list(num_channels_skip),
+             filter_size_down, filter_size_up, filter_skip_size, need_sigmoid, need_tanh, need_bias, pad, upsample_mode,
+             downsample_mode, act_fun, need1x1_up)
+    if given != default:
+        raise NotImplementedError("the HIP generator engine implements skip() with the reference's default arguments only")
+    return SkipGenerator(device=device)
+
+
+def init_weights(net, init_type='normal', init_gain=0.02, debug=False):
+    """``models/networks.py:24-47``: conv weights by ``init_type``, conv bias 0, BN gamma ~ N(1, gain), beta 0."""
+    with torch.no_grad():
+        for (name, kind), p in zip(net._kinds.items(), net._plist):
+            if kind == "conv_w":
+                if init_type == 'normal':
+                    nn.init.normal_(p, 0.0, init_gain)
+                elif init_type == 'xavier':
+                    nn.init.xavier_normal_(p, gain=init_gain)
+                elif init_type == 'kaiming':
+                    nn.init.kaiming_normal_(p, a=0, mode='fan_in')
+                elif init_type == 'orthogonal':
+                    nn.init.orthogonal_(p, gain=init_gain)
+                else:
+                    raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
+            elif kind == "bn_w":
+                nn.init.normal_(p, 1.0, init_gain)
+            else:
+                nn.init.constant_(p, 0.0)
+
+
+def init_net(net, init_type='normal', init_gain=0.02, debug=False, initialize_weights=True):
+    if initialize_weights:
+        init_weights(net, init_type, init_gain=init_gain, debug=debug)
+    return net
+
+
+def define_G(init_type='normal', init_gain=0.02, initialize_weights=True, device="cuda"):
+    """``models/networks.py:56-58``."""
+    net = skip(device=device)
+    return init_net(net, init_type, init_gain, initialize_weights=initialize_weights)

@@ -1,0 +1,142 @@
+"""Drop-in for ``train.py``: ``train_model(dataroot, callback=None)``.
+
+Same contract as the reference (``train.py:15-80``): reads ``conf/default/config.yaml`` from the
+working directory (falling back to the packaged copy), seeds python / numpy / torch, opens the first
+image of ``<dataroot>/A`` and ``<dataroot>/B``, runs ``n_epochs`` optimisation steps and every
+``log_images_freq`` steps writes ``<dataroot>/out/output.png`` and calls ``callback(output[0])`` with
+the ``[3,H,W]`` float image.  The step itself is the fused HIP engine (``SpliceEngine``), one host
+call per step, losses read back only when a progress line is printed.
+
+Data feed: the reference augments PIL images on the CPU every step (``data/Dataset.py:62-70``).
+Here the images live on the GPU; per step a random square crop covering >= ``min_cover`` of the
+height (``data/transforms.py:19-27``) and the random horizontal flips of both pipelines are applied
+on device.  ColorJitter / GaussianBlur of the structure pipeline (``data/transforms.py:30-37``) are
+NOT implemented yet; ``use_augmentations: False`` is exact.
+"""
+import os
+import random
+from argparse import ArgumentParser
+
+import numpy as np
+import torch
+import yaml
+
+from .engine import SpliceEngine
+from .util import save_result
+
+device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+_PKG_CFG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conf", "default", "config.yaml")
+
+
+def _load_image(path, resize):
+    from PIL import Image
+    img = Image.open(path).convert('RGB')
+    if resize and resize > 0:   # transforms.Resize(int) on a PIL image: shorter edge -> resize, bilinear
+        w, h = img.size
+        short, long = (w, h) if w <= h else (h, w)
+        if short != resize:
+            ns, nl = resize, int(resize * long / short)
+            img = img.resize((ns, nl) if w <= h else (nl, ns), Image.BILINEAR)
+    arr = np.asarray(img, dtype=np.float32) / 255.0          # ToTensor
+    return torch.from_numpy(arr).permute(2, 0, 1).contiguous()
+
+
+def _first_file(d):
+    return os.path.join(d, os.listdir(d)[0])
+
+
+class DeviceDataFeed:
+    """GPU-side counterpart of ``SingleImageDataset`` (data/Dataset.py:12-73)."""
+
+    def __init__(self, cfg, A, B):
+        self.cfg, self.A, self.B = cfg, A.to(device), B.to(device)
+        self.step = -1
+
+    def get_A(self):
+        return self.A[None]
+
+    def _crop(self, img, min_cover, flip):
+        _, h, w = img.shape
+        size = int(round(np.random.uniform(min_cover * h, h)))   # data/transforms.py:21
+        size = min(size, w)                                      # :22
+        top = int(torch.randint(0, h - size + 1, (1,)).item())   # RandomCrop
+        left = int(torch.randint(0, w - size + 1, (1,)).item())
+        crop = img[:, top:top + size, left:left + size]
+        if flip and torch.rand(1).item() < 0.5:                  # RandomHorizontalFlip(p=0.5)
+            crop = crop.flip(-1)
+        return crop.contiguous()
+
+    def next(self):
+        self.step += 1
+        aug = bool(self.cfg['use_augmentations'])
+        sample = {'step': self.step}
+        if self.step % self.cfg['entire_A_every'] == 0:
+            sample['A'] = self.get_A()
+        sample['A_global'] = self._crop(self.A, self.cfg['global_A_crops_min_cover'], aug)
+        sample['B_global'] = self._crop(self.B, self.cfg['global_B_crops_min_cover'], aug)
+        return sample
+
+
+def train_model(dataroot, callback=None, cfg_overrides=None, vit_state=None, progress=True):
+    cfg_path = "conf/default/config.yaml" if os.path.exists("conf/default/config.yaml") else _PKG_CFG
+    with open(cfg_path, "r") as f:
+        cfg = yaml.safe_load(f)
+    if dataroot is not None:
+        cfg['dataroot'] = dataroot
+    cfg.update(cfg_overrides or {})
+    if cfg['global_A_crops_n_crops'] != 1 or cfg['global_B_crops_n_crops'] != 1:
+        raise NotImplementedError("the fused engine implements the reference default of one global crop per image")
+    if device.type != 'cuda':
+        raise RuntimeError("train_model needs an MI355X: the product path has no CPU fallback")
+
+    seed = cfg['seed']
+    if seed == -1:
+        seed = np.random.randint(2 ** 32 - 1, dtype=np.int64)
+    random.seed(int(seed))
+    np.random.seed(int(seed) % (2 ** 32))
+    torch.manual_seed(int(seed))
+    print(f'running with seed: {seed}.')
+
+    A = _load_image(_first_file(os.path.join(cfg['dataroot'], 'A')), cfg['A_resize'])
+    B = _load_image(_first_file(os.path.join(cfg['dataroot'], 'B')), cfg['B_resize'])
+    if cfg['direction'] == 'BtoA':
+        A, B = B, A
+    print("Image sizes %s and %s" % (str((A.shape[2], A.shape[1])), str((B.shape[2], B.shape[1]))))
+    feed = DeviceDataFeed(cfg, A, B)
+
+    if vit_state is None:
+        ckpt = os.environ.get("SPLICE_DINO_CHECKPOINT")
+        if ckpt:
+            vit_state = {k: v for k, v in torch.load(ckpt, map_location="cpu").items() if not k.startswith("head")}
+        elif os.environ.get("SPLICE_SYNTHETIC_WEIGHTS") == "1":
+            from . import synth
+            vit_state = synth.vit_params(1234, cfg['dino_model_name'], img_size=224)
+        else:
+            raise RuntimeError("train_model: no DINO weights (set SPLICE_DINO_CHECKPOINT=<dino .pth>, pass vit_state=..., "
+                               "or SPLICE_SYNTHETIC_WEIGHTS=1); the reference's torch.hub download is not available here")
+    # generator initialised exactly as define_G(init_type, init_gain): xavier-normal from the torch RNG seeded above
+    from .networks import define_G
+    netG = define_G(cfg['init_type'], cfg['init_gain'], device=device)
+    gen_state = {k: v.detach() for k, v in netG.state_dict().items() if k in netG.engine.table}
+    crop_max = max(min(A.shape[1], A.shape[2]), min(B.shape[1], B.shape[2]))   # crops are squares of side <= min(h, w)
+    engine = SpliceEngine(cfg, vit_state, gen_state, (crop_max, crop_max), tuple(A.shape[1:]), device=device)
+    del netG
+
+    for epoch in range(1, cfg['n_epochs'] + 1):
+        inputs = feed.next()
+        engine.step(inputs['A_global'], inputs['B_global'], inputs.get('A', [None])[0] if 'A' in inputs else None)
+        if progress and (epoch % 50 == 0 or epoch == 1):
+            print(f"Epoch {epoch}: loss={engine.losses()['loss']:.4f} lr={cfg['lr']}")
+        if epoch % cfg['log_images_freq'] == 0:
+            output = engine.generate(feed.get_A())
+            save_result(output[0], cfg['dataroot'])
+            if callback is not None:
+                callback(output[0])
+    return engine
+
+
+if __name__ == '__main__':
+    parser = ArgumentParser()
+    parser.add_argument("--dataroot", type=str)
+    args = parser.parse_args()
+    train_model(args.dataroot)

@@ -1,0 +1,112 @@
+"""GPU: the drop-in Python API (VitExtractor / Model + netG / LossG / get_optimizer / train_model)
+mirrors the reference's and reproduces its numbers: the same fixtures that pin the oracle
+(recorded from the reference modules) are replayed through the facade classes, exactly as
+train.py:51-80 composes them."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from splice_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _cfg(**over):
+    from splice_amd.engine import DEFAULT_CFG
+    return dict(DEFAULT_CFG, dino_model_name="dino_vits8", dino_global_patch_size=64, **over)
+
+
+def test_extractor_api_golden(golden_dir):
+    from splice_amd.extractor import VitExtractor, attn_cosine_sim
+    g = np.load(os.path.join(golden_dir, "extractor.npz"))
+    ext = VitExtractor("dino_vits8", DEV, state_dict=synth.vit_params(7, "dino_vits8", img_size=32, w_std=0.05))
+    assert ext.get_patch_size() == 8 and ext.get_head_num() == 6 and ext.get_embedding_dim() == 384
+    assert VitExtractor.KEY_LIST == ['block', 'attn', 'patch_imd', 'qkv']
+    img = torch.from_numpy(synth.normal(13, "img32", (1, 3, 32, 32))).to(DEV)
+    assert ext.get_patch_num(img.shape) == 17
+    feats = ext.get_feature_from_input(img)
+    assert len(feats) == 12 and feats[0].shape == (1, 17, 384)
+    rel = lambda a, b: ((a.cpu().double() - torch.from_numpy(b).double()).norm() / torch.from_numpy(b).double().norm()).item()
+    assert rel(feats[-1], g["vits8_block_last"]) < 2e-2
+    qkv = ext.get_qkv_feature_from_input(img)
+    assert len(qkv) == 12 and qkv[11].shape == (1, 17, 1152)
+    assert rel(qkv[11], g["vits8_qkv11"]) < 2e-2
+    qkv_raw = torch.from_numpy(synth.normal(12, "qkv", (1, 17, 3 * 384))).to(DEV)
+    assert np.array_equal(ext.get_keys_from_qkv(qkv_raw, img.shape).cpu().numpy(), g["k_from_qkv"])
+    assert np.array_equal(ext.get_queries_from_qkv(qkv_raw, img.shape).cpu().numpy(), g["q_from_qkv"])
+    assert np.array_equal(ext.get_values_from_qkv(qkv_raw, img.shape).cpu().numpy(), g["v_from_qkv"])
+    keys = ext.get_keys_from_input(img, 11)
+    assert keys.shape == (6, 17, 64) and rel(keys, g["vits8_keys11"]) < 2e-2
+    ss = ext.get_keys_self_sim_from_input(img, 11)
+    assert ss.shape == (1, 17, 17) and (ss.cpu() - torch.from_numpy(g["vits8_selfsim11"])).abs().max().item() < 2e-2
+    attn = ext.get_attn_feature_from_input(img)
+    assert len(attn) == 12 and attn[11].shape == (1, 6, 17, 17)
+    assert (attn[11].cpu() - torch.from_numpy(g["vits8_attn11"])).abs().max().item() < 1e-2
+    x = torch.from_numpy(synth.normal(11, "cos/197", (1, 1, 197, 64))).to(DEV)
+    assert (attn_cosine_sim(x).cpu() - torch.from_numpy(g["cos_T197_D64"])).abs().max().item() < 8e-3
+    # gradients flow from a hooked feature back to the image
+    img2 = img.clone().requires_grad_(True)
+    ext.get_keys_self_sim_from_input(img2, 11).square().mean().backward()
+    assert img2.grad is not None and torch.isfinite(img2.grad).all() and img2.grad.abs().max().item() > 0
+
+
+def test_reference_loop_through_facade(golden_dir):
+    """train.py:51-80 written with the facade classes (Model, LossG, get_optimizer): losses of the
+    first three steps match the reference fixture; netG exposes the reference's state_dict names."""
+    from splice_amd.losses import LossG
+    from splice_amd.model import Model
+    from splice_amd.util import get_optimizer, get_scheduler
+    g = np.load(os.path.join(golden_dir, "steps.npz"))
+    keys = [str(k) for k in g["loss_keys"]]
+    cfg = _cfg()
+    model = Model(cfg)
+    names = [n for n, _ in model.netG.named_parameters()]
+    assert names == [n for n, _, _ in synth.generator_param_specs()]
+    assert "1.0.2.running_mean" in model.netG.state_dict()
+    sd = {k: torch.from_numpy(v) for k, v in synth.generator_params(31, 0.02).items()}
+    model.netG.load_state_dict(sd, strict=False)
+    criterion = LossG(cfg, state_dict=synth.vit_params(7, "dino_vits8", img_size=64, w_std=0.05))
+    optimizer = get_optimizer(cfg, model.netG.parameters())
+    scheduler = get_scheduler(optimizer, lr_policy=cfg['scheduler_policy'])
+    assert isinstance(get_optimizer(dict(cfg, optimizer="nope"), []), NotImplementedError)   # reference returns, not raises
+    A, B = synth.smooth_image_pair(32, 0, 64, 64)
+    A, B = torch.from_numpy(A).to(DEV), torch.from_numpy(B).to(DEV)
+    for step in range(3):
+        inputs = {"step": torch.tensor(float(step)), "A_global": A[None], "B_global": B[None]}
+        if step % cfg["entire_A_every"] == 0:
+            inputs["A"] = A[None]
+        optimizer.zero_grad()
+        outputs = model(inputs)
+        losses = criterion(outputs, inputs)
+        losses["loss"].backward()
+        for j, k in enumerate(keys):
+            ref = g["a/losses"][step, j]
+            if np.isnan(ref):
+                assert k not in losses
+            else:
+                assert abs(losses[k].item() - ref) / abs(ref) < 3e-2, (step, k, losses[k].item(), ref)
+        optimizer.step()
+        scheduler.step()
+    with torch.no_grad():
+        out = model.netG(A[None])
+    assert out.shape == (1, 3, 64, 64) and 0 < out.min().item() and out.max().item() < 1
+
+
+def test_train_model_smoke(tmp_path, monkeypatch):
+    from PIL import Image
+    from splice_amd.train import train_model
+    A, B = synth.smooth_image_pair(50, 0, 72, 96)
+    for name, img in (("A", A), ("B", B)):
+        d = tmp_path / name
+        d.mkdir()
+        Image.fromarray((img.transpose(1, 2, 0) * 255).astype(np.uint8)).save(d / "img.png")
+    seen = []
+    eng = train_model(str(tmp_path), callback=lambda im: seen.append(tuple(im.shape)),
+                      cfg_overrides=dict(seed=3, n_epochs=20, dino_model_name="dino_vits8", dino_global_patch_size=64, log_images_freq=10),
+                      vit_state=synth.vit_params(7, "dino_vits8", img_size=64, w_std=0.05), progress=False)
+    assert seen == [(3, 72, 96), (3, 72, 96)]
+    assert (tmp_path / "out" / "output.png").exists()
+    assert eng.step_idx == 19 and np.isfinite(eng.losses()["loss"])
