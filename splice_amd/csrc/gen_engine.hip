@@ -132,7 +132,7 @@ static int unit_alloc(SpliceGenPlan* p, Unit& u, bool own_out) {
     const size_t plane = (size_t)u.Cout * u.Ho * u.Wo;
     if (u.ks) RC(palloc(p, &u.y, N * plane));
     RC(palloc(p, &u.mean, N * u.Cout)); RC(palloc(p, &u.rstd, N * u.Cout));
-    RC(palloc(p, &u.s1, N * u.Cout)); RC(palloc(p, &u.s2, N * u.Cout));
+    RC(palloc(p, &u.s1, (size_t)bn_part_floats((int)N, u.Cout)));
     if (own_out) RC(palloc(p, &u.out, N * plane));
     if (p->need_grad) {
         RC(palloc(p, &u.dy, N * plane));
@@ -200,8 +200,7 @@ static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* para
         RC(conv_launch(a, s));
         y = u.y; y_ns = u.y_ns;
     }
-    RC(bn_stats_launch(y, y_ns, N, u.Cout, u.Ho * u.Wo, BN_EPS, u.mean, u.rstd, s));
-    RC(bn_act_launch(y, y_ns, u.out, u.out_ns, N, u.Cout, u.Ho * u.Wo, params + u.g_off, params + u.be_off, u.mean, u.rstd, u.slope, s));
+    RC(bn_fwd_launch(y, y_ns, u.out, u.out_ns, N, u.Cout, u.Ho * u.Wo, params + u.g_off, params + u.be_off, BN_EPS, u.s1, u.mean, u.rstd, u.slope, s));
     return SPLICE_OK;
 }
 
@@ -213,9 +212,12 @@ static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* par
     float* dy = u.ks ? u.dy : u.d_in;          // BN-only unit: dy IS the input gradient
     const size_t dy_ns = u.ks ? u.y_ns : u.d_in_ns;
     RC(bn_bwd_launch(u.d_out, u.d_out_ns, u.out, u.out_ns, y, y_ns, dy, dy_ns, N, u.Cout, HW, params + u.g_off, u.mean, u.rstd, u.slope,
-                     u.s1, u.s2, grads + u.g_off, grads + u.be_off, acc, s));
+                     u.s1, grads + u.g_off, grads + u.be_off, acc, s));
     if (!u.ks) return SPLICE_OK;
-    RC(channel_sum_launch(u.dy, u.y_ns, N, u.Cout, HW, grads + u.b_off, acc, s));
+    // The bias of a conv that feeds a train-mode BatchNorm has an analytically ZERO gradient (BN subtracts the
+    // per-channel mean, sum_p dy = 0); the reference's autograd returns fp32 rounding noise there.  We write the
+    // exact value and skip the reduction.
+    if (!acc) RC(fill_zero_launch(grads + u.b_off, u.Cout, s));
     {
         WgradArgs a = {};
         a.x = u.in; a.dy = u.dy; a.ws = p->wgrad_ws;

@@ -28,12 +28,15 @@ struct WgradArgs {
 int wgrad_chunks(int N, int Ho, int Wo, int* pix_per_chunk, int* chunks_per_img);
 int conv_wgrad_launch(WgradArgs a, float* dw, int accumulate, hipStream_t s);
 
-int bn_stats_launch(const float* y, size_t nstride, int N, int C, int HW, float eps, float* mean, float* rstd, hipStream_t s);
-int bn_act_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
-                  const float* beta, const float* mean, const float* rstd, float slope, hipStream_t s);
+// train-mode BatchNorm (+LeakyReLU when slope != 1) forward: statistics in two deterministic stages
+// (per-segment partials, recombined in the apply kernel); `part` = bn_part_floats(N, C) floats of scratch.
+int bn_part_floats(int N, int C);
+int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
+                  const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s);
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
-                  float* s1, float* s2, float* dgamma, float* dbeta, int accumulate, hipStream_t s);
+                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s);
+int fill_zero_launch(float* p, int n, hipStream_t s);
 int channel_sum_launch(const float* dy, size_t nstride, int N, int C, int HW, float* db, int accumulate, hipStream_t s);
 int upsample2x_fwd_launch(const float* in, size_t in_nstride, float* out, size_t out_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s);
 int upsample2x_bwd_launch(const float* dout, size_t dout_nstride, float* din, size_t din_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s);

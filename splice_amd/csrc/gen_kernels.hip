@@ -17,15 +17,19 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // N = output channels (16*FN per workgroup), K = (channel, ky, kx) in the weight's own
 // memory order, consumed CK channels at a time.  TRANSPOSED = data-gradient form:
 // out[c][iy][ix] = sum_{n,ky,kx} in[n][oy][ox] w[n][c][ky][kx] with oy*stride + ky - pad = iy.
-template <int KS, bool TRANSPOSED, int FN>
+// The gather offsets of a thread do not depend on the channel tile, so they are computed once;
+// the next tile's operands are fetched into registers while the current one feeds the MFMAs.
+template <int KS, bool TRANSPOSED, int FN, int CK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     constexpr int T = KS * KS;
-    constexpr int CK = (KS == 3) ? 4 : 16;
-    constexpr int KT = CK * T;          // 36 or 16
+    constexpr int KT = CK * T;          // k extent of one LDS tile (multiple of 4)
     constexpr int BM = 64;
     constexpr int LDA = BM + 16;        // 80: k-rows 16 banks apart -> conflict-free ds_read_b32
-    constexpr int LDW = KT + 2;         // 38 / 18 = 2*odd -> conflict-free
+    constexpr int LDW = KT + 2;         // 2*odd -> conflict-free
     constexpr int BN = 16 * FN;
+    constexpr int NA = KT / 4;                      // gathered elements per thread per tile
+    constexpr int NW = (BN * KT + 255) / 256;       // weight elements per thread per tile
+    static_assert(KT % 4 == 0 && ((LDW / 2) & 1) == 1, "tile shape");
     __shared__ float As[KT * LDA];
     __shared__ float Ws[BN * LDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -33,64 +37,83 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int HWo = a.Ho * a.Wo;
     const float* in = a.in + (size_t)img * a.in_nstride;
-    // this thread gathers pixel pl for k = wave + 4*i
     const int pl = tid & 63;
     const int p = m0 + pl;
     const bool pvalid = p < HWo;
     const int oy = pvalid ? p / a.Wo : 0, ox = pvalid ? p % a.Wo : 0;
+    const int Kc = a.Cin;  // reduction channels
+    // ---- per-thread gather descriptors (k = wave + 4*i is wave-uniform)
+    int a_off[NA], a_cl[NA];
+    unsigned a_ok = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int k = wave + 4 * i;
+        const int cl = k / T, tap = k % T;
+        const int ky = tap / KS, kx = tap % KS;
+        int sy, sx;
+        bool ok;
+        if (!TRANSPOSED) {
+            sy = oy * a.stride + ky - a.pad;
+            sx = ox * a.stride + kx - a.pad;
+            ok = sy >= 0 && sy < a.Hi && sx >= 0 && sx < a.Wi;
+        } else {
+            const int ty = oy + a.pad - ky, tx = ox + a.pad - kx;
+            ok = ty >= 0 && tx >= 0;
+            if (a.stride == 2) {
+                ok = ok && !(ty & 1) && !(tx & 1);
+                sy = ty >> 1; sx = tx >> 1;
+            } else {
+                sy = ty; sx = tx;
+            }
+            ok = ok && sy < a.Hi && sx < a.Wi;
+        }
+        ok = ok && pvalid;
+        a_cl[i] = cl;
+        a_off[i] = ok ? (int)(cl * a.in_cstride) + sy * a.Wi + sx : 0;
+        if (ok) a_ok |= 1u << i;
+    }
+    int w_off[NW], w_cl[NW], w_lds[NW];
+    unsigned w_ok = 0;
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+        const int e = tid + 256 * t;
+        const int j = e / KT, k = e % KT;
+        const int cl = k / T, tap = k % T;
+        const bool ok = e < BN * KT && (n0 + j) < a.Cout;
+        w_cl[t] = cl;
+        w_off[t] = ok ? (int)((size_t)(n0 + j) * a.w_jstride + (size_t)cl * a.w_cstride + tap) : 0;
+        w_lds[t] = e < BN * KT ? j * LDW + k : -1;
+        if (ok) w_ok |= 1u << t;
+    }
+    float av[NA], wv[NW];
+    auto fetch = [&](int c0) {
+        const float* inc = in + (size_t)c0 * a.in_cstride;
+        const float* wc = a.w + (size_t)c0 * a.w_cstride;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) av[i] = ((a_ok >> i) & 1u) && (c0 + a_cl[i] < Kc) ? inc[a_off[i]] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NW; ++t) wv[t] = ((w_ok >> t) & 1u) && (c0 + w_cl[t] < Kc) ? wc[w_off[t]] : 0.f;
+    };
     f32x4 acc[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int Kc = a.Cin;  // reduction channels
+    fetch(0);
     for (int c0 = 0; c0 < Kc; c0 += CK) {
         __syncthreads();
-        // ---- gather A tile: As[k][pixel]
 #pragma unroll
-        for (int i = 0; i < KT / 4; ++i) {
-            const int k = wave + 4 * i;           // wave-uniform
-            const int cl = k / T, tap = k % T;
-            const int ky = tap / KS, kx = tap % KS;
-            const int c = c0 + cl;
-            float v = 0.f;
-            if (pvalid && c < Kc) {
-                int sy, sx;
-                bool ok;
-                if (!TRANSPOSED) {
-                    sy = oy * a.stride + ky - a.pad;
-                    sx = ox * a.stride + kx - a.pad;
-                    ok = sy >= 0 && sy < a.Hi && sx >= 0 && sx < a.Wi;
-                } else {
-                    const int ty = oy + a.pad - ky, tx = ox + a.pad - kx;
-                    ok = ty >= 0 && tx >= 0;
-                    if (a.stride == 2) {
-                        ok = ok && !(ty & 1) && !(tx & 1);
-                        sy = ty >> 1; sx = tx >> 1;
-                    } else {
-                        sy = ty; sx = tx;
-                    }
-                    ok = ok && sy < a.Hi && sx < a.Wi;
-                }
-                if (ok) v = in[(size_t)c * a.in_cstride + (size_t)sy * a.Wi + sx];
-            }
-            As[k * LDA + pl] = v;
-        }
-        // ---- weight tile: Ws[j][k] = w[(n0+j)*w_jstride + (c0+cl)*w_cstride + tap]
-        for (int e = tid; e < BN * KT; e += 256) {
-            const int j = e / KT, k = e % KT;
-            const int cl = k / T, tap = k % T;
-            const int n = n0 + j, c = c0 + cl;
-            float v = 0.f;
-            if (n < a.Cout && c < Kc) v = a.w[(size_t)n * a.w_jstride + (size_t)c * a.w_cstride + tap];
-            Ws[j * LDW + k] = v;
-        }
+        for (int i = 0; i < NA; ++i) As[(wave + 4 * i) * LDA + pl] = av[i];
+#pragma unroll
+        for (int t = 0; t < NW; ++t)
+            if (w_lds[t] >= 0) Ws[w_lds[t]] = wv[t];
         __syncthreads();
+        if (c0 + CK < Kc) fetch(c0 + CK);
 #pragma unroll
         for (int kk = 0; kk < KT / 4; ++kk) {
-            const float av = As[(kk * 4 + (lane >> 4)) * LDA + wave * 16 + (lane & 15)];
+            const float a_ = As[(kk * 4 + (lane >> 4)) * LDA + wave * 16 + (lane & 15)];
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const float bv = Ws[(j * 16 + (lane & 15)) * LDW + kk * 4 + (lane >> 4)];
-                acc[j] = mfma4(av, bv, acc[j]);
+                const float b_ = Ws[(j * 16 + (lane & 15)) * LDW + kk * 4 + (lane >> 4)];
+                acc[j] = mfma4(a_, b_, acc[j]);
             }
         }
     }
@@ -114,23 +137,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 }
 
-template <int KS, bool TR>
+template <int KS, bool TR, int CK>
 static void conv_launch_fn(const ConvArgs& a, hipStream_t s) {
     const int HWo = a.Ho * a.Wo;
     if (a.Cout <= 16) {
-        hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1>), dim3(cdiv(HWo, 64), 1, a.N), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1, CK>), dim3(cdiv(HWo, 64), 1, a.N), dim3(256), 0, s, a);
     } else if (a.Cout <= 32) {
-        hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 2>), dim3(cdiv(HWo, 64), 1, a.N), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 2, CK>), dim3(cdiv(HWo, 64), 1, a.N), dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 4>), dim3(cdiv(HWo, 64), cdiv(a.Cout, 64), a.N), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 4, CK>), dim3(cdiv(HWo, 64), cdiv(a.Cout, 64), a.N), dim3(256), 0, s, a);
     }
 }
 
 int conv_launch(const ConvArgs& a, hipStream_t s) {
     if (a.ks != 1 && a.ks != 3) return SPLICE_ERR_ARG;
     if (a.stride != 1 && a.stride != 2) return SPLICE_ERR_ARG;
-    if (a.ks == 3) { if (a.transposed) conv_launch_fn<3, true>(a, s); else conv_launch_fn<3, false>(a, s); }
-    else { if (a.transposed) conv_launch_fn<1, true>(a, s); else conv_launch_fn<1, false>(a, s); }
+    if ((size_t)a.Cin * a.in_cstride > 0x7fffffffULL) return SPLICE_ERR_ARG;   // 32-bit gather offsets
+    // deeper channel tiles where the reduction is long (fewer barrier rounds on the small, deep layers)
+    if (a.ks == 3) {
+        if (a.Cin >= 32) { if (a.transposed) conv_launch_fn<3, true, 8>(a, s); else conv_launch_fn<3, false, 8>(a, s); }
+        else { if (a.transposed) conv_launch_fn<3, true, 4>(a, s); else conv_launch_fn<3, false, 4>(a, s); }
+    } else {
+        if (a.Cin >= 64) { if (a.transposed) conv_launch_fn<1, true, 32>(a, s); else conv_launch_fn<1, false, 32>(a, s); }
+        else { if (a.transposed) conv_launch_fn<1, true, 16>(a, s); else conv_launch_fn<1, false, 16>(a, s); }
+    }
     return SPLICE_OK;
 }
 
@@ -274,34 +304,69 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
     b = red[4] + red[5] + red[6] + red[7];
 }
 
-// per-(image, channel) mean / rstd over the H*W plane (biased variance, two-pass)
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, size_t nstride, int C, int HW, float eps,
-                                                       float* __restrict__ mean, float* __restrict__ rstd) {
+// Plane reductions run in two deterministic stages so that planes with few channels still fill the
+// chip: stage 1 = PB workgroups per (image, channel) plane write partials; stage 2 = the consuming
+// element-wise kernel recombines the <= 64 partials in a fixed order in its prologue.
+constexpr int MAX_PB = 64;
+__host__ __device__ inline int seg_len(int HW, int PB) { return (HW + PB - 1) / PB; }
+
+// stage 1 of the BN statistics: per-segment (count, mean, M2), two-pass inside the segment
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ y, size_t nstride, int C, int HW, int PB,
+                                                               float* __restrict__ part /* [N][C][PB][2] */) {
     __shared__ float red[8];
-    const int c = blockIdx.x, img = blockIdx.y;
+    const int pb = blockIdx.x, c = blockIdx.y, img = blockIdx.z;
+    const int seg = seg_len(HW, PB), lo = pb * seg, hi = min(lo + seg, HW);
     const float* p = y + (size_t)img * nstride + (size_t)c * HW;
     float s = 0.f, dummy = 0.f;
-    for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    for (int i = lo + threadIdx.x; i < hi; i += 256) s += p[i];
     block_sum2(s, dummy, red);
-    const float m = s / (float)HW;
+    const int cnt = hi - lo;
+    const float m = cnt > 0 ? s / (float)cnt : 0.f;
     float sq = 0.f;
     dummy = 0.f;
-    for (int i = threadIdx.x; i < HW; i += 256) { const float d = p[i] - m; sq += d * d; }
+    for (int i = lo + threadIdx.x; i < hi; i += 256) { const float d = p[i] - m; sq += d * d; }
     block_sum2(sq, dummy, red);
     if (threadIdx.x == 0) {
-        mean[img * C + c] = m;
-        rstd[img * C + c] = rsqrtf(sq / (float)HW + eps);
+        float* o = part + (((size_t)img * C + c) * PB + pb) * 2;
+        o[0] = m;
+        o[1] = sq;
     }
 }
 
-// a = act(gamma * (y - mean) * rstd + beta), written to a channel slice of `out`
+// Chan et al. pairwise combination of the segment statistics, in segment order (deterministic)
+__device__ __forceinline__ void bn_combine(const float* part, int PB, int HW, float eps, float& mean, float& rstd) {
+    const int seg = seg_len(HW, PB);
+    float n = 0.f, m = 0.f, M2 = 0.f;
+    for (int b = 0; b < PB; ++b) {
+        const int lo = b * seg;
+        const int cnt = min(lo + seg, HW) - lo;
+        if (cnt <= 0) break;
+        const float nb = (float)cnt, mb = part[2 * b], Mb = part[2 * b + 1];
+        const float d = mb - m, nt = n + nb;
+        m += d * nb / nt;
+        M2 += Mb + d * d * n * nb / nt;
+        n = nt;
+    }
+    mean = m;
+    rstd = rsqrtf(M2 / (float)HW + eps);
+}
+
+// stage 2 + apply: a = act(gamma * (y - mean) * rstd + beta), written to a channel slice of `out`
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y, size_t y_nstride, float* __restrict__ out,
-                                                     size_t out_nstride, int C, int HW, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, float slope) {
+                                                     size_t out_nstride, int C, int HW, int PB, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ part, float eps,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o, float slope) {
+    __shared__ float st[2];
     const int c = blockIdx.y, img = blockIdx.z;
-    const float sc = gamma[c] * rstd[img * C + c];
-    const float sh = beta[c] - mean[img * C + c] * sc;
+    if (threadIdx.x == 0) {
+        float m, r;
+        bn_combine(part + ((size_t)img * C + c) * PB * 2, PB, HW, eps, m, r);
+        st[0] = m; st[1] = r;
+        if (blockIdx.x == 0) { mean_o[img * C + c] = m; rstd_o[img * C + c] = r; }
+    }
+    __syncthreads();
+    const float sc = gamma[c] * st[1];
+    const float sh = beta[c] - st[0] * sc;
     const float* p = y + (size_t)img * y_nstride + (size_t)c * HW;
     float* q = out + (size_t)img * out_nstride + (size_t)c * HW;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
@@ -310,39 +375,62 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y
     }
 }
 
-// BN backward, reduction half: s1 = sum dz, s2 = sum dz * xhat, dz = da * act'(a)
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ da, size_t da_nstride, const float* __restrict__ aout,
-                                                            size_t a_nstride, const float* __restrict__ y, size_t y_nstride, int C, int HW,
-                                                            const float* __restrict__ mean, const float* __restrict__ rstd, float slope,
-                                                            float* __restrict__ s1o, float* __restrict__ s2o) {
+// BN backward stage 1: per-segment s1 = sum dz, s2 = sum dz * xhat, dz = da * act'(a)
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ da, size_t da_nstride, const float* __restrict__ aout,
+                                                             size_t a_nstride, const float* __restrict__ y, size_t y_nstride, int C, int HW,
+                                                             int PB, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             float slope, float* __restrict__ part /* [N][C][PB][2] */) {
     __shared__ float red[8];
-    const int c = blockIdx.x, img = blockIdx.y;
+    const int pb = blockIdx.x, c = blockIdx.y, img = blockIdx.z;
+    const int seg = seg_len(HW, PB), lo = pb * seg, hi = min(lo + seg, HW);
     const float m = mean[img * C + c], r = rstd[img * C + c];
     const float* pd = da + (size_t)img * da_nstride + (size_t)c * HW;
     const float* pa = aout + (size_t)img * a_nstride + (size_t)c * HW;
     const float* py = y + (size_t)img * y_nstride + (size_t)c * HW;
     float s1 = 0.f, s2 = 0.f;
-    for (int i = threadIdx.x; i < HW; i += 256) {
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
         float dz = pd[i];
         if (slope != 1.0f && !(pa[i] > 0.f)) dz *= slope;
         s1 += dz;
         s2 += dz * (py[i] - m) * r;
     }
     block_sum2(s1, s2, red);
-    if (threadIdx.x == 0) { s1o[img * C + c] = s1; s2o[img * C + c] = s2; }
+    if (threadIdx.x == 0) {
+        float* o = part + (((size_t)img * C + c) * PB + pb) * 2;
+        o[0] = s1;
+        o[1] = s2;
+    }
 }
 
-// apply half: dy = gamma * rstd * (dz - s1/HW - xhat * s2/HW); also dgamma/dbeta (sum over images)
+// stage 2 + apply: dy = gamma * rstd * (dz - s1/HW - xhat * s2/HW); also dgamma/dbeta (sum over images)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ da, size_t da_nstride, const float* __restrict__ aout,
                                                            size_t a_nstride, const float* __restrict__ y, size_t y_nstride,
-                                                           float* __restrict__ dy, size_t dy_nstride, int C, int HW, int N,
+                                                           float* __restrict__ dy, size_t dy_nstride, int C, int HW, int N, int PB,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, float slope, const float* __restrict__ s1i,
-                                                           const float* __restrict__ s2i, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int accumulate) {
+                                                           const float* __restrict__ rstd, float slope, const float* __restrict__ part,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    __shared__ float st[2];
     const int c = blockIdx.y, img = blockIdx.z;
+    if (threadIdx.x == 0) {
+        const float* pp = part + ((size_t)img * C + c) * PB * 2;
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < PB; ++k) { a += pp[2 * k]; b += pp[2 * k + 1]; }
+        st[0] = a; st[1] = b;
+        if (img == 0 && blockIdx.x == 0) {
+            float g = 0.f, be = 0.f;
+            for (int n = 0; n < N; ++n) {
+                const float* pn = part + ((size_t)n * C + c) * PB * 2;
+                float an = 0.f, bn = 0.f;
+                for (int k = 0; k < PB; ++k) { an += pn[2 * k]; bn += pn[2 * k + 1]; }
+                g += bn; be += an;
+            }
+            dgamma[c] = accumulate ? dgamma[c] + g : g;
+            dbeta[c] = accumulate ? dbeta[c] + be : be;
+        }
+    }
+    __syncthreads();
     const float m = mean[img * C + c], r = rstd[img * C + c];
-    const float k1 = s1i[img * C + c] / (float)HW, k2 = s2i[img * C + c] / (float)HW;
+    const float k1 = st[0] / (float)HW, k2 = st[1] / (float)HW;
     const float gr = gamma[c] * r;
     const float* pd = da + (size_t)img * da_nstride + (size_t)c * HW;
     const float* pa = aout + (size_t)img * a_nstride + (size_t)c * HW;
@@ -352,12 +440,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         float dz = pd[i];
         if (slope != 1.0f && !(pa[i] > 0.f)) dz *= slope;
         po[i] = gr * (dz - k1 - (py[i] - m) * r * k2);
-    }
-    if (img == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
-        float g = 0.f, b = 0.f;
-        for (int n = 0; n < N; ++n) { g += s2i[n * C + c]; b += s1i[n * C + c]; }
-        dgamma[c] = accumulate ? dgamma[c] + g : g;
-        dbeta[c] = accumulate ? dbeta[c] + b : b;
     }
 }
 
@@ -375,22 +457,30 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;
 }
 
-int bn_stats_launch(const float* y, size_t nstride, int N, int C, int HW, float eps, float* mean, float* rstd, hipStream_t s) {
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, N), dim3(256), 0, s, y, nstride, C, HW, eps, mean, rstd);
-    return SPLICE_OK;
-}
-static inline int plane_blocks(int HW) { int b = cdiv(HW, 1024); return b < 1 ? 1 : (b > 64 ? 64 : b); }
-int bn_act_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
-                  const float* beta, const float* mean, const float* rstd, float slope, hipStream_t s) {
-    hipLaunchKernelGGL(bn_act_kernel, dim3(plane_blocks(HW), C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, gamma, beta, mean, rstd, slope);
+static inline int plane_blocks(int HW) { int b = cdiv(HW, 1024); return b < 1 ? 1 : (b > MAX_PB ? MAX_PB : b); }
+int bn_part_floats(int N, int C) { return N * C * MAX_PB * 2; }
+int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
+                  const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s) {
+    const int PB = plane_blocks(HW);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, C, HW, PB, part);
+    hipLaunchKernelGGL(bn_act_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, PB, gamma, beta, part, eps, mean, rstd, slope);
     return SPLICE_OK;
 }
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
-                  float* s1, float* s2, float* dgamma, float* dbeta, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, C, HW, mean, rstd, slope, s1, s2);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(plane_blocks(HW), C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy,
-                       dy_nstride, C, HW, N, gamma, mean, rstd, slope, s1, s2, dgamma, dbeta, accumulate);
+                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s) {
+    const int PB = plane_blocks(HW);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, C, HW, PB, mean, rstd, slope, part);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy,
+                       dy_nstride, C, HW, N, PB, gamma, mean, rstd, slope, part, dgamma, dbeta, accumulate);
+    return SPLICE_OK;
+}
+__global__ void fill_zero_kernel(float* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+int fill_zero_launch(float* p, int n, hipStream_t s) {
+    hipLaunchKernelGGL(fill_zero_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, n);
     return SPLICE_OK;
 }
 int channel_sum_launch(const float* dy, size_t nstride, int N, int C, int HW, float* db, int accumulate, hipStream_t s) {
