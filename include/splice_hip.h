@@ -72,6 +72,9 @@ enum {
 int splice_gemm_nt_bf16(unsigned flags, const splice_bf16* A, int lda, const splice_bf16* B, int ldb,
                         int M, int N, int K, const splice_gemm_epilogue* epi, splice_stream_t stream);
 
+/* benchmarking hook (tools/gemm_bench.py): force the tile shape, 0 = automatic */
+int splice_gemm_force_tile(int tile);
+
 /* LayerNorm(D, eps) of the DINO blocks (eps 1e-6), fp32 in -> bf16 out, and its dgrad
  * accumulated into the fp32 residual-gradient stream: g_out = g_in + dLN(dy). */
 int splice_layernorm_fwd(const float* x, const float* gamma, const float* beta, splice_bf16* y,

@@ -42,17 +42,76 @@ __device__ __forceinline__ float group4_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------
-// forward: workgroup = 4 waves, wave = QB blocks of 16 queries; loop over 32-key tiles.
+// LDS tiles shared by the 4 waves of a workgroup (one global read per workgroup instead of per wave).
+//   row tile  [64 rows][64 d]   : 128-byte rows, 16-byte chunk c stored at chunk c ^ (row & 7)
+//                                 -> the 16-lane fragment reads (ds_read_b128) are conflict-free;
+//   col tile  [64 d][64 tokens] : transposed operand, 8-byte chunk c stored at c ^ (((d >> 1) & 7) << 1)
+//                                 -> the (d, token-group) fragment reads (ds_read_b64) are conflict-free and
+//                                    an aligned 16-byte pair stays an aligned pair (16-byte stores).
+__device__ __forceinline__ int row_tile_off(int row, int chunk16) { return row * 64 + ((chunk16 ^ (row & 7)) << 3); }
+__device__ __forceinline__ int col_tile_off(int d, int chunk8) { return d * 64 + ((chunk8 ^ (((d >> 1) & 7) << 1)) << 2); }
+
+struct TileLoader {   // thread t moves chunks t and t+256 of a [64][64] bf16 tile (16 bytes each)
+    int row[2], ch[2];
+    __device__ __forceinline__ TileLoader() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int idx = threadIdx.x + 256 * i; row[i] = idx >> 3; ch[i] = idx & 7; }
+    }
+};
+// token-major source: rows = tokens tok0.. (clamped to tok_max), 64 contiguous d at `base + tok*ld`
+__device__ __forceinline__ void load_row_tile(const TileLoader& L, const bf16_t* base, int ld, int tok0, int tok_max, u32x4* r) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int t = tok0 + L.row[i];
+        t = t < tok_max ? t : tok_max;
+        r[i] = *reinterpret_cast<const u32x4*>(base + (size_t)t * ld + L.ch[i] * 8);
+    }
+}
+__device__ __forceinline__ void store_row_tile(const TileLoader& L, bf16_t* lds, const u32x4* r) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(lds + row_tile_off(L.row[i], L.ch[i])) = r[i];
+}
+// d-major source (transposed matrix): rows = d, 64 contiguous tokens from tok0 (column clamped in-bounds)
+__device__ __forceinline__ void load_col_tile(const TileLoader& L, const bf16_t* baseT, int ldt, int tok0, int tok_lim, u32x4* r) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int t = tok0 + L.ch[i] * 8;
+        t = t <= tok_lim - 8 ? t : tok_lim - 8;
+        r[i] = *reinterpret_cast<const u32x4*>(baseT + (size_t)L.row[i] * ldt + t);
+    }
+}
+__device__ __forceinline__ void store_col_tile(const TileLoader& L, bf16_t* lds, const u32x4* r) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(lds + col_tile_off(L.row[i], L.ch[i] * 2)) = r[i];
+}
+// fragments
+__device__ __forceinline__ u32x4 frag_row(const bf16_t* lds, int row, int chunk16) {
+    return *reinterpret_cast<const u32x4*>(lds + row_tile_off(row, chunk16));
+}
+__device__ __forceinline__ u32x4 frag_col(const bf16_t* lds, int d, int sub, int g) {   // tokens sub*32 + g*4.. and +16
+    const uint2 lo = *reinterpret_cast<const uint2*>(lds + col_tile_off(d, sub * 8 + g));
+    const uint2 hi = *reinterpret_cast<const uint2*>(lds + col_tile_off(d, sub * 8 + 4 + g));
+    return u32x4{lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ u32x4 pack8v(const f32x4& a, const f32x4& b) {
+    return u32x4{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+}
+__device__ __forceinline__ u32x4 ld16v(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+// ---------------------------------------------------------------------------------------
+// forward: workgroup = 4 waves x QB blocks of 16 queries; 64-key K / V^T tiles staged through LDS
+// (register prefetch of the next tile), each consumed as two 32-key sub-tiles.
 template <int QB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * 64];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int h = blockIdx.y, b = blockIdx.z;
     const int ld = 3 * a.D;
     const int qbase = blockIdx.x * (64 * QB) + wave * (16 * QB);
-    if (qbase >= a.Tld) return;
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.Tld * ld;
-    uint4 qf[QB][2];
+    u32x4 qf[QB][2];
     int qidx[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -60,8 +119,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         qidx[qb] = q;
         q = q < a.Tld ? q : a.Tld - 1;
         const bf16_t* p = qkv_b + (size_t)q * ld + h * 64 + g * 8;
-        qf[qb][0] = ld16(p);
-        qf[qb][1] = ld16(p + 32);
+        qf[qb][0] = ld16v(p);
+        qf[qb][1] = ld16v(p + 32);
     }
     float m[QB], l[QB];
     f32x4 o[QB][4];
@@ -72,57 +131,71 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int nd = 0; nd < 4; ++nd) o[qb][nd] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const bf16_t* kbase = qkv_b + a.D + h * 64 + g * 8;
-    const bf16_t* vT = a.qkvT + (size_t)(2 * a.D + h * 64 + c) * a.ldt + (size_t)b * a.Tld + g * 4;
-    for (int kt = 0; kt < a.Tld; kt += 32) {
-        uint4 kf[2][2], vf[4];
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const bf16_t* p = kbase + (size_t)(kt + nb * 16 + c) * ld;
-            kf[nb][0] = ld16(p);
-            kf[nb][1] = ld16(p + 32);
+    const bf16_t* kbase = qkv_b + a.D + h * 64;
+    const bf16_t* vT = a.qkvT + (size_t)(2 * a.D + h * 64) * a.ldt + (size_t)b * a.Tld;
+    TileLoader L;
+    u32x4 kr[2], vr[2];
+    load_row_tile(L, kbase, ld, 0, a.Tld - 1, kr);
+    load_col_tile(L, vT, a.ldt, 0, a.Tld, vr);
+    for (int kt = 0; kt < a.Tld; kt += 64) {
+        __syncthreads();
+        store_row_tile(L, Ks, kr);
+        store_col_tile(L, Vs, vr);
+        __syncthreads();
+        if (kt + 64 < a.Tld) {
+            load_row_tile(L, kbase, ld, kt + 64, a.Tld - 1, kr);
+            load_col_tile(L, vT, a.ldt, kt + 64, a.Tld, vr);
         }
-#pragma unroll
-        for (int nd = 0; nd < 4; ++nd) vf[nd] = ld8x2(vT + (size_t)(nd * 16) * a.ldt + kt);
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            f32x4 s[2];
+        const int nsub = (kt + 32 < a.Tld) ? 2 : 1;
+        for (int sub = 0; sub < nsub; ++sub) {
+            u32x4 kf[2][2], vf[4];
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-                s[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                s[nb] = mfma16(kf[nb][0], qf[qb][0], s[nb]);
-                s[nb] = mfma16(kf[nb][1], qf[qb][1], s[nb]);
+                kf[nb][0] = frag_row(Ks, sub * 32 + nb * 16 + c, g);
+                kf[nb][1] = frag_row(Ks, sub * 32 + nb * 16 + c, 4 + g);
             }
-            float mx = NEG_BIG;
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nd = 0; nd < 4; ++nd) vf[nd] = frag_col(Vs, nd * 16 + c, sub, g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt + nb * 16 + g * 4 + r;
-                    const float v = key < a.T ? s[nb][r] * a.scale : NEG_BIG;
-                    s[nb][r] = v;
-                    mx = fmaxf(mx, v);
+            for (int qb = 0; qb < QB; ++qb) {
+                f32x4 s[2];
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    s[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    s[nb] = mfma16(kf[nb][0], qf[qb][0], s[nb]);
+                    s[nb] = mfma16(kf[nb][1], qf[qb][1], s[nb]);
                 }
-            mx = group4_max(mx);
-            const float mn = fmaxf(m[qb], mx);
-            const float alpha = __expf(m[qb] - mn);
-            m[qb] = mn;
-            float ps = 0.f;
+                float mx = NEG_BIG;
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = __expf(s[nb][r] - mn);
-                    s[nb][r] = p;
-                    ps += p;
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt + sub * 32 + nb * 16 + g * 4 + r;
+                        const float v = key < a.T ? s[nb][r] * a.scale : NEG_BIG;
+                        s[nb][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = group4_max(mx);
+                const float mn = fmaxf(m[qb], mx);
+                const float alpha = __expf(m[qb] - mn);
+                m[qb] = mn;
+                float ps = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __expf(s[nb][r] - mn);
+                        s[nb][r] = p;
+                        ps += p;
+                    }
+                l[qb] = l[qb] * alpha + ps;
+                const u32x4 pb = pack8v(s[0], s[1]);
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[qb][nd][r] *= alpha;
+                    o[qb][nd] = mfma16(vf[nd], pb, o[qb][nd]);
                 }
-            l[qb] = l[qb] * alpha + ps;
-            const uint4 pb = pack8(s[0], s[1]);
-#pragma unroll
-            for (int nd = 0; nd < 4; ++nd) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[qb][nd][r] *= alpha;
-                o[qb][nd] = mfma16(vf[nd], pb, o[qb][nd]);
             }
         }
     }
@@ -165,64 +238,92 @@ __global__ void attn_delta_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// backward, dK / dV: wave owns 16 keys (lane&15 = key), loops over 32-query tiles.
+// backward, dK / dV: wave owns 16 keys (lane&15 = key); the workgroup's 4 waves share 64-query tiles of
+// Q, dO (row tiles) and Q^T, dO^T (col tiles) plus lse / delta through LDS.
 __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * 64];
+    __shared__ __attribute__((aligned(16))) bf16_t Ds[64 * 64];
+    __shared__ __attribute__((aligned(16))) bf16_t QTs[64 * 64];
+    __shared__ __attribute__((aligned(16))) bf16_t DTs[64 * 64];
+    __shared__ __attribute__((aligned(16))) float Ls[64];
+    __shared__ __attribute__((aligned(16))) float Es[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int h = blockIdx.y, b = blockIdx.z;
     const int ld = 3 * a.D;
-    const int kbase_idx = blockIdx.x * 64 + wave * 16;
-    if (kbase_idx >= a.Tld) return;
-    const int key = kbase_idx + c;
+    const int key = blockIdx.x * 64 + wave * 16 + c;
     const int keyc = key < a.Tld ? key : a.Tld - 1;
     const bool key_valid = key < a.T;
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.Tld * ld;
-    uint4 kf[2], vf[2];
+    u32x4 kf[2], vf[2];
     {
         const bf16_t* pk = qkv_b + (size_t)keyc * ld + a.D + h * 64 + g * 8;
         const bf16_t* pv = qkv_b + (size_t)keyc * ld + 2 * a.D + h * 64 + g * 8;
-        kf[0] = ld16(pk); kf[1] = ld16(pk + 32);
-        vf[0] = ld16(pv); vf[1] = ld16(pv + 32);
+        kf[0] = ld16v(pk); kf[1] = ld16v(pk + 32);
+        vf[0] = ld16v(pv); vf[1] = ld16v(pv + 32);
     }
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int nd = 0; nd < 4; ++nd) { dk[nd] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[nd] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const bf16_t* qrow = qkv_b + h * 64 + g * 8;                                   // + q*ld
-    const bf16_t* dorow = a.dout + (size_t)b * a.Tld * a.D + h * 64 + g * 8;       // + q*D
-    const bf16_t* qT = a.qkvT + (size_t)(h * 64 + c) * a.ldt + (size_t)b * a.Tld + g * 4;
-    const bf16_t* doT = a.doutT + (size_t)(h * 64 + c) * a.ldt + (size_t)b * a.Tld + g * 4;
+    const bf16_t* qrow = qkv_b + h * 64;
+    const bf16_t* dorow = a.dout + (size_t)b * a.Tld * a.D + h * 64;
+    const bf16_t* qT = a.qkvT + (size_t)(h * 64) * a.ldt + (size_t)b * a.Tld;
+    const bf16_t* doT = a.doutT + (size_t)(h * 64) * a.ldt + (size_t)b * a.Tld;
     const float* lse = a.lse + ((size_t)b * a.H + h) * a.Tld;
     const float* dl = a.delta + ((size_t)b * a.H + h) * a.Tld;
-    for (int qt = 0; qt < a.Tld; qt += 32) {
-        f32x4 s[2], dp[2];
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            const bf16_t* pq = qrow + (size_t)(qt + qb * 16 + c) * ld;
-            const bf16_t* pd = dorow + (size_t)(qt + qb * 16 + c) * a.D;
-            const uint4 q0 = ld16(pq), q1 = ld16(pq + 32), d0 = ld16(pd), d1 = ld16(pd + 32);
-            s[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            s[qb] = mfma16(q0, kf[0], s[qb]);      // S[q][key]: rows q = qb*16+g*4+r, col = key
-            s[qb] = mfma16(q1, kf[1], s[qb]);
-            dp[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dp[qb] = mfma16(d0, vf[0], dp[qb]);    // dP[q][key]
-            dp[qb] = mfma16(d1, vf[1], dp[qb]);
+    TileLoader L;
+    u32x4 r_q[2], r_d[2], r_qt[2], r_dt[2];
+    float r_l = 0.f, r_e = 0.f;
+    auto fetch = [&](int qt) {
+        load_row_tile(L, qrow, ld, qt, a.Tld - 1, r_q);
+        load_row_tile(L, dorow, a.D, qt, a.Tld - 1, r_d);
+        load_col_tile(L, qT, a.ldt, qt, a.Tld, r_qt);
+        load_col_tile(L, doT, a.ldt, qt, a.Tld, r_dt);
+        if (threadIdx.x < 64) {
+            const int q = qt + threadIdx.x < a.Tld ? qt + threadIdx.x : a.Tld - 1;
+            r_l = lse[q]; r_e = dl[q];
         }
+    };
+    fetch(0);
+    for (int qt = 0; qt < a.Tld; qt += 64) {
+        __syncthreads();
+        store_row_tile(L, Qs, r_q);
+        store_row_tile(L, Ds, r_d);
+        store_col_tile(L, QTs, r_qt);
+        store_col_tile(L, DTs, r_dt);
+        if (threadIdx.x < 64) { Ls[threadIdx.x] = r_l; Es[threadIdx.x] = r_e; }
+        __syncthreads();
+        if (qt + 64 < a.Tld) fetch(qt + 64);
+        const int nsub = (qt + 32 < a.Tld) ? 2 : 1;
+        for (int sub = 0; sub < nsub; ++sub) {
+            f32x4 s[2], dp[2];
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            const f32x4 ls = *reinterpret_cast<const f32x4*>(lse + qt + qb * 16 + g * 4);
-            const f32x4 de = *reinterpret_cast<const f32x4*>(dl + qt + qb * 16 + g * 4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = key_valid ? __expf(s[qb][r] * a.scale - ls[r]) : 0.f;
-                s[qb][r] = p;
-                dp[qb][r] = p * (dp[qb][r] - de[r]);
+            for (int qb = 0; qb < 2; ++qb) {
+                const int row = sub * 32 + qb * 16 + c;
+                s[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                s[qb] = mfma16(frag_row(Qs, row, g), kf[0], s[qb]);        // S[q][key]
+                s[qb] = mfma16(frag_row(Qs, row, 4 + g), kf[1], s[qb]);
+                dp[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[qb] = mfma16(frag_row(Ds, row, g), vf[0], dp[qb]);      // dP[q][key]
+                dp[qb] = mfma16(frag_row(Ds, row, 4 + g), vf[1], dp[qb]);
             }
-        }
-        const uint4 pb = pack8(s[0], s[1]), dsb = pack8(dp[0], dp[1]);
 #pragma unroll
-        for (int nd = 0; nd < 4; ++nd) {
-            dv[nd] = mfma16(ld8x2(doT + (size_t)(nd * 16) * a.ldt + qt), pb, dv[nd]);   // dV^T[d][key]
-            dk[nd] = mfma16(ld8x2(qT + (size_t)(nd * 16) * a.ldt + qt), dsb, dk[nd]);   // dK^T[d][key]
+            for (int qb = 0; qb < 2; ++qb) {
+                const f32x4 ls = *reinterpret_cast<const f32x4*>(Ls + sub * 32 + qb * 16 + g * 4);
+                const f32x4 de = *reinterpret_cast<const f32x4*>(Es + sub * 32 + qb * 16 + g * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = key_valid ? __expf(s[qb][r] * a.scale - ls[r]) : 0.f;
+                    s[qb][r] = p;
+                    dp[qb][r] = p * (dp[qb][r] - de[r]);
+                }
+            }
+            const u32x4 pb = pack8v(s[0], s[1]), dsb = pack8v(dp[0], dp[1]);
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd) {
+                dv[nd] = mfma16(frag_col(DTs, nd * 16 + c, sub, g), pb, dv[nd]);    // dV^T[d][key]
+                dk[nd] = mfma16(frag_col(QTs, nd * 16 + c, sub, g), dsb, dk[nd]);   // dK^T[d][key]
+            }
         }
     }
     if (key < a.Tld) {
@@ -236,58 +337,74 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
     }
 }
 
-// backward, dQ: wave owns 16 queries (lane&15 = query), loops over 32-key tiles.
+// backward, dQ: wave owns 16 queries (lane&15 = query); K, V (row tiles) and K^T (col tile) shared via LDS.
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * 64];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * 64];
+    __shared__ __attribute__((aligned(16))) bf16_t KTs[64 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int h = blockIdx.y, b = blockIdx.z;
     const int ld = 3 * a.D;
-    const int qbase = blockIdx.x * 64 + wave * 16;
-    if (qbase >= a.Tld) return;
-    const int q = qbase + c;
+    const int q = blockIdx.x * 64 + wave * 16 + c;
     const int qc = q < a.Tld ? q : a.Tld - 1;
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.Tld * ld;
-    uint4 qf[2], dof[2];
+    u32x4 qf[2], dof[2];
     {
         const bf16_t* pq = qkv_b + (size_t)qc * ld + h * 64 + g * 8;
         const bf16_t* pd = a.dout + ((size_t)b * a.Tld + qc) * a.D + h * 64 + g * 8;
-        qf[0] = ld16(pq); qf[1] = ld16(pq + 32);
-        dof[0] = ld16(pd); dof[1] = ld16(pd + 32);
+        qf[0] = ld16v(pq); qf[1] = ld16v(pq + 32);
+        dof[0] = ld16v(pd); dof[1] = ld16v(pd + 32);
     }
     const float lse_q = a.lse[((size_t)b * a.H + h) * a.Tld + qc];
     const float del_q = a.delta[((size_t)b * a.H + h) * a.Tld + qc];
     f32x4 dq[4];
 #pragma unroll
     for (int nd = 0; nd < 4; ++nd) dq[nd] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bf16_t* krow = qkv_b + a.D + h * 64 + g * 8;
-    const bf16_t* vrow = qkv_b + 2 * a.D + h * 64 + g * 8;
-    const bf16_t* kT = a.qkvT + (size_t)(a.D + h * 64 + c) * a.ldt + (size_t)b * a.Tld + g * 4;
-    for (int kt = 0; kt < a.Tld; kt += 32) {
-        f32x4 s[2], dp[2];
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const bf16_t* pk = krow + (size_t)(kt + nb * 16 + c) * ld;
-            const bf16_t* pv = vrow + (size_t)(kt + nb * 16 + c) * ld;
-            const uint4 k0 = ld16(pk), k1 = ld16(pk + 32), v0 = ld16(pv), v1 = ld16(pv + 32);
-            s[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            s[nb] = mfma16(k0, qf[0], s[nb]);      // S^T[key][q]
-            s[nb] = mfma16(k1, qf[1], s[nb]);
-            dp[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dp[nb] = mfma16(v0, dof[0], dp[nb]);   // dP^T[key][q]
-            dp[nb] = mfma16(v1, dof[1], dp[nb]);
+    const bf16_t* krow = qkv_b + a.D + h * 64;
+    const bf16_t* vrow = qkv_b + 2 * a.D + h * 64;
+    const bf16_t* kT = a.qkvT + (size_t)(a.D + h * 64) * a.ldt + (size_t)b * a.Tld;
+    TileLoader L;
+    u32x4 r_k[2], r_v[2], r_kt[2];
+    load_row_tile(L, krow, ld, 0, a.Tld - 1, r_k);
+    load_row_tile(L, vrow, ld, 0, a.Tld - 1, r_v);
+    load_col_tile(L, kT, a.ldt, 0, a.Tld, r_kt);
+    for (int kt = 0; kt < a.Tld; kt += 64) {
+        __syncthreads();
+        store_row_tile(L, Ks, r_k);
+        store_row_tile(L, Vs, r_v);
+        store_col_tile(L, KTs, r_kt);
+        __syncthreads();
+        if (kt + 64 < a.Tld) {
+            load_row_tile(L, krow, ld, kt + 64, a.Tld - 1, r_k);
+            load_row_tile(L, vrow, ld, kt + 64, a.Tld - 1, r_v);
+            load_col_tile(L, kT, a.ldt, kt + 64, a.Tld, r_kt);
         }
+        const int nsub = (kt + 32 < a.Tld) ? 2 : 1;
+        for (int sub = 0; sub < nsub; ++sub) {
+            f32x4 s[2], dp[2];
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt + nb * 16 + g * 4 + r;
-                const float p = key < a.T ? __expf(s[nb][r] * a.scale - lse_q) : 0.f;
-                dp[nb][r] = p * (dp[nb][r] - del_q);
+            for (int nb = 0; nb < 2; ++nb) {
+                const int row = sub * 32 + nb * 16 + c;
+                s[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                s[nb] = mfma16(frag_row(Ks, row, g), qf[0], s[nb]);        // S^T[key][q]
+                s[nb] = mfma16(frag_row(Ks, row, 4 + g), qf[1], s[nb]);
+                dp[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[nb] = mfma16(frag_row(Vs, row, g), dof[0], dp[nb]);     // dP^T[key][q]
+                dp[nb] = mfma16(frag_row(Vs, row, 4 + g), dof[1], dp[nb]);
             }
-        const uint4 dsb = pack8(dp[0], dp[1]);
 #pragma unroll
-        for (int nd = 0; nd < 4; ++nd)
-            dq[nd] = mfma16(ld8x2(kT + (size_t)(nd * 16) * a.ldt + kt), dsb, dq[nd]);   // dQ^T[d][q]
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt + sub * 32 + nb * 16 + g * 4 + r;
+                    const float p = key < a.T ? __expf(s[nb][r] * a.scale - lse_q) : 0.f;
+                    dp[nb][r] = p * (dp[nb][r] - del_q);
+                }
+            const u32x4 dsb = pack8v(dp[0], dp[1]);
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd) dq[nd] = mfma16(frag_col(KTs, nd * 16 + c, sub, g), dsb, dq[nd]);   // dQ^T[d][q]
+        }
     }
     if (q < a.Tld) {
         bf16_t* p = a.dqkv + ((size_t)b * a.Tld + q) * ld + h * 64 + g * 4;

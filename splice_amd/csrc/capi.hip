@@ -39,6 +39,9 @@ int splice_gemm_nt_bf16(unsigned flags, const splice_bf16* A, int lda, const spl
     return finish(gemm_nt_launch(flags, A, lda, B, ldb, M, N, K, *epi, ST(stream)), "splice_gemm_nt_bf16");
 }
 
+/* benchmarking hook: force the GEMM tile (0 auto, 1 128x128, 2 128x64, 3 64x64) */
+int splice_gemm_force_tile(int tile) { gemm_force_tile(tile); return SPLICE_OK; }
+
 int splice_layernorm_fwd(const float* x, const float* gamma, const float* beta, splice_bf16* y, float* mean, float* rstd,
                          int rows, int D, float eps, splice_stream_t stream) {
     return finish(layernorm_fwd_launch(x, gamma, beta, y, mean, rstd, rows, D, eps, ST(stream)), "splice_layernorm_fwd");

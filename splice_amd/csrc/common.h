@@ -32,12 +32,26 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// erf-form GELU (torch.nn.GELU default) and its derivative
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-form GELU (torch.nn.GELU default) and its derivative.  erf by Abramowitz-Stegun 7.1.26
+// (|abs err| <= 1.5e-7, far below the bf16 output rounding) sharing one exp(-x^2/2) between the
+// cdf and the pdf term: ~12 VALU ops instead of libm's erff.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& ex) {
+    const float ax = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    ex = __expf(-0.5f * x * x);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float erf_abs = 1.0f - poly * ex;
+    cdf = 0.5f * (1.0f + (x < 0.f ? -erf_abs : erf_abs));
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float cdf, ex;
+    gelu_parts(x, cdf, ex);
+    return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float cdf, ex;
+    gelu_parts(x, cdf, ex);
+    return cdf + x * 0.3989422804014327f * ex;
 }
 
 // D = A(16xK32) * B(K32x16) + C on one wave.  Operand layout (gfx950, 16x16x32 bf16):

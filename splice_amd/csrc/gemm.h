@@ -14,7 +14,9 @@
 
 constexpr int GEMM_BK = 64;
 
-template <int BM, int BN>
+// SWAP = true computes the transposed fragments (MFMA operands exchanged): each lane then owns 4 consecutive
+// COLUMNS of one output row, so the epilogue moves 8/16-byte vectors instead of scalar elements.
+template <int BM, int BN, bool SWAP = false>
 struct GemmTile {
     static constexpr int FM = BM / 32;  // 16-row fragments per wave along M
     static constexpr int FN = BN / 32;
@@ -94,6 +96,87 @@ struct GemmTile {
                     for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
             }
         }
+    }
+
+    // Same contraction with direct-to-LDS staging (global_load_lds, 16 B per lane): no VGPR round trip, no
+    // ds_write pass.  A wave-instruction fills 8 rows x 128 B of LDS linearly (dest = wave base + lane*16), so the
+    // XOR swizzle is applied on the SOURCE chunk each lane fetches.  Two LDS stages; the loads of slice t+1 are
+    // issued right after the barrier that publishes slice t and fly during its MFMAs (one barrier per slice).
+    __device__ __forceinline__ void run_glds(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+                                             int M, int N, int K, int m0, int n0, bf16_t* smem) {
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef __attribute__((address_space(1))) const void glb_void;
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int lrow = lane >> 3, gchunk = (lane & 7) ^ lrow;
+        const bf16_t* ag[A_LOADS];
+        const bf16_t* bg[B_LOADS];
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            int gr = m0 + wave * 8 + 32 * i + lrow;
+            gr = gr < M ? gr : M - 1;
+            ag[i] = A + (size_t)gr * lda + gchunk * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            int gr = n0 + wave * 8 + 32 * i + lrow;
+            gr = gr < N ? gr : N - 1;
+            bg[i] = B + (size_t)gr * ldb + gchunk * 8;
+        }
+        auto issue = [&](int k0, int stage) {
+            bf16_t* st = smem + stage * LDS_ELEMS;
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i)
+                __builtin_amdgcn_global_load_lds((glb_void*)(ag[i] + k0), (lds_void*)(st + (wave * 8 + 32 * i) * GEMM_BK), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i)
+                __builtin_amdgcn_global_load_lds((glb_void*)(bg[i] + k0), (lds_void*)(st + BM * GEMM_BK + (wave * 8 + 32 * i) * GEMM_BK), 16, 0, 0);
+        };
+        issue(0, 0);
+        const int frow = lane & 15, fchunk = lane >> 4;
+        int it = 0;
+        for (int k0 = 0; k0 < K; k0 += GEMM_BK, ++it) {
+            __syncthreads();   // slice `it` has landed (the barrier drains the LDS-DMA queue); slice it-1 fully consumed
+            if (k0 + GEMM_BK < K) issue(k0 + GEMM_BK, (it + 1) & 1);
+            const bf16_t* As = smem + (it & 1) * LDS_ELEMS;
+            const bf16_t* Bs = As + BM * GEMM_BK;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4 af[FM], bf[FN];
+                const int chunk = kk * 4 + fchunk;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int row = wm * (BM / 2) + i * 16 + frow;
+                    af[i] = *reinterpret_cast<const u32x4*>(As + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int row = wn * (BN / 2) + j * 16 + frow;
+                    bf[j] = *reinterpret_cast<const u32x4*>(Bs + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = SWAP ? mfma16(bf[j], af[i], acc[i][j]) : mfma16(af[i], bf[j], acc[i][j]);
+            }
+        }
+    }
+
+    // SWAP layout: f(row, col0, v) where v[r] is C[row][col0 + r].
+    template <class F>
+    __device__ __forceinline__ void for_each_cols(int m0, int n0, F&& f) {
+        static_assert(SWAP, "for_each_cols needs the swapped fragment layout");
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                f(m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4, acc[i][j]);
     }
 
     // Visit every accumulator fragment: f(row0, col, v) where v[r] is C[row0 + r][col].
@@ -181,17 +264,94 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, int M, int N, in
     }
 }
 
+// Epilogue for the swapped fragment layout: lane holds C[row][col0 .. col0+3].
+template <unsigned FLAGS>
+__device__ __forceinline__ void gemm_epilogue_cols(const GemmEpi& e, int M, int N, int row, int col0, f32x4 v) {
+    if (row >= M || col0 >= N) return;
+    const bool full = col0 + 3 < N;
+    float x[4] = {v[0], v[1], v[2], v[3]};
+    if (FLAGS & EPI_ALPHA) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] *= e.alpha;
+    }
+    if (FLAGS & EPI_BIAS) {
+        if (full) {
+            const float4 b = *reinterpret_cast<const float4*>(e.bias + col0);
+            x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (col0 + r < N) x[r] += e.bias[col0 + r];
+        }
+    }
+    if (FLAGS & EPI_RESID) {
+        const int rr = e.resid_mod ? row % e.resid_mod : row;
+        const float* p = e.resid + (size_t)rr * e.ldr + col0;
+        if (full && !(e.ldr & 3)) {
+            const float4 b = *reinterpret_cast<const float4*>(p);
+            x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (col0 + r < N) x[r] += p[r];
+        }
+    }
+    if (FLAGS & EPI_GELU_GRAD) {
+        const bf16_t* p = e.aux + (size_t)row * e.ldaux + col0;
+        if (full && !(e.ldaux & 3)) {
+            const uint2 u = *reinterpret_cast<const uint2*>(p);
+            x[0] *= gelu_grad_f(bf2f((bf16_t)(u.x & 0xFFFF))); x[1] *= gelu_grad_f(bf2f((bf16_t)(u.x >> 16)));
+            x[2] *= gelu_grad_f(bf2f((bf16_t)(u.y & 0xFFFF))); x[3] *= gelu_grad_f(bf2f((bf16_t)(u.y >> 16)));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (col0 + r < N) x[r] *= gelu_grad_f(bf2f(p[r]));
+        }
+    }
+    auto store_bf = [&](bf16_t* base, int ld) {
+        bf16_t* p = base + (size_t)row * ld + col0;
+        if (full && !(ld & 3)) *reinterpret_cast<uint2*>(p) = uint2{pack2bf(x[0], x[1]), pack2bf(x[2], x[3])};
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (col0 + r < N) p[r] = f2bf(x[r]);
+        }
+    };
+    if (FLAGS & EPI_GELU) {
+        if (e.out_pre) store_bf(e.out_pre, e.ldp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = gelu_f(x[r]);
+    }
+    if (FLAGS & EPI_OUT_F32) {
+        float* p = e.out_f32 + (size_t)row * e.ldo + col0;
+        if (full && !(e.ldo & 3)) *reinterpret_cast<float4*>(p) = float4{x[0], x[1], x[2], x[3]};
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (col0 + r < N) p[r] = x[r];
+        }
+    }
+    if (FLAGS & EPI_OUT_BF) store_bf(e.out_bf, e.ldbf);
+    if (FLAGS & EPI_OUT_T) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (col0 + r < N) e.out_bf_t[(size_t)(col0 + r) * e.ldt + row] = f2bf(x[r]);   // 16 lanes -> 32 contiguous bytes
+    }
+    if (FLAGS & EPI_COLS_F32) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = col0 + r;
+            if (c < N && c >= e.col_lo && c < e.col_hi) e.out_f32_cols[(size_t)row * e.ld_cols + (c - e.col_lo)] = x[r];
+        }
+    }
+}
+
 template <int BM, int BN, unsigned FLAGS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
                                                       int ldb, int M, int N, int K, GemmEpi e) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[GemmTile<BM, BN>::LDS_ELEMS];
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * GemmTile<BM, BN>::LDS_ELEMS];
     const int tiles_n = (N + BN - 1) / BN;
     const int nwg = gridDim.x;
     const int t = xcd_remap(blockIdx.x, nwg);
     const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
-    GemmTile<BM, BN> tile;
-    tile.run(A, lda, B, ldb, M, N, K, m0, n0, smem);
-    tile.for_each(m0, n0, [&](int row0, int col, f32x4 v) { gemm_epilogue<FLAGS>(e, M, N, row0, col, v); });
+    GemmTile<BM, BN, true> tile;
+    tile.run_glds(A, lda, B, ldb, M, N, K, m0, n0, smem);
+    tile.for_each_cols(m0, n0, [&](int row, int col0, f32x4 v) { gemm_epilogue_cols<FLAGS>(e, M, N, row, col0, v); });
 }
 
 template <int BM, int BN, unsigned FLAGS>

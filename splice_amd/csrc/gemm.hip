@@ -2,12 +2,18 @@
 // DINO-ViT forward / dgrad path uses (K3, K5, K7, K8 of SURVEY.md section 2b).
 #include "kernels.h"
 
+static int g_force_tile = 0;   // 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 (tools/gemm_bench.py)
+void gemm_force_tile(int t) { g_force_tile = t; }
+
 template <unsigned FLAGS>
 static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e,
                          hipStream_t s) {
     // 256 CUs: prefer the biggest tile that still yields >= ~1 workgroup per CU.
     const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
     const long t12864 = (long)cdiv(M, 128) * cdiv(N, 64);
+    if (g_force_tile == 1) { launch_gemm_nt<128, 128, FLAGS>(s, A, lda, B, ldb, M, N, K, e); return SPLICE_OK; }
+    if (g_force_tile == 2) { launch_gemm_nt<128, 64, FLAGS>(s, A, lda, B, ldb, M, N, K, e); return SPLICE_OK; }
+    if (g_force_tile == 3) { launch_gemm_nt<64, 64, FLAGS>(s, A, lda, B, ldb, M, N, K, e); return SPLICE_OK; }
     if (t128 >= 224) launch_gemm_nt<128, 128, FLAGS>(s, A, lda, B, ldb, M, N, K, e);
     else if (t12864 >= 200) launch_gemm_nt<128, 64, FLAGS>(s, A, lda, B, ldb, M, N, K, e);
     else launch_gemm_nt<64, 64, FLAGS>(s, A, lda, B, ldb, M, N, K, e);

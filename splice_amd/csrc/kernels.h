@@ -28,6 +28,8 @@ int attn_probs_launch(const AttnArgs* a, float* probs, hipStream_t s);
 int gemm_nt_launch(unsigned flags, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K,
                    const GemmEpi& e, hipStream_t s);
 
+void gemm_force_tile(int t);   // benchmarking hook: 0 auto, 1 128x128, 2 128x64, 3 64x64
+
 // ---- vit_ops.hip -----------------------------------------------------------------------
 // LayerNorm over the last dim (D % 256 == 0 handled generally), one wave per row.
 int layernorm_fwd_launch(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,

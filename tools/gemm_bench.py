@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the bf16 NT GEMM on the ViT shapes, per tile config (run on the GPU box)."""
+import ctypes as C
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from splice_amd import _lib
+
+L = _lib.lib()
+shapes = [("qkv", 3200, 2304, 768), ("proj", 3200, 768, 768), ("fc1", 3200, 3072, 768), ("fc2", 3200, 768, 3072),
+          ("fc2T", 1600, 3072, 768), ("fc1T", 1600, 768, 3072), ("projT", 1600, 768, 768), ("qkvT", 1600, 768, 2304),
+          ("patch", 3200, 768, 192)]
+names = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 4: "256x128", 5: "128x128x8w"}
+tiles = [int(t) for t in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3]
+for name, M, N, K in shapes:
+    A = torch.randn(M, K, device="cuda").bfloat16()
+    B = torch.randn(N, K, device="cuda").bfloat16()
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    e = _lib.GemmEpilogue()
+    e.out_bf = out.data_ptr(); e.ldbf = N
+    row = []
+    for t in tiles:
+        L.splice_gemm_force_tile(t)
+        for _ in range(3):
+            L.splice_gemm_nt_bf16(_lib.EPI_OUT_BF, _lib.ptr(A), K, _lib.ptr(B), K, M, N, K, C.byref(e), _lib.current_stream())
+        torch.cuda.synchronize()
+        s, f = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(20):
+            L.splice_gemm_nt_bf16(_lib.EPI_OUT_BF, _lib.ptr(A), K, _lib.ptr(B), K, M, N, K, C.byref(e), _lib.current_stream())
+        f.record(); torch.cuda.synchronize()
+        us = s.elapsed_time(f) / 20 * 1e3
+        row.append(f"{names.get(t,t)} {us:6.1f}us {2*M*N*K/us/1e6:6.0f}TF")
+    L.splice_gemm_force_tile(0)
+    print(f"{name:6s} {M}x{N}x{K}: " + " | ".join(row))
