@@ -184,6 +184,7 @@ int splice_adam_step(float* params, float* grads, float* m, float* v, long long 
  * which 1 = fc1 GEMM fwd, 2 = qkv GEMM fwd (layers 0..depth-2), 3 = attention fwd */
 int splice_prof_begin(int which);
 int splice_prof_end(float* total_ms, int* launches);
+int splice_prof_active(void);
 int splice_vit_ctx_dims(void* ctx, int* B, int* H, int* W, int* D, int* depth, int* heads, int* patch);
 int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams);
 /* re-target a plan to a smaller input without reallocating (per-step random crop sizes,
@@ -213,6 +214,9 @@ int splice_step_run(void* step, float* params, float* grads, float* m, float* v,
                     const float* B_crop, const float* A_entire, int step_idx, float* losses_out,
                     splice_stream_t stream);
 int splice_step_output(void* step, int which, float** out_ptr);
+/* 1 (default): capture the step's launch sequence once per regime into a hipGraph and replay it;
+ * 0: launch every kernel eagerly (also used automatically while splice_prof_begin is armed) */
+int splice_step_use_graph(void* step, int on);
 /* per-step crop sizes (<= creation size).  Equal A/B sizes run the N=2 plan; different sizes
  * (the reference draws them independently, data/Dataset.py:66-67) run two N=1 plans that must
  * have been attached once with splice_step_attach_split_plans. */

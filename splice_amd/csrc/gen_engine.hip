@@ -12,6 +12,8 @@
 
 #include "gen_kernels.h"
 
+int dev_copy_launch(void* dst, const void* src, size_t bytes, hipStream_t s);
+
 void splice_set_error(const char* fmt, ...);
 
 #define RC(x)                                                                                     \
@@ -378,7 +380,7 @@ int splice_gen_forward(void* plan, const float* params, const float* x, float* y
     SpliceGenPlan* p = (SpliceGenPlan*)plan;
     if (!p || !params || !x || !y) return SPLICE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemcpyAsync(p->x_copy, x, (size_t)p->N * 3 * p->H * p->W * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return SPLICE_ERR_HIP;
+    RC(dev_copy_launch(p->x_copy, x, (size_t)p->N * 3 * p->H * p->W * sizeof(float), s));
     p->u_skip[0].in = p->x_copy; p->u_da[0].in = p->x_copy;
     RC(scale_forward(p, 0, params, s));
     {
@@ -391,7 +393,7 @@ int splice_gen_forward(void* plan, const float* params, const float* x, float* y
         RC(conv_launch(a, s));
     }
     if (p->need_grad) {
-        if (hipMemcpyAsync(p->out_copy, y, (size_t)p->N * 3 * p->H * p->W * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return SPLICE_ERR_HIP;
+        RC(dev_copy_launch(p->out_copy, y, (size_t)p->N * 3 * p->H * p->W * sizeof(float), s));
         p->forward_saved = 1;
     }
     const hipError_t e = hipGetLastError();

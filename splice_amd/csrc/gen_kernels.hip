@@ -582,7 +582,12 @@ int sigmoid_bwd_launch(const float* dout, const float* sout, float* dpre, size_t
 // util/util.py:28-32: no weight decay / amsgrad, eps added after sqrt(v_hat)).  Also clears the
 // gradient (optimizer.zero_grad, train.py:56) when zero_grad != 0.
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
-                            float b1, float b2, float eps, float bc1, float bc2_sqrt, int zero_grad) {
+                            float b1, float b2, float eps, float bc1, float bc2_sqrt, int zero_grad, const int* __restrict__ step_ptr) {
+    if (step_ptr) {   // step count lives on the device (graph replay): bias corrections computed here
+        const float t = (float)*step_ptr;
+        bc1 = 1.0f - powf(b1, t);
+        bc2_sqrt = sqrtf(1.0f - powf(b2, t));
+    }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float gi = g[i];
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -600,6 +605,19 @@ int adam_launch(float* p, float* g, float* m, float* v, size_t n, float lr, floa
     const float bc2 = 1.0f - powf(b2, (float)step);
     size_t g_ = (n + 255) / 256;
     if (g_ > 2048) g_ = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g_), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), zero_grad);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g_), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), zero_grad, (const int*)nullptr);
+    return SPLICE_OK;
+}
+// same, the step count t (>= 1) read from device memory at execution time
+int adam_launch_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, const int* step_dev,
+                    int zero_grad, hipStream_t s) {
+    size_t g_ = (n + 255) / 256;
+    if (g_ > 2048) g_ = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g_), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, 1.f, 1.f, zero_grad, step_dev);
+    return SPLICE_OK;
+}
+__global__ void set_int_kernel(int* p, int v) { *p = v; }
+int set_int_launch(int* p, int v, hipStream_t s) {
+    hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, p, v);
     return SPLICE_OK;
 }

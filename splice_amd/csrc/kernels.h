@@ -47,6 +47,9 @@ int cast_f32_bf16_launch(const float* x, bf16_t* y, size_t n, hipStream_t s);
 int cast_bf16_f32_launch(const bf16_t* x, float* y, size_t n, hipStream_t s);
 int transpose_f32_to_bf16_launch(const float* x, bf16_t* y, int rows, int cols, int ldy, hipStream_t s);  // y[c][r]
 int fill_f32_launch(float* x, float v, size_t n, hipStream_t s);
+// kernel-based copy / zero (graph-capture safe replacements of hipMemcpyAsync / hipMemsetAsync, bytes % 4 == 0)
+int dev_copy_launch(void* dst, const void* src, size_t bytes, hipStream_t s);
+int dev_zero_launch(void* dst, size_t bytes, hipStream_t s);
 // torchvision-0.10 tensor Resize = F.interpolate(bilinear, align_corners=False, no antialias) on [N][C][h][w]
 // (util/losses.py:20,77-78); backward is the exact adjoint in gather form (deterministic).
 int resize_bilinear_fwd_launch(const float* in, float* out, int planes, int h, int w, int oh, int ow, hipStream_t s);

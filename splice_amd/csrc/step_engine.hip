@@ -6,6 +6,13 @@
 // generated images and only data gradients.  Nothing is cached across steps.
 #include <vector>
 
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+
+#include "gen_kernels.h"
 #include "kernels.h"
 
 void splice_set_error(const char* fmt, ...);
@@ -22,6 +29,7 @@ int splice_gen_forward(void* plan, const float* params, const float* x, float* y
 int splice_gen_backward(void* plan, const float* params, const float* dy, float* grads, int accumulate, splice_stream_t stream);
 int splice_adam_step(float* params, float* grads, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                      int step, int zero_grad, splice_stream_t stream);
+int splice_prof_active(void);
 }
 
 #define RC(x)                                                                                     \
@@ -70,8 +78,21 @@ struct SpliceStep {
     float* losses = nullptr;     // [8] raw per-term losses of the current step
     std::vector<void*> allocs;
     int max_crop_h = 0, max_crop_w = 0;
+    // graph replay
+    float* in_b = nullptr;       // staging for B_crop when the crops are split (A_crop stages in gen_in)
+    float* ent_in = nullptr;     // staging for the entire structure image
+    int* dev_t = nullptr;        // Adam step count on the device
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    std::map<int, hipGraphExec_t> graphs;
+    void* graph_ptrs[4] = {nullptr, nullptr, nullptr, nullptr};
+    int graph_crops[4] = {0, 0, 0, 0};
+    int use_graph = 1;
+    int dbg_sync = 0, dbg_own_eager = 0;
     int ssim_id_on = 0;          // lambda_global_ssim / lambda_global_identity switched on (util/losses.py:35-37)
 };
+
+static void drop_graphs(SpliceStep* st);
 
 template <class T>
 static int salloc(SpliceStep* st, T** p, size_t n) {
@@ -109,14 +130,14 @@ __global__ void total_loss_kernel(float* l, float w_ssim, float w_essim, float w
 
 static int place_image(const float* src, int h, int w, float* dst, int oh, int ow, hipStream_t s) {
     if (h == oh && w == ow) {   // Resize returns its input when the shorter edge already matches
-        HIPCHK(hipMemcpyAsync(dst, src, (size_t)3 * h * w * sizeof(float), hipMemcpyDeviceToDevice, s));
+        RC(dev_copy_launch(dst, src, (size_t)3 * h * w * sizeof(float), s));
         return SPLICE_OK;
     }
     return resize_bilinear_fwd_launch(src, dst, 3, h, w, oh, ow, s);
 }
 static int unplace_grad(const float* dsrc, int oh, int ow, float* ddst, int h, int w, hipStream_t s) {
     if (h == oh && w == ow) {
-        HIPCHK(hipMemcpyAsync(ddst, dsrc, (size_t)3 * h * w * sizeof(float), hipMemcpyDeviceToDevice, s));
+        RC(dev_copy_launch(ddst, dsrc, (size_t)3 * h * w * sizeof(float), s));
         return SPLICE_OK;
     }
     return resize_bilinear_bwd_launch(dsrc, ddst, 3, h, w, oh, ow, s);
@@ -177,6 +198,18 @@ int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void
     if ((rc = salloc(st, &wsb, selfsim_ws_bytes(Tmax, st->vg.D))) != SPLICE_OK) return fail(rc);
     st->ssim_ws = wsb;
     if ((rc = salloc(st, &st->losses, 8)) != SPLICE_OK) return fail(rc);
+    if ((rc = salloc(st, &st->in_b, crop)) != SPLICE_OK) return fail(rc);
+    if (cfg->ent_h > 0 && (rc = salloc(st, &st->ent_in, (size_t)3 * cfg->ent_h * cfg->ent_w)) != SPLICE_OK) return fail(rc);
+    if ((rc = salloc(st, &st->dev_t, 4)) != SPLICE_OK) return fail(rc);
+    if (const char* e = getenv("SPLICE_STEP_GRAPH")) st->use_graph = atoi(e);
+    if (const char* e = getenv("SPLICE_STEP_SYNC")) st->dbg_sync = atoi(e);
+    if (const char* e = getenv("SPLICE_STEP_OWN_EAGER")) st->dbg_own_eager = atoi(e);
+    if (hipStreamCreateWithFlags(&st->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&st->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&st->ev_out, hipEventDisableTiming) != hipSuccess) {
+        splice_set_error("splice_step_create: stream/event creation failed");
+        return fail(SPLICE_ERR_HIP);
+    }
     *out = st;
     return SPLICE_OK;
 }
@@ -184,7 +217,11 @@ int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void
 void splice_step_destroy(void* h) {
     SpliceStep* st = (SpliceStep*)h;
     if (!st) return;
-    for (void* q : st->allocs) hipFree(q);
+    drop_graphs(st);
+    if (st->own_stream) { (void)hipStreamSynchronize(st->own_stream); (void)hipStreamDestroy(st->own_stream); }
+    if (st->ev_in) (void)hipEventDestroy(st->ev_in);
+    if (st->ev_out) (void)hipEventDestroy(st->ev_out);
+    for (void* q : st->allocs) (void)hipFree(q);
     delete st;
 }
 
@@ -239,30 +276,20 @@ int splice_step_set_crops(void* h, int a_h, int a_w, int b_h, int b_w) {
     return SPLICE_OK;
 }
 
-// One step.  step_idx is the reference's data step counter (0-based, data/Dataset.py:57,63).
-// params/grads/m/v: flat generator arenas.  losses_out: device fp32[8] =
-// {loss, loss_global_ssim, loss_entire_ssim, loss_entire_cls, loss_global_cls, loss_global_id_B, 0, 0}
-// (inactive terms are 0).  A_entire may be NULL on steps where step_idx % entire_every != 0.
-int splice_step_run(void* h, float* params, float* grads, float* m, float* v, const float* A_crop, const float* B_crop,
-                    const float* A_entire, int step_idx, float* losses_out, splice_stream_t stream) {
-    SpliceStep* st = (SpliceStep*)h;
-    if (!st || !params || !grads || !m || !v || !A_crop || !B_crop || step_idx < 0) return SPLICE_ERR_ARG;
-    hipStream_t s = (hipStream_t)stream;
+// ---- the launch sequence of one step (capturable: no allocation, no host sync, internal pointers only)
+static int step_body(SpliceStep* st, float* params, float* grads, float* m, float* v, bool ssim_on, bool entire, bool split,
+                     hipStream_t s) {
     const splice_step_config& c = st->cfg;
     VitView& vg = st->vg;
-    // ---- lambda schedule (util/losses.py:34-44)
-    if (step_idx == c.cls_warmup) st->ssim_id_on = 1;
-    const bool entire = c.ent_h > 0 && c.entire_every > 0 && (step_idx % c.entire_every == 0);
-    if (entire && !A_entire) { splice_set_error("splice_step_run: step %d needs the entire structure image", step_idx); return SPLICE_ERR_ARG; }
-    const float l_ssim = st->ssim_id_on ? c.lambda_global_ssim : 0.f, l_id = st->ssim_id_on ? c.lambda_global_identity : 0.f;
+    const float l_ssim = ssim_on ? c.lambda_global_ssim : 0.f, l_id = ssim_on ? c.lambda_global_identity : 0.f;
     const float l_cls = c.lambda_global_cls;
     const float l_essim = entire ? c.lambda_entire_ssim : 0.f, l_ecls = entire ? c.lambda_entire_cls : 0.f;
     const size_t crop = (size_t)3 * c.crop_h * c.crop_w, vimg = (size_t)3 * vg.H * vg.W;
-    const bool split = c.crop_h != st->cropb_h || c.crop_w != st->cropb_w;
+    const float* A_crop = st->gen_in;
+    const float* B_crop = split ? st->in_b : st->gen_in + crop;
+    const float* A_entire = st->ent_in;
     // ---- Model.forward: x_global = G(A_crop), y_global = G(B_crop) [, x_entire = G(A)]
     if (!split) {
-        HIPCHK(hipMemcpyAsync(st->gen_in, A_crop, crop * sizeof(float), hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync(st->gen_in + crop, B_crop, crop * sizeof(float), hipMemcpyDeviceToDevice, s));
         RC(splice_gen_forward(st->plan_g, params, st->gen_in, st->gen_out, s));
     } else {
         RC(splice_gen_forward(st->plan_a, params, A_crop, st->gen_out, s));
@@ -277,9 +304,9 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
     float *blk_g = nullptr, *qkv_g = nullptr;
     RC(splice_vit_get_tensor(vg.ctx, 0, vg.depth - 1, (void**)&blk_g));
     RC(splice_vit_get_tensor(vg.ctx, 3, vg.depth - 1, (void**)&qkv_g));
-    HIPCHK(hipMemsetAsync(st->losses, 0, 8 * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(vg.d_block, 0, (size_t)vg.rows * vg.D * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(vg.d_keys, 0, (size_t)vg.rows * vg.D * sizeof(float), s));
+    RC(dev_zero_launch(st->losses, 8 * sizeof(float), s));
+    RC(dev_zero_launch(vg.d_block, (size_t)vg.rows * vg.D * sizeof(float), s));
+    RC(dev_zero_launch(vg.d_keys, (size_t)vg.rows * vg.D * sizeof(float), s));
     const size_t passD = (size_t)vg.Tld * vg.D;
     // ---- losses on the global batch: passes 0 A', 1 B', 2 x', 3 y'
     if (l_ssim > 0.f) RC(ssim_term(st, vg, qkv_g, 0, 2, l_ssim, L_GLOBAL_SSIM, s));
@@ -299,8 +326,8 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
         float *blk_e = nullptr, *qkv_e = nullptr;
         RC(splice_vit_get_tensor(ve.ctx, 0, ve.depth - 1, (void**)&blk_e));
         RC(splice_vit_get_tensor(ve.ctx, 3, ve.depth - 1, (void**)&qkv_e));
-        HIPCHK(hipMemsetAsync(ve.d_block, 0, (size_t)ve.rows * ve.D * sizeof(float), s));
-        HIPCHK(hipMemsetAsync(ve.d_keys, 0, (size_t)ve.rows * ve.D * sizeof(float), s));
+        RC(dev_zero_launch(ve.d_block, (size_t)ve.rows * ve.D * sizeof(float), s));
+        RC(dev_zero_launch(ve.d_keys, (size_t)ve.rows * ve.D * sizeof(float), s));
         const size_t epassD = (size_t)ve.Tld * ve.D;
         if (l_essim > 0.f) RC(ssim_term(st, ve, qkv_e, 0, 1, l_essim, L_ENTIRE_SSIM, s));
         if (l_ecls > 0.f)   // target is the B_global crop's CLS (util/losses.py:60)
@@ -324,11 +351,115 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
         RC(splice_gen_backward(st->plan_e, params, st->d_ent_out, grads, 1, s));
     }
     hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(64), 0, s, st->losses, l_ssim, l_essim, l_ecls, l_cls, l_id);
+    // ---- optimizer.step() (train.py:79); Adam's step count (>= 1) is read from the device at execution time
+    RC(adam_launch_dev(params, grads, m, v, (size_t)st->nparams, c.lr, c.beta1, c.beta2, c.eps, st->dev_t, 0, s));
+    return SPLICE_OK;
+}
+
+static void drop_graphs(SpliceStep* st) {
+    for (auto& kv : st->graphs) (void)hipGraphExecDestroy(kv.second);
+    st->graphs.clear();
+}
+
+// One step.  step_idx is the reference's data step counter (0-based, data/Dataset.py:57,63).
+// params/grads/m/v: flat generator arenas.  losses_out: device fp32[8] =
+// {loss, loss_global_ssim, loss_entire_ssim, loss_entire_cls, loss_global_cls, loss_global_id_B, 0, 0}
+// (inactive terms are 0).  A_entire may be NULL on steps where step_idx % entire_every != 0.
+// The launch sequence (~500 kernels) is captured once per regime (first step / ordinary / entire-image,
+// equal or split crops) into a hipGraph and replayed; inputs are staged into handle-owned buffers first
+// so the graph only ever sees the same pointers.
+int splice_step_run(void* h, float* params, float* grads, float* m, float* v, const float* A_crop, const float* B_crop,
+                    const float* A_entire, int step_idx, float* losses_out, splice_stream_t stream) {
+    SpliceStep* st = (SpliceStep*)h;
+    if (!st || !params || !grads || !m || !v || !A_crop || !B_crop || step_idx < 0) return SPLICE_ERR_ARG;
+    hipStream_t caller = (hipStream_t)stream;
+    const splice_step_config& c = st->cfg;
+    // ---- lambda schedule (util/losses.py:34-44)
+    if (step_idx == c.cls_warmup) st->ssim_id_on = 1;
+    const bool entire = c.ent_h > 0 && c.entire_every > 0 && (step_idx % c.entire_every == 0);
+    if (entire && !A_entire) { splice_set_error("splice_step_run: step %d needs the entire structure image", step_idx); return SPLICE_ERR_ARG; }
+    const bool split = c.crop_h != st->cropb_h || c.crop_w != st->cropb_w;
+    const bool graph = st->use_graph && !splice_prof_active();
+    const bool own = graph || st->dbg_own_eager;
+    hipStream_t s = caller;
+    if (own) {   // graphs cannot be captured on the legacy default stream: run on the handle's own stream, fenced by events
+        s = st->own_stream;
+        HIPCHK(hipEventRecord(st->ev_in, caller));
+        HIPCHK(hipStreamWaitEvent(s, st->ev_in, 0));
+    }
+    // ---- stage the inputs (eager)
+    const size_t crop = (size_t)3 * c.crop_h * c.crop_w, cropb = (size_t)3 * st->cropb_h * st->cropb_w;
+    HIPCHK(hipMemcpyAsync(st->gen_in, A_crop, crop * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(split ? st->in_b : st->gen_in + crop, B_crop, cropb * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (entire) HIPCHK(hipMemcpyAsync(st->ent_in, A_entire, (size_t)3 * c.ent_h * c.ent_w * sizeof(float), hipMemcpyDeviceToDevice, s));
+    RC(set_int_launch(st->dev_t, step_idx + 1, s));
+    if (!graph) {
+        RC(step_body(st, params, grads, m, v, st->ssim_id_on != 0, entire, split, s));
+    } else {
+        void* ptrs[4] = {params, grads, m, v};
+        const int crops[4] = {c.crop_h, c.crop_w, st->cropb_h, st->cropb_w};
+        if (memcmp(ptrs, st->graph_ptrs, sizeof(ptrs)) || memcmp(crops, st->graph_crops, sizeof(crops))) {
+            drop_graphs(st);
+            memcpy(st->graph_ptrs, ptrs, sizeof(ptrs));
+            memcpy(st->graph_crops, crops, sizeof(crops));
+        }
+        const int variant = (st->ssim_id_on ? 1 : 0) | (entire ? 2 : 0) | (split ? 4 : 0);
+        auto it = st->graphs.find(variant);
+        if (it == st->graphs.end()) {
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            const int rc = step_body(st, params, grads, m, v, st->ssim_id_on != 0, entire, split, s);
+            const hipError_t ee = hipStreamEndCapture(s, &g);
+            if (rc != SPLICE_OK || ee != hipSuccess || !g) {
+                if (g) (void)hipGraphDestroy(g);
+                if (rc == SPLICE_OK) splice_set_error("splice_step_run: graph capture failed (%s)", hipGetErrorString(ee));
+                return rc != SPLICE_OK ? rc : SPLICE_ERR_HIP;
+            }
+            if (getenv("SPLICE_STEP_GRAPH_DEBUG")) {
+                size_t nn = 0, ne = 0, nr = 0;
+                (void)hipGraphGetNodes(g, nullptr, &nn);
+                (void)hipGraphGetEdges(g, nullptr, nullptr, &ne);
+                (void)hipGraphGetRootNodes(g, nullptr, &nr);
+                std::vector<hipGraphNode_t> nodes(nn);
+                (void)hipGraphGetNodes(g, nodes.data(), &nn);
+                int kinds[16] = {0};
+                size_t multi_dep = 0, no_dep = 0;
+                for (auto n : nodes) {
+                    hipGraphNodeType ty;
+                    if (hipGraphNodeGetType(n, &ty) == hipSuccess && (int)ty < 16) kinds[(int)ty]++;
+                    size_t nd = 0;
+                    (void)hipGraphNodeGetDependencies(n, nullptr, &nd);
+                    if (nd > 1) multi_dep++;
+                    if (nd == 0) no_dep++;
+                }
+                fprintf(stderr, "[splice graph] variant %d: nodes %zu edges %zu roots %zu nodes-without-deps %zu multi-dep %zu | kernel %d memcpy %d memset %d other %d\n",
+                        variant, nn, ne, nr, no_dep, multi_dep, kinds[hipGraphNodeTypeKernel], kinds[hipGraphNodeTypeMemcpy], kinds[hipGraphNodeTypeMemset],
+                        (int)nn - kinds[hipGraphNodeTypeKernel] - kinds[hipGraphNodeTypeMemcpy] - kinds[hipGraphNodeTypeMemset]);
+            }
+            hipGraphExec_t ex = nullptr;
+            const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (ei != hipSuccess) { splice_set_error("splice_step_run: hipGraphInstantiate: %s", hipGetErrorString(ei)); return SPLICE_ERR_HIP; }
+            it = st->graphs.emplace(variant, ex).first;
+        }
+        HIPCHK(hipGraphLaunch(it->second, s));
+    }
     if (losses_out) HIPCHK(hipMemcpyAsync(losses_out, st->losses, 8 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    // ---- optimizer.step() (train.py:79); Adam's own step counter starts at 1
-    RC(splice_adam_step(params, grads, m, v, st->nparams, c.lr, c.beta1, c.beta2, c.eps, step_idx + 1, 0, s));
+    if (own) {
+        HIPCHK(hipEventRecord(st->ev_out, s));
+        HIPCHK(hipStreamWaitEvent(caller, st->ev_out, 0));
+    }
+    if (st->dbg_sync) HIPCHK(hipStreamSynchronize(s));
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { splice_set_error("splice_step_run: %s", hipGetErrorString(e)); return SPLICE_ERR_HIP; }
+    return SPLICE_OK;
+}
+
+// 1 = replay captured hipGraphs (default), 0 = launch every kernel eagerly
+int splice_step_use_graph(void* h, int on) {
+    SpliceStep* st = (SpliceStep*)h;
+    if (!st) return SPLICE_ERR_ARG;
+    st->use_graph = on ? 1 : 0;
     return SPLICE_OK;
 }
 }

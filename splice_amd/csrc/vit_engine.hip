@@ -325,6 +325,7 @@ int splice_prof_begin(int which) {
     g_prof.used = 0;
     return SPLICE_OK;
 }
+int splice_prof_active(void) { return g_prof.which != 0; }
 int splice_prof_end(float* total_ms, int* launches) {
     float tot = 0.f;
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
@@ -504,7 +505,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
             }
             g_after_mlp = g;
         } else {
-            HIPCHK(hipMemsetAsync(dqkv, 0, (size_t)R * 3 * D * sizeof(bf16_t), s));
+            RC(dev_zero_launch(dqkv, (size_t)R * 3 * D * sizeof(bf16_t), s));
         }
         if (dq) hipLaunchKernelGGL(add_f32_into_bf16_kernel, dim3(grid_n((size_t)R * 3 * D)), dim3(256), 0, s, dqkv, 3 * D, 0, dq + r0 * 3 * D, 3 * D, R, 3 * D);
         if (dk) hipLaunchKernelGGL(add_f32_into_bf16_kernel, dim3(grid_n((size_t)R * D)), dim3(256), 0, s, dqkv, 3 * D, D, dk + r0 * D, D, R, D);
@@ -517,7 +518,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
         g_live = true;
     }
     if (!g_live) {
-        HIPCHK(hipMemsetAsync(d_img + (size_t)pass_begin * 3 * c->H * c->W, 0, (size_t)Bp * 3 * c->H * c->W * sizeof(float), s));
+        RC(dev_zero_launch(d_img + (size_t)pass_begin * 3 * c->H * c->W, (size_t)Bp * 3 * c->H * c->W * sizeof(float), s));
         return SPLICE_OK;
     }
     {

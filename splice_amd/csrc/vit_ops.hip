@@ -300,3 +300,28 @@ int resize_bilinear_bwd_launch(const float* dout, float* din, int planes, int h,
     hipLaunchKernelGGL(resize_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, dout, din, planes, h, w, oh, ow, (float)h / (float)oh, (float)w / (float)ow);
     return SPLICE_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// Kernel-based device copy / zero (bytes % 4 == 0).  Used inside the step's captured hipGraph instead of
+// hipMemcpyAsync / hipMemsetAsync: on ROCm 7.2 memcpy/memset graph nodes raced with the neighbouring kernel
+// nodes of a purely linear captured chain (intermittent garbage on replay); kernel nodes alone replay cleanly.
+__global__ void dev_copy_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ void dev_zero_kernel(uint32_t* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = 0u;
+}
+int dev_copy_launch(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (bytes & 3) return SPLICE_ERR_ARG;
+    const size_t n = bytes >> 2;
+    if (!n) return SPLICE_OK;
+    hipLaunchKernelGGL(dev_copy_kernel, dim3(grid_for(n)), dim3(256), 0, s, (uint32_t*)dst, (const uint32_t*)src, n);
+    return SPLICE_OK;
+}
+int dev_zero_launch(void* dst, size_t bytes, hipStream_t s) {
+    if (bytes & 3) return SPLICE_ERR_ARG;
+    const size_t n = bytes >> 2;
+    if (!n) return SPLICE_OK;
+    hipLaunchKernelGGL(dev_zero_kernel, dim3(grid_for(n)), dim3(256), 0, s, (uint32_t*)dst, n);
+    return SPLICE_OK;
+}
