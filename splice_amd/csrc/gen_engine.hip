@@ -59,6 +59,7 @@ struct Unit {
     float* d_in = nullptr; size_t d_in_ns = 0;      // grad w.r.t. `in` (null: not needed)
     int d_in_accumulate = 0;
     bool own_out = false;
+    size_t wg_off = 0;   // this layer's region of the wgrad partial workspace (floats)
 };
 
 struct SpliceGen {
@@ -79,6 +80,10 @@ struct SpliceGenPlan {
     float* d_head_pre = nullptr;          // [N][3][H][W]
     float* d_u0 = nullptr;                // grad w.r.t. u_0 (scale-0 output)
     float* wgrad_ws = nullptr;
+    float* conv_ws = nullptr;             // split-K scratch of the small deep convolutions
+    size_t conv_ws_floats = 0;
+    size_t head_wg_off = 0;
+    WgradReduceAll red;                   // filled during a backward, consumed by its single reduce launch
     float* out_copy = nullptr;            // generator output kept for the sigmoid backward
     float* x_copy = nullptr;              // private copy of the input (the caller may free x after forward)
     int forward_saved = 0;
@@ -199,6 +204,7 @@ static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* para
         a.w_jstride = (size_t)u.Cin * u.ks * u.ks; a.w_cstride = (size_t)u.ks * u.ks;
         a.N = N; a.Cin = u.Cin; a.Hi = u.Hi; a.Wi = u.Wi; a.Cout = u.Cout; a.Ho = u.Ho; a.Wo = u.Wo;
         a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2;
+        a.ws = p->conv_ws; a.ws_floats = p->conv_ws_floats;
         RC(conv_launch(a, s));
         y = u.y; y_ns = u.y_ns;
     }
@@ -222,11 +228,16 @@ static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* par
     if (!acc) RC(fill_zero_launch(grads + u.b_off, u.Cout, s));
     {
         WgradArgs a = {};
-        a.x = u.in; a.dy = u.dy; a.ws = p->wgrad_ws;
+        a.x = u.in; a.dy = u.dy;
         a.x_nstride = u.in_ns; a.x_cstride = (size_t)u.Hi * u.Wi; a.dy_nstride = u.y_ns; a.dy_cstride = (size_t)HW;
         a.N = N; a.Cin = u.Cin; a.Hi = u.Hi; a.Wi = u.Wi; a.Cout = u.Cout; a.Ho = u.Ho; a.Wo = u.Wo;
         a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2;
-        RC(conv_wgrad_launch(a, grads + u.w_off, acc, s));
+        a.ws = p->wgrad_ws + u.wg_off;
+        int chunks = 0;
+        RC(conv_wgrad_launch(a, &chunks, s));
+        WgradReduceAll& r = const_cast<SpliceGenPlan*>(p)->red;
+        const int li = r.count++;
+        r.n[li] = u.Cout * u.Cin * u.ks * u.ks; r.chunks[li] = chunks; r.ws_off[li] = (long long)u.wg_off; r.dw_off[li] = (long long)u.w_off;
     }
     if (u.d_in) {
         ConvArgs a = {};
@@ -235,6 +246,7 @@ static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* par
         a.w_jstride = (size_t)u.ks * u.ks; a.w_cstride = (size_t)u.Cin * u.ks * u.ks;
         a.N = N; a.Cin = u.Cout; a.Hi = u.Ho; a.Wi = u.Wo; a.Cout = u.Cin; a.Ho = u.Hi; a.Wo = u.Wi;
         a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2; a.transposed = 1; a.accumulate = u.d_in_accumulate;
+        a.ws = p->conv_ws; a.ws_floats = p->conv_ws_floats;
         RC(conv_launch(a, s));
     }
     return SPLICE_OK;
@@ -310,14 +322,16 @@ int splice_gen_plan_create(void* h, int N, int H, int W, int need_grad, void** o
         if ((rc = mk(p->u_cat[i], 3, 0, 1, (int)catC, (int)catC, hi, wi, hi, wi, true)) != SPLICE_OK) break;
         if ((rc = mk(p->u_up3[i], 4, 3, 1, (int)catC, UP[i], hi, wi, hi, wi, true)) != SPLICE_OK) break;
         if ((rc = mk(p->u_up1[i], 5, 1, 1, UP[i], UP[i], hi, wi, hi, wi, true)) != SPLICE_OK) break;
-        for (Unit* u : {&p->u_skip[i], &p->u_da[i], &p->u_db[i], &p->u_up3[i], &p->u_up1[i]}) { const size_t n = wgrad_ws_need(p, *u); if (n > ws_need) ws_need = n; }
+        for (Unit* u : {&p->u_skip[i], &p->u_da[i], &p->u_db[i], &p->u_up3[i], &p->u_up1[i]}) { u->wg_off = ws_need; ws_need += wgrad_ws_need(p, *u); }
     }
     if (rc != SPLICE_OK) return fail();
     {
-        const size_t n = (size_t)N * ((H * W + 63) / 64) * 3 * UP[0];
-        if (n > ws_need) ws_need = n;
+        p->head_wg_off = ws_need;
+        ws_need += (size_t)N * ((H * W + 63) / 64) * 3 * UP[0];
     }
     if ((rc = palloc(p, &p->x_copy, (size_t)N * 3 * H * W)) != SPLICE_OK) return fail();
+    p->conv_ws_floats = (size_t)16 * N * 132 * 8192;   // split-K is only chosen for layers with < 128 tiles (<= 8192 pixels)
+    if ((rc = palloc(p, &p->conv_ws, p->conv_ws_floats)) != SPLICE_OK) return fail();
     if (need_grad) {
         if ((rc = palloc(p, &p->wgrad_ws, ws_need)) != SPLICE_OK) return fail();
         if ((rc = palloc(p, &p->d_head_pre, (size_t)N * 3 * H * W)) != SPLICE_OK) return fail();
@@ -426,16 +440,22 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
     }
     hipStream_t s = (hipStream_t)stream;
     const size_t npix = (size_t)p->N * 3 * p->H * p->W;
+    p->red.count = 0;
     RC(sigmoid_bwd_launch(dy, p->out_copy, p->d_head_pre, npix, s));
     const Unit& u = p->u_up1[0];
     const int HW = p->H * p->W;
     RC(channel_sum_launch(p->d_head_pre, (size_t)3 * HW, p->N, 3, HW, grads + p->head_b, accumulate, s));
     {
         WgradArgs a = {};
-        a.x = u.out; a.dy = p->d_head_pre; a.ws = p->wgrad_ws;
+        a.x = u.out; a.dy = p->d_head_pre;
         a.x_nstride = u.out_ns; a.x_cstride = (size_t)HW; a.dy_nstride = (size_t)3 * HW; a.dy_cstride = (size_t)HW;
         a.N = p->N; a.Cin = UP[0]; a.Hi = p->H; a.Wi = p->W; a.Cout = 3; a.Ho = p->H; a.Wo = p->W; a.ks = 1; a.stride = 1; a.pad = 0;
-        RC(conv_wgrad_launch(a, grads + p->head_w, accumulate, s));
+        a.ws = p->wgrad_ws + p->head_wg_off;
+        int chunks = 0;
+        RC(conv_wgrad_launch(a, &chunks, s));
+        WgradReduceAll& r = p->red;
+        const int li = r.count++;
+        r.n[li] = 3 * UP[0]; r.chunks[li] = chunks; r.ws_off[li] = (long long)p->head_wg_off; r.dw_off[li] = (long long)p->head_w;
     }
     {
         ConvArgs a = {};
@@ -446,6 +466,13 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
         RC(conv_launch(a, s));
     }
     RC(scale_backward(p, 0, params, grads, accumulate, s));
+    {   // one deterministic reduction of every layer's per-chunk weight-gradient partials
+        WgradReduceAll& r = p->red;
+        r.prefix[0] = 0;
+        for (int i = 0; i < r.count; ++i) r.prefix[i + 1] = r.prefix[i] + r.n[i];
+        r.total = r.prefix[r.count];
+        RC(wgrad_reduce_all_launch(r, p->wgrad_ws, grads, accumulate, s));
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { splice_set_error("splice_gen_backward: %s", hipGetErrorString(e)); return SPLICE_ERR_HIP; }
     return SPLICE_OK;

@@ -14,6 +14,9 @@ struct ConvArgs {
     int act;          // 1 = sigmoid
     int transposed;   // data-gradient form
     int accumulate;   // out += result
+    float* ws;        // optional split-K scratch (ws_floats floats); null disables split-K
+    size_t ws_floats;
+    int ksplit;       // set by the launcher
 };
 int conv_launch(const ConvArgs& a, hipStream_t s);
 
@@ -26,7 +29,18 @@ struct WgradArgs {
     int pix_per_chunk, chunks_per_img;   // filled by the launcher
 };
 int wgrad_chunks(int N, int Ho, int Wo, int* pix_per_chunk, int* chunks_per_img);
-int conv_wgrad_launch(WgradArgs a, float* dw, int accumulate, hipStream_t s);
+int conv_wgrad_launch(WgradArgs a, int* chunks_out, hipStream_t s);   // writes per-chunk partials into a.ws
+
+constexpr int WGRAD_MAX_LAYERS = 32;
+struct WgradReduceAll {      // by-value kernel argument: one entry per conv layer of a backward
+    long long prefix[WGRAD_MAX_LAYERS + 1];   // prefix sums of n (output elements), prefix[count] = total
+    long long ws_off[WGRAD_MAX_LAYERS];       // offset of the layer's partials in the workspace (floats)
+    long long dw_off[WGRAD_MAX_LAYERS];       // offset of the layer's weight gradient in the arena
+    int n[WGRAD_MAX_LAYERS], chunks[WGRAD_MAX_LAYERS];
+    long long total;
+    int count;
+};
+int wgrad_reduce_all_launch(const WgradReduceAll& d, const float* ws, float* grads, int accumulate, hipStream_t s);
 
 // train-mode BatchNorm (+LeakyReLU when slope != 1) forward: statistics in two deterministic stages
 // (per-segment partials, recombined in the apply kernel); `part` = bn_part_floats(N, C) floats of scratch.

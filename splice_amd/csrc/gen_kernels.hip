@@ -34,14 +34,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     __shared__ float Ws[BN * LDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int img = blockIdx.z;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = blockIdx.x * BM;
     const int HWo = a.Ho * a.Wo;
     const float* in = a.in + (size_t)img * a.in_nstride;
     const int pl = tid & 63;
     const int p = m0 + pl;
     const bool pvalid = p < HWo;
     const int oy = pvalid ? p / a.Wo : 0, ox = pvalid ? p % a.Wo : 0;
-    const int Kc = a.Cin;  // reduction channels
+    // split-K: blockIdx.y = n_tile * ksplit + slice; each slice reduces its own channel range and writes a raw
+    // partial tile that conv_splitk_reduce_kernel sums in slice order (tiny deep layers: few tiles, long reductions)
+    const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
+    const int kslice = blockIdx.y % ksplit;
+    const int n0 = (blockIdx.y / ksplit) * BN;
+    const int cper = ((a.Cin + ksplit - 1) / ksplit + CK - 1) / CK * CK;
+    const int cbeg = kslice * cper;
+    const int Kc = min(a.Cin, cbeg + cper);  // reduction channels [cbeg, Kc)
     // ---- per-thread gather descriptors (k = wave + 4*i is wave-uniform)
     int a_off[NA], a_cl[NA];
     unsigned a_ok = 0;
@@ -97,8 +104,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     f32x4 acc[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    fetch(0);
-    for (int c0 = 0; c0 < Kc; c0 += CK) {
+    fetch(cbeg);
+    for (int c0 = cbeg; c0 < Kc; c0 += CK) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NA; ++i) As[(wave + 4 * i) * LDA + pl] = av[i];
@@ -118,6 +125,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
     }
     // epilogue: acc[j][r] = out[n = n0 + j*16 + (lane&15)][pixel = m0 + wave*16 + (lane>>4)*4 + r]
+    if (ksplit > 1) {
+        float* wsp = a.ws + (((size_t)kslice * a.N + img) * a.Cout) * HWo;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + j * 16 + (lane & 15);
+            if (n >= a.Cout) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pp = m0 + wave * 16 + (lane >> 4) * 4 + r;
+                if (pp < HWo) wsp[(size_t)n * HWo + pp] = acc[j][r];
+            }
+        }
+        return;
+    }
     float* out = a.out + (size_t)img * a.out_nstride;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
@@ -137,15 +158,47 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 }
 
-template <int KS, bool TR, int CK>
-static void conv_launch_fn(const ConvArgs& a, hipStream_t s) {
+// out = (accumulate ? out : 0) + bias + sum_slices ws   (slice order fixed)
+__global__ void conv_splitk_reduce_kernel(ConvArgs a, int ksplit) {
     const int HWo = a.Ho * a.Wo;
-    if (a.Cout <= 16) {
-        hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1, CK>), dim3(cdiv(HWo, 64), 1, a.N), dim3(256), 0, s, a);
-    } else if (a.Cout <= 32) {
-        hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 2, CK>), dim3(cdiv(HWo, 64), 1, a.N), dim3(256), 0, s, a);
-    } else {
-        hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 4, CK>), dim3(cdiv(HWo, 64), cdiv(a.Cout, 64), a.N), dim3(256), 0, s, a);
+    const size_t per = (size_t)a.N * a.Cout * HWo;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) {
+        const int pp = i % HWo;
+        const int n = (i / HWo) % a.Cout;
+        const int img = i / ((size_t)HWo * a.Cout);
+        float v = a.bias ? a.bias[n] : 0.f;
+        for (int k = 0; k < ksplit; ++k) v += a.ws[(size_t)k * per + i];
+        if (a.act == 1) v = 1.0f / (1.0f + __expf(-v));
+        float* q = a.out + (size_t)img * a.out_nstride + (size_t)n * a.out_cstride + pp;
+        *q = a.accumulate ? *q + v : v;
+    }
+}
+
+template <int KS, bool TR, int CK>
+static void conv_launch_fn(ConvArgs a, hipStream_t s) {
+    const int HWo = a.Ho * a.Wo;
+    const int mt = cdiv(HWo, 64);
+    const int fn = a.Cout <= 16 ? 1 : (a.Cout <= 32 ? 2 : 4);
+    const int nt = cdiv(a.Cout, 16 * fn);
+    const int wgs = mt * nt * a.N;
+    int ksplit = 1;
+    const int ktiles = cdiv(a.Cin, CK);
+    if (a.ws && wgs < 128 && ktiles >= 4 && (size_t)a.N * a.Cout * HWo * 16 <= a.ws_floats) {
+        ksplit = cdiv(256, wgs);
+        if (ksplit > ktiles / 2) ksplit = ktiles / 2;
+        if (ksplit > 16) ksplit = 16;
+        if (ksplit < 2) ksplit = 1;
+    }
+    a.ksplit = ksplit;
+    dim3 grid(mt, nt * ksplit, a.N);
+    if (fn == 1) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1, CK>), grid, dim3(256), 0, s, a);
+    else if (fn == 2) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 2, CK>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 4, CK>), grid, dim3(256), 0, s, a);
+    if (ksplit > 1) {
+        const size_t per = (size_t)a.N * a.Cout * HWo;
+        size_t g = (per + 255) / 256;
+        if (g > 1024) g = 1024;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, a, ksplit);
     }
 }
 
@@ -166,8 +219,9 @@ int conv_launch(const ConvArgs& a, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------
 // Weight gradient: dW[n][c][tap] = sum_{img,pixel} dy[n][pixel] * x[c][tap-shifted pixel].
-// Workgroup = (pixel chunk, 4-or-16-channel K tile); MFMA reduces over pixels; the partial
-// tile goes to ws[chunk][n][k] and wgrad_reduce_kernel sums chunks in a fixed order.
+// Workgroup = (pixel chunk, 4-or-16-channel K tile); MFMA reduces over pixels (64 per LDS fill, the next
+// fill prefetched into registers); the partial tile goes to ws[chunk][n][c][tap] and ONE
+// wgrad_reduce_all_kernel per backward sums every layer's chunks in a fixed order (bit-reproducible).
 template <int KS, int NI>   // NI = 16-row fragments of output channels
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int T = KS * KS;
@@ -177,6 +231,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int PC = 64;                     // pixels per LDS fill
     constexpr int LD = PC + 2;                 // 66 = 2*33
     constexpr int NQ = (NI * NJ + 3) / 4;      // fragment pairs per wave
+    constexpr int NA = KT / 4;                 // gathered x elements per thread per fill
+    constexpr int ND = NI * 16 * PC / 256;     // dy elements per thread per fill
     __shared__ float Xs[NJ * 16 * LD];         // [k][pixel]
     __shared__ float Ds[NI * 16 * LD];         // [n][pixel]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -184,40 +240,59 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int HWo = a.Ho * a.Wo;
     const int chunks_per_img = a.chunks_per_img;
     const int img = chunk / chunks_per_img, ch_in_img = chunk % chunks_per_img;
-    const float* x = a.x + (size_t)img * a.x_nstride;
+    const float* x = a.x + (size_t)img * a.x_nstride + (size_t)c0 * a.x_cstride;
     const float* dy = a.dy + (size_t)img * a.dy_nstride;
     f32x4 acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // zero the k-padding rows of Xs once (k in [KT, NJ*16))
-    for (int e = tid; e < (NJ * 16 - KT) * LD; e += 256) Xs[KT * LD + e] = 0.f;
+    for (int e = tid; e < (NJ * 16 - KT) * LD; e += 256) Xs[KT * LD + e] = 0.f;   // k-padding rows stay zero
     const int pl = tid & 63;
     const int p_begin = ch_in_img * a.pix_per_chunk;
     const int p_end = min(p_begin + a.pix_per_chunk, HWo);
-    for (int pb = p_begin; pb < p_end; pb += PC) {
-        __syncthreads();
+    // per-thread gather descriptors (k = wave + 4*i is wave-uniform): channel + tap displacement
+    int g_coff[NA], g_dy[NA], g_dx[NA];
+    unsigned g_cok = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int k = wave + 4 * i;
+        const int cl = k / T, tap = k % T;
+        g_coff[i] = (int)(cl * a.x_cstride);
+        g_dy[i] = tap / KS - a.pad;
+        g_dx[i] = tap % KS - a.pad;
+        if (c0 + cl < a.Cin) g_cok |= 1u << i;
+    }
+    float xv[NA], dv[ND];
+    auto fetch = [&](int pb) {
         const int p = pb + pl;
         const bool pvalid = p < p_end;
         const int oy = pvalid ? p / a.Wo : 0, ox = pvalid ? p % a.Wo : 0;
+        const int by = oy * a.stride, bx = ox * a.stride;
 #pragma unroll
-        for (int i = 0; i < KT / 4; ++i) {
-            const int k = wave + 4 * i;
-            const int cl = k / T, tap = k % T;
-            const int ky = tap / KS, kx = tap % KS;
-            const int c = c0 + cl;
-            float v = 0.f;
-            if (pvalid && c < a.Cin) {
-                const int sy = oy * a.stride + ky - a.pad, sx = ox * a.stride + kx - a.pad;
-                if (sy >= 0 && sy < a.Hi && sx >= 0 && sx < a.Wi) v = x[(size_t)c * a.x_cstride + (size_t)sy * a.Wi + sx];
-            }
-            Xs[k * LD + pl] = v;
+        for (int i = 0; i < NA; ++i) {
+            const int sy = by + g_dy[i], sx = bx + g_dx[i];
+            const bool ok = pvalid && ((g_cok >> i) & 1u) && sy >= 0 && sy < a.Hi && sx >= 0 && sx < a.Wi;
+            xv[i] = ok ? x[g_coff[i] + sy * a.Wi + sx] : 0.f;
         }
-        for (int e = tid; e < NI * 16 * PC; e += 256) {
+#pragma unroll
+        for (int t = 0; t < ND; ++t) {
+            const int e = tid + 256 * t;
             const int n = e / PC, q = e % PC;
             const int pp = pb + q;
-            Ds[n * LD + q] = (n < a.Cout && pp < p_end) ? dy[(size_t)n * a.dy_cstride + pp] : 0.f;
+            dv[t] = (n < a.Cout && pp < p_end) ? dy[(size_t)n * a.dy_cstride + pp] : 0.f;
+        }
+    };
+    fetch(p_begin);
+    for (int pb = p_begin; pb < p_end; pb += PC) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NA; ++i) Xs[(wave + 4 * i) * LD + pl] = xv[i];
+#pragma unroll
+        for (int t = 0; t < ND; ++t) {
+            const int e = tid + 256 * t;
+            Ds[(e / PC) * LD + (e % PC)] = dv[t];
         }
         __syncthreads();
+        if (pb + PC < p_end) fetch(pb + PC);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int pair = wave + 4 * q;
@@ -252,12 +327,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int n, int chunks, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += ws[(size_t)c * n + i];
-    dw[i] = accumulate ? dw[i] + s : s;
+// dw[layer][i] (+)= sum_chunk ws[layer][chunk][i] for every conv layer of a backward in one launch
+__global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(WgradReduceAll d, const float* __restrict__ ws, float* __restrict__ grads,
+                                                               int accumulate) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= d.total) return;
+    int l = 0;
+#pragma unroll 1
+    while (l + 1 < d.count && gid >= d.prefix[l + 1]) ++l;
+    const int i = (int)(gid - d.prefix[l]);
+    const int n = d.n[l], chunks = d.chunks[l];
+    const float* p = ws + d.ws_off[l] + i;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // 4 independent chains in a FIXED association order
+    int c = 0;
+    for (; c + 3 < chunks; c += 4) {
+        s0 += p[(size_t)c * n];
+        s1 += p[(size_t)(c + 1) * n];
+        s2 += p[(size_t)(c + 2) * n];
+        s3 += p[(size_t)(c + 3) * n];
+    }
+    for (; c < chunks; ++c) s0 += p[(size_t)c * n];
+    const float s = (s0 + s1) + (s2 + s3);
+    float* q = grads + d.dw_off[l] + i;
+    *q = accumulate ? *q + s : s;
 }
 
 template <int KS>
@@ -280,14 +372,21 @@ int wgrad_chunks(int N, int Ho, int Wo, int* pix_per_chunk, int* chunks_per_img)
     return N * *chunks_per_img;
 }
 
-int conv_wgrad_launch(WgradArgs a, float* dw, int accumulate, hipStream_t s) {
+// partial sums only; returns the number of chunks written (the caller records it for wgrad_reduce_all_launch)
+int conv_wgrad_launch(WgradArgs a, int* chunks_out, hipStream_t s) {
     if (a.Cout > 128 || (a.ks != 1 && a.ks != 3)) return SPLICE_ERR_ARG;
+    if ((size_t)a.Cin * a.x_cstride > 0x7fffffffULL) return SPLICE_ERR_ARG;
     const int chunks = wgrad_chunks(a.N, a.Ho, a.Wo, &a.pix_per_chunk, &a.chunks_per_img);
-    const int T = a.ks * a.ks, CK = a.ks == 3 ? 4 : 16;
+    const int CK = a.ks == 3 ? 4 : 16;
     if (a.ks == 3) wgrad_launch_fn<3>(a, chunks, cdiv(a.Cin, CK), s);
     else wgrad_launch_fn<1>(a, chunks, cdiv(a.Cin, CK), s);
-    const int n = a.Cout * a.Cin * T;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a.ws, dw, n, chunks, accumulate);
+    if (chunks_out) *chunks_out = chunks;
+    return SPLICE_OK;
+}
+
+int wgrad_reduce_all_launch(const WgradReduceAll& d, const float* ws, float* grads, int accumulate, hipStream_t s) {
+    if (d.count < 1 || d.count > WGRAD_MAX_LAYERS) return SPLICE_ERR_ARG;
+    hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3((unsigned)((d.total + 255) / 256)), dim3(256), 0, s, d, ws, grads, accumulate);
     return SPLICE_OK;
 }
 
