@@ -54,8 +54,8 @@ typedef struct splice_gemm_epilogue {
     int ldbf;
     splice_bf16* out_bf_t;    /* transposed [N][ldt] (ldt % 4 == 0) */
     int ldt;
-    splice_bf16* out_pre;     /* [M][ldp] value before GELU (may be NULL) */
-    int ldp;
+    splice_bf16* out_pre;     /* [M][ldp] value before GELU (may be NULL); written for rows >= pre_row_lo */
+    int ldp, pre_row_lo;
     const splice_bf16* aux;   /* [M][ldaux] pre-GELU activations for SPLICE_EPI_GELU_GRAD */
     int ldaux;
     float* out_f32_cols;      /* fp32 copy of columns [col_lo, col_hi): [M][ld_cols] */
@@ -144,6 +144,9 @@ void splice_vit_ctx_destroy(void* ctx);
 int splice_vit_ctx_info(void* ctx, int* T, int* Tld, int* rows);
 /* img fp32 [B][3][H][W]; normalize != 0 fuses transforms.Normalize (util/losses.py:19). */
 int splice_vit_forward(void* ctx, const float* img, int normalize, splice_stream_t stream);
+/* same; passes [0, grad_pass_begin) are no-grad targets (util/losses.py:79,91,101 `with torch.no_grad()`):
+ * tensors only a backward would read are not stored for them */
+int splice_vit_forward_ex(void* ctx, const float* img, int normalize, int grad_pass_begin, splice_stream_t stream);
 /* kind 0: block output l fp32 [rows][D] (models/extractor.py:56-60) | 1: raw qkv l bf16
  * [rows][3D] (:68-72) | 2: attention output l bf16 [rows][D] | 3: last-layer qkv fp32
  * [rows][3D] | 4: lse l fp32 [B][H][Tld] | 5: embedded tokens fp32 [rows][D] */

@@ -19,7 +19,7 @@ class GemmEpilogue(C.Structure):
         ("out_f32", C.c_void_p), ("ldo", C.c_int),
         ("out_bf", C.c_void_p), ("ldbf", C.c_int),
         ("out_bf_t", C.c_void_p), ("ldt", C.c_int),
-        ("out_pre", C.c_void_p), ("ldp", C.c_int),
+        ("out_pre", C.c_void_p), ("ldp", C.c_int), ("pre_row_lo", C.c_int),
         ("aux", C.c_void_p), ("ldaux", C.c_int),
         ("out_f32_cols", C.c_void_p), ("ld_cols", C.c_int), ("col_lo", C.c_int), ("col_hi", C.c_int),
         ("alpha", C.c_float),
@@ -72,6 +72,7 @@ _SIGNATURES = {
     "splice_vit_ctx_destroy": ([_vp], None),
     "splice_vit_ctx_info": ([_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _i),
     "splice_vit_forward": ([_vp, _vp, _i, _vp], _i),
+    "splice_vit_forward_ex": ([_vp, _vp, _i, _i, _vp], _i),
     "splice_vit_get_tensor": ([_vp, _i, _i, C.POINTER(_vp)], _i),
     "splice_vit_read_tensor": ([_vp, _i, _i, _vp, _sz, _vp], _i),
     "splice_vit_backward": ([_vp, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp, _i, _vp], _i),

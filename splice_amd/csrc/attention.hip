@@ -19,6 +19,10 @@
 
 
 #define NEG_BIG (-1.0e30f)
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+// softmax runs in base 2: scores are scaled by scale*log2(e) once, probabilities are v_exp_f32 (exp2) directly,
+// and the saved log-sum-exp is kept in log2 units (lse2 = m2 + log2(l)); the backward uses exp2(s*c - lse2).
 
 __device__ __forceinline__ uint4 ld16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ uint4 ld8x2(const bf16_t* p) {  // tokens [0,4) and [16,20) relative to p
@@ -133,6 +137,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     }
     const bf16_t* kbase = qkv_b + a.D + h * 64;
     const bf16_t* vT = a.qkvT + (size_t)(2 * a.D + h * 64) * a.ldt + (size_t)b * a.Tld;
+    const float c2 = a.scale * LOG2E;
     TileLoader L;
     u32x4 kr[2], vr[2];
     load_row_tile(L, kbase, ld, 0, a.Tld - 1, kr);
@@ -148,6 +153,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         }
         const int nsub = (kt + 32 < a.Tld) ? 2 : 1;
         for (int sub = 0; sub < nsub; ++sub) {
+            const bool tail = kt + sub * 32 + 32 > a.T;
             u32x4 kf[2][2], vf[4];
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
@@ -166,36 +172,48 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                     s[nb] = mfma16(kf[nb][1], qf[qb][1], s[nb]);
                 }
                 float mx = NEG_BIG;
+                if (tail) {   // only the last key tile of a pass holds padding keys (wave-uniform branch)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kt + sub * 32 + nb * 16 + g * 4 + r;
+                            s[nb][r] = key < a.T ? s[nb][r] * c2 : NEG_BIG;
+                        }
+                } else {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[nb][r] *= c2;
+                }
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kt + sub * 32 + nb * 16 + g * 4 + r;
-                        const float v = key < a.T ? s[nb][r] * a.scale : NEG_BIG;
-                        s[nb][r] = v;
-                        mx = fmaxf(mx, v);
-                    }
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[nb][r]);
                 mx = group4_max(mx);
                 const float mn = fmaxf(m[qb], mx);
-                const float alpha = __expf(m[qb] - mn);
+                const bool grew = mn > m[qb];
+                const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
                 m[qb] = mn;
                 float ps = 0.f;
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float p = __expf(s[nb][r] - mn);
+                        const float p = __builtin_amdgcn_exp2f(s[nb][r] - mn);
                         s[nb][r] = p;
                         ps += p;
                     }
                 l[qb] = l[qb] * alpha + ps;
                 const u32x4 pb = pack8v(s[0], s[1]);
+                if (__any(grew)) {   // the running max rarely moves after the first tiles: skip the accumulator rescale otherwise
 #pragma unroll
-                for (int nd = 0; nd < 4; ++nd) {
+                    for (int nd = 0; nd < 4; ++nd)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[qb][nd][r] *= alpha;
-                    o[qb][nd] = mfma16(vf[nd], pb, o[qb][nd]);
+                        for (int r = 0; r < 4; ++r) o[qb][nd][r] *= alpha;
                 }
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd) o[qb][nd] = mfma16(vf[nd], pb, o[qb][nd]);
             }
         }
     }
@@ -208,7 +226,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             bf16_t* op = a.out + ((size_t)b * a.Tld + q) * a.D + h * 64 + g * 4;
 #pragma unroll
             for (int nd = 0; nd < 4; ++nd) st4bf(op + nd * 16, o[qb][nd], inv);
-            if (g == 0) a.lse[((size_t)b * a.H + h) * a.Tld + q] = m[qb] + __logf(lt);
+            if (g == 0) a.lse[((size_t)b * a.H + h) * a.Tld + q] = m[qb] + __builtin_amdgcn_logf(lt);   // log2 units
         }
     }
 }
@@ -254,6 +272,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
     const int key = blockIdx.x * 64 + wave * 16 + c;
     const int keyc = key < a.Tld ? key : a.Tld - 1;
     const bool key_valid = key < a.T;
+    const float c2 = a.scale * LOG2E;
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.Tld * ld;
     u32x4 kf[2], vf[2];
     {
@@ -313,7 +332,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
                 const f32x4 de = *reinterpret_cast<const f32x4*>(Es + sub * 32 + qb * 16 + g * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = key_valid ? __expf(s[qb][r] * a.scale - ls[r]) : 0.f;
+                    const float p = key_valid ? __builtin_amdgcn_exp2f(s[qb][r] * c2 - ls[r]) : 0.f;
                     s[qb][r] = p;
                     dp[qb][r] = p * (dp[qb][r] - de[r]);
                 }
@@ -356,6 +375,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
         qf[0] = ld16v(pq); qf[1] = ld16v(pq + 32);
         dof[0] = ld16v(pd); dof[1] = ld16v(pd + 32);
     }
+    const float c2 = a.scale * LOG2E;
     const float lse_q = a.lse[((size_t)b * a.H + h) * a.Tld + qc];
     const float del_q = a.delta[((size_t)b * a.H + h) * a.Tld + qc];
     f32x4 dq[4];
@@ -398,7 +418,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt + sub * 32 + nb * 16 + g * 4 + r;
-                    const float p = key < a.T ? __expf(s[nb][r] * a.scale - lse_q) : 0.f;
+                    const float p = key < a.T ? __builtin_amdgcn_exp2f(s[nb][r] * c2 - lse_q) : 0.f;
                     dp[nb][r] = p * (dp[nb][r] - del_q);
                 }
             const u32x4 dsb = pack8v(dp[0], dp[1]);
@@ -430,7 +450,7 @@ __global__ void attn_probs_kernel(AttnArgs a, float* probs) {
         float s = 0.f;
 #pragma unroll
         for (int d = 0; d < 64; ++d) s += qv[d] * bf2f(pk[d]);
-        out[key] = __expf(s * a.scale - lse);
+        out[key] = __builtin_amdgcn_exp2f(s * a.scale * LOG2E - lse);
     }
 }
 

@@ -314,7 +314,7 @@ __device__ __forceinline__ void gemm_epilogue_cols(const GemmEpi& e, int M, int 
         }
     };
     if (FLAGS & EPI_GELU) {
-        if (e.out_pre) store_bf(e.out_pre, e.ldp);
+        if (e.out_pre && row >= e.pre_row_lo) store_bf(e.out_pre, e.ldp);   // only gradient-carrying rows need it
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = gelu_f(x[r]);
     }

@@ -14,6 +14,8 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
     if (g_force_tile == 1) { launch_gemm_nt<128, 128, FLAGS>(s, A, lda, B, ldb, M, N, K, e); return SPLICE_OK; }
     if (g_force_tile == 2) { launch_gemm_nt<128, 64, FLAGS>(s, A, lda, B, ldb, M, N, K, e); return SPLICE_OK; }
     if (g_force_tile == 3) { launch_gemm_nt<64, 64, FLAGS>(s, A, lda, B, ldb, M, N, K, e); return SPLICE_OK; }
+    // measured on MI355X (tools/gemm_bench.py): with N <= 768 the 64x64 tile wins (more workgroups on the long-K shapes)
+    if (N <= 768) { launch_gemm_nt<64, 64, FLAGS>(s, A, lda, B, ldb, M, N, K, e); return SPLICE_OK; }
     if (t128 >= 224) launch_gemm_nt<128, 128, FLAGS>(s, A, lda, B, ldb, M, N, K, e);
     else if (t12864 >= 200) launch_gemm_nt<128, 64, FLAGS>(s, A, lda, B, ldb, M, N, K, e);
     else launch_gemm_nt<64, 64, FLAGS>(s, A, lda, B, ldb, M, N, K, e);

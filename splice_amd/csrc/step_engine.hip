@@ -20,6 +20,7 @@ extern "C" {
 int splice_vit_ctx_info(void* ctx, int* T, int* Tld, int* rows);
 int splice_vit_ctx_dims(void* ctx, int* B, int* H, int* W, int* D, int* depth, int* heads, int* patch);
 int splice_vit_forward(void* ctx, const float* img, int normalize, splice_stream_t stream);
+int splice_vit_forward_ex(void* ctx, const float* img, int normalize, int grad_pass_begin, splice_stream_t stream);
 int splice_vit_get_tensor(void* ctx, int kind, int layer, void** out);
 int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* const* d_block, const float* const* d_qkv,
                         const float* const* d_keys, float* d_img, int normalize, splice_stream_t stream);
@@ -300,7 +301,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     RC(place_image(B_crop, st->cropb_h, st->cropb_w, vg.imgs + 1 * vimg, vg.H, vg.W, s));
     RC(place_image(st->gen_out, c.crop_h, c.crop_w, vg.imgs + 2 * vimg, vg.H, vg.W, s));
     RC(place_image(st->gen_out + crop, st->cropb_h, st->cropb_w, vg.imgs + 3 * vimg, vg.H, vg.W, s));
-    RC(splice_vit_forward(vg.ctx, vg.imgs, 1, s));
+    RC(splice_vit_forward_ex(vg.ctx, vg.imgs, 1, 2, s));
     float *blk_g = nullptr, *qkv_g = nullptr;
     RC(splice_vit_get_tensor(vg.ctx, 0, vg.depth - 1, (void**)&blk_g));
     RC(splice_vit_get_tensor(vg.ctx, 3, vg.depth - 1, (void**)&qkv_g));
@@ -322,7 +323,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         RC(splice_gen_forward(st->plan_e, params, A_entire, st->ent_out, s));
         RC(place_image(A_entire, c.ent_h, c.ent_w, ve.imgs, ve.H, ve.W, s));
         RC(place_image(st->ent_out, c.ent_h, c.ent_w, ve.imgs + eimg, ve.H, ve.W, s));
-        RC(splice_vit_forward(ve.ctx, ve.imgs, 1, s));
+        RC(splice_vit_forward_ex(ve.ctx, ve.imgs, 1, 1, s));
         float *blk_e = nullptr, *qkv_e = nullptr;
         RC(splice_vit_get_tensor(ve.ctx, 0, ve.depth - 1, (void**)&blk_e));
         RC(splice_vit_get_tensor(ve.ctx, 3, ve.depth - 1, (void**)&qkv_e));

@@ -85,6 +85,7 @@ struct SpliceVit {
 struct SpliceVitCtx {
     SpliceVit* vit = nullptr;
     int B = 0, H = 0, W = 0, T = 0, Tld = 0, rows = 0, need_grad = 0;
+    int grad_pass_begin = 0;               // passes below this index never run a backward (targets): skip backward-only saves
     float* pos_eff = nullptr;              // [Tld][D]
     bf16_t* patches = nullptr;             // [rows][3pp]
     std::vector<float*> xs;                // depth+1 x [rows][D]   residual stream (block outputs)
@@ -357,9 +358,16 @@ int splice_vit_ctx_dims(void* ctx, int* B, int* H, int* W, int* D, int* depth, i
 // Forward over the ctx's batch.  img: fp32 [B][3][H][W]; normalize != 0 applies the ImageNet
 // Normalize of util/losses.py:19 on the fly (input in [0,1]); == 0 expects a normalised image
 // (what VitExtractor receives, models/extractor.py:81).
+int splice_vit_forward_ex(void* ctx, const float* img, int normalize, int grad_pass_begin, splice_stream_t stream);
 int splice_vit_forward(void* ctx, const float* img, int normalize, splice_stream_t stream) {
+    return splice_vit_forward_ex(ctx, img, normalize, 0, stream);
+}
+// grad_pass_begin: passes [0, grad_pass_begin) are targets that will never be differentiated -- tensors only the
+// backward reads (the pre-GELU activations) are not stored for them.
+int splice_vit_forward_ex(void* ctx, const float* img, int normalize, int grad_pass_begin, splice_stream_t stream) {
     SpliceVitCtx* c = (SpliceVitCtx*)ctx;
-    if (!c || !img) return SPLICE_ERR_ARG;
+    if (!c || !img || grad_pass_begin < 0 || grad_pass_begin > c->B) return SPLICE_ERR_ARG;
+    c->grad_pass_begin = grad_pass_begin;
     SpliceVit* v = c->vit;
     hipStream_t s = (hipStream_t)stream;
     const int D = v->dim, Hd = v->hidden, pp3 = 3 * v->patch * v->patch, rows = c->rows, L = v->depth;
@@ -395,7 +403,8 @@ int splice_vit_forward(void* ctx, const float* img, int normalize, splice_stream
         RC(layernorm_fwd_launch(c->xmid[l], W.ln2_g, W.ln2_b, c->ln_out, c->mean2[l], c->rstd2[l], rows, D, 1e-6f, s));
         {
             GemmEpi e = {};
-            e.bias = W.fc1.b; e.out_bf = c->hact; e.ldbf = Hd; e.out_pre = c->hpre[l]; e.ldp = Hd;
+            e.bias = W.fc1.b; e.out_bf = c->hact; e.ldbf = Hd; e.out_pre = c->need_grad ? c->hpre[l] : nullptr; e.ldp = Hd;
+            e.pre_row_lo = c->grad_pass_begin * c->Tld;
             ProfScope ps(1, s);
             RC(gemm_nt_launch(EPI_BIAS | EPI_GELU | EPI_OUT_BF, c->ln_out, D, W.fc1.w, D, rows, Hd, D, e, s));
         }
@@ -449,7 +458,7 @@ int splice_vit_read_tensor(void* ctx, int kind, int layer, void* dst, size_t byt
 int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* const* d_block, const float* const* d_qkv,
                         const float* const* d_keys, float* d_img, int normalize, splice_stream_t stream) {
     SpliceVitCtx* c = (SpliceVitCtx*)ctx;
-    if (!c || !c->need_grad || !c->forward_done || pass_begin < 0 || pass_end > c->B || pass_begin >= pass_end || !d_img) {
+    if (!c || !c->need_grad || !c->forward_done || pass_begin < c->grad_pass_begin || pass_end > c->B || pass_begin >= pass_end || !d_img) {
         splice_set_error("splice_vit_backward: bad ctx / range / no forward / ctx created without need_grad");
         return SPLICE_ERR_STATE;
     }
