@@ -144,7 +144,7 @@ def main():
         ach = flops / (avg_ms * 1e-3) / 1e12
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and args.size == 224 and args.model == "dino_vitb8":
             try:
                 traffic = json.load(open(tfile)).get(str(args.prof_kernel))
             except Exception:

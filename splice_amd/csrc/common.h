@@ -11,14 +11,17 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even
-    uint32_t u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even, on gfx950's hardware converter (v_cvt_pk_bf16_f32: one instruction per
+// PAIR; the bit-twiddling form costs ~6 VALU ops per element and dominated the attention / epilogue VALU time)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    const __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, h);
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -71,6 +74,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
+}
+
+// Tile order inside each XCD's contiguous chunk: super-rows of `gm` tile-rows walked column-major, so the tiles an
+// XCD runs concurrently form a near-square block of the output (fewest distinct A and B panels per private L2).
+__device__ __forceinline__ void grouped_tile(int t, int tiles_m, int tiles_n, int gm, int& tm, int& tn) {
+    const int width = gm * tiles_n;
+    const int gid = t / width, first = gid * gm;
+    const int gsz = (tiles_m - first) < gm ? (tiles_m - first) : gm;
+    const int r = t - gid * width;
+    tm = first + r % gsz;
+    tn = r / gsz;
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

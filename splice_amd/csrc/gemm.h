@@ -343,12 +343,14 @@ __device__ __forceinline__ void gemm_epilogue_cols(const GemmEpi& e, int M, int 
 
 template <int BM, int BN, unsigned FLAGS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
-                                                      int ldb, int M, int N, int K, GemmEpi e) {
+                                                      int ldb, int M, int N, int K, GemmEpi e, int gm) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * GemmTile<BM, BN>::LDS_ELEMS];
-    const int tiles_n = (N + BN - 1) / BN;
+    const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
     const int nwg = gridDim.x;
     const int t = xcd_remap(blockIdx.x, nwg);
-    const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+    int tm, tn;
+    grouped_tile(t, tiles_m, tiles_n, gm, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
     GemmTile<BM, BN, true> tile;
     tile.run_glds(A, lda, B, ldb, M, N, K, m0, n0, smem);
     tile.for_each_cols(m0, n0, [&](int row, int col0, f32x4 v) { gemm_epilogue_cols<FLAGS>(e, M, N, row, col0, v); });
@@ -357,6 +359,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
 template <int BM, int BN, unsigned FLAGS>
 static inline void launch_gemm_nt(hipStream_t s, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K,
                                   const GemmEpi& e) {
-    const int grid = cdiv(M, BM) * cdiv(N, BN);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, FLAGS>), dim3(grid), dim3(256), 0, s, A, lda, B, ldb, M, N, K, e);
+    const int tm = cdiv(M, BM), tn = cdiv(N, BN);
+    const int grid = tm * tn;
+    // group height ~ sqrt(tiles per XCD), weighted by the tile aspect so the block is square in elements
+    int gm = 1;
+    while ((gm + 1) * (gm + 1) * BM <= (grid / 8 + 1) * BN && gm + 1 <= tm) ++gm;
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, FLAGS>), dim3(grid), dim3(256), 0, s, A, lda, B, ldb, M, N, K, e, gm);
 }

@@ -7,7 +7,7 @@ import sys
 
 ROOT = __file__.rsplit("/tools/", 1)[0]
 for src in sys.argv[1:]:
-    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT}/include",
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1", f"-I{ROOT}/include",
                           f"-I{ROOT}/splice_amd/csrc", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"],
                          capture_output=True, text=True).stderr
     cur = {}
