@@ -225,7 +225,11 @@ static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* par
     // The bias of a conv that feeds a train-mode BatchNorm has an analytically ZERO gradient (BN subtracts the
     // per-channel mean, sum_p dy = 0); the reference's autograd returns fp32 rounding noise there.  We write the
     // exact value and skip the reduction.
-    if (!acc) RC(fill_zero_launch(grads + u.b_off, u.Cout, s));
+    {
+        WgradReduceAll& r = const_cast<SpliceGenPlan*>(p)->red;
+        const int li = r.count++;
+        r.n[li] = u.Cout; r.chunks[li] = 0; r.ws_off[li] = 0; r.dw_off[li] = (long long)u.b_off;
+    }
     {
         WgradArgs a = {};
         a.x = u.in; a.dy = u.dy;
@@ -441,10 +445,10 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
     hipStream_t s = (hipStream_t)stream;
     const size_t npix = (size_t)p->N * 3 * p->H * p->W;
     p->red.count = 0;
-    RC(sigmoid_bwd_launch(dy, p->out_copy, p->d_head_pre, npix, s));
     const Unit& u = p->u_up1[0];
     const int HW = p->H * p->W;
-    RC(channel_sum_launch(p->d_head_pre, (size_t)3 * HW, p->N, 3, HW, grads + p->head_b, accumulate, s));
+    (void)npix;
+    RC(sigmoid_bwd_bias_launch(dy, p->out_copy, p->d_head_pre, p->N, 3, HW, p->u_up1[0].s1, grads + p->head_b, accumulate, s));
     {
         WgradArgs a = {};
         a.x = u.out; a.dy = p->d_head_pre;

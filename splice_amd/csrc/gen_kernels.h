@@ -31,7 +31,7 @@ struct WgradArgs {
 int wgrad_chunks(int N, int Ho, int Wo, int* pix_per_chunk, int* chunks_per_img);
 int conv_wgrad_launch(WgradArgs a, int* chunks_out, hipStream_t s);   // writes per-chunk partials into a.ws
 
-constexpr int WGRAD_MAX_LAYERS = 32;
+constexpr int WGRAD_MAX_LAYERS = 64;   // 26 conv weights + 25 exact-zero bias ranges (chunks == 0)
 struct WgradReduceAll {      // by-value kernel argument: one entry per conv layer of a backward
     long long prefix[WGRAD_MAX_LAYERS + 1];   // prefix sums of n (output elements), prefix[count] = total
     long long ws_off[WGRAD_MAX_LAYERS];       // offset of the layer's partials in the workspace (floats)
@@ -55,6 +55,10 @@ int channel_sum_launch(const float* dy, size_t nstride, int N, int C, int HW, fl
 int upsample2x_fwd_launch(const float* in, size_t in_nstride, float* out, size_t out_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s);
 int upsample2x_bwd_launch(const float* dout, size_t dout_nstride, float* din, size_t din_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s);
 int sigmoid_bwd_launch(const float* dout, const float* sout, float* dpre, size_t n, hipStream_t s);
+// sigmoid backward of the [N][C][HW] head + per-channel sums of the result (the head's bias gradient) in two
+// deterministic stages; part = C * 64 floats of scratch
+int sigmoid_bwd_bias_launch(const float* dout, const float* sout, float* dpre, int N, int C, int HW, float* part, float* db,
+                            int accumulate, hipStream_t s);
 int adam_launch(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step, int zero_grad, hipStream_t s);
 int adam_launch_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, const int* step_dev,
                     int zero_grad, hipStream_t s);

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(WgradReduceAll d,
         s3 += p[(size_t)(c + 3) * n];
     }
     for (; c < chunks; ++c) s0 += p[(size_t)c * n];
-    const float s = (s0 + s1) + (s2 + s3);
+    const float s = (s0 + s1) + (s2 + s3);   // chunks == 0: an exact-zero gradient range (BN-fed conv bias)
     float* q = grads + d.dw_off[l] + i;
     *q = accumulate ? *q + s : s;
 }
@@ -668,6 +668,40 @@ __global__ void sigmoid_bwd_kernel(const float* __restrict__ dout, const float* 
         const float sv = sout[i];
         dpre[i] = dout[i] * sv * (1.f - sv);
     }
+}
+// stage 1: block (pb, c) handles segment pb of channel c over every image; stage 2: one block sums the partials in order
+__global__ __launch_bounds__(256) void sigmoid_bwd_bias_kernel(const float* __restrict__ dout, const float* __restrict__ sout,
+                                                               float* __restrict__ dpre, int N, int C, int HW, int PB,
+                                                               float* __restrict__ part) {
+    __shared__ float red[8];
+    const int pb = blockIdx.x, c = blockIdx.y;
+    const int seg = seg_len(HW, PB), lo = pb * seg, hi = min(lo + seg, HW);
+    float acc = 0.f, dummy = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const size_t base = ((size_t)n * C + c) * HW;
+        for (int i = lo + threadIdx.x; i < hi; i += 256) {
+            const float sv = sout[base + i];
+            const float d = dout[base + i] * sv * (1.f - sv);
+            dpre[base + i] = d;
+            acc += d;
+        }
+    }
+    block_sum2(acc, dummy, red);
+    if (threadIdx.x == 0) part[c * PB + pb] = acc;
+}
+__global__ void bias_part_reduce_kernel(const float* __restrict__ part, int C, int PB, float* __restrict__ db, int accumulate) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < PB; ++k) s += part[c * PB + k];
+    db[c] = accumulate ? db[c] + s : s;
+}
+int sigmoid_bwd_bias_launch(const float* dout, const float* sout, float* dpre, int N, int C, int HW, float* part, float* db,
+                            int accumulate, hipStream_t s) {
+    const int PB = plane_blocks(HW);
+    hipLaunchKernelGGL(sigmoid_bwd_bias_kernel, dim3(PB, C), dim3(256), 0, s, dout, sout, dpre, N, C, HW, PB, part);
+    hipLaunchKernelGGL(bias_part_reduce_kernel, dim3(1), dim3(64), 0, s, part, C, PB, db, accumulate);
+    return SPLICE_OK;
 }
 int sigmoid_bwd_launch(const float* dout, const float* sout, float* dpre, size_t n, hipStream_t s) {
     size_t g = (n + 255) / 256;
