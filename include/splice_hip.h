@@ -61,6 +61,8 @@ typedef struct splice_gemm_epilogue {
     float* out_f32_cols;      /* fp32 copy of columns [col_lo, col_hi): [M][ld_cols] */
     int ld_cols, col_lo, col_hi;
     float alpha;
+    int ksplit;               /* > 1 with flags == SPLICE_EPI_OUT_F32 only: K is cut into ksplit slices, slice s writes */
+    long long slab_stride;    /* out_f32 + s * slab_stride; the consumer adds the slabs (deterministic split-K)       */
 } splice_gemm_epilogue;
 
 enum {

@@ -22,7 +22,7 @@ class GemmEpilogue(C.Structure):
         ("out_pre", C.c_void_p), ("ldp", C.c_int), ("pre_row_lo", C.c_int),
         ("aux", C.c_void_p), ("ldaux", C.c_int),
         ("out_f32_cols", C.c_void_p), ("ld_cols", C.c_int), ("col_lo", C.c_int), ("col_hi", C.c_int),
-        ("alpha", C.c_float),
+        ("alpha", C.c_float), ("ksplit", C.c_int), ("slab_stride", C.c_longlong),
     ]
 
 

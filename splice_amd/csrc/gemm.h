@@ -103,7 +103,7 @@ struct GemmTile {
     // XOR swizzle is applied on the SOURCE chunk each lane fetches.  Two LDS stages; the loads of slice t+1 are
     // issued right after the barrier that publishes slice t and fly during its MFMAs (one barrier per slice).
     __device__ __forceinline__ void run_glds(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
-                                             int M, int N, int K, int m0, int n0, bf16_t* smem) {
+                                             int M, int N, int K, int m0, int n0, bf16_t* smem, int kbeg = 0) {
         typedef __attribute__((address_space(3))) void lds_void;
         typedef __attribute__((address_space(1))) const void glb_void;
         const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -119,13 +119,13 @@ struct GemmTile {
         for (int i = 0; i < A_LOADS; ++i) {
             int gr = m0 + wave * 8 + 32 * i + lrow;
             gr = gr < M ? gr : M - 1;
-            ag[i] = A + (size_t)gr * lda + gchunk * 8;
+            ag[i] = A + (size_t)gr * lda + gchunk * 8 + kbeg;
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             int gr = n0 + wave * 8 + 32 * i + lrow;
             gr = gr < N ? gr : N - 1;
-            bg[i] = B + (size_t)gr * ldb + gchunk * 8;
+            bg[i] = B + (size_t)gr * ldb + gchunk * 8 + kbeg;
         }
         auto issue = [&](int k0, int stage) {
             bf16_t* st = smem + stage * LDS_ELEMS;
@@ -343,16 +343,24 @@ __device__ __forceinline__ void gemm_epilogue_cols(const GemmEpi& e, int M, int 
 
 template <int BM, int BN, unsigned FLAGS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
-                                                      int ldb, int M, int N, int K, GemmEpi e, int gm) {
+                                                      int ldb, int M, int N, int K, GemmEpi e, int gm, int ksplit) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * GemmTile<BM, BN>::LDS_ELEMS];
     const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
     const int nwg = gridDim.x;
-    const int t = xcd_remap(blockIdx.x, nwg);
+    int t = xcd_remap(blockIdx.x, nwg);
+    int kbeg = 0;
+    if (ksplit > 1) {   // split-K (plain fp32 output only): slice s of a tile writes slab s; the consumer sums the slabs in order
+        const int slice = t % ksplit;
+        t /= ksplit;
+        K /= ksplit;
+        kbeg = slice * K;
+        e.out_f32 += (size_t)slice * e.slab_stride;
+    }
     int tm, tn;
     grouped_tile(t, tiles_m, tiles_n, gm, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     GemmTile<BM, BN, true> tile;
-    tile.run_glds(A, lda, B, ldb, M, N, K, m0, n0, smem);
+    tile.run_glds(A, lda, B, ldb, M, N, K, m0, n0, smem, kbeg);
     tile.for_each_cols(m0, n0, [&](int row, int col0, f32x4 v) { gemm_epilogue_cols<FLAGS>(e, M, N, row, col0, v); });
 }
 
@@ -360,9 +368,10 @@ template <int BM, int BN, unsigned FLAGS>
 static inline void launch_gemm_nt(hipStream_t s, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K,
                                   const GemmEpi& e) {
     const int tm = cdiv(M, BM), tn = cdiv(N, BN);
-    const int grid = tm * tn;
+    const int ksplit = (FLAGS == EPI_OUT_F32 && e.ksplit > 1 && K % (e.ksplit * GEMM_BK) == 0) ? e.ksplit : 1;
+    const int grid = tm * tn * ksplit;
     // group height ~ sqrt(tiles per XCD), weighted by the tile aspect so the block is square in elements
     int gm = 1;
-    while ((gm + 1) * (gm + 1) * BM <= (grid / 8 + 1) * BN && gm + 1 <= tm) ++gm;
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, FLAGS>), dim3(grid), dim3(256), 0, s, A, lda, B, ldb, M, N, K, e, gm);
+    while ((gm + 1) * (gm + 1) * BM <= (tm * tn / 8 + 1) * BN && gm + 1 <= tm) ++gm;
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, FLAGS>), dim3(grid), dim3(256), 0, s, A, lda, B, ldb, M, N, K, e, gm, ksplit);
 }

@@ -37,6 +37,9 @@ int layernorm_fwd_launch(const float* x, const float* gamma, const float* beta, 
 // g_out = g_in + LN_backward(dy); also emits bf16(g_out).  dy is fp32 [rows][D].
 int layernorm_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                          const float* g_in, float* g_out, bf16_t* g_out_bf, int rows, int D, hipStream_t s);
+// same with dy given as n_slabs split-K slabs (dy + s * slab_stride), summed in order
+int layernorm_bwd_slabs_launch(const float* dy, int n_slabs, size_t slab_stride, const float* x, const float* gamma, const float* mean,
+                               const float* rstd, const float* g_in, float* g_out, bf16_t* g_out_bf, int rows, int D, hipStream_t s);
 // image [B][3][H][W] fp32 -> patch matrix bf16 [B*Tld][3*p*p] (row b*Tld+1+patch; row 0 and
 // rows >= T are zero), k index = c*p*p + py*p + px (Conv2d weight order).  Optional
 // ImageNet normalisation (x-mean)/std fused in.

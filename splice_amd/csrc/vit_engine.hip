@@ -286,7 +286,7 @@ int splice_vit_ctx_create(void* h, int B, int H, int W, const float* pos_TD, int
     A(c->ln_out, rows * D);
     A(c->hact, rows * Hd);
     if (need_grad) {
-        A(c->g, rows * D); A(c->g_bf, rows * D); A(c->dh, rows * Hd); A(c->dln, rows * D);
+        A(c->g, rows * D); A(c->g_bf, rows * D); A(c->dh, rows * Hd); A(c->dln, rows * D * 4);   // dln: up to 4 split-K slabs
         A(c->dout, rows * D); A(c->doutT, rows * D); A(c->dqkv, rows * 3 * D);
         A(c->delta, (size_t)B * v->heads * c->Tld);
         A(c->dpatches, rows * pp3);
@@ -471,6 +471,9 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
     float* g = c->g + r0 * D;
     bf16_t* g_bf = c->g_bf + r0 * D;
     bool g_live = false;  // gradient stream known non-zero
+    // the two long-K dgrad GEMMs (N = D) have too few tiles for the chip: split K in two, LayerNorm-backward adds the slabs
+    const size_t slab = (size_t)c->rows * D;
+    const int ks = (cdiv(R, 64) * cdiv(D, 64) <= 640 && D % 128 == 0) ? 2 : 1;
     for (int l = L - 1; l >= 0; --l) {
         const LayerW& W = v->layers[l];
         const float* db = d_block ? d_block[l] : nullptr;
@@ -492,10 +495,10 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
             }
             {
                 GemmEpi e = {};
-                e.out_f32 = c->dln + r0 * D; e.ldo = D;
+                e.out_f32 = c->dln + r0 * D; e.ldo = D; e.ksplit = ks; e.slab_stride = (long long)slab;
                 RC(gemm_nt_launch(EPI_OUT_F32, c->dh + r0 * Hd, Hd, W.fc1.wT, Hd, R, D, Hd, e, s));
             }
-            RC(layernorm_bwd_launch(c->dln + r0 * D, c->xmid[l] + r0 * D, W.ln2_g, c->mean2[l] + r0, c->rstd2[l] + r0, g, g, g_bf, R, D, s));
+            RC(layernorm_bwd_slabs_launch(c->dln + r0 * D, ks, slab, c->xmid[l] + r0 * D, W.ln2_g, c->mean2[l] + r0, c->rstd2[l] + r0, g, g, g_bf, R, D, s));
             // attention branch
             {
                 GemmEpi e = {};
@@ -520,10 +523,10 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
         if (dk) hipLaunchKernelGGL(add_f32_into_bf16_kernel, dim3(grid_n((size_t)R * D)), dim3(256), 0, s, dqkv, 3 * D, D, dk + r0 * D, D, R, D);
         {
             GemmEpi e = {};
-            e.out_f32 = c->dln + r0 * D; e.ldo = D;
+            e.out_f32 = c->dln + r0 * D; e.ldo = D; e.ksplit = ks; e.slab_stride = (long long)slab;
             RC(gemm_nt_launch(EPI_OUT_F32, dqkv, 3 * D, W.qkv.wT, 3 * D, R, D, 3 * D, e, s));
         }
-        RC(layernorm_bwd_launch(c->dln + r0 * D, c->xs[l] + r0 * D, W.ln1_g, c->mean1[l] + r0, c->rstd1[l] + r0, g_after_mlp, g, g_bf, R, D, s));
+        RC(layernorm_bwd_slabs_launch(c->dln + r0 * D, ks, slab, c->xs[l] + r0 * D, W.ln1_g, c->mean1[l] + r0, c->rstd1[l] + r0, g_after_mlp, g, g_bf, R, D, s));
         g_live = true;
     }
     if (!g_live) {

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                             const float* __restrict__ rstd_i, const float* __restrict__ g_in,
                                                             float* __restrict__ g_out, bf16_t* __restrict__ g_out_bf,
-                                                            int rows, int D) {
+                                                            int rows, int D, int n_slabs, size_t slab_stride) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -76,7 +76,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + 64 * i;
         if (idx < nv) {
-            const float4 xv = xr[idx], dv = dr[idx], g = g4[idx];
+            const float4 xv = xr[idx], g = g4[idx];
+            float4 dv = dr[idx];
+            for (int sl = 1; sl < n_slabs; ++sl) {   // split-K slabs of the producing GEMM, summed in slab order
+                const float4 e = reinterpret_cast<const float4*>(dy + (size_t)sl * slab_stride + (size_t)row * D)[idx];
+                dv.x += e.x; dv.y += e.y; dv.z += e.z; dv.w += e.w;
+            }
             xh[i] = float4{(xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd};
             dh[i] = float4{dv.x * g.x, dv.y * g.y, dv.z * g.z, dv.w * g.w};
             s1 += dh[i].x + dh[i].y + dh[i].z + dh[i].w;
@@ -103,11 +108,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
+int layernorm_bwd_slabs_launch(const float* dy, int n_slabs, size_t slab_stride, const float* x, const float* gamma, const float* mean,
+                               const float* rstd, const float* g_in, float* g_out, bf16_t* g_out_bf, int rows, int D, hipStream_t s) {
+    if (D % 4 || D > 64 * 4 * 4 || n_slabs < 1) return SPLICE_ERR_ARG;
+    hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, dy, x, gamma, mean, rstd, g_in, g_out, g_out_bf, rows, D,
+                       n_slabs, slab_stride);
+    return SPLICE_OK;
+}
 int layernorm_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                          const float* g_in, float* g_out, bf16_t* g_out_bf, int rows, int D, hipStream_t s) {
-    if (D % 4 || D > 64 * 4 * 4) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, dy, x, gamma, mean, rstd, g_in, g_out, g_out_bf, rows, D);
-    return SPLICE_OK;
+    return layernorm_bwd_slabs_launch(dy, 1, 0, x, gamma, mean, rstd, g_in, g_out, g_out_bf, rows, D, s);
 }
 
 // ---------------------------------------------------------------------------------------
