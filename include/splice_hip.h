@@ -76,6 +76,8 @@ int splice_gemm_nt_bf16(unsigned flags, const splice_bf16* A, int lda, const spl
 
 /* benchmarking hook (tools/gemm_bench.py): force the tile shape, 0 = automatic */
 int splice_gemm_force_tile(int tile);
+/* benchmarking hook (tools/attn_bench.py): pick an attention kernel variant, 0 = default */
+int splice_attention_variant(int variant);
 
 /* LayerNorm(D, eps) of the DINO blocks (eps 1e-6), fp32 in -> bf16 out, and its dgrad
  * accumulated into the fp32 residual-gradient stream: g_out = g_in + dLN(dy). */

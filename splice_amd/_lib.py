@@ -47,6 +47,7 @@ _SIGNATURES = {
     "splice_last_error": ([], C.c_char_p),
     "splice_gemm_nt_bf16": ([_u, _vp, _i, _vp, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _vp], _i),
     "splice_gemm_force_tile": ([_i], _i),
+    "splice_attention_variant": ([_i], _i),
     "splice_layernorm_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
     "splice_layernorm_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
     "splice_attention_fwd": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),

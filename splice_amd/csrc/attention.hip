@@ -5,9 +5,9 @@
 //
 // All products are "swapped" 16x16x32 bf16 MFMAs so that every lane owns ONE query (or
 // one key) column of the score tile: softmax statistics are per-lane scalars, the
-// probabilities feed the second MFMA straight from registers (no LDS, no shuffles beyond
-// a 4-lane-group reduce), and the k-index of the second product is permuted consistently
-// on both operands (lane group g, slot j  <->  key g*4+j | 16+g*4+(j-4)).
+// probabilities feed the second MFMA straight from registers (no LDS round trip, no
+// cross-lane traffic in the hot loop), and the rows of the score MFMA are permuted so that
+// a lane's 8 probabilities are 8 CONSECUTIVE tokens (see the tile toolkit below).
 //
 // Inputs: qkv  bf16 [B*Tld][3D]  (row = b*Tld + token; q | k | v column blocks, heads
 //                                 contiguous inside each block -- the layout
@@ -24,14 +24,9 @@
 // softmax runs in base 2: scores are scaled by scale*log2(e) once, probabilities are v_exp_f32 (exp2) directly,
 // and the saved log-sum-exp is kept in log2 units (lse2 = m2 + log2(l)); the backward uses exp2(s*c - lse2).
 
-__device__ __forceinline__ uint4 ld16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
-__device__ __forceinline__ uint4 ld8x2(const bf16_t* p) {  // tokens [0,4) and [16,20) relative to p
-    const uint2 lo = *reinterpret_cast<const uint2*>(p);
-    const uint2 hi = *reinterpret_cast<const uint2*>(p + 16);
-    return uint4{lo.x, lo.y, hi.x, hi.y};
-}
-__device__ __forceinline__ uint4 pack8(const f32x4& a, const f32x4& b) {
-    return uint4{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+__device__ __forceinline__ u32x4 ld16v(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ u32x4 pack8v(const f32x4& a, const f32x4& b) {
+    return u32x4{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
 }
 __device__ __forceinline__ void st4bf(bf16_t* p, const f32x4& v, float s) {
     *reinterpret_cast<uint2*>(p) = uint2{pack2bf(v[0] * s, v[1] * s), pack2bf(v[2] * s, v[3] * s)};
@@ -46,75 +41,191 @@ __device__ __forceinline__ float group4_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------
-// LDS tiles shared by the 4 waves of a workgroup (one global read per workgroup instead of per wave).
-//   row tile  [64 rows][64 d]   : 128-byte rows, 16-byte chunk c stored at chunk c ^ (row & 7)
-//                                 -> the 16-lane fragment reads (ds_read_b128) are conflict-free;
-//   col tile  [64 d][64 tokens] : transposed operand, 8-byte chunk c stored at c ^ (((d >> 1) & 7) << 1)
-//                                 -> the (d, token-group) fragment reads (ds_read_b64) are conflict-free and
-//                                    an aligned 16-byte pair stays an aligned pair (16-byte stores).
-__device__ __forceinline__ int row_tile_off(int row, int chunk16) { return row * 64 + ((chunk16 ^ (row & 7)) << 3); }
-__device__ __forceinline__ int col_tile_off(int d, int chunk8) { return d * 64 + ((chunk8 ^ (((d >> 1) & 7) << 1)) << 2); }
+// Tile toolkit: LDS-DMA staging (global_load_lds, 16 B per lane, no VGPR round trip) + fragment layouts that
+// need ONE ds_read_b128 per MFMA operand.
+//
+// A wave-instruction of the DMA fills 8 rows x 128 B of LDS linearly (dest = piece base + lane*16), so every
+// swizzle is applied on the SOURCE chunk a lane fetches.  Wave w of the 4 moves the 1-KiB pieces w and w+4 of a
+// [64][64] bf16 tile.
+//
+//   "token" tile [64 tokens][64 d] -- the operand whose rows become the ROWS of the score MFMA (keys in the
+//      forward / dQ kernels, queries in the dK/dV kernel).  Block nb (16 MFMA rows) of 32-token sub-tile `sub`
+//      takes row i = 4*j + r from token sub*32 + 8*j + 4*nb + r: lane group g then owns, over nb = 0,1, the EIGHT
+//      CONSECUTIVE tokens sub*32 + 8g .. 8g+7, which is exactly the k-slot order of the packed probabilities
+//      it feeds to the second MFMA -- whose other operand becomes a single 16-byte read of the
+//   "dim" tile [64 d][64 tokens] (transposed copy, from qkvT / doutT).
+//   16-byte chunk c of a row is stored at position c ^ swz(row): dim tile swz = row & 7; token tile
+//   swz = ((row >> 3) & 3) << 1 | (row >> 1) & 1  (conflict-free for the permuted row set above, b128 lane groups).
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
 
-struct TileLoader {   // thread t moves chunks t and t+256 of a [64][64] bf16 tile (16 bytes each)
-    int row[2], ch[2];
-    __device__ __forceinline__ TileLoader() {
+struct TileDma {
+    int wave;                 // scalar
+    int lrow, tchunk, dchunk;
+    __device__ __forceinline__ TileDma() {
+        const int lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        lrow = lane >> 3;
+        tchunk = (lane & 7) ^ ((wave << 1) | ((lrow >> 1) & 1));   // token tile: row = piece*8 + lrow, piece & 3 == wave
+        dchunk = (lane & 7) ^ lrow;                                // dim tile:   row & 7 == lrow
+    }
+    __device__ __forceinline__ void piece(const bf16_t* src, bf16_t* lds, int i) const {
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(lds + (wave + 4 * i) * 512), 16, 0, 0);
+    }
+    // token-major source: rows = tokens tok0.. (clamped to tok_max), 64 contiguous d at base + tok*ld
+    __device__ __forceinline__ void token_tile(const bf16_t* base, int ld, int tok0, int tok_max, bf16_t* lds) const {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { const int idx = threadIdx.x + 256 * i; row[i] = idx >> 3; ch[i] = idx & 7; }
+        for (int i = 0; i < 2; ++i) {
+            int t = tok0 + (wave + 4 * i) * 8 + lrow;
+            t = t < tok_max ? t : tok_max;
+            piece(base + (size_t)t * ld + tchunk * 8, lds, i);
+        }
+    }
+    // d-major source (rows = d), 64 contiguous tokens from tok0; an 8-token chunk starting past tok_lim-8 is replaced
+    // by the last in-bounds chunk (those tokens are masked keys / skipped queries: any finite value will do)
+    __device__ __forceinline__ void dim_tile(const bf16_t* baseT, int ldt, int tok0, int tok_lim, bf16_t* lds) const {
+        int t = tok0 + dchunk * 8;
+        t = t <= tok_lim - 8 ? t : tok_lim - 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) piece(baseT + (size_t)((wave + 4 * i) * 8 + lrow) * ldt + t, lds, i);
     }
 };
-// token-major source: rows = tokens tok0.. (clamped to tok_max), 64 contiguous d at `base + tok*ld`
-__device__ __forceinline__ void load_row_tile(const TileLoader& L, const bf16_t* base, int ld, int tok0, int tok_max, u32x4* r) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int t = tok0 + L.row[i];
-        t = t < tok_max ? t : tok_max;
-        r[i] = *reinterpret_cast<const u32x4*>(base + (size_t)t * ld + L.ch[i] * 8);
+
+struct FragAddr {   // per-lane LDS element offsets of the fragment reads (everything else is an immediate)
+    int tok[2];     // token tile: block nb of sub-tile sub, d-half hf   -> tok[hf] + sub*2048 + nb*256
+    int dim[2];     // dim tile:   d block nd, sub-tile sub             -> dim[sub] + nd*1024
+    __device__ __forceinline__ FragAddr(int g, int c) {
+        const int swz = ((c >> 2) << 1) | ((c >> 1) & 1);
+        const int row = (c >> 2) * 8 + (c & 3);
+        tok[0] = row * 64 + ((g ^ swz) << 3);
+        tok[1] = row * 64 + (((4 + g) ^ swz) << 3);
+        dim[0] = c * 64 + ((g ^ (c & 7)) << 3);
+        dim[1] = c * 64 + (((4 + g) ^ (c & 7)) << 3);
     }
+};
+__device__ __forceinline__ u32x4 lds16(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+// Workgroup -> (query/key block, head, pass): a 1-D grid walked through xcd_remap so that all blocks of one
+// (pass, head) run on ONE XCD and its K / V (200 KB) are fetched into a single L2.
+__device__ __forceinline__ void attn_block_coords(int nx, int H, int B, int& xb, int& h, int& b) {
+    const int lid = xcd_remap(blockIdx.x, nx * H * B);
+    xb = lid % nx;
+    const int bh = lid / nx;
+    h = bh % H;
+    b = bh / H;
 }
-__device__ __forceinline__ void store_row_tile(const TileLoader& L, bf16_t* lds, const u32x4* r) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(lds + row_tile_off(L.row[i], L.ch[i])) = r[i];
+// all of this wave's LDS-DMA has landed, then the workgroup barrier (other waves' pieces + ring slot free)
+__device__ __forceinline__ void dma_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 }
-// d-major source (transposed matrix): rows = d, 64 contiguous tokens from tok0 (column clamped in-bounds)
-__device__ __forceinline__ void load_col_tile(const TileLoader& L, const bf16_t* baseT, int ldt, int tok0, int tok_lim, u32x4* r) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int t = tok0 + L.ch[i] * 8;
-        t = t <= tok_lim - 8 ? t : tok_lim - 8;
-        r[i] = *reinterpret_cast<const u32x4*>(baseT + (size_t)L.row[i] * ldt + t);
-    }
-}
-__device__ __forceinline__ void store_col_tile(const TileLoader& L, bf16_t* lds, const u32x4* r) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(lds + col_tile_off(L.row[i], L.ch[i] * 2)) = r[i];
-}
-// fragments
-__device__ __forceinline__ u32x4 frag_row(const bf16_t* lds, int row, int chunk16) {
-    return *reinterpret_cast<const u32x4*>(lds + row_tile_off(row, chunk16));
-}
-__device__ __forceinline__ u32x4 frag_col(const bf16_t* lds, int d, int sub, int g) {   // tokens sub*32 + g*4.. and +16
-    const uint2 lo = *reinterpret_cast<const uint2*>(lds + col_tile_off(d, sub * 8 + g));
-    const uint2 hi = *reinterpret_cast<const uint2*>(lds + col_tile_off(d, sub * 8 + 4 + g));
-    return u32x4{lo.x, lo.y, hi.x, hi.y};
-}
-__device__ __forceinline__ u32x4 pack8v(const f32x4& a, const f32x4& b) {
-    return u32x4{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
-}
-__device__ __forceinline__ u32x4 ld16v(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
 
 // ---------------------------------------------------------------------------------------
-// forward: workgroup = 4 waves x QB blocks of 16 queries; 64-key K / V^T tiles staged through LDS
-// (register prefetch of the next tile), each consumed as two 32-key sub-tiles.
+// forward: workgroup = 4 waves x QB blocks of 16 queries; 64-key K / V^T tiles arrive by LDS-DMA into a 2-deep
+// ring (one barrier per tile, the next tile's DMA flies during this tile's MFMAs).  The hot loop is branch-free
+// except for ONE wave-uniform test per tile: probabilities are formed against the running maximum of the LAST
+// rescale (p = exp2(s*c - m), no per-tile max, no cross-lane traffic) and the exact max / rescale path only runs
+// when some lane's partial row sum leaves [0, 2^30) -- i.e. on the first tile and when the scores outgrow the
+// reference point by a factor 2^30.  softmax is shift-invariant, so the result is the same function; P stays
+// within bf16's fp32-sized exponent range and O, l accumulate in fp32.
+#define ATTN_RESCALE_LIMIT 1073741824.0f
+template <int QB, int NSUB, bool MASK>
+__device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs, const FragAddr& fa, const u32x4 (&qf)[QB][2],
+                                              float (&m)[QB], float (&l)[QB], f32x4 (&o)[QB][4], float c2, int kt, int T, int g) {
+    f32x4 s[QB][NSUB * 2];
+#pragma unroll
+    for (int nb = 0; nb < NSUB * 2; ++nb) {
+        const u32x4 k0 = lds16(Ks + fa.tok[0] + (nb >> 1) * 2048 + (nb & 1) * 256);
+        const u32x4 k1 = lds16(Ks + fa.tok[1] + (nb >> 1) * 2048 + (nb & 1) * 256);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            s[qb][nb] = mfma16(k0, qf[qb][0], f32x4{0.f, 0.f, 0.f, 0.f});
+            s[qb][nb] = mfma16(k1, qf[qb][1], s[qb][nb]);
+        }
+    }
+    if (MASK) {
+#pragma unroll
+        for (int nb = 0; nb < NSUB * 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool valid = kt + (nb >> 1) * 32 + g * 8 + (nb & 1) * 4 + r < T;
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) s[qb][nb][r] = valid ? s[qb][nb][r] : NEG_BIG;
+            }
+    }
+    f32x4 p[QB][NSUB * 2];
+    float ps[QB];
+    bool redo = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        float part[NSUB * 2];
+#pragma unroll
+        for (int nb = 0; nb < NSUB * 2; ++nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[qb][nb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][nb][r], c2, -m[qb]));
+            part[nb] = (p[qb][nb][0] + p[qb][nb][1]) + (p[qb][nb][2] + p[qb][nb][3]);
+        }
+        ps[qb] = NSUB == 2 ? (part[0] + part[1]) + (part[NSUB * 2 - 2] + part[NSUB * 2 - 1]) : part[0] + part[1];
+        redo |= !(ps[qb] < ATTN_RESCALE_LIMIT);
+    }
+    if (__any(redo)) {   // exact online-softmax step for the whole wave (rare)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int nb = 0; nb < NSUB * 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qb][nb][r]);
+            mx = group4_max(mx) * c2;
+            const float mn = fmaxf(m[qb], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
+            m[qb] = mn;
+            l[qb] *= alpha;
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[qb][nd][r] *= alpha;
+            ps[qb] = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < NSUB * 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[qb][nb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][nb][r], c2, -mn));
+                    ps[qb] += p[qb][nb][r];
+                }
+        }
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) l[qb] += ps[qb];
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+        u32x4 pb[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) pb[qb] = pack8v(p[qb][sub * 2], p[qb][sub * 2 + 1]);
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) {
+            const u32x4 vf = lds16(Vs + fa.dim[sub] + nd * 1024);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) o[qb][nd] = mfma16(vf, pb[qb], o[qb][nd]);
+        }
+    }
+}
+
 template <int QB>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * 64];
-    __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, int nx) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 4096];   // [stage][K | V^T] tiles
+    const int lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int xb, h, b;
+    attn_block_coords(nx, a.H, a.B, xb, h, b);
     const int ld = 3 * a.D;
-    const int qbase = blockIdx.x * (64 * QB) + wave * (16 * QB);
+    const TileDma dma;
+    const FragAddr fa(g, c);
+    const int qbase = xb * (64 * QB) + dma.wave * (16 * QB);
+    const bool active = qbase < a.Tld;   // a wave without queries still moves its share of every tile
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.Tld * ld;
+    const bf16_t* kbase = qkv_b + a.D + h * 64;
+    const bf16_t* vT = a.qkvT + (size_t)(2 * a.D + h * 64) * a.ldt + (size_t)b * a.Tld;
     u32x4 qf[QB][2];
     int qidx[QB];
 #pragma unroll
@@ -126,6 +237,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         qf[qb][0] = ld16v(p);
         qf[qb][1] = ld16v(p + 32);
     }
+    dma.token_tile(kbase, ld, 0, a.Tld - 1, smem);
+    dma.dim_tile(vT, a.ldt, 0, a.Tld, smem + 4096);
     float m[QB], l[QB];
     f32x4 o[QB][4];
 #pragma unroll
@@ -135,88 +248,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int nd = 0; nd < 4; ++nd) o[qb][nd] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const bf16_t* kbase = qkv_b + a.D + h * 64;
-    const bf16_t* vT = a.qkvT + (size_t)(2 * a.D + h * 64) * a.ldt + (size_t)b * a.Tld;
     const float c2 = a.scale * LOG2E;
-    TileLoader L;
-    u32x4 kr[2], vr[2];
-    load_row_tile(L, kbase, ld, 0, a.Tld - 1, kr);
-    load_col_tile(L, vT, a.ldt, 0, a.Tld, vr);
-    for (int kt = 0; kt < a.Tld; kt += 64) {
-        __syncthreads();
-        store_row_tile(L, Ks, kr);
-        store_col_tile(L, Vs, vr);
-        __syncthreads();
-        if (kt + 64 < a.Tld) {
-            load_row_tile(L, kbase, ld, kt + 64, a.Tld - 1, kr);
-            load_col_tile(L, vT, a.ldt, kt + 64, a.Tld, vr);
+    const int nfull = a.T / 64;   // tiles without padding keys
+    for (int it = 0; it < nfull; ++it) {
+        dma_wait_barrier();   // tile `it` has landed; tile it-1 fully consumed
+        const int kn = it * 64 + 64;
+        if (kn < a.Tld) {
+            bf16_t* nxt = smem + ((it + 1) & 1) * 8192;
+            dma.token_tile(kbase, ld, kn, a.Tld - 1, nxt);
+            dma.dim_tile(vT, a.ldt, kn, a.Tld, nxt + 4096);
         }
-        const int nsub = (kt + 32 < a.Tld) ? 2 : 1;
-        for (int sub = 0; sub < nsub; ++sub) {
-            const bool tail = kt + sub * 32 + 32 > a.T;
-            u32x4 kf[2][2], vf[4];
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                kf[nb][0] = frag_row(Ks, sub * 32 + nb * 16 + c, g);
-                kf[nb][1] = frag_row(Ks, sub * 32 + nb * 16 + c, 4 + g);
-            }
-#pragma unroll
-            for (int nd = 0; nd < 4; ++nd) vf[nd] = frag_col(Vs, nd * 16 + c, sub, g);
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                f32x4 s[2];
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    s[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    s[nb] = mfma16(kf[nb][0], qf[qb][0], s[nb]);
-                    s[nb] = mfma16(kf[nb][1], qf[qb][1], s[nb]);
-                }
-                float mx = NEG_BIG;
-                if (tail) {   // only the last key tile of a pass holds padding keys (wave-uniform branch)
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int key = kt + sub * 32 + nb * 16 + g * 4 + r;
-                            s[nb][r] = key < a.T ? s[nb][r] * c2 : NEG_BIG;
-                        }
-                } else {
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) s[nb][r] *= c2;
-                }
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[nb][r]);
-                mx = group4_max(mx);
-                const float mn = fmaxf(m[qb], mx);
-                const bool grew = mn > m[qb];
-                const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
-                m[qb] = mn;
-                float ps = 0.f;
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(s[nb][r] - mn);
-                        s[nb][r] = p;
-                        ps += p;
-                    }
-                l[qb] = l[qb] * alpha + ps;
-                const u32x4 pb = pack8v(s[0], s[1]);
-                if (__any(grew)) {   // the running max rarely moves after the first tiles: skip the accumulator rescale otherwise
-#pragma unroll
-                    for (int nd = 0; nd < 4; ++nd)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[qb][nd][r] *= alpha;
-                }
-#pragma unroll
-                for (int nd = 0; nd < 4; ++nd) o[qb][nd] = mfma16(vf[nd], pb, o[qb][nd]);
-            }
+        if (active) {
+            const bf16_t* cur = smem + (it & 1) * 8192;
+            attn_fwd_tile<QB, 2, false>(cur, cur + 4096, fa, qf, m, l, o, c2, it * 64, a.T, g);
         }
     }
+    if (nfull * 64 < a.T) {   // last tile: padding keys masked, second sub-tile skipped when it is all padding
+        dma_wait_barrier();
+        const int kt = nfull * 64;
+        if (active) {
+            const bf16_t* cur = smem + (nfull & 1) * 8192;
+            if (kt + 32 < a.T) attn_fwd_tile<QB, 2, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g);
+            else attn_fwd_tile<QB, 1, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g);
+        }
+    }
+    if (!active) return;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const float lt = group4_sum(l[qb]);
@@ -232,47 +288,172 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// delta[b][h][q] = sum_d dO[q][h*64+d] * O[q][h*64+d]
-__global__ void attn_delta_kernel(AttnArgs a) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over B*Tld*H
-    const int total = a.B * a.Tld * a.H;
-    if (idx >= total) return;
-    const int h = idx % a.H, row = idx / a.H;
-    const int b = row / a.Tld, q = row % a.Tld;
-    const bf16_t* po = a.out + (size_t)row * a.D + h * 64;
-    const bf16_t* pd = a.dout + (size_t)row * a.D + h * 64;
-    float acc = 0.f;
+// backward (same toolkit as the forward: LDS-DMA ring, one b128 read per MFMA operand, padding handled in a
+// peeled last tile so the hot loops are branch-free).
+//
+// dQ kernel: wave owns 16 queries (lane&15 = query); K, V (token tiles) and K^T (dim tile) shared via LDS.
+// It also forms delta[q] = sum_d dO[q][d] O[q][d] for its queries from the fragments it already holds and
+// publishes it for the dK/dV kernel, which runs after it.
+template <int NSUB, bool MASK>
+__device__ __forceinline__ void attn_bwd_q_tile(const bf16_t* Ks, const bf16_t* Vs, const bf16_t* KTs, const FragAddr& fa,
+                                                const u32x4 (&qf)[2], const u32x4 (&dof)[2], float lse_q, float del_q, f32x4 (&dq)[4],
+                                                float c2, int kt, int T, int g) {
+    f32x4 s[NSUB * 2], dp[NSUB * 2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint4 x = ld16(po + i * 8), y = ld16(pd + i * 8);
-        const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc += bf2f((bf16_t)(xs[j] & 0xFFFF)) * bf2f((bf16_t)(ys[j] & 0xFFFF));
-            acc += bf2f((bf16_t)(xs[j] >> 16)) * bf2f((bf16_t)(ys[j] >> 16));
-        }
+    for (int nb = 0; nb < NSUB * 2; ++nb) {
+        const int off = (nb >> 1) * 2048 + (nb & 1) * 256;
+        s[nb] = mfma16(lds16(Ks + fa.tok[0] + off), qf[0], f32x4{0.f, 0.f, 0.f, 0.f});      // S^T[key][q]
+        dp[nb] = mfma16(lds16(Vs + fa.tok[0] + off), dof[0], f32x4{0.f, 0.f, 0.f, 0.f});    // dP^T[key][q]
+        s[nb] = mfma16(lds16(Ks + fa.tok[1] + off), qf[1], s[nb]);
+        dp[nb] = mfma16(lds16(Vs + fa.tok[1] + off), dof[1], dp[nb]);
     }
-    a.delta[((size_t)b * a.H + h) * a.Tld + q] = acc;
+#pragma unroll
+    for (int nb = 0; nb < NSUB * 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[nb][r], c2, -lse_q));
+            if (MASK) p = kt + (nb >> 1) * 32 + g * 8 + (nb & 1) * 4 + r < T ? p : 0.f;
+            dp[nb][r] = p * (dp[nb][r] - del_q);
+        }
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+        const u32x4 dsb = pack8v(dp[sub * 2], dp[sub * 2 + 1]);
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) dq[nd] = mfma16(lds16(KTs + fa.dim[sub] + nd * 1024), dsb, dq[nd]);   // dQ^T[d][q]
+    }
 }
 
-// ---------------------------------------------------------------------------------------
-// backward, dK / dV: wave owns 16 keys (lane&15 = key); the workgroup's 4 waves share 64-query tiles of
-// Q, dO (row tiles) and Q^T, dO^T (col tiles) plus lse / delta through LDS.
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * 64];
-    __shared__ __attribute__((aligned(16))) bf16_t Ds[64 * 64];
-    __shared__ __attribute__((aligned(16))) bf16_t QTs[64 * 64];
-    __shared__ __attribute__((aligned(16))) bf16_t DTs[64 * 64];
-    __shared__ __attribute__((aligned(16))) float Ls[64];
-    __shared__ __attribute__((aligned(16))) float Es[64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ float dot8bf(const u32x4& x, const u32x4& y) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        acc = __builtin_fmaf(__uint_as_float(x[j] << 16), __uint_as_float(y[j] << 16), acc);
+        acc = __builtin_fmaf(__uint_as_float(x[j] & 0xFFFF0000u), __uint_as_float(y[j] & 0xFFFF0000u), acc);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a, int nx) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 3 * 4096];   // [stage][K | V | K^T]
+    const int lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int xb, h, b;
+    attn_block_coords(nx, a.H, a.B, xb, h, b);
     const int ld = 3 * a.D;
-    const int key = blockIdx.x * 64 + wave * 16 + c;
-    const int keyc = key < a.Tld ? key : a.Tld - 1;
-    const bool key_valid = key < a.T;
+    const TileDma dma;
+    const FragAddr fa(g, c);
+    const int qbase = xb * 64 + dma.wave * 16;
+    const bool active = qbase < a.Tld;
+    const int q = qbase + c;
+    const int qc = q < a.Tld ? q : a.Tld - 1;
+    const bf16_t* qkv_b = a.qkv + (size_t)b * a.Tld * ld;
+    u32x4 qf[2], dof[2];
+    float del_q;
+    {
+        const bf16_t* pq = qkv_b + (size_t)qc * ld + h * 64 + g * 8;
+        const bf16_t* pd = a.dout + ((size_t)b * a.Tld + qc) * a.D + h * 64 + g * 8;
+        const bf16_t* po = a.out + ((size_t)b * a.Tld + qc) * a.D + h * 64 + g * 8;
+        qf[0] = ld16v(pq); qf[1] = ld16v(pq + 32);
+        dof[0] = ld16v(pd); dof[1] = ld16v(pd + 32);
+        del_q = group4_sum(dot8bf(dof[0], ld16v(po)) + dot8bf(dof[1], ld16v(po + 32)));
+    }
+    const float lse_q = a.lse[((size_t)b * a.H + h) * a.Tld + qc];
+    if (active && g == 0 && q < a.Tld) a.delta[((size_t)b * a.H + h) * a.Tld + q] = del_q;
+    const bf16_t* krow = qkv_b + a.D + h * 64;
+    const bf16_t* vrow = qkv_b + 2 * a.D + h * 64;
+    const bf16_t* kT = a.qkvT + (size_t)(a.D + h * 64) * a.ldt + (size_t)b * a.Tld;
+    dma.token_tile(krow, ld, 0, a.Tld - 1, smem);
+    dma.token_tile(vrow, ld, 0, a.Tld - 1, smem + 4096);
+    dma.dim_tile(kT, a.ldt, 0, a.Tld, smem + 8192);
+    f32x4 dq[4];
+#pragma unroll
+    for (int nd = 0; nd < 4; ++nd) dq[nd] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float c2 = a.scale * LOG2E;
+    const int nfull = a.T / 64;
+    for (int it = 0; it < nfull; ++it) {
+        dma_wait_barrier();
+        const int kn = it * 64 + 64;
+        if (kn < a.Tld) {
+            bf16_t* nxt = smem + ((it + 1) & 1) * 12288;
+            dma.token_tile(krow, ld, kn, a.Tld - 1, nxt);
+            dma.token_tile(vrow, ld, kn, a.Tld - 1, nxt + 4096);
+            dma.dim_tile(kT, a.ldt, kn, a.Tld, nxt + 8192);
+        }
+        if (active) {
+            const bf16_t* cur = smem + (it & 1) * 12288;
+            attn_bwd_q_tile<2, false>(cur, cur + 4096, cur + 8192, fa, qf, dof, lse_q, del_q, dq, c2, it * 64, a.T, g);
+        }
+    }
+    if (nfull * 64 < a.T) {
+        dma_wait_barrier();
+        const int kt = nfull * 64;
+        if (active) {
+            const bf16_t* cur = smem + (nfull & 1) * 12288;
+            if (kt + 32 < a.T) attn_bwd_q_tile<2, true>(cur, cur + 4096, cur + 8192, fa, qf, dof, lse_q, del_q, dq, c2, kt, a.T, g);
+            else attn_bwd_q_tile<1, true>(cur, cur + 4096, cur + 8192, fa, qf, dof, lse_q, del_q, dq, c2, kt, a.T, g);
+        }
+    }
+    if (active && q < a.Tld) {
+        bf16_t* p = a.dqkv + ((size_t)b * a.Tld + q) * ld + h * 64 + g * 4;
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) st4bf(p + nd * 16, dq[nd], a.scale);
+    }
+}
+
+// dK / dV kernel: wave owns 16 keys (lane&15 = key); the workgroup's 4 waves share 64-query tiles of Q, dO (token
+// tiles) and Q^T, dO^T (dim tiles) plus lse / delta through LDS.  Padding keys accumulate garbage in their own
+// lanes only (MFMA output columns are independent) and are stored as exact zeros.
+#define KV_STAGE (4 * 4096 + 256)   // bf16 elements per ring stage: 4 tiles + 64 lse + 64 delta floats
+template <int NSUB>
+__device__ __forceinline__ void attn_bwd_kv_tile(const bf16_t* st, const FragAddr& fa, const u32x4 (&kf)[2], const u32x4 (&vf)[2],
+                                                 f32x4 (&dk)[4], f32x4 (&dv)[4], float c2, int g) {
+    const bf16_t *Qs = st, *Ds = st + 4096, *QTs = st + 8192, *DTs = st + 12288;
+    const float* Ls = reinterpret_cast<const float*>(st + 16384);
+    const float* Es = Ls + 64;
+    f32x4 s[NSUB * 2], dp[NSUB * 2];
+#pragma unroll
+    for (int nb = 0; nb < NSUB * 2; ++nb) {
+        const int off = (nb >> 1) * 2048 + (nb & 1) * 256;
+        s[nb] = mfma16(lds16(Qs + fa.tok[0] + off), kf[0], f32x4{0.f, 0.f, 0.f, 0.f});      // S[q][key]
+        dp[nb] = mfma16(lds16(Ds + fa.tok[0] + off), vf[0], f32x4{0.f, 0.f, 0.f, 0.f});     // dP[q][key]
+        s[nb] = mfma16(lds16(Qs + fa.tok[1] + off), kf[1], s[nb]);
+        dp[nb] = mfma16(lds16(Ds + fa.tok[1] + off), vf[1], dp[nb]);
+    }
+#pragma unroll
+    for (int nb = 0; nb < NSUB * 2; ++nb) {
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(Ls + (nb >> 1) * 32 + g * 8 + (nb & 1) * 4);
+        const f32x4 de = *reinterpret_cast<const f32x4*>(Es + (nb >> 1) * 32 + g * 8 + (nb & 1) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[nb][r], c2, -ls[r]));
+            s[nb][r] = p;
+            dp[nb][r] = p * (dp[nb][r] - de[r]);
+        }
+    }
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+        const u32x4 pb = pack8v(s[sub * 2], s[sub * 2 + 1]), dsb = pack8v(dp[sub * 2], dp[sub * 2 + 1]);
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) {
+            dv[nd] = mfma16(lds16(DTs + fa.dim[sub] + nd * 1024), pb, dv[nd]);    // dV^T[d][key]
+            dk[nd] = mfma16(lds16(QTs + fa.dim[sub] + nd * 1024), dsb, dk[nd]);   // dK^T[d][key]
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a, int nx) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * KV_STAGE];
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, c = lane & 15;
+    int xb, h, b;
+    attn_block_coords(nx, a.H, a.B, xb, h, b);
+    const int ld = 3 * a.D;
+    const TileDma dma;
+    const FragAddr fa(g, c);
+    const int kbase = xb * 64 + dma.wave * 16;
+    const bool active = kbase < a.Tld;
+    const int key = kbase + c;
+    const int keyc = key < a.Tld ? key : a.Tld - 1;
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.Tld * ld;
     u32x4 kf[2], vf[2];
     {
@@ -281,155 +462,48 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a) {
         kf[0] = ld16v(pk); kf[1] = ld16v(pk + 32);
         vf[0] = ld16v(pv); vf[1] = ld16v(pv + 32);
     }
-    f32x4 dk[4], dv[4];
-#pragma unroll
-    for (int nd = 0; nd < 4; ++nd) { dk[nd] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[nd] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const bf16_t* qrow = qkv_b + h * 64;
     const bf16_t* dorow = a.dout + (size_t)b * a.Tld * a.D + h * 64;
     const bf16_t* qT = a.qkvT + (size_t)(h * 64) * a.ldt + (size_t)b * a.Tld;
     const bf16_t* doT = a.doutT + (size_t)(h * 64) * a.ldt + (size_t)b * a.Tld;
     const float* lse = a.lse + ((size_t)b * a.H + h) * a.Tld;
     const float* dl = a.delta + ((size_t)b * a.H + h) * a.Tld;
-    TileLoader L;
-    u32x4 r_q[2], r_d[2], r_qt[2], r_dt[2];
-    float r_l = 0.f, r_e = 0.f;
-    auto fetch = [&](int qt) {
-        load_row_tile(L, qrow, ld, qt, a.Tld - 1, r_q);
-        load_row_tile(L, dorow, a.D, qt, a.Tld - 1, r_d);
-        load_col_tile(L, qT, a.ldt, qt, a.Tld, r_qt);
-        load_col_tile(L, doT, a.ldt, qt, a.Tld, r_dt);
-        if (threadIdx.x < 64) {
-            const int q = qt + threadIdx.x < a.Tld ? qt + threadIdx.x : a.Tld - 1;
-            r_l = lse[q]; r_e = dl[q];
+    auto issue = [&](int qt, bf16_t* st) {
+        dma.token_tile(qrow, ld, qt, a.Tld - 1, st);
+        dma.token_tile(dorow, a.D, qt, a.Tld - 1, st + 4096);
+        dma.dim_tile(qT, a.ldt, qt, a.Tld, st + 8192);
+        dma.dim_tile(doT, a.ldt, qt, a.Tld, st + 12288);
+        if (dma.wave < 2) {   // wave 0: 64 lse values, wave 1: 64 delta values (4 bytes per lane)
+            const int qq = qt + lane < a.Tld ? qt + lane : a.Tld - 1;
+            const float* src = (dma.wave == 0 ? lse : dl) + qq;
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(st + 16384 + dma.wave * 128), 4, 0, 0);
         }
     };
-    fetch(0);
-    for (int qt = 0; qt < a.Tld; qt += 64) {
-        __syncthreads();
-        store_row_tile(L, Qs, r_q);
-        store_row_tile(L, Ds, r_d);
-        store_col_tile(L, QTs, r_qt);
-        store_col_tile(L, DTs, r_dt);
-        if (threadIdx.x < 64) { Ls[threadIdx.x] = r_l; Es[threadIdx.x] = r_e; }
-        __syncthreads();
-        if (qt + 64 < a.Tld) fetch(qt + 64);
-        const int nsub = (qt + 32 < a.Tld) ? 2 : 1;
-        for (int sub = 0; sub < nsub; ++sub) {
-            f32x4 s[2], dp[2];
+    issue(0, smem);
+    f32x4 dk[4], dv[4];
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                const int row = sub * 32 + qb * 16 + c;
-                s[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                s[qb] = mfma16(frag_row(Qs, row, g), kf[0], s[qb]);        // S[q][key]
-                s[qb] = mfma16(frag_row(Qs, row, 4 + g), kf[1], s[qb]);
-                dp[qb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dp[qb] = mfma16(frag_row(Ds, row, g), vf[0], dp[qb]);      // dP[q][key]
-                dp[qb] = mfma16(frag_row(Ds, row, 4 + g), vf[1], dp[qb]);
-            }
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                const f32x4 ls = *reinterpret_cast<const f32x4*>(Ls + sub * 32 + qb * 16 + g * 4);
-                const f32x4 de = *reinterpret_cast<const f32x4*>(Es + sub * 32 + qb * 16 + g * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = key_valid ? __builtin_amdgcn_exp2f(s[qb][r] * c2 - ls[r]) : 0.f;
-                    s[qb][r] = p;
-                    dp[qb][r] = p * (dp[qb][r] - de[r]);
-                }
-            }
-            const u32x4 pb = pack8v(s[0], s[1]), dsb = pack8v(dp[0], dp[1]);
-#pragma unroll
-            for (int nd = 0; nd < 4; ++nd) {
-                dv[nd] = mfma16(frag_col(DTs, nd * 16 + c, sub, g), pb, dv[nd]);    // dV^T[d][key]
-                dk[nd] = mfma16(frag_col(QTs, nd * 16 + c, sub, g), dsb, dk[nd]);   // dK^T[d][key]
-            }
-        }
+    for (int nd = 0; nd < 4; ++nd) { dk[nd] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[nd] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const float c2 = a.scale * LOG2E;
+    const int nfull = a.Tld / 64;   // padding QUERIES carry dO = 0, delta = 0: no masking needed inside Tld
+    for (int it = 0; it < nfull; ++it) {
+        dma_wait_barrier();
+        const int qn = it * 64 + 64;
+        if (qn < a.Tld) issue(qn, smem + ((it + 1) & 1) * KV_STAGE);
+        if (active) attn_bwd_kv_tile<2>(smem + (it & 1) * KV_STAGE, fa, kf, vf, dk, dv, c2, g);
     }
-    if (key < a.Tld) {
+    if (nfull * 64 < a.Tld) {   // Tld % 64 == 32: one more half tile (rows beyond Tld are clamped duplicates: skipped)
+        dma_wait_barrier();
+        if (active) attn_bwd_kv_tile<1>(smem + (nfull & 1) * KV_STAGE, fa, kf, vf, dk, dv, c2, g);
+    }
+    if (active && key < a.Tld) {
+        const float sk = key < a.T ? a.scale : 0.f, sv = key < a.T ? 1.0f : 0.f;
         bf16_t* pk = a.dqkv + ((size_t)b * a.Tld + key) * ld + a.D + h * 64 + g * 4;
         bf16_t* pv = a.dqkv + ((size_t)b * a.Tld + key) * ld + 2 * a.D + h * 64 + g * 4;
 #pragma unroll
         for (int nd = 0; nd < 4; ++nd) {
-            st4bf(pk + nd * 16, dk[nd], a.scale);
-            st4bf(pv + nd * 16, dv[nd], 1.0f);
+            st4bf(pk + nd * 16, dk[nd], sk);
+            st4bf(pv + nd * 16, dv[nd], sv);
         }
-    }
-}
-
-// backward, dQ: wave owns 16 queries (lane&15 = query); K, V (row tiles) and K^T (col tile) shared via LDS.
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * 64];
-    __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * 64];
-    __shared__ __attribute__((aligned(16))) bf16_t KTs[64 * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, c = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int ld = 3 * a.D;
-    const int q = blockIdx.x * 64 + wave * 16 + c;
-    const int qc = q < a.Tld ? q : a.Tld - 1;
-    const bf16_t* qkv_b = a.qkv + (size_t)b * a.Tld * ld;
-    u32x4 qf[2], dof[2];
-    {
-        const bf16_t* pq = qkv_b + (size_t)qc * ld + h * 64 + g * 8;
-        const bf16_t* pd = a.dout + ((size_t)b * a.Tld + qc) * a.D + h * 64 + g * 8;
-        qf[0] = ld16v(pq); qf[1] = ld16v(pq + 32);
-        dof[0] = ld16v(pd); dof[1] = ld16v(pd + 32);
-    }
-    const float c2 = a.scale * LOG2E;
-    const float lse_q = a.lse[((size_t)b * a.H + h) * a.Tld + qc];
-    const float del_q = a.delta[((size_t)b * a.H + h) * a.Tld + qc];
-    f32x4 dq[4];
-#pragma unroll
-    for (int nd = 0; nd < 4; ++nd) dq[nd] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bf16_t* krow = qkv_b + a.D + h * 64;
-    const bf16_t* vrow = qkv_b + 2 * a.D + h * 64;
-    const bf16_t* kT = a.qkvT + (size_t)(a.D + h * 64) * a.ldt + (size_t)b * a.Tld;
-    TileLoader L;
-    u32x4 r_k[2], r_v[2], r_kt[2];
-    load_row_tile(L, krow, ld, 0, a.Tld - 1, r_k);
-    load_row_tile(L, vrow, ld, 0, a.Tld - 1, r_v);
-    load_col_tile(L, kT, a.ldt, 0, a.Tld, r_kt);
-    for (int kt = 0; kt < a.Tld; kt += 64) {
-        __syncthreads();
-        store_row_tile(L, Ks, r_k);
-        store_row_tile(L, Vs, r_v);
-        store_col_tile(L, KTs, r_kt);
-        __syncthreads();
-        if (kt + 64 < a.Tld) {
-            load_row_tile(L, krow, ld, kt + 64, a.Tld - 1, r_k);
-            load_row_tile(L, vrow, ld, kt + 64, a.Tld - 1, r_v);
-            load_col_tile(L, kT, a.ldt, kt + 64, a.Tld, r_kt);
-        }
-        const int nsub = (kt + 32 < a.Tld) ? 2 : 1;
-        for (int sub = 0; sub < nsub; ++sub) {
-            f32x4 s[2], dp[2];
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const int row = sub * 32 + nb * 16 + c;
-                s[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                s[nb] = mfma16(frag_row(Ks, row, g), qf[0], s[nb]);        // S^T[key][q]
-                s[nb] = mfma16(frag_row(Ks, row, 4 + g), qf[1], s[nb]);
-                dp[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dp[nb] = mfma16(frag_row(Vs, row, g), dof[0], dp[nb]);     // dP^T[key][q]
-                dp[nb] = mfma16(frag_row(Vs, row, 4 + g), dof[1], dp[nb]);
-            }
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt + sub * 32 + nb * 16 + g * 4 + r;
-                    const float p = key < a.T ? __builtin_amdgcn_exp2f(s[nb][r] * c2 - lse_q) : 0.f;
-                    dp[nb][r] = p * (dp[nb][r] - del_q);
-                }
-            const u32x4 dsb = pack8v(dp[0], dp[1]);
-#pragma unroll
-            for (int nd = 0; nd < 4; ++nd) dq[nd] = mfma16(frag_col(KTs, nd * 16 + c, sub, g), dsb, dq[nd]);   // dQ^T[d][q]
-        }
-    }
-    if (q < a.Tld) {
-        bf16_t* p = a.dqkv + ((size_t)b * a.Tld + q) * ld + h * 64 + g * 4;
-#pragma unroll
-        for (int nd = 0; nd < 4; ++nd) st4bf(p + nd * 16, dq[nd], a.scale);
     }
 }
 
@@ -455,21 +529,26 @@ __global__ void attn_probs_kernel(AttnArgs a, float* probs) {
 }
 
 // ---------------------------------------------------------------------------------------
+static int g_attn_variant = 0;   // benchmarking hook (splice_attention_variant): forward queries per wave 16*v, 0 = automatic
+void attn_set_variant(int v) { g_attn_variant = v; }
+
 int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
     if (a->Tld % 32 || a->D % 64 || a->D / 64 != a->H || a->ldt % 4) return SPLICE_ERR_ARG;
-    constexpr int QB = 2;
-    dim3 grid(cdiv(a->Tld, 64 * QB), a->H, a->B);
-    hipLaunchKernelGGL(attn_fwd_kernel<QB>, grid, dim3(256), 0, s, *a);
+    // 16 queries per wave while that still leaves fewer than ~3.5 waves per SIMD (latency hiding matters more than
+    // fragment reuse at ViT-B/8 @ 224: 2400 wave tasks on 1024 SIMDs); 32 per wave for the long sequences.
+    const long tasks = (long)a->B * a->H * cdiv(a->Tld, 16);
+    const int qb = g_attn_variant ? g_attn_variant : (tasks > 3600 ? 2 : 1);
+    const int nx = cdiv(a->Tld, 64 * qb);
+    if (qb == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(nx * a->H * a->B), dim3(256), 0, s, *a, nx);
+    else hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(nx * a->H * a->B), dim3(256), 0, s, *a, nx);
     return SPLICE_OK;
 }
 
 int attn_bwd_launch(const AttnArgs* a, hipStream_t s) {
     if (a->Tld % 32 || a->D % 64 || a->D / 64 != a->H || a->ldt % 4) return SPLICE_ERR_ARG;
-    const int total = a->B * a->Tld * a->H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, *a);
-    dim3 grid(cdiv(a->Tld, 64), a->H, a->B);
-    hipLaunchKernelGGL(attn_bwd_kv_kernel, grid, dim3(256), 0, s, *a);
-    hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(256), 0, s, *a);
+    const int nx = cdiv(a->Tld, 64);
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(nx * a->H * a->B), dim3(256), 0, s, *a, nx);    // also writes delta
+    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(nx * a->H * a->B), dim3(256), 0, s, *a, nx);
     return SPLICE_OK;
 }
 

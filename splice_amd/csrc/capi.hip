@@ -41,6 +41,7 @@ int splice_gemm_nt_bf16(unsigned flags, const splice_bf16* A, int lda, const spl
 
 /* benchmarking hook: force the GEMM tile (0 auto, 1 128x128, 2 128x64, 3 64x64) */
 int splice_gemm_force_tile(int tile) { gemm_force_tile(tile); return SPLICE_OK; }
+int splice_attention_variant(int variant) { attn_set_variant(variant); return SPLICE_OK; }
 
 int splice_layernorm_fwd(const float* x, const float* gamma, const float* beta, splice_bf16* y, float* mean, float* rstd,
                          int rows, int D, float eps, splice_stream_t stream) {

@@ -22,6 +22,7 @@ struct AttnArgs {
 int attn_fwd_launch(const AttnArgs* a, hipStream_t s);
 int attn_bwd_launch(const AttnArgs* a, hipStream_t s);
 int attn_probs_launch(const AttnArgs* a, float* probs, hipStream_t s);
+void attn_set_variant(int v);   // benchmarking hook
 
 // ---- gemm.hip --------------------------------------------------------------------------
 // Runtime dispatch over the instantiated (tile, epilogue-flag) combinations.
