@@ -151,6 +151,11 @@ int splice_vit_forward(void* ctx, const float* img, int normalize, splice_stream
 /* same; passes [0, grad_pass_begin) are no-grad targets (util/losses.py:79,91,101 `with torch.no_grad()`):
  * tensors only a backward would read are not stored for them */
 int splice_vit_forward_ex(void* ctx, const float* img, int normalize, int grad_pass_begin, splice_stream_t stream);
+/* same, restricted to passes (images) [pass_begin, pass_end) of the ctx batch; img is still the full [B] batch.
+ * The forward is row-parallel over the token matrix: disjoint pass ranges of one ctx may run concurrently on
+ * different streams (splice_step_run computes the no-grad target passes beside the generator forward). */
+int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int grad_pass_begin, int pass_begin, int pass_end,
+                              splice_stream_t stream);
 /* kind 0: block output l fp32 [rows][D] (models/extractor.py:56-60) | 1: raw qkv l bf16
  * [rows][3D] (:68-72) | 2: attention output l bf16 [rows][D] | 3: last-layer qkv fp32
  * [rows][3D] | 4: lse l fp32 [B][H][Tld] | 5: embedded tokens fp32 [rows][D] */

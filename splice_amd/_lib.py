@@ -74,6 +74,7 @@ _SIGNATURES = {
     "splice_vit_ctx_info": ([_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _i),
     "splice_vit_forward": ([_vp, _vp, _i, _vp], _i),
     "splice_vit_forward_ex": ([_vp, _vp, _i, _i, _vp], _i),
+    "splice_vit_forward_passes": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),
     "splice_vit_get_tensor": ([_vp, _i, _i, C.POINTER(_vp)], _i),
     "splice_vit_read_tensor": ([_vp, _i, _i, _vp, _sz, _vp], _i),
     "splice_vit_backward": ([_vp, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp, _i, _vp], _i),

@@ -85,6 +85,9 @@ struct SpliceStep {
     int* dev_t = nullptr;        // Adam step count on the device
     hipStream_t own_stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipStream_t side_stream = nullptr;               // target-pass ViT forward beside the generator forward
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int overlap = 1;                                 // SPLICE_STEP_OVERLAP=0 serialises (debugging)
     std::map<int, hipGraphExec_t> graphs;
     void* graph_ptrs[4] = {nullptr, nullptr, nullptr, nullptr};
     int graph_crops[4] = {0, 0, 0, 0};
@@ -205,7 +208,11 @@ int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void
     if (const char* e = getenv("SPLICE_STEP_GRAPH")) st->use_graph = atoi(e);
     if (const char* e = getenv("SPLICE_STEP_SYNC")) st->dbg_sync = atoi(e);
     if (const char* e = getenv("SPLICE_STEP_OWN_EAGER")) st->dbg_own_eager = atoi(e);
+    if (const char* e = getenv("SPLICE_STEP_OVERLAP")) st->overlap = atoi(e);
     if (hipStreamCreateWithFlags(&st->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&st->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&st->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&st->ev_out, hipEventDisableTiming) != hipSuccess) {
         splice_set_error("splice_step_create: stream/event creation failed");
@@ -220,6 +227,9 @@ void splice_step_destroy(void* h) {
     if (!st) return;
     drop_graphs(st);
     if (st->own_stream) { (void)hipStreamSynchronize(st->own_stream); (void)hipStreamDestroy(st->own_stream); }
+    if (st->side_stream) { (void)hipStreamSynchronize(st->side_stream); (void)hipStreamDestroy(st->side_stream); }
+    if (st->ev_fork) (void)hipEventDestroy(st->ev_fork);
+    if (st->ev_join) (void)hipEventDestroy(st->ev_join);
     if (st->ev_in) (void)hipEventDestroy(st->ev_in);
     if (st->ev_out) (void)hipEventDestroy(st->ev_out);
     for (void* q : st->allocs) (void)hipFree(q);
@@ -289,6 +299,20 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     const float* A_crop = st->gen_in;
     const float* B_crop = split ? st->in_b : st->gen_in + crop;
     const float* A_entire = st->ent_in;
+    // ---- the no-grad target passes A', B' (util/losses.py:79,91,101) do not depend on the generator: their ViT forward
+    // runs on a side stream beside the generator forward (hundreds of small latency-bound launches that leave most
+    // CUs idle); inside a capture this becomes a fork/join of the graph.  The instrumented (profiling) path stays serial.
+    const bool overlap = st->overlap && !splice_prof_active();
+    hipStream_t s2 = overlap ? st->side_stream : s;
+    if (overlap) {
+        HIPCHK(hipEventRecord(st->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(s2, st->ev_fork, 0));
+    }
+    // global_transform (Resize -> Normalize; the Normalize is fused into the ViT patch gather)
+    RC(place_image(A_crop, c.crop_h, c.crop_w, vg.imgs + 0 * vimg, vg.H, vg.W, s2));
+    RC(place_image(B_crop, st->cropb_h, st->cropb_w, vg.imgs + 1 * vimg, vg.H, vg.W, s2));
+    RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, 2, 0, 2, s2));
+    if (overlap) HIPCHK(hipEventRecord(st->ev_join, s2));
     // ---- Model.forward: x_global = G(A_crop), y_global = G(B_crop) [, x_entire = G(A)]
     if (!split) {
         RC(splice_gen_forward(st->plan_g, params, st->gen_in, st->gen_out, s));
@@ -296,12 +320,10 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         RC(splice_gen_forward(st->plan_a, params, A_crop, st->gen_out, s));
         RC(splice_gen_forward(st->plan_b, params, B_crop, st->gen_out + crop, s));
     }
-    // ---- global_transform (Resize -> Normalize; the Normalize is fused into the ViT patch gather)
-    RC(place_image(A_crop, c.crop_h, c.crop_w, vg.imgs + 0 * vimg, vg.H, vg.W, s));
-    RC(place_image(B_crop, st->cropb_h, st->cropb_w, vg.imgs + 1 * vimg, vg.H, vg.W, s));
     RC(place_image(st->gen_out, c.crop_h, c.crop_w, vg.imgs + 2 * vimg, vg.H, vg.W, s));
     RC(place_image(st->gen_out + crop, st->cropb_h, st->cropb_w, vg.imgs + 3 * vimg, vg.H, vg.W, s));
-    RC(splice_vit_forward_ex(vg.ctx, vg.imgs, 1, 2, s));
+    RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, 2, 2, 4, s));
+    if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
     float *blk_g = nullptr, *qkv_g = nullptr;
     RC(splice_vit_get_tensor(vg.ctx, 0, vg.depth - 1, (void**)&blk_g));
     RC(splice_vit_get_tensor(vg.ctx, 3, vg.depth - 1, (void**)&qkv_g));
@@ -358,6 +380,10 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
 }
 
 static void drop_graphs(SpliceStep* st) {
+    if (st->graphs.empty()) return;
+    // a replay may still be in flight: the forked (two-branch) graphs must not be destroyed under the runtime
+    if (st->own_stream) (void)hipStreamSynchronize(st->own_stream);
+    if (st->side_stream) (void)hipStreamSynchronize(st->side_stream);
     for (auto& kv : st->graphs) (void)hipGraphExecDestroy(kv.second);
     st->graphs.clear();
 }

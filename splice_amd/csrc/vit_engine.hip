@@ -358,60 +358,77 @@ int splice_vit_ctx_dims(void* ctx, int* B, int* H, int* W, int* D, int* depth, i
 // Forward over the ctx's batch.  img: fp32 [B][3][H][W]; normalize != 0 applies the ImageNet
 // Normalize of util/losses.py:19 on the fly (input in [0,1]); == 0 expects a normalised image
 // (what VitExtractor receives, models/extractor.py:81).
-int splice_vit_forward_ex(void* ctx, const float* img, int normalize, int grad_pass_begin, splice_stream_t stream);
+int splice_vit_forward_ex(void* ctx, const float* img, int normalize, int grad_pass_begin, splice_stream_t stream) {
+    SpliceVitCtx* c = (SpliceVitCtx*)ctx;
+    if (!c) return SPLICE_ERR_ARG;
+    return splice_vit_forward_passes(ctx, img, normalize, grad_pass_begin, 0, c->B, stream);
+}
 int splice_vit_forward(void* ctx, const float* img, int normalize, splice_stream_t stream) {
     return splice_vit_forward_ex(ctx, img, normalize, 0, stream);
 }
 // grad_pass_begin: passes [0, grad_pass_begin) are targets that will never be differentiated -- tensors only the
 // backward reads (the pre-GELU activations) are not stored for them.
-int splice_vit_forward_ex(void* ctx, const float* img, int normalize, int grad_pass_begin, splice_stream_t stream) {
+// [pass_begin, pass_end): the passes (images) of the ctx batch this call computes.  Every kernel of the forward is
+// row-parallel over the token matrix, so disjoint pass ranges of ONE ctx may run concurrently on different
+// streams (the step runs the target passes beside the generator forward); img is always the full [B] batch.
+int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int grad_pass_begin, int pass_begin, int pass_end,
+                              splice_stream_t stream) {
     SpliceVitCtx* c = (SpliceVitCtx*)ctx;
-    if (!c || !img || grad_pass_begin < 0 || grad_pass_begin > c->B) return SPLICE_ERR_ARG;
+    if (!c || !img || grad_pass_begin < 0 || grad_pass_begin > c->B || pass_begin < 0 || pass_end > c->B || pass_begin >= pass_end)
+        return SPLICE_ERR_ARG;
     c->grad_pass_begin = grad_pass_begin;
     SpliceVit* v = c->vit;
     hipStream_t s = (hipStream_t)stream;
-    const int D = v->dim, Hd = v->hidden, pp3 = 3 * v->patch * v->patch, rows = c->rows, L = v->depth;
-    RC(patchify_launch(img, c->patches, c->B, c->H, c->W, v->patch, c->Tld, normalize, s));
+    const int D = v->dim, Hd = v->hidden, pp3 = 3 * v->patch * v->patch, L = v->depth;
+    const int Bp = pass_end - pass_begin, R = Bp * c->Tld;
+    const size_t r0 = (size_t)pass_begin * c->Tld;
+    bf16_t* patches = c->patches + r0 * pp3;
+    bf16_t* ln_out = c->ln_out + r0 * D;
+    bf16_t* hact = c->hact + r0 * Hd;
+    RC(patchify_launch(img + (size_t)pass_begin * 3 * c->H * c->W, patches, Bp, c->H, c->W, v->patch, c->Tld, normalize, s));
     {
         GemmEpi e = {};
-        e.bias = v->pe.b; e.resid = c->pos_eff; e.ldr = D; e.resid_mod = c->Tld; e.out_f32 = c->xs[0]; e.ldo = D;
-        RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, c->patches, pp3, v->pe.w, pp3, rows, D, pp3, e, s));
+        e.bias = v->pe.b; e.resid = c->pos_eff; e.ldr = D; e.resid_mod = c->Tld; e.out_f32 = c->xs[0] + r0 * D; e.ldo = D;
+        RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, patches, pp3, v->pe.w, pp3, R, D, pp3, e, s));
     }
     for (int l = 0; l < L; ++l) {
         const LayerW& W = v->layers[l];
-        RC(layernorm_fwd_launch(c->xs[l], W.ln1_g, W.ln1_b, c->ln_out, c->mean1[l], c->rstd1[l], rows, D, 1e-6f, s));
+        float* x_in = c->xs[l] + r0 * D;
+        float* x_mid = c->xmid[l] + r0 * D;
+        RC(layernorm_fwd_launch(x_in, W.ln1_g, W.ln1_b, ln_out, c->mean1[l] + r0, c->rstd1[l] + r0, R, D, 1e-6f, s));
         {
             GemmEpi e = {};
-            e.bias = W.qkv.b; e.out_bf = c->qkv[l]; e.ldbf = 3 * D; e.out_bf_t = c->qkvT[l]; e.ldt = rows;
+            e.bias = W.qkv.b; e.out_bf = c->qkv[l] + r0 * 3 * D; e.ldbf = 3 * D; e.out_bf_t = c->qkvT[l] + r0; e.ldt = c->rows;
             unsigned fl = EPI_BIAS | EPI_OUT_BF | EPI_OUT_T;
-            if (l == L - 1) { fl |= EPI_COLS_F32; e.out_f32_cols = c->qkv_last_f32; e.ld_cols = 3 * D; e.col_lo = 0; e.col_hi = 3 * D; }
+            if (l == L - 1) { fl |= EPI_COLS_F32; e.out_f32_cols = c->qkv_last_f32 + r0 * 3 * D; e.ld_cols = 3 * D; e.col_lo = 0; e.col_hi = 3 * D; }
             ProfScope ps(l == L - 1 ? 0 : 2, s);
-            RC(gemm_nt_launch(fl, c->ln_out, D, W.qkv.w, D, rows, 3 * D, D, e, s));
+            RC(gemm_nt_launch(fl, ln_out, D, W.qkv.w, D, R, 3 * D, D, e, s));
         }
         {
             AttnArgs a = {};
-            a.qkv = c->qkv[l]; a.qkvT = c->qkvT[l]; a.ldt = rows; a.B = c->B; a.T = c->T; a.Tld = c->Tld; a.D = D; a.H = v->heads;
-            a.scale = 0.125f; a.out = c->attn_out[l]; a.lse = c->lse[l];
+            a.qkv = c->qkv[l] + r0 * 3 * D; a.qkvT = c->qkvT[l] + r0; a.ldt = c->rows; a.B = Bp; a.T = c->T; a.Tld = c->Tld; a.D = D; a.H = v->heads;
+            a.scale = 0.125f; a.out = c->attn_out[l] + r0 * D; a.lse = c->lse[l] + (size_t)pass_begin * v->heads * c->Tld;
             ProfScope ps(3, s);
             RC(attn_fwd_launch(&a, s));
         }
         {
             GemmEpi e = {};
-            e.bias = W.proj.b; e.resid = c->xs[l]; e.ldr = D; e.out_f32 = c->xmid[l]; e.ldo = D;
-            RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, c->attn_out[l], D, W.proj.w, D, rows, D, D, e, s));
+            e.bias = W.proj.b; e.resid = x_in; e.ldr = D; e.out_f32 = x_mid; e.ldo = D;
+            RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, c->attn_out[l] + r0 * D, D, W.proj.w, D, R, D, D, e, s));
         }
-        RC(layernorm_fwd_launch(c->xmid[l], W.ln2_g, W.ln2_b, c->ln_out, c->mean2[l], c->rstd2[l], rows, D, 1e-6f, s));
+        RC(layernorm_fwd_launch(x_mid, W.ln2_g, W.ln2_b, ln_out, c->mean2[l] + r0, c->rstd2[l] + r0, R, D, 1e-6f, s));
         {
             GemmEpi e = {};
-            e.bias = W.fc1.b; e.out_bf = c->hact; e.ldbf = Hd; e.out_pre = c->need_grad ? c->hpre[l] : nullptr; e.ldp = Hd;
-            e.pre_row_lo = c->grad_pass_begin * c->Tld;
+            e.bias = W.fc1.b; e.out_bf = hact; e.ldbf = Hd; e.out_pre = c->need_grad ? c->hpre[l] + r0 * Hd : nullptr; e.ldp = Hd;
+            const long lo = (long)c->grad_pass_begin * c->Tld - (long)r0;   // first local row whose pre-activation is kept
+            e.pre_row_lo = lo > 0 ? (int)lo : 0;
             ProfScope ps(1, s);
-            RC(gemm_nt_launch(EPI_BIAS | EPI_GELU | EPI_OUT_BF, c->ln_out, D, W.fc1.w, D, rows, Hd, D, e, s));
+            RC(gemm_nt_launch(EPI_BIAS | EPI_GELU | EPI_OUT_BF, ln_out, D, W.fc1.w, D, R, Hd, D, e, s));
         }
         {
             GemmEpi e = {};
-            e.bias = W.fc2.b; e.resid = c->xmid[l]; e.ldr = D; e.out_f32 = c->xs[l + 1]; e.ldo = D;
-            RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, c->hact, Hd, W.fc2.w, Hd, rows, D, Hd, e, s));
+            e.bias = W.fc2.b; e.resid = x_mid; e.ldr = D; e.out_f32 = c->xs[l + 1] + r0 * D; e.ldo = D;
+            RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, hact, Hd, W.fc2.w, Hd, R, D, Hd, e, s));
         }
     }
     c->forward_done = 1;
