@@ -72,7 +72,19 @@ struct TileDma {
     __device__ __forceinline__ void piece(const bf16_t* src, bf16_t* lds, int i) const {
         __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(lds + (wave + 4 * i) * 512), 16, 0, 0);
     }
-    // token-major source: rows = tokens tok0.. (clamped to tok_max), 64 contiguous d at base + tok*ld
+    // Interior tiles: a uniform (scalar) tile base + per-lane byte offsets that are fixed for the whole kernel -- one
+    // VALU op per DMA instead of the clamp / multiply / 64-bit add chain.
+    __device__ __forceinline__ uint32_t token_off(int ld) const { return (uint32_t)(((wave * 8 + lrow) * ld + tchunk * 8) * 2); }
+    __device__ __forceinline__ uint32_t dim_off(int ldt) const { return (uint32_t)(((wave * 8 + lrow) * ldt + dchunk * 8) * 2); }
+    // tile = first element of the tile (token tile: base + tok0*ld; dim tile: baseT + tok0); stride = ld resp. ldt
+    __device__ __forceinline__ void fast_tile(const bf16_t* tile, uint32_t off, int stride, bf16_t* lds) const {
+        const char* b0 = reinterpret_cast<const char*>(tile);
+        const char* b1 = reinterpret_cast<const char*>(tile + (size_t)32 * stride);
+        asm volatile("" : "+s"(b0), "+s"(b1));   // keep the bases scalar
+        piece(reinterpret_cast<const bf16_t*>(b0 + off), lds, 0);
+        piece(reinterpret_cast<const bf16_t*>(b1 + off), lds, 1);
+    }
+    // Edge tiles: token-major source, rows = tokens tok0.. (clamped to tok_max), 64 contiguous d at base + tok*ld
     __device__ __forceinline__ void token_tile(const bf16_t* base, int ld, int tok0, int tok_max, bf16_t* lds) const {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -237,8 +249,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, int nx) {
         qf[qb][0] = ld16v(p);
         qf[qb][1] = ld16v(p + 32);
     }
-    dma.token_tile(kbase, ld, 0, a.Tld - 1, smem);
-    dma.dim_tile(vT, a.ldt, 0, a.Tld, smem + 4096);
+    const uint32_t koff = dma.token_off(ld), voff = dma.dim_off(a.ldt);
+    auto issue = [&](int kt, bf16_t* st) {
+        if (kt + 64 <= a.Tld) {
+            dma.fast_tile(kbase + (size_t)kt * ld, koff, ld, st);
+            dma.fast_tile(vT + kt, voff, a.ldt, st + 4096);
+        } else {
+            dma.token_tile(kbase, ld, kt, a.Tld - 1, st);
+            dma.dim_tile(vT, a.ldt, kt, a.Tld, st + 4096);
+        }
+    };
+    issue(0, smem);
     float m[QB], l[QB];
     f32x4 o[QB][4];
 #pragma unroll
@@ -253,11 +274,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, int nx) {
     for (int it = 0; it < nfull; ++it) {
         dma_wait_barrier();   // tile `it` has landed; tile it-1 fully consumed
         const int kn = it * 64 + 64;
-        if (kn < a.Tld) {
-            bf16_t* nxt = smem + ((it + 1) & 1) * 8192;
-            dma.token_tile(kbase, ld, kn, a.Tld - 1, nxt);
-            dma.dim_tile(vT, a.ldt, kn, a.Tld, nxt + 4096);
-        }
+        if (kn < a.Tld) issue(kn, smem + ((it + 1) & 1) * 8192);
         if (active) {
             const bf16_t* cur = smem + (it & 1) * 8192;
             attn_fwd_tile<QB, 2, false>(cur, cur + 4096, fa, qf, m, l, o, c2, it * 64, a.T, g);
@@ -362,9 +379,19 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a, int nx) {
     const bf16_t* krow = qkv_b + a.D + h * 64;
     const bf16_t* vrow = qkv_b + 2 * a.D + h * 64;
     const bf16_t* kT = a.qkvT + (size_t)(a.D + h * 64) * a.ldt + (size_t)b * a.Tld;
-    dma.token_tile(krow, ld, 0, a.Tld - 1, smem);
-    dma.token_tile(vrow, ld, 0, a.Tld - 1, smem + 4096);
-    dma.dim_tile(kT, a.ldt, 0, a.Tld, smem + 8192);
+    const uint32_t koff = dma.token_off(ld), toff = dma.dim_off(a.ldt);
+    auto issue = [&](int kt, bf16_t* st) {
+        if (kt + 64 <= a.Tld) {
+            dma.fast_tile(krow + (size_t)kt * ld, koff, ld, st);
+            dma.fast_tile(vrow + (size_t)kt * ld, koff, ld, st + 4096);
+            dma.fast_tile(kT + kt, toff, a.ldt, st + 8192);
+        } else {
+            dma.token_tile(krow, ld, kt, a.Tld - 1, st);
+            dma.token_tile(vrow, ld, kt, a.Tld - 1, st + 4096);
+            dma.dim_tile(kT, a.ldt, kt, a.Tld, st + 8192);
+        }
+    };
+    issue(0, smem);
     f32x4 dq[4];
 #pragma unroll
     for (int nd = 0; nd < 4; ++nd) dq[nd] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -373,12 +400,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a, int nx) {
     for (int it = 0; it < nfull; ++it) {
         dma_wait_barrier();
         const int kn = it * 64 + 64;
-        if (kn < a.Tld) {
-            bf16_t* nxt = smem + ((it + 1) & 1) * 12288;
-            dma.token_tile(krow, ld, kn, a.Tld - 1, nxt);
-            dma.token_tile(vrow, ld, kn, a.Tld - 1, nxt + 4096);
-            dma.dim_tile(kT, a.ldt, kn, a.Tld, nxt + 8192);
-        }
+        if (kn < a.Tld) issue(kn, smem + ((it + 1) & 1) * 12288);
         if (active) {
             const bf16_t* cur = smem + (it & 1) * 12288;
             attn_bwd_q_tile<2, false>(cur, cur + 4096, cur + 8192, fa, qf, dof, lse_q, del_q, dq, c2, it * 64, a.T, g);
@@ -468,11 +490,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a, int nx) {
     const bf16_t* doT = a.doutT + (size_t)(h * 64) * a.ldt + (size_t)b * a.Tld;
     const float* lse = a.lse + ((size_t)b * a.H + h) * a.Tld;
     const float* dl = a.delta + ((size_t)b * a.H + h) * a.Tld;
+    const uint32_t qoff = dma.token_off(ld), dooff = dma.token_off(a.D), toff = dma.dim_off(a.ldt);
     auto issue = [&](int qt, bf16_t* st) {
-        dma.token_tile(qrow, ld, qt, a.Tld - 1, st);
-        dma.token_tile(dorow, a.D, qt, a.Tld - 1, st + 4096);
-        dma.dim_tile(qT, a.ldt, qt, a.Tld, st + 8192);
-        dma.dim_tile(doT, a.ldt, qt, a.Tld, st + 12288);
+        if (qt + 64 <= a.Tld) {
+            dma.fast_tile(qrow + (size_t)qt * ld, qoff, ld, st);
+            dma.fast_tile(dorow + (size_t)qt * a.D, dooff, a.D, st + 4096);
+            dma.fast_tile(qT + qt, toff, a.ldt, st + 8192);
+            dma.fast_tile(doT + qt, toff, a.ldt, st + 12288);
+        } else {
+            dma.token_tile(qrow, ld, qt, a.Tld - 1, st);
+            dma.token_tile(dorow, a.D, qt, a.Tld - 1, st + 4096);
+            dma.dim_tile(qT, a.ldt, qt, a.Tld, st + 8192);
+            dma.dim_tile(doT, a.ldt, qt, a.Tld, st + 12288);
+        }
         if (dma.wave < 2) {   // wave 0: 64 lse values, wave 1: 64 delta values (4 bytes per lane)
             const int qq = qt + lane < a.Tld ? qt + lane : a.Tld - 1;
             const float* src = (dma.wave == 0 ? lse : dl) + qq;

@@ -106,35 +106,40 @@ struct GemmTile {
                                              int M, int N, int K, int m0, int n0, bf16_t* smem, int kbeg = 0) {
         typedef __attribute__((address_space(3))) void lds_void;
         typedef __attribute__((address_space(1))) const void glb_void;
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int tid = threadIdx.x, lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA destinations (M0) stay on the SALU
         const int wm = wave >> 1, wn = wave & 1;
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int lrow = lane >> 3, gchunk = (lane & 7) ^ lrow;
-        const bf16_t* ag[A_LOADS];
-        const bf16_t* bg[B_LOADS];
+        // per-lane BYTE offsets (32-bit, fixed for the whole K loop) from a uniform base that the SALU advances:
+        // global_load_lds in its scalar-base + vector-offset form, no per-slice address VALU
+        uint32_t ao[A_LOADS], bo[B_LOADS];
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
             int gr = m0 + wave * 8 + 32 * i + lrow;
             gr = gr < M ? gr : M - 1;
-            ag[i] = A + (size_t)gr * lda + gchunk * 8 + kbeg;
+            ao[i] = ((uint32_t)gr * (uint32_t)lda + gchunk * 8) * 2u;
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
             int gr = n0 + wave * 8 + 32 * i + lrow;
             gr = gr < N ? gr : N - 1;
-            bg[i] = B + (size_t)gr * ldb + gchunk * 8 + kbeg;
+            bo[i] = ((uint32_t)gr * (uint32_t)ldb + gchunk * 8) * 2u;
         }
         auto issue = [&](int k0, int stage) {
             bf16_t* st = smem + stage * LDS_ELEMS;
+            const char* ab = reinterpret_cast<const char*>(A + kbeg + k0);
+            const char* bb = reinterpret_cast<const char*>(B + kbeg + k0);
+            asm volatile("" : "+s"(ab), "+s"(bb));   // keep the bases scalar (the loop optimiser would fold them into 8 vector pointers)
 #pragma unroll
             for (int i = 0; i < A_LOADS; ++i)
-                __builtin_amdgcn_global_load_lds((glb_void*)(ag[i] + k0), (lds_void*)(st + (wave * 8 + 32 * i) * GEMM_BK), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void*)(ab + ao[i]), (lds_void*)(st + (wave * 8 + 32 * i) * GEMM_BK), 16, 0, 0);
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i)
-                __builtin_amdgcn_global_load_lds((glb_void*)(bg[i] + k0), (lds_void*)(st + BM * GEMM_BK + (wave * 8 + 32 * i) * GEMM_BK), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void*)(bb + bo[i]), (lds_void*)(st + BM * GEMM_BK + (wave * 8 + 32 * i) * GEMM_BK), 16, 0, 0);
         };
         issue(0, 0);
         const int frow = lane & 15, fchunk = lane >> 4;
@@ -163,6 +168,89 @@ struct GemmTile {
 #pragma unroll
                     for (int j = 0; j < FN; ++j) acc[i][j] = SWAP ? mfma16(bf[j], af[i], acc[i][j]) : mfma16(af[i], bf[j], acc[i][j]);
             }
+        }
+    }
+
+    // Deep LDS-DMA ring (NS stages, NS-1 slices in flight) for the latency-bound shapes: with one workgroup per CU
+    // and a short slice (a 64x64 tile issues 8 MFMAs per wave per slice) a 2-stage ring exposes the full
+    // global->LDS latency (~0.7-1.5 us under load) on EVERY slice.  The DMA is issued from inline asm in its
+    // scalar-base + 32-bit-lane-offset form (no address VALU, and hipcc's scoreboard -- which would drain the
+    // queue with vmcnt(0) at every barrier / first LDS read -- does not see it); the waits are counted by hand:
+    // before slice t is read, only the NS-2 younger slices may still be in flight.
+    template <int NL>
+    static __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory"); }
+    static __device__ __forceinline__ void dma16(uint32_t lds_byte, uint32_t voff, const void* sbase) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte), "v"(voff), "s"(sbase) : "memory");
+    }
+    template <int NS>
+    __device__ __forceinline__ void run_ring(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+                                             int M, int N, int K, int m0, int n0, bf16_t* smem, int kbeg = 0) {
+        static_assert(NS >= 3, "use run_glds for the 2-stage form");
+        constexpr int NL = A_LOADS + B_LOADS;
+        const int tid = threadIdx.x, lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int lrow = lane >> 3, gchunk = (lane & 7) ^ lrow;
+        uint32_t ao[A_LOADS], bo[B_LOADS];
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            int gr = m0 + wave * 8 + 32 * i + lrow;
+            gr = gr < M ? gr : M - 1;
+            ao[i] = ((uint32_t)gr * (uint32_t)lda + gchunk * 8) * 2u;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            int gr = n0 + wave * 8 + 32 * i + lrow;
+            gr = gr < N ? gr : N - 1;
+            bo[i] = ((uint32_t)gr * (uint32_t)ldb + gchunk * 8) * 2u;
+        }
+        const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) bf16_t*)smem + (uint32_t)wave * (8 * GEMM_BK * 2);
+        auto issue = [&](int sl, int stage) {
+            const uint32_t st = lds0 + (uint32_t)stage * (LDS_ELEMS * 2);
+            const bf16_t* ab = A + kbeg + sl * GEMM_BK;
+            const bf16_t* bb = B + kbeg + sl * GEMM_BK;
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) dma16(st + i * (32 * GEMM_BK * 2), ao[i], ab);
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) dma16(st + (BM + 32 * i) * (GEMM_BK * 2), bo[i], bb);
+        };
+        const int nsl = K / GEMM_BK;
+#pragma unroll
+        for (int p = 0; p < NS - 1; ++p)
+            if (p < nsl) issue(p, p);
+        const int frow = lane & 15, fchunk = lane >> 4;
+        int stage = 0, nstage = NS - 1;   // stage of slice t, stage of slice t + NS - 1
+        for (int t = 0; t < nsl; ++t) {
+            if (t + NS - 2 < nsl) wait_dma<(NS - 2) * NL>(); else wait_dma<0>();
+            __builtin_amdgcn_s_barrier();   // slice t landed for every wave; the stage of slice t-1 is free again
+            if (t + NS - 1 < nsl) issue(t + NS - 1, nstage);
+            const bf16_t* As = smem + stage * LDS_ELEMS;
+            const bf16_t* Bs = As + BM * GEMM_BK;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4 af[FM], bf[FN];
+                const int chunk = kk * 4 + fchunk;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int row = wm * (BM / 2) + i * 16 + frow;
+                    af[i] = *reinterpret_cast<const u32x4*>(As + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int row = wn * (BN / 2) + j * 16 + frow;
+                    bf[j] = *reinterpret_cast<const u32x4*>(Bs + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = SWAP ? mfma16(bf[j], af[i], acc[i][j]) : mfma16(af[i], bf[j], acc[i][j]);
+            }
+            stage = stage + 1 == NS ? 0 : stage + 1;
+            nstage = nstage + 1 == NS ? 0 : nstage + 1;
         }
     }
 
@@ -341,10 +429,10 @@ __device__ __forceinline__ void gemm_epilogue_cols(const GemmEpi& e, int M, int 
     }
 }
 
-template <int BM, int BN, unsigned FLAGS>
+template <int BM, int BN, unsigned FLAGS, int NS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
                                                       int ldb, int M, int N, int K, GemmEpi e, int gm, int ksplit) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * GemmTile<BM, BN>::LDS_ELEMS];
+    extern __shared__ __attribute__((aligned(16))) bf16_t gemm_smem[];   // NS * LDS_ELEMS
     const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
     const int nwg = gridDim.x;
     int t = xcd_remap(blockIdx.x, nwg);
@@ -360,11 +448,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
     grouped_tile(t, tiles_m, tiles_n, gm, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     GemmTile<BM, BN, true> tile;
-    tile.run_glds(A, lda, B, ldb, M, N, K, m0, n0, smem, kbeg);
+    if (NS == 2) tile.run_glds(A, lda, B, ldb, M, N, K, m0, n0, gemm_smem, kbeg);
+    else tile.template run_ring<(NS < 3 ? 3 : NS)>(A, lda, B, ldb, M, N, K, m0, n0, gemm_smem, kbeg);
     tile.for_each_cols(m0, n0, [&](int row, int col0, f32x4 v) { gemm_epilogue_cols<FLAGS>(e, M, N, row, col0, v); });
 }
 
-template <int BM, int BN, unsigned FLAGS>
+template <int BM, int BN, unsigned FLAGS, int NS>
 static inline void launch_gemm_nt(hipStream_t s, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K,
                                   const GemmEpi& e) {
     const int tm = cdiv(M, BM), tn = cdiv(N, BN);
@@ -373,5 +462,11 @@ static inline void launch_gemm_nt(hipStream_t s, const bf16_t* A, int lda, const
     // group height ~ sqrt(tiles per XCD), weighted by the tile aspect so the block is square in elements
     int gm = 1;
     while ((gm + 1) * (gm + 1) * BM <= (tm * tn / 8 + 1) * BN && gm + 1 <= tm) ++gm;
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, FLAGS>), dim3(grid), dim3(256), 0, s, A, lda, B, ldb, M, N, K, e, gm, ksplit);
+    constexpr size_t lds = (size_t)NS * GemmTile<BM, BN>::LDS_ELEMS * sizeof(bf16_t);
+    static bool attr_set = false;   // > 64 KB of dynamic LDS has to be allowed once per kernel
+    if (lds > 65536 && !attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, FLAGS, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, FLAGS, NS>), dim3(grid), dim3(256), lds, s, A, lda, B, ldb, M, N, K, e, gm, ksplit);
 }

@@ -2,23 +2,33 @@
 // DINO-ViT forward / dgrad path uses (K3, K5, K7, K8 of SURVEY.md section 2b).
 #include "kernels.h"
 
-static int g_force_tile = 0;   // 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64 (tools/gemm_bench.py)
+static int g_force_tile = 0;   // 0 auto; tile + 10 * ring: tile 1 = 128x128, 2 = 128x64, 3 = 64x64; ring 0 = 2 stages, 1 = 4 stages (tools/gemm_bench.py)
 void gemm_force_tile(int t) { g_force_tile = t; }
 
 template <unsigned FLAGS>
 static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e,
                          hipStream_t s) {
-    // 256 CUs: prefer the biggest tile that still yields >= ~1 workgroup per CU.
     const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
     const long t12864 = (long)cdiv(M, 128) * cdiv(N, 64);
-    if (g_force_tile == 1) { launch_gemm_nt<128, 128, FLAGS>(s, A, lda, B, ldb, M, N, K, e); return SPLICE_OK; }
-    if (g_force_tile == 2) { launch_gemm_nt<128, 64, FLAGS>(s, A, lda, B, ldb, M, N, K, e); return SPLICE_OK; }
-    if (g_force_tile == 3) { launch_gemm_nt<64, 64, FLAGS>(s, A, lda, B, ldb, M, N, K, e); return SPLICE_OK; }
-    // measured on MI355X (tools/gemm_bench.py): with N <= 768 the 64x64 tile wins (more workgroups on the long-K shapes)
-    if (N <= 768) { launch_gemm_nt<64, 64, FLAGS>(s, A, lda, B, ldb, M, N, K, e); return SPLICE_OK; }
-    if (t128 >= 224) launch_gemm_nt<128, 128, FLAGS>(s, A, lda, B, ldb, M, N, K, e);
-    else if (t12864 >= 200) launch_gemm_nt<128, 64, FLAGS>(s, A, lda, B, ldb, M, N, K, e);
-    else launch_gemm_nt<64, 64, FLAGS>(s, A, lda, B, ldb, M, N, K, e);
+    int tile, ring;
+    if (g_force_tile) { tile = g_force_tile % 10; ring = g_force_tile / 10; }
+    else {
+        // measured on MI355X (tools/gemm_bench.py): with N <= 768 the 64x64 tile wins (more workgroups on the long-K shapes);
+        // otherwise the biggest tile that still yields >= ~1 workgroup per CU
+        tile = N <= 768 ? 3 : t128 >= 224 ? 1 : t12864 >= 200 ? 2 : 3;
+        // few workgroups walking a long K (fc2, the fc1 / qkv dgrads): the per-slice DMA latency is exposed with 2 stages,
+        // the 4-stage ring keeps 3 slices in flight (fc1T 800x768x3072: 23.4 -> 15.3 us); elsewhere its LDS footprint costs occupancy
+        const int ks = (FLAGS == EPI_OUT_F32 && e.ksplit > 1 && K % (e.ksplit * GEMM_BK) == 0) ? e.ksplit : 1;
+        ring = (tile == 3 && K / ks >= 1536 && (long)cdiv(M, 64) * cdiv(N, 64) * ks <= 640) ? 1 : 0;
+    }
+    switch (tile * 2 + (ring ? 1 : 0)) {
+        case 2: launch_gemm_nt<128, 128, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e); break;
+        case 3: launch_gemm_nt<128, 128, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e); break;
+        case 4: launch_gemm_nt<128, 64, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e); break;
+        case 5: launch_gemm_nt<128, 64, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e); break;
+        case 6: launch_gemm_nt<64, 64, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e); break;
+        default: launch_gemm_nt<64, 64, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e); break;
+    }
     return SPLICE_OK;
 }
 

@@ -357,9 +357,22 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
             RC(mse2_launch(blk_e + 1 * epassD, ve.D, blk_g + 1 * passD, vg.D, 1, ve.D, 1.0f, l_ecls, st->losses + L_ENTIRE_CLS, ve.d_block + 1 * epassD, ve.D, s));
     }
     // ---- backward (train.py:78): ViT dgrad for the generated images only, then the generator
-    RC(splice_vit_backward(vg.ctx, 2, 4, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
-    RC(unplace_grad(vg.d_imgs + 2 * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, s));
-    RC(unplace_grad(vg.d_imgs + 3 * vimg, vg.H, vg.W, st->d_gen_out + crop, st->cropb_h, st->cropb_w, s));
+    // the two generated images are independent chains until the generator: one per stream (every launch of a
+    // dependent chain pays ~8 us of fixed latency; two chains in flight hide each other's)
+    if (overlap) {
+        HIPCHK(hipEventRecord(st->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(s2, st->ev_fork, 0));
+        RC(splice_vit_backward(vg.ctx, 3, 4, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s2));
+        RC(unplace_grad(vg.d_imgs + 3 * vimg, vg.H, vg.W, st->d_gen_out + crop, st->cropb_h, st->cropb_w, s2));
+        HIPCHK(hipEventRecord(st->ev_join, s2));
+        RC(splice_vit_backward(vg.ctx, 2, 3, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
+        RC(unplace_grad(vg.d_imgs + 2 * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, s));
+        HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
+    } else {
+        RC(splice_vit_backward(vg.ctx, 2, 4, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
+        RC(unplace_grad(vg.d_imgs + 2 * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, s));
+        RC(unplace_grad(vg.d_imgs + 3 * vimg, vg.H, vg.W, st->d_gen_out + crop, st->cropb_h, st->cropb_w, s));
+    }
     if (!split) {
         RC(splice_gen_backward(st->plan_g, params, st->d_gen_out, grads, 0, s));
     } else {

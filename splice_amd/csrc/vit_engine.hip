@@ -529,7 +529,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
                 a.qkv = c->qkv[l] + r0 * 3 * D; a.qkvT = c->qkvT[l] + r0; a.ldt = c->rows; a.B = Bp; a.T = c->T; a.Tld = c->Tld;
                 a.D = D; a.H = v->heads; a.scale = 0.125f; a.out = c->attn_out[l] + r0 * D;
                 a.lse = c->lse[l] + (size_t)pass_begin * v->heads * c->Tld;
-                a.dout = c->dout + r0 * D; a.doutT = c->doutT + r0; a.delta = c->delta; a.dqkv = dqkv;
+                a.dout = c->dout + r0 * D; a.doutT = c->doutT + r0; a.delta = c->delta + (size_t)pass_begin * v->heads * c->Tld; a.dqkv = dqkv;
                 RC(attn_bwd_launch(&a, s));
             }
             g_after_mlp = g;
