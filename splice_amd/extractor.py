@@ -114,8 +114,8 @@ class VitExtractor:
             if state_dict is None:
                 checkpoint = checkpoint or os.environ.get("SPLICE_DINO_CHECKPOINT")
                 if checkpoint:
-                    state_dict = torch.load(checkpoint, map_location="cpu")
-                    state_dict = {k: v for k, v in state_dict.items() if not k.startswith("head")}
+                    from .checkpoint import load_dino_checkpoint
+                    _, state_dict = load_dino_checkpoint(checkpoint, model_name)
                 elif synthetic or os.environ.get("SPLICE_SYNTHETIC_WEIGHTS") == "1":
                     state_dict = synth.vit_params(seed, model_name, img_size=224)
                 else:

@@ -3,15 +3,14 @@
 Same contract as the reference (``train.py:15-80``): reads ``conf/default/config.yaml`` from the
 working directory (falling back to the packaged copy), seeds python / numpy / torch, opens the first
 image of ``<dataroot>/A`` and ``<dataroot>/B``, runs ``n_epochs`` optimisation steps and every
-``log_images_freq`` steps writes ``<dataroot>/out/output.png`` and calls ``callback(output[0])`` with
-the ``[3,H,W]`` float image.  The step itself is the fused HIP engine (``SpliceEngine``), one host
+``log_images_freq`` steps writes ``<dataroot>/out/output.png`` (asynchronously: ``util.AsyncResultWriter``) and calls
+``callback(output[0])`` with the ``[3,H,W]`` float image.  The step itself is the fused HIP engine (``SpliceEngine``), one host
 call per step, losses read back only when a progress line is printed.
 
 Data feed: the reference augments PIL images on the CPU every step (``data/Dataset.py:62-70``).
-Here the images live on the GPU; per step a random square crop covering >= ``min_cover`` of the
-height (``data/transforms.py:19-27``) and the random horizontal flips of both pipelines are applied
-on device.  ColorJitter / GaussianBlur of the structure pipeline (``data/transforms.py:30-37``) are
-NOT implemented yet; ``use_augmentations: False`` is exact.
+Here the images live on the GPU and the same pipelines run on device tensors (``splice_amd/augment.py``):
+structure image = h-flip(0.5), ColorJitter(.4,.4,.2,.1)@0.5, GaussianBlur(3)@0.2; texture image = h-flip(0.5);
+then one random square crop covering >= ``min_cover`` of the height (``data/transforms.py:7-41``).
 """
 import os
 import random
@@ -21,8 +20,9 @@ import numpy as np
 import torch
 import yaml
 
+from . import augment
 from .engine import SpliceEngine
-from .util import save_result
+from .util import AsyncResultWriter
 
 device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
 _PKG_CFG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conf", "default", "config.yaml")
@@ -55,16 +55,11 @@ class DeviceDataFeed:
     def get_A(self):
         return self.A[None]
 
-    def _crop(self, img, min_cover, flip):
+    @staticmethod
+    def _crop(img, min_cover):
         _, h, w = img.shape
-        size = int(round(np.random.uniform(min_cover * h, h)))   # data/transforms.py:21
-        size = min(size, w)                                      # :22
-        top = int(torch.randint(0, h - size + 1, (1,)).item())   # RandomCrop
-        left = int(torch.randint(0, w - size + 1, (1,)).item())
-        crop = img[:, top:top + size, left:left + size]
-        if flip and torch.rand(1).item() < 0.5:                  # RandomHorizontalFlip(p=0.5)
-            crop = crop.flip(-1)
-        return crop.contiguous()
+        top, left, size = augment.global_crop_box(h, w, min_cover)
+        return img[:, top:top + size, left:left + size].contiguous()
 
     def next(self):
         self.step += 1
@@ -72,8 +67,11 @@ class DeviceDataFeed:
         sample = {'step': self.step}
         if self.step % self.cfg['entire_A_every'] == 0:
             sample['A'] = self.get_A()
-        sample['A_global'] = self._crop(self.A, self.cfg['global_A_crops_min_cover'], aug)
-        sample['B_global'] = self._crop(self.B, self.cfg['global_B_crops_min_cover'], aug)
+        # data/Dataset.py:67-68: augment the whole image, then crop
+        A = augment.structure_transforms(self.A) if aug else self.A
+        sample['A_global'] = self._crop(A, self.cfg['global_A_crops_min_cover'])
+        B = augment.texture_transforms(self.B) if aug else self.B
+        sample['B_global'] = self._crop(B, self.cfg['global_B_crops_min_cover'])
         return sample
 
 
@@ -107,7 +105,8 @@ def train_model(dataroot, callback=None, cfg_overrides=None, vit_state=None, pro
     if vit_state is None:
         ckpt = os.environ.get("SPLICE_DINO_CHECKPOINT")
         if ckpt:
-            vit_state = {k: v for k, v in torch.load(ckpt, map_location="cpu").items() if not k.startswith("head")}
+            from .checkpoint import load_dino_checkpoint
+            _, vit_state = load_dino_checkpoint(ckpt, cfg['dino_model_name'])
         elif os.environ.get("SPLICE_SYNTHETIC_WEIGHTS") == "1":
             from . import synth
             vit_state = synth.vit_params(1234, cfg['dino_model_name'], img_size=224)
@@ -122,16 +121,20 @@ def train_model(dataroot, callback=None, cfg_overrides=None, vit_state=None, pro
     engine = SpliceEngine(cfg, vit_state, gen_state, (crop_max, crop_max), tuple(A.shape[1:]), device=device)
     del netG
 
-    for epoch in range(1, cfg['n_epochs'] + 1):
-        inputs = feed.next()
-        engine.step(inputs['A_global'], inputs['B_global'], inputs.get('A', [None])[0] if 'A' in inputs else None)
-        if progress and (epoch % 50 == 0 or epoch == 1):
-            print(f"Epoch {epoch}: loss={engine.losses()['loss']:.4f} lr={cfg['lr']}")
-        if epoch % cfg['log_images_freq'] == 0:
-            output = engine.generate(feed.get_A())
-            save_result(output[0], cfg['dataroot'])
-            if callback is not None:
-                callback(output[0])
+    writer = AsyncResultWriter(cfg['dataroot'])   # PNG encode + disk write happen on a worker thread
+    try:
+        for epoch in range(1, cfg['n_epochs'] + 1):
+            inputs = feed.next()
+            engine.step(inputs['A_global'], inputs['B_global'], inputs.get('A', [None])[0] if 'A' in inputs else None)
+            if progress and (epoch % 50 == 0 or epoch == 1):
+                print(f"Epoch {epoch}: loss={engine.losses()['loss']:.4f} lr={cfg['lr']}")
+            if epoch % cfg['log_images_freq'] == 0:
+                output = engine.generate(feed.get_A())
+                writer.submit(output[0])
+                if callback is not None:
+                    callback(output[0])
+    finally:
+        writer.close()
     return engine
 
 

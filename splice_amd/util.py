@@ -61,3 +61,63 @@ def save_result(image_t, dataroot):
     path = Path(f"{dataroot}/out")
     path.mkdir(exist_ok=True, parents=True)
     Image.fromarray(arr).save(f"{path}/output.png")
+
+
+class AsyncResultWriter:
+    """``save_result`` off the critical path.
+
+    The reference's ``train.py:70-76`` stalls the loop every ``log_images_freq`` steps on a device->host copy plus
+    a PNG encode.  ``submit`` only enqueues an asynchronous copy into a pinned host buffer on the current stream and
+    an event; a worker thread waits for the event, converts (ToPILImage semantics) and writes
+    ``<dataroot>/out/output.png``.  At most one image is in flight per slot (two slots): a newer result simply
+    overwrites the file later, as the reference does.  ``close()`` drains the queue (called at the end of
+    ``train_model`` so the final PNG is on disk when it returns)."""
+
+    def __init__(self, dataroot, slots=2):
+        import queue
+        import threading
+        self.dir = Path(f"{dataroot}/out")
+        self.dir.mkdir(exist_ok=True, parents=True)
+        self._q = queue.Queue()
+        self._free = queue.Queue()
+        for _ in range(slots):
+            self._free.put(None)
+        self._err = None
+        self._t = threading.Thread(target=self._run, name="splice-result-writer", daemon=True)
+        self._t.start()
+
+    def submit(self, image_t):
+        buf = self._free.get()                      # blocks only if `slots` images are still being written
+        img = image_t.detach()
+        if buf is None or buf.shape != img.shape:
+            buf = torch.empty(img.shape, dtype=torch.float32, pin_memory=img.is_cuda)
+        buf.copy_(img, non_blocking=True)
+        ev = None
+        if img.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+        self._q.put((buf, ev))
+
+    def _run(self):
+        from PIL import Image
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            buf, ev = item
+            try:
+                if ev is not None:
+                    ev.synchronize()
+                arr = (buf.clamp(0.0, 1.0).numpy().transpose(1, 2, 0) * 255.0).astype(np.uint8)
+                tmp = self.dir / "output.png.tmp"
+                Image.fromarray(arr).save(tmp, format="PNG")
+                tmp.replace(self.dir / "output.png")      # readers never see a half-written file
+            except Exception as e:                         # surfaced by close()
+                self._err = e
+            self._free.put(buf)
+
+    def close(self):
+        self._q.put(None)
+        self._t.join()
+        if self._err is not None:
+            raise self._err

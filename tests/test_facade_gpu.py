@@ -110,3 +110,34 @@ def test_train_model_smoke(tmp_path, monkeypatch):
     assert seen == [(3, 72, 96), (3, 72, 96)]
     assert (tmp_path / "out" / "output.png").exists()
     assert eng.step_idx == 19 and np.isfinite(eng.losses()["loss"])
+
+
+@pytest.mark.parametrize("name", ["dino_vits8", "dino_vits16", "dino_vitb8", "dino_vitb16"])
+def test_checkpoint_to_extractor_all_variants(name, tmp_path):
+    """a DINO .pth on disk (224-grid position table) -> VitExtractor, for every variant
+    models/extractor.py:105-130 can parse; features on a non-square image (interpolated position table)
+    against the fp32 oracle with the same weights."""
+    from oracle import dino_vit
+    from splice_amd.extractor import VitExtractor
+    patch, dim, depth, heads = synth.DINO_CONFIGS[name]
+    sd = synth.vit_params(21, name, img_size=224, w_std=0.04)
+    path = tmp_path / f"{name}_pretrain.pth"
+    torch.save({"teacher": {"module.backbone." + k: torch.from_numpy(v) for k, v in sd.items()}}, path)
+    ext = VitExtractor(name, DEV, checkpoint=str(path))
+    assert (ext.get_patch_size(), ext.get_head_num(), ext.get_embedding_dim()) == (patch, heads, dim)
+    H, W = 96, 64
+    img = torch.from_numpy(synth.normal(4, f"ck/{name}", (1, 3, H, W)))
+    m = dino_vit.VisionTransformer(patch, dim, depth, heads, img_size=224).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    from oracle import extractor as oext
+    with torch.no_grad():
+        ref_block = dino_vit.forward_features(m, img)["block"][-1]
+        ref_keys = oext.keys_from_input(m, img, depth - 1)
+    feats = ext.get_feature_from_input(img.to(DEV))
+    T = 1 + (H // patch) * (W // patch)
+    assert len(feats) == depth and feats[-1].shape == (1, T, dim)
+    rel = lambda a, b: ((a.cpu().double() - b.double()).norm() / b.double().norm()).item()
+    assert rel(feats[-1], ref_block) < 2e-2
+    assert rel(ext.get_keys_from_input(img.to(DEV), depth - 1), ref_keys) < 2e-2
+    with pytest.raises(ValueError, match="was requested"):
+        VitExtractor("dino_vitb16" if name != "dino_vitb16" else "dino_vits8", DEV, checkpoint=str(path))

@@ -1,6 +1,7 @@
 """CPU: host-side logic of the product (no HIP calls): Resize output sizes, position-embedding
 interpolation, the synthetic generators, the device data feed's crop law."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import dino_vit, losses as olosses
@@ -76,3 +77,135 @@ def test_device_data_feed_crop_law():
     feed = train.DeviceDataFeed(cfg, A, A)
     s = feed.next()
     assert torch.equal(s['A_global'], A[:, :, :100]) or s['A_global'].shape == (3, 100, 100)
+
+
+# ---- device augmentations (splice_amd/augment.py) against PIL / colorsys: the arithmetic the reference's PIL pipeline
+# (data/transforms.py:30-41) performs, up to its uint8 rounding (one or two grey levels per op)
+def _pil(img):
+    from PIL import Image
+    return Image.fromarray((img.permute(1, 2, 0).numpy() * 255.0 + 0.5).astype(np.uint8))
+
+
+def _unpil(im):
+    return torch.from_numpy(np.asarray(im, dtype=np.float32) / 255.0).permute(2, 0, 1)
+
+
+@pytest.mark.parametrize("factor", [0.6, 0.93, 1.4])
+def test_color_jitter_ops_match_pil(factor):
+    from PIL import ImageEnhance
+    from splice_amd import augment
+    img = _unpil(_pil(torch.from_numpy(synth.smooth_image_pair(3, 0, 40, 56)[0])))   # exactly representable in uint8
+    tol = 2.5 / 255
+    assert (augment.adjust_brightness(img, factor) - _unpil(ImageEnhance.Brightness(_pil(img)).enhance(factor))).abs().max() < tol
+    assert (augment.adjust_contrast(img, factor) - _unpil(ImageEnhance.Contrast(_pil(img)).enhance(factor))).abs().max() < tol
+    assert (augment.adjust_saturation(img, factor) - _unpil(ImageEnhance.Color(_pil(img)).enhance(factor))).abs().max() < tol
+
+
+@pytest.mark.parametrize("shift", [-0.1, 0.037, 0.1])
+def test_adjust_hue_matches_colorsys(shift):
+    import colorsys
+    from splice_amd import augment
+    img = torch.from_numpy(synth.image_pair(9, 0, 12, 10)[0])
+    out = augment.adjust_hue(img, shift)
+    ref = np.empty((3, 12, 10), dtype=np.float64)
+    a = img.numpy().astype(np.float64)
+    for y in range(12):
+        for x in range(10):
+            h, s, v = colorsys.rgb_to_hsv(a[0, y, x], a[1, y, x], a[2, y, x])
+            ref[:, y, x] = colorsys.hsv_to_rgb((h + shift) % 1.0, s, v)
+    assert np.abs(out.numpy() - ref).max() < 2e-6
+    # hue rotation keeps value (max channel) and saturation
+    assert (out.max(0).values - img.max(0).values).abs().max() < 1e-6
+
+
+def test_gaussian_blur3_is_separable_reflect():
+    from splice_amd import augment
+    img = torch.from_numpy(synth.image_pair(5, 0, 9, 11)[0])
+    for sigma in (0.1, 0.8, 2.0):
+        wc, ws = augment.blur_sigma_to_weights(sigma)
+        assert abs(wc + 2 * ws - 1) < 1e-12
+        pad = np.pad(img.numpy(), ((0, 0), (1, 1), (1, 1)), mode="reflect").astype(np.float64)
+        rows = ws * pad[:, :, :-2] + wc * pad[:, :, 1:-1] + ws * pad[:, :, 2:]
+        ref = ws * rows[:, :-2] + wc * rows[:, 1:-1] + ws * rows[:, 2:]
+        assert np.abs(augment.gaussian_blur3(img, sigma).numpy() - ref).max() < 1e-6
+    assert (augment.gaussian_blur3(img, 0.1) - img).abs().max() < 1e-6   # sigma 0.1: identity to 1e-22
+
+
+def test_structure_pipeline_statistics():
+    """Rates of the three random branches and ranges of their parameters (data/transforms.py:30-37)."""
+    from splice_amd import augment
+    torch.manual_seed(11)
+    img = torch.from_numpy(synth.smooth_image_pair(3, 0, 24, 32)[0])
+    n, flips, jit, blur = 2000, 0, 0, 0
+    for _ in range(n):
+        out = augment.structure_transforms(img)
+        assert out.shape == img.shape and out.min() >= -1e-6 and out.max() <= 1 + 1e-6
+        same, mirrored = torch.equal(out, img), torch.equal(out, img.flip(-1))
+        if not (same or mirrored):
+            jit += 1   # jitter and/or blur changed the pixels
+    torch.manual_seed(12)
+    for _ in range(n):
+        flips += int(torch.equal(augment.texture_transforms(img), img.flip(-1)))
+    assert abs(flips / n - 0.5) < 0.04
+    assert abs(jit / n - (1 - 0.5 * 0.8)) < 0.04          # P(jitter or blur) = 1 - 0.5 * 0.8 = 0.6
+    orders, facs = set(), []
+    for _ in range(500):
+        o, f = augment.color_jitter_params()
+        orders.add(tuple(o)); facs.append(f)
+    facs = np.array(facs)
+    assert len(orders) == 24
+    assert facs[:, 0].min() >= 0.6 and facs[:, 0].max() <= 1.4 and facs[:, 1].min() >= 0.6 and facs[:, 1].max() <= 1.4
+    assert facs[:, 2].min() >= 0.8 and facs[:, 2].max() <= 1.2 and np.abs(facs[:, 3]).max() <= 0.1
+    assert abs(facs[:, 0].mean() - 1.0) < 0.03 and abs(facs[:, 3].mean()) < 0.01
+
+
+# ---- local DINO checkpoint loader (splice_amd/checkpoint.py), all four variants, both public file layouts
+@pytest.mark.parametrize("name", ["dino_vits8", "dino_vits16", "dino_vitb8", "dino_vitb16"])
+def test_checkpoint_loader_variants(name, tmp_path):
+    from splice_amd import checkpoint
+    patch, dim, depth, heads = synth.DINO_CONFIGS[name]
+    specs = synth.vit_param_specs(patch, dim, depth, 224)
+    flat = {n: torch.full(tuple(s), 0.5) for n, s, _ in specs}
+    assert tuple(flat["pos_embed"].shape) == (1, 1 + (224 // patch) ** 2, dim)
+    p1 = tmp_path / "backbone.pth"
+    torch.save(flat, p1)
+    got_name, sd = checkpoint.load_dino_checkpoint(str(p1))
+    assert got_name == name and list(sd) == [n for n, _, _ in specs]
+    assert all(v.dtype == np.float32 for v in sd.values())
+    # *_full_checkpoint.pth layout: teacher / student with DDP + backbone prefixes and a projection head
+    full = {"teacher": {"module.backbone." + k: v.half() for k, v in flat.items()}, "student": {}, "epoch": 100}
+    full["teacher"]["module.head.mlp.0.weight"] = torch.zeros(8, dim)
+    full["teacher"]["module.head.last_layer.weight_g"] = torch.zeros(8, 1)
+    p2 = tmp_path / "full.pth"
+    torch.save(full, p2)
+    got_name, sd2 = checkpoint.load_dino_checkpoint(str(p2), name)
+    assert got_name == name and set(sd2) == set(sd) and sd2["cls_token"].dtype == np.float32
+    other = "dino_vitb16" if name != "dino_vitb16" else "dino_vits8"
+    with pytest.raises(ValueError, match="was requested"):
+        checkpoint.load_dino_checkpoint(str(p1), other)
+    bad = dict(flat)
+    del bad["blocks.3.mlp.fc2.bias"]
+    torch.save(bad, p1)
+    with pytest.raises(ValueError, match="missing"):
+        checkpoint.load_dino_checkpoint(str(p1))
+    bad = dict(flat)
+    bad["blocks.0.attn.qkv.weight"] = torch.zeros(3 * dim, dim + 1)
+    torch.save(bad, p1)
+    with pytest.raises(ValueError, match="shape"):
+        checkpoint.load_dino_checkpoint(str(p1))
+
+
+def test_async_result_writer(tmp_path):
+    """util/util.py:55-59 semantics (ToPILImage: float [0,1] -> uint8 by truncation), written by the worker thread."""
+    from PIL import Image
+    from splice_amd.util import AsyncResultWriter, save_result
+    w = AsyncResultWriter(str(tmp_path))
+    imgs = [torch.from_numpy(synth.image_pair(3, i, 20, 28)[0]) for i in range(5)]
+    for im in imgs:
+        w.submit(im)
+    w.close()
+    got = np.asarray(Image.open(tmp_path / "out" / "output.png"))
+    assert np.array_equal(got, (imgs[-1].numpy().transpose(1, 2, 0) * 255.0).astype(np.uint8))
+    save_result(imgs[-1], str(tmp_path / "sync"))
+    assert np.array_equal(got, np.asarray(Image.open(tmp_path / "sync" / "out" / "output.png")))
+    assert not (tmp_path / "out" / "output.png.tmp").exists()
