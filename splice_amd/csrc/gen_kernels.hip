@@ -556,10 +556,83 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
     if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;
 }
 
+// Small planes (<= BN_SMALL_HW pixels: every layer from the 56x56 scale down at 224^2): ONE workgroup owns a whole
+// (image, channel) plane, so statistics + apply are a single launch (the plane is re-read from L1/L2).  These layers are
+// pure launch latency -- a kernel boundary costs more than the work.
+constexpr int BN_SMALL_HW = 4096;
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ y, size_t y_nstride, float* __restrict__ out,
+                                                           size_t out_nstride, int C, int HW, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float* __restrict__ mean_o,
+                                                           float* __restrict__ rstd_o, float slope) {
+    __shared__ float red[8];
+    const int c = blockIdx.x, img = blockIdx.y;
+    const float* p = y + (size_t)img * y_nstride + (size_t)c * HW;
+    float* q = out + (size_t)img * out_nstride + (size_t)c * HW;
+    float s = 0.f, dummy = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    block_sum2(s, dummy, red);
+    const float m = s / (float)HW;
+    float sq = 0.f;
+    dummy = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) { const float d = p[i] - m; sq += d * d; }
+    block_sum2(sq, dummy, red);
+    const float r = rsqrtf(sq / (float)HW + eps);
+    if (threadIdx.x == 0) { mean_o[img * C + c] = m; rstd_o[img * C + c] = r; }
+    const float sc = gamma[c] * r;
+    const float sh = beta[c] - m * sc;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float v = p[i] * sc + sh;
+        q[i] = v > 0.f ? v : v * slope;
+    }
+}
+// one workgroup per channel walks the images in order (dgamma / dbeta sum over images deterministically)
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ da, size_t da_nstride, const float* __restrict__ aout,
+                                                           size_t a_nstride, const float* __restrict__ y, size_t y_nstride,
+                                                           float* __restrict__ dy, size_t dy_nstride, int C, int HW, int N,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, float slope, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int accumulate) {
+    __shared__ float red[8];
+    const int c = blockIdx.x;
+    float g = 0.f, be = 0.f;
+    for (int img = 0; img < N; ++img) {
+        const float m = mean[img * C + c], r = rstd[img * C + c];
+        const float* pd = da + (size_t)img * da_nstride + (size_t)c * HW;
+        const float* pa = aout + (size_t)img * a_nstride + (size_t)c * HW;
+        const float* py = y + (size_t)img * y_nstride + (size_t)c * HW;
+        float* po = dy + (size_t)img * dy_nstride + (size_t)c * HW;
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            float dz = pd[i];
+            if (slope != 1.0f && !(pa[i] > 0.f)) dz *= slope;
+            s1 += dz;
+            s2 += dz * (py[i] - m) * r;
+        }
+        block_sum2(s1, s2, red);
+        be += s1;
+        g += s2;
+        const float k1 = s1 / (float)HW, k2 = s2 / (float)HW;
+        const float gr = gamma[c] * r;
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            float dz = pd[i];
+            if (slope != 1.0f && !(pa[i] > 0.f)) dz *= slope;
+            po[i] = gr * (dz - k1 - (py[i] - m) * r * k2);
+        }
+    }
+    if (threadIdx.x == 0) {
+        dgamma[c] = accumulate ? dgamma[c] + g : g;
+        dbeta[c] = accumulate ? dbeta[c] + be : be;
+    }
+}
+
 static inline int plane_blocks(int HW) { int b = cdiv(HW, 1024); return b < 1 ? 1 : (b > MAX_PB ? MAX_PB : b); }
 int bn_part_floats(int N, int C) { return N * C * MAX_PB * 2; }
 int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
                   const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s) {
+    if (HW <= BN_SMALL_HW) {
+        hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd, slope);
+        return SPLICE_OK;
+    }
     const int PB = plane_blocks(HW);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, C, HW, PB, part);
     hipLaunchKernelGGL(bn_act_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, PB, gamma, beta, part, eps, mean, rstd, slope);
@@ -568,6 +641,11 @@ int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstri
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
                   float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s) {
+    if (HW <= BN_SMALL_HW) {
+        hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(C), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy, dy_nstride, C, HW, N,
+                           gamma, mean, rstd, slope, dgamma, dbeta, accumulate);
+        return SPLICE_OK;
+    }
     const int PB = plane_blocks(HW);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, C, HW, PB, mean, rstd, slope, part);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy,
