@@ -84,6 +84,7 @@ struct SpliceGenPlan {
     size_t conv_ws_floats = 0;
     size_t head_wg_off = 0;
     WgradReduceAll red;                   // filled during a backward, consumed by its single reduce launch
+    WgradBatch wg;                        // every layer's weight-gradient work of a backward: one launch after the dgrad chain
     float* out_copy = nullptr;            // generator output kept for the sigmoid backward
     float* x_copy = nullptr;              // private copy of the input (the caller may free x after forward)
     int forward_saved = 0;
@@ -238,7 +239,7 @@ static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* par
         a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2;
         a.ws = p->wgrad_ws + u.wg_off;
         int chunks = 0;
-        RC(conv_wgrad_launch(a, &chunks, s));
+        RC(conv_wgrad_add(&const_cast<SpliceGenPlan*>(p)->wg, a, &chunks));
         WgradReduceAll& r = const_cast<SpliceGenPlan*>(p)->red;
         const int li = r.count++;
         r.n[li] = u.Cout * u.Cin * u.ks * u.ks; r.chunks[li] = chunks; r.ws_off[li] = (long long)u.wg_off; r.dw_off[li] = (long long)u.w_off;
@@ -445,6 +446,7 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
     hipStream_t s = (hipStream_t)stream;
     const size_t npix = (size_t)p->N * 3 * p->H * p->W;
     p->red.count = 0;
+    p->wg.count = 0; p->wg.total_wgs = 0;
     const Unit& u = p->u_up1[0];
     const int HW = p->H * p->W;
     (void)npix;
@@ -456,7 +458,7 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
         a.N = p->N; a.Cin = UP[0]; a.Hi = p->H; a.Wi = p->W; a.Cout = 3; a.Ho = p->H; a.Wo = p->W; a.ks = 1; a.stride = 1; a.pad = 0;
         a.ws = p->wgrad_ws + p->head_wg_off;
         int chunks = 0;
-        RC(conv_wgrad_launch(a, &chunks, s));
+        RC(conv_wgrad_add(&p->wg, a, &chunks));
         WgradReduceAll& r = p->red;
         const int li = r.count++;
         r.n[li] = 3 * UP[0]; r.chunks[li] = chunks; r.ws_off[li] = (long long)p->head_wg_off; r.dw_off[li] = (long long)p->head_w;
@@ -470,6 +472,7 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
         RC(conv_launch(a, s));
     }
     RC(scale_backward(p, 0, params, grads, accumulate, s));
+    RC(conv_wgrad_batched_launch(p->wg, s));   // all layers' partials, one launch
     {   // one deterministic reduction of every layer's per-chunk weight-gradient partials
         WgradReduceAll& r = p->red;
         r.prefix[0] = 0;

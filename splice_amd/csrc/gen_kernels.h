@@ -29,7 +29,18 @@ struct WgradArgs {
     int pix_per_chunk, chunks_per_img;   // filled by the launcher
 };
 int wgrad_chunks(int N, int Ho, int Wo, int* pix_per_chunk, int* chunks_per_img);
-int conv_wgrad_launch(WgradArgs a, int* chunks_out, hipStream_t s);   // writes per-chunk partials into a.ws
+constexpr int WGRAD_BATCH_MAX = 32;
+struct WgradDesc {           // compact per-layer descriptor of the batched weight-gradient launch (72 bytes)
+    const float* x; const float* dy; float* ws;
+    uint32_t x_nstride, x_cstride, dy_nstride, dy_cstride;
+    uint16_t Cin, Cout, Hi, Wi, Ho, Wo;
+    uint8_t ks, stride, pad, variant;
+    uint16_t pix_per_chunk, chunks_per_img;
+    uint32_t wg_begin, chunks;
+};
+struct WgradBatch { int count; int total_wgs; WgradDesc d[WGRAD_BATCH_MAX]; };   // by-value kernel argument
+int conv_wgrad_add(WgradBatch* b, WgradArgs a, int* chunks_out);       // queue one layer; partials go to a.ws
+int conv_wgrad_batched_launch(const WgradBatch& b, hipStream_t s);     // one launch for every queued layer
 
 constexpr int WGRAD_MAX_LAYERS = 64;   // 26 conv weights + 25 exact-zero bias ranges (chunks == 0)
 struct WgradReduceAll {      // by-value kernel argument: one entry per conv layer of a backward

@@ -222,21 +222,23 @@ int conv_launch(const ConvArgs& a, hipStream_t s) {
 // Workgroup = (pixel chunk, 4-or-16-channel K tile); MFMA reduces over pixels (64 per LDS fill, the next
 // fill prefetched into registers); the partial tile goes to ws[chunk][n][c][tap] and ONE
 // wgrad_reduce_all_kernel per backward sums every layer's chunks in a fixed order (bit-reproducible).
+constexpr int WG_PC = 64;                      // pixels per LDS fill
+constexpr int WG_LD = WG_PC + 2;               // 66 = 2*33
+constexpr int WG_XS_FLOATS = 3 * 16 * WG_LD;   // [k][pixel], largest variant (3x3: 36 -> 48 k rows)
+constexpr int WG_DS_FLOATS = 8 * 16 * WG_LD;   // [n][pixel], largest variant (128 output channels)
 template <int KS, int NI>   // NI = 16-row fragments of output channels
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+__device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, int chunk, int ktile, float* Xs, float* Ds) {
     constexpr int T = KS * KS;
     constexpr int CK = (KS == 3) ? 4 : 16;
     constexpr int KT = CK * T;                 // 36 / 16
     constexpr int NJ = (KT + 15) / 16;         // 3 / 1
-    constexpr int PC = 64;                     // pixels per LDS fill
-    constexpr int LD = PC + 2;                 // 66 = 2*33
+    constexpr int PC = WG_PC;
+    constexpr int LD = WG_LD;
     constexpr int NQ = (NI * NJ + 3) / 4;      // fragment pairs per wave
     constexpr int NA = KT / 4;                 // gathered x elements per thread per fill
     constexpr int ND = NI * 16 * PC / 256;     // dy elements per thread per fill
-    __shared__ float Xs[NJ * 16 * LD];         // [k][pixel]
-    __shared__ float Ds[NI * 16 * LD];         // [n][pixel]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = blockIdx.x, c0 = blockIdx.y * CK;
+    const int c0 = ktile * CK;
     const int HWo = a.Ho * a.Wo;
     const int chunks_per_img = a.chunks_per_img;
     const int img = chunk / chunks_per_img, ch_in_img = chunk % chunks_per_img;
@@ -352,16 +354,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(WgradReduceAll d,
     *q = accumulate ? *q + s : s;
 }
 
-template <int KS>
-static void wgrad_launch_fn(const WgradArgs& a, int chunks, int ktiles, hipStream_t s) {
-    const int ni = cdiv(a.Cout, 16);
-    dim3 grid(chunks, ktiles);
-    if (ni <= 1) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 1>), grid, dim3(256), 0, s, a);
-    else if (ni <= 2) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 2>), grid, dim3(256), 0, s, a);
-    else if (ni <= 4) hipLaunchKernelGGL((conv_wgrad_kernel<KS, 4>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<KS, 8>), grid, dim3(256), 0, s, a);
-}
-
 int wgrad_chunks(int N, int Ho, int Wo, int* pix_per_chunk, int* chunks_per_img) {
     const int HWo = Ho * Wo;
     int ppc = 512;
@@ -372,15 +364,61 @@ int wgrad_chunks(int N, int Ho, int Wo, int* pix_per_chunk, int* chunks_per_img)
     return N * *chunks_per_img;
 }
 
-// partial sums only; returns the number of chunks written (the caller records it for wgrad_reduce_all_launch)
-int conv_wgrad_launch(WgradArgs a, int* chunks_out, hipStream_t s) {
-    if (a.Cout > 128 || (a.ks != 1 && a.ks != 3)) return SPLICE_ERR_ARG;
-    if ((size_t)a.Cin * a.x_cstride > 0x7fffffffULL) return SPLICE_ERR_ARG;
+// Every conv layer's weight gradient of a backward in ONE launch: the layers are independent of each other (each needs
+// only its own input and output gradient, all in place once the dgrad chain has finished), so instead of ~30 small
+// serial kernels the workgroups of all layers fill the chip together.  Workgroup -> (layer, pixel chunk, channel tile)
+// through the prefix table of the by-value descriptor array; the (filter size, output-channel fragments) variant is a
+// workgroup-uniform switch.
+__global__ __launch_bounds__(256) void conv_wgrad_batched_kernel(WgradBatch b) {
+    __shared__ float Xs[WG_XS_FLOATS];
+    __shared__ float Ds[WG_DS_FLOATS];
+    int l = 0;
+#pragma unroll 1
+    while (l + 1 < b.count && blockIdx.x >= b.d[l + 1].wg_begin) ++l;
+    const WgradDesc& d = b.d[l];
+    WgradArgs a;
+    a.x = d.x; a.dy = d.dy; a.ws = d.ws;
+    a.x_nstride = d.x_nstride; a.x_cstride = d.x_cstride; a.dy_nstride = d.dy_nstride; a.dy_cstride = d.dy_cstride;
+    a.N = 0; a.Cin = d.Cin; a.Hi = d.Hi; a.Wi = d.Wi; a.Cout = d.Cout; a.Ho = d.Ho; a.Wo = d.Wo;
+    a.ks = d.ks; a.stride = d.stride; a.pad = d.pad; a.pix_per_chunk = d.pix_per_chunk; a.chunks_per_img = d.chunks_per_img;
+    const int local = blockIdx.x - d.wg_begin;
+    const int chunk = local % d.chunks, ktile = local / d.chunks;
+    switch (d.variant) {
+        case 0: conv_wgrad_body<1, 1>(a, chunk, ktile, Xs, Ds); break;
+        case 1: conv_wgrad_body<1, 2>(a, chunk, ktile, Xs, Ds); break;
+        case 2: conv_wgrad_body<1, 4>(a, chunk, ktile, Xs, Ds); break;
+        case 3: conv_wgrad_body<1, 8>(a, chunk, ktile, Xs, Ds); break;
+        case 4: conv_wgrad_body<3, 1>(a, chunk, ktile, Xs, Ds); break;
+        case 5: conv_wgrad_body<3, 2>(a, chunk, ktile, Xs, Ds); break;
+        case 6: conv_wgrad_body<3, 4>(a, chunk, ktile, Xs, Ds); break;
+        default: conv_wgrad_body<3, 8>(a, chunk, ktile, Xs, Ds); break;
+    }
+}
+
+// append one layer to a batch (partial sums only: ws gets chunks * Cout*Cin*ks*ks floats); returns the number of chunks
+int conv_wgrad_add(WgradBatch* b, WgradArgs a, int* chunks_out) {
+    if (a.Cout > 128 || (a.ks != 1 && a.ks != 3) || b->count >= WGRAD_BATCH_MAX) return SPLICE_ERR_ARG;
+    if ((size_t)a.Cin * a.x_cstride > 0x7fffffffULL || a.x_nstride > 0xffffffffULL || a.dy_nstride > 0xffffffffULL) return SPLICE_ERR_ARG;
+    if (a.Hi > 65535 || a.Wi > 65535 || a.Cin > 65535) return SPLICE_ERR_ARG;
     const int chunks = wgrad_chunks(a.N, a.Ho, a.Wo, &a.pix_per_chunk, &a.chunks_per_img);
     const int CK = a.ks == 3 ? 4 : 16;
-    if (a.ks == 3) wgrad_launch_fn<3>(a, chunks, cdiv(a.Cin, CK), s);
-    else wgrad_launch_fn<1>(a, chunks, cdiv(a.Cin, CK), s);
+    const int ktiles = cdiv(a.Cin, CK);
+    const int ni = cdiv(a.Cout, 16);
+    WgradDesc& d = b->d[b->count++];
+    d.x = a.x; d.dy = a.dy; d.ws = a.ws;
+    d.x_nstride = (uint32_t)a.x_nstride; d.x_cstride = (uint32_t)a.x_cstride; d.dy_nstride = (uint32_t)a.dy_nstride; d.dy_cstride = (uint32_t)a.dy_cstride;
+    d.Cin = (uint16_t)a.Cin; d.Cout = (uint16_t)a.Cout; d.Hi = (uint16_t)a.Hi; d.Wi = (uint16_t)a.Wi; d.Ho = (uint16_t)a.Ho; d.Wo = (uint16_t)a.Wo;
+    d.ks = (uint8_t)a.ks; d.stride = (uint8_t)a.stride; d.pad = (uint8_t)a.pad;
+    d.variant = (uint8_t)((a.ks == 3 ? 4 : 0) + (ni <= 1 ? 0 : ni <= 2 ? 1 : ni <= 4 ? 2 : 3));
+    d.pix_per_chunk = (uint16_t)a.pix_per_chunk; d.chunks_per_img = (uint16_t)a.chunks_per_img;
+    d.wg_begin = (uint32_t)b->total_wgs; d.chunks = (uint32_t)chunks;
+    b->total_wgs += chunks * ktiles;
     if (chunks_out) *chunks_out = chunks;
+    return SPLICE_OK;
+}
+int conv_wgrad_batched_launch(const WgradBatch& b, hipStream_t s) {
+    if (b.count < 1) return SPLICE_OK;
+    hipLaunchKernelGGL(conv_wgrad_batched_kernel, dim3((unsigned)b.total_wgs), dim3(256), 0, s, b);
     return SPLICE_OK;
 }
 
@@ -560,6 +598,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 // (image, channel) plane, so statistics + apply are a single launch (the plane is re-read from L1/L2).  These layers are
 // pure launch latency -- a kernel boundary costs more than the work.
 constexpr int BN_SMALL_HW = 4096;
+constexpr int BN_SMALL_PER = BN_SMALL_HW / 256;   // plane elements a thread keeps in registers
 __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ y, size_t y_nstride, float* __restrict__ out,
                                                            size_t out_nstride, int C, int HW, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float* __restrict__ mean_o,
@@ -568,24 +607,39 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
     const int c = blockIdx.x, img = blockIdx.y;
     const float* p = y + (size_t)img * y_nstride + (size_t)c * HW;
     float* q = out + (size_t)img * out_nstride + (size_t)c * HW;
+    float v[BN_SMALL_PER];
     float s = 0.f, dummy = 0.f;
-    for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; ++k) {
+        const int i = threadIdx.x + k * 256;
+        v[k] = i < HW ? p[i] : 0.f;
+        s += v[k];
+    }
     block_sum2(s, dummy, red);
     const float m = s / (float)HW;
     float sq = 0.f;
     dummy = 0.f;
-    for (int i = threadIdx.x; i < HW; i += 256) { const float d = p[i] - m; sq += d * d; }
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; ++k) {
+        const float d = threadIdx.x + k * 256 < HW ? v[k] - m : 0.f;
+        sq += d * d;
+    }
     block_sum2(sq, dummy, red);
     const float r = rsqrtf(sq / (float)HW + eps);
     if (threadIdx.x == 0) { mean_o[img * C + c] = m; rstd_o[img * C + c] = r; }
     const float sc = gamma[c] * r;
     const float sh = beta[c] - m * sc;
-    for (int i = threadIdx.x; i < HW; i += 256) {
-        const float v = p[i] * sc + sh;
-        q[i] = v > 0.f ? v : v * slope;
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; ++k) {
+        const int i = threadIdx.x + k * 256;
+        if (i < HW) {
+            const float t = v[k] * sc + sh;
+            q[i] = t > 0.f ? t : t * slope;
+        }
     }
 }
-// one workgroup per channel walks the images in order (dgamma / dbeta sum over images deterministically)
+// one workgroup per channel walks the images in order (dgamma / dbeta sum over images deterministically); each plane is
+// read once and kept in registers between the reduction and the apply pass
 __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ da, size_t da_nstride, const float* __restrict__ aout,
                                                            size_t a_nstride, const float* __restrict__ y, size_t y_nstride,
                                                            float* __restrict__ dy, size_t dy_nstride, int C, int HW, int N,
@@ -601,22 +655,30 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
         const float* pa = aout + (size_t)img * a_nstride + (size_t)c * HW;
         const float* py = y + (size_t)img * y_nstride + (size_t)c * HW;
         float* po = dy + (size_t)img * dy_nstride + (size_t)c * HW;
+        float dz[BN_SMALL_PER], xh[BN_SMALL_PER];
         float s1 = 0.f, s2 = 0.f;
-        for (int i = threadIdx.x; i < HW; i += 256) {
-            float dz = pd[i];
-            if (slope != 1.0f && !(pa[i] > 0.f)) dz *= slope;
-            s1 += dz;
-            s2 += dz * (py[i] - m) * r;
+#pragma unroll
+        for (int k = 0; k < BN_SMALL_PER; ++k) {
+            const int i = threadIdx.x + k * 256;
+            float d = 0.f, x = 0.f;
+            if (i < HW) {
+                d = pd[i];
+                if (slope != 1.0f && !(pa[i] > 0.f)) d *= slope;
+                x = (py[i] - m) * r;
+            }
+            dz[k] = d; xh[k] = x;
+            s1 += d;
+            s2 += d * x;
         }
         block_sum2(s1, s2, red);
         be += s1;
         g += s2;
         const float k1 = s1 / (float)HW, k2 = s2 / (float)HW;
         const float gr = gamma[c] * r;
-        for (int i = threadIdx.x; i < HW; i += 256) {
-            float dz = pd[i];
-            if (slope != 1.0f && !(pa[i] > 0.f)) dz *= slope;
-            po[i] = gr * (dz - k1 - (py[i] - m) * r * k2);
+#pragma unroll
+        for (int k = 0; k < BN_SMALL_PER; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i < HW) po[i] = gr * (dz[k] - k1 - xh[k] * k2);
         }
     }
     if (threadIdx.x == 0) {

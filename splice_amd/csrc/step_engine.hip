@@ -88,6 +88,8 @@ struct SpliceStep {
     hipStream_t side_stream = nullptr;               // target-pass ViT forward beside the generator forward
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int overlap = 1;                                 // SPLICE_STEP_OVERLAP=0 serialises (debugging)
+    int ablate = 0;                                  // SPLICE_STEP_ABLATE bitmask: TIMING experiments only (results are garbage):
+                                                     // 1 skip G fwd, 2 skip G bwd, 4 skip ViT bwd, 8 skip target ViT fwd, 16 skip generated ViT fwd
     std::map<int, hipGraphExec_t> graphs;
     void* graph_ptrs[4] = {nullptr, nullptr, nullptr, nullptr};
     int graph_crops[4] = {0, 0, 0, 0};
@@ -209,6 +211,7 @@ int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void
     if (const char* e = getenv("SPLICE_STEP_SYNC")) st->dbg_sync = atoi(e);
     if (const char* e = getenv("SPLICE_STEP_OWN_EAGER")) st->dbg_own_eager = atoi(e);
     if (const char* e = getenv("SPLICE_STEP_OVERLAP")) st->overlap = atoi(e);
+    if (const char* e = getenv("SPLICE_STEP_ABLATE")) st->ablate = atoi(e);
     if (hipStreamCreateWithFlags(&st->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&st->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -311,10 +314,11 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     // global_transform (Resize -> Normalize; the Normalize is fused into the ViT patch gather)
     RC(place_image(A_crop, c.crop_h, c.crop_w, vg.imgs + 0 * vimg, vg.H, vg.W, s2));
     RC(place_image(B_crop, st->cropb_h, st->cropb_w, vg.imgs + 1 * vimg, vg.H, vg.W, s2));
-    RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, 2, 0, 2, s2));
+    if (!(st->ablate & 8)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, 2, 0, 2, s2));
     if (overlap) HIPCHK(hipEventRecord(st->ev_join, s2));
     // ---- Model.forward: x_global = G(A_crop), y_global = G(B_crop) [, x_entire = G(A)]
-    if (!split) {
+    if (st->ablate & 1) {
+    } else if (!split) {
         RC(splice_gen_forward(st->plan_g, params, st->gen_in, st->gen_out, s));
     } else {
         RC(splice_gen_forward(st->plan_a, params, A_crop, st->gen_out, s));
@@ -322,7 +326,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     }
     RC(place_image(st->gen_out, c.crop_h, c.crop_w, vg.imgs + 2 * vimg, vg.H, vg.W, s));
     RC(place_image(st->gen_out + crop, st->cropb_h, st->cropb_w, vg.imgs + 3 * vimg, vg.H, vg.W, s));
-    RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, 2, 2, 4, s));
+    if (!(st->ablate & 16)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, 2, 2, 4, s));
     if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
     float *blk_g = nullptr, *qkv_g = nullptr;
     RC(splice_vit_get_tensor(vg.ctx, 0, vg.depth - 1, (void**)&blk_g));
@@ -359,7 +363,8 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     // ---- backward (train.py:78): ViT dgrad for the generated images only, then the generator
     // the two generated images are independent chains until the generator: one per stream (every launch of a
     // dependent chain pays ~8 us of fixed latency; two chains in flight hide each other's)
-    if (overlap) {
+    if (st->ablate & 4) {
+    } else if (overlap) {
         HIPCHK(hipEventRecord(st->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(s2, st->ev_fork, 0));
         RC(splice_vit_backward(vg.ctx, 3, 4, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s2));
@@ -373,7 +378,8 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         RC(unplace_grad(vg.d_imgs + 2 * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, s));
         RC(unplace_grad(vg.d_imgs + 3 * vimg, vg.H, vg.W, st->d_gen_out + crop, st->cropb_h, st->cropb_w, s));
     }
-    if (!split) {
+    if (st->ablate & 2) {
+    } else if (!split) {
         RC(splice_gen_backward(st->plan_g, params, st->d_gen_out, grads, 0, s));
     } else {
         RC(splice_gen_backward(st->plan_a, params, st->d_gen_out, grads, 0, s));
