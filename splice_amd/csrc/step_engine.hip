@@ -153,10 +153,12 @@ static int unplace_grad(const float* dsrc, int oh, int ow, float* ddst, int h, i
 static const float* keys_ptr(const VitView& v, const float* qkv_last, int pass) { return qkv_last + (size_t)pass * v.Tld * 3 * v.D + v.D; }
 
 // self-sim structure loss of `pass_x` against `pass_tgt` (util/losses.py:74-83): raw loss into slot, d_keys rows of pass_x
-static int ssim_term(SpliceStep* st, VitView& v, const float* qkv_last, int pass_tgt, int pass_x, float lambda, int slot, hipStream_t s) {
+// target_done: S_tgt has already been formed (on the side stream, beside the generator forward)
+static int ssim_term(SpliceStep* st, VitView& v, const float* qkv_last, int pass_tgt, int pass_x, float lambda, int slot, hipStream_t s,
+                     bool target_done = false) {
     SelfSimWs ws;
     selfsim_ws_carve(st->ssim_ws, v.T, v.D, &ws);
-    RC(selfsim_fwd_launch(keys_ptr(v, qkv_last, pass_tgt), 3 * v.D, v.T, v.D, 1e-8f, st->S_tgt, ws, s));
+    if (!target_done) RC(selfsim_fwd_launch(keys_ptr(v, qkv_last, pass_tgt), 3 * v.D, v.T, v.D, 1e-8f, st->S_tgt, ws, s));
     RC(selfsim_fwd_launch(keys_ptr(v, qkv_last, pass_x), 3 * v.D, v.T, v.D, 1e-8f, st->S, ws, s));
     RC(mse2_launch(st->S, v.T, st->S_tgt, v.T, v.T, v.T, 1.0f, lambda, st->losses + slot, st->dS, v.T, s));
     RC(selfsim_bwd_launch(st->dS, st->S, v.T, v.D, 1e-8f, v.d_keys + (size_t)pass_x * v.Tld * v.D, v.D, 0, ws, s));
@@ -315,6 +317,18 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     RC(place_image(A_crop, c.crop_h, c.crop_w, vg.imgs + 0 * vimg, vg.H, vg.W, s2));
     RC(place_image(B_crop, st->cropb_h, st->cropb_w, vg.imgs + 1 * vimg, vg.H, vg.W, s2));
     if (!(st->ablate & 8)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, 2, 0, 2, s2));
+    float *blk_g = nullptr, *qkv_g = nullptr;
+    RC(splice_vit_get_tensor(vg.ctx, 0, vg.depth - 1, (void**)&blk_g));
+    RC(splice_vit_get_tensor(vg.ctx, 3, vg.depth - 1, (void**)&qkv_g));
+    // everything of the loss stage that does not need the generated images also runs here, off the critical path
+    RC(dev_zero_launch(st->losses, 8 * sizeof(float), s2));
+    RC(dev_zero_launch(vg.d_block, (size_t)vg.rows * vg.D * sizeof(float), s2));
+    RC(dev_zero_launch(vg.d_keys, (size_t)vg.rows * vg.D * sizeof(float), s2));
+    if (l_ssim > 0.f) {   // target self-similarity S* of A' (util/losses.py:79)
+        SelfSimWs ws;
+        selfsim_ws_carve(st->ssim_ws, vg.T, vg.D, &ws);
+        RC(selfsim_fwd_launch(keys_ptr(vg, qkv_g, 0), 3 * vg.D, vg.T, vg.D, 1e-8f, st->S_tgt, ws, s2));
+    }
     if (overlap) HIPCHK(hipEventRecord(st->ev_join, s2));
     // ---- Model.forward: x_global = G(A_crop), y_global = G(B_crop) [, x_entire = G(A)]
     if (st->ablate & 1) {
@@ -328,15 +342,9 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     RC(place_image(st->gen_out + crop, st->cropb_h, st->cropb_w, vg.imgs + 3 * vimg, vg.H, vg.W, s));
     if (!(st->ablate & 16)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, 2, 2, 4, s));
     if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
-    float *blk_g = nullptr, *qkv_g = nullptr;
-    RC(splice_vit_get_tensor(vg.ctx, 0, vg.depth - 1, (void**)&blk_g));
-    RC(splice_vit_get_tensor(vg.ctx, 3, vg.depth - 1, (void**)&qkv_g));
-    RC(dev_zero_launch(st->losses, 8 * sizeof(float), s));
-    RC(dev_zero_launch(vg.d_block, (size_t)vg.rows * vg.D * sizeof(float), s));
-    RC(dev_zero_launch(vg.d_keys, (size_t)vg.rows * vg.D * sizeof(float), s));
     const size_t passD = (size_t)vg.Tld * vg.D;
     // ---- losses on the global batch: passes 0 A', 1 B', 2 x', 3 y'
-    if (l_ssim > 0.f) RC(ssim_term(st, vg, qkv_g, 0, 2, l_ssim, L_GLOBAL_SSIM, s));
+    if (l_ssim > 0.f) RC(ssim_term(st, vg, qkv_g, 0, 2, l_ssim, L_GLOBAL_SSIM, s, true));
     if (l_cls > 0.f)   // [CLS] of block 11, before the final LayerNorm (util/losses.py:90-93)
         RC(mse2_launch(blk_g + 2 * passD, vg.D, blk_g + 1 * passD, vg.D, 1, vg.D, 1.0f, l_cls, st->losses + L_GLOBAL_CLS, vg.d_block + 2 * passD, vg.D, s));
     if (l_id > 0.f)    // keys of y' against keys of B' (util/losses.py:96-105): mean over h*T*d = T*D
