@@ -63,12 +63,18 @@ typedef struct splice_gemm_epilogue {
     float alpha;
     int ksplit;               /* > 1 with flags == SPLICE_EPI_OUT_F32 only: K is cut into ksplit slices, slice s writes */
     long long slab_stride;    /* out_f32 + s * slab_stride; the consumer adds the slabs (deterministic split-K)       */
+    /* SPLICE_EPI_ROWDOT (with OUT_BF): rowdot[(row / rd_rows) * (N/64) * rd_rows + (col/64) * rd_rows + row % rd_rows]
+     * = sum over the 64 columns [col, col+64) of bf16(C[row][c]) * rd_other[row][c] -- the attention backward's
+     * delta = rowsum(dO * O) per (pass, head, query), formed where dO is produced (proj dgrad).  N % 64 == 0. */
+    const splice_bf16* rd_other;   /* [M][ld_rd] */
+    int ld_rd, rd_rows;
+    float* rowdot;
 } splice_gemm_epilogue;
 
 enum {
     SPLICE_EPI_BIAS = 1, SPLICE_EPI_RESID = 2, SPLICE_EPI_OUT_F32 = 4, SPLICE_EPI_OUT_BF = 8,
     SPLICE_EPI_OUT_T = 16, SPLICE_EPI_GELU = 32, SPLICE_EPI_GELU_GRAD = 64,
-    SPLICE_EPI_COLS_F32 = 128, SPLICE_EPI_ALPHA = 256
+    SPLICE_EPI_COLS_F32 = 128, SPLICE_EPI_ALPHA = 256, SPLICE_EPI_ROWDOT = 512
 };
 
 int splice_gemm_nt_bf16(unsigned flags, const splice_bf16* A, int lda, const splice_bf16* B, int ldb,
@@ -93,7 +99,7 @@ int splice_layernorm_bwd(const float* dy, const float* x, const float* gamma, co
 int splice_attention_fwd(const splice_bf16* qkv, const splice_bf16* qkvT, int ldt, int B, int T, int Tld,
                          int D, int H, float scale, splice_bf16* out, float* lse, splice_stream_t stream);
 /* dqkv [B*Tld][3D] bf16 from dout [B*Tld][D] (+ its transpose doutT [D][ldt]); delta is
- * [B][H][Tld] fp32 scratch. */
+ * [B][H][Tld] fp32 scratch (rowsum(dO * O), formed by the call). */
 int splice_attention_bwd(const splice_bf16* qkv, const splice_bf16* qkvT, int ldt, int B, int T, int Tld,
                          int D, int H, float scale, const splice_bf16* out, const float* lse,
                          const splice_bf16* dout, const splice_bf16* doutT, float* delta,

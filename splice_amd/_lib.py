@@ -23,6 +23,7 @@ class GemmEpilogue(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_int),
         ("out_f32_cols", C.c_void_p), ("ld_cols", C.c_int), ("col_lo", C.c_int), ("col_hi", C.c_int),
         ("alpha", C.c_float), ("ksplit", C.c_int), ("slab_stride", C.c_longlong),
+        ("rd_other", C.c_void_p), ("ld_rd", C.c_int), ("rd_rows", C.c_int), ("rowdot", C.c_void_p),
     ]
 
 
@@ -38,7 +39,7 @@ class StepConfig(C.Structure):
 
 
 EPI_BIAS, EPI_RESID, EPI_OUT_F32, EPI_OUT_BF, EPI_OUT_T = 1, 2, 4, 8, 16
-EPI_GELU, EPI_GELU_GRAD, EPI_COLS_F32, EPI_ALPHA = 32, 64, 128, 256
+EPI_GELU, EPI_GELU_GRAD, EPI_COLS_F32, EPI_ALPHA, EPI_ROWDOT = 32, 64, 128, 256, 512
 
 _vp, _i, _f, _sz, _u = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint
 

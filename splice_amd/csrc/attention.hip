@@ -308,9 +308,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, int nx) {
 // backward (same toolkit as the forward: LDS-DMA ring, one b128 read per MFMA operand, padding handled in a
 // peeled last tile so the hot loops are branch-free).
 //
-// dQ kernel: wave owns 16 queries (lane&15 = query); K, V (token tiles) and K^T (dim tile) shared via LDS.
-// It also forms delta[q] = sum_d dO[q][d] O[q][d] for its queries from the fragments it already holds and
-// publishes it for the dK/dV kernel, which runs after it.
+// delta[b][h][q] = sum_d dO[q][h*64+d] * O[q][h*64+d] is an INPUT of both halves (the ViT engine forms it in the
+// epilogue of the proj dgrad GEMM that produces dO; the stand-alone C entry point runs attn_delta_kernel first).
+// dQ half: wave owns 16 queries (lane&15 = query); K, V (token tiles) and K^T (dim tile) shared via LDS.
 template <int NSUB, bool MASK>
 __device__ __forceinline__ void attn_bwd_q_tile(const bf16_t* Ks, const bf16_t* Vs, const bf16_t* KTs, const FragAddr& fa,
                                                 const u32x4 (&qf)[2], const u32x4 (&dof)[2], float lse_q, float del_q, f32x4 (&dq)[4],
@@ -350,12 +350,9 @@ __device__ __forceinline__ float dot8bf(const u32x4& x, const u32x4& y) {
     return acc;
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a, int nx) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 3 * 4096];   // [stage][K | V | K^T]
+__device__ __forceinline__ void attn_bwd_q_body(const AttnArgs& a, int xb, int h, int b, bf16_t* smem /* [stage][K | V | K^T] */) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
-    int xb, h, b;
-    attn_block_coords(nx, a.H, a.B, xb, h, b);
     const int ld = 3 * a.D;
     const TileDma dma;
     const FragAddr fa(g, c);
@@ -365,17 +362,14 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a, int nx) {
     const int qc = q < a.Tld ? q : a.Tld - 1;
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.Tld * ld;
     u32x4 qf[2], dof[2];
-    float del_q;
     {
         const bf16_t* pq = qkv_b + (size_t)qc * ld + h * 64 + g * 8;
         const bf16_t* pd = a.dout + ((size_t)b * a.Tld + qc) * a.D + h * 64 + g * 8;
-        const bf16_t* po = a.out + ((size_t)b * a.Tld + qc) * a.D + h * 64 + g * 8;
         qf[0] = ld16v(pq); qf[1] = ld16v(pq + 32);
         dof[0] = ld16v(pd); dof[1] = ld16v(pd + 32);
-        del_q = group4_sum(dot8bf(dof[0], ld16v(po)) + dot8bf(dof[1], ld16v(po + 32)));
     }
     const float lse_q = a.lse[((size_t)b * a.H + h) * a.Tld + qc];
-    if (active && g == 0 && q < a.Tld) a.delta[((size_t)b * a.H + h) * a.Tld + q] = del_q;
+    const float del_q = a.delta[((size_t)b * a.H + h) * a.Tld + qc];
     const bf16_t* krow = qkv_b + a.D + h * 64;
     const bf16_t* vrow = qkv_b + 2 * a.D + h * 64;
     const bf16_t* kT = a.qkvT + (size_t)(a.D + h * 64) * a.ldt + (size_t)b * a.Tld;
@@ -463,12 +457,9 @@ __device__ __forceinline__ void attn_bwd_kv_tile(const bf16_t* st, const FragAdd
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a, int nx) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * KV_STAGE];
+__device__ __forceinline__ void attn_bwd_kv_body(const AttnArgs& a, int xb, int h, int b, bf16_t* smem /* 2 * KV_STAGE */) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
-    int xb, h, b;
-    attn_block_coords(nx, a.H, a.B, xb, h, b);
     const int ld = 3 * a.D;
     const TileDma dma;
     const FragAddr fa(g, c);
@@ -537,6 +528,46 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a, int nx) {
     }
 }
 
+// One launch for the whole attention backward: the dQ and the dK/dV halves are independent given delta, so their
+// workgroups are interleaved in one grid (even logical id = dQ block, odd = dK/dV block of the same (pass, head, block)
+// triple, neighbours on one XCD) instead of two dependent launches of ~15 us each.
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a, int nx) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * KV_STAGE];
+    const int n = nx * a.H * a.B;
+    const int lid = xcd_remap(blockIdx.x, 2 * n);
+    const int pair = lid >> 1;
+    const int xb = pair % nx, bh = pair / nx;
+    const int h = bh % a.H, b = bh / a.H;
+    if (lid & 1) attn_bwd_kv_body(a, xb, h, b, smem);
+    else attn_bwd_q_body(a, xb, h, b, smem);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a, int nx) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 3 * 4096];
+    int xb, h, b;
+    attn_block_coords(nx, a.H, a.B, xb, h, b);
+    attn_bwd_q_body(a, xb, h, b, smem);
+}
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a, int nx) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * KV_STAGE];
+    int xb, h, b;
+    attn_block_coords(nx, a.H, a.B, xb, h, b);
+    attn_bwd_kv_body(a, xb, h, b, smem);
+}
+
+__global__ void attn_delta_kernel(AttnArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over B*Tld*H
+    if (idx >= a.B * a.Tld * a.H) return;
+    const int h = idx % a.H, row = idx / a.H;
+    const int b = row / a.Tld, q = row % a.Tld;
+    const bf16_t* po = a.out + (size_t)row * a.D + h * 64;
+    const bf16_t* pd = a.dout + (size_t)row * a.D + h * 64;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += dot8bf(ld16v(po + i * 8), ld16v(pd + i * 8));
+    a.delta[((size_t)b * a.H + h) * a.Tld + q] = acc;
+}
+
 // attention probabilities of one layer, fp32 [B][H][T][T] (models/extractor.py:44-45,97-103);
 // only materialised when the API asks for them.
 __global__ void attn_probs_kernel(AttnArgs a, float* probs) {
@@ -577,8 +608,16 @@ int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
 int attn_bwd_launch(const AttnArgs* a, hipStream_t s) {
     if (a->Tld % 32 || a->D % 64 || a->D / 64 != a->H || a->ldt % 4) return SPLICE_ERR_ARG;
     const int nx = cdiv(a->Tld, 64);
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(nx * a->H * a->B), dim3(256), 0, s, *a, nx);    // also writes delta
-    hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(nx * a->H * a->B), dim3(256), 0, s, *a, nx);
+    if (!a->delta_ready) hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(a->B * a->Tld * a->H, 256)), dim3(256), 0, s, *a);
+    const int n = nx * a->H * a->B;
+    // the two halves in one launch while the chip is not full anyway (a dependent launch costs more than the dQ half's
+    // lower occupancy under the dK/dV half's LDS footprint); two launches once every CU has several workgroups
+    if (2 * n <= 768) {
+        hipLaunchKernelGGL(attn_bwd_kernel, dim3(2 * n), dim3(256), 0, s, *a, nx);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(n), dim3(256), 0, s, *a, nx);
+        hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(n), dim3(256), 0, s, *a, nx);
+    }
     return SPLICE_OK;
 }
 

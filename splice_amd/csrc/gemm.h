@@ -285,7 +285,8 @@ typedef splice_gemm_epilogue GemmEpi;
 enum : unsigned {
     EPI_BIAS = SPLICE_EPI_BIAS, EPI_RESID = SPLICE_EPI_RESID, EPI_OUT_F32 = SPLICE_EPI_OUT_F32,
     EPI_OUT_BF = SPLICE_EPI_OUT_BF, EPI_OUT_T = SPLICE_EPI_OUT_T, EPI_GELU = SPLICE_EPI_GELU,
-    EPI_GELU_GRAD = SPLICE_EPI_GELU_GRAD, EPI_COLS_F32 = SPLICE_EPI_COLS_F32, EPI_ALPHA = SPLICE_EPI_ALPHA
+    EPI_GELU_GRAD = SPLICE_EPI_GELU_GRAD, EPI_COLS_F32 = SPLICE_EPI_COLS_F32, EPI_ALPHA = SPLICE_EPI_ALPHA,
+    EPI_ROWDOT = SPLICE_EPI_ROWDOT
 };
 
 template <unsigned FLAGS>
@@ -451,6 +452,40 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
     if (NS == 2) tile.run_glds(A, lda, B, ldb, M, N, K, m0, n0, gemm_smem, kbeg);
     else tile.template run_ring<(NS < 3 ? 3 : NS)>(A, lda, B, ldb, M, N, K, m0, n0, gemm_smem, kbeg);
     tile.for_each_cols(m0, n0, [&](int row, int col0, f32x4 v) { gemm_epilogue_cols<FLAGS>(e, M, N, row, col0, v); });
+    if (FLAGS & EPI_ROWDOT) {
+        // 64-column row dots of the bf16-rounded result against rd_other (BN == 64: one workgroup = one 64-column block):
+        // lane partial over its 4 columns x 2 fragments -> 4 lane groups (shuffles) -> the 2 waves of a row (LDS)
+        static_assert(!(FLAGS & EPI_ROWDOT) || BN == 64, "EPI_ROWDOT needs the 64-column tile");
+        constexpr int FMt = GemmTile<BM, BN>::FM, FNt = GemmTile<BM, BN>::FN;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+        float* red = reinterpret_cast<float*>(gemm_smem);   // [2 wn][BM] (the K loop is over)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < FMt; ++i) {
+            const int lrow = wm * (BM / 2) + i * 16 + (lane & 15);
+            const int row = m0 + lrow;
+            float part = 0.f;
+            if (row < M) {
+#pragma unroll
+                for (int j = 0; j < FNt; ++j) {
+                    const int col = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+                    const uint2 o = *reinterpret_cast<const uint2*>(e.rd_other + (size_t)row * e.ld_rd + col);
+                    const f32x4 v = tile.acc[i][j];
+                    part += bf2f(f2bf(v[0])) * bf2f((bf16_t)(o.x & 0xFFFF)) + bf2f(f2bf(v[1])) * bf2f((bf16_t)(o.x >> 16)) +
+                            bf2f(f2bf(v[2])) * bf2f((bf16_t)(o.y & 0xFFFF)) + bf2f(f2bf(v[3])) * bf2f((bf16_t)(o.y >> 16));
+                }
+            }
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            if (lane < 16) red[wn * BM + lrow] = part;
+        }
+        __syncthreads();
+        if (threadIdx.x < BM) {
+            const int row = m0 + threadIdx.x;
+            if (row < M)
+                e.rowdot[((size_t)(row / e.rd_rows) * (N / 64) + n0 / 64) * e.rd_rows + row % e.rd_rows] = red[threadIdx.x] + red[BM + threadIdx.x];
+        }
+    }
 }
 
 template <int BM, int BN, unsigned FLAGS, int NS>

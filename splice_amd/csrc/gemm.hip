@@ -11,23 +11,28 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
     const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
     const long t12864 = (long)cdiv(M, 128) * cdiv(N, 64);
     int tile, ring;
-    if (g_force_tile) { tile = g_force_tile % 10; ring = g_force_tile / 10; }
+    if (g_force_tile && !(FLAGS & EPI_ROWDOT)) { tile = g_force_tile % 10; ring = g_force_tile / 10; }
     else {
         // measured on MI355X (tools/gemm_bench.py): with N <= 768 the 64x64 tile wins (more workgroups on the long-K shapes);
         // otherwise the biggest tile that still yields >= ~1 workgroup per CU
-        tile = N <= 768 ? 3 : t128 >= 224 ? 1 : t12864 >= 200 ? 2 : 3;
+        tile = (N <= 768 || (FLAGS & EPI_ROWDOT)) ? 3 : t128 >= 224 ? 1 : t12864 >= 200 ? 2 : 3;
         // few workgroups walking a long K (fc2, the fc1 / qkv dgrads): the per-slice DMA latency is exposed with 2 stages,
         // the 4-stage ring keeps 3 slices in flight (fc1T 800x768x3072: 23.4 -> 15.3 us); elsewhere its LDS footprint costs occupancy
         const int ks = (FLAGS == EPI_OUT_F32 && e.ksplit > 1 && K % (e.ksplit * GEMM_BK) == 0) ? e.ksplit : 1;
         ring = (tile == 3 && K / ks >= 1536 && (long)cdiv(M, 64) * cdiv(N, 64) * ks <= 640) ? 1 : 0;
     }
-    switch (tile * 2 + (ring ? 1 : 0)) {
-        case 2: launch_gemm_nt<128, 128, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e); break;
-        case 3: launch_gemm_nt<128, 128, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e); break;
-        case 4: launch_gemm_nt<128, 64, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e); break;
-        case 5: launch_gemm_nt<128, 64, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e); break;
-        case 6: launch_gemm_nt<64, 64, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e); break;
-        default: launch_gemm_nt<64, 64, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e); break;
+    if constexpr ((FLAGS & EPI_ROWDOT) != 0) {   // only instantiated for the 64-column tile
+        if (ring) launch_gemm_nt<64, 64, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e);
+        else launch_gemm_nt<64, 64, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e);
+    } else {
+        switch (tile * 2 + (ring ? 1 : 0)) {
+            case 2: launch_gemm_nt<128, 128, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e); break;
+            case 3: launch_gemm_nt<128, 128, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e); break;
+            case 4: launch_gemm_nt<128, 64, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e); break;
+            case 5: launch_gemm_nt<128, 64, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e); break;
+            case 6: launch_gemm_nt<64, 64, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e); break;
+            default: launch_gemm_nt<64, 64, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e); break;
+        }
     }
     return SPLICE_OK;
 }
@@ -36,6 +41,7 @@ int gemm_nt_launch(unsigned flags, const bf16_t* A, int lda, const bf16_t* B, in
                    const GemmEpi& e, hipStream_t s) {
     if (M < 1 || N < 1 || K < GEMM_BK || K % GEMM_BK || lda % 8 || ldb % 8) return SPLICE_ERR_ARG;
     if ((flags & EPI_OUT_T) && (e.ldt % 4)) return SPLICE_ERR_ARG;
+    if ((flags & EPI_ROWDOT) && (N % 64 || !e.rd_other || !e.rowdot || e.rd_rows < 1 || e.ld_rd % 4)) return SPLICE_ERR_ARG;
 #define CASE(F) case (F): return dispatch_tile<(F)>(A, lda, B, ldb, M, N, K, e, s)
     switch (flags) {
         CASE(EPI_BIAS | EPI_OUT_BF | EPI_OUT_T);                  // qkv
@@ -48,6 +54,7 @@ int gemm_nt_launch(unsigned flags, const bf16_t* A, int lda, const bf16_t* B, in
         CASE(EPI_OUT_F32 | EPI_ALPHA);
         CASE(EPI_OUT_BF);                                         // dgrad -> next GEMM
         CASE(EPI_OUT_BF | EPI_OUT_T);                             // proj dgrad -> attention backward
+        CASE(EPI_OUT_BF | EPI_OUT_T | EPI_ROWDOT);                // same + delta = rowsum(dO * O) per head
         CASE(EPI_GELU_GRAD | EPI_OUT_BF);                         // fc2 dgrad
         default: return SPLICE_ERR_ARG;
     }

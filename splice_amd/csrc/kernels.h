@@ -16,7 +16,8 @@ struct AttnArgs {
     // backward only
     const bf16_t* dout;    // [B*Tld][D]
     const bf16_t* doutT;   // [D][ldt]
-    float* delta;          // [B][H][Tld]  rowsum(dO * O) (scratch, written by the bwd launcher)
+    float* delta;          // [B][H][Tld]  rowsum(dO * O)
+    int delta_ready;       // != 0: the caller already filled delta (the ViT engine: proj-dgrad GEMM epilogue)
     bf16_t* dqkv;          // [B*Tld][3D]
 };
 int attn_fwd_launch(const AttnArgs* a, hipStream_t s);

@@ -89,7 +89,7 @@ struct SpliceStep {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int overlap = 1;                                 // SPLICE_STEP_OVERLAP=0 serialises (debugging)
     int ablate = 0;                                  // SPLICE_STEP_ABLATE bitmask: TIMING experiments only (results are garbage):
-                                                     // 1 skip G fwd, 2 skip G bwd, 4 skip ViT bwd, 8 skip target ViT fwd, 16 skip generated ViT fwd
+                                                     // 1 skip G fwd, 2 skip G bwd, 4 skip ViT bwd, 8 skip target ViT fwd, 16 skip generated ViT fwd, 32 skip the y' chain of the ViT bwd
     std::map<int, hipGraphExec_t> graphs;
     void* graph_ptrs[4] = {nullptr, nullptr, nullptr, nullptr};
     int graph_crops[4] = {0, 0, 0, 0};
@@ -375,7 +375,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     } else if (overlap) {
         HIPCHK(hipEventRecord(st->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(s2, st->ev_fork, 0));
-        RC(splice_vit_backward(vg.ctx, 3, 4, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s2));
+        if (!(st->ablate & 32)) RC(splice_vit_backward(vg.ctx, 3, 4, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s2));
         RC(unplace_grad(vg.d_imgs + 3 * vimg, vg.H, vg.W, st->d_gen_out + crop, st->cropb_h, st->cropb_w, s2));
         HIPCHK(hipEventRecord(st->ev_join, s2));
         RC(splice_vit_backward(vg.ctx, 2, 3, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));

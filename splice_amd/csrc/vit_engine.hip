@@ -522,14 +522,17 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
                 e.out_bf = c->dout + r0 * D; e.ldbf = D; e.out_bf_t = c->doutT; e.ldt = c->rows;
                 // transposed output is addressed by GEMM row index (0..R) -> shift the base so column = global row
                 e.out_bf_t = c->doutT + r0;
-                RC(gemm_nt_launch(EPI_OUT_BF | EPI_OUT_T, g_bf, D, W.proj.wT, D, R, D, D, e, s));
+                // delta = rowsum(dO * O) per (pass, head, query) for the attention backward, formed where dO is produced
+                e.rd_other = c->attn_out[l] + r0 * D; e.ld_rd = D; e.rd_rows = c->Tld;
+                e.rowdot = c->delta + (size_t)pass_begin * v->heads * c->Tld;
+                RC(gemm_nt_launch(EPI_OUT_BF | EPI_OUT_T | EPI_ROWDOT, g_bf, D, W.proj.wT, D, R, D, D, e, s));
             }
             {
                 AttnArgs a = {};
                 a.qkv = c->qkv[l] + r0 * 3 * D; a.qkvT = c->qkvT[l] + r0; a.ldt = c->rows; a.B = Bp; a.T = c->T; a.Tld = c->Tld;
                 a.D = D; a.H = v->heads; a.scale = 0.125f; a.out = c->attn_out[l] + r0 * D;
                 a.lse = c->lse[l] + (size_t)pass_begin * v->heads * c->Tld;
-                a.dout = c->dout + r0 * D; a.doutT = c->doutT + r0; a.delta = c->delta + (size_t)pass_begin * v->heads * c->Tld; a.dqkv = dqkv;
+                a.dout = c->dout + r0 * D; a.doutT = c->doutT + r0; a.delta = c->delta + (size_t)pass_begin * v->heads * c->Tld; a.delta_ready = 1; a.dqkv = dqkv;
                 RC(attn_bwd_launch(&a, s));
             }
             g_after_mlp = g;
