@@ -13,7 +13,7 @@ optimises its OWN pair on its own GPU (independent units, no data-path collectiv
 value = total steps of all ranks / max-over-ranks time.
 
 Printed JSON (one line, rank 0) additionally carries
-  roofline     : the dominant kernel (fc1 bf16 MFMA GEMM of the batched ViT forward): algorithmic
+  roofline     : the dominant kernel (fc2 bf16 MFMA GEMM of the ViT forward, the largest single share of the step): algorithmic
                  FLOPs per launch / live HIP-event duration of its launches inside the timed region
   cpu_baseline : the fp32 CPU oracle (a port of the reference-shaped loop: 6 ViT forwards + 3
                  backwards per step) timed on this host's cores on a bounded sample.
@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--size", type=int, default=224, help="pair height = width (configs[1]: 224)")
     ap.add_argument("--model", default="dino_vitb8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prof-kernel", type=int, default=1, help="1 fc1 GEMM, 2 qkv GEMM, 3 attention fwd, 0 off")
+    ap.add_argument("--prof-kernel", type=int, default=4, help="4 fc2 GEMM (largest share of the step), 1 fc1 GEMM, 2 qkv GEMM, 3 attention fwd, 0 off")
     args = ap.parse_args()
 
     import torch
@@ -143,10 +143,13 @@ def main():
     n_entire = sum(1 for s in range(W, W + K) if s % eng.cfg["entire_A_every"] == 0)
     roof = None
     if args.prof_kernel and prof_n.value:
-        # algorithmic FLOPs of ONE launch of the timed kernel on the global batch (4 passes x T tokens)
-        shapes = {1: ("gemm_nt_kernel<128,128,BIAS|GELU|OUT_BF> (fc1 fwd)", 2.0 * 4 * T * hidden * D),
-                  2: ("gemm_nt_kernel<128,128,BIAS|OUT_BF|OUT_T> (qkv fwd)", 2.0 * 4 * T * 3 * D * D),
-                  3: ("attn_fwd_kernel<2>", 4.0 * 4 * T * T * D)}
+        # algorithmic FLOPs of ONE launch of the timed kernel: every ViT forward launch covers 2 passes x T tokens
+        # (targets A', B' on one stream, generated x', y' on the other; the entire-image branch is a 2-pass batch too)
+        P = 2
+        shapes = {1: ("gemm_nt_kernel<128,128,BIAS|GELU|OUT_BF,2> (fc1 fwd)", 2.0 * P * T * hidden * D),
+                  2: ("gemm_nt_kernel<128,64,BIAS|OUT_BF|OUT_T,2> (qkv fwd)", 2.0 * P * T * 3 * D * D),
+                  3: ("attn_fwd_kernel<1>", 4.0 * P * T * T * D),
+                  4: ("gemm_nt_kernel<64,64,BIAS|RESID|OUT_F32,4> (fc2 fwd)", 2.0 * P * T * hidden * D)}
         kname, flops = shapes[args.prof_kernel]
         raw_ms = prof_ms.value / prof_n.value
         avg_ms = max(raw_ms - ev_overhead_ms, 1e-6)
@@ -161,7 +164,7 @@ def main():
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": 2500.0, "unit": "TFLOP/s",
                 "frac": round(ach / 2500.0, 4), "traffic": traffic, "avg_launch_us": round(avg_ms * 1e3, 2), "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2),
                 "launches": prof_n.value,
-                "note": "algorithmic FLOPs of one launch on the 4x785-token batch / mean HIP-event duration of its launches, "
+                "note": "algorithmic FLOPs of one launch (2 passes x T tokens) / mean HIP-event duration of its launches, "
                         "measured on the launch stream over the instrumented continuation of the timed steps (the timed "
                         "region itself replays hipGraphs), minus the median cost of an empty event pair"}
     cpu = None

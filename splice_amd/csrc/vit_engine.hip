@@ -428,6 +428,7 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
         {
             GemmEpi e = {};
             e.bias = W.fc2.b; e.resid = x_mid; e.ldr = D; e.out_f32 = c->xs[l + 1] + r0 * D; e.ldo = D;
+            ProfScope ps(4, s);
             RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, hact, Hd, W.fc2.w, Hd, R, D, Hd, e, s));
         }
     }
