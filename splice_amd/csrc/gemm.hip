@@ -14,12 +14,12 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
     if (g_force_tile && !(FLAGS & EPI_ROWDOT)) { tile = g_force_tile % 10; ring = g_force_tile / 10; }
     else {
         // measured on MI355X (tools/gemm_bench.py): with N <= 768 the 64x64 tile wins (more workgroups on the long-K shapes);
-        // otherwise the biggest tile that still yields >= ~1 workgroup per CU
-        tile = (N <= 768 || (FLAGS & EPI_ROWDOT)) ? 3 : t128 >= 224 ? 1 : t12864 >= 200 ? 2 : 3;
+        // otherwise the biggest tile that still yields ~2 workgroups per CU (M = 1600: 128x64 beats 128x128 by 10 %, M = 800: 64x64)
+        tile = (N <= 768 || (FLAGS & EPI_ROWDOT)) ? 3 : t128 >= 640 ? 1 : t12864 >= 400 ? 2 : 3;
         // few workgroups walking a long K (fc2, the fc1 / qkv dgrads): the per-slice DMA latency is exposed with 2 stages,
         // the 4-stage ring keeps 3 slices in flight (fc1T 800x768x3072: 23.4 -> 15.3 us); elsewhere its LDS footprint costs occupancy
         const int ks = (FLAGS == EPI_OUT_F32 && e.ksplit > 1 && K % (e.ksplit * GEMM_BK) == 0) ? e.ksplit : 1;
-        ring = (tile == 3 && K / ks >= 1536 && (long)cdiv(M, 64) * cdiv(N, 64) * ks <= 640) ? 1 : 0;
+        ring = (tile == 3 && K / ks >= (ks > 1 ? 768 : 1536) && (long)cdiv(M, 64) * cdiv(N, 64) * ks <= 640) ? 1 : 0;
     }
     if constexpr ((FLAGS & EPI_ROWDOT) != 0) {   // only instantiated for the 64-column tile
         if (ring) launch_gemm_nt<64, 64, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e);

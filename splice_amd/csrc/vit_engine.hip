@@ -489,9 +489,10 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
     float* g = c->g + r0 * D;
     bf16_t* g_bf = c->g_bf + r0 * D;
     bool g_live = false;  // gradient stream known non-zero
-    // the two long-K dgrad GEMMs (N = D) have too few tiles for the chip: split K in two, LayerNorm-backward adds the slabs
+    // the two long-K dgrad GEMMs (N = D) have too few tiles for the chip: split K in three (tools/gemm_splitk_bench.py) or two,
+    // LayerNorm-backward adds the slabs
     const size_t slab = (size_t)c->rows * D;
-    const int ks = (cdiv(R, 64) * cdiv(D, 64) <= 640 && D % 128 == 0) ? 2 : 1;
+    const int ks = (cdiv(R, 64) * cdiv(D, 64) * 3 <= 640 && D % 192 == 0) ? 3 : (cdiv(R, 64) * cdiv(D, 64) <= 640 && D % 128 == 0) ? 2 : 1;
     for (int l = L - 1; l >= 0; --l) {
         const LayerW& W = v->layers[l];
         const float* db = d_block ? d_block[l] : nullptr;
