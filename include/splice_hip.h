@@ -235,6 +235,9 @@ int splice_step_output(void* step, int which, float** out_ptr);
 /* 1 (default): capture the step's launch sequence once per regime into a hipGraph and replay it;
  * 0: launch every kernel eagerly (also used automatically while splice_prof_begin is armed) */
 int splice_step_use_graph(void* step, int on);
+/* 1 = the independent chains of a step (target passes beside the generator, the two ViT backward chains) run on two
+ * streams (default), 0 = one stream; results are bit-identical either way */
+int splice_step_use_overlap(void* step, int on);
 /* per-step crop sizes (<= creation size).  Equal A/B sizes run the N=2 plan; different sizes
  * (the reference draws them independently, data/Dataset.py:66-67) run two N=1 plans that must
  * have been attached once with splice_step_attach_split_plans. */

@@ -83,5 +83,9 @@ int selfsim_bwd_launch(const float* dS, const float* S, int T, int D, float eps,
 int mse_launch(const float* a, int lda, const float* b, int ldb, int rows, int cols, float weight, float* loss_accum,
                float* grad, int ldg, hipStream_t s);
 // same with separate scales: loss_accum[0] += loss_weight * mean(d^2); grad = grad_weight * 2 d / n
+// partial sums only (no atomics): part = SPLICE_MSE_PARTIALS zeroed floats, summed in index order by the caller
+#define SPLICE_MSE_PARTIALS 1024
+int mse_partials_launch(const float* a, int lda, const float* b, int ldb, int rows, int cols, float loss_weight, float grad_weight,
+                        float* part, float* grad, int ldg, hipStream_t s);
 int mse2_launch(const float* a, int lda, const float* b, int ldb, int rows, int cols, float loss_weight, float grad_weight,
                 float* loss_accum, float* grad, int ldg, hipStream_t s);

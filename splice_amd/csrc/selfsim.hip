@@ -131,8 +131,11 @@ int selfsim_bwd_launch(const float* dS, const float* S, int T, int D, float eps,
 }
 
 // ---------------------------------------------------------------------------------------
+// mean((a-b)^2) and its gradient.  The per-workgroup partial sums go to part[blockIdx.x] (no float atomics: the
+// caller adds them in index order -- mse_sum_kernel below, or the step engine's total_loss_kernel).
+constexpr int MSE_MAX_WG = SPLICE_MSE_PARTIALS;
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int rows,
-                                                  int cols, float wmean, float gmean, float* __restrict__ loss_accum, float* __restrict__ grad,
+                                                  int cols, float wmean, float gmean, float* __restrict__ part, float* __restrict__ grad,
                                                   int ldg) {
     const size_t n = (size_t)rows * cols;
     float acc = 0.f;
@@ -146,17 +149,49 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ a, i
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss_accum, (red[0] + red[1] + red[2] + red[3]) * wmean);
+    if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * wmean;
+}
+// fixed-order sum of up to MSE_MAX_WG partials (entries the launch did not write must be zero)
+__device__ __forceinline__ float mse_partials_sum(const float* part, float* red /* 4 floats of LDS */) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < MSE_MAX_WG; i += 256) acc += part[i];
+    acc = wave_sum(acc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void mse_sum_kernel(float* __restrict__ part, float* __restrict__ loss_accum) {
+    __shared__ float red[4];
+    const float t = mse_partials_sum(part, red);
+    __syncthreads();
+    for (int i = threadIdx.x; i < MSE_MAX_WG; i += 256) part[i] = 0.f;   // ready for the next call
+    if (threadIdx.x == 0) loss_accum[0] += t;
 }
 
+// part: SPLICE_MSE_PARTIALS floats, all zero on entry except what this launch writes; the caller sums them
+int mse_partials_launch(const float* a, int lda, const float* b, int ldb, int rows, int cols, float loss_weight, float grad_weight,
+                        float* part, float* grad, int ldg, hipStream_t s) {
+    const size_t n = (size_t)rows * cols;
+    if (!n || !part) return SPLICE_ERR_ARG;
+    size_t g = (n + 255) / 256;
+    if (g > MSE_MAX_WG) g = MSE_MAX_WG;
+    hipLaunchKernelGGL(mse_kernel, dim3((unsigned)g), dim3(256), 0, s, a, lda, b, ldb, rows, cols, loss_weight / (float)n,
+                       grad_weight / (float)n, part, grad, ldg);
+    return SPLICE_OK;
+}
+// stand-alone form: loss_accum[0] += loss_weight * mean(d^2).  Uses one process-wide scratch line (allocated on first
+// use, consumed by the sum kernel launched right behind the partials kernel): calls must not overlap on different streams.
 int mse2_launch(const float* a, int lda, const float* b, int ldb, int rows, int cols, float loss_weight, float grad_weight,
                 float* loss_accum, float* grad, int ldg, hipStream_t s) {
-    const size_t n = (size_t)rows * cols;
-    if (!n) return SPLICE_ERR_ARG;
-    size_t g = (n + 255) / 256;
-    if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(mse_kernel, dim3((unsigned)g), dim3(256), 0, s, a, lda, b, ldb, rows, cols, loss_weight / (float)n,
-                       grad_weight / (float)n, loss_accum, grad, ldg);
+    static float* scratch = nullptr;
+    if (!scratch) {
+        if (hipMalloc(&scratch, MSE_MAX_WG * sizeof(float)) != hipSuccess) return SPLICE_ERR_HIP;
+        if (hipMemset(scratch, 0, MSE_MAX_WG * sizeof(float)) != hipSuccess) return SPLICE_ERR_HIP;
+    }
+    const int rc = mse_partials_launch(a, lda, b, ldb, rows, cols, loss_weight, grad_weight, scratch, grad, ldg, s);
+    if (rc != SPLICE_OK) return rc;
+    hipLaunchKernelGGL(mse_sum_kernel, dim3(1), dim3(256), 0, s, scratch, loss_accum);
     return SPLICE_OK;
 }
 int mse_launch(const float* a, int lda, const float* b, int ldb, int rows, int cols, float weight, float* loss_accum,

@@ -76,7 +76,7 @@ struct SpliceStep {
     float* d_ent_out = nullptr;
     float *S = nullptr, *S_tgt = nullptr, *dS = nullptr;   // [Tmax][Tmax]
     void* ssim_ws = nullptr;
-    float* losses = nullptr;     // [8] raw per-term losses of the current step
+    float* losses = nullptr;     // [8] raw per-term losses of the current step, then [8][SPLICE_MSE_PARTIALS] workgroup partials of each term
     std::vector<void*> allocs;
     int max_crop_h = 0, max_crop_w = 0;
     // graph replay
@@ -128,11 +128,28 @@ static int view_init(SpliceStep* st, VitView& v, void* ctx, int want_B) {
     return SPLICE_OK;
 }
 
+// raw_k = fixed-order sum of term k's workgroup partials (no float atomics anywhere: replicas are bit-reproducible);
 // total = sum_k lambda_k * raw_k   (util/losses.py:53-71)
-__global__ void total_loss_kernel(float* l, float w_ssim, float w_essim, float w_ecls, float w_cls, float w_id) {
-    if (threadIdx.x == 0)
-        l[L_TOTAL] = w_ssim * l[L_GLOBAL_SSIM] + w_essim * l[L_ENTIRE_SSIM] + w_ecls * l[L_ENTIRE_CLS] + w_cls * l[L_GLOBAL_CLS] + w_id * l[L_GLOBAL_ID];
+__global__ __launch_bounds__(256) void total_loss_kernel(float* l, float w_ssim, float w_essim, float w_ecls, float w_cls, float w_id) {
+    __shared__ float red[4];
+    __shared__ float raw[8];
+    for (int k = 1; k <= 5; ++k) {
+        const float* part = l + 8 + k * SPLICE_MSE_PARTIALS;
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < SPLICE_MSE_PARTIALS; i += 256) acc += part[i];
+        acc = wave_sum(acc);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) raw[k] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k <= 5; ++k) l[k] = raw[k];
+        l[L_TOTAL] = w_ssim * raw[L_GLOBAL_SSIM] + w_essim * raw[L_ENTIRE_SSIM] + w_ecls * raw[L_ENTIRE_CLS] + w_cls * raw[L_GLOBAL_CLS] + w_id * raw[L_GLOBAL_ID];
+    }
 }
+static float* loss_part(SpliceStep* st, int slot) { return st->losses + 8 + slot * SPLICE_MSE_PARTIALS; }
 
 static int place_image(const float* src, int h, int w, float* dst, int oh, int ow, hipStream_t s) {
     if (h == oh && w == ow) {   // Resize returns its input when the shorter edge already matches
@@ -160,7 +177,7 @@ static int ssim_term(SpliceStep* st, VitView& v, const float* qkv_last, int pass
     selfsim_ws_carve(st->ssim_ws, v.T, v.D, &ws);
     if (!target_done) RC(selfsim_fwd_launch(keys_ptr(v, qkv_last, pass_tgt), 3 * v.D, v.T, v.D, 1e-8f, st->S_tgt, ws, s));
     RC(selfsim_fwd_launch(keys_ptr(v, qkv_last, pass_x), 3 * v.D, v.T, v.D, 1e-8f, st->S, ws, s));
-    RC(mse2_launch(st->S, v.T, st->S_tgt, v.T, v.T, v.T, 1.0f, lambda, st->losses + slot, st->dS, v.T, s));
+    RC(mse_partials_launch(st->S, v.T, st->S_tgt, v.T, v.T, v.T, 1.0f, lambda, loss_part(st, slot), st->dS, v.T, s));
     RC(selfsim_bwd_launch(st->dS, st->S, v.T, v.D, 1e-8f, v.d_keys + (size_t)pass_x * v.Tld * v.D, v.D, 0, ws, s));
     return SPLICE_OK;
 }
@@ -205,7 +222,7 @@ int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void
     char* wsb = nullptr;
     if ((rc = salloc(st, &wsb, selfsim_ws_bytes(Tmax, st->vg.D))) != SPLICE_OK) return fail(rc);
     st->ssim_ws = wsb;
-    if ((rc = salloc(st, &st->losses, 8)) != SPLICE_OK) return fail(rc);
+    if ((rc = salloc(st, &st->losses, 8 + 8 * SPLICE_MSE_PARTIALS)) != SPLICE_OK) return fail(rc);
     if ((rc = salloc(st, &st->in_b, crop)) != SPLICE_OK) return fail(rc);
     if (cfg->ent_h > 0 && (rc = salloc(st, &st->ent_in, (size_t)3 * cfg->ent_h * cfg->ent_w)) != SPLICE_OK) return fail(rc);
     if ((rc = salloc(st, &st->dev_t, 4)) != SPLICE_OK) return fail(rc);
@@ -321,7 +338,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     RC(splice_vit_get_tensor(vg.ctx, 0, vg.depth - 1, (void**)&blk_g));
     RC(splice_vit_get_tensor(vg.ctx, 3, vg.depth - 1, (void**)&qkv_g));
     // everything of the loss stage that does not need the generated images also runs here, off the critical path
-    RC(dev_zero_launch(st->losses, 8 * sizeof(float), s2));
+    RC(dev_zero_launch(st->losses, (8 + 8 * SPLICE_MSE_PARTIALS) * sizeof(float), s2));
     RC(dev_zero_launch(vg.d_block, (size_t)vg.rows * vg.D * sizeof(float), s2));
     RC(dev_zero_launch(vg.d_keys, (size_t)vg.rows * vg.D * sizeof(float), s2));
     if (l_ssim > 0.f) {   // target self-similarity S* of A' (util/losses.py:79)
@@ -346,9 +363,9 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     // ---- losses on the global batch: passes 0 A', 1 B', 2 x', 3 y'
     if (l_ssim > 0.f) RC(ssim_term(st, vg, qkv_g, 0, 2, l_ssim, L_GLOBAL_SSIM, s, true));
     if (l_cls > 0.f)   // [CLS] of block 11, before the final LayerNorm (util/losses.py:90-93)
-        RC(mse2_launch(blk_g + 2 * passD, vg.D, blk_g + 1 * passD, vg.D, 1, vg.D, 1.0f, l_cls, st->losses + L_GLOBAL_CLS, vg.d_block + 2 * passD, vg.D, s));
+        RC(mse_partials_launch(blk_g + 2 * passD, vg.D, blk_g + 1 * passD, vg.D, 1, vg.D, 1.0f, l_cls, loss_part(st, L_GLOBAL_CLS), vg.d_block + 2 * passD, vg.D, s));
     if (l_id > 0.f)    // keys of y' against keys of B' (util/losses.py:96-105): mean over h*T*d = T*D
-        RC(mse2_launch(keys_ptr(vg, qkv_g, 3), 3 * vg.D, keys_ptr(vg, qkv_g, 1), 3 * vg.D, vg.T, vg.D, 1.0f, l_id, st->losses + L_GLOBAL_ID,
+        RC(mse_partials_launch(keys_ptr(vg, qkv_g, 3), 3 * vg.D, keys_ptr(vg, qkv_g, 1), 3 * vg.D, vg.T, vg.D, 1.0f, l_id, loss_part(st, L_GLOBAL_ID),
                        vg.d_keys + 3 * passD, vg.D, s));
     // ---- entire-image branch (every entire_every-th step)
     if (entire) {
@@ -366,25 +383,22 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         const size_t epassD = (size_t)ve.Tld * ve.D;
         if (l_essim > 0.f) RC(ssim_term(st, ve, qkv_e, 0, 1, l_essim, L_ENTIRE_SSIM, s));
         if (l_ecls > 0.f)   // target is the B_global crop's CLS (util/losses.py:60)
-            RC(mse2_launch(blk_e + 1 * epassD, ve.D, blk_g + 1 * passD, vg.D, 1, ve.D, 1.0f, l_ecls, st->losses + L_ENTIRE_CLS, ve.d_block + 1 * epassD, ve.D, s));
+            RC(mse_partials_launch(blk_e + 1 * epassD, ve.D, blk_g + 1 * passD, vg.D, 1, ve.D, 1.0f, l_ecls, loss_part(st, L_ENTIRE_CLS), ve.d_block + 1 * epassD, ve.D, s));
     }
     // ---- backward (train.py:78): ViT dgrad for the generated images only, then the generator
     // the two generated images are independent chains until the generator: one per stream (every launch of a
     // dependent chain pays ~8 us of fixed latency; two chains in flight hide each other's)
-    if (st->ablate & 4) {
-    } else if (overlap) {
-        HIPCHK(hipEventRecord(st->ev_fork, s));
-        HIPCHK(hipStreamWaitEvent(s2, st->ev_fork, 0));
+    if (!(st->ablate & 4)) {   // (the same launches whether or not the second stream is used: results are bit-identical)
+        if (overlap) {
+            HIPCHK(hipEventRecord(st->ev_fork, s));
+            HIPCHK(hipStreamWaitEvent(s2, st->ev_fork, 0));
+        }
         if (!(st->ablate & 32)) RC(splice_vit_backward(vg.ctx, 3, 4, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s2));
         RC(unplace_grad(vg.d_imgs + 3 * vimg, vg.H, vg.W, st->d_gen_out + crop, st->cropb_h, st->cropb_w, s2));
-        HIPCHK(hipEventRecord(st->ev_join, s2));
+        if (overlap) HIPCHK(hipEventRecord(st->ev_join, s2));
         RC(splice_vit_backward(vg.ctx, 2, 3, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
         RC(unplace_grad(vg.d_imgs + 2 * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, s));
-        HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
-    } else {
-        RC(splice_vit_backward(vg.ctx, 2, 4, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
-        RC(unplace_grad(vg.d_imgs + 2 * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, s));
-        RC(unplace_grad(vg.d_imgs + 3 * vimg, vg.H, vg.W, st->d_gen_out + crop, st->cropb_h, st->cropb_w, s));
+        if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
     }
     if (st->ablate & 2) {
     } else if (!split) {
@@ -400,7 +414,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         RC(unplace_grad(ve.d_imgs + eimg, ve.H, ve.W, st->d_ent_out, c.ent_h, c.ent_w, s));
         RC(splice_gen_backward(st->plan_e, params, st->d_ent_out, grads, 1, s));
     }
-    hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(64), 0, s, st->losses, l_ssim, l_essim, l_ecls, l_cls, l_id);
+    hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(256), 0, s, st->losses, l_ssim, l_essim, l_ecls, l_cls, l_id);
     // ---- optimizer.step() (train.py:79); Adam's step count (>= 1) is read from the device at execution time
     RC(adam_launch_dev(params, grads, m, v, (size_t)st->nparams, c.lr, c.beta1, c.beta2, c.eps, st->dev_t, 0, s));
     return SPLICE_OK;
@@ -514,6 +528,15 @@ int splice_step_use_graph(void* h, int on) {
     SpliceStep* st = (SpliceStep*)h;
     if (!st) return SPLICE_ERR_ARG;
     st->use_graph = on ? 1 : 0;
+    return SPLICE_OK;
+}
+// 1 = the independent chains of a step run on two streams (default), 0 = everything on one stream.  The results are
+// bit-identical either way (every kernel is deterministic and owns its outputs); captured graphs are dropped.
+int splice_step_use_overlap(void* h, int on) {
+    SpliceStep* st = (SpliceStep*)h;
+    if (!st) return SPLICE_ERR_ARG;
+    if (st->overlap != (on ? 1 : 0)) drop_graphs(st);
+    st->overlap = on ? 1 : 0;
     return SPLICE_OK;
 }
 }

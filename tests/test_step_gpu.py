@@ -129,3 +129,25 @@ def test_step_gradients_vs_oracle_teacher_forced():
         rel = (num / den) ** 0.5
         print(f"    step {step}: loss {le['loss']:.3f} vs {lo['loss']:.3f}; generator-gradient rel err vs oracle {rel:.3e}")
         assert rel < 5e-2, rel
+
+
+def test_streams_and_graph_do_not_change_results():
+    """The two-stream hipGraph replay, the two-stream eager path and the single-stream eager path launch the same
+    deterministic kernels: parameters after 5 steps (incl. the entire-image branch at step 0, the warm-up switch at
+    step 2 and unequal crops at step 3) must agree BIT FOR BIT."""
+    from splice_amd import _lib
+    A, B = synth.smooth_image_pair(77, 0, 64, 64)
+    A2 = np.ascontiguousarray(A[:, :60, :60])
+    outs = []
+    for graph, overlap in ((1, 1), (0, 1), (0, 0)):
+        eng = _engine(dict(cls_warmup=2, entire_A_every=4), A, B, gen_seed=5, img_size=64)
+        _lib.check(_lib.lib().splice_step_use_graph(eng.handle, graph))
+        _lib.check(_lib.lib().splice_step_use_overlap(eng.handle, overlap))
+        At, Bt, A2t = (torch.from_numpy(x).to(DEV) for x in (A, B, A2))
+        for i in range(5):
+            eng.step(A2t if i == 3 else At, Bt, At)
+        torch.cuda.synchronize()
+        outs.append((eng.params.clone(), eng.losses_dev.clone()))
+    for p, l in outs[1:]:
+        assert torch.equal(l, outs[0][1]), (l, outs[0][1])
+        assert torch.equal(p, outs[0][0]), (p - outs[0][0]).abs().max()
