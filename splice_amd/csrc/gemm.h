@@ -5,7 +5,7 @@
 // 2x2 grid; each wave owns a (BM/2)x(BN/2) sub-tile built from 16x16x32 bf16 MFMAs.
 // K is consumed in BK=64 slices staged through LDS with an XOR swizzle of the 16-byte
 // chunks (chunk ^= row&7) that makes the ds_read_b128 fragment reads conflict-free;
-// the next slice is prefetched into registers while the current one feeds the MFMAs.
+// slices arrive by LDS-DMA into a 2-stage ring (run_glds) or a 4-stage ring (run_ring).
 //
 // Ragged M / N are handled by clamping the load row and predicating the epilogue, so any
 // M, N >= 1 works; K must be a multiple of 64 and lda/ldb multiples of 8 (16-byte rows).
@@ -25,81 +25,7 @@ struct GemmTile {
     static constexpr int LDS_ELEMS = (BM + BN) * GEMM_BK;
     f32x4 acc[FM][FN];
 
-    __device__ __forceinline__ void run(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
-                                        int M, int N, int K, int m0, int n0, bf16_t* smem) {
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-        const int wm = wave >> 1, wn = wave & 1;
-        bf16_t* As = smem;
-        bf16_t* Bs = smem + BM * GEMM_BK;
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        const bf16_t* ag[A_LOADS];
-        const bf16_t* bg[B_LOADS];
-        int as_off[A_LOADS], bs_off[B_LOADS];
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
-            int gr = m0 + row;
-            gr = gr < M ? gr : M - 1;
-            ag[i] = A + (size_t)gr * lda + kc * 8;
-            as_off[i] = row * GEMM_BK + ((kc ^ (row & 7)) << 3);
-        }
-#pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) {
-            const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
-            int gr = n0 + row;
-            gr = gr < N ? gr : N - 1;
-            bg[i] = B + (size_t)gr * ldb + kc * 8;
-            bs_off[i] = row * GEMM_BK + ((kc ^ (row & 7)) << 3);
-        }
-        u32x4 ar[A_LOADS], br[B_LOADS];   // native vectors: HIP's uint4 (a union struct) defeats SROA here -> scratch
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) ar[i] = *reinterpret_cast<const u32x4*>(ag[i]);
-#pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) br[i] = *reinterpret_cast<const u32x4*>(bg[i]);
-
-        const int frow = lane & 15, fchunk = lane >> 4;
-        for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
-            __syncthreads();  // previous slice fully consumed
-#pragma unroll
-            for (int i = 0; i < A_LOADS; ++i) *reinterpret_cast<u32x4*>(As + as_off[i]) = ar[i];
-#pragma unroll
-            for (int i = 0; i < B_LOADS; ++i) *reinterpret_cast<u32x4*>(Bs + bs_off[i]) = br[i];
-            __syncthreads();
-            // unconditional prefetch (the last iteration re-reads its own slice): a branch here makes
-            // hipcc park ar/br in scratch and wait for every load at once
-            const int kn = (k0 + GEMM_BK < K) ? k0 + GEMM_BK : k0;
-#pragma unroll
-            for (int i = 0; i < A_LOADS; ++i) ar[i] = *reinterpret_cast<const u32x4*>(ag[i] + kn);
-#pragma unroll
-            for (int i = 0; i < B_LOADS; ++i) br[i] = *reinterpret_cast<const u32x4*>(bg[i] + kn);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                u32x4 af[FM], bf[FN];
-                const int chunk = kk * 4 + fchunk;
-#pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    const int row = wm * (BM / 2) + i * 16 + frow;
-                    af[i] = *reinterpret_cast<const u32x4*>(As + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
-                }
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const int row = wn * (BN / 2) + j * 16 + frow;
-                    bf[j] = *reinterpret_cast<const u32x4*>(Bs + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
-                }
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
-            }
-        }
-    }
-
-    // Same contraction with direct-to-LDS staging (global_load_lds, 16 B per lane): no VGPR round trip, no
-    // ds_write pass.  A wave-instruction fills 8 rows x 128 B of LDS linearly (dest = wave base + lane*16), so the
+    // Direct-to-LDS staging (global_load_lds, 16 B per lane): no VGPR round trip, no ds_write pass.  A wave-instruction fills 8 rows x 128 B of LDS linearly (dest = wave base + lane*16), so the
     // XOR swizzle is applied on the SOURCE chunk each lane fetches.  Two LDS stages; the loads of slice t+1 are
     // issued right after the barrier that publishes slice t and fly during its MFMAs (one barrier per slice).
     __device__ __forceinline__ void run_glds(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,

@@ -10,6 +10,9 @@
 #include "kernels.h"
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+// both GEMMs are ~170 workgroups walking 12-13 K slices: latency-bound, so they use the 4-stage LDS-DMA ring (64 KB)
+constexpr int SS_RING = 4;
+constexpr size_t SS_LDS = (size_t)SS_RING * GemmTile<64, 64>::LDS_ELEMS * sizeof(bf16_t);
 
 size_t selfsim_ws_bytes(int T, int D) {
     const size_t Tp = round_up(T, 64);
@@ -46,12 +49,12 @@ __global__ __launch_bounds__(256) void selfsim_prep_kernel(const float* __restri
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void selfsim_gemm_kernel(const bf16_t* __restrict__ Kb, int T, int D, const float* __restrict__ norm,
                                                            float eps, float* __restrict__ S) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[GemmTile<BM, BN>::LDS_ELEMS];
+    extern __shared__ __attribute__((aligned(16))) bf16_t selfsim_smem[];   // SS_RING stages
     const int tiles_n = (T + BN - 1) / BN;
     const int t = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
     GemmTile<BM, BN> tile;
-    tile.run(Kb, D, Kb, D, T, T, D, m0, n0, smem);
+    tile.template run_ring<SS_RING>(Kb, D, Kb, D, T, T, D, m0, n0, selfsim_smem);
     tile.for_each(m0, n0, [&](int row0, int col, f32x4 v) {
         if (col >= T) return;
         const float nj = norm[col];
@@ -65,7 +68,7 @@ int selfsim_fwd_launch(const float* K, int ldk, int T, int D, float eps, float* 
     if (D % 64) return SPLICE_ERR_ARG;
     hipLaunchKernelGGL(selfsim_prep_kernel, dim3(cdiv(ws.Tp, 4)), dim3(256), 0, s, K, ldk, T, D, ws);
     const int grid = cdiv(T, 64) * cdiv(T, 64);
-    hipLaunchKernelGGL((selfsim_gemm_kernel<64, 64>), dim3(grid), dim3(256), 0, s, ws.kbf, T, D, ws.norm, eps, S);
+    hipLaunchKernelGGL((selfsim_gemm_kernel<64, 64>), dim3(grid), dim3(256), SS_LDS, s, ws.kbf, T, D, ws.norm, eps, S);
     return SPLICE_OK;
 }
 
@@ -101,12 +104,12 @@ __global__ __launch_bounds__(256) void selfsim_wmat_kernel(const float* __restri
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void selfsim_bwd_gemm_kernel(SelfSimWs ws, int T, int D, float* __restrict__ dK, int lddk,
                                                                int accumulate) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[GemmTile<BM, BN>::LDS_ELEMS];
+    extern __shared__ __attribute__((aligned(16))) bf16_t selfsim_smem[];
     const int tiles_n = (D + BN - 1) / BN;
     const int t = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
     GemmTile<BM, BN> tile;
-    tile.run(ws.wmat, ws.Tp, ws.kbfT, ws.Tp, T, D, ws.Tp, m0, n0, smem);
+    tile.template run_ring<SS_RING>(ws.wmat, ws.Tp, ws.kbfT, ws.Tp, T, D, ws.Tp, m0, n0, selfsim_smem);
     tile.for_each(m0, n0, [&](int row0, int col, f32x4 v) {
         if (col >= D) return;
 #pragma unroll
@@ -126,7 +129,7 @@ int selfsim_bwd_launch(const float* dS, const float* S, int T, int D, float eps,
     if (D % 64) return SPLICE_ERR_ARG;
     hipLaunchKernelGGL(selfsim_wmat_kernel, dim3(ws.Tp), dim3(256), 0, s, dS, S, T, eps, ws);
     const int grid = cdiv(T, 64) * cdiv(D, 64);
-    hipLaunchKernelGGL((selfsim_bwd_gemm_kernel<64, 64>), dim3(grid), dim3(256), 0, s, ws, T, D, dK, lddk, accumulate);
+    hipLaunchKernelGGL((selfsim_bwd_gemm_kernel<64, 64>), dim3(grid), dim3(256), SS_LDS, s, ws, T, D, dK, lddk, accumulate);
     return SPLICE_OK;
 }
 
