@@ -130,22 +130,17 @@ static int view_init(SpliceStep* st, VitView& v, void* ctx, int want_B) {
 
 // raw_k = fixed-order sum of term k's workgroup partials (no float atomics anywhere: replicas are bit-reproducible);
 // total = sum_k lambda_k * raw_k   (util/losses.py:53-71)
-__global__ __launch_bounds__(256) void total_loss_kernel(float* l, float w_ssim, float w_essim, float w_ecls, float w_cls, float w_id) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(320) void total_loss_kernel(float* l, float w_ssim, float w_essim, float w_ecls, float w_cls, float w_id) {
     __shared__ float raw[8];
-    for (int k = 1; k <= 5; ++k) {
-        const float* part = l + 8 + k * SPLICE_MSE_PARTIALS;
-        float acc = 0.f;
-        for (int i = threadIdx.x; i < SPLICE_MSE_PARTIALS; i += 256) acc += part[i];
-        acc = wave_sum(acc);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) raw[k] = (red[0] + red[1]) + (red[2] + red[3]);
-    }
+    const int k = 1 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave k-1 owns term k (5 waves)
+    const float* part = l + 8 + k * SPLICE_MSE_PARTIALS;
+    float acc = 0.f;
+    for (int i = lane; i < SPLICE_MSE_PARTIALS; i += 64) acc += part[i];
+    acc = wave_sum(acc);
+    if (lane == 0) raw[k] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k <= 5; ++k) l[k] = raw[k];
+        for (int t = 1; t <= 5; ++t) l[t] = raw[t];
         l[L_TOTAL] = w_ssim * raw[L_GLOBAL_SSIM] + w_essim * raw[L_ENTIRE_SSIM] + w_ecls * raw[L_ENTIRE_CLS] + w_cls * raw[L_GLOBAL_CLS] + w_id * raw[L_GLOBAL_ID];
     }
 }
@@ -414,7 +409,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         RC(unplace_grad(ve.d_imgs + eimg, ve.H, ve.W, st->d_ent_out, c.ent_h, c.ent_w, s));
         RC(splice_gen_backward(st->plan_e, params, st->d_ent_out, grads, 1, s));
     }
-    hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(256), 0, s, st->losses, l_ssim, l_essim, l_ecls, l_cls, l_id);
+    hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(320), 0, s, st->losses, l_ssim, l_essim, l_ecls, l_cls, l_id);
     // ---- optimizer.step() (train.py:79); Adam's step count (>= 1) is read from the device at execution time
     RC(adam_launch_dev(params, grads, m, v, (size_t)st->nparams, c.lr, c.beta1, c.beta2, c.eps, st->dev_t, 0, s));
     return SPLICE_OK;
