@@ -206,8 +206,16 @@ static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* para
         a.N = N; a.Cin = u.Cin; a.Hi = u.Hi; a.Wi = u.Wi; a.Cout = u.Cout; a.Ho = u.Ho; a.Wo = u.Wo;
         a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2;
         a.ws = p->conv_ws; a.ws_floats = p->conv_ws_floats;
-        RC(conv_launch(a, s));
+        // small planes: a split-K convolution leaves its slabs for the BatchNorm kernel, which adds them while it loads the plane
+        a.defer_reduce = u.Ho * u.Wo <= bn_small_hw();
+        int ksplit = 1;
+        RC(conv_launch(a, s, &ksplit));
         y = u.y; y_ns = u.y_ns;
+        if (a.defer_reduce && ksplit > 1) {
+            RC(bn_fwd_slabs_launch(p->conv_ws, ksplit, a.bias, u.y, u.y_ns, u.out, u.out_ns, N, u.Cout, u.Ho * u.Wo, params + u.g_off,
+                                   params + u.be_off, BN_EPS, u.mean, u.rstd, u.slope, s));
+            return SPLICE_OK;
+        }
     }
     RC(bn_fwd_launch(y, y_ns, u.out, u.out_ns, N, u.Cout, u.Ho * u.Wo, params + u.g_off, params + u.be_off, BN_EPS, u.s1, u.mean, u.rstd, u.slope, s));
     return SPLICE_OK;

@@ -17,8 +17,9 @@ struct ConvArgs {
     float* ws;        // optional split-K scratch (ws_floats floats); null disables split-K
     size_t ws_floats;
     int ksplit;       // set by the launcher
+    int defer_reduce; // split-K: leave the raw slabs in ws (ksplit_out tells how many); the consumer adds bias + slabs in slice order
 };
-int conv_launch(const ConvArgs& a, hipStream_t s);
+int conv_launch(const ConvArgs& a, hipStream_t s, int* ksplit_out = nullptr);
 
 struct WgradArgs {
     const float* x;       // layer input  [N][*][Hi][Wi]
@@ -58,6 +59,11 @@ int wgrad_reduce_all_launch(const WgradReduceAll& d, const float* ws, float* gra
 int bn_part_floats(int N, int C);
 int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
                   const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s);
+// same, fused with the split-K reduction of the convolution that feeds it (small planes only: HW <= bn_small_hw()):
+// y = bias + sum_k slabs[k] is formed, stored (the backward reads it) and normalised in one launch
+int bn_small_hw();
+int bn_fwd_slabs_launch(const float* slabs, int ksplit, const float* bias, float* y, size_t y_nstride, float* out, size_t out_nstride, int N,
+                        int C, int HW, const float* gamma, const float* beta, float eps, float* mean, float* rstd, float slope, hipStream_t s);
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
                   float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s);

@@ -175,7 +175,7 @@ __global__ void conv_splitk_reduce_kernel(ConvArgs a, int ksplit) {
 }
 
 template <int KS, bool TR, int CK>
-static void conv_launch_fn(ConvArgs a, hipStream_t s) {
+static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
     const int HWo = a.Ho * a.Wo;
     const int mt = cdiv(HWo, 64);
     const int fn = a.Cout <= 16 ? 1 : (a.Cout <= 32 ? 2 : 4);
@@ -194,7 +194,8 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s) {
     if (fn == 1) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1, CK>), grid, dim3(256), 0, s, a);
     else if (fn == 2) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 2, CK>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 4, CK>), grid, dim3(256), 0, s, a);
-    if (ksplit > 1) {
+    if (ksplit_out) *ksplit_out = ksplit;
+    if (ksplit > 1 && !a.defer_reduce) {
         const size_t per = (size_t)a.N * a.Cout * HWo;
         size_t g = (per + 255) / 256;
         if (g > 1024) g = 1024;
@@ -202,17 +203,17 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s) {
     }
 }
 
-int conv_launch(const ConvArgs& a, hipStream_t s) {
+int conv_launch(const ConvArgs& a, hipStream_t s, int* ksplit_out) {
     if (a.ks != 1 && a.ks != 3) return SPLICE_ERR_ARG;
     if (a.stride != 1 && a.stride != 2) return SPLICE_ERR_ARG;
     if ((size_t)a.Cin * a.in_cstride > 0x7fffffffULL) return SPLICE_ERR_ARG;   // 32-bit gather offsets
     // deeper channel tiles where the reduction is long (fewer barrier rounds on the small, deep layers)
     if (a.ks == 3) {
-        if (a.Cin >= 32) { if (a.transposed) conv_launch_fn<3, true, 8>(a, s); else conv_launch_fn<3, false, 8>(a, s); }
-        else { if (a.transposed) conv_launch_fn<3, true, 4>(a, s); else conv_launch_fn<3, false, 4>(a, s); }
+        if (a.Cin >= 32) { if (a.transposed) conv_launch_fn<3, true, 8>(a, s, ksplit_out); else conv_launch_fn<3, false, 8>(a, s, ksplit_out); }
+        else { if (a.transposed) conv_launch_fn<3, true, 4>(a, s, ksplit_out); else conv_launch_fn<3, false, 4>(a, s, ksplit_out); }
     } else {
-        if (a.Cin >= 64) { if (a.transposed) conv_launch_fn<1, true, 32>(a, s); else conv_launch_fn<1, false, 32>(a, s); }
-        else { if (a.transposed) conv_launch_fn<1, true, 16>(a, s); else conv_launch_fn<1, false, 16>(a, s); }
+        if (a.Cin >= 64) { if (a.transposed) conv_launch_fn<1, true, 32>(a, s, ksplit_out); else conv_launch_fn<1, false, 32>(a, s, ksplit_out); }
+        else { if (a.transposed) conv_launch_fn<1, true, 16>(a, s, ksplit_out); else conv_launch_fn<1, false, 16>(a, s, ksplit_out); }
     }
     return SPLICE_OK;
 }
@@ -599,21 +600,42 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 // pure launch latency -- a kernel boundary costs more than the work.
 constexpr int BN_SMALL_HW = 4096;
 constexpr int BN_SMALL_PER = BN_SMALL_HW / 256;   // plane elements a thread keeps in registers
+// slabs != null: the plane is first formed as bias + sum of the feeding convolution's split-K slabs (slice order) and stored to y
 __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ y, size_t y_nstride, float* __restrict__ out,
                                                            size_t out_nstride, int C, int HW, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float* __restrict__ mean_o,
-                                                           float* __restrict__ rstd_o, float slope) {
+                                                           float* __restrict__ rstd_o, float slope, const float* __restrict__ slabs,
+                                                           int ksplit, const float* __restrict__ bias, float* __restrict__ y_out) {
     __shared__ float red[8];
     const int c = blockIdx.x, img = blockIdx.y;
     const float* p = y + (size_t)img * y_nstride + (size_t)c * HW;
     float* q = out + (size_t)img * out_nstride + (size_t)c * HW;
     float v[BN_SMALL_PER];
     float s = 0.f, dummy = 0.f;
+    if (slabs) {
+        const size_t per = (size_t)gridDim.y * C * HW;
+        const float* sp = slabs + ((size_t)img * C + c) * HW;
+        float* yo = y_out + (size_t)img * y_nstride + (size_t)c * HW;
+        const float b = bias ? bias[c] : 0.f;
 #pragma unroll
-    for (int k = 0; k < BN_SMALL_PER; ++k) {
-        const int i = threadIdx.x + k * 256;
-        v[k] = i < HW ? p[i] : 0.f;
-        s += v[k];
+        for (int k = 0; k < BN_SMALL_PER; ++k) {
+            const int i = threadIdx.x + k * 256;
+            float t = 0.f;
+            if (i < HW) {
+                t = b;
+                for (int ks = 0; ks < ksplit; ++ks) t += sp[(size_t)ks * per + i];
+                yo[i] = t;
+            }
+            v[k] = t;
+            s += t;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < BN_SMALL_PER; ++k) {
+            const int i = threadIdx.x + k * 256;
+            v[k] = i < HW ? p[i] : 0.f;
+            s += v[k];
+        }
     }
     block_sum2(s, dummy, red);
     const float m = s / (float)HW;
@@ -692,12 +714,21 @@ int bn_part_floats(int N, int C) { return N * C * MAX_PB * 2; }
 int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
                   const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s) {
     if (HW <= BN_SMALL_HW) {
-        hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd, slope);
+        hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd, slope,
+                           (const float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
         return SPLICE_OK;
     }
     const int PB = plane_blocks(HW);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, C, HW, PB, part);
     hipLaunchKernelGGL(bn_act_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, PB, gamma, beta, part, eps, mean, rstd, slope);
+    return SPLICE_OK;
+}
+int bn_small_hw() { return BN_SMALL_HW; }
+int bn_fwd_slabs_launch(const float* slabs, int ksplit, const float* bias, float* y, size_t y_nstride, float* out, size_t out_nstride, int N,
+                        int C, int HW, const float* gamma, const float* beta, float eps, float* mean, float* rstd, float slope, hipStream_t s) {
+    if (HW > BN_SMALL_HW || ksplit < 2 || !slabs) return SPLICE_ERR_ARG;
+    hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C, N), dim3(256), 0, s, (const float*)y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd,
+                       slope, slabs, ksplit, bias, y);
     return SPLICE_OK;
 }
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
