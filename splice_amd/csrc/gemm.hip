@@ -40,6 +40,8 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
 int gemm_nt_launch(unsigned flags, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K,
                    const GemmEpi& e, hipStream_t s) {
     if (M < 1 || N < 1 || K < GEMM_BK || K % GEMM_BK || lda % 8 || ldb % 8) return SPLICE_ERR_ARG;
+    // the LDS-DMA uses 32-bit byte offsets from the operand bases
+    if ((size_t)M * lda * sizeof(bf16_t) >= (1ull << 32) || (size_t)N * ldb * sizeof(bf16_t) >= (1ull << 32)) return SPLICE_ERR_ARG;
     if ((flags & EPI_OUT_T) && (e.ldt % 4)) return SPLICE_ERR_ARG;
     if ((flags & EPI_ROWDOT) && (N % 64 || !e.rd_other || !e.rowdot || e.rd_rows < 1 || e.ld_rd % 4)) return SPLICE_ERR_ARG;
 #define CASE(F) case (F): return dispatch_tile<(F)>(A, lda, B, ldb, M, N, K, e, s)
