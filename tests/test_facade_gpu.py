@@ -141,3 +141,19 @@ def test_checkpoint_to_extractor_all_variants(name, tmp_path):
     assert rel(ext.get_keys_from_input(img.to(DEV), depth - 1), ref_keys) < 2e-2
     with pytest.raises(ValueError, match="was requested"):
         VitExtractor("dino_vitb16" if name != "dino_vitb16" else "dino_vits8", DEV, checkpoint=str(path))
+
+
+def test_keys_self_sim_pca_script(tmp_path):
+    """SURVEY 8f rank 4 (first half): the keys-self-similarity PCA visualisation on the HIP extractor."""
+    from PIL import Image
+    from splice_amd import keys_self_sim_pca as ksp
+    from splice_amd.extractor import VitExtractor
+    img = torch.from_numpy(synth.smooth_image_pair(8, 0, 64, 96)[0])
+    ext = VitExtractor("dino_vits8", DEV, state_dict=synth.vit_params(7, "dino_vits8", img_size=64, w_std=0.05))
+    pic = ksp.keys_self_sim_pca_image(img, ext, layer=11)
+    assert pic.shape == (64, 96, 3) and pic.dtype == np.uint8 and pic.min() == 0 and pic.max() >= 250
+    # the picture is a function of the self-similarity map: same map -> same PCA (sign conventions included)
+    ss = ext.get_keys_self_sim_from_input(((img[None].to(DEV) - torch.tensor(ksp._MEAN, device=DEV).view(1, 3, 1, 1))
+                                           / torch.tensor(ksp._STD, device=DEV).view(1, 3, 1, 1)), 11)
+    assert ss.shape == (1, 1 + 8 * 12, 1 + 8 * 12)
+    Image.fromarray(pic).save(tmp_path / "pca.png")
