@@ -9,7 +9,8 @@ expected outputs / strided samples are stored).  What is driven:
 
   * ``models.extractor.attn_cosine_sim`` and ``VitExtractor.get_{queries,keys,values}_from_qkv``,
     ``get_keys_from_input``, ``get_keys_self_sim_from_input``, ``get_feature_from_input``
-  * ``models.networks.define_G`` / ``models.unet.skip.skip`` forward + autograd backward
+  * ``models.networks.define_G`` / ``models.unet.skip.skip`` forward + autograd backward (default architecture, and the
+    6-scale reflection-padded net of ``inversion.py``)
   * ``util.losses.LossG`` + ``models.model.Model`` + ``util.util.get_optimizer`` for
     step losses, d loss / d params and a 20-step trajectory.
 
@@ -178,6 +179,33 @@ def golden_generator(ref_networks_mod):
     print("generator.npz", len(out))
 
 
+INVERSION_NET = dict(num_channels_down=[16, 32, 64, 128, 128, 128], num_channels_up=[16, 32, 64, 128, 128, 128],
+                     num_channels_skip=[4, 4, 4, 4, 4, 4], filter_size_down=[7, 7, 5, 5, 3, 3], filter_size_up=[7, 7, 5, 5, 3, 3],
+                     downsample_mode='stride', pad='reflection')
+
+
+def golden_inversion_net():
+    """The 6-scale reflection-padded skip() of inversion.py:21-25 (reference module), parameters seeded BY POSITION in
+    parameters() order (conv weights N(0, 0.05), everything else 1 + N(0, 0.05) / N(0, 0.05)), forward + backward."""
+    from models.unet.skip import skip as ref_skip
+    net = ref_skip(8, 3, **INVERSION_NET)
+    with torch.no_grad():
+        for i, (name, p) in enumerate(net.named_parameters()):
+            off = 1.0 if p.dim() == 1 and name.endswith("weight") else 0.0   # BatchNorm gains around 1
+            p.copy_(torch.from_numpy(synth.normal(31, f"inv/p{i}", tuple(p.shape), 0.05, off)))
+    out = {"n_params": np.int64(sum(p.numel() for p in net.parameters())), "n_tensors": np.int64(len(list(net.parameters())))}
+    for tag, (h, w) in {"96x72": (96, 72), "100x84": (100, 84)}.items():   # the second one exercises the Concat centre crop
+        x = torch.from_numpy(synth.normal(32, "inv/x" + tag, (1, 8, h, w)))
+        net.zero_grad()
+        y = net(x)
+        (y * y).mean().backward()
+        out[f"{tag}/out_sample"] = sample(y, 2053)
+        out[f"{tag}/out_stats"] = stats(y)
+        out[f"{tag}/grad_stats"] = np.stack([stats(p.grad) for p in net.parameters()])
+    np.savez_compressed(os.path.join(OUT, "inversion_net.npz"), **out)
+    print("inversion_net.npz", len(out))
+
+
 def run_reference_loop(cfg, A, B, n_steps, ref, A_entire=None, record_grads_at=()):
     """The body of ``train.py:51-80`` with the dataset replaced by fixed full crops
     (``Global_crops`` with min_cover=1 returns the whole image, data/transforms.py:22-23)."""
@@ -269,9 +297,15 @@ def main():
     from models.model import Model
     from util.losses import LossG
     from util.util import get_optimizer
-    golden_extractor(ref_extractor)
-    golden_generator(ref_networks)
-    golden_steps((Model, LossG, get_optimizer))
+    only = set(sys.argv[1:])   # e.g. `python oracle/make_golden.py inversion_net` regenerates one fixture
+    if not only or "extractor" in only:
+        golden_extractor(ref_extractor)
+    if not only or "generator" in only:
+        golden_generator(ref_networks)
+    if not only or "steps" in only:
+        golden_steps((Model, LossG, get_optimizer))
+    if not only or "inversion_net" in only:
+        golden_inversion_net()
 
 
 if __name__ == "__main__":

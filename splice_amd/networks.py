@@ -4,9 +4,9 @@
 ``netG`` is an ``nn.Module`` whose 112 parameters carry the reference's ``state_dict`` names
 (``1.0.1.0.weight`` ... ``9.0.bias``, the numbering of ``models/unet/common.py:6-9``) and are
 VIEWS into one flat fp32 arena, so ``torch.optim`` / ``state_dict`` / ``load_state_dict`` work
-unchanged while the engine reads and writes the arena directly.  Only the reference's default
-architecture (``skip()`` with its default arguments, which is all ``define_G`` ever builds) is
-implemented; other ``skip(...)`` arguments raise NotImplementedError.
+unchanged while the engine reads and writes the arena directly.  The fused engine implements the reference's
+default architecture (``skip()`` with its default arguments, which is all ``define_G`` ever builds); any other
+``skip(...)`` arguments return a stock-PyTorch module (``unet_general.GeneralSkip``, used by ``inversion.py``).
 """
 import math
 
@@ -107,14 +107,19 @@ def skip(num_input_channels=3, num_output_channels=3, num_channels_down=[16, 32,
          num_channels_up=[16, 32, 64, 128, 128], num_channels_skip=[4, 4, 4, 4, 4], filter_size_down=3, filter_size_up=3,
          filter_skip_size=1, need_sigmoid=True, need_tanh=False, need_bias=True, pad='zero', upsample_mode='bilinear',
          downsample_mode='stride', act_fun='LeakyReLU', need1x1_up=True, device="cuda"):
-    """``models/unet/skip.py:4-11`` -- only the default arguments are supported by the HIP engine."""
+    """``models/unet/skip.py:4-11``: the default arguments give the fused HIP generator, anything else a PyTorch module."""
     default = (3, 3, [16, 32, 64, 128, 128], [16, 32, 64, 128, 128], [4, 4, 4, 4, 4], 3, 3, 1, True, False, True, 'zero',
                'bilinear', 'stride', 'LeakyReLU', True)
     given = (num_input_channels, num_output_channels, list(num_channels_down), list(num_channels_up), list(num_channels_skip),
              filter_size_down, filter_size_up, filter_skip_size, need_sigmoid, need_tanh, need_bias, pad, upsample_mode,
              downsample_mode, act_fun, need1x1_up)
     if given != default:
-        raise NotImplementedError("the HIP generator engine implements skip() with the reference's default arguments only")
+        # any other architecture (e.g. the 6-scale reflection-padded net of inversion.py:21-25) is outside the Splice hot
+        # path: assembled from stock PyTorch-ROCm modules (splice_amd/unet_general.py)
+        from .unet_general import GeneralSkip
+        return GeneralSkip(num_input_channels, num_output_channels, num_channels_down, num_channels_up, num_channels_skip,
+                           filter_size_down, filter_size_up, filter_skip_size, need_sigmoid, need_tanh, need_bias, pad,
+                           upsample_mode, downsample_mode, act_fun, need1x1_up).to(device)
     return SkipGenerator(device=device)
 
 

@@ -157,3 +157,22 @@ def test_keys_self_sim_pca_script(tmp_path):
                                            / torch.tensor(ksp._STD, device=DEV).view(1, 3, 1, 1)), 11)
     assert ss.shape == (1, 1 + 8 * 12, 1 + 8 * 12)
     Image.fromarray(pic).save(tmp_path / "pca.png")
+
+
+def test_inversion_script_smoke(tmp_path):
+    """SURVEY 8f rank 4 (second half): inversion.py on the HIP extractor -- the loss of both feature kinds goes down."""
+    import types
+    from PIL import Image
+    from splice_amd import inversion
+    img = synth.smooth_image_pair(9, 0, 224, 224)[0]
+    Image.fromarray((img.transpose(1, 2, 0) * 255).astype(np.uint8)).save(tmp_path / "ref.png")
+    torch.manual_seed(3)
+    for feature, n_iter in (("keys", 25), ("cls", 25)):
+        args = types.SimpleNamespace(feature=feature, layer=11, dino_model_name="dino_vits16", image_path=str(tmp_path / "ref.png"),
+                                     save_path=str(tmp_path / f"inv_{feature}.png"), log_freq=10, input_depth=8, LR=0.01, n_iter=n_iter,
+                                     reduce_noise_stage_1_iter=10, reduce_noise_stage_2_iter=20, checkpoint=None, synthetic=True)
+        losses = inversion.invert(args)
+        assert len(losses) == n_iter and all(np.isfinite(losses))
+        assert np.mean(losses[-5:]) < np.mean(losses[:5])
+        assert (tmp_path / f"inv_{feature}.png").exists()
+    assert inversion.noise_scale(0, 10, 20) == 10.0 and inversion.noise_scale(10, 10, 20) == 2.0 and inversion.noise_scale(20, 10, 20) == 0.5

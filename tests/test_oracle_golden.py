@@ -140,3 +140,28 @@ def test_steps_b_resize_nonsquare(golden_dir):
     _check_rows(rows[:2], g["b/losses"], keys, 2e-4)
     _check_rows(rows, g["b/losses"], keys, 2e-2)
     assert final.shape == g["b/final_out"].shape
+
+
+def test_general_skip_matches_reference_inversion_net(golden_dir):
+    """splice_amd.unet_general.GeneralSkip (the non-default skip() used by inversion.py) against outputs and parameter
+    gradients recorded from the reference's models/unet/skip.py with the same position-seeded parameters."""
+    from splice_amd.networks import skip
+    from oracle.make_golden import INVERSION_NET, sample, stats
+    g = np.load(os.path.join(golden_dir, "inversion_net.npz"))
+    net = skip(8, 3, device="cpu", **INVERSION_NET)
+    params = list(net.named_parameters())
+    assert len(params) == int(g["n_tensors"]) and sum(p.numel() for _, p in params) == int(g["n_params"])
+    with torch.no_grad():
+        for i, (name, p) in enumerate(params):
+            off = 1.0 if p.dim() == 1 and name.endswith("weight") else 0.0
+            p.copy_(torch.from_numpy(synth.normal(31, f"inv/p{i}", tuple(p.shape), 0.05, off)))
+    for tag, (h, w) in {"96x72": (96, 72), "100x84": (100, 84)}.items():
+        x = torch.from_numpy(synth.normal(32, "inv/x" + tag, (1, 8, h, w)))
+        net.zero_grad()
+        y = net(x)
+        (y * y).mean().backward()
+        assert y.shape == (1, 3, h, w)
+        np.testing.assert_allclose(sample(y, 2053), g[f"{tag}/out_sample"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(stats(y), g[f"{tag}/out_stats"], rtol=1e-6)
+        gs = np.stack([stats(p.grad) for _, p in params])
+        np.testing.assert_allclose(gs[:, 1:], g[f"{tag}/grad_stats"][:, 1:], rtol=2e-4, atol=1e-10)   # |g| and g^2 sums
