@@ -27,6 +27,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import splice_amd  # noqa: E402,F401  (sets GPU_MAX_HW_QUEUES before the HIP runtime starts; see splice_amd/__init__.py)
 
 
 def host_threads():
