@@ -144,6 +144,27 @@ __global__ __launch_bounds__(320) void total_loss_kernel(float* l, float w_ssim,
         l[L_TOTAL] = w_ssim * raw[L_GLOBAL_SSIM] + w_essim * raw[L_ENTIRE_SSIM] + w_ecls * raw[L_ENTIRE_CLS] + w_cls * raw[L_GLOBAL_CLS] + w_id * raw[L_GLOBAL_ID];
     }
 }
+// All per-step inputs in ONE eager launch in front of the graph replay (three copies + the Adam step count were four
+// launches with ~10-30 us of host/queue gaps between them): up to three fp32 buffers and one int.
+struct StageArgs { const float* src[3]; float* dst[3]; unsigned long long n[3]; int* ip; int iv; };
+__global__ __launch_bounds__(256) void stage_inputs_kernel(StageArgs a) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (!a.src[k]) continue;
+        const size_t n4 = a.n[k] / 4;   // element counts are multiples of 4? not guaranteed: vector body + scalar tail
+        const float4* s4 = reinterpret_cast<const float4*>(a.src[k]);
+        float4* d4 = reinterpret_cast<float4*>(a.dst[k]);
+        const bool vec = ((reinterpret_cast<size_t>(a.src[k]) | reinterpret_cast<size_t>(a.dst[k])) & 15) == 0;
+        if (vec) {
+            for (size_t i = gid; i < n4; i += stride) d4[i] = s4[i];
+            for (size_t i = n4 * 4 + gid; i < a.n[k]; i += stride) a.dst[k][i] = a.src[k][i];
+        } else {
+            for (size_t i = gid; i < a.n[k]; i += stride) a.dst[k][i] = a.src[k][i];
+        }
+    }
+    if (gid == 0) *a.ip = a.iv;
+}
 static float* loss_part(SpliceStep* st, int slot) { return st->losses + 8 + slot * SPLICE_MSE_PARTIALS; }
 
 static int place_image(const float* src, int h, int w, float* dst, int oh, int ow, hipStream_t s) {
@@ -452,10 +473,14 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
     }
     // ---- stage the inputs (eager)
     const size_t crop = (size_t)3 * c.crop_h * c.crop_w, cropb = (size_t)3 * st->cropb_h * st->cropb_w;
-    HIPCHK(hipMemcpyAsync(st->gen_in, A_crop, crop * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(split ? st->in_b : st->gen_in + crop, B_crop, cropb * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (entire) HIPCHK(hipMemcpyAsync(st->ent_in, A_entire, (size_t)3 * c.ent_h * c.ent_w * sizeof(float), hipMemcpyDeviceToDevice, s));
-    RC(set_int_launch(st->dev_t, step_idx + 1, s));
+    {
+        StageArgs sa = {};
+        sa.src[0] = A_crop; sa.dst[0] = st->gen_in; sa.n[0] = crop;
+        sa.src[1] = B_crop; sa.dst[1] = split ? st->in_b : st->gen_in + crop; sa.n[1] = cropb;
+        if (entire) { sa.src[2] = A_entire; sa.dst[2] = st->ent_in; sa.n[2] = (size_t)3 * c.ent_h * c.ent_w; }
+        sa.ip = st->dev_t; sa.iv = step_idx + 1;
+        hipLaunchKernelGGL(stage_inputs_kernel, dim3(128), dim3(256), 0, s, sa);
+    }
     if (!graph) {
         RC(step_body(st, params, grads, m, v, st->ssim_id_on != 0, entire, split, s));
     } else {
