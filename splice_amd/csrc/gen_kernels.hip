@@ -19,20 +19,28 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // out[c][iy][ix] = sum_{n,ky,kx} in[n][oy][ox] w[n][c][ky][kx] with oy*stride + ky - pad = iy.
 // The gather offsets of a thread do not depend on the channel tile, so they are computed once;
 // the next tile's operands are fetched into registers while the current one feeds the MFMAs.
-template <int KS, bool TRANSPOSED, int FN, int CK>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+// NG = 2: an 8-wave workgroup -- the second wave group takes the other half of every K tile's MFMA steps (and half of
+// the gather), its accumulators are added through LDS at the end.  For the layers with at most ~2 workgroups per CU the
+// run time is the serial K walk of one workgroup (fp32 MFMA: 32 cycles per 16x16x4 step), and this halves it.
+template <int KS, bool TRANSPOSED, int FN, int CK, int NG>
+__global__ __launch_bounds__(256 * NG) void conv_igemm_kernel(ConvArgs a) {
     constexpr int T = KS * KS;
     constexpr int KT = CK * T;          // k extent of one LDS tile (multiple of 4)
     constexpr int BM = 64;
     constexpr int LDA = BM + 16;        // 80: k-rows 16 banks apart -> conflict-free ds_read_b32
     constexpr int LDW = KT + 2;         // 2*odd -> conflict-free
     constexpr int BN = 16 * FN;
-    constexpr int NA = KT / 4;                      // gathered elements per thread per tile
-    constexpr int NW = (BN * KT + 255) / 256;       // weight elements per thread per tile
-    static_assert(KT % 4 == 0 && ((LDW / 2) & 1) == 1, "tile shape");
+    constexpr int NTH = 256 * NG;
+    constexpr int NWV = 4 * NG;                     // waves
+    constexpr int NA = KT / NWV;                    // gathered elements per thread per tile
+    constexpr int NW = (BN * KT + NTH - 1) / NTH;   // weight elements per thread per tile
+    constexpr int KSTEPS = KT / 4 / NG;             // MFMA k steps per wave group per tile
+    static_assert(KT % (4 * NG) == 0 && ((LDW / 2) & 1) == 1, "tile shape");
+    static_assert(NG == 1 || KT * LDA >= FN * 4 * 256, "accumulator exchange reuses the A tile");
     __shared__ float As[KT * LDA];
     __shared__ float Ws[BN * LDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pw = wave & 3, grp = wave >> 2;       // pixel fragment / wave group
     const int img = blockIdx.z;
     const int m0 = blockIdx.x * BM;
     const int HWo = a.Ho * a.Wo;
@@ -49,12 +57,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int cper = ((a.Cin + ksplit - 1) / ksplit + CK - 1) / CK * CK;
     const int cbeg = kslice * cper;
     const int Kc = min(a.Cin, cbeg + cper);  // reduction channels [cbeg, Kc)
-    // ---- per-thread gather descriptors (k = wave + 4*i is wave-uniform)
+    // ---- per-thread gather descriptors (k = wave + NWV*i is wave-uniform)
     int a_off[NA], a_cl[NA];
     unsigned a_ok = 0;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int k = wave + 4 * i;
+        const int k = wave + NWV * i;
         const int cl = k / T, tap = k % T;
         const int ky = tap / KS, kx = tap % KS;
         int sy, sx;
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     unsigned w_ok = 0;
 #pragma unroll
     for (int t = 0; t < NW; ++t) {
-        const int e = tid + 256 * t;
+        const int e = tid + NTH * t;
         const int j = e / KT, k = e % KT;
         const int cl = k / T, tap = k % T;
         const bool ok = e < BN * KT && (n0 + j) < a.Cout;
@@ -108,15 +116,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     for (int c0 = cbeg; c0 < Kc; c0 += CK) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < NA; ++i) As[(wave + 4 * i) * LDA + pl] = av[i];
+        for (int i = 0; i < NA; ++i) As[(wave + NWV * i) * LDA + pl] = av[i];
 #pragma unroll
         for (int t = 0; t < NW; ++t)
             if (w_lds[t] >= 0) Ws[w_lds[t]] = wv[t];
         __syncthreads();
         if (c0 + CK < Kc) fetch(c0 + CK);
 #pragma unroll
-        for (int kk = 0; kk < KT / 4; ++kk) {
-            const float a_ = As[(kk * 4 + (lane >> 4)) * LDA + wave * 16 + (lane & 15)];
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int kk = grp * KSTEPS + ks;
+            const float a_ = As[(kk * 4 + (lane >> 4)) * LDA + pw * 16 + (lane & 15)];
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 const float b_ = Ws[(j * 16 + (lane & 15)) * LDW + kk * 4 + (lane >> 4)];
@@ -124,7 +133,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             }
         }
     }
-    // epilogue: acc[j][r] = out[n = n0 + j*16 + (lane&15)][pixel = m0 + wave*16 + (lane>>4)*4 + r]
+    if (NG == 2) {   // second wave group -> first, through the (now idle) A tile
+        __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) As[(j * 4 + r) * 256 + (tid & 255)] = acc[j][r];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[j][r] += As[(j * 4 + r) * 256 + tid];
+    }
+    // epilogue: acc[j][r] = out[n = n0 + j*16 + (lane&15)][pixel = m0 + pw*16 + (lane>>4)*4 + r]
     if (ksplit > 1) {
         float* wsp = a.ws + (((size_t)kslice * a.N + img) * a.Cout) * HWo;
 #pragma unroll
@@ -133,7 +157,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             if (n >= a.Cout) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int pp = m0 + wave * 16 + (lane >> 4) * 4 + r;
+                const int pp = m0 + pw * 16 + (lane >> 4) * 4 + r;
                 if (pp < HWo) wsp[(size_t)n * HWo + pp] = acc[j][r];
             }
         }
@@ -147,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const float b = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int pp = m0 + wave * 16 + (lane >> 4) * 4 + r;
+            const int pp = m0 + pw * 16 + (lane >> 4) * 4 + r;
             if (pp < HWo) {
                 float v = acc[j][r] + b;
                 if (a.act == 1) v = 1.0f / (1.0f + __expf(-v));
@@ -191,9 +215,20 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
     }
     a.ksplit = ksplit;
     dim3 grid(mt, nt * ksplit, a.N);
-    if (fn == 1) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1, CK>), grid, dim3(256), 0, s, a);
-    else if (fn == 2) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 2, CK>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 4, CK>), grid, dim3(256), 0, s, a);
+    // 8-wave workgroups while the chip holds at most ~2 workgroups per CU (the serial K walk is the run time then)
+    constexpr bool CAN8 = KS == 3 && CK == 8;   // (K tile of 72: 9 steps per wave group; the A tile is big enough for the exchange)
+    const bool ng2 = CAN8 && (long)mt * nt * ksplit * a.N <= 512 && cdiv(a.Cin, CK) >= 2;
+    if (ng2) {
+        if constexpr (CAN8) {
+            if (fn == 1) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1, CK, 2>), grid, dim3(512), 0, s, a);
+            else if (fn == 2) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 2, CK, 2>), grid, dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 4, CK, 2>), grid, dim3(512), 0, s, a);
+        }
+    } else {
+        if (fn == 1) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1, CK, 1>), grid, dim3(256), 0, s, a);
+        else if (fn == 2) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 2, CK, 1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 4, CK, 1>), grid, dim3(256), 0, s, a);
+    }
     if (ksplit_out) *ksplit_out = ksplit;
     if (ksplit > 1 && !a.defer_reduce) {
         const size_t per = (size_t)a.N * a.Cout * HWo;
