@@ -151,3 +151,99 @@ def test_streams_and_graph_do_not_change_results():
     for p, l in outs[1:]:
         assert torch.equal(l, outs[0][1]), (l, outs[0][1])
         assert torch.equal(p, outs[0][0]), (p - outs[0][0]).abs().max()
+
+
+def test_full_size_step_vs_oracle_and_replay_modes():
+    """BASELINE configs[1] at full size (224x224 pair, ViT-B/8, T = 785): the first step (CLS warm-up regime + the
+    entire-image branch) against the fp32 CPU oracle at identical parameters -- every loss term within 3e-2, whole-arena
+    generator gradient within 5e-2 rel-L2 -- and, as the size-independent property, graph replay == eager single-stream
+    launches bit for bit over 3 steps."""
+    from oracle import dino_vit
+    from oracle.step import SpliceOracle
+    from splice_amd import _lib
+    from splice_amd.engine import SpliceEngine
+    cfg = dict(dino_model_name="dino_vitb8", dino_global_patch_size=224)
+    A, B = synth.smooth_image_pair(123, 0, 224, 224)
+    vit_state = synth.vit_params(7, "dino_vitb8", img_size=224, w_std=0.03)
+    gen_state = synth.generator_params(9, 0.02)
+    eng = SpliceEngine(cfg, vit_state, gen_state, (224, 224), (224, 224))
+    m = dino_vit.VisionTransformer(8, 768, 12, 12, img_size=224).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in vit_state.items()})
+    orc = SpliceOracle(m, {k: torch.from_numpy(v) for k, v in gen_state.items()}, cfg)
+    At, Bt = torch.from_numpy(A), torch.from_numpy(B)
+    Ad, Bd = At.to(DEV), Bt.to(DEV)
+    lo, _, og = orc.step(At[None], Bt[None], At[None])
+    eng.step(Ad, Bd, Ad)
+    le = eng.losses()
+    assert set(le) == set(lo)
+    for k in lo:
+        assert abs(le[k] - lo[k]) / abs(lo[k]) < 3e-2, (k, le[k], lo[k])
+    num = den = 0.0
+    for (name, gt), go in zip(eng.gen.unflatten(eng.grads).items(), og):
+        if name.endswith("0.bias") and name != "9.0.bias":   # conv biases feeding a BatchNorm: analytically zero
+            continue
+        d = (gt.cpu().double() - go.reshape(-1).double()).norm().item()
+        num, den = num + d * d, den + go.double().norm().item() ** 2
+    assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
+    # replay modes at full size
+    ref = None
+    for graph, overlap in ((1, 1), (0, 0)):
+        e2 = SpliceEngine(cfg, None, gen_state, (224, 224), (224, 224), vit_engine=eng.vit)
+        _lib.check(_lib.lib().splice_step_use_graph(e2.handle, graph))
+        _lib.check(_lib.lib().splice_step_use_overlap(e2.handle, overlap))
+        for _ in range(3):
+            e2.step(Ad, Bd, Ad)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = e2.params.clone()
+        else:
+            assert torch.equal(e2.params, ref)
+        del e2
+
+
+def test_large_size_step_replay_modes_and_vit_parity():
+    """BASELINE configs[3] (448x448 pair, ViT-B/8, T = 3137): the long-sequence kernel variants (32 queries per wave,
+    separate dQ / dK-dV launches, 128-wide GEMM tiles, interpolated position table).  Size-independent properties:
+    graph replay == eager single-stream launches bit for bit; losses finite and decreasing over the CLS warm-up; and the
+    layer-11 keys of the generated image against the fp32 oracle ViT on the same pixels (2e-2 rel-L2)."""
+    from oracle import dino_vit
+    from oracle import extractor as oext
+    from splice_amd import _lib
+    from splice_amd.engine import SpliceEngine
+    from splice_amd.vit import KIND_QKV_LAST_F32
+    cfg = dict(dino_model_name="dino_vitb8", dino_global_patch_size=448, entire_A_every=10 ** 9)
+    A, B = synth.smooth_image_pair(321, 0, 448, 448)
+    vit_state = synth.vit_params(7, "dino_vitb8", img_size=224, w_std=0.03)
+    gen_state = synth.generator_params(9, 0.02)
+    Ad, Bd = torch.from_numpy(A).to(DEV), torch.from_numpy(B).to(DEV)
+    ref, vit = None, None
+    for graph, overlap in ((1, 1), (0, 0)):
+        eng = SpliceEngine(cfg, vit_state if vit is None else None, gen_state, (448, 448), None, vit_engine=vit)
+        vit = eng.vit
+        _lib.check(_lib.lib().splice_step_use_graph(eng.handle, graph))
+        _lib.check(_lib.lib().splice_step_use_overlap(eng.handle, overlap))
+        ls = []
+        for _ in range(3):
+            eng.step(Ad, Bd, None)
+            ls.append(eng.losses()["loss"])
+        torch.cuda.synchronize()
+        assert all(np.isfinite(ls)) and ls[2] < ls[0]
+        if ref is None:
+            ref = eng.params.clone()
+            # keys of pass 2 (x' = G(A)) of the last forward vs the oracle ViT applied to the same generated image
+            x = eng.generate(Ad[None])   # parameters AFTER the 3rd update: compare on a fresh forward of both sides
+            ctx = vit.context(1, 448, 448, need_grad=False)
+            ctx.forward(x, normalize=True)
+            qkv = ctx.read(KIND_QKV_LAST_F32, 11)[0, : ctx.T].cpu()
+            m = dino_vit.VisionTransformer(8, 768, 12, 12, img_size=224).eval()
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in vit_state.items()})
+            mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+            std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+            with torch.no_grad():
+                k_ref = oext.keys_from_input(m, (x.cpu() - mean) / std, 11)          # [h, T, d]
+            k_got = qkv[:, 768:1536].reshape(ctx.T, 12, 64).permute(1, 0, 2)
+            rel = ((k_got.double() - k_ref.double()).norm() / k_ref.double().norm()).item()
+            assert rel < 2e-2, rel
+        else:
+            assert torch.equal(eng.params, ref)
+        del eng
