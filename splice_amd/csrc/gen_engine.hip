@@ -311,7 +311,7 @@ int splice_gen_plan_create(void* h, int N, int H, int W, int need_grad, void** o
     build_table(tmp, offs, head);
     p->head_w = head[0]; p->head_b = head[1];
     int rc = SPLICE_OK;
-    auto fail = [&]() { for (void* q : p->allocs) hipFree(q); delete p; return rc; };
+    auto fail = [&]() { for (void* q : p->allocs) (void)hipFree(q); delete p; return rc; };
     size_t ws_need = 0;
     for (int i = 0; i < 5 && rc == SPLICE_OK; ++i) {
         const int cin = i == 0 ? 3 : DOWN[i - 1];
@@ -380,7 +380,7 @@ int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams)
 void splice_gen_plan_destroy(void* plan) {
     SpliceGenPlan* p = (SpliceGenPlan*)plan;
     if (!p) return;
-    for (void* q : p->allocs) hipFree(q);
+    for (void* q : p->allocs) (void)hipFree(q);
     delete p;
 }
 

@@ -208,7 +208,7 @@ int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void
     st->max_crop_h = cfg->crop_h; st->max_crop_w = cfg->crop_w;
     st->cropb_h = st->max_cropb_h = cfg->crop_h; st->cropb_w = st->max_cropb_w = cfg->crop_w;
     int rc = SPLICE_OK;
-    auto fail = [&](int code) { for (void* q : st->allocs) hipFree(q); delete st; return code; };
+    auto fail = [&](int code) { for (void* q : st->allocs) (void)hipFree(q); delete st; return code; };
     if ((rc = view_init(st, st->vg, vit_ctx_global, 4)) != SPLICE_OK) return fail(rc);
     if (st->vg.H != cfg->vit_h || st->vg.W != cfg->vit_w) { splice_set_error("splice_step_create: global ViT context shape mismatch"); return fail(SPLICE_ERR_ARG); }
     int n, h, w;

@@ -163,7 +163,7 @@ int splice_vit_create(int patch, int dim, int depth, int heads, void** out) {
     }
     SpliceVit* v = new SpliceVit();
     v->patch = patch; v->dim = dim; v->depth = depth; v->heads = heads; v->hidden = 4 * dim;
-    hipGetDevice(&v->device);
+    (void)hipGetDevice(&v->device);
     v->layers.resize(depth);
     *out = v;
     return SPLICE_OK;
@@ -172,7 +172,7 @@ int splice_vit_create(int patch, int dim, int depth, int heads, void** out) {
 void splice_vit_destroy(void* h) {
     SpliceVit* v = (SpliceVit*)h;
     if (!v) return;
-    for (void* p : v->allocs) hipFree(p);
+    for (void* p : v->allocs) (void)hipFree(p);
     delete v;
 }
 
@@ -293,7 +293,7 @@ int splice_vit_ctx_create(void* h, int B, int H, int W, const float* pos_TD, int
     }
 #undef A
     if (rc != SPLICE_OK) {
-        for (void* q : c->allocs) hipFree(q);
+        for (void* q : c->allocs) (void)hipFree(q);
         delete c;
         return rc;
     }
@@ -305,7 +305,7 @@ int splice_vit_ctx_create(void* h, int B, int H, int W, const float* pos_TD, int
 void splice_vit_ctx_destroy(void* ctx) {
     SpliceVitCtx* c = (SpliceVitCtx*)ctx;
     if (!c) return;
-    for (void* p : c->allocs) hipFree(p);
+    for (void* p : c->allocs) (void)hipFree(p);
     delete c;
 }
 
