@@ -704,8 +704,27 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
         }
     }
 }
-// one workgroup per channel walks the images in order (dgamma / dbeta sum over images deterministically); each plane is
-// read once and kept in registers between the reduction and the apply pass
+// one workgroup per (channel, image); each plane is read once and kept in registers between the reduction and the apply
+// pass.  dgamma / dbeta need the sums of EVERY image: the workgroup of image 0 recomputes the other images' two sums
+// (reads only) and adds them in image order -- deterministic, no second launch, no cross-workgroup wait.
+__device__ __forceinline__ void bn_small_bwd_sums(const float* pd, const float* pa, const float* py, int HW, float m, float r, float slope,
+                                                  float (&dz)[BN_SMALL_PER], float (&xh)[BN_SMALL_PER], float& s1, float& s2, float* red) {
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; ++k) {
+        const int i = threadIdx.x + k * 256;
+        float d = 0.f, x = 0.f;
+        if (i < HW) {
+            d = pd[i];
+            if (slope != 1.0f && !(pa[i] > 0.f)) d *= slope;
+            x = (py[i] - m) * r;
+        }
+        dz[k] = d; xh[k] = x;
+        s1 += d;
+        s2 += d * x;
+    }
+    block_sum2(s1, s2, red);
+}
 __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ da, size_t da_nstride, const float* __restrict__ aout,
                                                            size_t a_nstride, const float* __restrict__ y, size_t y_nstride,
                                                            float* __restrict__ dy, size_t dy_nstride, int C, int HW, int N,
@@ -713,39 +732,30 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
                                                            const float* __restrict__ rstd, float slope, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int accumulate) {
     __shared__ float red[8];
-    const int c = blockIdx.x;
-    float g = 0.f, be = 0.f;
-    for (int img = 0; img < N; ++img) {
+    const int c = blockIdx.x, img = blockIdx.y;
+    float dz[BN_SMALL_PER], xh[BN_SMALL_PER];
+    float s1, s2;
+    {
         const float m = mean[img * C + c], r = rstd[img * C + c];
-        const float* pd = da + (size_t)img * da_nstride + (size_t)c * HW;
-        const float* pa = aout + (size_t)img * a_nstride + (size_t)c * HW;
-        const float* py = y + (size_t)img * y_nstride + (size_t)c * HW;
-        float* po = dy + (size_t)img * dy_nstride + (size_t)c * HW;
-        float dz[BN_SMALL_PER], xh[BN_SMALL_PER];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < BN_SMALL_PER; ++k) {
-            const int i = threadIdx.x + k * 256;
-            float d = 0.f, x = 0.f;
-            if (i < HW) {
-                d = pd[i];
-                if (slope != 1.0f && !(pa[i] > 0.f)) d *= slope;
-                x = (py[i] - m) * r;
-            }
-            dz[k] = d; xh[k] = x;
-            s1 += d;
-            s2 += d * x;
-        }
-        block_sum2(s1, s2, red);
-        be += s1;
-        g += s2;
+        bn_small_bwd_sums(da + (size_t)img * da_nstride + (size_t)c * HW, aout + (size_t)img * a_nstride + (size_t)c * HW,
+                          y + (size_t)img * y_nstride + (size_t)c * HW, HW, m, r, slope, dz, xh, s1, s2, red);
         const float k1 = s1 / (float)HW, k2 = s2 / (float)HW;
         const float gr = gamma[c] * r;
+        float* po = dy + (size_t)img * dy_nstride + (size_t)c * HW;
 #pragma unroll
         for (int k = 0; k < BN_SMALL_PER; ++k) {
             const int i = threadIdx.x + k * 256;
             if (i < HW) po[i] = gr * (dz[k] - k1 - xh[k] * k2);
         }
+    }
+    if (img != 0) return;
+    float g = s2, be = s1;
+    for (int n = 1; n < N; ++n) {
+        float t1, t2;
+        bn_small_bwd_sums(da + (size_t)n * da_nstride + (size_t)c * HW, aout + (size_t)n * a_nstride + (size_t)c * HW,
+                          y + (size_t)n * y_nstride + (size_t)c * HW, HW, mean[n * C + c], rstd[n * C + c], slope, dz, xh, t1, t2, red);
+        be += t1;
+        g += t2;
     }
     if (threadIdx.x == 0) {
         dgamma[c] = accumulate ? dgamma[c] + g : g;
@@ -779,7 +789,7 @@ int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t 
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
                   float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s) {
     if (HW <= BN_SMALL_HW) {
-        hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(C), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy, dy_nstride, C, HW, N,
+        hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy, dy_nstride, C, HW, N,
                            gamma, mean, rstd, slope, dgamma, dbeta, accumulate);
         return SPLICE_OK;
     }
