@@ -838,6 +838,15 @@ __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __rest
         q[i] = top * (1.f - ly) + bot * ly;
     }
 }
+__device__ __forceinline__ void up_adjoint_weights(int m, int n, int No, float (&wt)[4]) {
+    wt[0] = m > 0 ? 0.25f : 0.f;                  // o = 2m-1 (odd output of input m-1, upper neighbour = m)
+    wt[1] = m > 0 ? 0.75f : 1.0f;                 // o = 2m   (source m - 1/4, clamped to 0 at the border)
+    wt[2] = m < n - 1 ? 0.75f : 1.0f;             // o = 2m+1 (source m + 1/4, upper neighbour clamped to n-1)
+    wt[3] = m < n - 1 ? 0.25f : 0.f;              // o = 2m+2 (even output of input m+1, lower neighbour = m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (2 * m - 1 + t >= No) wt[t] = 0.f;
+}
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dout, size_t dout_nstride, float* __restrict__ din,
                                                              size_t din_nstride, int C, int h, int w, int Ho, int Wo) {
     const int c = blockIdx.y, img = blockIdx.z;
@@ -845,24 +854,12 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
     float* q = din + (size_t)img * din_nstride + (size_t)c * h * w;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < h * w; i += gridDim.x * 256) {
         const int my = i / w, mx = i % w;
+        // adjoint weights of the x2 bilinear (align_corners=False) in closed form: output o = 2m-1+t, t = 0..3, reads input m
+        // with weight {1/4, 3/4, 3/4, 1/4}; at the borders the clamped source index folds the missing neighbour's share
+        // in (o = 0 and o = 2n-1 read their input pixel with weight 1), and outputs outside the Ho x Wo window do not exist
         float wy[4], wx[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int oy = 2 * my - 1 + t, ox = 2 * mx - 1 + t;
-            wy[t] = 0.f; wx[t] = 0.f;
-            if (oy >= 0 && oy < Ho) {
-                int a0, a1; float l;
-                up_coord(oy, h, a0, a1, l);
-                if (a0 == my) wy[t] += 1.f - l;
-                if (a1 == my) wy[t] += l;
-            }
-            if (ox >= 0 && ox < Wo) {
-                int a0, a1; float l;
-                up_coord(ox, w, a0, a1, l);
-                if (a0 == mx) wx[t] += 1.f - l;
-                if (a1 == mx) wx[t] += l;
-            }
-        }
+        up_adjoint_weights(my, h, Ho, wy);
+        up_adjoint_weights(mx, w, Wo, wx);
         float acc = 0.f;
 #pragma unroll
         for (int ty = 0; ty < 4; ++ty) {
