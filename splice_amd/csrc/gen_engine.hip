@@ -84,7 +84,7 @@ struct SpliceGenPlan {
     size_t conv_ws_floats = 0;
     size_t head_wg_off = 0;
     WgradReduceAll red;                   // filled during a backward, consumed by its single reduce launch
-    WgradBatch wg;                        // every layer's weight-gradient work of a backward: one launch after the dgrad chain
+    WgradBatchPair wg;                    // every layer's weight-gradient work of a backward: launched after the dgrad chain
     float* out_copy = nullptr;            // generator output kept for the sigmoid backward
     float* x_copy = nullptr;              // private copy of the input (the caller may free x after forward)
     int forward_saved = 0;
@@ -454,7 +454,8 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
     hipStream_t s = (hipStream_t)stream;
     const size_t npix = (size_t)p->N * 3 * p->H * p->W;
     p->red.count = 0;
-    p->wg.count = 0; p->wg.total_wgs = 0;
+    p->wg.small.count = p->wg.small.total_wgs = 0;
+    p->wg.big.count = p->wg.big.total_wgs = 0;
     const Unit& u = p->u_up1[0];
     const int HW = p->H * p->W;
     (void)npix;

@@ -40,8 +40,9 @@ struct WgradDesc {           // compact per-layer descriptor of the batched weig
     uint32_t wg_begin, chunks;
 };
 struct WgradBatch { int count; int total_wgs; WgradDesc d[WGRAD_BATCH_MAX]; };   // by-value kernel argument
-int conv_wgrad_add(WgradBatch* b, WgradArgs a, int* chunks_out);       // queue one layer; partials go to a.ws
-int conv_wgrad_batched_launch(const WgradBatch& b, hipStream_t s);     // one launch for every queued layer
+struct WgradBatchPair { WgradBatch small, big; };   // layers with <= 32 / > 32 output channels (different kernel occupancy)
+int conv_wgrad_add(WgradBatchPair* b, WgradArgs a, int* chunks_out);       // queue one layer; partials go to a.ws
+int conv_wgrad_batched_launch(const WgradBatchPair& b, hipStream_t s);     // one launch per class for every queued layer
 
 constexpr int WGRAD_MAX_LAYERS = 64;   // 26 conv weights + 25 exact-zero bias ranges (chunks == 0)
 struct WgradReduceAll {      // by-value kernel argument: one entry per conv layer of a backward

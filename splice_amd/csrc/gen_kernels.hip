@@ -405,9 +405,13 @@ int wgrad_chunks(int N, int Ho, int Wo, int* pix_per_chunk, int* chunks_per_img)
 // serial kernels the workgroups of all layers fill the chip together.  Workgroup -> (layer, pixel chunk, channel tile)
 // through the prefix table of the by-value descriptor array; the (filter size, output-channel fragments) variant is a
 // workgroup-uniform switch.
+// Two instantiations: BIG = false runs the layers with <= 32 output channels (1 or 2 fragments: ~60 VGPRs, 21 KB of LDS,
+// several workgroups per CU -- these are the layers with thousands of workgroups), BIG = true the 64 / 128-channel ones
+// (up to 229 VGPRs).  One kernel for everything ran the small layers at the big variant's occupancy.
+template <bool BIG>
 __global__ __launch_bounds__(256) void conv_wgrad_batched_kernel(WgradBatch b) {
     __shared__ float Xs[WG_XS_FLOATS];
-    __shared__ float Ds[WG_DS_FLOATS];
+    __shared__ float Ds[(BIG ? 8 : 2) * 16 * WG_LD];
     int l = 0;
 #pragma unroll 1
     while (l + 1 < b.count && blockIdx.x >= b.d[l + 1].wg_begin) ++l;
@@ -419,20 +423,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_batched_kernel(WgradBatch b) {
     a.ks = d.ks; a.stride = d.stride; a.pad = d.pad; a.pix_per_chunk = d.pix_per_chunk; a.chunks_per_img = d.chunks_per_img;
     const int local = blockIdx.x - d.wg_begin;
     const int chunk = local % d.chunks, ktile = local / d.chunks;
-    switch (d.variant) {
-        case 0: conv_wgrad_body<1, 1>(a, chunk, ktile, Xs, Ds); break;
-        case 1: conv_wgrad_body<1, 2>(a, chunk, ktile, Xs, Ds); break;
-        case 2: conv_wgrad_body<1, 4>(a, chunk, ktile, Xs, Ds); break;
-        case 3: conv_wgrad_body<1, 8>(a, chunk, ktile, Xs, Ds); break;
-        case 4: conv_wgrad_body<3, 1>(a, chunk, ktile, Xs, Ds); break;
-        case 5: conv_wgrad_body<3, 2>(a, chunk, ktile, Xs, Ds); break;
-        case 6: conv_wgrad_body<3, 4>(a, chunk, ktile, Xs, Ds); break;
-        default: conv_wgrad_body<3, 8>(a, chunk, ktile, Xs, Ds); break;
+    if (BIG) {
+        switch (d.variant) {
+            case 2: conv_wgrad_body<1, 4>(a, chunk, ktile, Xs, Ds); break;
+            case 3: conv_wgrad_body<1, 8>(a, chunk, ktile, Xs, Ds); break;
+            case 6: conv_wgrad_body<3, 4>(a, chunk, ktile, Xs, Ds); break;
+            default: conv_wgrad_body<3, 8>(a, chunk, ktile, Xs, Ds); break;
+        }
+    } else {
+        switch (d.variant) {
+            case 0: conv_wgrad_body<1, 1>(a, chunk, ktile, Xs, Ds); break;
+            case 1: conv_wgrad_body<1, 2>(a, chunk, ktile, Xs, Ds); break;
+            case 4: conv_wgrad_body<3, 1>(a, chunk, ktile, Xs, Ds); break;
+            default: conv_wgrad_body<3, 2>(a, chunk, ktile, Xs, Ds); break;
+        }
     }
 }
 
 // append one layer to a batch (partial sums only: ws gets chunks * Cout*Cin*ks*ks floats); returns the number of chunks
-int conv_wgrad_add(WgradBatch* b, WgradArgs a, int* chunks_out) {
+int conv_wgrad_add(WgradBatchPair* pair, WgradArgs a, int* chunks_out) {
+    WgradBatch* b = a.Cout > 32 ? &pair->big : &pair->small;
     if (a.Cout > 128 || (a.ks != 1 && a.ks != 3) || b->count >= WGRAD_BATCH_MAX) return SPLICE_ERR_ARG;
     if ((size_t)a.Cin * a.x_cstride > 0x7fffffffULL || a.x_nstride > 0xffffffffULL || a.dy_nstride > 0xffffffffULL) return SPLICE_ERR_ARG;
     if (a.Hi > 65535 || a.Wi > 65535 || a.Cin > 65535) return SPLICE_ERR_ARG;
@@ -452,9 +462,9 @@ int conv_wgrad_add(WgradBatch* b, WgradArgs a, int* chunks_out) {
     if (chunks_out) *chunks_out = chunks;
     return SPLICE_OK;
 }
-int conv_wgrad_batched_launch(const WgradBatch& b, hipStream_t s) {
-    if (b.count < 1) return SPLICE_OK;
-    hipLaunchKernelGGL(conv_wgrad_batched_kernel, dim3((unsigned)b.total_wgs), dim3(256), 0, s, b);
+int conv_wgrad_batched_launch(const WgradBatchPair& p, hipStream_t s) {
+    if (p.big.count > 0) hipLaunchKernelGGL(conv_wgrad_batched_kernel<true>, dim3((unsigned)p.big.total_wgs), dim3(256), 0, s, p.big);
+    if (p.small.count > 0) hipLaunchKernelGGL(conv_wgrad_batched_kernel<false>, dim3((unsigned)p.small.total_wgs), dim3(256), 0, s, p.small);
     return SPLICE_OK;
 }
 
