@@ -672,16 +672,20 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
         float* yo = y_out + (size_t)img * y_nstride + (size_t)c * HW;
         const float b = bias ? bias[c] : 0.f;
 #pragma unroll
+        for (int k = 0; k < BN_SMALL_PER; ++k) v[k] = threadIdx.x + k * 256 < HW ? b : 0.f;
+        for (int ks = 0; ks < ksplit; ++ks) {   // slice order (as conv_splitk_reduce_kernel); 16 independent loads in flight per slice
+            const float* sk = sp + (size_t)ks * per;
+#pragma unroll
+            for (int k = 0; k < BN_SMALL_PER; ++k) {
+                const int i = threadIdx.x + k * 256;
+                if (i < HW) v[k] += sk[i];
+            }
+        }
+#pragma unroll
         for (int k = 0; k < BN_SMALL_PER; ++k) {
             const int i = threadIdx.x + k * 256;
-            float t = 0.f;
-            if (i < HW) {
-                t = b;
-                for (int ks = 0; ks < ksplit; ++ks) t += sp[(size_t)ks * per + i];
-                yo[i] = t;
-            }
-            v[k] = t;
-            s += t;
+            if (i < HW) yo[i] = v[k];
+            s += v[k];
         }
     } else {
 #pragma unroll
