@@ -93,6 +93,8 @@ struct SpliceStep {
     std::map<int, hipGraphExec_t> graphs;
     void* graph_ptrs[4] = {nullptr, nullptr, nullptr, nullptr};
     int graph_crops[4] = {0, 0, 0, 0};
+    float* grads_b = nullptr;                        // split crops: gradient arena of the B-crop plan (added to `grads` before Adam)
+    hipEvent_t ev_gb = nullptr;                      // split crops: G(B_crop) finished on the side stream
     int shape_repeats = 0;                           // consecutive steps with the same arenas and crop sizes
     int use_graph = 1;
     int dbg_sync = 0, dbg_own_eager = 0;
@@ -252,6 +254,7 @@ int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void
         hipStreamCreateWithFlags(&st->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&st->ev_gb, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&st->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&st->ev_out, hipEventDisableTiming) != hipSuccess) {
         splice_set_error("splice_step_create: stream/event creation failed");
@@ -269,6 +272,7 @@ void splice_step_destroy(void* h) {
     if (st->side_stream) { (void)hipStreamSynchronize(st->side_stream); (void)hipStreamDestroy(st->side_stream); }
     if (st->ev_fork) (void)hipEventDestroy(st->ev_fork);
     if (st->ev_join) (void)hipEventDestroy(st->ev_join);
+    if (st->ev_gb) (void)hipEventDestroy(st->ev_gb);
     if (st->ev_in) (void)hipEventDestroy(st->ev_in);
     if (st->ev_out) (void)hipEventDestroy(st->ev_out);
     for (void* q : st->allocs) (void)hipFree(q);
@@ -292,13 +296,17 @@ int splice_step_set_crop(void* h, int crop_h, int crop_w) {
     if (!st) return SPLICE_ERR_ARG;
     if (crop_h > st->max_crop_h || crop_w > st->max_crop_w) { splice_set_error("splice_step_set_crop: larger than the creation size"); return SPLICE_ERR_ARG; }
     RC(splice_gen_plan_resize(st->plan_g, crop_h, crop_w));
+    if (st->plan_a) RC(splice_gen_plan_resize(st->plan_a, crop_h, crop_w));
+    if (st->plan_b) RC(splice_gen_plan_resize(st->plan_b, crop_h, crop_w));
     st->cfg.crop_h = st->cropb_h = crop_h;
     st->cfg.crop_w = st->cropb_w = crop_w;
     return SPLICE_OK;
 }
 
-// Independent crop sizes for the structure and the appearance image (the reference draws them
-// separately, data/Dataset.py:66-67): needs the two N=1 plans given here (created for the maxima).
+// Two N=1 generator plans (created for the maximum crop size).  Required for independent crop sizes of the structure and
+// the appearance image (the reference draws them separately, data/Dataset.py:66-67) -- and, once attached, used for EQUAL
+// sizes too: G(A_crop) and G(B_crop) then form two independent chains (forward beside each other, each backward chain
+// continuing into its own plan), which measured faster than the batched N=2 plan (4.75 vs 4.84 ms/step).
 int splice_step_attach_split_plans(void* h, void* plan_a, void* plan_b) {
     SpliceStep* st = (SpliceStep*)h;
     if (!st || !plan_a || !plan_b) return SPLICE_ERR_ARG;
@@ -312,6 +320,7 @@ int splice_step_attach_split_plans(void* h, void* plan_a, void* plan_b) {
         return SPLICE_ERR_ARG;
     }
     st->plan_a = plan_a; st->plan_b = plan_b;
+    if (!st->grads_b) RC(salloc(st, &st->grads_b, (size_t)st->nparams));
     return SPLICE_OK;
 }
 int splice_step_set_crops(void* h, int a_h, int a_w, int b_h, int b_w) {
@@ -348,6 +357,12 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         HIPCHK(hipStreamWaitEvent(s2, st->ev_fork, 0));
     }
     // global_transform (Resize -> Normalize; the Normalize is fused into the ViT patch gather)
+    // unequal crop sizes (random crops): the generator runs as two N=1 plans; G(B_crop) goes first on the side stream so
+    // that it runs beside G(A_crop) instead of behind it
+    if (split && !(st->ablate & 1)) {
+        RC(splice_gen_forward(st->plan_b, params, B_crop, st->gen_out + crop, s2));
+        if (overlap) HIPCHK(hipEventRecord(st->ev_gb, s2));
+    }
     RC(place_image(A_crop, c.crop_h, c.crop_w, vg.imgs + 0 * vimg, vg.H, vg.W, s2));
     RC(place_image(B_crop, st->cropb_h, st->cropb_w, vg.imgs + 1 * vimg, vg.H, vg.W, s2));
     if (!(st->ablate & 8)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, 2, 0, 2, s2));
@@ -370,7 +385,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         RC(splice_gen_forward(st->plan_g, params, st->gen_in, st->gen_out, s));
     } else {
         RC(splice_gen_forward(st->plan_a, params, A_crop, st->gen_out, s));
-        RC(splice_gen_forward(st->plan_b, params, B_crop, st->gen_out + crop, s));
+        if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_gb, 0));
     }
     RC(place_image(st->gen_out, c.crop_h, c.crop_w, vg.imgs + 2 * vimg, vg.H, vg.W, s));
     RC(place_image(st->gen_out + crop, st->cropb_h, st->cropb_w, vg.imgs + 3 * vimg, vg.H, vg.W, s));
@@ -412,18 +427,16 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         }
         if (!(st->ablate & 32)) RC(splice_vit_backward(vg.ctx, 3, 4, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s2));
         RC(unplace_grad(vg.d_imgs + 3 * vimg, vg.H, vg.W, st->d_gen_out + crop, st->cropb_h, st->cropb_w, s2));
+        // split crops: each chain continues into its own generator plan (own gradient arena: no cross-chain accumulation)
+        if (split && !(st->ablate & 2)) RC(splice_gen_backward(st->plan_b, params, st->d_gen_out + crop, st->grads_b, 0, s2));
         if (overlap) HIPCHK(hipEventRecord(st->ev_join, s2));
         RC(splice_vit_backward(vg.ctx, 2, 3, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
         RC(unplace_grad(vg.d_imgs + 2 * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, s));
+        if (split && !(st->ablate & 2)) RC(splice_gen_backward(st->plan_a, params, st->d_gen_out, grads, 0, s));
         if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
+        if (split && !(st->ablate & 2)) RC(add_f32_launch(grads, st->grads_b, (size_t)st->nparams, s));   // grads = g(A) + g(B)
     }
-    if (st->ablate & 2) {
-    } else if (!split) {
-        RC(splice_gen_backward(st->plan_g, params, st->d_gen_out, grads, 0, s));
-    } else {
-        RC(splice_gen_backward(st->plan_a, params, st->d_gen_out, grads, 0, s));
-        RC(splice_gen_backward(st->plan_b, params, st->d_gen_out + crop, grads, 1, s));
-    }
+    if (!split && !(st->ablate & 2)) RC(splice_gen_backward(st->plan_g, params, st->d_gen_out, grads, 0, s));
     if (entire) {
         VitView& ve = st->ve;
         const size_t eimg = (size_t)3 * ve.H * ve.W;
@@ -463,7 +476,9 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
     if (step_idx == c.cls_warmup) st->ssim_id_on = 1;
     const bool entire = c.ent_h > 0 && c.entire_every > 0 && (step_idx % c.entire_every == 0);
     if (entire && !A_entire) { splice_set_error("splice_step_run: step %d needs the entire structure image", step_idx); return SPLICE_ERR_ARG; }
-    const bool split = c.crop_h != st->cropb_h || c.crop_w != st->cropb_w;
+    const bool unequal = c.crop_h != st->cropb_h || c.crop_w != st->cropb_w;
+    if (unequal && !(st->plan_a && st->plan_b)) { splice_set_error("splice_step_run: different A/B crop sizes need splice_step_attach_split_plans"); return SPLICE_ERR_STATE; }
+    const bool split = st->plan_a && st->plan_b;   // two per-image generator chains whenever the N=1 plans exist
     // Graphs pay off only while the launch sequence repeats: with random crop sizes (data/transforms.py:21) nearly every
     // step has new shapes, and re-capturing + instantiating ~600 nodes costs as much as the step itself (9.9 vs 5.8 ms
     // measured).  So a step whose arenas / crop sizes differ from the previous step's runs eagerly (same kernels, same

@@ -84,7 +84,12 @@ class SpliceEngine:
         self.losses_dev = torch.zeros(8, device=self.device)
         self.step_idx = -1  # data/Dataset.py:57 -- the first step is 0
         self._cur_crops = (ch, cw, ch, cw)
-        self._split_plans = None
+        # two N=1 plans: independent A / B crop sizes (data/Dataset.py:66-67) and, also for equal sizes, two per-image
+        # generator chains that run beside each other (faster than the batched N=2 plan)
+        # (private plan objects: the shape-keyed plan cache could hand out the entire-image plan of the same size)
+        self._split_plans = (GeneratorPlanAlias(self.gen, (ch, cw)), GeneratorPlanAlias(self.gen, (ch, cw)))
+        _lib.check(_lib.lib().splice_step_attach_split_plans(self.handle, self._split_plans[0].handle, self._split_plans[1].handle),
+                   "step_attach_split_plans")
 
     def __del__(self):
         try:
@@ -103,11 +108,6 @@ class SpliceEngine:
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
         crops = tuple(A_crop.shape[-2:]) + tuple(B_crop.shape[-2:])
         if crops != self._cur_crops:   # per-step random crop sizes (data/transforms.py:21-22)
-            if crops[:2] != crops[2:] and self._split_plans is None:
-                self._split_plans = (self.gen.plan(1, self.crop_hw[0], self.crop_hw[1], need_grad=True),
-                                     GeneratorPlanAlias(self.gen, self.crop_hw))
-                _lib.check(_lib.lib().splice_step_attach_split_plans(self.handle, self._split_plans[0].handle,
-                                                                      self._split_plans[1].handle), "step_attach_split_plans")
             _lib.check(_lib.lib().splice_step_set_crops(self.handle, *crops), "step_set_crops")
             self._cur_crops = crops
         if A_entire is not None:
