@@ -108,6 +108,13 @@ int splice_attention_bwd(const splice_bf16* qkv, const splice_bf16* qkvT, int ld
 int splice_attention_probs(const splice_bf16* qkv, int B, int T, int Tld, int D, int H, float scale,
                            const float* lse, float* probs, splice_stream_t stream);
 
+/* dino_structure_transforms (data/transforms.py:30-37) on a device image fp32 [3][H][W] in [0,1]: horizontal flip,
+ * ColorJitter (order[k] in {0 brightness, 1 contrast, 2 saturation, 3 hue}: the op order of this draw, n_ops = 0 for
+ * none; factors[4] indexed by op) and GaussianBlur(3) (blur_sigma <= 0 for none); torchvision-0.10 tensor arithmetic.
+ * out != img; scratch >= 3*H*W + 256 floats.  Replaces the per-step PIL pipeline of data/Dataset.py:62-70. */
+int splice_augment_structure(const float* img, float* out, float* scratch, int H, int W, int flip, int n_ops, const int* order,
+                             const float* factors, float blur_sigma, splice_stream_t stream);
+
 /* attn_cosine_sim (models/extractor.py:4-9) on K fp32 [T][ldk] (D columns): S fp32 [T][T].
  * `ws` is caller scratch of splice_keys_selfsim_ws_bytes(T, D) bytes; the backward needs the
  * state the forward left in it. */

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "splice_attention_fwd": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
     "splice_attention_bwd": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "splice_attention_probs": ([_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
+    "splice_augment_structure": ([_vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_float), _f, _vp], _i),
     "splice_keys_selfsim_ws_bytes": ([_i, _i], _sz),
     "splice_keys_selfsim_fwd": ([_vp, _i, _i, _i, _f, _vp, _vp, _vp], _i),
     "splice_keys_selfsim_bwd": ([_vp, _vp, _i, _i, _f, _vp, _i, _i, _vp, _vp], _i),

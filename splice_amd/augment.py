@@ -10,9 +10,11 @@
 followed by ``Global_crops`` (``data/transforms.py:7-27``): one random square crop whose side is
 ``round(U(min_cover*h, h))`` clipped to the width.  The reference runs these on PIL images on the host every
 step (``data/Dataset.py:62-70``, serial with the optimisation step); here the image stays on the GPU as a
-``[3,H,W]`` float tensor in [0,1] and the same operations run as tensor ops on it (torchvision-0.10's own tensor
-code path: ``functional_tensor.adjust_*``, ``gaussian_blur``), in the reference's order -- the whole image is
-augmented, THEN cropped, so ColorJitter's contrast uses the mean of the whole image.
+``[3,H,W]`` float tensor in [0,1] and the same operations run on it (torchvision-0.10's own tensor code path:
+``functional_tensor.adjust_*``, ``gaussian_blur``): as HIP kernels when the image is on the GPU
+(``splice_augment_structure``, the whole structure pipeline in at most three launches), as the torch ops below
+otherwise.  The reference's order is kept: the whole image is augmented, THEN cropped, so ColorJitter's contrast uses
+the mean of the whole image.
 
 Random draws are made in the order torchvision makes them (``torch.rand`` for the flips and ``RandomApply``,
 ``randperm`` + four ``uniform_`` for ColorJitter, ``uniform_`` for the blur sigma, ``np.random.uniform`` for the crop
@@ -126,17 +128,60 @@ def gaussian_blur3(img, sigma):
     return torch.nn.functional.conv2d(x, k2, groups=3)[0]
 
 
-def structure_transforms(img):
-    """dino_structure_transforms on a [3,H,W] tensor (whole image)."""
-    if torch.rand(1) < FLIP_P:
-        img = img.flip(-1)
+def draw_structure_params():
+    """One draw of dino_structure_transforms' random decisions, in torchvision's call order:
+    (flip, (order, factors) or None, sigma or None)."""
+    flip = bool(torch.rand(1) < FLIP_P)
+    jitter = None
     if not (JITTER_P < torch.rand(1)):
-        order, factors = color_jitter_params()
-        img = color_jitter(img, order, factors)
+        jitter = color_jitter_params()
+    sigma = None
     if not (BLUR_P < torch.rand(1)):
         sigma = float(torch.empty(1).uniform_(*BLUR_SIGMA))
+    return flip, jitter, sigma
+
+
+def apply_structure_torch(img, flip, jitter, sigma):
+    """Reference implementation with torch ops (any device)."""
+    if flip:
+        img = img.flip(-1)
+    if jitter is not None:
+        img = color_jitter(img, *jitter)
+    if sigma is not None:
         img = gaussian_blur3(img, sigma)
     return img
+
+
+_scratch = {}
+
+
+def apply_structure_hip(img, flip, jitter, sigma):
+    """The same on the HIP kernels (splice_augment_structure): at most three launches for the whole pipeline."""
+    import ctypes as C
+    from . import _lib
+    if not (flip or jitter is not None or sigma is not None):
+        return img
+    img = img.contiguous()
+    _, H, W = img.shape
+    key = (img.device, H, W)
+    if key not in _scratch:
+        _scratch[key] = torch.empty(3 * H * W + 256, device=img.device)
+    out = torch.empty_like(img)
+    order, factors = jitter if jitter is not None else ([], (1.0, 1.0, 1.0, 0.0))
+    c_order = (C.c_int * 4)(*(list(order) + [0] * (4 - len(order))))
+    c_fac = (C.c_float * 4)(*factors)
+    _lib.check(_lib.lib().splice_augment_structure(_lib.ptr(img), _lib.ptr(out), _lib.ptr(_scratch[key]), H, W, int(flip), len(order),
+                                                   c_order, c_fac, float(sigma) if sigma is not None else 0.0, _lib.current_stream()),
+               "augment_structure")
+    return out
+
+
+def structure_transforms(img):
+    """dino_structure_transforms on a [3,H,W] float tensor (whole image): HIP kernels on the GPU, torch ops otherwise."""
+    flip, jitter, sigma = draw_structure_params()
+    if img.is_cuda and img.dtype == torch.float32:
+        return apply_structure_hip(img, flip, jitter, sigma)
+    return apply_structure_torch(img, flip, jitter, sigma)
 
 
 def texture_transforms(img):

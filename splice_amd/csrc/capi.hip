@@ -75,6 +75,11 @@ int splice_attention_probs(const splice_bf16* qkv, int B, int T, int Tld, int D,
     return finish(attn_probs_launch(&a, probs, ST(stream)), "splice_attention_probs");
 }
 
+int splice_augment_structure(const float* img, float* out, float* scratch, int H, int W, int flip, int n_ops, const int* order,
+                             const float* factors, float blur_sigma, splice_stream_t stream) {
+    return finish(augment_structure_launch(img, out, scratch, H, W, flip, n_ops, order, factors, blur_sigma, ST(stream)), "splice_augment_structure");
+}
+
 size_t splice_keys_selfsim_ws_bytes(int T, int D) { return selfsim_ws_bytes(T, D); }
 int splice_keys_selfsim_fwd(const float* K, int ldk, int T, int D, float eps, float* S, void* ws, splice_stream_t stream) {
     SelfSimWs w;

@@ -61,6 +61,10 @@ int resize_bilinear_fwd_launch(const float* in, float* out, int planes, int h, i
 int resize_bilinear_bwd_launch(const float* dout, float* din, int planes, int h, int w, int oh, int ow, hipStream_t s);
 int add_f32_launch(float* y, const float* x, size_t n, hipStream_t s);  // y += x
 
+// ---- augment.hip ----------------------------------------------------------------------
+int augment_structure_launch(const float* img, float* out, float* scratch, int H, int W, int flip, int n_ops, const int* order,
+                             const float* factors, float blur_sigma, hipStream_t s);
+
 // ---- selfsim.hip -----------------------------------------------------------------------
 // Cosine self-similarity of the rows of K (fp32 [T][ldk], D columns), models/extractor.py:4-9.
 struct SelfSimWs {          // carved from caller-provided scratch (selfsim_ws_bytes)

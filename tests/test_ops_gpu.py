@@ -257,3 +257,26 @@ def test_patchify_roundtrip(p, H, W):
     _lib.check(L.splice_unpatchify(_lib.ptr(dp), _lib.ptr(dimg), B, H, W, p, Tld, 1, _st()))
     refd = torch.nn.functional.fold(dp.reshape(B, Tld, -1)[:, 1:T].transpose(1, 2).contiguous(), (H, W), p, stride=p) / std
     assert _relerr(dimg, refd) < 1e-6
+
+
+def test_augment_structure_hip_vs_torch():
+    """splice_augment_structure (flip / ColorJitter in every op order / GaussianBlur) against the torch restatement of the
+    same torchvision-0.10 arithmetic (splice_amd/augment.py, itself pinned against PIL / colorsys on the CPU)."""
+    from splice_amd import augment
+    img = torch.from_numpy(synth.smooth_image_pair(6, 0, 57, 83)[0]).to(DEV)
+    torch.manual_seed(4)
+    n_jit = n_blur = n_flip = 0
+    for _ in range(60):
+        flip, jitter, sigma = augment.draw_structure_params()
+        ref = augment.apply_structure_torch(img, flip, jitter, sigma)
+        got = augment.apply_structure_hip(img, flip, jitter, sigma)
+        assert got.shape == ref.shape
+        err = (got - ref).abs().max().item()
+        assert err < 2e-5, (flip, jitter, sigma, err)   # hue: two divisions + a 6-way select per pixel
+        n_jit += jitter is not None; n_blur += sigma is not None; n_flip += flip
+    assert n_jit > 15 and n_blur > 3 and n_flip > 15
+    # every position of the contrast op in the chain (the op list is cut there)
+    for order in ([1, 0, 2, 3], [0, 1, 3, 2], [3, 2, 1, 0], [2, 3, 0, 1]):
+        jitter = (order, (1.3, 0.7, 1.15, -0.08))
+        err = (augment.apply_structure_hip(img, True, jitter, 1.1) - augment.apply_structure_torch(img, True, jitter, 1.1)).abs().max().item()
+        assert err < 2e-5, (order, err)
