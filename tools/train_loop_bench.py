@@ -16,10 +16,12 @@ for name, img in (("A", A), ("B", B)):
     Image.fromarray((img.transpose(1, 2, 0) * 255).astype(np.uint8)).save(os.path.join(d, name, "img.png"))
 for aug in (False, True):
     n = 400
+    FREQ = int(os.environ.get("LOG_FREQ", "100"))
     t = {}
     def cb(img, t=t):
         t.setdefault("first", time.perf_counter())
         t["last"] = time.perf_counter(); t["n"] = t.get("n", 0) + 1
-    train_model(d, callback=cb, cfg_overrides=dict(n_epochs=n, log_images_freq=100, use_augmentations=aug, seed=1), progress=False)
-    # callbacks fire at steps 100, 200, 300, 400: 300 steps between the first and the last
-    print(f"use_augmentations={aug}: {300 / (t['last'] - t['first']):.1f} steps/s end to end (random crops, PNG every 100 steps)")
+    train_model(d, callback=cb, cfg_overrides=dict(n_epochs=n, log_images_freq=FREQ, use_augmentations=aug, seed=1), progress=False)
+    # callbacks fire every FREQ steps: n - FREQ steps between the first and the last
+    rate = (n - FREQ) / (t["last"] - t["first"])
+    print(f"use_augmentations={aug}: {rate:.1f} steps/s end to end (random crops, PNG every {FREQ} steps)")
