@@ -664,6 +664,8 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
     const int c = blockIdx.x, img = blockIdx.y;
     const float* p = y + (size_t)img * y_nstride + (size_t)c * HW;
     float* q = out + (size_t)img * out_nstride + (size_t)c * HW;
+    // loads are issued branch-free (wave-uniform guards only; a thread past the end of the plane re-reads element 0 and
+    // is masked afterwards): lane-guarded loads compile to load + s_waitcnt per element, i.e. one memory round trip each
     float v[BN_SMALL_PER];
     float s = 0.f, dummy = 0.f;
     if (slabs) {
@@ -672,26 +674,43 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
         float* yo = y_out + (size_t)img * y_nstride + (size_t)c * HW;
         const float b = bias ? bias[c] : 0.f;
 #pragma unroll
-        for (int k = 0; k < BN_SMALL_PER; ++k) v[k] = threadIdx.x + k * 256 < HW ? b : 0.f;
-        for (int ks = 0; ks < ksplit; ++ks) {   // slice order (as conv_splitk_reduce_kernel); 16 independent loads in flight per slice
-            const float* sk = sp + (size_t)ks * per;
+        for (int k = 0; k < BN_SMALL_PER; ++k) v[k] = b;
+        for (int ks = 0; ks < ksplit; ks += 4) {   // slice order (as conv_splitk_reduce_kernel); four slices of loads in flight
+            float t[4][BN_SMALL_PER];
 #pragma unroll
-            for (int k = 0; k < BN_SMALL_PER; ++k) {
-                const int i = threadIdx.x + k * 256;
-                if (i < HW) v[k] += sk[i];
+            for (int u = 0; u < 4; ++u) {
+                if (ks + u >= ksplit) continue;
+                const float* sk = sp + (size_t)(ks + u) * per;
+#pragma unroll
+                for (int k = 0; k < BN_SMALL_PER; ++k) {
+                    if (k * 256 >= HW) continue;
+                    const int i = threadIdx.x + k * 256;
+                    t[u][k] = sk[i < HW ? i : 0];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ks + u >= ksplit) continue;
+#pragma unroll
+                for (int k = 0; k < BN_SMALL_PER; ++k)
+                    if (k * 256 < HW) v[k] += t[u][k];
             }
         }
 #pragma unroll
         for (int k = 0; k < BN_SMALL_PER; ++k) {
             const int i = threadIdx.x + k * 256;
-            if (i < HW) yo[i] = v[k];
+            if (i < HW) yo[i] = v[k]; else v[k] = 0.f;
             s += v[k];
         }
     } else {
 #pragma unroll
         for (int k = 0; k < BN_SMALL_PER; ++k) {
             const int i = threadIdx.x + k * 256;
-            v[k] = i < HW ? p[i] : 0.f;
+            v[k] = k * 256 < HW ? p[i < HW ? i : 0] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < BN_SMALL_PER; ++k) {
+            if (threadIdx.x + k * 256 >= HW) v[k] = 0.f;
             s += v[k];
         }
     }
@@ -724,14 +743,27 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
 __device__ __forceinline__ void bn_small_bwd_sums(const float* pd, const float* pa, const float* py, int HW, float m, float r, float slope,
                                                   float (&dz)[BN_SMALL_PER], float (&xh)[BN_SMALL_PER], float& s1, float& s2, float* red) {
     s1 = 0.f; s2 = 0.f;
+    // branch-free loads first (see bn_small_fwd_kernel), arithmetic after
+    const bool act = slope != 1.0f;
+    float vd[BN_SMALL_PER], va[BN_SMALL_PER], vy[BN_SMALL_PER];
+#pragma unroll
+    for (int k = 0; k < BN_SMALL_PER; ++k) {
+        if (k * 256 >= HW) continue;
+        const int i = threadIdx.x + k * 256;
+        const int j = i < HW ? i : 0;
+        vd[k] = pd[j];
+        vy[k] = py[j];
+        va[k] = act ? pa[j] : 1.f;
+    }
 #pragma unroll
     for (int k = 0; k < BN_SMALL_PER; ++k) {
         const int i = threadIdx.x + k * 256;
         float d = 0.f, x = 0.f;
-        if (i < HW) {
-            d = pd[i];
-            if (slope != 1.0f && !(pa[i] > 0.f)) d *= slope;
-            x = (py[i] - m) * r;
+        if (k * 256 < HW) {
+            d = vd[k];
+            if (act && !(va[k] > 0.f)) d *= slope;
+            x = (vy[k] - m) * r;
+            if (i >= HW) { d = 0.f; x = 0.f; }
         }
         dz[k] = d; xh[k] = x;
         s1 += d;
@@ -874,16 +906,22 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
         float wy[4], wx[4];
         up_adjoint_weights(my, h, Ho, wy);
         up_adjoint_weights(mx, w, Wo, wx);
+        // all 16 taps are loaded unconditionally from clamped coordinates (a zero weight marks the taps that do not
+        // exist; guarded loads would serialise into 16 memory round trips)
+        float t[4][4];
+#pragma unroll
+        for (int ty = 0; ty < 4; ++ty) {
+            const int oy = min(max(2 * my - 1 + ty, 0), Ho - 1);
+#pragma unroll
+            for (int tx = 0; tx < 4; ++tx) t[ty][tx] = p[oy * Wo + min(max(2 * mx - 1 + tx, 0), Wo - 1)];
+        }
         float acc = 0.f;
 #pragma unroll
         for (int ty = 0; ty < 4; ++ty) {
-            if (wy[ty] == 0.f) continue;
-            const int oy = 2 * my - 1 + ty;
             float row = 0.f;
 #pragma unroll
-            for (int tx = 0; tx < 4; ++tx)
-                if (wx[tx] != 0.f) row += wx[tx] * p[oy * Wo + 2 * mx - 1 + tx];
-            acc += wy[ty] * row;
+            for (int tx = 0; tx < 4; ++tx) row += wx[tx] != 0.f ? wx[tx] * t[ty][tx] : 0.f;
+            acc += wy[ty] != 0.f ? wy[ty] * row : 0.f;
         }
         q[i] = acc;
     }
@@ -893,7 +931,7 @@ int upsample2x_fwd_launch(const float* in, size_t in_nstride, float* out, size_t
     return SPLICE_OK;
 }
 int upsample2x_bwd_launch(const float* dout, size_t dout_nstride, float* din, size_t din_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s) {
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(plane_blocks(h * w), C, N), dim3(256), 0, s, dout, dout_nstride, din, din_nstride, C, h, w, Ho, Wo);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(cdiv(h * w, 256), C, N), dim3(256), 0, s, dout, dout_nstride, din, din_nstride, C, h, w, Ho, Wo);
     return SPLICE_OK;
 }
 

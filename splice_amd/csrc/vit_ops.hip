@@ -56,6 +56,7 @@ int layernorm_fwd_launch(const float* x, const float* gamma, const float* beta, 
 }
 
 // dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)),  dxhat = dy * gamma
+constexpr int LN_MAX_SLABS = 4;
 template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean_i,
@@ -69,30 +70,41 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
     const float4* dr = reinterpret_cast<const float4*>(dy + (size_t)row * D);
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* gi = g_in ? reinterpret_cast<const float4*>(g_in + (size_t)row * D) : nullptr;
     const float mean = mean_i[row], rstd = rstd_i[row];
+    // every load of the row is issued before the first use: the guards below are wave-uniform (a lane past the end of
+    // the row re-reads element nv-1 and is masked afterwards), so nothing waits between the loads -- lane-guarded loads
+    // compile to one load + s_waitcnt per element and made this kernel a chain of ~20 serial memory round trips
+    float4 xv[MAXV], gv[MAXV], dv[MAXV], ev[LN_MAX_SLABS - 1][MAXV], av[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (64 * i >= nv) continue;
+        const int j = min(lane + 64 * i, nv - 1);
+        xv[i] = xr[j]; gv[i] = g4[j]; dv[i] = dr[j];
+#pragma unroll
+        for (int sl = 1; sl < LN_MAX_SLABS; ++sl)
+            if (sl < n_slabs) ev[sl - 1][i] = reinterpret_cast<const float4*>(dy + (size_t)sl * slab_stride + (size_t)row * D)[j];
+        if (gi) av[i] = gi[j];
+    }
     float4 xh[MAXV], dh[MAXV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int idx = lane + 64 * i;
-        if (idx < nv) {
-            const float4 xv = xr[idx], g = g4[idx];
-            float4 dv = dr[idx];
-            for (int sl = 1; sl < n_slabs; ++sl) {   // split-K slabs of the producing GEMM, summed in slab order
-                const float4 e = reinterpret_cast<const float4*>(dy + (size_t)sl * slab_stride + (size_t)row * D)[idx];
-                dv.x += e.x; dv.y += e.y; dv.z += e.z; dv.w += e.w;
-            }
-            xh[i] = float4{(xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd};
-            dh[i] = float4{dv.x * g.x, dv.y * g.y, dv.z * g.z, dv.w * g.w};
-            s1 += dh[i].x + dh[i].y + dh[i].z + dh[i].w;
-            s2 += dh[i].x * xh[i].x + dh[i].y * xh[i].y + dh[i].z * xh[i].z + dh[i].w * xh[i].w;
-        } else {
-            xh[i] = float4{0.f, 0.f, 0.f, 0.f};
-            dh[i] = xh[i];
+        const bool in = 64 * i < nv && lane + 64 * i < nv;
+        if (64 * i < nv) {
+            float4 d = dv[i];
+#pragma unroll
+            for (int sl = 1; sl < LN_MAX_SLABS; ++sl)   // split-K slabs of the producing GEMM, summed in slab order
+                if (sl < n_slabs) { const float4 e = ev[sl - 1][i]; d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
+            const float4 xv_ = xv[i], g = gv[i];
+            xh[i] = float4{(xv_.x - mean) * rstd, (xv_.y - mean) * rstd, (xv_.z - mean) * rstd, (xv_.w - mean) * rstd};
+            dh[i] = float4{d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w};
         }
+        if (!in) { xh[i] = float4{0.f, 0.f, 0.f, 0.f}; dh[i] = xh[i]; }
+        s1 += dh[i].x + dh[i].y + dh[i].z + dh[i].w;
+        s2 += dh[i].x * xh[i].x + dh[i].y * xh[i].y + dh[i].z * xh[i].z + dh[i].w * xh[i].w;
     }
     const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
-    const float4* gi = g_in ? reinterpret_cast<const float4*>(g_in + (size_t)row * D) : nullptr;
     float4* go = reinterpret_cast<float4*>(g_out + (size_t)row * D);
     uint2* gb = g_out_bf ? reinterpret_cast<uint2*>(g_out_bf + (size_t)row * D) : nullptr;
 #pragma unroll
@@ -101,7 +113,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         if (idx < nv) {
             float4 r = float4{rstd * (dh[i].x - m1 - xh[i].x * m2), rstd * (dh[i].y - m1 - xh[i].y * m2),
                               rstd * (dh[i].z - m1 - xh[i].z * m2), rstd * (dh[i].w - m1 - xh[i].w * m2)};
-            if (gi) { const float4 a = gi[idx]; r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w; }
+            if (gi) { const float4 a = av[i]; r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w; }
             go[idx] = r;
             if (gb) gb[idx] = uint2{pack2bf(r.x, r.y), pack2bf(r.z, r.w)};
         }
@@ -110,7 +122,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 int layernorm_bwd_slabs_launch(const float* dy, int n_slabs, size_t slab_stride, const float* x, const float* gamma, const float* mean,
                                const float* rstd, const float* g_in, float* g_out, bf16_t* g_out_bf, int rows, int D, hipStream_t s) {
-    if (D % 4 || D > 64 * 4 * 4 || n_slabs < 1) return SPLICE_ERR_ARG;
+    if (D % 4 || D > 64 * 4 * 4 || n_slabs < 1 || n_slabs > LN_MAX_SLABS) return SPLICE_ERR_ARG;
     hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, dy, x, gamma, mean, rstd, g_in, g_out, g_out_bf, rows, D,
                        n_slabs, slab_stride);
     return SPLICE_OK;

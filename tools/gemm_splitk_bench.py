@@ -5,10 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from splice_amd import _lib
 L = _lib.lib()
-for name, M, N, K in [("fc2_16", 1600, 768, 3072), ("fc1T8", 800, 768, 3072), ("qkvT8", 800, 768, 2304), ("proj16", 1600, 768, 768)]:
+for name, M, N, K in [("fc2_16", 1600, 768, 3072), ("fc1T8", 800, 768, 3072), ("qkvT8", 800, 768, 2304), ("proj16", 1600, 768, 768), ("fc1_16", 1600, 3072, 768), ("qkv_16", 1600, 2304, 768), ("fc2T8", 800, 3072, 768)]:
     A = torch.randn(M, K, device="cuda").bfloat16(); B = torch.randn(N, K, device="cuda").bfloat16()
     row = []
-    for tile in (3, 13, 2, 12):
+    for tile in (3, 13, 2, 12, 1, 11):
         for ks in (1, 2, 3, 4, 6):
             if K % (ks * 64): continue
             out = torch.empty(ks, M, N, device="cuda")
