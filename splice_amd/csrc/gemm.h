@@ -280,10 +280,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmEpi& e, int M, int N, in
 }
 
 // Epilogue for the swapped fragment layout: lane holds C[row][col0 .. col0+3].
-template <unsigned FLAGS>
-__device__ __forceinline__ void gemm_epilogue_cols(const GemmEpi& e, int M, int N, int row, int col0, f32x4 v) {
+// PRE: the bias / residual / GELU' operands were loaded beforehand (gemm_nt_kernel issues the loads of every
+// fragment before the first one is consumed); otherwise they are loaded here, one fragment at a time.
+template <unsigned FLAGS, bool PRE = false>
+__device__ __forceinline__ void gemm_epilogue_cols(const GemmEpi& e, int M, int N, int row, int col0, f32x4 v, float4 pre_bias = float4{},
+                                                   float4 pre_resid = float4{}, uint2 pre_aux = uint2{}) {
     if (row >= M || col0 >= N) return;
-    const bool full = col0 + 3 < N;
+    const bool full = PRE || col0 + 3 < N;
     float x[4] = {v[0], v[1], v[2], v[3]};
     if (FLAGS & EPI_ALPHA) {
 #pragma unroll
@@ -291,7 +294,7 @@ __device__ __forceinline__ void gemm_epilogue_cols(const GemmEpi& e, int M, int 
     }
     if (FLAGS & EPI_BIAS) {
         if (full) {
-            const float4 b = *reinterpret_cast<const float4*>(e.bias + col0);
+            const float4 b = PRE ? pre_bias : *reinterpret_cast<const float4*>(e.bias + col0);
             x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w;
         } else {
 #pragma unroll
@@ -299,10 +302,10 @@ __device__ __forceinline__ void gemm_epilogue_cols(const GemmEpi& e, int M, int 
         }
     }
     if (FLAGS & EPI_RESID) {
-        const int rr = e.resid_mod ? row % e.resid_mod : row;
+        const int rr = PRE ? 0 : (e.resid_mod ? row % e.resid_mod : row);
         const float* p = e.resid + (size_t)rr * e.ldr + col0;
-        if (full && !(e.ldr & 3)) {
-            const float4 b = *reinterpret_cast<const float4*>(p);
+        if (PRE || (full && !(e.ldr & 3))) {
+            const float4 b = PRE ? pre_resid : *reinterpret_cast<const float4*>(p);
             x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w;
         } else {
 #pragma unroll
@@ -311,8 +314,8 @@ __device__ __forceinline__ void gemm_epilogue_cols(const GemmEpi& e, int M, int 
     }
     if (FLAGS & EPI_GELU_GRAD) {
         const bf16_t* p = e.aux + (size_t)row * e.ldaux + col0;
-        if (full && !(e.ldaux & 3)) {
-            const uint2 u = *reinterpret_cast<const uint2*>(p);
+        if (PRE || (full && !(e.ldaux & 3))) {
+            const uint2 u = PRE ? pre_aux : *reinterpret_cast<const uint2*>(p);
             x[0] *= gelu_grad_f(bf2f((bf16_t)(u.x & 0xFFFF))); x[1] *= gelu_grad_f(bf2f((bf16_t)(u.x >> 16)));
             x[2] *= gelu_grad_f(bf2f((bf16_t)(u.y & 0xFFFF))); x[3] *= gelu_grad_f(bf2f((bf16_t)(u.y >> 16)));
         } else {
@@ -377,7 +380,41 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
     GemmTile<BM, BN, true> tile;
     if (NS == 2) tile.run_glds(A, lda, B, ldb, M, N, K, m0, n0, gemm_smem, kbeg);
     else tile.template run_ring<(NS < 3 ? 3 : NS)>(A, lda, B, ldb, M, N, K, m0, n0, gemm_smem, kbeg);
-    tile.for_each_cols(m0, n0, [&](int row, int col0, f32x4 v) { gemm_epilogue_cols<FLAGS>(e, M, N, row, col0, v); });
+    // Epilogue operands: lane-guarded loads inside the per-fragment epilogue compile to load + s_waitcnt per fragment,
+    // one memory round trip each (4 ... 16 per lane, the residual usually an L2 miss).  With N and the leading dimensions
+    // multiples of 4 every fragment's operands are loaded first, from clamped (always valid) addresses.
+    constexpr bool HAS_OPERANDS = (FLAGS & (EPI_BIAS | EPI_RESID | EPI_GELU_GRAD)) != 0;
+    const bool pre_ok = HAS_OPERANDS && !(N & 3) && (!(FLAGS & EPI_RESID) || !(e.ldr & 3)) && (!(FLAGS & EPI_GELU_GRAD) || !(e.ldaux & 3));
+    if (pre_ok) {
+        constexpr int FMt = GemmTile<BM, BN>::FM, FNt = GemmTile<BM, BN>::FN;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+        float4 pb[FNt], pr[FMt][FNt];
+        uint2 pa[FMt][FNt];
+        int colc[FNt];
+#pragma unroll
+        for (int j = 0; j < FNt; ++j) {
+            colc[j] = min(n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4, N - 4);
+            if (FLAGS & EPI_BIAS) pb[j] = *reinterpret_cast<const float4*>(e.bias + colc[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < FMt; ++i) {
+            const int rowc = min(m0 + wm * (BM / 2) + i * 16 + (lane & 15), M - 1);
+            const int rr = e.resid_mod ? rowc % e.resid_mod : rowc;
+#pragma unroll
+            for (int j = 0; j < FNt; ++j) {
+                if (FLAGS & EPI_RESID) pr[i][j] = *reinterpret_cast<const float4*>(e.resid + (size_t)rr * e.ldr + colc[j]);
+                if (FLAGS & EPI_GELU_GRAD) pa[i][j] = *reinterpret_cast<const uint2*>(e.aux + (size_t)rowc * e.ldaux + colc[j]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FMt; ++i)
+#pragma unroll
+            for (int j = 0; j < FNt; ++j)
+                gemm_epilogue_cols<FLAGS, true>(e, M, N, m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4,
+                                                tile.acc[i][j], pb[j], pr[i][j], pa[i][j]);
+    } else {
+        tile.for_each_cols(m0, n0, [&](int row, int col0, f32x4 v) { gemm_epilogue_cols<FLAGS>(e, M, N, row, col0, v); });
+    }
     if (FLAGS & EPI_ROWDOT) {
         // 64-column row dots of the bf16-rounded result against rd_other (BN == 64: one workgroup = one 64-column block):
         // lane partial over its 4 columns x 2 fragments -> 4 lane groups (shuffles) -> the 2 waves of a row (LDS)
@@ -386,6 +423,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
         float* red = reinterpret_cast<float*>(gemm_smem);   // [2 wn][BM] (the K loop is over)
         __syncthreads();
+        uint2 ov[FMt][FNt];   // every fragment's operand is loaded before the first use (clamped row: the loads are unconditional)
+#pragma unroll
+        for (int i = 0; i < FMt; ++i)
+#pragma unroll
+            for (int j = 0; j < FNt; ++j)
+                ov[i][j] = *reinterpret_cast<const uint2*>(e.rd_other + (size_t)min(m0 + wm * (BM / 2) + i * 16 + (lane & 15), M - 1) * e.ld_rd + n0 +
+                                                           wn * (BN / 2) + j * 16 + (lane >> 4) * 4);
 #pragma unroll
         for (int i = 0; i < FMt; ++i) {
             const int lrow = wm * (BM / 2) + i * 16 + (lane & 15);
@@ -394,8 +438,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
             if (row < M) {
 #pragma unroll
                 for (int j = 0; j < FNt; ++j) {
-                    const int col = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
-                    const uint2 o = *reinterpret_cast<const uint2*>(e.rd_other + (size_t)row * e.ld_rd + col);
+                    const uint2 o = ov[i][j];
                     const f32x4 v = tile.acc[i][j];
                     part += bf2f(f2bf(v[0])) * bf2f((bf16_t)(o.x & 0xFFFF)) + bf2f(f2bf(v[1])) * bf2f((bf16_t)(o.x >> 16)) +
                             bf2f(f2bf(v[2])) * bf2f((bf16_t)(o.y & 0xFFFF)) + bf2f(f2bf(v[3])) * bf2f((bf16_t)(o.y >> 16));
