@@ -164,19 +164,30 @@ __global__ __launch_bounds__(256 * NG) void conv_igemm_kernel(ConvArgs a) {
         return;
     }
     float* out = a.out + (size_t)img * a.out_nstride;
+    // bias and (accumulate) the previous values are loaded up front from clamped addresses: a guarded load per element
+    // would be one memory round trip per element
+    float bj[FN], prev[FN][4];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int nc = min(n0 + j * 16 + (lane & 15), a.Cout - 1);
+        bj[j] = a.bias ? a.bias[nc] : 0.f;
+        if (a.accumulate) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) prev[j][r] = out[(size_t)nc * a.out_cstride + min(m0 + pw * 16 + (lane >> 4) * 4 + r, HWo - 1)];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int n = n0 + j * 16 + (lane & 15);
         if (n >= a.Cout) continue;
-        const float b = a.bias ? a.bias[n] : 0.f;
+        const float b = bj[j];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int pp = m0 + pw * 16 + (lane >> 4) * 4 + r;
             if (pp < HWo) {
                 float v = acc[j][r] + b;
                 if (a.act == 1) v = 1.0f / (1.0f + __expf(-v));
-                float* q = out + (size_t)n * a.out_cstride + pp;
-                *q = a.accumulate ? *q + v : v;
+                out[(size_t)n * a.out_cstride + pp] = a.accumulate ? prev[j][r] + v : v;
             }
         }
     }
@@ -191,10 +202,17 @@ __global__ void conv_splitk_reduce_kernel(ConvArgs a, int ksplit) {
         const int n = (i / HWo) % a.Cout;
         const int img = i / ((size_t)HWo * a.Cout);
         float v = a.bias ? a.bias[n] : 0.f;
-        for (int k = 0; k < ksplit; ++k) v += a.ws[(size_t)k * per + i];
-        if (a.act == 1) v = 1.0f / (1.0f + __expf(-v));
         float* q = a.out + (size_t)img * a.out_nstride + (size_t)n * a.out_cstride + pp;
-        *q = a.accumulate ? *q + v : v;
+        const float prev = a.accumulate ? *q : 0.f;
+        int k = 0;
+        for (; k + 3 < ksplit; k += 4) {   // four slices in flight, added in slice order
+            const float t0 = a.ws[(size_t)k * per + i], t1 = a.ws[(size_t)(k + 1) * per + i], t2 = a.ws[(size_t)(k + 2) * per + i],
+                        t3 = a.ws[(size_t)(k + 3) * per + i];
+            v += t0; v += t1; v += t2; v += t3;
+        }
+        for (; k < ksplit; ++k) v += a.ws[(size_t)k * per + i];
+        if (a.act == 1) v = 1.0f / (1.0f + __expf(-v));
+        *q = a.accumulate ? prev + v : v;
     }
 }
 
@@ -378,6 +396,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(WgradReduceAll d,
     const float* p = ws + d.ws_off[l] + i;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // 4 independent chains in a FIXED association order
     int c = 0;
+    for (; c + 15 < chunks; c += 16) {   // 16 loads in flight, added in the order of the 4-wide loop below (same bits)
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(c + u) * n];
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+    }
     for (; c + 3 < chunks; c += 4) {
         s0 += p[(size_t)c * n];
         s1 += p[(size_t)(c + 1) * n];

@@ -420,6 +420,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     // ---- backward (train.py:78): ViT dgrad for the generated images only, then the generator
     // the two generated images are independent chains until the generator: one per stream (every launch of a
     // dependent chain pays ~8 us of fixed latency; two chains in flight hide each other's)
+    bool loss_summed = false;
     if (!(st->ablate & 4)) {   // (the same launches whether or not the second stream is used: results are bit-identical)
         if (overlap) {
             HIPCHK(hipEventRecord(st->ev_fork, s));
@@ -429,7 +430,13 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         RC(unplace_grad(vg.d_imgs + 3 * vimg, vg.H, vg.W, st->d_gen_out + crop, st->cropb_h, st->cropb_w, s2));
         // split crops: each chain continues into its own generator plan (own gradient arena: no cross-chain accumulation)
         if (split && !(st->ablate & 2)) RC(splice_gen_backward(st->plan_b, params, st->d_gen_out + crop, st->grads_b, 0, s2));
-        if (overlap) HIPCHK(hipEventRecord(st->ev_join, s2));
+        if (overlap) {
+            // the reported loss values depend on nothing downstream: summed at the tail of the side chain instead of
+            // between the generator backward and Adam on the critical one
+            hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(320), 0, s2, st->losses, l_ssim, l_essim, l_ecls, l_cls, l_id);
+            loss_summed = true;
+            HIPCHK(hipEventRecord(st->ev_join, s2));
+        }
         RC(splice_vit_backward(vg.ctx, 2, 3, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
         RC(unplace_grad(vg.d_imgs + 2 * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, s));
         if (split && !(st->ablate & 2)) RC(splice_gen_backward(st->plan_a, params, st->d_gen_out, grads, 0, s));
@@ -444,7 +451,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         RC(unplace_grad(ve.d_imgs + eimg, ve.H, ve.W, st->d_ent_out, c.ent_h, c.ent_w, s));
         RC(splice_gen_backward(st->plan_e, params, st->d_ent_out, grads, 1, s));
     }
-    hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(320), 0, s, st->losses, l_ssim, l_essim, l_ecls, l_cls, l_id);
+    if (!loss_summed) hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(320), 0, s, st->losses, l_ssim, l_essim, l_ecls, l_cls, l_id);
     // ---- optimizer.step() (train.py:79); Adam's step count (>= 1) is read from the device at execution time
     RC(adam_launch_dev(params, grads, m, v, (size_t)st->nparams, c.lr, c.beta1, c.beta2, c.eps, st->dev_t, 0, s));
     return SPLICE_OK;
