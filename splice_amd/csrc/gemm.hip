@@ -1,6 +1,7 @@
 // Instantiations + runtime dispatch of the bf16 NT GEMM (gemm.h) for the epilogues the
 // DINO-ViT forward / dgrad path uses (K3, K5, K7, K8 of SURVEY.md section 2b).
 #include "kernels.h"
+#include <cstdlib>
 
 static int g_force_tile = 0;   // 0 auto; tile + 10 * ring: tile 1 = 128x128, 2 = 128x64, 3 = 64x64; ring 0 = 2 stages, 1 = 4 stages (tools/gemm_bench.py)
 void gemm_force_tile(int t) { g_force_tile = t; }
@@ -15,11 +16,16 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
     else {
         // measured on MI355X (tools/gemm_bench.py): with N <= 768 the 64x64 tile wins (more workgroups on the long-K shapes);
         // otherwise the biggest tile that still yields ~2 workgroups per CU (M = 1600: 128x64 beats 128x128 by 10 %, M = 800: 64x64)
-        tile = (N <= 768 || (FLAGS & EPI_ROWDOT)) ? 3 : t128 >= 640 ? 1 : t12864 >= 400 ? 2 : 3;
+        static const int t2min = getenv("SPLICE_GEMM_T2MIN") ? atoi(getenv("SPLICE_GEMM_T2MIN")) : 400;
+        static const int t2ring = getenv("SPLICE_GEMM_T2RING") ? atoi(getenv("SPLICE_GEMM_T2RING")) : 0;
+        tile = (N <= 768 || (FLAGS & EPI_ROWDOT)) ? 3 : t128 >= 640 ? 1 : t12864 >= t2min ? 2 : 3;
         // few workgroups walking a long K (fc2, the fc1 / qkv dgrads): the per-slice DMA latency is exposed with 2 stages,
         // the 4-stage ring keeps 3 slices in flight (fc1T 800x768x3072: 23.4 -> 15.3 us); elsewhere its LDS footprint costs occupancy
         const int ks = (FLAGS == EPI_OUT_F32 && e.ksplit > 1 && K % (e.ksplit * GEMM_BK) == 0) ? e.ksplit : 1;
-        ring = (tile == 3 && K / ks >= (ks > 1 ? 768 : 1536) && (long)cdiv(M, 64) * cdiv(N, 64) * ks <= 640) ? 1 : 0;
+        static const int ringk = getenv("SPLICE_GEMM_RINGK") ? atoi(getenv("SPLICE_GEMM_RINGK")) : 768;
+        static const int ringwg = getenv("SPLICE_GEMM_RINGWG") ? atoi(getenv("SPLICE_GEMM_RINGWG")) : 640;
+        ring = (tile == 3 && K / ks >= (ks > 1 ? 768 : ringk) && (long)cdiv(M, 64) * cdiv(N, 64) * ks <= ringwg) ? 1 : 0;
+        if (tile == 2 && t2ring) ring = 1;
     }
     if constexpr ((FLAGS & EPI_ROWDOT) != 0) {   // only instantiated for the 64-column tile
         if (ring) launch_gemm_nt<64, 64, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e);
