@@ -3,7 +3,7 @@
 #include "kernels.h"
 #include <cstdlib>
 
-static int g_force_tile = 0;   // 0 auto; tile + 10 * ring: tile 1 = 128x128, 2 = 128x64, 3 = 64x64; ring 0 = 2 stages, 1 = 4 stages (tools/gemm_bench.py)
+static int g_force_tile = 0;   // 0 auto; tile + 10 * ring: tile 1 = 128x128, 2 = 128x64, 3 = 64x64; ring 0 = 2 stages, 1 = 4 stages, 2 = 3 stages (64x64 only) (tools/gemm_bench.py)
 void gemm_force_tile(int t) { g_force_tile = t; }
 
 template <unsigned FLAGS>
@@ -26,11 +26,17 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
         static const int ringwg = getenv("SPLICE_GEMM_RINGWG") ? atoi(getenv("SPLICE_GEMM_RINGWG")) : 640;
         ring = (tile == 3 && K / ks >= (ks > 1 ? 768 : ringk) && (long)cdiv(M, 64) * cdiv(N, 64) * ks <= ringwg) ? 1 : 0;
         if (tile == 2 && t2ring) ring = 1;
+        // the short-K ring shapes (proj, projT: 12 slices) run the 3-stage form -- its own instantiation, so profiles keep
+        // them apart from the long-K launches of the same epilogue (fc2)
+        static const int shortns = getenv("SPLICE_GEMM_SHORTNS") ? atoi(getenv("SPLICE_GEMM_SHORTNS")) : 3;
+        if (ring && tile == 3 && ks == 1 && K < 1536 && shortns == 3) ring = 2;
     }
     if constexpr ((FLAGS & EPI_ROWDOT) != 0) {   // only instantiated for the 64-column tile
-        if (ring) launch_gemm_nt<64, 64, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e);
+        if (ring == 2) launch_gemm_nt<64, 64, FLAGS, 3>(s, A, lda, B, ldb, M, N, K, e);
+        else if (ring) launch_gemm_nt<64, 64, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e);
         else launch_gemm_nt<64, 64, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e);
     } else {
+        if (tile == 3 && ring == 2) { launch_gemm_nt<64, 64, FLAGS, 3>(s, A, lda, B, ldb, M, N, K, e); return SPLICE_OK; }
         switch (tile * 2 + (ring ? 1 : 0)) {
             case 2: launch_gemm_nt<128, 128, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e); break;
             case 3: launch_gemm_nt<128, 128, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e); break;

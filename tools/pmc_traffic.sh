@@ -8,15 +8,25 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python - "$K" <<'PY'
 import csv, glob, os, sys
+# One template instantiation can serve several shapes (the 64x64 ring kernel runs both fc2 forward, K = 3072, and proj
+# forward, K = 768): launches are clustered by their FETCH_SIZE and every cluster is reported with its own average.
 root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out"
-out = {}
+rows = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    vals = []
     for f in glob.glob(f"{root}/pmc_{c}/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             if sys.argv[1] in r["Kernel_Name"] and r["Counter_Name"] == c:
-                vals.append(float(r["Counter_Value"]))
-    out[c] = (sum(vals) / max(len(vals), 1), len(vals))
-f, w = out["FETCH_SIZE"][0], out["WRITE_SIZE"][0]
-print(f"kernel '{sys.argv[1]}': FETCH_SIZE {f:.1f} KB x2 (gfx950) + WRITE_SIZE {w:.1f} KB over {out['FETCH_SIZE'][1]} launches -> {(2*f+w)*1024/1e6:.2f} MB per launch (rocprofv3 reports KB)")
+                rows.setdefault(c, []).append(float(r["Counter_Value"]))
+f, w = sorted(rows.get("FETCH_SIZE", [0.0])), rows.get("WRITE_SIZE", [0.0])
+wavg = sum(w) / len(w)
+clusters, cur = [], [f[0]]
+for v in f[1:]:
+    if v > 1.25 * cur[0]:
+        clusters.append(cur); cur = [v]
+    else:
+        cur.append(v)
+clusters.append(cur)
+for cl in clusters:
+    fa = sum(cl) / len(cl)
+    print(f"kernel '{sys.argv[1]}': {len(cl)} launches with FETCH_SIZE {fa:.1f} KB x2 (gfx950) + WRITE_SIZE {wavg:.1f} KB -> {(2*fa+wavg)*1024/1e6:.2f} MB per launch (rocprofv3 reports KB)")
 PY
