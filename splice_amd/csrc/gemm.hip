@@ -17,7 +17,7 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
         // measured on MI355X (tools/gemm_bench.py): with N <= 768 the 64x64 tile wins (more workgroups on the long-K shapes);
         // otherwise the biggest tile that still yields ~2 workgroups per CU (M = 1600: 128x64 beats 128x128 by 10 %, M = 800: 64x64)
         static const int t2min = getenv("SPLICE_GEMM_T2MIN") ? atoi(getenv("SPLICE_GEMM_T2MIN")) : 400;
-        static const int t2ring = getenv("SPLICE_GEMM_T2RING") ? atoi(getenv("SPLICE_GEMM_T2RING")) : 0;
+        static const int t2ring = getenv("SPLICE_GEMM_T2RING") ? atoi(getenv("SPLICE_GEMM_T2RING")) : 3;
         tile = (N <= 768 || (FLAGS & EPI_ROWDOT)) ? 3 : t128 >= 640 ? 1 : t12864 >= t2min ? 2 : 3;
         // few workgroups walking a long K (fc2, the fc1 / qkv dgrads): the per-slice DMA latency is exposed with 2 stages,
         // the 4-stage ring keeps 3 slices in flight (fc1T 800x768x3072: 23.4 -> 15.3 us); elsewhere its LDS footprint costs occupancy
@@ -25,7 +25,7 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
         static const int ringk = getenv("SPLICE_GEMM_RINGK") ? atoi(getenv("SPLICE_GEMM_RINGK")) : 768;
         static const int ringwg = getenv("SPLICE_GEMM_RINGWG") ? atoi(getenv("SPLICE_GEMM_RINGWG")) : 640;
         ring = (tile == 3 && K / ks >= (ks > 1 ? 768 : ringk) && (long)cdiv(M, 64) * cdiv(N, 64) * ks <= ringwg) ? 1 : 0;
-        if (tile == 2 && t2ring) ring = 1;
+        if (tile == 2 && t2ring) ring = t2ring == 3 ? 2 : 1;
         // the short-K ring shapes (proj, projT: 12 slices) run the 3-stage form -- its own instantiation, so profiles keep
         // them apart from the long-K launches of the same epilogue (fc2)
         static const int shortns = getenv("SPLICE_GEMM_SHORTNS") ? atoi(getenv("SPLICE_GEMM_SHORTNS")) : 3;
@@ -37,6 +37,7 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
         else launch_gemm_nt<64, 64, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e);
     } else {
         if (tile == 3 && ring == 2) { launch_gemm_nt<64, 64, FLAGS, 3>(s, A, lda, B, ldb, M, N, K, e); return SPLICE_OK; }
+        if (tile == 2 && ring == 2) { launch_gemm_nt<128, 64, FLAGS, 3>(s, A, lda, B, ldb, M, N, K, e); return SPLICE_OK; }
         switch (tile * 2 + (ring ? 1 : 0)) {
             case 2: launch_gemm_nt<128, 128, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e); break;
             case 3: launch_gemm_nt<128, 128, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e); break;

@@ -65,6 +65,25 @@ def test_gemm_plain_f32(M, N, K):
     assert torch.allclose(out[0, N - 1], ref[0, N - 1], rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("force", [1, 11, 2, 12, 22, 3, 13, 23])
+def test_gemm_forced_tiles_and_rings(force):
+    """Every tile (128x128 / 128x64 / 64x64) x pipeline (2-stage, 4- and 3-stage ring) variant the dispatcher can pick,
+    on ragged shapes, through the epilogue with prefetched operands (N % 4 == 0) and its per-fragment fallback (N % 4 != 0)."""
+    L = _lib.lib()
+    try:
+        L.splice_gemm_force_tile(force)
+        for M, N, K in [(333, 200, 256), (130, 198, 192), (70, 64, 64)]:
+            A, B = _bf(_rand(M, K, seed=11)), _bf(_rand(N, K, seed=12, std=0.05))
+            bias, resid = _rand(N, seed=13), _rand(M, N, seed=14)
+            out = torch.full((M, N), float("nan"), device=DEV)
+            _gemm(_lib.EPI_BIAS | _lib.EPI_RESID | _lib.EPI_OUT_F32, A, B, M, N, K, bias=bias, resid=resid, ldr=N, resid_mod=0, out_f32=out, ldo=N)
+            ref = A.float() @ B.float().T + bias + resid
+            assert torch.isfinite(out).all(), (force, M, N, K)
+            assert _relerr(out, ref) < 2e-6, (force, M, N, K, _relerr(out, ref))
+    finally:
+        L.splice_gemm_force_tile(0)
+
+
 def test_gemm_epilogues():
     M, N, K = 785, 768, 768
     A, B = _bf(_rand(M, K, seed=3)), _bf(_rand(N, K, seed=4, std=0.05))
