@@ -79,5 +79,5 @@ int sigmoid_bwd_bias_launch(const float* dout, const float* sout, float* dpre, i
                             int accumulate, hipStream_t s);
 int adam_launch(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step, int zero_grad, hipStream_t s);
 int adam_launch_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, const int* step_dev,
-                    int zero_grad, hipStream_t s);
+                    int zero_grad, hipStream_t s, const float* g2 = nullptr);
 int set_int_launch(int* p, int v, hipStream_t s);

@@ -1014,14 +1014,16 @@ int sigmoid_bwd_launch(const float* dout, const float* sout, float* dpre, size_t
 // util/util.py:28-32: no weight decay / amsgrad, eps added after sqrt(v_hat)).  Also clears the
 // gradient (optimizer.zero_grad, train.py:56) when zero_grad != 0.
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
-                            float b1, float b2, float eps, float bc1, float bc2_sqrt, int zero_grad, const int* __restrict__ step_ptr) {
+                            float b1, float b2, float eps, float bc1, float bc2_sqrt, int zero_grad, const int* __restrict__ step_ptr,
+                            const float* __restrict__ g2) {
     if (step_ptr) {   // step count lives on the device (graph replay): bias corrections computed here
         const float t = (float)*step_ptr;
         bc1 = 1.0f - powf(b1, t);
         bc2_sqrt = sqrtf(1.0f - powf(b2, t));
     }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float gi = g[i];
+        float gi = g[i];
+        if (g2) { gi += g2[i]; g[i] = gi; }   // second gradient arena (the B-crop plan): g = g + g2, as a separate add would leave it
         const float mi = b1 * m[i] + (1.f - b1) * gi;
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         m[i] = mi;
@@ -1037,15 +1039,15 @@ int adam_launch(float* p, float* g, float* m, float* v, size_t n, float lr, floa
     const float bc2 = 1.0f - powf(b2, (float)step);
     size_t g_ = (n + 255) / 256;
     if (g_ > 2048) g_ = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g_), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), zero_grad, (const int*)nullptr);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g_), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), zero_grad, (const int*)nullptr, (const float*)nullptr);
     return SPLICE_OK;
 }
 // same, the step count t (>= 1) read from device memory at execution time
 int adam_launch_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, const int* step_dev,
-                    int zero_grad, hipStream_t s) {
+                    int zero_grad, hipStream_t s, const float* g2) {
     size_t g_ = (n + 255) / 256;
     if (g_ > 2048) g_ = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g_), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, 1.f, 1.f, zero_grad, step_dev);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g_), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, 1.f, 1.f, zero_grad, step_dev, g2);
     return SPLICE_OK;
 }
 __global__ void set_int_kernel(int* p, int v) { *p = v; }

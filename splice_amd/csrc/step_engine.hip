@@ -91,7 +91,8 @@ struct SpliceStep {
     int ablate = 0;                                  // SPLICE_STEP_ABLATE bitmask: TIMING experiments only (results are garbage):
                                                      // 1 skip G fwd, 2 skip G bwd, 4 skip ViT bwd, 8 skip target ViT fwd, 16 skip generated ViT fwd, 32 skip the y' chain of the ViT bwd
     std::map<int, hipGraphExec_t> graphs;
-    void* graph_ptrs[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* graph_ptrs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // arenas + the caller's losses buffer a captured graph is bound to
+    float* losses_out = nullptr;                     // this step's destination of the 8 loss values (written by total_loss_kernel)
     int graph_crops[4] = {0, 0, 0, 0};
     float* grads_b = nullptr;                        // split crops: gradient arena of the B-crop plan (added to `grads` before Adam)
     hipEvent_t ev_gb = nullptr;                      // split crops: G(B_crop) finished on the side stream
@@ -133,7 +134,7 @@ static int view_init(SpliceStep* st, VitView& v, void* ctx, int want_B) {
 
 // raw_k = fixed-order sum of term k's workgroup partials (no float atomics anywhere: replicas are bit-reproducible);
 // total = sum_k lambda_k * raw_k   (util/losses.py:53-71)
-__global__ __launch_bounds__(320) void total_loss_kernel(float* l, float w_ssim, float w_essim, float w_ecls, float w_cls, float w_id) {
+__global__ __launch_bounds__(320) void total_loss_kernel(float* l, float w_ssim, float w_essim, float w_ecls, float w_cls, float w_id, float* out8) {
     __shared__ float raw[8];
     const int k = 1 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave k-1 owns term k (5 waves)
     const float* part = l + 8 + k * SPLICE_MSE_PARTIALS;
@@ -145,6 +146,11 @@ __global__ __launch_bounds__(320) void total_loss_kernel(float* l, float w_ssim,
     if (threadIdx.x == 0) {
         for (int t = 1; t <= 5; ++t) l[t] = raw[t];
         l[L_TOTAL] = w_ssim * raw[L_GLOBAL_SSIM] + w_essim * raw[L_ENTIRE_SSIM] + w_ecls * raw[L_ENTIRE_CLS] + w_cls * raw[L_GLOBAL_CLS] + w_id * raw[L_GLOBAL_ID];
+        if (out8) {   // the caller's losses buffer, written here instead of by a copy behind the step
+            out8[0] = l[L_TOTAL];
+            for (int t = 1; t <= 5; ++t) out8[t] = raw[t];
+            out8[6] = 0.f; out8[7] = 0.f;
+        }
     }
 }
 // All per-step inputs in ONE eager launch in front of the graph replay (three copies + the Adam step count were four
@@ -421,6 +427,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     // the two generated images are independent chains until the generator: one per stream (every launch of a
     // dependent chain pays ~8 us of fixed latency; two chains in flight hide each other's)
     bool loss_summed = false;
+    const float* adam_g2 = nullptr;
     if (!(st->ablate & 4)) {   // (the same launches whether or not the second stream is used: results are bit-identical)
         if (overlap) {
             HIPCHK(hipEventRecord(st->ev_fork, s));
@@ -433,7 +440,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         if (overlap) {
             // the reported loss values depend on nothing downstream: summed at the tail of the side chain instead of
             // between the generator backward and Adam on the critical one
-            hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(320), 0, s2, st->losses, l_ssim, l_essim, l_ecls, l_cls, l_id);
+            hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(320), 0, s2, st->losses, l_ssim, l_essim, l_ecls, l_cls, l_id, st->losses_out);
             loss_summed = true;
             HIPCHK(hipEventRecord(st->ev_join, s2));
         }
@@ -441,7 +448,12 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         RC(unplace_grad(vg.d_imgs + 2 * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, s));
         if (split && !(st->ablate & 2)) RC(splice_gen_backward(st->plan_a, params, st->d_gen_out, grads, 0, s));
         if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
-        if (split && !(st->ablate & 2)) RC(add_f32_launch(grads, st->grads_b, (size_t)st->nparams, s));   // grads = g(A) + g(B)
+        // grads = g(A) + g(B): folded into the Adam kernel on ordinary steps; a separate add when the entire-image branch
+        // still has to accumulate into the sum (same association order either way)
+        if (split && !(st->ablate & 2)) {
+            if (entire) RC(add_f32_launch(grads, st->grads_b, (size_t)st->nparams, s));
+            else adam_g2 = st->grads_b;
+        }
     }
     if (!split && !(st->ablate & 2)) RC(splice_gen_backward(st->plan_g, params, st->d_gen_out, grads, 0, s));
     if (entire) {
@@ -451,9 +463,9 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         RC(unplace_grad(ve.d_imgs + eimg, ve.H, ve.W, st->d_ent_out, c.ent_h, c.ent_w, s));
         RC(splice_gen_backward(st->plan_e, params, st->d_ent_out, grads, 1, s));
     }
-    if (!loss_summed) hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(320), 0, s, st->losses, l_ssim, l_essim, l_ecls, l_cls, l_id);
+    if (!loss_summed) hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(320), 0, s, st->losses, l_ssim, l_essim, l_ecls, l_cls, l_id, st->losses_out);
     // ---- optimizer.step() (train.py:79); Adam's step count (>= 1) is read from the device at execution time
-    RC(adam_launch_dev(params, grads, m, v, (size_t)st->nparams, c.lr, c.beta1, c.beta2, c.eps, st->dev_t, 0, s));
+    RC(adam_launch_dev(params, grads, m, v, (size_t)st->nparams, c.lr, c.beta1, c.beta2, c.eps, st->dev_t, 0, s, adam_g2));
     return SPLICE_OK;
 }
 
@@ -491,7 +503,8 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
     // measured).  So a step whose arenas / crop sizes differ from the previous step's runs eagerly (same kernels, same
     // results) and a graph is captured only from the second consecutive step with identical shapes on.
     {
-        void* ptrs[4] = {params, grads, m, v};
+        void* ptrs[5] = {params, grads, m, v, losses_out};
+        st->losses_out = losses_out;
         const int crops[4] = {c.crop_h, c.crop_w, st->cropb_h, st->cropb_w};
         if (memcmp(ptrs, st->graph_ptrs, sizeof(ptrs)) || memcmp(crops, st->graph_crops, sizeof(crops))) {
             drop_graphs(st);
@@ -564,7 +577,6 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
         }
         HIPCHK(hipGraphLaunch(it->second, s));
     }
-    if (losses_out) HIPCHK(hipMemcpyAsync(losses_out, st->losses, 8 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (own) {
         HIPCHK(hipEventRecord(st->ev_out, s));
         HIPCHK(hipStreamWaitEvent(caller, st->ev_out, 0));
