@@ -14,12 +14,21 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     if (row >= rows) return;
     const int nv = D >> 2;  // float4 per row
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
-    float4 v[MAXV];
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+    float4 v[MAXV], gv[MAXV], bv[MAXV];
     float sum = 0.f;
+    // row, gamma and beta are all requested up front, from clamped addresses under wave-uniform guards (lane-guarded
+    // loads would each wait for their own round trip)
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int idx = lane + 64 * i;
-        v[i] = idx < nv ? xr[idx] : float4{0.f, 0.f, 0.f, 0.f};
+        if (64 * i >= nv) continue;
+        const int j = min(lane + 64 * i, nv - 1);
+        v[i] = xr[j]; gv[i] = g4[j]; bv[i] = b4[j];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (!(64 * i < nv && lane + 64 * i < nv)) v[i] = float4{0.f, 0.f, 0.f, 0.f};
         sum += v[i].x + v[i].y + v[i].z + v[i].w;
     }
     const float mean = wave_sum(sum) / (float)D;
@@ -35,13 +44,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
     if (lane == 0 && mean_o) { mean_o[row] = mean; rstd_o[row] = rstd; }
     uint2* yr = reinterpret_cast<uint2*>(y + (size_t)row * D);
-    const float4* g4 = reinterpret_cast<const float4*>(gamma);
-    const float4* b4 = reinterpret_cast<const float4*>(beta);
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + 64 * i;
         if (idx < nv) {
-            const float4 g = g4[idx], b = b4[idx];
+            const float4 g = gv[i], b = bv[i];
             yr[idx] = uint2{pack2bf((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y),
                             pack2bf((v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w)};
         }
