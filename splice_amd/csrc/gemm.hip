@@ -18,7 +18,8 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
         // otherwise the biggest tile that still yields ~2 workgroups per CU (M = 1600: 128x64 beats 128x128 by 10 %, M = 800: 64x64)
         static const int t2min = getenv("SPLICE_GEMM_T2MIN") ? atoi(getenv("SPLICE_GEMM_T2MIN")) : 400;
         static const int t2ring = getenv("SPLICE_GEMM_T2RING") ? atoi(getenv("SPLICE_GEMM_T2RING")) : 3;
-        tile = (N <= 768 || (FLAGS & EPI_ROWDOT)) ? 3 : t128 >= 640 ? 1 : t12864 >= t2min ? 2 : 3;
+        static const int t1min = getenv("SPLICE_GEMM_T1MIN") ? atoi(getenv("SPLICE_GEMM_T1MIN")) : 640;
+        tile = (N <= 768 || (FLAGS & EPI_ROWDOT)) ? 3 : t128 >= t1min ? 1 : t12864 >= t2min ? 2 : 3;
         // few workgroups walking a long K (fc2, the fc1 / qkv dgrads): the per-slice DMA latency is exposed with 2 stages,
         // the 4-stage ring keeps 3 slices in flight (fc1T 800x768x3072: 23.4 -> 15.3 us); elsewhere its LDS footprint costs occupancy
         const int ks = (FLAGS == EPI_OUT_F32 && e.ksplit > 1 && K % (e.ksplit * GEMM_BK) == 0) ? e.ksplit : 1;
@@ -36,6 +37,16 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
         else if (ring) launch_gemm_nt<64, 64, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e);
         else launch_gemm_nt<64, 64, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e);
     } else {
+        if constexpr (FLAGS == (EPI_BIAS | EPI_RESID | EPI_OUT_F32)) {   // proj forward at M = 2 x 800 (K = 768): one wave of 64x96 tiles (200 workgroups) instead of 300 64x64 ones, in-step -0.4 %;
+            // the same tile for fc2 (K = 3072) measured equal or worse (SPLICE_GEMM_T96: 0 off, 3 both, 5 long-K only, 6 short-K only)
+            static const int t96 = getenv("SPLICE_GEMM_T96") ? atoi(getenv("SPLICE_GEMM_T96")) : 6;
+            const long wg64 = (long)cdiv(M, 64) * cdiv(N, 64), wg96 = (long)cdiv(M, 64) * (N / 96);
+            if (t96 && !(t96 == 5 && K < 1536) && !(t96 == 6 && K >= 1536) && tile == 3 && N % 96 == 0 && wg64 > 256 && wg96 <= 256) {
+                if (K >= 1536 && t96 != 3) launch_gemm_nt<64, 96, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e);
+                else launch_gemm_nt<64, 96, FLAGS, 3>(s, A, lda, B, ldb, M, N, K, e);
+                return SPLICE_OK;
+            }
+        }
         if (tile == 3 && ring == 2) { launch_gemm_nt<64, 64, FLAGS, 3>(s, A, lda, B, ldb, M, N, K, e); return SPLICE_OK; }
         if (tile == 2 && ring == 2) { launch_gemm_nt<128, 64, FLAGS, 3>(s, A, lda, B, ldb, M, N, K, e); return SPLICE_OK; }
         switch (tile * 2 + (ring ? 1 : 0)) {

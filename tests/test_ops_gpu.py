@@ -84,6 +84,21 @@ def test_gemm_forced_tiles_and_rings(force):
         L.splice_gemm_force_tile(0)
 
 
+@pytest.mark.parametrize("K", [768, 3072])
+def test_gemm_one_wave_tiles(K):
+    """2 x 785 tokens, N = 768 with the bias + residual epilogue (proj / fc2 forward): for K = 768 the dispatcher takes one
+    wave of 64x96 tiles (200 workgroups) instead of 300 64x64 ones."""
+    M, N = 1570, 768
+    A, B = _bf(_rand(M, K, seed=21)), _bf(_rand(N, K, seed=22, std=0.05))
+    bias, resid = _rand(N, seed=23), _rand(M, N, seed=24)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    _gemm(_lib.EPI_BIAS | _lib.EPI_RESID | _lib.EPI_OUT_F32, A, B, M, N, K, bias=bias, resid=resid, ldr=N, resid_mod=0, out_f32=out, ldo=N)
+    ref = A.float() @ B.float().T + bias + resid
+    assert torch.isfinite(out).all()
+    assert _relerr(out, ref) < 2e-6, _relerr(out, ref)
+    assert torch.allclose(out[M - 1, 0], ref[M - 1, 0], rtol=1e-4, atol=1e-3) and torch.allclose(out[0, N - 1], ref[0, N - 1], rtol=1e-4, atol=1e-3)
+
+
 def test_gemm_epilogues():
     M, N, K = 785, 768, 768
     A, B = _bf(_rand(M, K, seed=3)), _bf(_rand(N, K, seed=4, std=0.05))
