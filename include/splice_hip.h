@@ -236,7 +236,10 @@ int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void
                        void* gen_plan_global, void* gen_plan_entire, void** out_handle);
 void splice_step_destroy(void* step);
 /* losses_out: device fp32[8] = {loss, loss_global_ssim, loss_entire_ssim, loss_entire_cls,
- * loss_global_cls, loss_global_id_B, 0, 0} -- the keys of the dict LossG.forward returns. */
+ * loss_global_cls, loss_global_id_B, 0, 0} -- the keys of the dict LossG.forward returns.  Written by the step's own
+ * loss kernel; the captured hipGraph is bound to the arena pointers AND to losses_out, so keep passing the same buffers
+ * (a different pointer re-captures; two consecutive steps with identical pointers and crop sizes are needed before a
+ * graph is used at all). */
 int splice_step_run(void* step, float* params, float* grads, float* m, float* v, const float* A_crop,
                     const float* B_crop, const float* A_entire, int step_idx, float* losses_out,
                     splice_stream_t stream);
