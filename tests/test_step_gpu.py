@@ -201,6 +201,37 @@ def test_full_size_step_vs_oracle_and_replay_modes():
         del e2
 
 
+@pytest.mark.parametrize("name,patch,dim,heads", [("dino_vits16", 16, 384, 6), ("dino_vitb16", 16, 768, 12), ("dino_vits8", 8, 384, 6)])
+def test_first_step_vs_oracle_other_dino_variants(name, patch, dim, heads):
+    """The other three DINO variants the reference's `dino_model_name` accepts (models/extractor.py:20), 224x224 pair: first
+    step (CLS warm-up + entire-image branch) against the fp32 CPU oracle, same bars as the ViT-B/8 test above."""
+    from oracle import dino_vit
+    from oracle.step import SpliceOracle
+    from splice_amd.engine import SpliceEngine
+    cfg = dict(dino_model_name=name, dino_global_patch_size=224)
+    A, B = synth.smooth_image_pair(321, 0, 224, 224)
+    vit_state = synth.vit_params(7, name, img_size=224, w_std=0.03)
+    gen_state = synth.generator_params(9, 0.02)
+    eng = SpliceEngine(cfg, vit_state, gen_state, (224, 224), (224, 224))
+    m = dino_vit.VisionTransformer(patch, dim, 12, heads, img_size=224).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in vit_state.items()})
+    orc = SpliceOracle(m, {k: torch.from_numpy(v) for k, v in gen_state.items()}, cfg)
+    At, Bt = torch.from_numpy(A), torch.from_numpy(B)
+    lo, _, og = orc.step(At[None], Bt[None], At[None])
+    eng.step(At.to(DEV), Bt.to(DEV), At.to(DEV))
+    le = eng.losses()
+    assert set(le) == set(lo)
+    for k in lo:
+        assert abs(le[k] - lo[k]) / abs(lo[k]) < 3e-2, (k, le[k], lo[k])
+    num = den = 0.0
+    for (pname, gt), go in zip(eng.gen.unflatten(eng.grads).items(), og):
+        if pname.endswith("0.bias") and pname != "9.0.bias":
+            continue
+        d = (gt.cpu().double() - go.reshape(-1).double()).norm().item()
+        num, den = num + d * d, den + go.double().norm().item() ** 2
+    assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
+
+
 def test_large_size_step_replay_modes_and_vit_parity():
     """BASELINE configs[3] (448x448 pair, ViT-B/8, T = 3137): the long-sequence kernel variants (32 queries per wave,
     separate dQ / dK-dV launches, 128-wide GEMM tiles, interpolated position table).  Size-independent properties:
