@@ -198,6 +198,9 @@ int splice_gen_plan_create(void* gen, int N, int H, int W, int need_grad, void**
 void splice_gen_plan_destroy(void* plan);
 /* y = netG(x) per image (models/model.py:15-23): x,y fp32 [N][3][H][W] */
 int splice_gen_forward(void* plan, const float* params, const float* x, float* y, splice_stream_t stream);
+/* same, without the plan's private copies of x and y (two launches): the caller keeps both buffers unchanged until the
+ * matching splice_gen_backward has run (splice_step_run owns its staged inputs and outputs) */
+int splice_gen_forward_borrowed(void* plan, const float* params, const float* x, float* y, splice_stream_t stream);
 /* parameter gradients of the last forward from dy = dL/dy (autograd backward through netG,
  * train.py:78); grads overwritten, or accumulated when accumulate != 0 */
 int splice_gen_backward(void* plan, const float* params, const float* dy, float* grads, int accumulate,

@@ -89,6 +89,7 @@ _SIGNATURES = {
     "splice_gen_plan_create": ([_vp, _i, _i, _i, _i, C.POINTER(_vp)], _i),
     "splice_gen_plan_destroy": ([_vp], None),
     "splice_gen_forward": ([_vp, _vp, _vp, _vp, _vp], _i),
+    "splice_gen_forward_borrowed": ([_vp, _vp, _vp, _vp, _vp], _i),
     "splice_gen_backward": ([_vp, _vp, _vp, _vp, _i, _vp], _i),
     "splice_adam_step": ([_vp, _vp, _vp, _vp, C.c_longlong, _f, _f, _f, _f, _i, _i, _vp], _i),
     "splice_prof_begin": ([_i], _i),

@@ -87,6 +87,8 @@ struct SpliceGenPlan {
     WgradBatchPair wg;                    // every layer's weight-gradient work of a backward: launched after the dgrad chain
     float* out_copy = nullptr;            // generator output kept for the sigmoid backward
     float* x_copy = nullptr;              // private copy of the input (the caller may free x after forward)
+    const float* x_in = nullptr;          // input of the last forward: x_copy, or the caller's buffer (splice_gen_forward_borrowed)
+    const float* y_saved = nullptr;       // output of the last forward: out_copy, or the caller's buffer
     int forward_saved = 0;
 };
 
@@ -403,12 +405,17 @@ static int scale_forward(SpliceGenPlan* p, int i, const float* params, hipStream
 }
 
 // x [N][3][H][W] in [0,1] -> y [N][3][H][W] in (0,1)   (netG(input), models/model.py:15-23)
-int splice_gen_forward(void* plan, const float* params, const float* x, float* y, splice_stream_t stream) {
+static int gen_forward_impl(void* plan, const float* params, const float* x, float* y, bool borrowed, splice_stream_t stream) {
     SpliceGenPlan* p = (SpliceGenPlan*)plan;
     if (!p || !params || !x || !y) return SPLICE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    RC(dev_copy_launch(p->x_copy, x, (size_t)p->N * 3 * p->H * p->W * sizeof(float), s));
-    p->u_skip[0].in = p->x_copy; p->u_da[0].in = p->x_copy;
+    if (borrowed) {
+        p->x_in = x;
+    } else {
+        RC(dev_copy_launch(p->x_copy, x, (size_t)p->N * 3 * p->H * p->W * sizeof(float), s));
+        p->x_in = p->x_copy;
+    }
+    p->u_skip[0].in = p->x_in; p->u_da[0].in = p->x_in;
     RC(scale_forward(p, 0, params, s));
     {
         const Unit& u = p->u_up1[0];
@@ -420,12 +427,24 @@ int splice_gen_forward(void* plan, const float* params, const float* x, float* y
         RC(conv_launch(a, s));
     }
     if (p->need_grad) {
-        RC(dev_copy_launch(p->out_copy, y, (size_t)p->N * 3 * p->H * p->W * sizeof(float), s));
+        if (borrowed) {
+            p->y_saved = y;
+        } else {
+            RC(dev_copy_launch(p->out_copy, y, (size_t)p->N * 3 * p->H * p->W * sizeof(float), s));
+            p->y_saved = p->out_copy;
+        }
         p->forward_saved = 1;
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { splice_set_error("splice_gen_forward: %s", hipGetErrorString(e)); return SPLICE_ERR_HIP; }
     return SPLICE_OK;
+}
+int splice_gen_forward(void* plan, const float* params, const float* x, float* y, splice_stream_t stream) {
+    return gen_forward_impl(plan, params, x, y, false, stream);
+}
+// x and y stay untouched by the caller until the matching splice_gen_backward has run: no private copies (two launches)
+int splice_gen_forward_borrowed(void* plan, const float* params, const float* x, float* y, splice_stream_t stream) {
+    return gen_forward_impl(plan, params, x, y, true, stream);
 }
 
 static int scale_backward(SpliceGenPlan* p, int i, const float* params, float* grads, int acc, hipStream_t s) {
@@ -459,7 +478,7 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
     const Unit& u = p->u_up1[0];
     const int HW = p->H * p->W;
     (void)npix;
-    RC(sigmoid_bwd_bias_launch(dy, p->out_copy, p->d_head_pre, p->N, 3, HW, p->u_up1[0].s1, grads + p->head_b, accumulate, s));
+    RC(sigmoid_bwd_bias_launch(dy, p->y_saved, p->d_head_pre, p->N, 3, HW, p->u_up1[0].s1, grads + p->head_b, accumulate, s));
     {
         WgradArgs a = {};
         a.x = u.out; a.dy = p->d_head_pre;

@@ -24,6 +24,7 @@ int splice_vit_forward_ex(void* ctx, const float* img, int normalize, int grad_p
 int splice_vit_get_tensor(void* ctx, int kind, int layer, void** out);
 int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* const* d_block, const float* const* d_qkv,
                         const float* const* d_keys, float* d_img, int normalize, splice_stream_t stream);
+int splice_gen_forward_borrowed(void* plan, const float* params, const float* x, float* y, splice_stream_t stream);
 int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams);
 int splice_gen_plan_resize(void* plan, int H, int W);
 int splice_gen_forward(void* plan, const float* params, const float* x, float* y, splice_stream_t stream);
@@ -366,7 +367,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     // unequal crop sizes (random crops): the generator runs as two N=1 plans; G(B_crop) goes first on the side stream so
     // that it runs beside G(A_crop) instead of behind it
     if (split && !(st->ablate & 1)) {
-        RC(splice_gen_forward(st->plan_b, params, B_crop, st->gen_out + crop, s2));
+        RC(splice_gen_forward_borrowed(st->plan_b, params, B_crop, st->gen_out + crop, s2));
         if (overlap) HIPCHK(hipEventRecord(st->ev_gb, s2));
     }
     RC(place_image(A_crop, c.crop_h, c.crop_w, vg.imgs + 0 * vimg, vg.H, vg.W, s2));
@@ -388,9 +389,9 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     // ---- Model.forward: x_global = G(A_crop), y_global = G(B_crop) [, x_entire = G(A)]
     if (st->ablate & 1) {
     } else if (!split) {
-        RC(splice_gen_forward(st->plan_g, params, st->gen_in, st->gen_out, s));
+        RC(splice_gen_forward_borrowed(st->plan_g, params, st->gen_in, st->gen_out, s));
     } else {
-        RC(splice_gen_forward(st->plan_a, params, A_crop, st->gen_out, s));
+        RC(splice_gen_forward_borrowed(st->plan_a, params, A_crop, st->gen_out, s));
         if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_gb, 0));
     }
     RC(place_image(st->gen_out, c.crop_h, c.crop_w, vg.imgs + 2 * vimg, vg.H, vg.W, s));
@@ -409,7 +410,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     if (entire) {
         VitView& ve = st->ve;
         const size_t eimg = (size_t)3 * ve.H * ve.W;
-        RC(splice_gen_forward(st->plan_e, params, A_entire, st->ent_out, s));
+        RC(splice_gen_forward_borrowed(st->plan_e, params, A_entire, st->ent_out, s));
         RC(place_image(A_entire, c.ent_h, c.ent_w, ve.imgs, ve.H, ve.W, s));
         RC(place_image(st->ent_out, c.ent_h, c.ent_w, ve.imgs + eimg, ve.H, ve.W, s));
         RC(splice_vit_forward_ex(ve.ctx, ve.imgs, 1, 1, s));
