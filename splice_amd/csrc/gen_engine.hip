@@ -196,7 +196,7 @@ static void plan_configure(SpliceGenPlan* p, int H, int W) {
     p->forward_saved = 0;
 }
 
-static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* params, hipStream_t s) {
+static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* params, hipStream_t s, const BnUpsample* up = nullptr) {
     const int N = p->N;
     const float* y = u.in;
     size_t y_ns = u.in_ns;
@@ -219,19 +219,20 @@ static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* para
             return SPLICE_OK;
         }
     }
-    RC(bn_fwd_launch(y, y_ns, u.out, u.out_ns, N, u.Cout, u.Ho * u.Wo, params + u.g_off, params + u.be_off, BN_EPS, u.s1, u.mean, u.rstd, u.slope, s));
+    RC(bn_fwd_launch(y, y_ns, u.out, u.out_ns, N, u.Cout, u.Ho * u.Wo, params + u.g_off, params + u.be_off, BN_EPS, u.s1, u.mean, u.rstd, u.slope, s, up));
     return SPLICE_OK;
 }
 
 // backward of one unit: consumes u.d_out, produces parameter grads and (optionally) u.d_in
-static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* params, float* grads, int acc, hipStream_t s) {
+static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* params, float* grads, int acc, hipStream_t s,
+                         const BnUpsample* up = nullptr) {
     const int N = p->N, HW = u.Ho * u.Wo;
     const float* y = u.ks ? u.y : u.in;
     const size_t y_ns = u.ks ? u.y_ns : u.in_ns;
     float* dy = u.ks ? u.dy : u.d_in;          // BN-only unit: dy IS the input gradient
     const size_t dy_ns = u.ks ? u.y_ns : u.d_in_ns;
     RC(bn_bwd_launch(u.d_out, u.d_out_ns, u.out, u.out_ns, y, y_ns, dy, dy_ns, N, u.Cout, HW, params + u.g_off, u.mean, u.rstd, u.slope,
-                     u.s1, grads + u.g_off, grads + u.be_off, acc, s));
+                     u.s1, grads + u.g_off, grads + u.be_off, acc, s, up));
     if (!u.ks) return SPLICE_OK;
     // The bias of a conv that feeds a train-mode BatchNorm has an analytically ZERO gradient (BN subtracts the
     // per-channel mean, sum_p dy = 0); the reference's autograd returns fp32 rounding noise there.  We write the
@@ -397,8 +398,11 @@ static int scale_forward(SpliceGenPlan* p, int i, const float* params, hipStream
         deep = p->u_up1[i + 1].out; deep_ns = p->u_up1[i + 1].out_ns;
     }
     const int hi = p->h[i], wi = p->w[i];
-    RC(upsample2x_fwd_launch(deep, deep_ns, p->cat[i] + (size_t)SKIPC * hi * wi, p->u_skip[i].out_ns, p->N, p->kch[i], p->h[i + 1], p->w[i + 1], hi, wi, s));
-    RC(unit_forward(p, p->u_cat[i], params, s));
+    // nn.Upsample(x2, bilinear) of the deeper branch into channels SKIPC.. of the concat: produced inside the concat's
+    // BatchNorm kernels (bn_fwd_launch with a BnUpsample), not by a launch of its own
+    BnUpsample up;
+    up.src = deep; up.src_ns = deep_ns; up.c0 = SKIPC; up.h = p->h[i + 1]; up.w = p->w[i + 1]; up.Ho = hi; up.Wo = wi;
+    RC(unit_forward(p, p->u_cat[i], params, s, &up));
     RC(unit_forward(p, p->u_up3[i], params, s));
     RC(unit_forward(p, p->u_up1[i], params, s));
     return SPLICE_OK;
@@ -451,11 +455,15 @@ static int scale_backward(SpliceGenPlan* p, int i, const float* params, float* g
     // u_up1[i].d_out holds d u_i
     RC(unit_backward(p, p->u_up1[i], params, grads, acc, s));
     RC(unit_backward(p, p->u_up3[i], params, grads, acc, s));
-    RC(unit_backward(p, p->u_cat[i], params, grads, acc, s));   // -> d_cat[i]
     const int hi = p->h[i], wi = p->w[i];
     Unit& deep = i < 4 ? p->u_up1[i + 1] : p->u_db[i];
-    RC(upsample2x_bwd_launch(p->d_cat[i] + (size_t)SKIPC * hi * wi, p->u_skip[i].d_out_ns, deep.d_out, deep.d_out_ns, p->N, p->kch[i],
-                             p->h[i + 1], p->w[i + 1], hi, wi, s));
+    // small planes: the upsampled channels' gradient goes through the adjoint inside the concat's BatchNorm backward
+    BnUpsample up;
+    up.d_src = deep.d_out; up.d_src_ns = deep.d_out_ns; up.c0 = SKIPC; up.h = p->h[i + 1]; up.w = p->w[i + 1]; up.Ho = hi; up.Wo = wi;
+    RC(unit_backward(p, p->u_cat[i], params, grads, acc, s, &up));   // -> d_cat[i]
+    if (!bn_bwd_fuses_upsample(hi * wi, up.h, up.w))
+        RC(upsample2x_bwd_launch(p->d_cat[i] + (size_t)SKIPC * hi * wi, p->u_skip[i].d_out_ns, deep.d_out, deep.d_out_ns, p->N, p->kch[i],
+                                 p->h[i + 1], p->w[i + 1], hi, wi, s));
     if (i < 4) RC(scale_backward(p, i + 1, params, grads, acc, s));   // leaves d x_{i+1} in u_db[i].d_out
     RC(unit_backward(p, p->u_db[i], params, grads, acc, s));
     RC(unit_backward(p, p->u_da[i], params, grads, acc, s));

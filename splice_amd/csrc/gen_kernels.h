@@ -58,8 +58,18 @@ int wgrad_reduce_all_launch(const WgradReduceAll& d, const float* ws, float* gra
 // train-mode BatchNorm (+LeakyReLU when slope != 1) forward: statistics in two deterministic stages
 // (per-segment partials, recombined in the apply kernel); `part` = bn_part_floats(N, C) floats of scratch.
 int bn_part_floats(int N, int C);
+// Optional fusion of the decoder's x2 bilinear upsampling (models/unet/skip.py: nn.Upsample in front of the concat's
+// BatchNorm) into the BatchNorm kernels of the concat unit: channels >= c0 of the normalised tensor ARE the upsampling of
+// `src`.  Forward: they are computed on the fly (and stored into y for the backward) instead of by a launch of their
+// own; backward (planes <= bn_small_hw() only): their input gradient goes straight through the adjoint into d_src.
+struct BnUpsample {
+    const float* src = nullptr; size_t src_ns = 0;   // [N][C - c0][h][w]
+    float* d_src = nullptr; size_t d_src_ns = 0;
+    int c0 = 0, h = 0, w = 0, Ho = 0, Wo = 0;
+};
+bool bn_bwd_fuses_upsample(int HW, int h, int w);
 int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
-                  const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s);
+                  const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s, const BnUpsample* up = nullptr);
 // same, fused with the split-K reduction of the convolution that feeds it (small planes only: HW <= bn_small_hw()):
 // y = bias + sum_k slabs[k] is formed, stored (the backward reads it) and normalised in one launch
 int bn_small_hw();
@@ -67,7 +77,7 @@ int bn_fwd_slabs_launch(const float* slabs, int ksplit, const float* bias, float
                         int C, int HW, const float* gamma, const float* beta, float eps, float* mean, float* rstd, float slope, hipStream_t s);
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
-                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s);
+                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up = nullptr);
 int fill_zero_launch(float* p, int n, hipStream_t s);
 int channel_sum_launch(const float* dy, size_t nstride, int N, int C, int HW, float* db, int accumulate, hipStream_t s);
 int upsample2x_fwd_launch(const float* in, size_t in_nstride, float* out, size_t out_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s);

@@ -518,15 +518,76 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
 constexpr int MAX_PB = 64;
 __host__ __device__ inline int seg_len(int HW, int PB) { return (HW + PB - 1) / PB; }
 
+// x2 bilinear (align_corners=False) source coordinates of output o, and one upsampled value from a plane p[h][w] (global
+// or LDS): the expression order of upsample2x_fwd_kernel
+__device__ __forceinline__ void up_coord(int o, int n, int& i0, int& i1, float& lam) {
+    float src = ((float)o + 0.5f) * 0.5f - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+    lam = src - (float)i0;
+}
+template <class P>
+__device__ __forceinline__ float up_value(P p, int h, int w, int oy, int ox) {
+    int y0, y1, x0, x1;
+    float ly, lx;
+    up_coord(oy, h, y0, y1, ly);
+    up_coord(ox, w, x0, x1, lx);
+    const float top = p[y0 * w + x0] * (1.f - lx) + p[y0 * w + x1] * lx;
+    const float bot = p[y1 * w + x0] * (1.f - lx) + p[y1 * w + x1] * lx;
+    return top * (1.f - ly) + bot * ly;
+}
+__device__ __forceinline__ void up_adjoint_weights(int m, int n, int No, float (&wt)[4]) {
+    wt[0] = m > 0 ? 0.25f : 0.f;                  // o = 2m-1 (odd output of input m-1, upper neighbour = m)
+    wt[1] = m > 0 ? 0.75f : 1.0f;                 // o = 2m   (source m - 1/4, clamped to 0 at the border)
+    wt[2] = m < n - 1 ? 0.75f : 1.0f;             // o = 2m+1 (source m + 1/4, upper neighbour clamped to n-1)
+    wt[3] = m < n - 1 ? 0.25f : 0.f;              // o = 2m+2 (even output of input m+1, lower neighbour = m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (2 * m - 1 + t >= No) wt[t] = 0.f;
+}
+// adjoint of the above for input pixel (my, mx), read from the output-sized gradient plane p[Ho][Wo] (upsample2x_bwd_kernel)
+template <class P>
+__device__ __forceinline__ float up_adjoint_value(P p, int h, int w, int Ho, int Wo, int my, int mx) {
+    float wy[4], wx[4];
+    up_adjoint_weights(my, h, Ho, wy);
+    up_adjoint_weights(mx, w, Wo, wx);
+    float t[4][4];
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+        const int oy = min(max(2 * my - 1 + ty, 0), Ho - 1);
+#pragma unroll
+        for (int tx = 0; tx < 4; ++tx) t[ty][tx] = p[oy * Wo + min(max(2 * mx - 1 + tx, 0), Wo - 1)];
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+        float row = 0.f;
+#pragma unroll
+        for (int tx = 0; tx < 4; ++tx) row += wx[tx] != 0.f ? wx[tx] * t[ty][tx] : 0.f;
+        acc += wy[ty] != 0.f ? wy[ty] * row : 0.f;
+    }
+    return acc;
+}
 // stage 1 of the BN statistics: per-segment (count, mean, M2), two-pass inside the segment
-__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ y, size_t nstride, int C, int HW, int PB,
-                                                               float* __restrict__ part /* [N][C][PB][2] */) {
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* y, size_t nstride, int C, int HW, int PB,
+                                                               float* __restrict__ part /* [N][C][PB][2] */, BnUpsample up) {
     __shared__ float red[8];
     const int pb = blockIdx.x, c = blockIdx.y, img = blockIdx.z;
     const int seg = seg_len(HW, PB), lo = pb * seg, hi = min(lo + seg, HW);
     const float* p = y + (size_t)img * nstride + (size_t)c * HW;
     float s = 0.f, dummy = 0.f;
-    for (int i = lo + threadIdx.x; i < hi; i += 256) s += p[i];
+    if (up.src && c >= up.c0) {   // upsampled channel: the values are produced here (and stored: the second pass, the apply kernel and the backward read them)
+        const float* sp = up.src + (size_t)img * up.src_ns + (size_t)(c - up.c0) * up.h * up.w;
+        float* yo = const_cast<float*>(p);
+        for (int i = lo + threadIdx.x; i < hi; i += 256) {
+            const float v = up_value(sp, up.h, up.w, i / up.Wo, i % up.Wo);
+            yo[i] = v;
+            s += v;
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) s += p[i];
+    }
     block_sum2(s, dummy, red);
     const int cnt = hi - lo;
     const float m = cnt > 0 ? s / (float)cnt : 0.f;
@@ -679,13 +740,15 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 // pure launch latency -- a kernel boundary costs more than the work.
 constexpr int BN_SMALL_HW = 4096;
 constexpr int BN_SMALL_PER = BN_SMALL_HW / 256;   // plane elements a thread keeps in registers
+constexpr int BN_UP_SRC = 34 * 34;            // low-resolution plane of a fused upsampling staged in LDS (else read from global)
 // slabs != null: the plane is first formed as bias + sum of the feeding convolution's split-K slabs (slice order) and stored to y
-__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restrict__ y, size_t y_nstride, float* __restrict__ out,
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_t y_nstride, float* __restrict__ out,
                                                            size_t out_nstride, int C, int HW, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float* __restrict__ mean_o,
                                                            float* __restrict__ rstd_o, float slope, const float* __restrict__ slabs,
-                                                           int ksplit, const float* __restrict__ bias, float* __restrict__ y_out) {
+                                                           int ksplit, const float* __restrict__ bias, float* __restrict__ y_out, BnUpsample up) {
     __shared__ float red[8];
+    __shared__ float up_src_s[BN_UP_SRC];
     const int c = blockIdx.x, img = blockIdx.y;
     const float* p = y + (size_t)img * y_nstride + (size_t)c * HW;
     float* q = out + (size_t)img * out_nstride + (size_t)c * HW;
@@ -725,6 +788,32 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* __restri
         for (int k = 0; k < BN_SMALL_PER; ++k) {
             const int i = threadIdx.x + k * 256;
             if (i < HW) yo[i] = v[k]; else v[k] = 0.f;
+            s += v[k];
+        }
+    } else if (up.src && c >= up.c0) {
+        // upsampled channel of the concat: the values are produced here from the low-resolution plane (staged through LDS
+        // when it fits) and stored into y for the backward -- the upsampling is not a launch of its own
+        const float* sp = up.src + (size_t)img * up.src_ns + (size_t)(c - up.c0) * up.h * up.w;
+        float* yo = const_cast<float*>(p);
+        const bool in_lds = up.h * up.w <= BN_UP_SRC;
+        if (in_lds) {
+            for (int e = threadIdx.x; e < up.h * up.w; e += 256) up_src_s[e] = sp[e];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < BN_SMALL_PER; ++k) {
+            const int i = threadIdx.x + k * 256;
+            v[k] = 0.f;
+            if (k * 256 < HW) {
+                const int ii = i < HW ? i : HW - 1;
+                const int oy = ii / up.Wo, ox = ii - oy * up.Wo;
+                v[k] = in_lds ? up_value((const float*)up_src_s, up.h, up.w, oy, ox) : up_value(sp, up.h, up.w, oy, ox);
+                if (i < HW) yo[i] = v[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < BN_SMALL_PER; ++k) {
+            if (threadIdx.x + k * 256 >= HW) v[k] = 0.f;
             s += v[k];
         }
     } else {
@@ -801,8 +890,9 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
                                                            float* __restrict__ dy, size_t dy_nstride, int C, int HW, int N,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, float slope, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int accumulate) {
+                                                           float* __restrict__ dbeta, int accumulate, BnUpsample up) {
     __shared__ float red[8];
+    __shared__ float up_grad_s[BN_SMALL_HW];   // fused upsampling adjoint: this plane's input gradient
     const int c = blockIdx.x, img = blockIdx.y;
     float dz[BN_SMALL_PER], xh[BN_SMALL_PER];
     float s1, s2;
@@ -813,10 +903,22 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
         const float k1 = s1 / (float)HW, k2 = s2 / (float)HW;
         const float gr = gamma[c] * r;
         float* po = dy + (size_t)img * dy_nstride + (size_t)c * HW;
+        const bool through_adjoint = up.d_src && c >= up.c0;   // workgroup-uniform
 #pragma unroll
         for (int k = 0; k < BN_SMALL_PER; ++k) {
             const int i = threadIdx.x + k * 256;
-            if (i < HW) po[i] = gr * (dz[k] - k1 - xh[k] * k2);
+            if (i < HW) {
+                const float gv = gr * (dz[k] - k1 - xh[k] * k2);
+                if (through_adjoint) up_grad_s[i] = gv; else po[i] = gv;
+            }
+        }
+        if (through_adjoint) {
+            // this channel is an upsampled one: nobody but the upsampling's adjoint reads its input gradient, so it goes
+            // from LDS straight into the gradient of the low-resolution plane (the arithmetic of upsample2x_bwd_kernel)
+            __syncthreads();
+            float* qd = up.d_src + (size_t)img * up.d_src_ns + (size_t)(c - up.c0) * up.h * up.w;
+            for (int e = threadIdx.x; e < up.h * up.w; e += 256)
+                qd[e] = up_adjoint_value((const float*)up_grad_s, up.h, up.w, up.Ho, up.Wo, e / up.w, e % up.w);
         }
     }
     if (img != 0) return;
@@ -837,31 +939,35 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
 static inline int plane_blocks(int HW) { int b = cdiv(HW, 1024); return b < 1 ? 1 : (b > MAX_PB ? MAX_PB : b); }
 int bn_part_floats(int N, int C) { return N * C * MAX_PB * 2; }
 int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
-                  const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s) {
+                  const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s, const BnUpsample* up) {
+    const BnUpsample u = up ? *up : BnUpsample{};
     if (HW <= BN_SMALL_HW) {
         hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd, slope,
-                           (const float*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
+                           (const float*)nullptr, 0, (const float*)nullptr, (float*)nullptr, u);
         return SPLICE_OK;
     }
     const int PB = plane_blocks(HW);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, C, HW, PB, part);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, C, HW, PB, part, u);
     hipLaunchKernelGGL(bn_act_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, PB, gamma, beta, part, eps, mean, rstd, slope);
     return SPLICE_OK;
 }
+bool bn_bwd_fuses_upsample(int HW, int h, int w) { return HW <= BN_SMALL_HW && h > 0 && w > 0; }
 int bn_small_hw() { return BN_SMALL_HW; }
 int bn_fwd_slabs_launch(const float* slabs, int ksplit, const float* bias, float* y, size_t y_nstride, float* out, size_t out_nstride, int N,
                         int C, int HW, const float* gamma, const float* beta, float eps, float* mean, float* rstd, float slope, hipStream_t s) {
     if (HW > BN_SMALL_HW || ksplit < 2 || !slabs) return SPLICE_ERR_ARG;
     hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C, N), dim3(256), 0, s, (const float*)y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd,
-                       slope, slabs, ksplit, bias, y);
+                       slope, slabs, ksplit, bias, y, BnUpsample{});
     return SPLICE_OK;
 }
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
-                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s) {
+                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up) {
     if (HW <= BN_SMALL_HW) {
+        BnUpsample u = up ? *up : BnUpsample{};
+        if (!bn_bwd_fuses_upsample(HW, u.h, u.w)) u.d_src = nullptr;
         hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy, dy_nstride, C, HW, N,
-                           gamma, mean, rstd, slope, dgamma, dbeta, accumulate);
+                           gamma, mean, rstd, slope, dgamma, dbeta, accumulate, u);
         return SPLICE_OK;
     }
     const int PB = plane_blocks(HW);
@@ -886,37 +992,14 @@ int channel_sum_launch(const float* dy, size_t nstride, int N, int C, int HW, fl
 // ---------------------------------------------------------------------------------------
 // bilinear x2 (align_corners=False) of in[C][h][w] -> the top-left Ho x Wo window of the 2h x 2w
 // result (Concat's centre-crop offset is always 0 here: models/unet/common.py:24-37).
-__device__ __forceinline__ void up_coord(int o, int n, int& i0, int& i1, float& lam) {
-    float src = ((float)o + 0.5f) * 0.5f - 0.5f;
-    src = src < 0.f ? 0.f : src;
-    i0 = (int)src;
-    i1 = i0 + 1 < n ? i0 + 1 : n - 1;
-    lam = src - (float)i0;
-}
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ in, size_t in_nstride, float* __restrict__ out,
                                                              size_t out_nstride, int C, int h, int w, int Ho, int Wo) {
     const int c = blockIdx.y, img = blockIdx.z;
     const float* p = in + (size_t)img * in_nstride + (size_t)c * h * w;
     float* q = out + (size_t)img * out_nstride + (size_t)c * Ho * Wo;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < Ho * Wo; i += gridDim.x * 256) {
-        const int oy = i / Wo, ox = i % Wo;
-        int y0, y1, x0, x1;
-        float ly, lx;
-        up_coord(oy, h, y0, y1, ly);
-        up_coord(ox, w, x0, x1, lx);
-        const float top = p[y0 * w + x0] * (1.f - lx) + p[y0 * w + x1] * lx;
-        const float bot = p[y1 * w + x0] * (1.f - lx) + p[y1 * w + x1] * lx;
-        q[i] = top * (1.f - ly) + bot * ly;
+        q[i] = up_value(p, h, w, i / Wo, i % Wo);
     }
-}
-__device__ __forceinline__ void up_adjoint_weights(int m, int n, int No, float (&wt)[4]) {
-    wt[0] = m > 0 ? 0.25f : 0.f;                  // o = 2m-1 (odd output of input m-1, upper neighbour = m)
-    wt[1] = m > 0 ? 0.75f : 1.0f;                 // o = 2m   (source m - 1/4, clamped to 0 at the border)
-    wt[2] = m < n - 1 ? 0.75f : 1.0f;             // o = 2m+1 (source m + 1/4, upper neighbour clamped to n-1)
-    wt[3] = m < n - 1 ? 0.25f : 0.f;              // o = 2m+2 (even output of input m+1, lower neighbour = m)
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-        if (2 * m - 1 + t >= No) wt[t] = 0.f;
 }
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dout, size_t dout_nstride, float* __restrict__ din,
                                                              size_t din_nstride, int C, int h, int w, int Ho, int Wo) {
@@ -924,31 +1007,11 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
     const float* p = dout + (size_t)img * dout_nstride + (size_t)c * Ho * Wo;
     float* q = din + (size_t)img * din_nstride + (size_t)c * h * w;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < h * w; i += gridDim.x * 256) {
-        const int my = i / w, mx = i % w;
         // adjoint weights of the x2 bilinear (align_corners=False) in closed form: output o = 2m-1+t, t = 0..3, reads input m
         // with weight {1/4, 3/4, 3/4, 1/4}; at the borders the clamped source index folds the missing neighbour's share
-        // in (o = 0 and o = 2n-1 read their input pixel with weight 1), and outputs outside the Ho x Wo window do not exist
-        float wy[4], wx[4];
-        up_adjoint_weights(my, h, Ho, wy);
-        up_adjoint_weights(mx, w, Wo, wx);
-        // all 16 taps are loaded unconditionally from clamped coordinates (a zero weight marks the taps that do not
-        // exist; guarded loads would serialise into 16 memory round trips)
-        float t[4][4];
-#pragma unroll
-        for (int ty = 0; ty < 4; ++ty) {
-            const int oy = min(max(2 * my - 1 + ty, 0), Ho - 1);
-#pragma unroll
-            for (int tx = 0; tx < 4; ++tx) t[ty][tx] = p[oy * Wo + min(max(2 * mx - 1 + tx, 0), Wo - 1)];
-        }
-        float acc = 0.f;
-#pragma unroll
-        for (int ty = 0; ty < 4; ++ty) {
-            float row = 0.f;
-#pragma unroll
-            for (int tx = 0; tx < 4; ++tx) row += wx[tx] != 0.f ? wx[tx] * t[ty][tx] : 0.f;
-            acc += wy[ty] != 0.f ? wy[ty] * row : 0.f;
-        }
-        q[i] = acc;
+        // in (o = 0 and o = 2n-1 read their input pixel with weight 1), and outputs outside the Ho x Wo window do not exist.
+        // All 16 taps are loaded unconditionally from clamped coordinates (a zero weight marks the taps that do not exist).
+        q[i] = up_adjoint_value(p, h, w, Ho, Wo, i / w, i % w);
     }
 }
 int upsample2x_fwd_launch(const float* in, size_t in_nstride, float* out, size_t out_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s) {
