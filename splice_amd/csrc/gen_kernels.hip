@@ -6,6 +6,7 @@
 // up-sampling written straight into the concat buffer, sigmoid head.  Every reduction runs
 // in a fixed order (no float atomics): replicas are bit-reproducible.
 #include "gen_kernels.h"
+#include <cstdlib>
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     // A: lane l holds A[i = l&15][k = l>>4];  B: lane l holds B[k = l>>4][n = l&15]
@@ -226,8 +227,10 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
     int ksplit = 1;
     const int ktiles = cdiv(a.Cin, CK);
     if (a.ws && wgs < 128 && ktiles >= 4 && (size_t)a.N * a.Cout * HWo * 16 <= a.ws_floats) {
+        // down to ONE channel tile per slice: in-step (cold caches, latency-bound) more, shorter workgroups win 0.5 % over
+        // two tiles per slice, although the second tile's loads would overlap the first one's MFMAs
         ksplit = cdiv(256, wgs);
-        if (ksplit > ktiles / 2) ksplit = ktiles / 2;
+        if (ksplit > ktiles) ksplit = ktiles;
         if (ksplit > 16) ksplit = 16;
         if (ksplit < 2) ksplit = 1;
     }
