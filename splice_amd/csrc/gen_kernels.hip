@@ -229,7 +229,7 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
     if (a.ws && wgs < 128 && ktiles >= 4 && (size_t)a.N * a.Cout * HWo * 16 <= a.ws_floats) {
         // down to ONE channel tile per slice: in-step (cold caches, latency-bound) more, shorter workgroups win 0.5 % over
         // two tiles per slice, although the second tile's loads would overlap the first one's MFMAs
-        ksplit = cdiv(256, wgs);
+        ksplit = cdiv(256, wgs);   // (a target of 512 workgroups loses 0.4 %)
         if (ksplit > ktiles) ksplit = ktiles;
         if (ksplit > 16) ksplit = 16;
         if (ksplit < 2) ksplit = 1;
@@ -420,8 +420,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(WgradReduceAll d,
 
 int wgrad_chunks(int N, int Ho, int Wo, int* pix_per_chunk, int* chunks_per_img) {
     const int HWo = Ho * Wo;
+    // tuned in-step with alternating runs (512 / 256 / 64; 1024 or 256 for the big planes and 128 or 512 for the middle ones lose 0.2-0.4 %)
     int ppc = 512;
-    if (HWo <= 1024) ppc = 128;
+    if (HWo <= 1024) ppc = 256;
     if (HWo <= 256) ppc = 64;
     *pix_per_chunk = ppc;
     *chunks_per_img = cdiv(HWo, ppc);
