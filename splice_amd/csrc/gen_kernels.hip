@@ -221,7 +221,10 @@ template <int KS, bool TR, int CK>
 static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
     const int HWo = a.Ho * a.Wo;
     const int mt = cdiv(HWo, 64);
-    const int fn = a.Cout <= 16 ? 1 : (a.Cout <= 32 ? 2 : 4);
+    // output-channel fragments per workgroup, tuned in-step with alternating runs: the 64 / 128-channel layers of the deep
+    // scales run fastest with ONE 16-channel fragment per workgroup (FN = 4: +2.2 %, FN = 2: +0.6 %) -- these launches are
+    // latency-bound and more, smaller workgroups shorten them; the 32-channel layers are indifferent (2 kept)
+    const int fn = (a.Cout > 16 && a.Cout <= 32) ? 2 : 1;
     const int nt = cdiv(a.Cout, 16 * fn);
     const int wgs = mt * nt * a.N;
     int ksplit = 1;
@@ -229,7 +232,7 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
     if (a.ws && wgs < 128 && ktiles >= 4 && (size_t)a.N * a.Cout * HWo * 16 <= a.ws_floats) {
         // down to ONE channel tile per slice: in-step (cold caches, latency-bound) more, shorter workgroups win 0.5 % over
         // two tiles per slice, although the second tile's loads would overlap the first one's MFMAs
-        ksplit = cdiv(256, wgs);   // (a target of 512 workgroups loses 0.4 %)
+        ksplit = cdiv(256, wgs);   // (targets of 128 / 384 / 512 workgroups lose 0.3-0.6 %, splitting grids of up to 256 loses 0.8 %)
         if (ksplit > ktiles) ksplit = ktiles;
         if (ksplit > 16) ksplit = 16;
         if (ksplit < 2) ksplit = 1;
