@@ -83,11 +83,27 @@ def validate(sd, model_name):
             raise ValueError(f"DINO checkpoint is not a {model_name}: {n} has shape {tuple(sd[n].shape)}, expected {shp}")
 
 
+def _load_pickle(path):
+    """``torch.load`` with ``weights_only`` stated explicitly.  Backbone-only files (``dino_*_pretrain.pth``) are plain
+    tensor dicts.  The ``*_full_checkpoint.pth`` files additionally pickle the training ``argparse.Namespace``: those are
+    retried with Namespace allow-listed (still no arbitrary code execution)."""
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as first:
+        import argparse
+        try:
+            with torch.serialization.safe_globals([argparse.Namespace]):
+                return torch.load(path, map_location="cpu", weights_only=True)
+        except Exception:
+            raise ValueError(f"{path}: cannot be read as a tensor-only checkpoint ({type(first).__name__}: {first}); "
+                             "re-save it as a plain state dict (torch.save(model.state_dict(), ...))") from first
+
+
 def load_dino_checkpoint(path, model_name=None):
     """Read ``path`` and return ``(model_name, state)`` with ``state`` = ordered {name: fp32 numpy array} ready for
     ``VitEngine.load_state_dict``.  ``model_name`` (one of DINO_CONFIGS) is checked against the file when given and
     inferred from the shapes otherwise."""
-    obj = torch.load(path, map_location="cpu")
+    obj = _load_pickle(path)
     sd = normalize_state_dict(obj)
     if "cls_token" not in sd or "patch_embed.proj.weight" not in sd:
         raise ValueError(f"{path}: not a DINO VisionTransformer checkpoint (no cls_token / patch_embed.proj.weight)")

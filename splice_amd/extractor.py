@@ -105,6 +105,7 @@ class VitExtractor:
 
     def __init__(self, model_name, device, state_dict=None, checkpoint=None, synthetic=None, seed=1234, engine=None):
         self.model_name = model_name
+        self._arch = _arch_of(model_name)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("VitExtractor (HIP engine) needs a GPU device; there is no CPU fallback")
@@ -168,38 +169,38 @@ class VitExtractor:
         self._release(vctx)
         return out
 
+    # ---- shape helpers + q/k/v slicing (models/extractor.py:105-156) -------------------------------------------------
+    # The reference derives (patch, heads, width) from sub-strings of the model name on every call; the four DINO names it
+    # documents are a table here, any other name goes through the same sub-string rules once (`_arch_of`).
     def get_patch_size(self):
-        return 8 if "8" in self.model_name else 16
-
-    def get_width_patch_num(self, input_img_shape):
-        b, c, h, w = input_img_shape
-        patch_size = self.get_patch_size()
-        return w // patch_size
-
-    def get_height_patch_num(self, input_img_shape):
-        b, c, h, w = input_img_shape
-        patch_size = self.get_patch_size()
-        return h // patch_size
-
-    def get_patch_num(self, input_img_shape):
-        patch_num = 1 + (self.get_height_patch_num(input_img_shape) * self.get_width_patch_num(input_img_shape))
-        return patch_num
+        return self._arch[0]
 
     def get_head_num(self):
-        if "dino" in self.model_name:
-            return 6 if "s" in self.model_name else 12
-        return 6 if "small" in self.model_name else 12
+        return self._arch[1]
 
     def get_embedding_dim(self):
-        if "dino" in self.model_name:
-            return 384 if "s" in self.model_name else 768
-        return 384 if "small" in self.model_name else 768
+        return self._arch[2]
+
+    def _grid(self, input_img_shape):
+        """(patch rows, patch columns) of a ``[b,c,h,w]`` shape."""
+        p = self._arch[0]
+        return input_img_shape[2] // p, input_img_shape[3] // p
+
+    def get_height_patch_num(self, input_img_shape):
+        return self._grid(input_img_shape)[0]
+
+    def get_width_patch_num(self, input_img_shape):
+        return self._grid(input_img_shape)[1]
+
+    def get_patch_num(self, input_img_shape):
+        rows, cols = self._grid(input_img_shape)
+        return rows * cols + 1          # + [CLS]
 
     def _split(self, qkv, input_img_shape, which):
-        patch_num = self.get_patch_num(input_img_shape)
-        head_num = self.get_head_num()
-        embedding_dim = self.get_embedding_dim()
-        return qkv.reshape(patch_num, 3, head_num, embedding_dim // head_num).permute(1, 2, 0, 3)[which]
+        """Slice ``which`` (0 q, 1 k, 2 v) of a raw qkv ``[1,T,3D]`` as ``[heads,T,head_dim]`` (batch 1 only)."""
+        _, heads, width = self._arch
+        tokens = self.get_patch_num(input_img_shape)
+        return qkv.reshape(tokens, 3, heads, width // heads)[:, which].transpose(0, 1)
 
     def get_queries_from_qkv(self, qkv, input_img_shape):
         return self._split(qkv, input_img_shape, 0)
@@ -211,13 +212,28 @@ class VitExtractor:
         return self._split(qkv, input_img_shape, 2)
 
     def get_keys_from_input(self, input_img, layer_num):
-        qkv_features = self.get_qkv_feature_from_input(input_img)[layer_num]
-        keys = self.get_keys_from_qkv(qkv_features, input_img.shape)
-        return keys
+        raw = self.get_qkv_feature_from_input(input_img)[layer_num]
+        return self.get_keys_from_qkv(raw, input_img.shape)
 
     def get_keys_self_sim_from_input(self, input_img, layer_num):
-        keys = self.get_keys_from_input(input_img, layer_num=layer_num)
-        h, t, d = keys.shape
-        concatenated_keys = keys.transpose(0, 1).reshape(t, h * d)
-        ssim_map = attn_cosine_sim(concatenated_keys[None, None, ...])
-        return ssim_map
+        """Cosine self-similarity of the layer's keys with the heads laid side by side (models/extractor.py:158-163)."""
+        per_head = self.get_keys_from_input(input_img, layer_num=layer_num)          # [heads, T, d]
+        tokens = per_head.shape[1]
+        token_major = per_head.permute(1, 0, 2).reshape(1, 1, tokens, -1)            # [1, 1, T, heads*d]
+        return attn_cosine_sim(token_major)
+
+
+_DINO_ARCH = {  # model name -> (patch size, heads, embedding width)
+    "dino_vits16": (16, 6, 384), "dino_vits8": (8, 6, 384),
+    "dino_vitb16": (16, 12, 768), "dino_vitb8": (8, 12, 768),
+}
+
+
+def _arch_of(model_name):
+    """Architecture triple of a model name.  Unknown names follow the reference's sub-string conventions
+    (models/extractor.py:105-130): an '8' anywhere means patch 8, and the small variant is flagged by an 's' in a dino name
+    or by the word 'small' otherwise."""
+    if model_name in _DINO_ARCH:
+        return _DINO_ARCH[model_name]
+    small = ("s" in model_name) if "dino" in model_name else ("small" in model_name)
+    return (8 if "8" in model_name else 16,) + ((6, 384) if small else (12, 768))

@@ -23,6 +23,27 @@ device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 _MEAN = (0.485, 0.456, 0.406)
 _STD = (0.229, 0.224, 0.225)
 
+# feature name -> reader(extractor, normalised image [1,3,H,W], layer)
+_FEATURE_READERS = {
+    "cls": lambda ext, img, layer: ext.get_feature_from_input(img)[layer][:, 0, :],    # [CLS] row of the block output
+    "keys": lambda ext, img, layer: ext.get_keys_from_input(img, layer),               # [heads, T, 64]
+}
+_REQUIRED = object()
+_CLI = (  # (flag, type, default, help)
+    ("feature", str, None, "which feature to invert: " + " | ".join(sorted(_FEATURE_READERS))),
+    ("layer", int, 11, "index of the transformer block the feature is read from (0..11)"),
+    ("dino_model_name", str, "dino_vitb8", "dino_vit{s,b}{8,16}"),
+    ("image_path", str, "datasets/feature_visualization/limes.jpeg", "image whose feature is inverted"),
+    ("save_path", str, _REQUIRED, "where the reconstructed image is written"),
+    ("log_freq", int, 100, "write the current reconstruction every this many iterations"),
+    ("input_depth", int, 32, "channels of the fixed noise the generator is fed with"),
+    ("LR", float, 0.01, "Adam learning rate"),
+    ("n_iter", int, 20000, "optimisation steps"),
+    ("reduce_noise_stage_1_iter", int, 10000, "[cls] input-noise amplitude 10 -> 2 at this iteration"),
+    ("reduce_noise_stage_2_iter", int, 15000, "[cls] input-noise amplitude 2 -> 0.5 at this iteration"),
+    ("checkpoint", str, None, "local DINO .pth (default: $SPLICE_DINO_CHECKPOINT)"),
+)
+
 
 def make_net(input_depth):
     """``inversion.py:21-25``."""
@@ -45,13 +66,12 @@ def invert(args, callback=None):
     std = torch.tensor(_STD, device=device).view(1, 3, 1, 1)
     ext = VitExtractor(args.dino_model_name, device, checkpoint=getattr(args, "checkpoint", None), synthetic=getattr(args, "synthetic", False))
 
+    if args.feature not in _FEATURE_READERS:
+        raise ValueError(f"unknown --feature {args.feature!r}: choose one of {sorted(_FEATURE_READERS)}")
+    read = _FEATURE_READERS[args.feature]
+
     def extract_feature(x):   # the image is already 224 on its short edge: Resize(224) of inversion.py:29 is the identity
-        x = (x - mean) / std
-        if args.feature == 'cls':
-            return ext.get_feature_from_input(x)[args.layer][:, 0, :]
-        if args.feature == 'keys':
-            return ext.get_keys_from_input(x, args.layer)
-        raise ValueError('feature {} not supported.'.format(args.feature))
+        return read(ext, (x - mean) / std, args.layer)
 
     with torch.no_grad():
         ref_feature = extract_feature(input_img)
@@ -76,19 +96,19 @@ def invert(args, callback=None):
     return losses
 
 
+def build_parser():
+    """Same flags and defaults as the reference script (``inversion.py:78-92``) plus the two weight-source flags."""
+    parser = ArgumentParser(description="Invert a DINO-ViT feature back to an image on the MI355X engine.")
+    for flag, kind, default, doc in _CLI:
+        kw = dict(type=kind, help=doc)
+        if default is _REQUIRED:
+            kw["required"] = True
+        else:
+            kw["default"] = default
+        parser.add_argument("--" + flag, **kw)
+    parser.add_argument("--synthetic", action="store_true", help="use the seeded synthetic ViT weights (smoke tests only)")
+    return parser
+
+
 if __name__ == '__main__':
-    parser = ArgumentParser()
-    parser.add_argument("--feature", type=str, help='DINO-ViT feature to invert. options: cls | keys')
-    parser.add_argument("--layer", type=int, default=11, help='Transformer layer from which to extract the feature, between 0-11')
-    parser.add_argument("--dino_model_name", type=str, default='dino_vitb8')
-    parser.add_argument("--image_path", type=str, default='datasets/feature_visualization/limes.jpeg', help='path to the image to be used for the inversion.')
-    parser.add_argument("--save_path", type=str, required=True, help='path to save the result.')
-    parser.add_argument("--log_freq", type=int, default=100)
-    parser.add_argument("--input_depth", type=int, default=32)
-    parser.add_argument("--LR", type=float, default=0.01)
-    parser.add_argument("--n_iter", type=int, default=20000)
-    parser.add_argument("--reduce_noise_stage_1_iter", type=int, default=10000)
-    parser.add_argument("--reduce_noise_stage_2_iter", type=int, default=15000)
-    parser.add_argument("--checkpoint", type=str, default=None, help='local DINO .pth (default: $SPLICE_DINO_CHECKPOINT)')
-    parser.add_argument("--synthetic", action="store_true", help='seeded synthetic weights (smoke tests)')
-    invert(parser.parse_args())
+    invert(build_parser().parse_args())

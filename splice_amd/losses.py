@@ -52,82 +52,76 @@ class GlobalTransform:
         return (img - mean) / std
 
 
+# One row per entry of the dict LossG.forward returns (util/losses.py:46-72), in the reference's evaluation order:
+# (dict key, lambda name, feature compared, key of the generated batch in `outputs`, key of the target batch in `inputs`)
+_TERMS = (
+    ("loss_global_ssim", "lambda_global_ssim", "self_sim", "x_global", "A_global"),
+    ("loss_entire_ssim", "lambda_entire_ssim", "self_sim", "x_entire", "A"),
+    ("loss_entire_cls", "lambda_entire_cls", "cls", "x_entire", "B_global"),
+    ("loss_global_cls", "lambda_global_cls", "cls", "x_global", "B_global"),
+    ("loss_global_id_B", "lambda_global_identity", "keys", "y_global", "B_global"),
+)
+_SCHEDULED_AT_WARMUP = ("lambda_global_ssim", "lambda_global_identity")
+_SCHEDULED_PERIODIC = ("lambda_entire_ssim", "lambda_entire_cls")
+_LAST_LAYER = 11
+
+
 class LossG(torch.nn.Module):
+    """``util/losses.py:11-105``.  The five terms are rows of ``_TERMS``; each compares ONE DINO feature of a generated
+    image with the same feature of a target image (no gradient into the target) crop by crop, and the three public
+    ``calculate_*`` methods are that comparison with the feature fixed."""
+
     def __init__(self, cfg, extractor=None, **extractor_kwargs):
         super().__init__()
         self.cfg = cfg
         self.extractor = extractor or VitExtractor(model_name=cfg['dino_model_name'], device=device, **extractor_kwargs)
         self.global_transform = GlobalTransform(cfg['dino_global_patch_size'], max_size=480)
-        self.lambdas = dict(
-            lambda_global_cls=cfg['lambda_global_cls'],
-            lambda_global_ssim=0,
-            lambda_entire_ssim=0,
-            lambda_entire_cls=0,
-            lambda_global_identity=0
-        )
+        # only the [CLS] appearance term is live before the warm-up step (util/losses.py:25-32)
+        self.lambdas = {name: 0 for _, name, _, _, _ in _TERMS}
+        self.lambdas['lambda_global_cls'] = cfg['lambda_global_cls']
+        self._features = {
+            "self_sim": lambda img: self.extractor.get_keys_self_sim_from_input(img, layer_num=_LAST_LAYER),
+            "cls": lambda img: self.extractor.get_feature_from_input(img)[-1][0, 0, :],
+            "keys": lambda img: self.extractor.get_keys_from_input(img, _LAST_LAYER),
+        }
 
     def update_lambda_config(self, step):
-        if step == self.cfg['cls_warmup']:
-            self.lambdas['lambda_global_ssim'] = self.cfg['lambda_global_ssim']
-            self.lambdas['lambda_global_identity'] = self.cfg['lambda_global_identity']
-        if step % self.cfg['entire_A_every'] == 0:
-            self.lambdas['lambda_entire_ssim'] = self.cfg['lambda_entire_ssim']
-            self.lambdas['lambda_entire_cls'] = self.cfg['lambda_entire_cls']
-        else:
-            self.lambdas['lambda_entire_ssim'] = 0
-            self.lambdas['lambda_entire_cls'] = 0
+        """Lambda schedule of util/losses.py:34-44: structure + identity terms are switched on for good at
+        ``cls_warmup``; the entire-image terms are live only on multiples of ``entire_A_every``."""
+        cfg = self.cfg
+        if step == cfg['cls_warmup']:
+            self.lambdas.update((name, cfg[name]) for name in _SCHEDULED_AT_WARMUP)
+        entire_step = step % cfg['entire_A_every'] == 0
+        self.lambdas.update((name, cfg[name] if entire_step else 0) for name in _SCHEDULED_PERIODIC)
 
     def forward(self, outputs, inputs):
         self.update_lambda_config(int(inputs['step']))
-        losses = {}
-        loss_G = 0
-        if self.lambdas['lambda_global_ssim'] > 0:
-            losses['loss_global_ssim'] = self.calculate_global_ssim_loss(outputs['x_global'], inputs['A_global'])
-            loss_G += losses['loss_global_ssim'] * self.lambdas['lambda_global_ssim']
-        if self.lambdas['lambda_entire_ssim'] > 0:
-            losses['loss_entire_ssim'] = self.calculate_global_ssim_loss(outputs['x_entire'], inputs['A'])
-            loss_G += losses['loss_entire_ssim'] * self.lambdas['lambda_entire_ssim']
-        if self.lambdas['lambda_entire_cls'] > 0:
-            losses['loss_entire_cls'] = self.calculate_crop_cls_loss(outputs['x_entire'], inputs['B_global'])
-            loss_G += losses['loss_entire_cls'] * self.lambdas['lambda_entire_cls']
-        if self.lambdas['lambda_global_cls'] > 0:
-            losses['loss_global_cls'] = self.calculate_crop_cls_loss(outputs['x_global'], inputs['B_global'])
-            loss_G += losses['loss_global_cls'] * self.lambdas['lambda_global_cls']
-        if self.lambdas['lambda_global_identity'] > 0:
-            losses['loss_global_id_B'] = self.calculate_global_id_loss(outputs['y_global'], inputs['B_global'])
-            loss_G += losses['loss_global_id_B'] * self.lambdas['lambda_global_identity']
-        losses['loss'] = loss_G
+        losses, total = {}, 0
+        for key, lam_name, feature, out_key, in_key in _TERMS:
+            lam = self.lambdas[lam_name]
+            if lam > 0:
+                losses[key] = self._feature_mse(feature, outputs[out_key], inputs[in_key])
+                total = total + lam * losses[key]
+        losses['loss'] = total
         return losses
 
-    def calculate_global_ssim_loss(self, outputs, inputs):
-        loss = 0.0
-        for a, b in zip(inputs, outputs):  # one crop at a time, as the reference
-            a = self.global_transform(a)
-            b = self.global_transform(b)
+    def _feature_mse(self, feature, generated, targets):
+        """sum over crops of mse(feature(T(generated_i)), feature(T(target_i))), target side under no_grad."""
+        f = self._features[feature]
+        acc = 0.0
+        for gen_img, tgt_img in zip(generated, targets):   # one crop at a time: the extractor is batch-1
             with torch.no_grad():
-                target_keys_self_sim = self.extractor.get_keys_self_sim_from_input(a.unsqueeze(0), layer_num=11)
-            keys_ssim = self.extractor.get_keys_self_sim_from_input(b.unsqueeze(0), layer_num=11)
-            loss += F.mse_loss(keys_ssim, target_keys_self_sim)
-        return loss
+                want = f(self.global_transform(tgt_img).unsqueeze(0).to(device))
+            got = f(self.global_transform(gen_img).unsqueeze(0).to(device))
+            acc = acc + F.mse_loss(got, want)
+        return acc
+
+    # the reference's public per-term entry points (argument order as in util/losses.py:74,85,96)
+    def calculate_global_ssim_loss(self, outputs, inputs):
+        return self._feature_mse("self_sim", outputs, inputs)
 
     def calculate_crop_cls_loss(self, outputs, inputs):
-        loss = 0.0
-        for a, b in zip(outputs, inputs):
-            a = self.global_transform(a).unsqueeze(0).to(device)
-            b = self.global_transform(b).unsqueeze(0).to(device)
-            cls_token = self.extractor.get_feature_from_input(a)[-1][0, 0, :]
-            with torch.no_grad():
-                target_cls_token = self.extractor.get_feature_from_input(b)[-1][0, 0, :]
-            loss += F.mse_loss(cls_token, target_cls_token)
-        return loss
+        return self._feature_mse("cls", outputs, inputs)
 
     def calculate_global_id_loss(self, outputs, inputs):
-        loss = 0.0
-        for a, b in zip(inputs, outputs):
-            a = self.global_transform(a)
-            b = self.global_transform(b)
-            with torch.no_grad():
-                keys_a = self.extractor.get_keys_from_input(a.unsqueeze(0), 11)
-            keys_b = self.extractor.get_keys_from_input(b.unsqueeze(0), 11)
-            loss += F.mse_loss(keys_a, keys_b)
-        return loss
+        return self._feature_mse("keys", outputs, inputs)

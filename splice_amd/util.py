@@ -7,57 +7,63 @@ import torch
 from torch.optim import lr_scheduler
 
 
+# ---- scheduler / optimizer factories -------------------------------------------------------------------------------------
+# One entry per policy the reference's config accepts (util/util.py:8-39).  Each builder gets the optimizer and the keyword
+# arguments of get_scheduler and returns a torch.optim.lr_scheduler object with the reference's hyper-parameters.
+def _linear_decay(opt, n_epochs_decay=None, **_):
+    span = float(n_epochs_decay + 1)
+    return lr_scheduler.LambdaLR(opt, lr_lambda=lambda epoch: max(1.0 - max(0, epoch) / span, 0))
+
+
+_SCHEDULERS = {
+    'linear': _linear_decay,
+    'step': lambda opt, lr_decay_iters=None, **_: lr_scheduler.StepLR(opt, step_size=lr_decay_iters, gamma=0.5),
+    'plateau': lambda opt, **_: lr_scheduler.ReduceLROnPlateau(opt, mode='min', factor=0.2, threshold=0.01, patience=5),
+    'cosine': lambda opt, n_epochs=None, **_: lr_scheduler.CosineAnnealingLR(opt, T_max=n_epochs, eta_min=0),
+    'none': lambda opt, **_: lr_scheduler.LambdaLR(opt, lr_lambda=lambda _epoch: 1),
+}
+_OPTIMIZERS = {
+    'adam': lambda cfg, params: torch.optim.Adam(params, lr=cfg['lr'], betas=(cfg['optimizer_beta1'], cfg['optimizer_beta2'])),
+    'rmsprop': lambda cfg, params: torch.optim.RMSprop(params, lr=cfg['lr']),
+    'sgd': lambda cfg, params: torch.optim.SGD(params, lr=cfg['lr']),
+}
+
+
 def get_scheduler(optimizer, lr_policy, n_epochs=None, n_epochs_decay=None, lr_decay_iters=None):
-    """``util/util.py:8-25``.  Unknown policies RETURN NotImplementedError, as the reference does."""
-    if lr_policy == 'linear':
-        def lambda_rule(epoch):
-            lr_l = 1.0 - max(0, epoch) / float(n_epochs_decay + 1)
-            return max(lr_l, 0)
-        scheduler = lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda_rule)
-    elif lr_policy == 'step':
-        scheduler = lr_scheduler.StepLR(optimizer, step_size=lr_decay_iters, gamma=0.5)
-    elif lr_policy == 'plateau':
-        scheduler = lr_scheduler.ReduceLROnPlateau(optimizer, mode='min', factor=0.2, threshold=0.01, patience=5)
-    elif lr_policy == 'cosine':
-        scheduler = lr_scheduler.CosineAnnealingLR(optimizer, T_max=n_epochs, eta_min=0)
-    elif lr_policy == 'none':
-        scheduler = lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda x: 1)
-    else:
+    """``util/util.py:8-25``.  An unknown policy RETURNS (does not raise) a NotImplementedError, as the reference does."""
+    build = _SCHEDULERS.get(lr_policy)
+    if build is None:
         return NotImplementedError('learning rate policy [%s] is not implemented', lr_policy)
-    return scheduler
+    return build(optimizer, n_epochs=n_epochs, n_epochs_decay=n_epochs_decay, lr_decay_iters=lr_decay_iters)
 
 
 def get_optimizer(cfg, params):
-    """``util/util.py:28-39``."""
-    if cfg['optimizer'] == 'adam':
-        optimizer = torch.optim.Adam(params, lr=cfg['lr'], betas=(cfg['optimizer_beta1'], cfg['optimizer_beta2']))
-    elif cfg['optimizer'] == 'rmsprop':
-        optimizer = torch.optim.RMSprop(params, lr=cfg['lr'])
-    elif cfg['optimizer'] == 'sgd':
-        optimizer = torch.optim.SGD(params, lr=cfg['lr'])
-    else:
+    """``util/util.py:28-39``; same return-the-exception convention for unknown names."""
+    build = _OPTIMIZERS.get(cfg['optimizer'])
+    if build is None:
         return NotImplementedError('optimizer [%s] is not implemented', cfg['optimizer'])
-    return optimizer
+    return build(cfg, params)
+
+
+def _to_uint8_hwc(chw):
+    """[3,H,W] float tensor in (roughly) [0,1] -> HxWx3 array scaled to 0..255 (still float)."""
+    return chw.detach().clamp(0.0, 1.0).cpu().float().numpy().transpose(1, 2, 0) * 255.0
 
 
 def tensor2im(input_image, imtype=np.uint8):
-    """``util/util.py:42-52``."""
-    if not isinstance(input_image, np.ndarray):
-        if isinstance(input_image, torch.Tensor):
-            image_tensor = input_image.data
-        else:
-            return input_image
-        image_numpy = image_tensor[0].clamp(0.0, 1.0).cpu().float().numpy()
-        image_numpy = np.transpose(image_numpy, (1, 2, 0)) * 255.0
-    else:
-        image_numpy = input_image
-    return image_numpy.astype(imtype)
+    """``util/util.py:42-52``: first image of a batch tensor -> HxWx3 array of ``imtype``; arrays are only cast, anything
+    that is neither a tensor nor an array is handed back untouched."""
+    if isinstance(input_image, np.ndarray):
+        return input_image.astype(imtype)
+    if not isinstance(input_image, torch.Tensor):
+        return input_image
+    return _to_uint8_hwc(input_image[0]).astype(imtype)
 
 
 def save_result(image_t, dataroot):
     """``util/util.py:55-59``: writes ``<dataroot>/out/output.png`` (ToPILImage semantics: [3,H,W] float in [0,1] -> uint8)."""
     from PIL import Image
-    arr = (image_t.detach().clamp(0.0, 1.0).cpu().float().numpy().transpose(1, 2, 0) * 255.0).astype(np.uint8)
+    arr = _to_uint8_hwc(image_t).astype(np.uint8)
     path = Path(f"{dataroot}/out")
     path.mkdir(exist_ok=True, parents=True)
     Image.fromarray(arr).save(f"{path}/output.png")

@@ -173,7 +173,9 @@ def test_checkpoint_loader_variants(name, tmp_path):
     assert got_name == name and list(sd) == [n for n, _, _ in specs]
     assert all(v.dtype == np.float32 for v in sd.values())
     # *_full_checkpoint.pth layout: teacher / student with DDP + backbone prefixes and a projection head
-    full = {"teacher": {"module.backbone." + k: v.half() for k, v in flat.items()}, "student": {}, "epoch": 100}
+    import argparse
+    full = {"teacher": {"module.backbone." + k: v.half() for k, v in flat.items()}, "student": {}, "epoch": 100,
+            "args": argparse.Namespace(arch="vit", patch_size=patch)}   # the public full checkpoints pickle their Namespace
     full["teacher"]["module.head.mlp.0.weight"] = torch.zeros(8, dim)
     full["teacher"]["module.head.last_layer.weight_g"] = torch.zeros(8, 1)
     p2 = tmp_path / "full.pth"
@@ -209,3 +211,39 @@ def test_async_result_writer(tmp_path):
     save_result(imgs[-1], str(tmp_path / "sync"))
     assert np.array_equal(got, np.asarray(Image.open(tmp_path / "sync" / "out" / "output.png")))
     assert not (tmp_path / "out" / "output.png.tmp").exists()
+
+
+def test_facade_factories_cpu():
+    """util/util.py:8-39 conventions of the registries: every documented policy builds, unknown names are RETURNED as
+    NotImplementedError (not raised), tensor2im casts arrays / passes foreign objects through."""
+    from splice_amd.util import get_optimizer, get_scheduler, tensor2im
+    w = [torch.nn.Parameter(torch.zeros(3))]
+    cfg = dict(lr=2e-3, optimizer_beta1=0.0, optimizer_beta2=0.99)
+    for name, cls in (("adam", torch.optim.Adam), ("rmsprop", torch.optim.RMSprop), ("sgd", torch.optim.SGD)):
+        opt = get_optimizer(dict(cfg, optimizer=name), w)
+        assert isinstance(opt, cls) and opt.param_groups[0]["lr"] == 2e-3
+    assert get_optimizer(dict(cfg, optimizer="adam"), w).param_groups[0]["betas"] == (0.0, 0.99)
+    assert isinstance(get_optimizer(dict(cfg, optimizer="lion"), w), NotImplementedError)
+    opt = get_optimizer(dict(cfg, optimizer="sgd"), w)
+    for policy in ("linear", "step", "plateau", "cosine", "none"):
+        sch = get_scheduler(opt, policy, n_epochs=10, n_epochs_decay=4, lr_decay_iters=3)
+        assert hasattr(sch, "step")
+    lin = get_scheduler(get_optimizer(dict(cfg, optimizer="sgd"), w), "linear", n_epochs_decay=4)
+    assert [round(lin.lr_lambdas[0](e), 3) for e in (0, 1, 5, 9)] == [1.0, 0.8, 0.0, 0]
+    assert isinstance(get_scheduler(opt, "warmup"), NotImplementedError)
+    img = torch.tensor([[[[0.5, 2.0]], [[-1.0, 0.25]], [[1.0, 0.0]]]])           # [1,3,1,2]
+    assert tensor2im(img).tolist() == [[[127, 0, 255], [255, 63, 0]]]
+    arr = np.array([[1.7, 2.2]])
+    assert tensor2im(arr).dtype == np.uint8 and tensor2im("x") == "x"
+
+
+def test_extractor_arch_table_matches_reference_substring_rules():
+    """models/extractor.py:105-130 parses the model name on every call; the table + fallback must agree with those rules."""
+    from splice_amd.extractor import _arch_of
+
+    def rule(name):
+        patch = 8 if "8" in name else 16
+        small = ("s" in name) if "dino" in name else ("small" in name)
+        return (patch, 6 if small else 12, 384 if small else 768)
+    for name in ("dino_vits8", "dino_vits16", "dino_vitb8", "dino_vitb16", "vit_small_patch8_224", "vit_base_patch16_224", "dino_xcit_s8"):
+        assert _arch_of(name) == rule(name), name
