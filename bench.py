@@ -2,7 +2,8 @@
 """Benchmark of the Splice per-pair optimisation step on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: either under a launcher -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+   ... bench.py --gpus N ... -- or bare: the script then starts its own N workers, one per GPU via HIP_VISIBLE_DEVICES)
 
 Workload (config.workload): BASELINE.json configs[1] -- one 224x224 structure/appearance pair,
 DINO ViT-B/8 (T = 785 tokens), bf16 ViT / fp32 generator, reference hyper-parameters
@@ -70,6 +71,41 @@ def cpu_baseline(cfg, hw, seed, budget_s=25.0):
                       f"reference-shaped 6-forward/3-backward loop, torch {torch.__version__} CPU"}
 
 
+def spawn_workers(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N copies of this script, worker i pinned to GPU i through
+    HIP_VISIBLE_DEVICES (one process per GPU), rendezvous on 127.0.0.1.  Worker 0 prints the JSON."""
+    import socket
+    import subprocess
+    n_dev = visible_gpu_count()
+    if n_dev < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {n_dev} GPU(s) visible on this node")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    parent_visible = os.environ.get("HIP_VISIBLE_DEVICES")
+    ids = parent_visible.split(",") if parent_visible else [str(i) for i in range(n_dev)]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HIP_VISIBLE_DEVICES=ids[r], SPLICE_BENCH_SPAWNED="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.pop("CUDA_VISIBLE_DEVICES", None)
+        env.pop("ROCR_VISIBLE_DEVICES", None)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        raise SystemExit(f"bench.py: worker exit codes {rcs}")
+
+
+def visible_gpu_count():
+    """GPUs this process could use, WITHOUT initialising the HIP runtime in the parent (the workers own the devices)."""
+    import subprocess
+    code = "import torch; print(torch.cuda.device_count() if torch.cuda.is_available() else 0)"
+    try:
+        return int(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +116,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-kernel", type=int, default=4, help="4 fc2 GEMM (largest share of the step), 1 fc1 GEMM, 2 qkv GEMM, 3 attention fwd, 0 off")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_workers(args.gpus, sys.argv[1:])
 
     import torch
     from splice_amd import _lib
@@ -89,12 +127,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         f"(or without a launcher: bench.py spawns its own workers)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
-    rep = Replicas(backend="nccl", device=dev)   # RCCL; used for the barrier + max-over-ranks only
+    # self-spawned workers see exactly one GPU each (HIP_VISIBLE_DEVICES); torchrun workers see all and pick LOCAL_RANK
+    dev_index = 0 if os.environ.get("SPLICE_BENCH_SPAWNED") == "1" else local_rank
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {local_rank} has no GPU (visible devices: {torch.cuda.device_count()})")
+    torch.cuda.set_device(dev_index)
+    dev = f"cuda:{dev_index}"
+    # The replicas exchange NO data (independent pairs): the process group exists only for the start/stop barrier and the
+    # max-over-ranks of one float, so it runs over gloo on the host -- an RCCL communicator would add an xGMI bootstrap that
+    # can only hurt (north_star: "no RCCL required").
+    rep = Replicas(backend="gloo", device=None)
     rank = rep.rank
 
     cfg = dict(dino_model_name=args.model, dino_global_patch_size=args.size)
@@ -134,6 +180,7 @@ def main():
         ev_overhead_ms = sorted(a_.elapsed_time(b_) for a_, b_ in evs)[len(evs) // 2]
     else:
         ev_overhead_ms = 0.0
+    per_rank_elapsed = rep.gather_floats(elapsed)
     elapsed = rep.max_over_ranks(elapsed)
     if rank != 0:
         rep.close()
@@ -163,7 +210,9 @@ def main():
             except Exception:
                 traffic = None
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": round(ach / 2500.0, 4), "traffic": traffic, "avg_launch_us": round(avg_ms * 1e3, 2), "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2),
+                "frac": round(ach / 2500.0, 4), "traffic": traffic,
+                "traffic_source": None if traffic is None else "static: profiles/roofline_traffic.json (PMC passes of an earlier run, not re-measured by this command)",
+                "avg_launch_us": round(avg_ms * 1e3, 2), "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2),
                 "launches": prof_n.value,
                 "note": "algorithmic FLOPs of one launch (2 passes x T tokens) / mean HIP-event duration of its launches, "
                         "measured on the launch stream over the instrumented continuation of the timed steps (the timed "
@@ -182,6 +231,7 @@ def main():
         "config": {"workload": f"Splice pair {hw[0]}x{hw[1]}, {args.model} (T={T}), 1 pair per GPU, "
                                f"{n_entire} of {K} timed steps include the entire-image branch",
                    "pairs": world, "pairs_per_hour_at_2000_steps": round(value * 3600 / 2000, 2),
+                   "per_rank_steps_per_s": [round(K / t, 2) for t in per_rank_elapsed],
                    "generator_dtype": "f32", "last_loss": round(losses["loss"], 5)},
         "roofline": roof, "cpu_baseline": cpu,
     }

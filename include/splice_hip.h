@@ -126,8 +126,8 @@ int splice_keys_selfsim_bwd(const float* dS, const float* S, int T, int D, float
 
 /* F.mse_loss(a, b) (util/losses.py:82,93,104) on 2-D strided fp32 views:
  * loss_accum[0] += weight * mean((a-b)^2); grad (optional) = weight * 2 (a-b) / (rows*cols).
- * Workgroup partials are added in a fixed order (no float atomics) through one process-wide scratch line: calls must
- * not overlap on different streams of one process. */
+ * Workgroup partials are added in a fixed order (no float atomics) through a scratch line owned by the (device, stream)
+ * pair of the call: calls on different streams or devices are independent. */
 int splice_mse(const float* a, int lda, const float* b, int ldb, int rows, int cols, float weight,
                float* loss_accum, float* grad, int ldg, splice_stream_t stream);
 

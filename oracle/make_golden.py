@@ -206,6 +206,20 @@ def golden_inversion_net():
     print("inversion_net.npz", len(out))
 
 
+def golden_define_g_init(ref_networks_mod):
+    """Initial generator of ``torch.manual_seed(s); define_G(init_type, 0.02)`` (models/networks.py:24-58) for a few
+    seeds / init types: per-tensor (sum, |sum|, sum sq) + a strided sample.  Pins the seed -> initial-weights map of
+    splice_amd.networks (constructor draws + init draws on the CPU generator)."""
+    out = {}
+    for seed, init_type in ((0, "xavier"), (3, "xavier"), (5, "normal"), (7, "kaiming")):
+        torch.manual_seed(seed)
+        net = ref_networks_mod.define_G(init_type, 0.02)
+        out[f"{init_type}/{seed}/stats"] = np.stack([stats(p) for p in net.parameters()])
+        out[f"{init_type}/{seed}/samples"] = np.stack([np.resize(sample(p, 8), 8) for p in net.parameters()])
+    np.savez_compressed(os.path.join(OUT, "define_g_init.npz"), **out)
+    print("define_g_init.npz", len(out))
+
+
 def run_reference_loop(cfg, A, B, n_steps, ref, A_entire=None, record_grads_at=()):
     """The body of ``train.py:51-80`` with the dataset replaced by fixed full crops
     (``Global_crops`` with min_cover=1 returns the whole image, data/transforms.py:22-23)."""
@@ -306,6 +320,8 @@ def main():
         golden_steps((Model, LossG, get_optimizer))
     if not only or "inversion_net" in only:
         golden_inversion_net()
+    if not only or "define_g_init" in only:
+        golden_define_g_init(ref_networks)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,137 @@
+"""Many pairs on one node: a directory of K structure/appearance pairs -> a queue over N GPUs.
+
+The reference optimises one pair per process invocation (``train.py:34-49,83-89``: one ``--dataroot`` with ``A/`` and
+``B/``); K pairs are K independent runs.  Pairs share nothing but the frozen ViT weights, so the
+node-level driver is embarrassingly parallel: pair *i* goes to GPU *i mod N*, one worker PROCESS per GPU (its own HIP
+context, pinned with ``HIP_VISIBLE_DEVICES``), each worker walks its pairs in index order, no collective, no shared
+state.  The result of a pair therefore does not depend on N: ``run_batch(root, 1)`` and ``run_batch(root, 8)`` write
+bit-identical outputs (tests/test_batch_cpu.py pins that with a stub runner on CPU workers, tests/test_batch_gpu.py
+with the real engine on one GPU).
+
+Layout::
+
+    root/<pair name>/A/<image>      structure image      (what ``train_model(dataroot)`` expects as dataroot)
+    root/<pair name>/B/<image>      appearance image
+    root/<pair name>/out/output.png written by the run
+    root/<pair name>/out/result.json {"pair", "gpu", "steps", "loss", "seconds", ...}
+
+    python -m splice_amd.batch --root pairs/ --gpus 8 [--n_epochs 2000] [--set key=value ...]
+"""
+import importlib
+import json
+import os
+import sys
+import time
+from argparse import ArgumentParser
+
+
+def discover_pairs(root):
+    """Sorted names of the sub-directories of ``root`` that hold both ``A/`` and ``B/`` with at least one file each."""
+    names = []
+    for name in sorted(os.listdir(root)):
+        d = os.path.join(root, name)
+        if all(os.path.isdir(os.path.join(d, s)) and os.listdir(os.path.join(d, s)) for s in ("A", "B")):
+            names.append(name)
+    return names
+
+
+def assignment(n_pairs, n_gpus):
+    """pair index -> GPU: ``i mod n_gpus``; returned as one index list per GPU."""
+    return [list(range(g, n_pairs, n_gpus)) for g in range(n_gpus)]
+
+
+def train_runner(pair_dir, overrides):
+    """Default runner: the drop-in ``train_model`` on the pair's directory."""
+    from .train import train_model
+    t0 = time.perf_counter()
+    eng = train_model(pair_dir, cfg_overrides=overrides, progress=False)
+    import torch
+    torch.cuda.synchronize()
+    return {"steps": eng.step_idx + 1, "loss": eng.losses()["loss"], "seconds": round(time.perf_counter() - t0, 3)}
+
+
+def _resolve(runner):
+    if callable(runner):
+        return runner
+    mod, _, fn = runner.partition(":")
+    return getattr(importlib.import_module(mod), fn)
+
+
+def _worker(gpu, visible_id, root, names, indices, runner, overrides, pin_gpu):
+    if pin_gpu:   # must happen before the HIP runtime starts in this process
+        os.environ["HIP_VISIBLE_DEVICES"] = str(visible_id)
+        os.environ.pop("CUDA_VISIBLE_DEVICES", None)
+    run = _resolve(runner)
+    for i in indices:
+        pair_dir = os.path.join(root, names[i])
+        res = dict(run(pair_dir, dict(overrides)) or {})
+        res.update(pair=names[i], index=i, gpu=gpu)
+        os.makedirs(os.path.join(pair_dir, "out"), exist_ok=True)
+        tmp = os.path.join(pair_dir, "out", "result.json.tmp")
+        with open(tmp, "w") as f:
+            json.dump(res, f)
+        os.replace(tmp, os.path.join(pair_dir, "out", "result.json"))
+
+
+def run_batch(root, n_gpus=1, overrides=None, runner="splice_amd.batch:train_runner", pin_gpu=True, visible_ids=None):
+    """Optimise every pair under ``root`` on ``n_gpus`` worker processes; returns the per-pair result dicts in pair order.
+
+    ``runner``: ``"module:function"`` (or a picklable callable) ``(pair_dir, overrides) -> dict``; the default trains the
+    pair.  ``pin_gpu=False`` leaves device visibility alone (CPU tests).  A worker that dies takes the batch down with a
+    RuntimeError naming its pairs; finished pairs keep their ``result.json``."""
+    import multiprocessing as mp
+    names = discover_pairs(root)
+    if not names:
+        raise ValueError(f"{root}: no <pair>/A + <pair>/B directories found")
+    n_gpus = max(1, min(int(n_gpus), len(names)))
+    plan = assignment(len(names), n_gpus)
+    if visible_ids is None:
+        parent = os.environ.get("HIP_VISIBLE_DEVICES")
+        visible_ids = parent.split(",") if parent else [str(g) for g in range(n_gpus)]
+    if pin_gpu and len(visible_ids) < n_gpus:
+        raise ValueError(f"run_batch: {n_gpus} workers requested, {len(visible_ids)} visible GPUs")
+    ctx = mp.get_context("spawn")   # fresh interpreters: the HIP runtime must not be inherited through fork
+    procs = [ctx.Process(target=_worker, args=(g, visible_ids[g] if pin_gpu else g, root, names, plan[g], runner, dict(overrides or {}), pin_gpu))
+             for g in range(n_gpus)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join()
+    failed = [g for g, p in enumerate(procs) if p.exitcode != 0]
+    if failed:
+        raise RuntimeError("run_batch: worker(s) failed: " + "; ".join(f"gpu {g} (pairs {[names[i] for i in plan[g]]}, exit {procs[g].exitcode})" for g in failed))
+    out = []
+    for name in names:
+        with open(os.path.join(root, name, "out", "result.json")) as f:
+            out.append(json.load(f))
+    return out
+
+
+def _parse_value(text):
+    try:
+        return json.loads(text)
+    except ValueError:
+        return text
+
+
+def main(argv=None):
+    ap = ArgumentParser(description="Optimise a directory of Splice pairs over the GPUs of one node (pair i -> GPU i mod N).")
+    ap.add_argument("--root", required=True, help="directory of <pair>/A, <pair>/B sub-directories")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--n_epochs", type=int, default=None, help="optimisation steps per pair (config default otherwise)")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="config override (conf/default/config.yaml keys)")
+    args = ap.parse_args(argv)
+    over = {}
+    if args.n_epochs is not None:
+        over["n_epochs"] = args.n_epochs
+    for kv in args.set:
+        k, _, v = kv.partition("=")
+        over[k] = _parse_value(v)
+    t0 = time.perf_counter()
+    res = run_batch(args.root, args.gpus, over)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"pairs": len(res), "gpus": args.gpus, "seconds": round(dt, 2), "pairs_per_hour": round(len(res) * 3600 / dt, 2), "results": res}))
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -10,6 +10,7 @@
 // Ragged M / N are handled by clamping the load row and predicating the epilogue, so any
 // M, N >= 1 works; K must be a multiple of 64 and lda/ldb multiples of 8 (16-byte rows).
 #pragma once
+#include <atomic>
 #include "common.h"
 
 constexpr int GEMM_BK = 64;
@@ -467,10 +468,15 @@ static inline void launch_gemm_nt(hipStream_t s, const bf16_t* A, int lda, const
     int gm = 1;
     while ((gm + 1) * (gm + 1) * BM <= (tm * tn / 8 + 1) * BN && gm + 1 <= tm) ++gm;
     constexpr size_t lds = (size_t)NS * GemmTile<BM, BN>::LDS_ELEMS * sizeof(bf16_t);
-    static bool attr_set = false;   // > 64 KB of dynamic LDS has to be allowed once per kernel
-    if (lds > 65536 && !attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, FLAGS, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    if (lds > 65536) {   // > 64 KB of dynamic LDS has to be allowed once per kernel AND per device (the attribute lives on the
+        int dev = 0;     // device's copy of the function: a process that drives several GPUs sets it on each)
+        (void)hipGetDevice(&dev);
+        static std::atomic<unsigned long long> done_mask{0};
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, FLAGS, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            done_mask.fetch_or(bit, std::memory_order_relaxed);
+        }
     }
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, FLAGS, NS>), dim3(grid), dim3(256), lds, s, A, lda, B, ldb, M, N, K, e, gm, ksplit);
 }

@@ -7,6 +7,10 @@
 //            engine with the normalising epilogue.
 // Backward = E = dS + dS^T;  W_ij = E_ij / c_ij;  r_i = sum_j [n_i n_j > eps] E_ij S_ij / n_i^2;
 //            dK = W K - diag(r) K   (second MFMA GEMM, K-dim = tokens, via the transposed copy).
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "kernels.h"
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -183,15 +187,26 @@ int mse_partials_launch(const float* a, int lda, const float* b, int ldb, int ro
                        grad_weight / (float)n, part, grad, ldg);
     return SPLICE_OK;
 }
-// stand-alone form: loss_accum[0] += loss_weight * mean(d^2).  Uses one process-wide scratch line (allocated on first
-// use, consumed by the sum kernel launched right behind the partials kernel): calls must not overlap on different streams.
+// stand-alone form: loss_accum[0] += loss_weight * mean(d^2).  The partials line is scoped to (device, stream): the sum
+// kernel launched right behind the partials kernel on the same stream consumes and re-zeroes it, so calls on one stream
+// are ordered by the stream and calls on different streams / devices never share a line.
+static float* mse_scratch_for(hipStream_t s) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, float*> lines;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    float*& line = lines[{dev, s}];
+    if (!line) {
+        if (hipMalloc(&line, MSE_MAX_WG * sizeof(float)) != hipSuccess) { line = nullptr; return nullptr; }
+        if (hipMemset(line, 0, MSE_MAX_WG * sizeof(float)) != hipSuccess) { (void)hipFree(line); line = nullptr; return nullptr; }
+    }
+    return line;
+}
 int mse2_launch(const float* a, int lda, const float* b, int ldb, int rows, int cols, float loss_weight, float grad_weight,
                 float* loss_accum, float* grad, int ldg, hipStream_t s) {
-    static float* scratch = nullptr;
-    if (!scratch) {
-        if (hipMalloc(&scratch, MSE_MAX_WG * sizeof(float)) != hipSuccess) return SPLICE_ERR_HIP;
-        if (hipMemset(scratch, 0, MSE_MAX_WG * sizeof(float)) != hipSuccess) return SPLICE_ERR_HIP;
-    }
+    float* scratch = mse_scratch_for(s);
+    if (!scratch) return SPLICE_ERR_HIP;
     const int rc = mse_partials_launch(a, lda, b, ldb, rows, cols, loss_weight, grad_weight, scratch, grad, ldg, s);
     if (rc != SPLICE_OK) return rc;
     hipLaunchKernelGGL(mse_sum_kernel, dim3(1), dim3(256), 0, s, scratch, loss_accum);

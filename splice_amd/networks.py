@@ -120,28 +120,57 @@ def skip(num_input_channels=3, num_output_channels=3, num_channels_down=[16, 32,
         return GeneralSkip(num_input_channels, num_output_channels, num_channels_down, num_channels_up, num_channels_skip,
                            filter_size_down, filter_size_up, filter_skip_size, need_sigmoid, need_tanh, need_bias, pad,
                            upsample_mode, downsample_mode, act_fun, need1x1_up).to(device)
+    _burn_constructor_draws()
     return SkipGenerator(device=device)
 
 
+def _burn_constructor_draws():
+    """The reference builds ``skip()`` out of ``nn.Conv2d`` modules on the CPU; every constructor draws its default
+    (kaiming-uniform) weights and bias from the global CPU generator BEFORE ``init_weights`` overwrites them
+    (models/unet/skip.py:46-97, models/unet/common.py:121).  Consuming the same draws in the same order keeps
+    ``torch.manual_seed(s); define_G(...)`` on the reference's random stream, so a fixed seed gives the reference's
+    initial generator."""
+    down = up = [16, 32, 64, 128, 128]
+    for i, d in enumerate(down):
+        cin = 3 if i == 0 else down[i - 1]
+        k = up[i + 1] if i + 1 < len(down) else d
+        for ci, co, ks in ((cin, 4, 1), (cin, d, 3), (d, d, 3), (4 + k, up[i], 3), (up[i], up[i], 1)):
+            nn.Conv2d(ci, co, ks)
+    nn.Conv2d(up[0], 3, 1)
+
+
+_CONV_INIT = {  # init_type -> in-place initialiser of a conv weight (models/networks.py:30-39)
+    'normal': lambda w, gain: nn.init.normal_(w, 0.0, gain),
+    'xavier': lambda w, gain: nn.init.xavier_normal_(w, gain=gain),
+    'kaiming': lambda w, gain: nn.init.kaiming_normal_(w, a=0, mode='fan_in'),
+    'orthogonal': lambda w, gain: nn.init.orthogonal_(w, gain=gain),
+}
+
+
+def _draw_initial_state(init_type, init_gain):
+    """{state_dict name: CPU tensor} drawn from the global CPU generator in the reference's module order."""
+    if init_type not in _CONV_INIT:
+        raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
+    from .synth import generator_param_specs
+    state = {}
+    for name, shape, kind in generator_param_specs():
+        host = torch.zeros(shape)
+        if kind == "conv_w":
+            _CONV_INIT[init_type](host, init_gain)
+        elif kind == "bn_w":
+            nn.init.normal_(host, 1.0, init_gain)
+        state[name] = host
+    return state
+
+
 def init_weights(net, init_type='normal', init_gain=0.02, debug=False):
-    """``models/networks.py:24-47``: conv weights by ``init_type``, conv bias 0, BN gamma ~ N(1, gain), beta 0."""
+    """``models/networks.py:24-47``: conv weights by ``init_type``, conv bias 0, BN gamma ~ N(1, gain), beta 0.  Values are
+    drawn on the CPU in module order (the reference initialises on the CPU and moves the net afterwards), then uploaded
+    into the arena."""
+    state = _draw_initial_state(init_type, init_gain)
     with torch.no_grad():
-        for (name, kind), p in zip(net._kinds.items(), net._plist):
-            if kind == "conv_w":
-                if init_type == 'normal':
-                    nn.init.normal_(p, 0.0, init_gain)
-                elif init_type == 'xavier':
-                    nn.init.xavier_normal_(p, gain=init_gain)
-                elif init_type == 'kaiming':
-                    nn.init.kaiming_normal_(p, a=0, mode='fan_in')
-                elif init_type == 'orthogonal':
-                    nn.init.orthogonal_(p, gain=init_gain)
-                else:
-                    raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
-            elif kind == "bn_w":
-                nn.init.normal_(p, 1.0, init_gain)
-            else:
-                nn.init.constant_(p, 0.0)
+        for name, p in zip(net._kinds, net._plist):
+            p.copy_(state[name])
 
 
 def init_net(net, init_type='normal', init_gain=0.02, debug=False, initialize_weights=True):

@@ -1,0 +1,69 @@
+"""CPU: the pair queue of splice_amd/batch.py (pair i -> worker i mod N, one process per worker, no shared state).
+A stub runner stands in for the GPU engine: its output is a deterministic function of the pair's images and the
+overrides, so "N workers == serial" is checked bit for bit, as is the order / assignment / failure reporting."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from splice_amd import batch, synth
+
+
+def stub_runner(pair_dir, overrides):
+    """Deterministic stand-in for train_model: digest of both images + the overrides; also writes out/output.png bytes."""
+    h = hashlib.sha256(json.dumps(overrides, sort_keys=True).encode())
+    for side in ("A", "B"):
+        d = os.path.join(pair_dir, side)
+        with open(os.path.join(d, sorted(os.listdir(d))[0]), "rb") as f:
+            h.update(f.read())
+    os.makedirs(os.path.join(pair_dir, "out"), exist_ok=True)
+    with open(os.path.join(pair_dir, "out", "output.png"), "wb") as f:
+        f.write(h.digest())
+    if overrides.get("explode") == os.path.basename(pair_dir):
+        raise RuntimeError("boom")
+    return {"digest": h.hexdigest(), "steps": overrides.get("n_epochs", 0), "pid": os.getpid()}
+
+
+def _make_pairs(root, k):
+    for i in range(k):
+        A, B = synth.image_pair(99, i, 8, 8)
+        for side, img in (("A", A), ("B", B)):
+            d = root / f"pair{i:02d}" / side
+            d.mkdir(parents=True)
+            np.save(d / "img.npy", img)
+    (root / "not_a_pair").mkdir()
+    (root / "half" / "A").mkdir(parents=True)
+
+
+def test_assignment_round_robin():
+    assert batch.assignment(5, 2) == [[0, 2, 4], [1, 3]]
+    assert batch.assignment(3, 8)[:3] == [[0], [1], [2]]
+
+
+def test_queue_matches_serial(tmp_path):
+    roots = []
+    for tag, n in (("serial", 1), ("two", 2)):
+        root = tmp_path / tag
+        root.mkdir()
+        _make_pairs(root, 5)
+        res = batch.run_batch(str(root), n, {"n_epochs": 7}, runner="test_batch_cpu:stub_runner", pin_gpu=False)
+        roots.append((root, res))
+    (r1, a), (r2, b) = roots
+    assert [x["pair"] for x in a] == [f"pair{i:02d}" for i in range(5)] == [x["pair"] for x in b]
+    assert [x["digest"] for x in a] == [x["digest"] for x in b]                      # result independent of N
+    assert [x["gpu"] for x in b] == [0, 1, 0, 1, 0] and {x["gpu"] for x in a} == {0}   # pair i -> worker i mod N
+    assert len({x["pid"] for x in b}) == 2                                           # one process per worker
+    for i in range(5):
+        assert (r1 / f"pair{i:02d}" / "out" / "output.png").read_bytes() == (r2 / f"pair{i:02d}" / "out" / "output.png").read_bytes()
+    assert len({x["digest"] for x in a}) == 5                                        # pairs differ
+
+
+def test_worker_failure_is_reported(tmp_path):
+    _make_pairs(tmp_path, 3)
+    with pytest.raises(RuntimeError, match="gpu 1"):
+        batch.run_batch(str(tmp_path), 2, {"explode": "pair01"}, runner="test_batch_cpu:stub_runner", pin_gpu=False)
+    assert (tmp_path / "pair00" / "out" / "result.json").exists()      # the healthy worker finished its pairs
+    with pytest.raises(ValueError):
+        batch.run_batch(str(tmp_path / "not_a_pair"), 1, runner="test_batch_cpu:stub_runner", pin_gpu=False)

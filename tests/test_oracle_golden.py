@@ -165,3 +165,21 @@ def test_general_skip_matches_reference_inversion_net(golden_dir):
         np.testing.assert_allclose(stats(y), g[f"{tag}/out_stats"], rtol=1e-6)
         gs = np.stack([stats(p.grad) for _, p in params])
         np.testing.assert_allclose(gs[:, 1:], g[f"{tag}/grad_stats"][:, 1:], rtol=2e-4, atol=1e-10)   # |g| and g^2 sums
+
+
+def test_define_g_seed_parity(golden_dir):
+    """``torch.manual_seed(s); define_G(init_type, gain)`` gives the reference's initial generator (fixture recorded from
+    models/networks.py:24-58 by oracle/make_golden.py): splice_amd.networks consumes the constructor draws of the reference's
+    nn.Conv2d modules, then draws every tensor on the CPU generator in module order.  Bit-exact (same torch build)."""
+    from splice_amd import networks
+    g = np.load(os.path.join(golden_dir, "define_g_init.npz"))
+    sample = lambda t, n=8: np.resize(t.reshape(-1)[::max(1, t.numel() // n)][:n].numpy(), n)
+    for key in [k for k in g.files if k.endswith("/stats")]:
+        init_type, seed, _ = key.split("/")
+        torch.manual_seed(int(seed))
+        networks._burn_constructor_draws()
+        state = networks._draw_initial_state(init_type, 0.02)
+        got_stats = np.stack([[t.double().sum().item(), t.double().abs().sum().item(), (t.double() ** 2).sum().item()] for t in state.values()])
+        got_samples = np.stack([sample(t) for t in state.values()])
+        assert np.array_equal(got_samples, g[f"{init_type}/{seed}/samples"]), key
+        np.testing.assert_allclose(got_stats, g[key], rtol=1e-12, atol=0)
