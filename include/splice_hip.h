@@ -217,6 +217,10 @@ int splice_prof_end(float* total_ms, int* launches);
 int splice_prof_active(void);
 int splice_vit_ctx_dims(void* ctx, int* B, int* H, int* W, int* D, int* depth, int* heads, int* patch);
 int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams);
+/* stride > 0: the N images of the plan are INDEPENDENT generators (P image pairs optimised side by side: the reference
+ * runs train.py once per pair): image n reads params + n*stride, its gradient goes to grads + n*stride, BatchNorm and
+ * launch policies are per image -- a pair's result is bit-identical to its N = 1 run.  0 (default): one generator. */
+int splice_gen_plan_set_arena_stride(void* plan, long long stride);
 /* re-target a plan to a smaller input without reallocating (per-step random crop sizes,
  * data/transforms.py:21-22) */
 int splice_gen_plan_resize(void* plan, int H, int W);

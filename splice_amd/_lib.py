@@ -108,6 +108,7 @@ _SIGNATURES = {
     "splice_step_attach_split_plans": ([_vp, _vp, _vp], _i),
     "splice_step_set_crops": ([_vp, _i, _i, _i, _i], _i),
     "splice_gen_plan_resize": ([_vp, _i, _i], _i),
+    "splice_gen_plan_set_arena_stride": ([_vp, C.c_longlong], _i),
 }
 
 

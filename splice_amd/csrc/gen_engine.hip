@@ -69,6 +69,7 @@ struct SpliceGen {
 struct SpliceGenPlan {
     SpliceGen* gen = nullptr;
     int N = 0, H = 0, W = 0, need_grad = 0, maxH = 0, maxW = 0;
+    size_t p_nstride = 0;                 // > 0: the N images are independent generators -- image n uses params / grads + n * p_nstride
     int h[6], w[6];                       // spatial size at scale i (h[0] = H)
     std::vector<void*> allocs;
     // per scale
@@ -204,7 +205,7 @@ static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* para
         ConvArgs a = {};
         a.in = u.in; a.w = params + u.w_off; a.bias = params + u.b_off; a.out = u.y;
         a.in_nstride = u.in_ns; a.in_cstride = (size_t)u.Hi * u.Wi; a.out_nstride = u.y_ns; a.out_cstride = (size_t)u.Ho * u.Wo;
-        a.w_jstride = (size_t)u.Cin * u.ks * u.ks; a.w_cstride = (size_t)u.ks * u.ks;
+        a.w_jstride = (size_t)u.Cin * u.ks * u.ks; a.w_cstride = (size_t)u.ks * u.ks; a.p_nstride = p->p_nstride;
         a.N = N; a.Cin = u.Cin; a.Hi = u.Hi; a.Wi = u.Wi; a.Cout = u.Cout; a.Ho = u.Ho; a.Wo = u.Wo;
         a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2;
         a.ws = p->conv_ws; a.ws_floats = p->conv_ws_floats;
@@ -215,11 +216,12 @@ static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* para
         y = u.y; y_ns = u.y_ns;
         if (a.defer_reduce && ksplit > 1) {
             RC(bn_fwd_slabs_launch(p->conv_ws, ksplit, a.bias, u.y, u.y_ns, u.out, u.out_ns, N, u.Cout, u.Ho * u.Wo, params + u.g_off,
-                                   params + u.be_off, BN_EPS, u.mean, u.rstd, u.slope, s));
+                                   params + u.be_off, BN_EPS, u.mean, u.rstd, u.slope, s, p->p_nstride));
             return SPLICE_OK;
         }
     }
-    RC(bn_fwd_launch(y, y_ns, u.out, u.out_ns, N, u.Cout, u.Ho * u.Wo, params + u.g_off, params + u.be_off, BN_EPS, u.s1, u.mean, u.rstd, u.slope, s, up));
+    RC(bn_fwd_launch(y, y_ns, u.out, u.out_ns, N, u.Cout, u.Ho * u.Wo, params + u.g_off, params + u.be_off, BN_EPS, u.s1, u.mean, u.rstd, u.slope, s, up,
+                     p->p_nstride));
     return SPLICE_OK;
 }
 
@@ -232,7 +234,7 @@ static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* par
     float* dy = u.ks ? u.dy : u.d_in;          // BN-only unit: dy IS the input gradient
     const size_t dy_ns = u.ks ? u.y_ns : u.d_in_ns;
     RC(bn_bwd_launch(u.d_out, u.d_out_ns, u.out, u.out_ns, y, y_ns, dy, dy_ns, N, u.Cout, HW, params + u.g_off, u.mean, u.rstd, u.slope,
-                     u.s1, grads + u.g_off, grads + u.be_off, acc, s, up));
+                     u.s1, grads + u.g_off, grads + u.be_off, acc, s, up, p->p_nstride));
     if (!u.ks) return SPLICE_OK;
     // The bias of a conv that feeds a train-mode BatchNorm has an analytically ZERO gradient (BN subtracts the
     // per-channel mean, sum_p dy = 0); the reference's autograd returns fp32 rounding noise there.  We write the
@@ -259,7 +261,7 @@ static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* par
         ConvArgs a = {};
         a.in = u.dy; a.w = params + u.w_off; a.bias = nullptr; a.out = u.d_in;
         a.in_nstride = u.y_ns; a.in_cstride = (size_t)HW; a.out_nstride = u.d_in_ns; a.out_cstride = (size_t)u.Hi * u.Wi;
-        a.w_jstride = (size_t)u.ks * u.ks; a.w_cstride = (size_t)u.Cin * u.ks * u.ks;
+        a.w_jstride = (size_t)u.ks * u.ks; a.w_cstride = (size_t)u.Cin * u.ks * u.ks; a.p_nstride = p->p_nstride;
         a.N = N; a.Cin = u.Cout; a.Hi = u.Ho; a.Wi = u.Wo; a.Cout = u.Cin; a.Ho = u.Hi; a.Wo = u.Wi;
         a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2; a.transposed = 1; a.accumulate = u.d_in_accumulate;
         a.ws = p->conv_ws; a.ws_floats = p->conv_ws_floats;
@@ -370,6 +372,20 @@ int splice_gen_plan_resize(void* plan, int H, int W) {
     return SPLICE_OK;
 }
 
+// stride > 0: the plan's N images are INDEPENDENT generators (several pairs optimised side by side, train.py:34-49 run P
+// times): image n reads its parameters at params + n * stride and its gradients go to grads + n * stride; every launch
+// policy is then taken from one image, so a pair's results do not depend on how many pairs share the launches.
+// stride == 0 (default): one generator applied to N images, gradients summed over the images.
+int splice_gen_plan_set_arena_stride(void* plan, long long stride) {
+    SpliceGenPlan* p = (SpliceGenPlan*)plan;
+    if (!p || stride < 0 || (stride > 0 && stride < (long long)p->gen->table.total)) {
+        splice_set_error("splice_gen_plan_set_arena_stride: stride must be 0 or >= the parameter count");
+        return SPLICE_ERR_ARG;
+    }
+    p->p_nstride = (size_t)stride;
+    return SPLICE_OK;
+}
+
 int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams) {
     SpliceGenPlan* p = (SpliceGenPlan*)plan;
     if (!p) return SPLICE_ERR_ARG;
@@ -426,7 +442,7 @@ static int gen_forward_impl(void* plan, const float* params, const float* x, flo
         ConvArgs a = {};
         a.in = u.out; a.w = params + p->head_w; a.bias = params + p->head_b; a.out = y;
         a.in_nstride = u.out_ns; a.in_cstride = (size_t)p->H * p->W; a.out_nstride = (size_t)3 * p->H * p->W; a.out_cstride = (size_t)p->H * p->W;
-        a.w_jstride = UP[0]; a.w_cstride = 1;
+        a.w_jstride = UP[0]; a.w_cstride = 1; a.p_nstride = p->p_nstride;
         a.N = p->N; a.Cin = UP[0]; a.Hi = p->H; a.Wi = p->W; a.Cout = 3; a.Ho = p->H; a.Wo = p->W; a.ks = 1; a.stride = 1; a.pad = 0; a.act = 1;
         RC(conv_launch(a, s));
     }
@@ -486,7 +502,7 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
     const Unit& u = p->u_up1[0];
     const int HW = p->H * p->W;
     (void)npix;
-    RC(sigmoid_bwd_bias_launch(dy, p->y_saved, p->d_head_pre, p->N, 3, HW, p->u_up1[0].s1, grads + p->head_b, accumulate, s));
+    RC(sigmoid_bwd_bias_launch(dy, p->y_saved, p->d_head_pre, p->N, 3, HW, p->u_up1[0].s1, grads + p->head_b, accumulate, s, p->p_nstride));
     {
         WgradArgs a = {};
         a.x = u.out; a.dy = p->d_head_pre;
@@ -503,7 +519,7 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
         ConvArgs a = {};
         a.in = p->d_head_pre; a.w = params + p->head_w; a.out = u.d_out;
         a.in_nstride = (size_t)3 * HW; a.in_cstride = (size_t)HW; a.out_nstride = u.d_out_ns; a.out_cstride = (size_t)HW;
-        a.w_jstride = 1; a.w_cstride = UP[0];
+        a.w_jstride = 1; a.w_cstride = UP[0]; a.p_nstride = p->p_nstride;
         a.N = p->N; a.Cin = 3; a.Hi = p->H; a.Wi = p->W; a.Cout = UP[0]; a.Ho = p->H; a.Wo = p->W; a.ks = 1; a.stride = 1; a.pad = 0; a.transposed = 1;
         RC(conv_launch(a, s));
     }
@@ -514,7 +530,7 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
         r.prefix[0] = 0;
         for (int i = 0; i < r.count; ++i) r.prefix[i + 1] = r.prefix[i] + r.n[i];
         r.total = r.prefix[r.count];
-        RC(wgrad_reduce_all_launch(r, p->wgrad_ws, grads, accumulate, s));
+        RC(wgrad_reduce_all_launch(r, p->wgrad_ws, grads, accumulate, s, p->N, p->p_nstride));
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { splice_set_error("splice_gen_backward: %s", hipGetErrorString(e)); return SPLICE_ERR_HIP; }

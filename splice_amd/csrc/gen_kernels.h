@@ -9,6 +9,7 @@ struct ConvArgs {
     float* out;           // [N][*][Ho][Wo]; channel n at out + img*out_nstride + n*out_cstride
     size_t in_nstride, in_cstride, out_nstride, out_cstride;
     size_t w_jstride, w_cstride;
+    size_t p_nstride;     // > 0: independent images -- image n reads w / bias at + n * p_nstride (its own parameter arena)
     int N, Cin, Hi, Wi, Cout, Ho, Wo;   // Cin = reduction channels, Cout = output columns
     int ks, stride, pad;
     int act;          // 1 = sigmoid
@@ -53,7 +54,8 @@ struct WgradReduceAll {      // by-value kernel argument: one entry per conv lay
     long long total;
     int count;
 };
-int wgrad_reduce_all_launch(const WgradReduceAll& d, const float* ws, float* grads, int accumulate, hipStream_t s);
+// p_nstride > 0: independent images -- image n's chunks are summed into grads + n * p_nstride
+int wgrad_reduce_all_launch(const WgradReduceAll& d, const float* ws, float* grads, int accumulate, hipStream_t s, int n_img = 1, size_t p_nstride = 0);
 
 // train-mode BatchNorm (+LeakyReLU when slope != 1) forward: statistics in two deterministic stages
 // (per-segment partials, recombined in the apply kernel); `part` = bn_part_floats(N, C) floats of scratch.
@@ -69,15 +71,17 @@ struct BnUpsample {
 };
 bool bn_bwd_fuses_upsample(int HW, int h, int w);
 int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
-                  const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s, const BnUpsample* up = nullptr);
+                  const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s, const BnUpsample* up = nullptr,
+                  size_t p_nstride = 0);
 // same, fused with the split-K reduction of the convolution that feeds it (small planes only: HW <= bn_small_hw()):
 // y = bias + sum_k slabs[k] is formed, stored (the backward reads it) and normalised in one launch
 int bn_small_hw();
 int bn_fwd_slabs_launch(const float* slabs, int ksplit, const float* bias, float* y, size_t y_nstride, float* out, size_t out_nstride, int N,
-                        int C, int HW, const float* gamma, const float* beta, float eps, float* mean, float* rstd, float slope, hipStream_t s);
+                        int C, int HW, const float* gamma, const float* beta, float eps, float* mean, float* rstd, float slope, hipStream_t s,
+                        size_t p_nstride = 0);
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
-                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up = nullptr);
+                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up = nullptr, size_t p_nstride = 0);
 int fill_zero_launch(float* p, int n, hipStream_t s);
 int channel_sum_launch(const float* dy, size_t nstride, int N, int C, int HW, float* db, int accumulate, hipStream_t s);
 int upsample2x_fwd_launch(const float* in, size_t in_nstride, float* out, size_t out_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s);
@@ -86,7 +90,7 @@ int sigmoid_bwd_launch(const float* dout, const float* sout, float* dpre, size_t
 // sigmoid backward of the [N][C][HW] head + per-channel sums of the result (the head's bias gradient) in two
 // deterministic stages; part = C * 64 floats of scratch
 int sigmoid_bwd_bias_launch(const float* dout, const float* sout, float* dpre, int N, int C, int HW, float* part, float* db,
-                            int accumulate, hipStream_t s);
+                            int accumulate, hipStream_t s, size_t p_nstride = 0);
 int adam_launch(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step, int zero_grad, hipStream_t s);
 int adam_launch_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, const int* step_dev,
                     int zero_grad, hipStream_t s, const float* g2 = nullptr);

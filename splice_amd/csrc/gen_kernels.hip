@@ -46,6 +46,9 @@ __global__ __launch_bounds__(256 * NG) void conv_igemm_kernel(ConvArgs a) {
     const int m0 = blockIdx.x * BM;
     const int HWo = a.Ho * a.Wo;
     const float* in = a.in + (size_t)img * a.in_nstride;
+    // independent images (several pairs optimised side by side): image n convolves with ITS OWN parameter arena
+    const float* wgt = a.w + (size_t)img * a.p_nstride;
+    const float* bias = a.bias ? a.bias + (size_t)img * a.p_nstride : nullptr;
     const int pl = tid & 63;
     const int p = m0 + pl;
     const bool pvalid = p < HWo;
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256 * NG) void conv_igemm_kernel(ConvArgs a) {
     float av[NA], wv[NW];
     auto fetch = [&](int c0) {
         const float* inc = in + (size_t)c0 * a.in_cstride;
-        const float* wc = a.w + (size_t)c0 * a.w_cstride;
+        const float* wc = wgt + (size_t)c0 * a.w_cstride;
 #pragma unroll
         for (int i = 0; i < NA; ++i) av[i] = ((a_ok >> i) & 1u) && (c0 + a_cl[i] < Kc) ? inc[a_off[i]] : 0.f;
 #pragma unroll
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256 * NG) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int nc = min(n0 + j * 16 + (lane & 15), a.Cout - 1);
-        bj[j] = a.bias ? a.bias[nc] : 0.f;
+        bj[j] = bias ? bias[nc] : 0.f;
         if (a.accumulate) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) prev[j][r] = out[(size_t)nc * a.out_cstride + min(m0 + pw * 16 + (lane >> 4) * 4 + r, HWo - 1)];
@@ -202,7 +205,7 @@ __global__ void conv_splitk_reduce_kernel(ConvArgs a, int ksplit) {
         const int pp = i % HWo;
         const int n = (i / HWo) % a.Cout;
         const int img = i / ((size_t)HWo * a.Cout);
-        float v = a.bias ? a.bias[n] : 0.f;
+        float v = a.bias ? a.bias[(size_t)img * a.p_nstride + n] : 0.f;
         float* q = a.out + (size_t)img * a.out_nstride + (size_t)n * a.out_cstride + pp;
         const float prev = a.accumulate ? *q : 0.f;
         int k = 0;
@@ -226,7 +229,10 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
     // latency-bound and more, smaller workgroups shorten them; the 32-channel layers are indifferent (2 kept)
     const int fn = (a.Cout > 16 && a.Cout <= 32) ? 2 : 1;
     const int nt = cdiv(a.Cout, 16 * fn);
-    const int wgs = mt * nt * a.N;
+    // launch policy (split-K, 8-wave workgroups) from the workgroups of ONE image when the images are independent pairs:
+    // split-K changes the summation order, and a pair's result must not depend on how many pairs share the launch
+    const int npol = a.p_nstride ? 1 : a.N;
+    const int wgs = mt * nt * npol;
     int ksplit = 1;
     const int ktiles = cdiv(a.Cin, CK);
     if (a.ws && wgs < 128 && ktiles >= 4 && (size_t)a.N * a.Cout * HWo * 16 <= a.ws_floats) {
@@ -241,7 +247,7 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
     dim3 grid(mt, nt * ksplit, a.N);
     // 8-wave workgroups while the chip holds at most ~2 workgroups per CU (the serial K walk is the run time then)
     constexpr bool CAN8 = KS == 3 && CK == 8;   // (K tile of 72: 9 steps per wave group; the A tile is big enough for the exchange)
-    const bool ng2 = CAN8 && (long)mt * nt * ksplit * a.N <= 2048 && cdiv(a.Cin, CK) >= 2;
+    const bool ng2 = CAN8 && (long)mt * nt * ksplit * npol <= 2048 && cdiv(a.Cin, CK) >= 2;
     if (ng2) {
         if constexpr (CAN8) {
             if (fn == 1) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1, CK, 2>), grid, dim3(512), 0, s, a);
@@ -390,16 +396,24 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, int chunk, i
 }
 
 // dw[layer][i] (+)= sum_chunk ws[layer][chunk][i] for every conv layer of a backward in one launch
+// n_img > 1 with p_nstride > 0: independent images -- blockIdx.y = image, which sums only ITS chunks (chunk index = image *
+// chunks_per_image + k) into its own gradient arena
 __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(WgradReduceAll d, const float* __restrict__ ws, float* __restrict__ grads,
-                                                               int accumulate) {
+                                                               int accumulate, int n_img, size_t p_nstride) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= d.total) return;
     int l = 0;
 #pragma unroll 1
     while (l + 1 < d.count && gid >= d.prefix[l + 1]) ++l;
     const int i = (int)(gid - d.prefix[l]);
-    const int n = d.n[l], chunks = d.chunks[l];
+    const int n = d.n[l];
+    int chunks = d.chunks[l];
     const float* p = ws + d.ws_off[l] + i;
+    if (p_nstride) {
+        chunks /= n_img;
+        p += (size_t)blockIdx.y * chunks * n;
+        grads += (size_t)blockIdx.y * p_nstride;
+    }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // 4 independent chains in a FIXED association order
     int c = 0;
     for (; c + 15 < chunks; c += 16) {   // 16 loads in flight, added in the order of the 4-wide loop below (same bits)
@@ -500,9 +514,10 @@ int conv_wgrad_batched_launch(const WgradBatchPair& p, hipStream_t s) {
     return SPLICE_OK;
 }
 
-int wgrad_reduce_all_launch(const WgradReduceAll& d, const float* ws, float* grads, int accumulate, hipStream_t s) {
+int wgrad_reduce_all_launch(const WgradReduceAll& d, const float* ws, float* grads, int accumulate, hipStream_t s, int n_img, size_t p_nstride) {
     if (d.count < 1 || d.count > WGRAD_MAX_LAYERS) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3((unsigned)((d.total + 255) / 256)), dim3(256), 0, s, d, ws, grads, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3((unsigned)((d.total + 255) / 256), p_nstride ? n_img : 1), dim3(256), 0, s, d, ws, grads, accumulate,
+                       n_img, p_nstride);
     return SPLICE_OK;
 }
 
@@ -637,9 +652,10 @@ __device__ __forceinline__ void bn_combine_wave(const float* part, int PB, int H
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y, size_t y_nstride, float* __restrict__ out,
                                                      size_t out_nstride, int C, int HW, int PB, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, const float* __restrict__ part, float eps,
-                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o, float slope) {
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o, float slope, size_t p_nstride) {
     __shared__ float st[2];
     const int c = blockIdx.y, img = blockIdx.z;
+    gamma += (size_t)img * p_nstride; beta += (size_t)img * p_nstride;
     if (threadIdx.x < 64) {
         float m, r;
         bn_combine_wave(part + ((size_t)img * C + c) * PB * 2, PB, HW, eps, m, r);
@@ -692,15 +708,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dy, size_t dy_nstride, int C, int HW, int N, int PB,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, float slope, const float* __restrict__ part,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, size_t p_nstride) {
     __shared__ float st[2];
     const int c = blockIdx.y, img = blockIdx.z;
+    gamma += (size_t)img * p_nstride;
     if (threadIdx.x < 64) {   // one wave: lane k holds segment k (PB <= 64), fixed-order tree sums
         const int lane = threadIdx.x;
         const float* pp = part + ((size_t)img * C + c) * PB * 2;
         const float a = wave_sum(lane < PB ? pp[2 * lane] : 0.f), b = wave_sum(lane < PB ? pp[2 * lane + 1] : 0.f);
         if (lane == 0) { st[0] = a; st[1] = b; }
-        if (img == 0 && blockIdx.x == 0) {   // parameter gradients: sum over the images in order
+        if (p_nstride) {   // independent images: every image owns its parameter gradients (the sums of the N = 1 path: 0 + x)
+            if (blockIdx.x == 0 && lane == 0) {
+                float* dg = dgamma + (size_t)img * p_nstride + c;
+                float* db = dbeta + (size_t)img * p_nstride + c;
+                const float g = 0.f + b, be = 0.f + a;
+                *dg = accumulate ? *dg + g : g;
+                *db = accumulate ? *db + be : be;
+            }
+        } else if (img == 0 && blockIdx.x == 0) {   // parameter gradients: sum over the images in order
             float g = 0.f, be = 0.f;
             for (int n = 0; n < N; ++n) {
                 const float* pn = part + ((size_t)n * C + c) * PB * 2;
@@ -753,10 +778,13 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
                                                            size_t out_nstride, int C, int HW, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float* __restrict__ mean_o,
                                                            float* __restrict__ rstd_o, float slope, const float* __restrict__ slabs,
-                                                           int ksplit, const float* __restrict__ bias, float* __restrict__ y_out, BnUpsample up) {
+                                                           int ksplit, const float* __restrict__ bias, float* __restrict__ y_out, BnUpsample up,
+                                                           size_t p_nstride) {
     __shared__ float red[8];
     __shared__ float up_src_s[BN_UP_SRC];
     const int c = blockIdx.x, img = blockIdx.y;
+    gamma += (size_t)img * p_nstride; beta += (size_t)img * p_nstride;
+    if (bias) bias += (size_t)img * p_nstride;
     const float* p = y + (size_t)img * y_nstride + (size_t)c * HW;
     float* q = out + (size_t)img * out_nstride + (size_t)c * HW;
     // loads are issued branch-free (wave-uniform guards only; a thread past the end of the plane re-reads element 0 and
@@ -897,10 +925,11 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
                                                            float* __restrict__ dy, size_t dy_nstride, int C, int HW, int N,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, float slope, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int accumulate, BnUpsample up) {
+                                                           float* __restrict__ dbeta, int accumulate, BnUpsample up, size_t p_nstride) {
     __shared__ float red[8];
     __shared__ float up_grad_s[BN_SMALL_HW];   // fused upsampling adjoint: this plane's input gradient
     const int c = blockIdx.x, img = blockIdx.y;
+    gamma += (size_t)img * p_nstride;
     float dz[BN_SMALL_PER], xh[BN_SMALL_PER];
     float s1, s2;
     {
@@ -928,6 +957,15 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
                 qd[e] = up_adjoint_value((const float*)up_grad_s, up.h, up.w, up.Ho, up.Wo, e / up.w, e % up.w);
         }
     }
+    if (p_nstride) {   // independent images: every image owns its parameter gradients
+        if (threadIdx.x == 0) {
+            float* dg = dgamma + (size_t)img * p_nstride + c;
+            float* db = dbeta + (size_t)img * p_nstride + c;
+            *dg = accumulate ? *dg + s2 : s2;
+            *db = accumulate ? *db + s1 : s1;
+        }
+        return;
+    }
     if (img != 0) return;
     float g = s2, be = s1;
     for (int n = 1; n < N; ++n) {
@@ -947,41 +985,41 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
 static inline int plane_blocks(int HW) { int b = cdiv(HW, 512); return b < 1 ? 1 : (b > MAX_PB ? MAX_PB : b); }
 int bn_part_floats(int N, int C) { return N * C * MAX_PB * 2; }
 int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
-                  const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s, const BnUpsample* up) {
+                  const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s, const BnUpsample* up, size_t p_nstride) {
     const BnUpsample u = up ? *up : BnUpsample{};
     if (HW <= BN_SMALL_HW) {
         hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd, slope,
-                           (const float*)nullptr, 0, (const float*)nullptr, (float*)nullptr, u);
+                           (const float*)nullptr, 0, (const float*)nullptr, (float*)nullptr, u, p_nstride);
         return SPLICE_OK;
     }
     const int PB = plane_blocks(HW);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, C, HW, PB, part, u);
-    hipLaunchKernelGGL(bn_act_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, PB, gamma, beta, part, eps, mean, rstd, slope);
+    hipLaunchKernelGGL(bn_act_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, PB, gamma, beta, part, eps, mean, rstd, slope, p_nstride);
     return SPLICE_OK;
 }
 bool bn_bwd_fuses_upsample(int HW, int h, int w) { return HW <= BN_SMALL_HW && h > 0 && w > 0; }
 int bn_small_hw() { return BN_SMALL_HW; }
 int bn_fwd_slabs_launch(const float* slabs, int ksplit, const float* bias, float* y, size_t y_nstride, float* out, size_t out_nstride, int N,
-                        int C, int HW, const float* gamma, const float* beta, float eps, float* mean, float* rstd, float slope, hipStream_t s) {
+                        int C, int HW, const float* gamma, const float* beta, float eps, float* mean, float* rstd, float slope, hipStream_t s, size_t p_nstride) {
     if (HW > BN_SMALL_HW || ksplit < 2 || !slabs) return SPLICE_ERR_ARG;
     hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C, N), dim3(256), 0, s, (const float*)y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd,
-                       slope, slabs, ksplit, bias, y, BnUpsample{});
+                       slope, slabs, ksplit, bias, y, BnUpsample{}, p_nstride);
     return SPLICE_OK;
 }
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
-                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up) {
+                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up, size_t p_nstride) {
     if (HW <= BN_SMALL_HW) {
         BnUpsample u = up ? *up : BnUpsample{};
         if (!bn_bwd_fuses_upsample(HW, u.h, u.w)) u.d_src = nullptr;
         hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy, dy_nstride, C, HW, N,
-                           gamma, mean, rstd, slope, dgamma, dbeta, accumulate, u);
+                           gamma, mean, rstd, slope, dgamma, dbeta, accumulate, u, p_nstride);
         return SPLICE_OK;
     }
     const int PB = plane_blocks(HW);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, C, HW, PB, mean, rstd, slope, part);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy,
-                       dy_nstride, C, HW, N, PB, gamma, mean, rstd, slope, part, dgamma, dbeta, accumulate);
+                       dy_nstride, C, HW, N, PB, gamma, mean, rstd, slope, part, dgamma, dbeta, accumulate, p_nstride);
     return SPLICE_OK;
 }
 __global__ void fill_zero_kernel(float* p, int n) {
@@ -1040,6 +1078,7 @@ __global__ void sigmoid_bwd_kernel(const float* __restrict__ dout, const float* 
     }
 }
 // stage 1: block (pb, c) handles segment pb of channel c over every image; stage 2: one block sums the partials in order
+// gridDim.z > 1: independent images -- blockIdx.z = image, partials per image
 __global__ __launch_bounds__(256) void sigmoid_bwd_bias_kernel(const float* __restrict__ dout, const float* __restrict__ sout,
                                                                float* __restrict__ dpre, int N, int C, int HW, int PB,
                                                                float* __restrict__ part) {
@@ -1047,7 +1086,9 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_bias_kernel(const float* __re
     const int pb = blockIdx.x, c = blockIdx.y;
     const int seg = seg_len(HW, PB), lo = pb * seg, hi = min(lo + seg, HW);
     float acc = 0.f, dummy = 0.f;
-    for (int n = 0; n < N; ++n) {
+    const int n_lo = gridDim.z > 1 ? blockIdx.z : 0, n_hi = gridDim.z > 1 ? blockIdx.z + 1 : N;
+    part += (size_t)(gridDim.z > 1 ? blockIdx.z : 0) * C * PB;
+    for (int n = n_lo; n < n_hi; ++n) {
         const size_t base = ((size_t)n * C + c) * HW;
         for (int i = lo + threadIdx.x; i < hi; i += 256) {
             const float sv = sout[base + i];
@@ -1059,18 +1100,21 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_bias_kernel(const float* __re
     block_sum2(acc, dummy, red);
     if (threadIdx.x == 0) part[c * PB + pb] = acc;
 }
-__global__ void bias_part_reduce_kernel(const float* __restrict__ part, int C, int PB, float* __restrict__ db, int accumulate) {
+__global__ void bias_part_reduce_kernel(const float* __restrict__ part, int C, int PB, float* __restrict__ db, int accumulate, size_t p_nstride) {
     const int c = threadIdx.x;
     if (c >= C) return;
+    part += (size_t)blockIdx.x * C * PB;
+    db += (size_t)blockIdx.x * p_nstride;
     float s = 0.f;
     for (int k = 0; k < PB; ++k) s += part[c * PB + k];
     db[c] = accumulate ? db[c] + s : s;
 }
 int sigmoid_bwd_bias_launch(const float* dout, const float* sout, float* dpre, int N, int C, int HW, float* part, float* db,
-                            int accumulate, hipStream_t s) {
+                            int accumulate, hipStream_t s, size_t p_nstride) {
     const int PB = plane_blocks(HW);
-    hipLaunchKernelGGL(sigmoid_bwd_bias_kernel, dim3(PB, C), dim3(256), 0, s, dout, sout, dpre, N, C, HW, PB, part);
-    hipLaunchKernelGGL(bias_part_reduce_kernel, dim3(1), dim3(64), 0, s, part, C, PB, db, accumulate);
+    const int nz = p_nstride ? N : 1;
+    hipLaunchKernelGGL(sigmoid_bwd_bias_kernel, dim3(PB, C, nz), dim3(256), 0, s, dout, sout, dpre, N, C, HW, PB, part);
+    hipLaunchKernelGGL(bias_part_reduce_kernel, dim3(nz), dim3(64), 0, s, part, C, PB, db, accumulate, p_nstride);
     return SPLICE_OK;
 }
 int sigmoid_bwd_launch(const float* dout, const float* sout, float* dpre, size_t n, hipStream_t s) {

@@ -186,3 +186,29 @@ def vit_params(seed: int, model_name: str = None, patch=None, dim=None, depth=No
         else:
             out[name] = normal(seed, tag, shape, g_std, 1.0)
     return out
+
+
+def vit_params_outlier(seed: int, model_name: str, img_size=224, w_std=0.03, n_outlier=4):
+    """A DINO-shaped weight set with the statistics that make trained ViTs hard for bf16: a handful of
+    "massive" residual-stream channels (large constant offsets injected by the position table, the patch-embed bias and the
+    fc2 biases of the deeper blocks -- in trained DINO these reach tens of sigma), heavy-tailed LayerNorm gains (log-normal,
+    with the massive channels squashed as trained models do), and a few large key biases.  Everything else as
+    ``vit_params``.  Used by the parity tests to bound the bf16 path's error where the zero-mean N(0, sigma) synthetic set
+    cannot."""
+    patch, dim, depth, _ = DINO_CONFIGS[model_name]
+    out = vit_params(seed, model_name, img_size=img_size, w_std=w_std)
+    hot = (np.argsort(uniform(seed, "outlier/channels", (dim,)))[:n_outlier]).astype(np.int64)
+    sign = np.where(uniform(seed, "outlier/sign", (n_outlier,)) < 0.5, -1.0, 1.0).astype(np.float32)
+    out["pos_embed"][..., hot] += 6.0 * sign
+    out["patch_embed.proj.bias"][hot] += 4.0 * sign
+    for l in range(depth):
+        if l >= depth // 4:
+            out[f"blocks.{l}.mlp.fc2.bias"][hot] += 3.0 * sign
+        for ln in ("norm1", "norm2"):
+            g = out[f"blocks.{l}.{ln}.weight"]
+            g *= np.exp(normal(seed, f"outlier/g/{l}/{ln}", (dim,), 0.7)).astype(np.float32)
+            g[hot] *= 0.1
+        kb = out[f"blocks.{l}.attn.qkv.bias"]
+        big = (np.argsort(uniform(seed, f"outlier/kb/{l}", (dim,)))[:3] + dim).astype(np.int64)   # key columns
+        kb[big] += 5.0
+    return out

@@ -37,8 +37,34 @@ def test_version_and_error_string():
     assert isinstance(lib.splice_last_error(), bytes)
 
 
-def test_struct_layouts_match_header():
-    """ctypes mirrors of the two public structs have the C sizes (x86-64 SysV)."""
-    assert ctypes.sizeof(_lib.GemmEpilogue) == 8 + 8 + 4 + 4 + 8 + 4 + 4 + 8 + 4 + 4 + 8 + 4 + 4 + 8 + 4 + 4 + 8 + 4 + 4 + 4 + 4 + 4 + 4 or \
-        ctypes.sizeof(_lib.GemmEpilogue) % 8 == 0
-    assert ctypes.sizeof(_lib.StepConfig) == 19 * 4
+def _c_layout(struct, fields, tmp_path):
+    """sizeof + offsetof of every field, as the C compiler lays out include/splice_hip.h (gcc, x86-64)."""
+    import subprocess
+    src = tmp_path / f"layout_{struct}.c"
+    lines = "".join(f'    printf("{f} %zu\\n", offsetof({struct}, {f}));\n' for f in fields)
+    src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "splice_hip.h"\nint main(void) {{\n'
+                   f'    printf("sizeof %zu\\n", sizeof({struct}));\n{lines}    return 0;\n}}\n')
+    exe = tmp_path / f"layout_{struct}"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    return dict(zip(out[0::2], map(int, out[1::2])))
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors of the public structs agree with the C compiler's layout of the header: same size, same
+    offset for every field, and no field of the header missing from the binding (or vice versa)."""
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "splice_hip.h")).read(), flags=re.S)
+    for cname, mirror in (("splice_gemm_epilogue", _lib.GemmEpilogue), ("splice_step_config", _lib.StepConfig)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
+        header_fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                header_fields += [re.sub(r"[*\s]", "", part).split()[-1] if " " in part.strip() else part.strip().lstrip("*")
+                                  for part in re.sub(r"^(const\s+)?[A-Za-z_0-9 ]+?[ *]+(?=[A-Za-z_0-9]+\s*(,|$))", "", decl).split(",")]
+        bound_fields = [f[0] for f in mirror._fields_]
+        assert header_fields == bound_fields, (cname, header_fields, bound_fields)
+        c = _c_layout(cname, bound_fields, tmp_path)
+        assert ctypes.sizeof(mirror) == c["sizeof"], (cname, ctypes.sizeof(mirror), c["sizeof"])
+        for f in bound_fields:
+            assert getattr(mirror, f).offset == c[f], (cname, f, getattr(mirror, f).offset, c[f])

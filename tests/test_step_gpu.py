@@ -21,6 +21,8 @@ from splice_amd.engine import LOSS_KEYS, SpliceEngine
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+# bars of the output-pixel check in test_trajectory_a (set from the measured values)
+PIX_MEAN_TOL, PIX_STD_TOL, PIX_PSNR_FLOOR = 0.05, 0.35, 15.0   # measured r2: <= 0.034, <= 0.22, 17.0 dB
 
 
 def _engine(cfg_over, A, B, gen_seed, img_size):
@@ -52,6 +54,50 @@ def _check(rows, gl, keys, lo, hi, rtol):
     print(f"    steps {lo}..{hi - 1}: worst rel loss deviation {worst:.3e}")
 
 
+def _oracle_for(name, img_size, vit_state, gen_state, cfg):
+    from oracle import dino_vit
+    from oracle.step import SpliceOracle
+    patch, dim, depth, heads = dino_vit.DINO_CONFIGS[name]
+    m = dino_vit.VisionTransformer(patch, dim, depth, heads, img_size=img_size).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in vit_state.items()})
+    return SpliceOracle(m, {k: torch.from_numpy(v) for k, v in gen_state.items()}, cfg)
+
+
+def _grad_rel_err(eng, og):
+    """whole-arena relative L2 distance of the engine's generator gradient to the oracle's autograd gradient"""
+    num = den = 0.0
+    for (name, gt), go in zip(eng.gen.unflatten(eng.grads).items(), og):
+        if name.endswith("0.bias") and name != "9.0.bias":
+            continue   # conv biases that feed a train-mode BatchNorm: analytically zero (the oracle holds rounding noise)
+        d = (gt.cpu().double() - go.reshape(-1).double()).norm().item()
+        num, den = num + d * d, den + go.double().norm().item() ** 2
+    return (num / den) ** 0.5
+
+
+def _teacher_forced(eng, orc, A, B, A_ent, steps, loss_tol=3e-2, grad_tol=5e-2, tag=""):
+    """Before every step the engine's parameters are reset to the oracle's, so both sides evaluate the SAME point
+    (see test_step_gradients_vs_oracle_teacher_forced for why); every loss entry and the whole gradient are compared."""
+    At, Bt = torch.from_numpy(A), torch.from_numpy(B)
+    Et = None if A_ent is None else torch.from_numpy(A_ent)
+    Ad, Bd, Ed = At.to(DEV), Bt.to(DEV), None if Et is None else Et.to(DEV)
+    worst_l = worst_g = 0.0
+    for step in range(steps):
+        eng.params.copy_(eng.gen.flatten({k: v.detach() for k, v in orc.params.items()}))
+        lo, _, og = orc.step(At[None], Bt[None], None if Et is None else Et[None])
+        eng.step(Ad, Bd, Ed)
+        le = eng.losses()
+        assert set(le) == set(lo), (step, sorted(le), sorted(lo))
+        for k in lo:
+            rel = abs(le[k] - lo[k]) / abs(lo[k])
+            worst_l = max(worst_l, rel)
+            assert rel < loss_tol, (tag, step, k, le[k], lo[k])
+        rel = _grad_rel_err(eng, og)
+        worst_g = max(worst_g, rel)
+        print(f"    {tag} step {step}: loss {le['loss']:.4f} vs oracle {lo['loss']:.4f}; gradient rel err {rel:.3e}")
+        assert rel < grad_tol, (tag, step, rel)
+    return worst_l, worst_g
+
+
 def test_trajectory_a_identity_resize(golden_dir):
     g = np.load(os.path.join(golden_dir, "steps.npz"))
     keys = [str(k) for k in g["loss_keys"]]
@@ -74,8 +120,17 @@ def test_trajectory_a_identity_resize(golden_dir):
     refimg = g["a/final_out"]
     mse = float(((out - refimg) ** 2).mean())
     psnr = 10 * np.log10(1.0 / max(mse, 1e-12))
-    print(f"    final image PSNR(HIP engine vs reference CPU fp32) after 78 steps: {psnr:.1f} dB (reported, chaotic)")
+    print(f"    final image PSNR(HIP engine vs reference CPU fp32) after 78 steps: {psnr:.1f} dB")
     assert out.shape == refimg.shape and np.isfinite(out).all() and 0.0 <= out.min() and out.max() <= 1.0
+    # output PIXELS (north_star: "loss trajectories and output pixels"): the trajectory is chaotic pointwise (see the module
+    # docstring), but both runs descend the same loss, so the image statistics must agree: per-channel mean / std of the
+    # generated image, its PSNR against the reference's image, and -- the structure term at work -- its correlation with
+    # the structure image's luminance layout
+    for c in range(3):
+        mo, mr, so, sr = out[0, c].mean(), refimg[0, c].mean(), out[0, c].std(), refimg[0, c].std()
+        print(f"    channel {c}: mean {mo:.4f} vs {mr:.4f}, std {so:.4f} vs {sr:.4f}")
+        assert abs(mo - mr) < PIX_MEAN_TOL and abs(so - sr) < PIX_STD_TOL * max(sr, 1e-3), (c, mo, mr, so, sr)
+    assert psnr > PIX_PSNR_FLOOR, psnr
 
 
 def test_trajectory_b_resize_nonsquare(golden_dir):
@@ -154,12 +209,12 @@ def test_streams_and_graph_do_not_change_results():
 
 
 def test_full_size_step_vs_oracle_and_replay_modes():
-    """BASELINE configs[1] at full size (224x224 pair, ViT-B/8, T = 785): the first step (CLS warm-up regime + the
-    entire-image branch) against the fp32 CPU oracle at identical parameters -- every loss term within 3e-2, whole-arena
-    generator gradient within 5e-2 rel-L2 -- and, as the size-independent property, graph replay == eager single-stream
-    launches bit for bit over 3 steps."""
-    from oracle import dino_vit
-    from oracle.step import SpliceOracle
+    """BASELINE configs[1] at full size (224x224 pair, ViT-B/8, T = 785), teacher-forced steps 0, 1, 2 against the fp32 CPU
+    oracle: step 0 is the CLS warm-up regime + the entire-image branch, steps 1-2 are the ORDINARY regime every timed step
+    of bench.py runs (global ssim + cls + id, two N=1 generator plans, split-K dgrads, id-loss seeds at T = 785).  Every
+    loss term within 3e-2, whole-arena generator gradient within 5e-2 rel-L2 (bf16 ViT; synthetic N(0, 0.03) weights -- a
+    trained checkpoint has outlier channels, see test_outlier_weights_step_vs_oracle).  Then the size-independent property:
+    graph replay == eager single-stream launches bit for bit over 3 steps."""
     from splice_amd import _lib
     from splice_amd.engine import SpliceEngine
     cfg = dict(dino_model_name="dino_vitb8", dino_global_patch_size=224)
@@ -167,24 +222,9 @@ def test_full_size_step_vs_oracle_and_replay_modes():
     vit_state = synth.vit_params(7, "dino_vitb8", img_size=224, w_std=0.03)
     gen_state = synth.generator_params(9, 0.02)
     eng = SpliceEngine(cfg, vit_state, gen_state, (224, 224), (224, 224))
-    m = dino_vit.VisionTransformer(8, 768, 12, 12, img_size=224).eval()
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in vit_state.items()})
-    orc = SpliceOracle(m, {k: torch.from_numpy(v) for k, v in gen_state.items()}, cfg)
-    At, Bt = torch.from_numpy(A), torch.from_numpy(B)
-    Ad, Bd = At.to(DEV), Bt.to(DEV)
-    lo, _, og = orc.step(At[None], Bt[None], At[None])
-    eng.step(Ad, Bd, Ad)
-    le = eng.losses()
-    assert set(le) == set(lo)
-    for k in lo:
-        assert abs(le[k] - lo[k]) / abs(lo[k]) < 3e-2, (k, le[k], lo[k])
-    num = den = 0.0
-    for (name, gt), go in zip(eng.gen.unflatten(eng.grads).items(), og):
-        if name.endswith("0.bias") and name != "9.0.bias":   # conv biases feeding a BatchNorm: analytically zero
-            continue
-        d = (gt.cpu().double() - go.reshape(-1).double()).norm().item()
-        num, den = num + d * d, den + go.double().norm().item() ** 2
-    assert (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
+    orc = _oracle_for("dino_vitb8", 224, vit_state, gen_state, cfg)
+    _teacher_forced(eng, orc, A, B, A, 3, tag="224/B8")
+    Ad, Bd = torch.from_numpy(A).to(DEV), torch.from_numpy(B).to(DEV)
     # replay modes at full size
     ref = None
     for graph, overlap in ((1, 1), (0, 0)):
@@ -278,3 +318,53 @@ def test_large_size_step_replay_modes_and_vit_parity():
         else:
             assert torch.equal(eng.params, ref)
         del eng
+
+
+def test_config0_128px_vitb16_resize_vs_oracle():
+    """BASELINE configs[0]: 128x128 pair, DINO ViT-B/16, dino_global_patch_size 224 -- every ViT input goes through the
+    NON-identity bilinear Resize 128 -> 224 (and its adjoint in the backward), T = 197.  Teacher-forced steps 0-1 (entire +
+    cls, then ssim + cls + id) against the fp32 oracle: losses 3e-2, gradient 5e-2."""
+    cfg = dict(dino_model_name="dino_vitb16", dino_global_patch_size=224)
+    A, B = synth.smooth_image_pair(128, 0, 128, 128)
+    vit_state = synth.vit_params(7, "dino_vitb16", img_size=224, w_std=0.03)
+    gen_state = synth.generator_params(9, 0.02)
+    eng = SpliceEngine(cfg, vit_state, gen_state, (128, 128), (128, 128))
+    assert eng.vit_hw == (224, 224) and eng.ctx_g.T == 197
+    orc = _oracle_for("dino_vitb16", 224, vit_state, gen_state, cfg)
+    _teacher_forced(eng, orc, A, B, A, 2, tag="128->224/B16")
+
+
+@pytest.mark.parametrize("term", ["cls", "ssim", "id"])
+def test_448_step_loss_and_gradient_vs_oracle(term):
+    """BASELINE configs[3] (448x448 pair, ViT-B/8, T = 3137: attn_fwd_kernel<2>, the two-launch attention backward, the
+    T = 3137 self-similarity GEMMs, interpolated position table), LOSS and whole-arena GRADIENT against the fp32 CPU oracle
+    at identical parameters.  One loss term per case (the other lambdas are zero on both sides) so that the oracle's
+    autograd holds ONE differentiated ViT pass of 12 x [12, 3137, 3137] probabilities in host memory, not three."""
+    lam = dict(lambda_global_cls=0.0, lambda_global_ssim=0.0, lambda_global_identity=0.0, lambda_entire_cls=0.0, lambda_entire_ssim=0.0)
+    lam[{"cls": "lambda_global_cls", "ssim": "lambda_global_ssim", "id": "lambda_global_identity"}[term]] = {"cls": 10.0, "ssim": 1.0, "id": 1.0}[term]
+    cfg = dict(dino_model_name="dino_vitb8", dino_global_patch_size=448, entire_A_every=10 ** 9, cls_warmup=0, **lam)
+    A, B = synth.smooth_image_pair(448, 0, 448, 448)
+    vit_state = synth.vit_params(7, "dino_vitb8", img_size=224, w_std=0.03)
+    gen_state = synth.generator_params(9, 0.02)
+    eng = SpliceEngine(cfg, vit_state, gen_state, (448, 448), None)
+    assert eng.ctx_g.T == 3137
+    orc = _oracle_for("dino_vitb8", 224, vit_state, gen_state, cfg)
+    _teacher_forced(eng, orc, A, B, None, 1, tag=f"448/{term}")
+
+
+@pytest.mark.parametrize("name,size", [("dino_vits8", 64), ("dino_vitb8", 224)])
+def test_outlier_weights_step_vs_oracle(name, size):
+    """every other bf16 tolerance in this suite is measured on zero-mean N(0, sigma) synthetic ViTs, while trained
+    DINO checkpoints carry massive residual-stream channels, heavy-tailed LayerNorm gains and large key biases (no real
+    checkpoint is available offline).  `synth.vit_params_outlier` builds such a set; teacher-forced steps 0-2 against the
+    fp32 oracle bound what the bf16 path (bf16 LN outputs / qkv / attention / self-similarity Gram) does to the loss terms
+    and to the generator gradient there.  Bars: losses 2e-2, gradient 3e-2 (measured r2: 7e-3 / 1.3e-2 -- no worse than the
+    zero-mean synthetic set)."""
+    cfg = dict(dino_model_name=name, dino_global_patch_size=size)
+    A, B = synth.smooth_image_pair(77, 3, size, size)
+    vit_state = synth.vit_params_outlier(7, name, img_size=size)
+    gen_state = synth.generator_params(9, 0.02)
+    eng = SpliceEngine(cfg, vit_state, gen_state, (size, size), (size, size))
+    orc = _oracle_for(name, size, vit_state, gen_state, cfg)
+    wl, wg = _teacher_forced(eng, orc, A, B, A, 3, loss_tol=2e-2, grad_tol=3e-2, tag=f"outlier/{name}")
+    print(f"    outlier-weight {name}: worst loss rel err {wl:.3e}, worst gradient rel err {wg:.3e}")
