@@ -106,6 +106,30 @@ def visible_gpu_count():
         return 0
 
 
+# live-timed kernel families (splice_prof_begin): name, launches cover `passes(P)` ViT passes, FLOPs per pass
+def kernel_families(T, D, heads, P):
+    hidden = 4 * D
+    return {
+        4: ("gemm_nt_kernel<64,64,BIAS|RESID|OUT_F32,4> (fc2 fwd)", 2 * P, 2.0 * T * hidden * D),
+        1: ("gemm_nt_kernel<128,64|128,BIAS|GELU|OUT_BF,*> (fc1 fwd)", 2 * P, 2.0 * T * hidden * D),
+        2: ("gemm_nt_kernel<128,64,BIAS|OUT_BF|OUT_T,3> (qkv fwd)", 2 * P, 2.0 * T * 3 * D * D),
+        3: ("attn_fwd_kernel", 2 * P, 4.0 * T * T * D),
+        5: ("gemm_nt_kernel<64,64,OUT_F32,4> split-K (fc1^T and qkv^T dgrads, mean of both)", P, 2.0 * T * D * (hidden + 3 * D) / 2),
+        6: ("attn_bwd_kernel", P, 10.0 * T * T * D),
+    }
+
+
+def time_steps(eng, A, B, K, W, barrier):
+    for _ in range(W):
+        eng.step(A, B, A)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        eng.step(A, B, A)
+    barrier()
+    return time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,8 +137,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=224, help="pair height = width (configs[1]: 224)")
     ap.add_argument("--model", default="dino_vitb8")
+    ap.add_argument("--pairs", type=int, default=1, help="pairs optimised side by side per GPU in the timed region (1 = the reference's unit: the latency form of the metric)")
+    ap.add_argument("--pairs-sweep", default="2,4,8", help="additional pairs-per-GPU settings timed briefly after the main region (throughput form: pairs/hr); '' = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prof-kernel", type=int, default=4, help="4 fc2 GEMM (largest share of the step), 1 fc1 GEMM, 2 qkv GEMM, 3 attention fwd, 0 off")
+    ap.add_argument("--prof-kernels", default="4,5,3,6", help="kernel families timed live with HIP events for the roofline leg ('' = off): 4 fc2 fwd, 1 fc1 fwd, 2 qkv fwd, 3 attention fwd, 5 split-K dgrads, 6 attention bwd")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_workers(args.gpus, sys.argv[1:])
@@ -145,7 +171,8 @@ def main():
 
     cfg = dict(dino_model_name=args.model, dino_global_patch_size=args.size)
     hw = (args.size, args.size)
-    eng, A, B = synthetic_engine(cfg, pair_id=rep.pair_id(), hw=hw, seed=1234, device=dev)
+    P = max(1, args.pairs)
+    eng, A, B = synthetic_engine(cfg, pair_id=rep.pair_id() * P, hw=hw, seed=1234, device=dev, pairs=P)
     K, W = args.steps, args.warmup
 
     def barrier():
@@ -153,70 +180,81 @@ def main():
         rep.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(W):
-        eng.step(A, B, A)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(K):
-        eng.step(A, B, A)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    losses = eng.losses()
+    elapsed = time_steps(eng, A, B, K, W, barrier)
+    losses = eng.losses() if P == 1 else eng.losses(0)
     # roofline leg: the timed region replays captured hipGraphs (event records cannot be threaded through a
-    # replay), so the SAME steps continue for a short instrumented stretch with every launch of the chosen
-    # kernel bracketed by HIP events on its own stream (eager launches; the kernel itself is identical).
-    prof_ms, prof_n = C.c_float(0), C.c_int(0)
-    if args.prof_kernel and rank == 0:
-        _lib.check(_lib.lib().splice_prof_begin(args.prof_kernel))
-        for _ in range(min(K, 30)):
-            eng.step(A, B, A)
-        torch.cuda.synchronize()
-        _lib.check(_lib.lib().splice_prof_end(C.byref(prof_ms), C.byref(prof_n)))
+    # replay), so the SAME steps continue for short instrumented stretches with every launch of one kernel family
+    # bracketed by HIP events on its own stream (eager launches; the kernels themselves are identical).
+    prof = {}
+    ev_overhead_ms = 0.0
+    fam_ids = [int(x) for x in args.prof_kernels.split(",") if x.strip()] if rank == 0 else []
+    if fam_ids:
         # an event pair costs time by itself: calibrate on empty pairs (same stream) and subtract
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
         for a_, b_ in evs:
             a_.record(); b_.record()
         torch.cuda.synchronize()
         ev_overhead_ms = sorted(a_.elapsed_time(b_) for a_, b_ in evs)[len(evs) // 2]
-    else:
-        ev_overhead_ms = 0.0
+        for fam in fam_ids:
+            ms, n = C.c_float(0), C.c_int(0)
+            _lib.check(_lib.lib().splice_prof_begin(fam))
+            for _ in range(min(K, 20)):
+                eng.step(A, B, A)
+            torch.cuda.synchronize()
+            _lib.check(_lib.lib().splice_prof_end(C.byref(ms), C.byref(n)))
+            if n.value:
+                prof[fam] = (ms.value, n.value, min(K, 20))
     per_rank_elapsed = rep.gather_floats(elapsed)
     elapsed = rep.max_over_ranks(elapsed)
+    T = eng.ctx_g.T
+    D = eng.vit.dim
+    n_entire = sum(1 for s in range(W, W + K) if s % eng.cfg["entire_A_every"] == 0)
+    # ---- throughput form of the metric: P pairs per GPU through the shared ViT (same barrier-bracketed timing, fewer steps)
+    sweep = {P: K / elapsed}
+    sweep_ids = [int(x) for x in args.pairs_sweep.split(",") if x.strip()] if (world == 1 and P == 1) else []
+    vit = eng.vit
+    for Ps in sweep_ids:
+        try:
+            e2, A2, B2 = synthetic_engine(cfg, pair_id=0, hw=hw, seed=1234, device=dev, pairs=Ps, vit_engine=vit)
+            k2 = max(20, K // 4)
+            sweep[Ps] = k2 / time_steps(e2, A2, B2, k2, max(5, W // 2), barrier)
+            del e2, A2, B2
+            torch.cuda.empty_cache()
+        except Exception as e:   # the sweep must never take the headline number down
+            sweep[Ps] = None
+            print(f"[bench] pairs={Ps} sweep leg failed: {e}", file=sys.stderr)
     if rank != 0:
         rep.close()
         return
 
-    T = eng.ctx_g.T
-    D, hidden = eng.vit.dim, 4 * eng.vit.dim
-    n_entire = sum(1 for s in range(W, W + K) if s % eng.cfg["entire_A_every"] == 0)
-    roof = None
-    if args.prof_kernel and prof_n.value:
-        # algorithmic FLOPs of ONE launch of the timed kernel: every ViT forward launch covers 2 passes x T tokens
-        # (targets A', B' on one stream, generated x', y' on the other; the entire-image branch is a 2-pass batch too)
-        P = 2
-        shapes = {1: ("gemm_nt_kernel<128,128,BIAS|GELU|OUT_BF,2> (fc1 fwd)", 2.0 * P * T * hidden * D),
-                  2: ("gemm_nt_kernel<128,64,BIAS|OUT_BF|OUT_T,2> (qkv fwd)", 2.0 * P * T * 3 * D * D),
-                  3: ("attn_fwd_kernel<1>", 4.0 * P * T * T * D),
-                  4: ("gemm_nt_kernel<64,64,BIAS|RESID|OUT_F32,4> (fc2 fwd)", 2.0 * P * T * hidden * D)}
-        kname, flops = shapes[args.prof_kernel]
-        raw_ms = prof_ms.value / prof_n.value
-        avg_ms = max(raw_ms - ev_overhead_ms, 1e-6)
+    fams = kernel_families(T, D, eng.vit.heads, P)
+    roofs = []
+    traffic_file = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    static_traffic = {}
+    if os.path.exists(traffic_file) and args.size == 224 and args.model == "dino_vitb8" and P == 1:
+        try:
+            static_traffic = json.load(open(traffic_file))
+        except Exception:
+            static_traffic = {}
+    for fam, (tot_ms, n, steps) in prof.items():
+        kname, passes, flops_per_pass = fams[fam]
+        flops = flops_per_pass * passes
+        avg_ms = max(tot_ms / n - ev_overhead_ms, 1e-6)
         ach = flops / (avg_ms * 1e-3) / 1e12
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tfile) and args.size == 224 and args.model == "dino_vitb8":
-            try:
-                traffic = json.load(open(tfile)).get(str(args.prof_kernel))
-            except Exception:
-                traffic = None
-        roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": round(ach / 2500.0, 4), "traffic": traffic,
-                "traffic_source": None if traffic is None else "static: profiles/roofline_traffic.json (PMC passes of an earlier run, not re-measured by this command)",
-                "avg_launch_us": round(avg_ms * 1e3, 2), "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2),
-                "launches": prof_n.value,
-                "note": "algorithmic FLOPs of one launch (2 passes x T tokens) / mean HIP-event duration of its launches, "
-                        "measured on the launch stream over the instrumented continuation of the timed steps (the timed "
-                        "region itself replays hipGraphs), minus the median cost of an empty event pair"}
+        traffic = static_traffic.get(str(fam))
+        roofs.append({"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                      "frac": round(ach / 2500.0, 4), "traffic": traffic,
+                      "traffic_source": None if traffic is None else "static: profiles/roofline_traffic.json (PMC passes of an earlier run, not re-measured by this command)",
+                      "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": round(n / steps, 1),
+                      "share_of_step_ms": round((tot_ms - n * ev_overhead_ms) / steps, 4), "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2)})
+    roofs.sort(key=lambda r: -r["share_of_step_ms"])
+    roof = None
+    if roofs:
+        roof = dict(roofs[0])
+        roof["note"] = ("dominant = the live-timed kernel family with the largest total time per step; achieved = algorithmic FLOPs of one "
+                        "launch / mean HIP-event duration of its launches, measured on the launch stream over an instrumented continuation "
+                        "of the timed steps (the timed region itself replays hipGraphs), minus the median cost of an empty event pair")
+        roof["other_kernels"] = roofs[1:]
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         try:
@@ -228,10 +266,14 @@ def main():
         "metric": "opt_steps_per_sec", "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"Splice pair {hw[0]}x{hw[1]}, {args.model} (T={T}), 1 pair per GPU, "
+        "config": {"workload": f"Splice pair {hw[0]}x{hw[1]}, {args.model} (T={T}), {P} pair(s) per GPU per step, "
                                f"{n_entire} of {K} timed steps include the entire-image branch",
-                   "pairs": world, "pairs_per_hour_at_2000_steps": round(value * 3600 / 2000, 2),
+                   "gpus": world, "pairs_per_gpu": P, "pair_steps_per_s": round(value * P, 3),
+                   "pairs_per_hour_at_2000_steps": round(value * P * 3600 / 2000, 2),
                    "per_rank_steps_per_s": [round(K / t, 2) for t in per_rank_elapsed],
+                   "throughput_by_pairs_per_gpu": {str(k): (None if v is None else {"steps_per_s": round(v, 2), "pair_steps_per_s": round(v * k, 2),
+                                                                                    "pairs_per_hour_at_2000_steps": round(v * k * 3600 / 2000, 1)})
+                                                   for k, v in sorted(sweep.items())},
                    "generator_dtype": "f32", "last_loss": round(losses["loss"], 5)},
         "roofline": roof, "cpu_baseline": cpu,
     }

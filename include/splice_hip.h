@@ -173,7 +173,7 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
                               splice_stream_t stream);
 /* kind 0: block output l fp32 [rows][D] (models/extractor.py:56-60) | 1: raw qkv l bf16
  * [rows][3D] (:68-72) | 2: attention output l bf16 [rows][D] | 3: last-layer qkv fp32
- * [rows][3D] | 4: lse l fp32 [B][H][Tld] | 5: embedded tokens fp32 [rows][D] */
+ * [rows][3D] | 4: lse l fp32 [B][H][Tld] | 5: embedded tokens fp32 [rows][D] | 6: raw qkv l transposed, bf16 [3D][rows] */
 int splice_vit_get_tensor(void* ctx, int kind, int layer, void** out_ptr);
 int splice_vit_read_tensor(void* ctx, int kind, int layer, void* dst, size_t bytes, splice_stream_t stream);
 /* dgrad-only backward over passes [pass_begin, pass_end): gradients may be injected at
@@ -205,13 +205,22 @@ int splice_gen_forward_borrowed(void* plan, const float* params, const float* x,
  * train.py:78); grads overwritten, or accumulated when accumulate != 0 */
 int splice_gen_backward(void* plan, const float* params, const float* dy, float* grads, int accumulate,
                         splice_stream_t stream);
+/* BatchNorm buffers of netG.state_dict() ("<bn>.running_mean", "<bn>.running_var"; fp32 arena in state_dict order) and their
+ * train-mode update from the batch statistics of the LAST forward of each listed plan, applied in the order given (the
+ * order of the netG calls).  Plans of independent images (arena stride set) update arena n for image n. */
+long long splice_gen_buffer_count(void* gen);
+int splice_gen_num_buffers(void* gen);
+int splice_gen_buffer_info(void* gen, int i, const char** name, long long* offset, long long* numel);
+int splice_gen_running_stats_update(void* const* plans, int n_plans, float* running, long long running_stride, float momentum,
+                                    splice_stream_t stream);
 /* torch.optim.Adam(lr, betas) step (util/util.py:28-32, train.py:79) fused over the arena;
  * step counts from 1; zero_grad != 0 also clears grads (optimizer.zero_grad, train.py:56) */
 int splice_adam_step(float* params, float* grads, float* m, float* v, long long n, float lr, float beta1,
                      float beta2, float eps, int step, int zero_grad, splice_stream_t stream);
 
 /* live HIP-event timing of one kernel family on its launch stream (bench.py roofline leg):
- * which 1 = fc1 GEMM fwd, 2 = qkv GEMM fwd (layers 0..depth-2), 3 = attention fwd */
+ * which 1 = fc1 GEMM fwd, 2 = qkv GEMM fwd (layers 0..depth-2), 3 = attention fwd, 4 = fc2 GEMM fwd, 5 = split-K dgrad GEMMs
+ * (fc1^T, qkv^T), 6 = attention bwd */
 int splice_prof_begin(int which);
 int splice_prof_end(float* total_ms, int* launches);
 int splice_prof_active(void);
@@ -226,30 +235,38 @@ int splice_gen_plan_set_arena_stride(void* plan, long long stride);
 int splice_gen_plan_resize(void* plan, int H, int W);
 
 /* ------------------------------------------------------------------ fused optimisation step
- * train.py:51-80 for one image pair: Model.forward (models/model.py:12-25), LossG.forward incl.
- * its lambda schedule (util/losses.py:34-72), loss.backward(), optimizer.step().
- * Built on a B=4 ViT context [T(A_crop), T(B_crop), T(G(A_crop)), T(G(B_crop))] and an N=2
- * generator plan (+ a B=2 context / N=1 plan for the every-75th-step entire-image branch). */
+ * train.py:51-80 for P image pairs side by side (P = 1: the reference's one pair per process): Model.forward
+ * (models/model.py:12-25), LossG.forward incl. its lambda schedule (util/losses.py:34-72), loss.backward(),
+ * optimizer.step().  Built on a B = 4P ViT context [A'_0.. | B'_0.. | x'_0.. | y'_0..] (X' = T(X crop), x = G(A crop),
+ * y = G(B crop)), two generator plans of P independent images (A crops, B crops) and, for the every-75th-step
+ * entire-image branch, a B = 2P context and a third plan.  Pairs share only the frozen ViT; a pair's results do not
+ * depend on P (bit-identical to its P = 1 run). */
 typedef struct splice_step_config {
-    int crop_h, crop_w;          /* size of the global crops fed to G */
+    int crop_h, crop_w;          /* (maximum) size of the global crops fed to G */
     int vit_h, vit_w;            /* after global_transform's Resize (== crop when it is the identity) */
     int ent_h, ent_w;            /* entire structure image (0 = branch disabled) */
     int ent_vit_h, ent_vit_w;    /* its size after Resize */
     float lambda_global_cls, lambda_global_ssim, lambda_global_identity, lambda_entire_cls, lambda_entire_ssim;
     int entire_every, cls_warmup;
     float lr, beta1, beta2, eps;
+    int pairs;                   /* P (0 or 1: one pair) */
+    long long arena_stride;      /* P > 1: floats between the pairs' parameter / gradient / Adam-moment arenas (>= param count);
+                                  * the generator plans must have been given the same stride (splice_gen_plan_set_arena_stride) */
 } splice_step_config;
-int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void* vit_ctx_entire,
-                       void* gen_plan_global, void* gen_plan_entire, void** out_handle);
+/* gen_plan_a / gen_plan_b: N = P plans at the crop size for the A and the B crops; gen_plan_entire: N = P at the entire size
+ * (NULL with ent_h == 0).  Contexts: need_grad, B = 4P / 2P. */
+int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void* vit_ctx_entire, void* gen_plan_a, void* gen_plan_b,
+                       void* gen_plan_entire, void** out_handle);
 void splice_step_destroy(void* step);
-/* losses_out: device fp32[8] = {loss, loss_global_ssim, loss_entire_ssim, loss_entire_cls,
- * loss_global_cls, loss_global_id_B, 0, 0} -- the keys of the dict LossG.forward returns.  Written by the step's own
- * loss kernel; the captured hipGraph is bound to the arena pointers AND to losses_out, so keep passing the same buffers
- * (a different pointer re-captures; two consecutive steps with identical pointers and crop sizes are needed before a
- * graph is used at all). */
-int splice_step_run(void* step, float* params, float* grads, float* m, float* v, const float* A_crop,
-                    const float* B_crop, const float* A_entire, int step_idx, float* losses_out,
-                    splice_stream_t stream);
+/* params / grads / m / v: [P][arena_stride] (one flat arena for P = 1); A_crop, B_crop: [P][3][h][w] at the current crop
+ * sizes; A_entire: [P][3][ent_h][ent_w] or NULL (needed when step_idx % entire_every == 0).
+ * losses_out: device fp32 [P][8], per pair {loss, loss_global_ssim, loss_entire_ssim, loss_entire_cls, loss_global_cls,
+ * loss_global_id_B, 0, 0} -- the keys of the dict LossG.forward returns.  Written by the step's own loss kernel; the
+ * captured hipGraph is bound to the arena pointers AND to losses_out, so keep passing the same buffers (a different
+ * pointer re-captures; two consecutive steps with identical pointers and crop sizes are needed before a graph is used). */
+int splice_step_run(void* step, float* params, float* grads, float* m, float* v, const float* A_crop, const float* B_crop,
+                    const float* A_entire, int step_idx, float* losses_out, splice_stream_t stream);
+/* generator outputs of the last step: which 0 x_global [P][3][a_h][a_w], 1 x_entire, 2 y_global */
 int splice_step_output(void* step, int which, float** out_ptr);
 /* 1 (default): capture the step's launch sequence once per regime into a hipGraph and replay it;
  * 0: launch every kernel eagerly (also used automatically while splice_prof_begin is armed) */
@@ -257,12 +274,13 @@ int splice_step_use_graph(void* step, int on);
 /* 1 = the independent chains of a step (target passes beside the generator, the two ViT backward chains) run on two
  * streams (default), 0 = one stream; results are bit-identical either way */
 int splice_step_use_overlap(void* step, int on);
-/* per-step crop sizes (<= creation size).  Equal A/B sizes run the N=2 plan; different sizes
- * (the reference draws them independently, data/Dataset.py:66-67) run two N=1 plans that must
- * have been attached once with splice_step_attach_split_plans. */
-int splice_step_set_crop(void* step, int crop_h, int crop_w);
-int splice_step_attach_split_plans(void* step, void* gen_plan_a, void* gen_plan_b);
+/* per-step crop sizes (<= creation size) of the A and the B crops (the reference draws them independently,
+ * data/Dataset.py:66-67); shared by all pairs of the batch */
 int splice_step_set_crops(void* step, int a_h, int a_w, int b_h, int b_w);
+/* BatchNorm running statistics of netG (models/unet/common.py:95-96, momentum 0.1): when `running` is set every step
+ * applies the updates of its generator calls in the reference's order (A_global, A on entire steps, B_global) to the
+ * caller's buffer arena(s): layout splice_gen_buffer_info, pair p at running + p * stride.  NULL = not tracked. */
+int splice_step_set_running_stats(void* step, float* running, long long stride);
 
 #ifdef __cplusplus
 }

@@ -18,15 +18,20 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
         // otherwise the biggest tile that still yields ~2 workgroups per CU (M = 1600: 128x64 beats 128x128 by 10 %, M = 800: 64x64)
         static const int t2min = getenv("SPLICE_GEMM_T2MIN") ? atoi(getenv("SPLICE_GEMM_T2MIN")) : 400;
         static const int t2ring = getenv("SPLICE_GEMM_T2RING") ? atoi(getenv("SPLICE_GEMM_T2RING")) : 3;
-        static const int t1min = getenv("SPLICE_GEMM_T1MIN") ? atoi(getenv("SPLICE_GEMM_T1MIN")) : 640;
-        tile = (N <= 768 || (FLAGS & EPI_ROWDOT)) ? 3 : t128 >= t1min ? 1 : t12864 >= t2min ? 2 : 3;
+        static const int t1min = getenv("SPLICE_GEMM_T1MIN") ? atoi(getenv("SPLICE_GEMM_T1MIN")) : 420;
+        // rows of a P-pair batch (tools/gemm_sweep.py, r2): with N <= 768 the 64x64 tile stops winning at ~4800 rows (fc2 at
+        // M = 6400: 688 TF on 128x64 vs 554; M = 12800: 872 vs 656); N >= 2304 takes 128x128 from 3200 rows on (t1min 640 -> 420)
+        static const int bigm = getenv("SPLICE_GEMM_BIGM") ? atoi(getenv("SPLICE_GEMM_BIGM")) : 4800;
+        tile = (FLAGS & EPI_ROWDOT) ? 3 : N <= 768 ? (M >= bigm ? 2 : 3) : t128 >= t1min ? 1 : t12864 >= t2min ? 2 : 3;
         // few workgroups walking a long K (fc2, the fc1 / qkv dgrads): the per-slice DMA latency is exposed with 2 stages,
         // the 4-stage ring keeps 3 slices in flight (fc1T 800x768x3072: 23.4 -> 15.3 us); elsewhere its LDS footprint costs occupancy
         const int ks = (FLAGS == EPI_OUT_F32 && e.ksplit > 1 && K % (e.ksplit * GEMM_BK) == 0) ? e.ksplit : 1;
         static const int ringk = getenv("SPLICE_GEMM_RINGK") ? atoi(getenv("SPLICE_GEMM_RINGK")) : 768;
         static const int ringwg = getenv("SPLICE_GEMM_RINGWG") ? atoi(getenv("SPLICE_GEMM_RINGWG")) : 640;
-        ring = (tile == 3 && K / ks >= (ks > 1 ? 768 : ringk) && (long)cdiv(M, 64) * cdiv(N, 64) * ks <= ringwg) ? 1 : 0;
-        if (tile == 2 && t2ring) ring = t2ring == 3 ? 2 : 1;
+        // (the rings pay while a launch is a single wave of latency-bound workgroups: M <= 2400 rows; beyond that the plain
+        // 2-stage pipeline is faster -- fc2 at M = 3200: 557 vs 460 TF, 128x64 at M = 6400: 688 vs 626)
+        ring = (tile == 3 && M <= 2400 && K / ks >= (ks > 1 ? 768 : ringk) && (long)cdiv(M, 64) * cdiv(N, 64) * ks <= ringwg) ? 1 : 0;
+        if (tile == 2 && t2ring && M <= 2400) ring = t2ring == 3 ? 2 : 1;
         // the short-K ring shapes (proj, projT: 12 slices) run the 3-stage form -- its own instantiation, so profiles keep
         // them apart from the long-K launches of the same epilogue (fc2)
         static const int shortns = getenv("SPLICE_GEMM_SHORTNS") ? atoi(getenv("SPLICE_GEMM_SHORTNS")) : 3;

@@ -46,6 +46,7 @@ struct ParamTable {
 struct Unit {
     int ks = 0, stride = 1, Cin = 0, Cout = 0, Hi = 0, Wi = 0, Ho = 0, Wo = 0;
     size_t w_off = 0, b_off = 0, g_off = 0, be_off = 0;   // offsets into the parameter arena
+    size_t r_off = 0;                                     // offset of running_mean in the buffer arena (running_var at + Cout)
     bool has_bn = true;
     float slope = LRELU;
     // tensors (device): input, conv output y, activation output a (+ strides, may be channel slices)
@@ -64,6 +65,7 @@ struct Unit {
 
 struct SpliceGen {
     ParamTable table;
+    ParamTable buffers;   // BatchNorm running statistics in state_dict order: "<bn>.running_mean" (C floats) then "<bn>.running_var" (C floats)
 };
 
 struct SpliceGenPlan {
@@ -93,14 +95,20 @@ struct SpliceGenPlan {
     int forward_saved = 0;
 };
 
-static void build_table(ParamTable& t, size_t* offs /* [5][6 units][4] */, size_t* head) {
+static void build_table(ParamTable& t, size_t* offs /* [5][6 units][4] */, size_t* head, ParamTable* bufs = nullptr, size_t* roffs /* [5][6] */ = nullptr) {
     auto conv = [&](const std::string& n, int co, int ci, int k, size_t* o) {
         o[0] = t.add(n + ".weight", (size_t)co * ci * k * k);
         o[1] = t.add(n + ".bias", co);
     };
+    size_t* cur_r = nullptr;   // where the next bn() records its running-buffer offset
     auto bn = [&](const std::string& n, int c, size_t* o) {
         o[2] = t.add(n + ".weight", c);
         o[3] = t.add(n + ".bias", c);
+        if (bufs) {
+            const size_t r = bufs->add(n + ".running_mean", c);
+            bufs->add(n + ".running_var", c);
+            if (cur_r) *cur_r = r;
+        }
     };
     std::string prefix[5];
     for (int i = 1; i < 5; ++i) prefix[i] = prefix[i - 1] + "1.1.7.";
@@ -108,20 +116,21 @@ static void build_table(ParamTable& t, size_t* offs /* [5][6 units][4] */, size_
     // i+1, then cat-BN, up3, up1 of scale i.
     struct Rec {
         static void go(int i, int cin, ParamTable& t, size_t* offs, std::string* prefix,
-                       decltype(conv)& conv, decltype(bn)& bn) {
+                       decltype(conv)& conv, decltype(bn)& bn, size_t*& cur_r, size_t* roffs) {
             const std::string p = prefix[i];
             size_t* o = offs + (size_t)i * 6 * 4;
-            conv(p + "1.0.1.0", SKIPC, cin, 1, o + 0 * 4); bn(p + "1.0.2", SKIPC, o + 0 * 4);
-            conv(p + "1.1.1.0", DOWN[i], cin, 3, o + 1 * 4); bn(p + "1.1.2", DOWN[i], o + 1 * 4);
-            conv(p + "1.1.4.0", DOWN[i], DOWN[i], 3, o + 2 * 4); bn(p + "1.1.5", DOWN[i], o + 2 * 4);
+            auto at = [&](int unit) { cur_r = roffs ? roffs + i * 6 + unit : nullptr; };
+            conv(p + "1.0.1.0", SKIPC, cin, 1, o + 0 * 4); at(0); bn(p + "1.0.2", SKIPC, o + 0 * 4);
+            conv(p + "1.1.1.0", DOWN[i], cin, 3, o + 1 * 4); at(1); bn(p + "1.1.2", DOWN[i], o + 1 * 4);
+            conv(p + "1.1.4.0", DOWN[i], DOWN[i], 3, o + 2 * 4); at(2); bn(p + "1.1.5", DOWN[i], o + 2 * 4);
             int k = DOWN[i];
-            if (i < 4) { go(i + 1, DOWN[i], t, offs, prefix, conv, bn); k = UP[i + 1]; }
-            bn(p + "2", SKIPC + k, o + 3 * 4);
-            conv(p + "3.0", UP[i], SKIPC + k, 3, o + 4 * 4); bn(p + "4", UP[i], o + 4 * 4);
-            conv(p + "6.0", UP[i], UP[i], 1, o + 5 * 4); bn(p + "7", UP[i], o + 5 * 4);
+            if (i < 4) { go(i + 1, DOWN[i], t, offs, prefix, conv, bn, cur_r, roffs); k = UP[i + 1]; }
+            at(3); bn(p + "2", SKIPC + k, o + 3 * 4);
+            conv(p + "3.0", UP[i], SKIPC + k, 3, o + 4 * 4); at(4); bn(p + "4", UP[i], o + 4 * 4);
+            conv(p + "6.0", UP[i], UP[i], 1, o + 5 * 4); at(5); bn(p + "7", UP[i], o + 5 * 4);
         }
     };
-    Rec::go(0, 3, t, offs, prefix, conv, bn);
+    Rec::go(0, 3, t, offs, prefix, conv, bn, cur_r, roffs);
     conv("9.0", 3, UP[0], 1, head);
 }
 
@@ -282,8 +291,8 @@ extern "C" {
 int splice_gen_create(void** out) {
     if (!out) return SPLICE_ERR_ARG;
     SpliceGen* g = new SpliceGen();
-    size_t offs[5 * 6 * 4], head[4];
-    build_table(g->table, offs, head);
+    size_t offs[5 * 6 * 4], head[4], roffs[5 * 6];
+    build_table(g->table, offs, head, &g->buffers, roffs);
     *out = g;
     return SPLICE_OK;
 }
@@ -311,9 +320,9 @@ int splice_gen_plan_create(void* h, int N, int H, int W, int need_grad, void** o
     p->gen = g; p->N = N; p->H = H; p->W = W; p->maxH = H; p->maxW = W; p->need_grad = need_grad;
     p->h[0] = H; p->w[0] = W;
     for (int i = 1; i <= 5; ++i) { p->h[i] = (p->h[i - 1] + 1) / 2; p->w[i] = (p->w[i - 1] + 1) / 2; }
-    size_t offs[5 * 6 * 4], head[4];
-    ParamTable tmp;
-    build_table(tmp, offs, head);
+    size_t offs[5 * 6 * 4], head[4], roffs[5 * 6];
+    ParamTable tmp, tmpb;
+    build_table(tmp, offs, head, &tmpb, roffs);
     p->head_w = head[0]; p->head_b = head[1];
     int rc = SPLICE_OK;
     auto fail = [&]() { for (void* q : p->allocs) (void)hipFree(q); delete p; return rc; };
@@ -327,7 +336,7 @@ int splice_gen_plan_create(void* h, int N, int H, int W, int need_grad, void** o
         if ((rc = palloc(p, &p->cat[i], (size_t)N * catC * hi * wi)) != SPLICE_OK) break;
         if (need_grad && (rc = palloc(p, &p->d_cat[i], (size_t)N * catC * hi * wi)) != SPLICE_OK) break;
         size_t* o = offs + (size_t)i * 6 * 4;
-        auto setp = [&](Unit& u, int idx) { u.w_off = o[idx * 4 + 0]; u.b_off = o[idx * 4 + 1]; u.g_off = o[idx * 4 + 2]; u.be_off = o[idx * 4 + 3]; };
+        auto setp = [&](Unit& u, int idx) { u.w_off = o[idx * 4 + 0]; u.b_off = o[idx * 4 + 1]; u.g_off = o[idx * 4 + 2]; u.be_off = o[idx * 4 + 3]; u.r_off = roffs[i * 6 + idx]; };
         auto mk = [&](Unit& u, int idx, int ks, int stride, int ci, int co, int Hi, int Wi, int Ho, int Wo, bool own) {
             u.ks = ks; u.stride = stride; u.Cin = ci; u.Cout = co; u.Hi = Hi; u.Wi = Wi; u.Ho = Ho; u.Wo = Wo;
             setp(u, idx);
@@ -393,6 +402,43 @@ int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams)
     if (H) *H = p->H;
     if (W) *W = p->W;
     if (nparams) *nparams = (long long)p->gen->table.total;
+    return SPLICE_OK;
+}
+
+// BatchNorm running statistics (nn.BatchNorm2d, momentum 0.1, train mode: models/unet/common.py:95-96) of the LAST forward
+// of each plan, applied in the order given (= the order of the netG calls they stand for: models/model.py:15-23 calls
+// A_global, A, B_global).  `running`: buffer arena(s) in state_dict order (splice_gen_buffer_info); plans whose images
+// are independent generators update arena n = image n at + n * running_stride.
+long long splice_gen_buffer_count(void* h) { return h ? (long long)((SpliceGen*)h)->buffers.total : -1; }
+int splice_gen_num_buffers(void* h) { return h ? (int)((SpliceGen*)h)->buffers.entries.size() : -1; }
+int splice_gen_buffer_info(void* h, int i, const char** name, long long* offset, long long* numel) {
+    SpliceGen* g = (SpliceGen*)h;
+    if (!g || i < 0 || i >= (int)g->buffers.entries.size()) return SPLICE_ERR_ARG;
+    if (name) *name = g->buffers.entries[i].name.c_str();
+    if (offset) *offset = (long long)g->buffers.entries[i].off;
+    if (numel) *numel = (long long)g->buffers.entries[i].numel;
+    return SPLICE_OK;
+}
+int splice_gen_running_stats_update(void* const* plans, int n_plans, float* running, long long running_stride, float momentum,
+                                    splice_stream_t stream) {
+    if (!plans || n_plans < 1 || n_plans > RUNSTAT_MAX_PLANS || !running) return SPLICE_ERR_ARG;
+    RunStatTable t = {};
+    t.n_plans = n_plans; t.n_bn = 30;
+    int max_images = 1;
+    for (int k = 0; k < n_plans; ++k) {
+        SpliceGenPlan* p = (SpliceGenPlan*)plans[k];
+        if (!p) return SPLICE_ERR_ARG;
+        t.N[k] = p->N; t.indep[k] = p->p_nstride ? 1 : 0;
+        if (t.indep[k] && p->N > max_images) max_images = p->N;
+        int bn = 0;
+        for (int i = 0; i < 5; ++i)
+            for (Unit* u : {&p->u_skip[i], &p->u_da[i], &p->u_db[i], &p->u_cat[i], &p->u_up3[i], &p->u_up1[i]}) {
+                if (k == 0) { t.C[bn] = u->Cout; t.r_off[bn] = (int)u->r_off; }
+                t.HW[k][bn] = u->Ho * u->Wo; t.mean[k][bn] = u->mean; t.rstd[k][bn] = u->rstd;
+                ++bn;
+            }
+    }
+    RC(bn_running_update_launch(t, running, (size_t)running_stride, momentum, BN_EPS, max_images, (hipStream_t)stream));
     return SPLICE_OK;
 }
 

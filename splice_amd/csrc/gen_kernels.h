@@ -95,3 +95,14 @@ int adam_launch(float* p, float* g, float* m, float* v, size_t n, float lr, floa
 int adam_launch_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, const int* step_dev,
                     int zero_grad, hipStream_t s, const float* g2 = nullptr);
 int set_int_launch(int* p, int v, hipStream_t s);
+// BatchNorm running statistics of up to 3 generator calls (in call order) in one launch; see gen_kernels.hip
+constexpr int RUNSTAT_MAX_PLANS = 3, RUNSTAT_MAX_BN = 36;
+struct RunStatTable {
+    int n_plans, n_bn;
+    int C[RUNSTAT_MAX_BN], r_off[RUNSTAT_MAX_BN];      // channels; offset of running_mean in the buffer arena (running_var follows at + C)
+    int N[RUNSTAT_MAX_PLANS], indep[RUNSTAT_MAX_PLANS];
+    int HW[RUNSTAT_MAX_PLANS][RUNSTAT_MAX_BN];
+    const float* mean[RUNSTAT_MAX_PLANS][RUNSTAT_MAX_BN];   // [N][C] batch statistics saved by the forward
+    const float* rstd[RUNSTAT_MAX_PLANS][RUNSTAT_MAX_BN];
+};
+int bn_running_update_launch(const RunStatTable& t, float* running, size_t r_nstride, float momentum, float eps, int max_images, hipStream_t s);

@@ -1165,6 +1165,37 @@ int adam_launch_dev(float* p, float* g, float* m, float* v, size_t n, float lr, 
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g_), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, 1.f, 1.f, zero_grad, step_dev, g2);
     return SPLICE_OK;
 }
+// ---------------------------------------------------------------------------------------
+// nn.BatchNorm2d bookkeeping (models/unet/common.py:95-96: every netG call in train mode moves running_mean / running_var
+// with momentum 0.1; nothing ever reads them, but they are part of netG.state_dict()).  One launch covers every
+// BatchNorm of up to RUNSTAT_MAX_PLANS generator calls IN CALL ORDER: thread (bn, channel) walks the plans in order (the
+// updates of one buffer do not commute exactly), and the images of a plan in order unless they are independent
+// generators (blockIdx.y = image = its own buffer arena).  var_unbiased is rebuilt from the saved rstd.
+__global__ __launch_bounds__(192) void bn_running_update_kernel(RunStatTable t, float* __restrict__ running, size_t r_nstride, float momentum, float eps) {
+    const int bn = blockIdx.x, c = threadIdx.x;
+    if (c >= t.C[bn]) return;
+    for (int p = 0; p < t.n_plans; ++p) {
+        const bool indep = t.indep[p] != 0;
+        if (indep && (int)blockIdx.y >= t.N[p]) continue;
+        if (!indep && blockIdx.y != 0) continue;
+        const int n_lo = indep ? blockIdx.y : 0, n_hi = indep ? blockIdx.y + 1 : t.N[p];
+        float* arena = running + (indep ? (size_t)blockIdx.y * r_nstride : 0) + t.r_off[bn];
+        const float hw = (float)t.HW[p][bn];
+        const float unbias = hw > 1.f ? hw / (hw - 1.f) : 1.f;
+        for (int n = n_lo; n < n_hi; ++n) {
+            const float m = t.mean[p][bn][n * t.C[bn] + c], r = t.rstd[p][bn][n * t.C[bn] + c];
+            const float var = fmaxf(1.0f / (r * r) - eps, 0.f) * unbias;
+            arena[c] = (1.f - momentum) * arena[c] + momentum * m;
+            arena[t.C[bn] + c] = (1.f - momentum) * arena[t.C[bn] + c] + momentum * var;
+        }
+    }
+}
+int bn_running_update_launch(const RunStatTable& t, float* running, size_t r_nstride, float momentum, float eps, int max_images, hipStream_t s) {
+    if (t.n_plans < 1 || t.n_plans > RUNSTAT_MAX_PLANS || t.n_bn < 1 || t.n_bn > RUNSTAT_MAX_BN) return SPLICE_ERR_ARG;
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(t.n_bn, max_images), dim3(192), 0, s, t, running, r_nstride, momentum, eps);
+    return SPLICE_OK;
+}
+
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
 int set_int_launch(int* p, int v, hipStream_t s) {
     hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, p, v);

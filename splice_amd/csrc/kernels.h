@@ -83,6 +83,30 @@ int selfsim_fwd_launch(const float* K, int ldk, int T, int D, float eps, float* 
 // ws state left by selfsim_fwd_launch on the same K, and S.
 int selfsim_bwd_launch(const float* dS, const float* S, int T, int D, float eps, float* dK, int lddk, int accumulate,
                        const SelfSimWs& ws, hipStream_t s);
+// ---- fused + batched structure loss of the optimisation step (blockIdx.y = pair); see selfsim.hip
+struct SelfSimBatch {
+    int T, Tp, D, pairs;
+    int ldk, ldt;                   // leading dimensions of the key matrices below
+    size_t k_pstride, kT_pstride;   // element strides between the pairs' problems
+    const bf16_t* k_tgt;            // target keys (A' passes)     bf16 [T][ldk], pair p at + p * k_pstride
+    const bf16_t* k_x;              // generated keys (x' passes)
+    const bf16_t* kT_x;             // transposed generated keys   bf16 [D][ldt], pair p at + p * kT_pstride
+    float* S_tgt;                   // [pairs][T][T] fp32 (upper-triangular 64x64 tiles valid)
+    bf16_t* wmat;                   // [pairs][Tp][Tp]
+    float *norm_tgt, *norm_x;       // [pairs][Tp]
+    float* rpart;                   // [pairs][Tp/64][Tp] per-tile partial row dots
+    float* loss_part;               // pair p's per-tile loss partials at + p * part_pstride (>= nt(nt+1)/2 floats, summed by the caller)
+    size_t part_pstride;
+    float* dk;                      // d keys fp32: pair p at + p * dk_pstride, [T][lddk]
+    size_t dk_pstride; int lddk;
+    float eps, e_scale, loss_scale; // e_scale = 4 lambda / T^2 ; loss_scale = 1 / T^2
+};
+size_t selfsim_batch_ws_bytes(int T, int D, int pairs);
+void selfsim_batch_carve(void* base, int T, int D, int pairs, SelfSimBatch* b);   // fills T, Tp, D, pairs and the workspace pointers
+int selfsim_target_launch(const SelfSimBatch& b, hipStream_t s);   // norms of k_tgt + S* (2 launches)
+int selfsim_loss_launch(const SelfSimBatch& b, hipStream_t s);     // norms of k_x + fused S / loss / W + dK (3 launches)
+int mse_batched_launch(const float* a, int lda, size_t a_ps, const float* b, int ldb, size_t b_ps, int rows, int cols, float loss_weight,
+                       float grad_weight, float* part, size_t part_ps, float* grad, int ldg, size_t g_ps, int pairs, hipStream_t s);
 // 2-D strided MSE: loss_accum[0] += weight * mean((a-b)^2); grad (optional) = weight * 2 (a-b) / (rows*cols)
 int mse_launch(const float* a, int lda, const float* b, int ldb, int rows, int cols, float weight, float* loss_accum,
                float* grad, int ldg, hipStream_t s);

@@ -4,6 +4,13 @@
 // passes [T(A_crop), T(B_crop), T(G(A_crop)), T(G(B_crop))] run as ONE batched forward (the
 // reference runs six batch-1 forwards, x' and B' twice), the backward covers only the two
 // generated images and only data gradients.  Nothing is cached across steps.
+//
+// P image pairs side by side (cfg.pairs): the reference optimises one pair per process (train.py:34-49); pairs share
+// nothing but the frozen ViT, so P of them can ride the SAME launches -- the ViT context holds 4P passes
+// [A'_0..A'_{P-1} | B'_0.. | x'_0.. | y'_0..], every GEMM / attention / LayerNorm launch covers P times the rows, the
+// generator plans hold P independent generators (own parameter / gradient / Adam arenas, own BatchNorm statistics), the
+// loss kernels take the pair as a grid dimension.  Every per-pair quantity is computed exactly as in a P = 1 step (no
+// policy depends on P), so a pair's trajectory is bit-identical whichever batch it rides in.
 #include <vector>
 
 #include <stdio.h>
@@ -25,6 +32,10 @@ int splice_vit_get_tensor(void* ctx, int kind, int layer, void** out);
 int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* const* d_block, const float* const* d_qkv,
                         const float* const* d_keys, float* d_img, int normalize, splice_stream_t stream);
 int splice_gen_forward_borrowed(void* plan, const float* params, const float* x, float* y, splice_stream_t stream);
+int splice_gen_running_stats_update(void* const* plans, int n_plans, float* running, long long running_stride, float momentum,
+                                    splice_stream_t stream);
+int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int grad_pass_begin, int pass_begin, int pass_end,
+                              splice_stream_t stream);
 int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams);
 int splice_gen_plan_resize(void* plan, int H, int W);
 int splice_gen_forward(void* plan, const float* params, const float* x, float* y, splice_stream_t stream);
@@ -65,24 +76,25 @@ struct VitView {
 
 struct SpliceStep {
     splice_step_config cfg;
+    int P = 1;                   // pairs optimised side by side
+    size_t astride = 0;          // floats between the pairs' parameter / gradient / moment arenas (P > 1)
     VitView vg, ve;
-    void *plan_g = nullptr, *plan_e = nullptr;
-    void *plan_a = nullptr, *plan_b = nullptr;   // N=1 plans used when the A and B crops differ in size
-    int cropb_h = 0, cropb_w = 0, max_cropb_h = 0, max_cropb_w = 0;
+    void *plan_a = nullptr, *plan_b = nullptr, *plan_e = nullptr;   // generator plans: P independent images each
+    int cropb_h = 0, cropb_w = 0;
     long long nparams = 0;
-    float* gen_in = nullptr;     // [2][3][s][s]   A_crop | B_crop
-    float* gen_out = nullptr;    // [2][3][s][s]   x_global | y_global
-    float* d_gen_out = nullptr;
-    float* ent_out = nullptr;    // [1][3][He][We]
+    float* gen_in = nullptr;     // [P][3][ha][wa]   A crops            (staged copies: a captured graph only sees own buffers)
+    float* in_b = nullptr;       // [P][3][hb][wb]   B crops
+    float* ent_in = nullptr;     // [P][3][He][We]   entire structure images
+    float* gen_out = nullptr;    // [P][3][ha][wa]   x_global
+    float* gen_out_b = nullptr;  // [P][3][hb][wb]   y_global
+    float *d_gen_out = nullptr, *d_gen_out_b = nullptr;
+    float* ent_out = nullptr;    // [P][3][He][We]
     float* d_ent_out = nullptr;
-    float *S = nullptr, *S_tgt = nullptr, *dS = nullptr;   // [Tmax][Tmax]
-    void* ssim_ws = nullptr;
-    float* losses = nullptr;     // [8] raw per-term losses of the current step, then [8][SPLICE_MSE_PARTIALS] workgroup partials of each term
+    void* ssim_ws = nullptr;     // SelfSimBatch workspace (shared by the global and the entire-image term: they run back to back)
+    float* losses = nullptr;     // per pair: [8] raw per-term losses, then [8][lp] workgroup partials of each term
+    size_t lp = 0, lstride = 0;  // partial slots per term; floats per pair
     std::vector<void*> allocs;
     int max_crop_h = 0, max_crop_w = 0;
-    // graph replay
-    float* in_b = nullptr;       // staging for B_crop when the crops are split (A_crop stages in gen_in)
-    float* ent_in = nullptr;     // staging for the entire structure image
     int* dev_t = nullptr;        // Adam step count on the device
     hipStream_t own_stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -92,15 +104,17 @@ struct SpliceStep {
     int ablate = 0;                                  // SPLICE_STEP_ABLATE bitmask: TIMING experiments only (results are garbage):
                                                      // 1 skip G fwd, 2 skip G bwd, 4 skip ViT bwd, 8 skip target ViT fwd, 16 skip generated ViT fwd, 32 skip the y' chain of the ViT bwd
     std::map<int, hipGraphExec_t> graphs;
-    void* graph_ptrs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // arenas + the caller's losses buffer a captured graph is bound to
-    float* losses_out = nullptr;                     // this step's destination of the 8 loss values (written by total_loss_kernel)
+    void* graph_ptrs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // arenas + the caller's losses / running buffers a captured graph is bound to
+    float* losses_out = nullptr;                     // this step's destination of the [P][8] loss values (written by total_loss_kernel)
     int graph_crops[4] = {0, 0, 0, 0};
-    float* grads_b = nullptr;                        // split crops: gradient arena of the B-crop plan (added to `grads` before Adam)
-    hipEvent_t ev_gb = nullptr;                      // split crops: G(B_crop) finished on the side stream
+    float* grads_b = nullptr;                        // gradient arena(s) of the B-crop plan (added to `grads` inside Adam)
+    hipEvent_t ev_gb = nullptr;                      // G(B_crop) finished on the side stream
     int shape_repeats = 0;                           // consecutive steps with the same arenas and crop sizes
     int use_graph = 1;
     int dbg_sync = 0, dbg_own_eager = 0;
     int ssim_id_on = 0;          // lambda_global_ssim / lambda_global_identity switched on (util/losses.py:35-37)
+    float* running = nullptr;    // BatchNorm running statistics arena(s) of the caller (null: not tracked)
+    long long running_stride = 0;
 };
 
 static void drop_graphs(SpliceStep* st);
@@ -126,6 +140,9 @@ static int view_init(SpliceStep* st, VitView& v, void* ctx, int want_B) {
     RC(salloc(st, &v.d_keys, (size_t)v.rows * v.D));
     RC(salloc(st, &v.imgs, (size_t)v.B * 3 * v.H * v.W));
     RC(salloc(st, &v.d_imgs, (size_t)v.B * 3 * v.H * v.W));
+    // rows no loss kernel ever writes (padding tokens, non-[CLS] rows of d_block) must read as zero gradient
+    if (hipMemset(v.d_block, 0, (size_t)v.rows * v.D * sizeof(float)) != hipSuccess || hipMemset(v.d_keys, 0, (size_t)v.rows * v.D * sizeof(float)) != hipSuccess)
+        return SPLICE_ERR_HIP;
     v.pb.assign(v.depth, nullptr);
     v.pk.assign(v.depth, nullptr);
     v.pb[v.depth - 1] = v.d_block;
@@ -133,14 +150,16 @@ static int view_init(SpliceStep* st, VitView& v, void* ctx, int want_B) {
     return SPLICE_OK;
 }
 
-// raw_k = fixed-order sum of term k's workgroup partials (no float atomics anywhere: replicas are bit-reproducible);
-// total = sum_k lambda_k * raw_k   (util/losses.py:53-71)
-__global__ __launch_bounds__(320) void total_loss_kernel(float* l, float w_ssim, float w_essim, float w_ecls, float w_cls, float w_id, float* out8) {
+// blockIdx.x = pair.  raw_k = fixed-order sum of term k's workgroup partials (no float atomics anywhere: replicas are
+// bit-reproducible); total = sum_k lambda_k * raw_k   (util/losses.py:53-71)
+__global__ __launch_bounds__(320) void total_loss_kernel(float* lbase, size_t lstride, int lp, float w_ssim, float w_essim, float w_ecls, float w_cls,
+                                                         float w_id, float* out8) {
     __shared__ float raw[8];
+    float* l = lbase + (size_t)blockIdx.x * lstride;
     const int k = 1 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave k-1 owns term k (5 waves)
-    const float* part = l + 8 + k * SPLICE_MSE_PARTIALS;
+    const float* part = l + 8 + (size_t)k * lp;
     float acc = 0.f;
-    for (int i = lane; i < SPLICE_MSE_PARTIALS; i += 64) acc += part[i];
+    for (int i = lane; i < lp; i += 64) acc += part[i];
     acc = wave_sum(acc);
     if (lane == 0) raw[k] = acc;
     __syncthreads();
@@ -148,9 +167,10 @@ __global__ __launch_bounds__(320) void total_loss_kernel(float* l, float w_ssim,
         for (int t = 1; t <= 5; ++t) l[t] = raw[t];
         l[L_TOTAL] = w_ssim * raw[L_GLOBAL_SSIM] + w_essim * raw[L_ENTIRE_SSIM] + w_ecls * raw[L_ENTIRE_CLS] + w_cls * raw[L_GLOBAL_CLS] + w_id * raw[L_GLOBAL_ID];
         if (out8) {   // the caller's losses buffer, written here instead of by a copy behind the step
-            out8[0] = l[L_TOTAL];
-            for (int t = 1; t <= 5; ++t) out8[t] = raw[t];
-            out8[6] = 0.f; out8[7] = 0.f;
+            float* o = out8 + (size_t)blockIdx.x * 8;
+            o[0] = l[L_TOTAL];
+            for (int t = 1; t <= 5; ++t) o[t] = raw[t];
+            o[6] = 0.f; o[7] = 0.f;
         }
     }
 }
@@ -162,7 +182,7 @@ __global__ __launch_bounds__(256) void stage_inputs_kernel(StageArgs a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if (!a.src[k]) continue;
-        const size_t n4 = a.n[k] / 4;   // element counts are multiples of 4? not guaranteed: vector body + scalar tail
+        const size_t n4 = a.n[k] / 4;   // vector body + scalar tail
         const float4* s4 = reinterpret_cast<const float4*>(a.src[k]);
         float4* d4 = reinterpret_cast<float4*>(a.dst[k]);
         const bool vec = ((reinterpret_cast<size_t>(a.src[k]) | reinterpret_cast<size_t>(a.dst[k])) & 15) == 0;
@@ -175,82 +195,97 @@ __global__ __launch_bounds__(256) void stage_inputs_kernel(StageArgs a) {
     }
     if (gid == 0) *a.ip = a.iv;
 }
-static float* loss_part(SpliceStep* st, int slot) { return st->losses + 8 + slot * SPLICE_MSE_PARTIALS; }
+static float* loss_part(SpliceStep* st, int slot) { return st->losses + 8 + (size_t)slot * st->lp; }   // pair 0; pair p at + p * lstride
 
-static int place_image(const float* src, int h, int w, float* dst, int oh, int ow, hipStream_t s) {
+// `n_img` images [3][h][w] -> [3][oh][ow] each (contiguous batches on both sides)
+static int place_images(const float* src, int h, int w, float* dst, int oh, int ow, int n_img, hipStream_t s) {
     if (h == oh && w == ow) {   // Resize returns its input when the shorter edge already matches
-        RC(dev_copy_launch(dst, src, (size_t)3 * h * w * sizeof(float), s));
+        RC(dev_copy_launch(dst, src, (size_t)n_img * 3 * h * w * sizeof(float), s));
         return SPLICE_OK;
     }
-    return resize_bilinear_fwd_launch(src, dst, 3, h, w, oh, ow, s);
+    return resize_bilinear_fwd_launch(src, dst, 3 * n_img, h, w, oh, ow, s);
 }
-static int unplace_grad(const float* dsrc, int oh, int ow, float* ddst, int h, int w, hipStream_t s) {
+static int unplace_grads(const float* dsrc, int oh, int ow, float* ddst, int h, int w, int n_img, hipStream_t s) {
     if (h == oh && w == ow) {
-        RC(dev_copy_launch(ddst, dsrc, (size_t)3 * h * w * sizeof(float), s));
+        RC(dev_copy_launch(ddst, dsrc, (size_t)n_img * 3 * h * w * sizeof(float), s));
         return SPLICE_OK;
     }
-    return resize_bilinear_bwd_launch(dsrc, ddst, 3, h, w, oh, ow, s);
+    return resize_bilinear_bwd_launch(dsrc, ddst, 3 * n_img, h, w, oh, ow, s);
 }
 
-// keys of pass b (fp32 view into the last layer's raw qkv): pointer + leading dimension 3D
+// fp32 keys of pass b (view into the last layer's raw qkv): pointer + leading dimension 3D
 static const float* keys_ptr(const VitView& v, const float* qkv_last, int pass) { return qkv_last + (size_t)pass * v.Tld * 3 * v.D + v.D; }
 
-// self-sim structure loss of `pass_x` against `pass_tgt` (util/losses.py:74-83): raw loss into slot, d_keys rows of pass_x
-// target_done: S_tgt has already been formed (on the side stream, beside the generator forward)
-static int ssim_term(SpliceStep* st, VitView& v, const float* qkv_last, int pass_tgt, int pass_x, float lambda, int slot, hipStream_t s,
-                     bool target_done = false) {
-    SelfSimWs ws;
-    selfsim_ws_carve(st->ssim_ws, v.T, v.D, &ws);
-    if (!target_done) RC(selfsim_fwd_launch(keys_ptr(v, qkv_last, pass_tgt), 3 * v.D, v.T, v.D, 1e-8f, st->S_tgt, ws, s));
-    RC(selfsim_fwd_launch(keys_ptr(v, qkv_last, pass_x), 3 * v.D, v.T, v.D, 1e-8f, st->S, ws, s));
-    RC(mse_partials_launch(st->S, v.T, st->S_tgt, v.T, v.T, v.T, 1.0f, lambda, loss_part(st, slot), st->dS, v.T, s));
-    RC(selfsim_bwd_launch(st->dS, st->S, v.T, v.D, 1e-8f, v.d_keys + (size_t)pass_x * v.Tld * v.D, v.D, 0, ws, s));
+// The structure term of P pairs (util/losses.py:74-83): targets = passes [pass_tgt, pass_tgt + P), generated = passes
+// [pass_x, pass_x + P) of view v.  `b` is carved over st->ssim_ws for v's token count.
+static int ssim_batch(SpliceStep* st, VitView& v, int pass_tgt, int pass_x, float lambda, int slot, SelfSimBatch* b) {
+    bf16_t *qkv = nullptr, *qkvT = nullptr;
+    RC(splice_vit_get_tensor(v.ctx, 1, v.depth - 1, (void**)&qkv));
+    RC(splice_vit_get_tensor(v.ctx, 6, v.depth - 1, (void**)&qkvT));
+    selfsim_batch_carve(st->ssim_ws, v.T, v.D, st->P, b);
+    const size_t pass_rows = (size_t)v.Tld * 3 * v.D;
+    b->ldk = 3 * v.D; b->ldt = v.rows; b->k_pstride = pass_rows; b->kT_pstride = (size_t)v.Tld;
+    b->k_tgt = qkv + (size_t)pass_tgt * pass_rows + v.D;
+    b->k_x = qkv + (size_t)pass_x * pass_rows + v.D;
+    b->kT_x = qkvT + (size_t)v.D * v.rows + (size_t)pass_x * v.Tld;
+    b->loss_part = loss_part(st, slot); b->part_pstride = st->lstride;
+    b->dk = v.d_keys + (size_t)pass_x * v.Tld * v.D; b->dk_pstride = (size_t)v.Tld * v.D; b->lddk = v.D;
+    b->eps = 1e-8f;
+    b->loss_scale = 1.0f / ((float)v.T * (float)v.T);
+    b->e_scale = 4.0f * lambda * b->loss_scale;
     return SPLICE_OK;
 }
 
 extern "C" {
 
-int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void* vit_ctx_entire, void* gen_plan_global,
+int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void* vit_ctx_entire, void* gen_plan_a, void* gen_plan_b,
                        void* gen_plan_entire, void** out) {
-    if (!cfg || !vit_ctx_global || !gen_plan_global || !out) return SPLICE_ERR_ARG;
+    if (!cfg || !vit_ctx_global || !gen_plan_a || !gen_plan_b || !out) return SPLICE_ERR_ARG;
     SpliceStep* st = new SpliceStep();
     st->cfg = *cfg;
+    const int P = st->P = cfg->pairs > 1 ? cfg->pairs : 1;
     st->max_crop_h = cfg->crop_h; st->max_crop_w = cfg->crop_w;
-    st->cropb_h = st->max_cropb_h = cfg->crop_h; st->cropb_w = st->max_cropb_w = cfg->crop_w;
+    st->cropb_h = cfg->crop_h; st->cropb_w = cfg->crop_w;
     int rc = SPLICE_OK;
     auto fail = [&](int code) { for (void* q : st->allocs) (void)hipFree(q); delete st; return code; };
-    if ((rc = view_init(st, st->vg, vit_ctx_global, 4)) != SPLICE_OK) return fail(rc);
+    if ((rc = view_init(st, st->vg, vit_ctx_global, 4 * P)) != SPLICE_OK) return fail(rc);
     if (st->vg.H != cfg->vit_h || st->vg.W != cfg->vit_w) { splice_set_error("splice_step_create: global ViT context shape mismatch"); return fail(SPLICE_ERR_ARG); }
     int n, h, w;
-    if ((rc = splice_gen_plan_dims(gen_plan_global, &n, &h, &w, &st->nparams)) != SPLICE_OK) return fail(rc);
-    if (n != 2 || h != cfg->crop_h || w != cfg->crop_w) { splice_set_error("splice_step_create: global generator plan must be N=2 at the crop size"); return fail(SPLICE_ERR_ARG); }
-    st->plan_g = gen_plan_global;
+    for (void* plan : {gen_plan_a, gen_plan_b}) {
+        if ((rc = splice_gen_plan_dims(plan, &n, &h, &w, &st->nparams)) != SPLICE_OK) return fail(rc);
+        if (n != P || h != cfg->crop_h || w != cfg->crop_w) { splice_set_error("splice_step_create: the crop generator plans must hold %d image(s) at the crop size", P); return fail(SPLICE_ERR_ARG); }
+    }
+    st->plan_a = gen_plan_a; st->plan_b = gen_plan_b;
+    if (P > 1) {
+        if (cfg->arena_stride < st->nparams) { splice_set_error("splice_step_create: pairs > 1 needs arena_stride >= the parameter count"); return fail(SPLICE_ERR_ARG); }
+        st->astride = (size_t)cfg->arena_stride;
+    }
     const size_t crop = (size_t)3 * cfg->crop_h * cfg->crop_w;
-    if ((rc = salloc(st, &st->gen_in, 2 * crop)) != SPLICE_OK) return fail(rc);
-    if ((rc = salloc(st, &st->gen_out, 2 * crop)) != SPLICE_OK) return fail(rc);
-    if ((rc = salloc(st, &st->d_gen_out, 2 * crop)) != SPLICE_OK) return fail(rc);
+    for (float** q : {&st->gen_in, &st->in_b, &st->gen_out, &st->gen_out_b, &st->d_gen_out, &st->d_gen_out_b})
+        if ((rc = salloc(st, q, P * crop)) != SPLICE_OK) return fail(rc);
+    if ((rc = salloc(st, &st->grads_b, P > 1 ? P * st->astride : (size_t)st->nparams)) != SPLICE_OK) return fail(rc);
     int Tmax = st->vg.T;
     if (cfg->ent_h > 0) {
         if (!vit_ctx_entire || !gen_plan_entire) { splice_set_error("splice_step_create: entire-image branch needs its ViT context and generator plan"); return fail(SPLICE_ERR_ARG); }
-        if ((rc = view_init(st, st->ve, vit_ctx_entire, 2)) != SPLICE_OK) return fail(rc);
+        if ((rc = view_init(st, st->ve, vit_ctx_entire, 2 * P)) != SPLICE_OK) return fail(rc);
         if (st->ve.H != cfg->ent_vit_h || st->ve.W != cfg->ent_vit_w) { splice_set_error("splice_step_create: entire ViT context shape mismatch"); return fail(SPLICE_ERR_ARG); }
         if ((rc = splice_gen_plan_dims(gen_plan_entire, &n, &h, &w, nullptr)) != SPLICE_OK) return fail(rc);
-        if (n != 1 || h != cfg->ent_h || w != cfg->ent_w) { splice_set_error("splice_step_create: entire generator plan must be N=1 at the entire-image size"); return fail(SPLICE_ERR_ARG); }
+        if (n != P || h != cfg->ent_h || w != cfg->ent_w) { splice_set_error("splice_step_create: the entire generator plan must hold %d image(s) at the entire-image size", P); return fail(SPLICE_ERR_ARG); }
         st->plan_e = gen_plan_entire;
         const size_t ent = (size_t)3 * cfg->ent_h * cfg->ent_w;
-        if ((rc = salloc(st, &st->ent_out, ent)) != SPLICE_OK) return fail(rc);
-        if ((rc = salloc(st, &st->d_ent_out, ent)) != SPLICE_OK) return fail(rc);
+        for (float** q : {&st->ent_in, &st->ent_out, &st->d_ent_out})
+            if ((rc = salloc(st, q, P * ent)) != SPLICE_OK) return fail(rc);
         if (st->ve.T > Tmax) Tmax = st->ve.T;
     }
-    if ((rc = salloc(st, &st->S, (size_t)Tmax * Tmax)) != SPLICE_OK) return fail(rc);
-    if ((rc = salloc(st, &st->S_tgt, (size_t)Tmax * Tmax)) != SPLICE_OK) return fail(rc);
-    if ((rc = salloc(st, &st->dS, (size_t)Tmax * Tmax)) != SPLICE_OK) return fail(rc);
     char* wsb = nullptr;
-    if ((rc = salloc(st, &wsb, selfsim_ws_bytes(Tmax, st->vg.D))) != SPLICE_OK) return fail(rc);
+    if ((rc = salloc(st, &wsb, selfsim_batch_ws_bytes(Tmax, st->vg.D, P))) != SPLICE_OK) return fail(rc);
     st->ssim_ws = wsb;
-    if ((rc = salloc(st, &st->losses, 8 + 8 * SPLICE_MSE_PARTIALS)) != SPLICE_OK) return fail(rc);
-    if ((rc = salloc(st, &st->in_b, crop)) != SPLICE_OK) return fail(rc);
-    if (cfg->ent_h > 0 && (rc = salloc(st, &st->ent_in, (size_t)3 * cfg->ent_h * cfg->ent_w)) != SPLICE_OK) return fail(rc);
+    {   // per-term partial slots: the MSE kernels use up to SPLICE_MSE_PARTIALS workgroups, the structure term one per upper-triangular tile
+        const size_t nt = (Tmax + 63) / 64, tri = nt * (nt + 1) / 2;
+        st->lp = tri > SPLICE_MSE_PARTIALS ? tri : SPLICE_MSE_PARTIALS;
+        st->lstride = 8 + 8 * st->lp;
+    }
+    if ((rc = salloc(st, &st->losses, P * st->lstride)) != SPLICE_OK) return fail(rc);
     if ((rc = salloc(st, &st->dev_t, 4)) != SPLICE_OK) return fail(rc);
     if (const char* e = getenv("SPLICE_STEP_GRAPH")) st->use_graph = atoi(e);
     if (const char* e = getenv("SPLICE_STEP_SYNC")) st->dbg_sync = atoi(e);
@@ -287,73 +322,51 @@ void splice_step_destroy(void* h) {
 }
 
 // Pointers to the generator outputs of the last step (device, valid until the next run):
-// which 0: x_global|y_global [2][3][crop_h][crop_w], 1: x_entire [1][3][ent_h][ent_w]
+// which 0: x_global [P][3][a_h][a_w], 1: x_entire [P][3][ent_h][ent_w], 2: y_global [P][3][b_h][b_w]
 int splice_step_output(void* h, int which, float** out) {
     SpliceStep* st = (SpliceStep*)h;
     if (!st || !out) return SPLICE_ERR_ARG;
-    *out = which == 0 ? st->gen_out : st->ent_out;
+    *out = which == 0 ? st->gen_out : which == 1 ? st->ent_out : which == 2 ? st->gen_out_b : nullptr;
     return *out ? SPLICE_OK : SPLICE_ERR_STATE;
 }
 
-// Crop size of the NEXT steps (<= the size the step was created for): the reference's data feed
-// draws size ~ U(min_cover*h, h) per step (data/transforms.py:21-22); the ViT input size
-// (after Resize) is unchanged for square crops.
-int splice_step_set_crop(void* h, int crop_h, int crop_w) {
-    SpliceStep* st = (SpliceStep*)h;
-    if (!st) return SPLICE_ERR_ARG;
-    if (crop_h > st->max_crop_h || crop_w > st->max_crop_w) { splice_set_error("splice_step_set_crop: larger than the creation size"); return SPLICE_ERR_ARG; }
-    RC(splice_gen_plan_resize(st->plan_g, crop_h, crop_w));
-    if (st->plan_a) RC(splice_gen_plan_resize(st->plan_a, crop_h, crop_w));
-    if (st->plan_b) RC(splice_gen_plan_resize(st->plan_b, crop_h, crop_w));
-    st->cfg.crop_h = st->cropb_h = crop_h;
-    st->cfg.crop_w = st->cropb_w = crop_w;
-    return SPLICE_OK;
-}
-
-// Two N=1 generator plans (created for the maximum crop size).  Required for independent crop sizes of the structure and
-// the appearance image (the reference draws them separately, data/Dataset.py:66-67) -- and, once attached, used for EQUAL
-// sizes too: G(A_crop) and G(B_crop) then form two independent chains (forward beside each other, each backward chain
-// continuing into its own plan), which measured faster than the batched N=2 plan (4.75 vs 4.84 ms/step).
-int splice_step_attach_split_plans(void* h, void* plan_a, void* plan_b) {
-    SpliceStep* st = (SpliceStep*)h;
-    if (!st || !plan_a || !plan_b) return SPLICE_ERR_ARG;
-    int n, ha, wa, hb, wb;
-    RC(splice_gen_plan_dims(plan_a, &n, &ha, &wa, nullptr));
-    if (n != 1) return SPLICE_ERR_ARG;
-    RC(splice_gen_plan_dims(plan_b, &n, &hb, &wb, nullptr));
-    if (n != 1) return SPLICE_ERR_ARG;
-    if (ha > st->max_crop_h || wa > st->max_crop_w || hb > st->max_crop_h || wb > st->max_crop_w) {
-        splice_set_error("splice_step_attach_split_plans: plans larger than the step's buffers");
-        return SPLICE_ERR_ARG;
-    }
-    st->plan_a = plan_a; st->plan_b = plan_b;
-    if (!st->grads_b) RC(salloc(st, &st->grads_b, (size_t)st->nparams));
-    return SPLICE_OK;
-}
+// Crop sizes of the NEXT steps (<= the creation size): the reference's data feed draws size ~ U(min_cover*h, h) per step
+// and image (data/transforms.py:21-22, data/Dataset.py:66-67); the ViT input size (after Resize) is unchanged for square
+// crops.  All pairs of a batch share the two sizes.
 int splice_step_set_crops(void* h, int a_h, int a_w, int b_h, int b_w) {
     SpliceStep* st = (SpliceStep*)h;
     if (!st) return SPLICE_ERR_ARG;
-    if (a_h == b_h && a_w == b_w) return splice_step_set_crop(h, a_h, a_w);
-    if (!st->plan_a || !st->plan_b) { splice_set_error("splice_step_set_crops: different A/B crop sizes need splice_step_attach_split_plans"); return SPLICE_ERR_STATE; }
-    if (a_h > st->max_crop_h || a_w > st->max_crop_w || b_h > st->max_crop_h || b_w > st->max_crop_w) return SPLICE_ERR_ARG;
+    if (a_h > st->max_crop_h || a_w > st->max_crop_w || b_h > st->max_crop_h || b_w > st->max_crop_w) { splice_set_error("splice_step_set_crops: larger than the creation size"); return SPLICE_ERR_ARG; }
     RC(splice_gen_plan_resize(st->plan_a, a_h, a_w));
     RC(splice_gen_plan_resize(st->plan_b, b_h, b_w));
     st->cfg.crop_h = a_h; st->cfg.crop_w = a_w; st->cropb_h = b_h; st->cropb_w = b_w;
     return SPLICE_OK;
 }
 
+// BatchNorm running statistics (models/unet/common.py:95-96): when set, every step applies the momentum-0.1 update of its
+// netG calls in the reference's order (A_global, A on entire steps, B_global; models/model.py:15-23) to the caller's
+// buffer arena(s) (layout: splice_gen_buffer_info; pair p at running + p * stride).  NULL switches tracking off.
+int splice_step_set_running_stats(void* h, float* running, long long stride) {
+    SpliceStep* st = (SpliceStep*)h;
+    if (!st || (running && st->P > 1 && stride <= 0)) return SPLICE_ERR_ARG;
+    st->running = running; st->running_stride = stride;
+    return SPLICE_OK;
+}
+
 // ---- the launch sequence of one step (capturable: no allocation, no host sync, internal pointers only)
-static int step_body(SpliceStep* st, float* params, float* grads, float* m, float* v, bool ssim_on, bool entire, bool split,
-                     hipStream_t s) {
+static int step_body(SpliceStep* st, float* params, float* grads, float* m, float* v, bool ssim_on, bool entire, hipStream_t s) {
     const splice_step_config& c = st->cfg;
     VitView& vg = st->vg;
+    const int P = st->P;
     const float l_ssim = ssim_on ? c.lambda_global_ssim : 0.f, l_id = ssim_on ? c.lambda_global_identity : 0.f;
     const float l_cls = c.lambda_global_cls;
     const float l_essim = entire ? c.lambda_entire_ssim : 0.f, l_ecls = entire ? c.lambda_entire_cls : 0.f;
-    const size_t crop = (size_t)3 * c.crop_h * c.crop_w, vimg = (size_t)3 * vg.H * vg.W;
+    const size_t vimg = (size_t)3 * vg.H * vg.W;
     const float* A_crop = st->gen_in;
-    const float* B_crop = split ? st->in_b : st->gen_in + crop;
+    const float* B_crop = st->in_b;
     const float* A_entire = st->ent_in;
+    // pass layout of the global context: [0, P) A'   [P, 2P) B'   [2P, 3P) x' = G(A crop)   [3P, 4P) y' = G(B crop)
+    const int pA = 0, pB = P, pX = 2 * P, pY = 3 * P;
     // ---- the no-grad target passes A', B' (util/losses.py:79,91,101) do not depend on the generator: their ViT forward
     // runs on a side stream beside the generator forward (hundreds of small latency-bound launches that leave most
     // CUs idle); inside a capture this becomes a fork/join of the graph.  The instrumented (profiling) path stays serial.
@@ -363,110 +376,125 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         HIPCHK(hipEventRecord(st->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(s2, st->ev_fork, 0));
     }
-    // global_transform (Resize -> Normalize; the Normalize is fused into the ViT patch gather)
-    // unequal crop sizes (random crops): the generator runs as two N=1 plans; G(B_crop) goes first on the side stream so
-    // that it runs beside G(A_crop) instead of behind it
-    if (split && !(st->ablate & 1)) {
-        RC(splice_gen_forward_borrowed(st->plan_b, params, B_crop, st->gen_out + crop, s2));
+    // global_transform (Resize -> Normalize; the Normalize is fused into the ViT patch gather).  The generator runs as one
+    // plan per crop kind (A crops | B crops: the reference draws their sizes independently, data/Dataset.py:66-67);
+    // G(B_crop) goes first on the side stream so that it runs beside G(A_crop) instead of behind it
+    if (!(st->ablate & 1)) {
+        RC(splice_gen_forward_borrowed(st->plan_b, params, B_crop, st->gen_out_b, s2));
         if (overlap) HIPCHK(hipEventRecord(st->ev_gb, s2));
     }
-    RC(place_image(A_crop, c.crop_h, c.crop_w, vg.imgs + 0 * vimg, vg.H, vg.W, s2));
-    RC(place_image(B_crop, st->cropb_h, st->cropb_w, vg.imgs + 1 * vimg, vg.H, vg.W, s2));
-    if (!(st->ablate & 8)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, 2, 0, 2, s2));
+    RC(place_images(A_crop, c.crop_h, c.crop_w, vg.imgs + pA * vimg, vg.H, vg.W, P, s2));
+    RC(place_images(B_crop, st->cropb_h, st->cropb_w, vg.imgs + pB * vimg, vg.H, vg.W, P, s2));
+    if (!(st->ablate & 8)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, pX, pA, pX, s2));
     float *blk_g = nullptr, *qkv_g = nullptr;
     RC(splice_vit_get_tensor(vg.ctx, 0, vg.depth - 1, (void**)&blk_g));
     RC(splice_vit_get_tensor(vg.ctx, 3, vg.depth - 1, (void**)&qkv_g));
     // everything of the loss stage that does not need the generated images also runs here, off the critical path
-    RC(dev_zero_launch(st->losses, (8 + 8 * SPLICE_MSE_PARTIALS) * sizeof(float), s2));
-    RC(dev_zero_launch(vg.d_block, (size_t)vg.rows * vg.D * sizeof(float), s2));
-    RC(dev_zero_launch(vg.d_keys, (size_t)vg.rows * vg.D * sizeof(float), s2));
+    RC(dev_zero_launch(st->losses, (size_t)P * st->lstride * sizeof(float), s2));
+    const size_t passD = (size_t)vg.Tld * vg.D;
+    RC(dev_zero_launch(vg.d_block + pX * passD, (size_t)2 * P * passD * sizeof(float), s2));
+    RC(dev_zero_launch(vg.d_keys + pX * passD, (size_t)2 * P * passD * sizeof(float), s2));
+    SelfSimBatch sb = {};
     if (l_ssim > 0.f) {   // target self-similarity S* of A' (util/losses.py:79)
-        SelfSimWs ws;
-        selfsim_ws_carve(st->ssim_ws, vg.T, vg.D, &ws);
-        RC(selfsim_fwd_launch(keys_ptr(vg, qkv_g, 0), 3 * vg.D, vg.T, vg.D, 1e-8f, st->S_tgt, ws, s2));
+        RC(ssim_batch(st, vg, pA, pX, l_ssim, L_GLOBAL_SSIM, &sb));
+        RC(selfsim_target_launch(sb, s2));
     }
     if (overlap) HIPCHK(hipEventRecord(st->ev_join, s2));
     // ---- Model.forward: x_global = G(A_crop), y_global = G(B_crop) [, x_entire = G(A)]
-    if (st->ablate & 1) {
-    } else if (!split) {
-        RC(splice_gen_forward_borrowed(st->plan_g, params, st->gen_in, st->gen_out, s));
-    } else {
+    if (!(st->ablate & 1)) {
         RC(splice_gen_forward_borrowed(st->plan_a, params, A_crop, st->gen_out, s));
         if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_gb, 0));
     }
-    RC(place_image(st->gen_out, c.crop_h, c.crop_w, vg.imgs + 2 * vimg, vg.H, vg.W, s));
-    RC(place_image(st->gen_out + crop, st->cropb_h, st->cropb_w, vg.imgs + 3 * vimg, vg.H, vg.W, s));
-    if (!(st->ablate & 16)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, 2, 2, 4, s));
+    RC(place_images(st->gen_out, c.crop_h, c.crop_w, vg.imgs + pX * vimg, vg.H, vg.W, P, s));
+    RC(place_images(st->gen_out_b, st->cropb_h, st->cropb_w, vg.imgs + pY * vimg, vg.H, vg.W, P, s));
+    if (!(st->ablate & 16)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, pX, pX, 4 * P, s));
     if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
-    const size_t passD = (size_t)vg.Tld * vg.D;
-    // ---- losses on the global batch: passes 0 A', 1 B', 2 x', 3 y'
-    if (l_ssim > 0.f) RC(ssim_term(st, vg, qkv_g, 0, 2, l_ssim, L_GLOBAL_SSIM, s, true));
+    // ---- losses on the global batch
+    if (l_ssim > 0.f) RC(selfsim_loss_launch(sb, s));
     if (l_cls > 0.f)   // [CLS] of block 11, before the final LayerNorm (util/losses.py:90-93)
-        RC(mse_partials_launch(blk_g + 2 * passD, vg.D, blk_g + 1 * passD, vg.D, 1, vg.D, 1.0f, l_cls, loss_part(st, L_GLOBAL_CLS), vg.d_block + 2 * passD, vg.D, s));
+        RC(mse_batched_launch(blk_g + pX * passD, vg.D, passD, blk_g + pB * passD, vg.D, passD, 1, vg.D, 1.0f, l_cls, loss_part(st, L_GLOBAL_CLS),
+                              st->lstride, vg.d_block + pX * passD, vg.D, passD, P, s));
     if (l_id > 0.f)    // keys of y' against keys of B' (util/losses.py:96-105): mean over h*T*d = T*D
-        RC(mse_partials_launch(keys_ptr(vg, qkv_g, 3), 3 * vg.D, keys_ptr(vg, qkv_g, 1), 3 * vg.D, vg.T, vg.D, 1.0f, l_id, loss_part(st, L_GLOBAL_ID),
-                       vg.d_keys + 3 * passD, vg.D, s));
-    // ---- entire-image branch (every entire_every-th step)
+        RC(mse_batched_launch(keys_ptr(vg, qkv_g, pY), 3 * vg.D, 3 * passD, keys_ptr(vg, qkv_g, pB), 3 * vg.D, 3 * passD, vg.T, vg.D, 1.0f, l_id,
+                              loss_part(st, L_GLOBAL_ID), st->lstride, vg.d_keys + pY * passD, vg.D, passD, P, s));
+    // ---- entire-image branch (every entire_every-th step): passes [0, P) A_entire', [P, 2P) x_entire'
     if (entire) {
         VitView& ve = st->ve;
         const size_t eimg = (size_t)3 * ve.H * ve.W;
         RC(splice_gen_forward_borrowed(st->plan_e, params, A_entire, st->ent_out, s));
-        RC(place_image(A_entire, c.ent_h, c.ent_w, ve.imgs, ve.H, ve.W, s));
-        RC(place_image(st->ent_out, c.ent_h, c.ent_w, ve.imgs + eimg, ve.H, ve.W, s));
-        RC(splice_vit_forward_ex(ve.ctx, ve.imgs, 1, 1, s));
-        float *blk_e = nullptr, *qkv_e = nullptr;
+        RC(place_images(A_entire, c.ent_h, c.ent_w, ve.imgs, ve.H, ve.W, P, s));
+        RC(place_images(st->ent_out, c.ent_h, c.ent_w, ve.imgs + P * eimg, ve.H, ve.W, P, s));
+        RC(splice_vit_forward_ex(ve.ctx, ve.imgs, 1, P, s));
+        float* blk_e = nullptr;
         RC(splice_vit_get_tensor(ve.ctx, 0, ve.depth - 1, (void**)&blk_e));
-        RC(splice_vit_get_tensor(ve.ctx, 3, ve.depth - 1, (void**)&qkv_e));
-        RC(dev_zero_launch(ve.d_block, (size_t)ve.rows * ve.D * sizeof(float), s));
-        RC(dev_zero_launch(ve.d_keys, (size_t)ve.rows * ve.D * sizeof(float), s));
         const size_t epassD = (size_t)ve.Tld * ve.D;
-        if (l_essim > 0.f) RC(ssim_term(st, ve, qkv_e, 0, 1, l_essim, L_ENTIRE_SSIM, s));
+        RC(dev_zero_launch(ve.d_block + P * epassD, (size_t)P * epassD * sizeof(float), s));
+        RC(dev_zero_launch(ve.d_keys + P * epassD, (size_t)P * epassD * sizeof(float), s));
+        if (l_essim > 0.f) {
+            SelfSimBatch se = {};
+            RC(ssim_batch(st, ve, 0, P, l_essim, L_ENTIRE_SSIM, &se));
+            RC(selfsim_target_launch(se, s));
+            RC(selfsim_loss_launch(se, s));
+        }
         if (l_ecls > 0.f)   // target is the B_global crop's CLS (util/losses.py:60)
-            RC(mse_partials_launch(blk_e + 1 * epassD, ve.D, blk_g + 1 * passD, vg.D, 1, ve.D, 1.0f, l_ecls, loss_part(st, L_ENTIRE_CLS), ve.d_block + 1 * epassD, ve.D, s));
+            RC(mse_batched_launch(blk_e + P * epassD, ve.D, epassD, blk_g + pB * passD, vg.D, passD, 1, ve.D, 1.0f, l_ecls, loss_part(st, L_ENTIRE_CLS),
+                                  st->lstride, ve.d_block + P * epassD, ve.D, epassD, P, s));
     }
     // ---- backward (train.py:78): ViT dgrad for the generated images only, then the generator
-    // the two generated images are independent chains until the generator: one per stream (every launch of a
+    // the x' and y' passes are independent chains until the generator: one per stream (every launch of a
     // dependent chain pays ~8 us of fixed latency; two chains in flight hide each other's)
     bool loss_summed = false;
+    auto sum_losses = [&](hipStream_t q) {
+        hipLaunchKernelGGL(total_loss_kernel, dim3(P), dim3(320), 0, q, st->losses, st->lstride, (int)st->lp, l_ssim, l_essim, l_ecls, l_cls, l_id, st->losses_out);
+    };
+    auto track_running = [&](hipStream_t q) -> int {   // BatchNorm running statistics in the reference's call order
+        if (!st->running || (st->ablate & 1)) return SPLICE_OK;
+        void* plans[3];
+        int np = 0;
+        plans[np++] = st->plan_a;
+        if (entire) plans[np++] = st->plan_e;
+        plans[np++] = st->plan_b;
+        return splice_gen_running_stats_update(plans, np, st->running, st->running_stride, 0.1f, q);
+    };
     const float* adam_g2 = nullptr;
     if (!(st->ablate & 4)) {   // (the same launches whether or not the second stream is used: results are bit-identical)
         if (overlap) {
             HIPCHK(hipEventRecord(st->ev_fork, s));
             HIPCHK(hipStreamWaitEvent(s2, st->ev_fork, 0));
         }
-        if (!(st->ablate & 32)) RC(splice_vit_backward(vg.ctx, 3, 4, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s2));
-        RC(unplace_grad(vg.d_imgs + 3 * vimg, vg.H, vg.W, st->d_gen_out + crop, st->cropb_h, st->cropb_w, s2));
-        // split crops: each chain continues into its own generator plan (own gradient arena: no cross-chain accumulation)
-        if (split && !(st->ablate & 2)) RC(splice_gen_backward(st->plan_b, params, st->d_gen_out + crop, st->grads_b, 0, s2));
+        if (!(st->ablate & 32)) RC(splice_vit_backward(vg.ctx, pY, 4 * P, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s2));
+        RC(unplace_grads(vg.d_imgs + pY * vimg, vg.H, vg.W, st->d_gen_out_b, st->cropb_h, st->cropb_w, P, s2));
+        // each chain continues into its own generator plan (own gradient arena: no cross-chain accumulation)
+        if (!(st->ablate & 2)) RC(splice_gen_backward(st->plan_b, params, st->d_gen_out_b, st->grads_b, 0, s2));
         if (overlap) {
-            // the reported loss values depend on nothing downstream: summed at the tail of the side chain instead of
-            // between the generator backward and Adam on the critical one
-            hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(320), 0, s2, st->losses, l_ssim, l_essim, l_ecls, l_cls, l_id, st->losses_out);
+            // the reported loss values and the BatchNorm bookkeeping depend on nothing downstream: they run at the tail of
+            // the side chain instead of between the generator backward and Adam on the critical one
+            sum_losses(s2);
             loss_summed = true;
+            RC(track_running(s2));
             HIPCHK(hipEventRecord(st->ev_join, s2));
         }
-        RC(splice_vit_backward(vg.ctx, 2, 3, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
-        RC(unplace_grad(vg.d_imgs + 2 * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, s));
-        if (split && !(st->ablate & 2)) RC(splice_gen_backward(st->plan_a, params, st->d_gen_out, grads, 0, s));
+        RC(splice_vit_backward(vg.ctx, pX, pY, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
+        RC(unplace_grads(vg.d_imgs + pX * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, P, s));
+        if (!(st->ablate & 2)) RC(splice_gen_backward(st->plan_a, params, st->d_gen_out, grads, 0, s));
         if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
         // grads = g(A) + g(B): folded into the Adam kernel on ordinary steps; a separate add when the entire-image branch
         // still has to accumulate into the sum (same association order either way)
-        if (split && !(st->ablate & 2)) {
-            if (entire) RC(add_f32_launch(grads, st->grads_b, (size_t)st->nparams, s));
+        if (!(st->ablate & 2)) {
+            if (entire) RC(add_f32_launch(grads, st->grads_b, P > 1 ? P * st->astride : (size_t)st->nparams, s));
             else adam_g2 = st->grads_b;
         }
     }
-    if (!split && !(st->ablate & 2)) RC(splice_gen_backward(st->plan_g, params, st->d_gen_out, grads, 0, s));
     if (entire) {
         VitView& ve = st->ve;
         const size_t eimg = (size_t)3 * ve.H * ve.W;
-        RC(splice_vit_backward(ve.ctx, 1, 2, ve.pb.data(), nullptr, ve.pk.data(), ve.d_imgs, 1, s));
-        RC(unplace_grad(ve.d_imgs + eimg, ve.H, ve.W, st->d_ent_out, c.ent_h, c.ent_w, s));
+        RC(splice_vit_backward(ve.ctx, P, 2 * P, ve.pb.data(), nullptr, ve.pk.data(), ve.d_imgs, 1, s));
+        RC(unplace_grads(ve.d_imgs + P * eimg, ve.H, ve.W, st->d_ent_out, c.ent_h, c.ent_w, P, s));
         RC(splice_gen_backward(st->plan_e, params, st->d_ent_out, grads, 1, s));
     }
-    if (!loss_summed) hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(320), 0, s, st->losses, l_ssim, l_essim, l_ecls, l_cls, l_id, st->losses_out);
-    // ---- optimizer.step() (train.py:79); Adam's step count (>= 1) is read from the device at execution time
-    RC(adam_launch_dev(params, grads, m, v, (size_t)st->nparams, c.lr, c.beta1, c.beta2, c.eps, st->dev_t, 0, s, adam_g2));
+    if (!loss_summed) { sum_losses(s); RC(track_running(s)); }
+    // ---- optimizer.step() (train.py:79) over every pair's arena; Adam's step count (>= 1) is read from the device at execution time
+    RC(adam_launch_dev(params, grads, m, v, P > 1 ? P * st->astride : (size_t)st->nparams, c.lr, c.beta1, c.beta2, c.eps, st->dev_t, 0, s, adam_g2));
     return SPLICE_OK;
 }
 
@@ -479,32 +507,30 @@ static void drop_graphs(SpliceStep* st) {
     st->graphs.clear();
 }
 
-// One step.  step_idx is the reference's data step counter (0-based, data/Dataset.py:57,63).
-// params/grads/m/v: flat generator arenas.  losses_out: device fp32[8] =
-// {loss, loss_global_ssim, loss_entire_ssim, loss_entire_cls, loss_global_cls, loss_global_id_B, 0, 0}
-// (inactive terms are 0).  A_entire may be NULL on steps where step_idx % entire_every != 0.
-// The launch sequence (~500 kernels) is captured once per regime (first step / ordinary / entire-image,
-// equal or split crops) into a hipGraph and replayed; inputs are staged into handle-owned buffers first
-// so the graph only ever sees the same pointers.
+// One step of every pair.  step_idx is the reference's data step counter (0-based, data/Dataset.py:57,63).
+// params/grads/m/v: the generator arenas, [P][arena_stride] (one flat arena when P = 1).  A_crop / B_crop: [P][3][h][w]
+// at the current crop sizes; A_entire [P][3][ent_h][ent_w] (may be NULL on steps where step_idx % entire_every != 0).
+// losses_out: device fp32 [P][8], per pair {loss, loss_global_ssim, loss_entire_ssim, loss_entire_cls, loss_global_cls,
+// loss_global_id_B, 0, 0} (inactive terms are 0).
+// The launch sequence (~500 kernels) is captured once per regime (first step / ordinary / entire-image) into a hipGraph
+// and replayed; inputs are staged into handle-owned buffers first so the graph only ever sees the same pointers.
 int splice_step_run(void* h, float* params, float* grads, float* m, float* v, const float* A_crop, const float* B_crop,
                     const float* A_entire, int step_idx, float* losses_out, splice_stream_t stream) {
     SpliceStep* st = (SpliceStep*)h;
     if (!st || !params || !grads || !m || !v || !A_crop || !B_crop || step_idx < 0) return SPLICE_ERR_ARG;
     hipStream_t caller = (hipStream_t)stream;
     const splice_step_config& c = st->cfg;
+    const int P = st->P;
     // ---- lambda schedule (util/losses.py:34-44)
     if (step_idx == c.cls_warmup) st->ssim_id_on = 1;
     const bool entire = c.ent_h > 0 && c.entire_every > 0 && (step_idx % c.entire_every == 0);
     if (entire && !A_entire) { splice_set_error("splice_step_run: step %d needs the entire structure image", step_idx); return SPLICE_ERR_ARG; }
-    const bool unequal = c.crop_h != st->cropb_h || c.crop_w != st->cropb_w;
-    if (unequal && !(st->plan_a && st->plan_b)) { splice_set_error("splice_step_run: different A/B crop sizes need splice_step_attach_split_plans"); return SPLICE_ERR_STATE; }
-    const bool split = st->plan_a && st->plan_b;   // two per-image generator chains whenever the N=1 plans exist
     // Graphs pay off only while the launch sequence repeats: with random crop sizes (data/transforms.py:21) nearly every
     // step has new shapes, and re-capturing + instantiating ~600 nodes costs as much as the step itself (9.9 vs 5.8 ms
     // measured).  So a step whose arenas / crop sizes differ from the previous step's runs eagerly (same kernels, same
     // results) and a graph is captured only from the second consecutive step with identical shapes on.
     {
-        void* ptrs[5] = {params, grads, m, v, losses_out};
+        void* ptrs[6] = {params, grads, m, v, losses_out, st->running};
         st->losses_out = losses_out;
         const int crops[4] = {c.crop_h, c.crop_w, st->cropb_h, st->cropb_w};
         if (memcmp(ptrs, st->graph_ptrs, sizeof(ptrs)) || memcmp(crops, st->graph_crops, sizeof(crops))) {
@@ -525,24 +551,23 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
         HIPCHK(hipStreamWaitEvent(s, st->ev_in, 0));
     }
     // ---- stage the inputs (eager)
-    const size_t crop = (size_t)3 * c.crop_h * c.crop_w, cropb = (size_t)3 * st->cropb_h * st->cropb_w;
     {
         StageArgs sa = {};
-        sa.src[0] = A_crop; sa.dst[0] = st->gen_in; sa.n[0] = crop;
-        sa.src[1] = B_crop; sa.dst[1] = split ? st->in_b : st->gen_in + crop; sa.n[1] = cropb;
-        if (entire) { sa.src[2] = A_entire; sa.dst[2] = st->ent_in; sa.n[2] = (size_t)3 * c.ent_h * c.ent_w; }
+        sa.src[0] = A_crop; sa.dst[0] = st->gen_in; sa.n[0] = (size_t)P * 3 * c.crop_h * c.crop_w;
+        sa.src[1] = B_crop; sa.dst[1] = st->in_b; sa.n[1] = (size_t)P * 3 * st->cropb_h * st->cropb_w;
+        if (entire) { sa.src[2] = A_entire; sa.dst[2] = st->ent_in; sa.n[2] = (size_t)P * 3 * c.ent_h * c.ent_w; }
         sa.ip = st->dev_t; sa.iv = step_idx + 1;
-        hipLaunchKernelGGL(stage_inputs_kernel, dim3(128), dim3(256), 0, s, sa);
+        hipLaunchKernelGGL(stage_inputs_kernel, dim3(128 * (P > 4 ? 4 : P)), dim3(256), 0, s, sa);
     }
     if (!graph) {
-        RC(step_body(st, params, grads, m, v, st->ssim_id_on != 0, entire, split, s));
+        RC(step_body(st, params, grads, m, v, st->ssim_id_on != 0, entire, s));
     } else {
-        const int variant = (st->ssim_id_on ? 1 : 0) | (entire ? 2 : 0) | (split ? 4 : 0);
+        const int variant = (st->ssim_id_on ? 1 : 0) | (entire ? 2 : 0);
         auto it = st->graphs.find(variant);
         if (it == st->graphs.end()) {
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            const int rc = step_body(st, params, grads, m, v, st->ssim_id_on != 0, entire, split, s);
+            const int rc = step_body(st, params, grads, m, v, st->ssim_id_on != 0, entire, s);
             const hipError_t ee = hipStreamEndCapture(s, &g);
             if (rc != SPLICE_OK || ee != hipSuccess || !g) {
                 if (g) (void)hipGraphDestroy(g);
@@ -554,21 +579,7 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
                 (void)hipGraphGetNodes(g, nullptr, &nn);
                 (void)hipGraphGetEdges(g, nullptr, nullptr, &ne);
                 (void)hipGraphGetRootNodes(g, nullptr, &nr);
-                std::vector<hipGraphNode_t> nodes(nn);
-                (void)hipGraphGetNodes(g, nodes.data(), &nn);
-                int kinds[16] = {0};
-                size_t multi_dep = 0, no_dep = 0;
-                for (auto n : nodes) {
-                    hipGraphNodeType ty;
-                    if (hipGraphNodeGetType(n, &ty) == hipSuccess && (int)ty < 16) kinds[(int)ty]++;
-                    size_t nd = 0;
-                    (void)hipGraphNodeGetDependencies(n, nullptr, &nd);
-                    if (nd > 1) multi_dep++;
-                    if (nd == 0) no_dep++;
-                }
-                fprintf(stderr, "[splice graph] variant %d: nodes %zu edges %zu roots %zu nodes-without-deps %zu multi-dep %zu | kernel %d memcpy %d memset %d other %d\n",
-                        variant, nn, ne, nr, no_dep, multi_dep, kinds[hipGraphNodeTypeKernel], kinds[hipGraphNodeTypeMemcpy], kinds[hipGraphNodeTypeMemset],
-                        (int)nn - kinds[hipGraphNodeTypeKernel] - kinds[hipGraphNodeTypeMemcpy] - kinds[hipGraphNodeTypeMemset]);
+                fprintf(stderr, "[splice graph] variant %d (pairs %d): nodes %zu edges %zu roots %zu\n", variant, P, nn, ne, nr);
             }
             hipGraphExec_t ex = nullptr;
             const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);

@@ -34,7 +34,8 @@ void splice_set_error(const char* fmt, ...);
     } while (0)
 
 // ---- optional live timing of ONE kernel family with HIP events on the launch stream (bench.py's
-// roofline leg).  which: 1 = fc1 GEMM (forward), 2 = qkv GEMM (forward), 3 = attention forward.
+// roofline leg).  which: 1 = fc1 GEMM (forward), 2 = qkv GEMM (forward), 3 = attention forward, 4 = fc2 GEMM (forward),
+// 5 = the split-K dgrad GEMMs (fc1^T and qkv^T), 6 = attention backward.
 struct ProfState {
     int which = 0;
     std::vector<hipEvent_t> ev;   // start/stop pairs
@@ -444,6 +445,8 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
 // kind 2: attention out l bf16 [rows][D]      (pre-projection; the hooked 'patch_imd' is proj of it)
 // kind 3: last-layer qkv  fp32 [rows][3D]
 // kind 4: lse          l  fp32 [B][H][Tld]
+// kind 5: embedded tokens fp32 [rows][D]
+// kind 6: raw qkv l, transposed  bf16 [3D][rows]   (row = feature, column = pass * Tld + token)
 int splice_vit_get_tensor(void* ctx, int kind, int layer, void** out) {
     SpliceVitCtx* c = (SpliceVitCtx*)ctx;
     if (!c || !out || layer < 0 || layer >= c->vit->depth) return SPLICE_ERR_ARG;
@@ -454,6 +457,7 @@ int splice_vit_get_tensor(void* ctx, int kind, int layer, void** out) {
         case 3: *out = c->qkv_last_f32; break;
         case 4: *out = c->lse[layer]; break;
         case 5: *out = c->xs[0]; break;
+        case 6: *out = c->qkvT[layer]; break;
         default: return SPLICE_ERR_ARG;
     }
     return SPLICE_OK;
@@ -492,7 +496,10 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
     // the two long-K dgrad GEMMs (N = D) have too few tiles for the chip: split K in three (tools/gemm_splitk_bench.py) or two,
     // LayerNorm-backward adds the slabs
     const size_t slab = (size_t)c->rows * D;
-    const int ks = (cdiv(R, 64) * cdiv(D, 64) * 3 <= 640 && D % 192 == 0) ? 3 : (cdiv(R, 64) * cdiv(D, 64) <= 640 && D % 128 == 0) ? 2 : 1;
+    // The split is chosen from the tiles of ONE pass, not of the range: split-K changes the summation order, and the
+    // gradient of an image must not depend on how many images (pairs) share the backward.
+    const int tiles1 = cdiv(c->Tld, 64) * cdiv(D, 64);
+    const int ks = (tiles1 * 3 <= 640 && D % 192 == 0) ? 3 : (tiles1 <= 640 && D % 128 == 0) ? 2 : 1;
     for (int l = L - 1; l >= 0; --l) {
         const LayerW& W = v->layers[l];
         const float* db = d_block ? d_block[l] : nullptr;
@@ -515,6 +522,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
             {
                 GemmEpi e = {};
                 e.out_f32 = c->dln + r0 * D; e.ldo = D; e.ksplit = ks; e.slab_stride = (long long)slab;
+                ProfScope ps(5, s);
                 RC(gemm_nt_launch(EPI_OUT_F32, c->dh + r0 * Hd, Hd, W.fc1.wT, Hd, R, D, Hd, e, s));
             }
             RC(layernorm_bwd_slabs_launch(c->dln + r0 * D, ks, slab, c->xmid[l] + r0 * D, W.ln2_g, c->mean2[l] + r0, c->rstd2[l] + r0, g, g, g_bf, R, D, s));
@@ -535,6 +543,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
                 a.D = D; a.H = v->heads; a.scale = 0.125f; a.out = c->attn_out[l] + r0 * D;
                 a.lse = c->lse[l] + (size_t)pass_begin * v->heads * c->Tld;
                 a.dout = c->dout + r0 * D; a.doutT = c->doutT + r0; a.delta = c->delta + (size_t)pass_begin * v->heads * c->Tld; a.delta_ready = 1; a.dqkv = dqkv;
+                ProfScope ps(6, s);
                 RC(attn_bwd_launch(&a, s));
             }
             g_after_mlp = g;
@@ -546,6 +555,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
         {
             GemmEpi e = {};
             e.out_f32 = c->dln + r0 * D; e.ldo = D; e.ksplit = ks; e.slab_stride = (long long)slab;
+            ProfScope ps(5, s);
             RC(gemm_nt_launch(EPI_OUT_F32, dqkv, 3 * D, W.qkv.wT, 3 * D, R, D, 3 * D, e, s));
         }
         RC(layernorm_bwd_slabs_launch(c->dln + r0 * D, ks, slab, c->xs[l] + r0 * D, W.ln1_g, c->mean1[l] + r0, c->rstd1[l] + r0, g_after_mlp, g, g_bf, R, D, s));

@@ -1,8 +1,9 @@
-"""SpliceEngine: the per-pair optimisation loop of ``train.py:34-80`` on one MI355X.
+"""SpliceEngine / MultiPairEngine: the per-pair optimisation loop of ``train.py:34-80`` on one MI355X.
 
 Owns the frozen DINO-ViT engine, the generator arenas (parameters / gradients / Adam moments,
-flat fp32 in ``netG.parameters()`` order) and the fused step handle.  One engine = one image pair
-= one GPU = one stream; pairs are independent (no collectives), see ``bench.py --gpus N``.
+flat fp32 in ``netG.parameters()`` order, one arena per pair) and the fused step handle.  One engine = one
+GPU = one stream; pairs are independent (no collectives): P of them ride one engine's launches
+(``MultiPairEngine``), and GPUs run independent engines (``bench.py --gpus N``, ``splice_amd.batch``).
 """
 import ctypes as C
 
@@ -10,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib, synth
-from .generator import GeneratorEngine
+from .generator import GeneratorEngine, GeneratorPlan
 from .vit import VitEngine
 
 LOSS_KEYS = ["loss", "loss_global_ssim", "loss_entire_ssim", "loss_entire_cls", "loss_global_cls", "loss_global_id_B"]
@@ -38,38 +39,60 @@ def resize_output_size(h, w, size, max_size=480):
     return (new_long, new_short) if w <= h else (new_short, new_long)
 
 
-class SpliceEngine:
-    def __init__(self, cfg, vit_state, gen_state, crop_hw, entire_hw=None, device="cuda", vit_engine=None):
-        """cfg: reference config keys (conf/default/config.yaml); vit_state: DINO state dict;
-        gen_state: generator state dict (reference names); crop_hw: (h, w) of the global crops;
-        entire_hw: (H, W) of the whole structure image or None to disable the entire branch."""
+class MultiPairEngine:
+    """P image pairs optimised side by side on one GPU (``pairs`` = P; P = 1 is the reference's one pair per process).
+
+    The pairs share the frozen ViT and every kernel launch of a step; each has its own generator (parameter / gradient /
+    Adam-moment arena ``[P, stride]``), its own BatchNorm statistics and its own loss values.  A pair's trajectory is
+    bit-identical whichever batch it rides in (tests/test_multipair_gpu.py).  All pairs of a batch share the image and
+    crop sizes."""
+
+    def __init__(self, cfg, vit_state, gen_states, crop_hw, entire_hw=None, device="cuda", vit_engine=None):
+        """cfg: reference config keys (conf/default/config.yaml); vit_state: DINO state dict; gen_states: list of P generator
+        state dicts (reference names); crop_hw: (h, w) of the (largest) global crops; entire_hw: (H, W) of the whole
+        structure image or None to disable the entire branch."""
         self.cfg = dict(DEFAULT_CFG, **cfg)
         c = self.cfg
         if c["optimizer"] != "adam" or c["scheduler_policy"] != "none":
-            raise NotImplementedError("SpliceEngine implements the reference's default optimizer 'adam' with scheduler 'none'")
+            raise NotImplementedError("the fused step implements the reference's default optimizer 'adam' with scheduler 'none'")
         self.device = torch.device(device)
+        self.P = P = len(gen_states)
         self.vit = vit_engine or VitEngine(c["dino_model_name"], device=device).load_state_dict(vit_state)
         self.gen = GeneratorEngine(device=device)
-        self.params = self.gen.flatten(gen_state)
+        n = self.gen.numel
+        self.stride = n if P == 1 else (n + 63) // 64 * 64
+        self.params = torch.zeros(P * self.stride, device=self.device)
+        for p_, st in enumerate(gen_states):
+            self.params[p_ * self.stride: p_ * self.stride + n] = self.gen.flatten(st)
         self.grads = torch.zeros_like(self.params)
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
-        P = c["dino_global_patch_size"]
+        # BatchNorm buffers of every pair's netG (running_mean 0 / running_var 1 at construction, as nn.BatchNorm2d)
+        self.running = torch.zeros(P, self.gen.buffer_numel, device=self.device)
+        for name, (off, cnt) in self.gen.buffer_table.items():
+            if name.endswith("running_var"):
+                self.running[:, off:off + cnt] = 1.0
+        self.generator_calls = 0   # = every BatchNorm's num_batches_tracked
+        Pz = c["dino_global_patch_size"]
         ch, cw = crop_hw
-        vh, vw = resize_output_size(ch, cw, P, 480)
+        vh, vw = resize_output_size(ch, cw, Pz, 480)
         self.crop_hw, self.vit_hw = (ch, cw), (vh, vw)
-        self.ctx_g = self.vit.context(4, vh, vw, need_grad=True)
-        self.plan_g = self.gen.plan(2, ch, cw, need_grad=True)
+        self.ctx_g = self.vit.context(4 * P, vh, vw, need_grad=True)
+        arena_stride = self.stride if P > 1 else 0
+        # private plan objects (the shape-keyed plan cache could hand out one plan twice)
+        self.plan_a = GeneratorPlan(self.gen, P, ch, cw, True, arena_stride)
+        self.plan_b = GeneratorPlan(self.gen, P, ch, cw, True, arena_stride)
         sc = _lib.StepConfig()
         sc.crop_h, sc.crop_w, sc.vit_h, sc.vit_w = ch, cw, vh, vw
+        sc.pairs, sc.arena_stride = P, arena_stride
         self.ctx_e = self.plan_e = None
         self.entire_hw = entire_hw
         use_entire = entire_hw is not None and (c["lambda_entire_ssim"] > 0 or c["lambda_entire_cls"] > 0)
         if use_entire:
             eh, ew = entire_hw
-            evh, evw = resize_output_size(eh, ew, P, 480)
-            self.ctx_e = self.vit.context(2, evh, evw, need_grad=True)
-            self.plan_e = self.gen.plan(1, eh, ew, need_grad=True)
+            evh, evw = resize_output_size(eh, ew, Pz, 480)
+            self.ctx_e = self.vit.context(2 * P, evh, evw, need_grad=True)
+            self.plan_e = GeneratorPlan(self.gen, P, eh, ew, True, arena_stride)
             sc.ent_h, sc.ent_w, sc.ent_vit_h, sc.ent_vit_w = eh, ew, evh, evw
         sc.lambda_global_cls, sc.lambda_global_ssim = c["lambda_global_cls"], c["lambda_global_ssim"]
         sc.lambda_global_identity = c["lambda_global_identity"]
@@ -78,18 +101,14 @@ class SpliceEngine:
         sc.lr, sc.beta1, sc.beta2, sc.eps = c["lr"], c["optimizer_beta1"], c["optimizer_beta2"], 1e-8
         h = C.c_void_p()
         _lib.check(_lib.lib().splice_step_create(C.byref(sc), self.ctx_g.handle, self.ctx_e.handle if self.ctx_e else None,
-                                                 self.plan_g.handle, self.plan_e.handle if self.plan_e else None, C.byref(h)),
+                                                 self.plan_a.handle, self.plan_b.handle, self.plan_e.handle if self.plan_e else None, C.byref(h)),
                    "step_create")
         self.handle = h
-        self.losses_dev = torch.zeros(8, device=self.device)
+        _lib.check(_lib.lib().splice_step_set_running_stats(self.handle, _lib.ptr(self.running), self.running.stride(0)), "step_set_running_stats")
+        self.losses_dev = torch.zeros(P, 8, device=self.device)
         self.step_idx = -1  # data/Dataset.py:57 -- the first step is 0
         self._cur_crops = (ch, cw, ch, cw)
-        # two N=1 plans: independent A / B crop sizes (data/Dataset.py:66-67) and, also for equal sizes, two per-image
-        # generator chains that run beside each other (faster than the batched N=2 plan)
-        # (private plan objects: the shape-keyed plan cache could hand out the entire-image plan of the same size)
-        self._split_plans = (GeneratorPlanAlias(self.gen, (ch, cw)), GeneratorPlanAlias(self.gen, (ch, cw)))
-        _lib.check(_lib.lib().splice_step_attach_split_plans(self.handle, self._split_plans[0].handle, self._split_plans[1].handle),
-                   "step_attach_split_plans")
+        self._log_plans = {}
 
     def __del__(self):
         try:
@@ -100,60 +119,108 @@ class SpliceEngine:
             pass
 
     def step(self, A_crop, B_crop, A_entire=None):
-        """One optimisation step, asynchronous on the current stream.  Tensors: fp32 CUDA
-        ``[3,h,w]`` (or ``[1,3,h,w]``) in [0,1].  Returns the device tensor of 8 losses
-        (see LOSS_KEYS); call ``losses()`` to sync and read them."""
+        """One optimisation step of every pair, asynchronous on the current stream.  Tensors: fp32 CUDA ``[P,3,h,w]`` in
+        [0,1] (``[3,h,w]`` accepted for P = 1).  Returns the device tensor ``[P,8]`` of losses (see LOSS_KEYS)."""
         self.step_idx += 1
         for t in (A_crop, B_crop):
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+            assert t.numel() == self.P * 3 * t.shape[-2] * t.shape[-1], (tuple(t.shape), self.P)
         crops = tuple(A_crop.shape[-2:]) + tuple(B_crop.shape[-2:])
         if crops != self._cur_crops:   # per-step random crop sizes (data/transforms.py:21-22)
             _lib.check(_lib.lib().splice_step_set_crops(self.handle, *crops), "step_set_crops")
             self._cur_crops = crops
+        entire = self.plan_e is not None and self.step_idx % self.cfg["entire_A_every"] == 0
         if A_entire is not None:
-            assert A_entire.is_cuda and A_entire.is_contiguous() and A_entire.numel() == 3 * self.entire_hw[0] * self.entire_hw[1]
+            assert A_entire.is_cuda and A_entire.is_contiguous() and A_entire.numel() == self.P * 3 * self.entire_hw[0] * self.entire_hw[1]
         _lib.check(_lib.lib().splice_step_run(self.handle, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.m), _lib.ptr(self.v),
                                               _lib.ptr(A_crop), _lib.ptr(B_crop), _lib.ptr(A_entire), self.step_idx,
                                               _lib.ptr(self.losses_dev), _lib.current_stream()), "step_run")
+        self.generator_calls += 3 if entire else 2   # models/model.py:15-23: G(A_global) [, G(A)], G(B_global)
         return self.losses_dev
 
-    def losses(self):
-        """Host dict of the last step's losses, with the reference's keys (inactive terms omitted)."""
-        vals = self.losses_dev.cpu().tolist()
+    def losses(self, pair=None):
+        """Host dict(s) of the last step's losses with the reference's keys (inactive terms omitted): one dict for ``pair``,
+        a list over the pairs for ``pair=None``."""
+        rows = self.losses_dev.cpu().tolist()
         c, s = self.cfg, self.step_idx
         on = s >= c["cls_warmup"]
         ent = self.plan_e is not None and s % c["entire_A_every"] == 0
         active = {"loss": True, "loss_global_ssim": on and c["lambda_global_ssim"] > 0, "loss_entire_ssim": ent and c["lambda_entire_ssim"] > 0,
                   "loss_entire_cls": ent and c["lambda_entire_cls"] > 0, "loss_global_cls": c["lambda_global_cls"] > 0,
                   "loss_global_id_B": on and c["lambda_global_identity"] > 0}
-        return {k: vals[i] for i, k in enumerate(LOSS_KEYS) if active[k]}
+        dicts = [{k: vals[i] for i, k in enumerate(LOSS_KEYS) if active[k]} for vals in rows]
+        return dicts if pair is None else dicts[pair]
 
-    def generate(self, img):
-        """netG(img) under no_grad (the logging forward of train.py:70-73); img ``[1,3,H,W]``."""
+    def pair_params(self, pair=0):
+        """View of one pair's parameter arena (``numel`` floats)."""
+        return self.params[pair * self.stride: pair * self.stride + self.gen.numel]
+
+    def pair_grads(self, pair=0):
+        return self.grads[pair * self.stride: pair * self.stride + self.gen.numel]
+
+    def generate(self, img, pair=0, track_running_stats=False):
+        """netG_pair(img) under no_grad (the logging forward of train.py:70-73); img ``[n,3,H,W]``.  The reference's net
+        is in train mode there too, so the call also moves the BatchNorm running statistics: pass
+        ``track_running_stats=True`` to book that (train_model does, after the step whose forwards precede it)."""
         n, _, h, w = img.shape
-        return self.gen.plan(n, h, w, need_grad=False).forward(self.params, img.contiguous())
+        key = (n, h, w)
+        if key not in self._log_plans:
+            self._log_plans[key] = GeneratorPlan(self.gen, n, h, w, False)
+        plan = self._log_plans[key]
+        out = plan.forward(self.pair_params(pair), img.contiguous())
+        self._last_logged = (plan, pair)
+        if track_running_stats:
+            self.book_running_stats(plan, pair)
+        return out
 
-    def state_dict(self):
-        return {k: v.clone() for k, v in self.gen.unflatten(self.params).items()}
+    def book_logged_forward(self):
+        """Book the BatchNorm statistics of the last ``generate()`` call NOW: the reference's logging forward sits between
+        the step's generator calls and the optimizer update (train.py:70-79), so ``train_model`` generates with the
+        pre-update weights BEFORE the fused step and books the statistics AFTER it -- the reference's buffer order."""
+        plan, pair = self._last_logged
+        self.book_running_stats(plan, pair)
+
+    def book_running_stats(self, plan, pair=0):
+        plans = (C.c_void_p * 1)(plan.handle)
+        _lib.check(_lib.lib().splice_gen_running_stats_update(plans, 1, _lib.ptr(self.running[pair]), 0, 0.1, _lib.current_stream()), "running_stats_update")
+        self.generator_calls += plan.N
+
+    def state_dict(self, pair=0):
+        """``netG.state_dict()`` of one pair: parameters, BatchNorm running statistics and ``num_batches_tracked``."""
+        out = {k: v.clone() for k, v in self.gen.unflatten(self.pair_params(pair)).items()}
+        for name, (off, cnt) in self.gen.buffer_table.items():
+            out[name] = self.running[pair, off:off + cnt].clone()
+            if name.endswith("running_var"):
+                out[name[:-len("running_var")] + "num_batches_tracked"] = torch.tensor(self.generator_calls, dtype=torch.long, device=self.device)
+        return out
 
 
-def GeneratorPlanAlias(gen, hw):
-    """A second, independent N=1 plan of the same maximum size (the plan cache is keyed by shape)."""
-    from .generator import GeneratorPlan
-    return GeneratorPlan(gen, 1, hw[0], hw[1], True)
+class SpliceEngine(MultiPairEngine):
+    """The per-pair optimisation loop of ``train.py:34-80`` for ONE pair (P = 1): the reference's unit of work."""
+
+    def __init__(self, cfg, vit_state, gen_state, crop_hw, entire_hw=None, device="cuda", vit_engine=None):
+        super().__init__(cfg, vit_state, [gen_state], crop_hw, entire_hw, device=device, vit_engine=vit_engine)
+
+    def losses(self):
+        return super().losses(0)
 
 
-def synthetic_engine(cfg, pair_id=0, hw=(224, 224), seed=1234, device="cuda", vit_engine=None, entire=True):
-    """Engine + inputs for the BASELINE benchmark configs: seeded synthetic ViT weights,
-    xavier generator init and a U[0,1) pair."""
+def synthetic_engine(cfg, pair_id=0, hw=(224, 224), seed=1234, device="cuda", vit_engine=None, entire=True, pairs=1):
+    """Engine + inputs for the BASELINE benchmark configs: seeded synthetic ViT weights, xavier generator init and U[0,1)
+    pairs.  ``pairs`` > 1: pairs ``pair_id .. pair_id + pairs - 1`` side by side on one engine
+    (inputs ``[P,3,h,w]``); ``pairs == 1``: the single-pair ``SpliceEngine`` with ``[3,h,w]`` inputs."""
     c = dict(DEFAULT_CFG, **cfg)
     P = c["dino_global_patch_size"]
     vit_state = None
     if vit_engine is None:
         vit_state = synth.vit_params(seed, c["dino_model_name"], img_size=P)
-    gen_state = synth.generator_params(seed + 1 + pair_id, c["init_gain"])
-    A, B = synth.image_pair(seed, pair_id, hw[0], hw[1])
-    eng = SpliceEngine(c, vit_state, gen_state, hw, hw if entire else None, device=device, vit_engine=vit_engine)
-    A = torch.from_numpy(A).to(device)
-    B = torch.from_numpy(B).to(device)
+    ids = [pair_id + k for k in range(pairs)]
+    gen_states = [synth.generator_params(seed + 1 + i, c["init_gain"]) for i in ids]
+    imgs = [synth.image_pair(seed, i, hw[0], hw[1]) for i in ids]
+    if pairs == 1:
+        eng = SpliceEngine(c, vit_state, gen_states[0], hw, hw if entire else None, device=device, vit_engine=vit_engine)
+        return eng, torch.from_numpy(imgs[0][0]).to(device), torch.from_numpy(imgs[0][1]).to(device)
+    eng = MultiPairEngine(c, vit_state, gen_states, hw, hw if entire else None, device=device, vit_engine=vit_engine)
+    A = torch.from_numpy(np.stack([a for a, _ in imgs])).to(device)
+    B = torch.from_numpy(np.stack([b for _, b in imgs])).to(device)
     return eng, A, B

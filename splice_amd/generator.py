@@ -22,6 +22,13 @@ class GeneratorEngine:
             name, off, n = C.c_char_p(), C.c_longlong(), C.c_longlong()
             _lib.check(L.splice_gen_tensor_info(h, i, C.byref(name), C.byref(off), C.byref(n)))
             self.table[name.value.decode()] = (off.value, n.value)
+        # BatchNorm buffers of netG.state_dict(): "<bn>.running_mean" / "<bn>.running_var" -> (offset, numel) in the buffer arena
+        self.buffer_numel = L.splice_gen_buffer_count(h)
+        self.buffer_table = OrderedDict()
+        for i in range(L.splice_gen_num_buffers(h)):
+            name, off, n = C.c_char_p(), C.c_longlong(), C.c_longlong()
+            _lib.check(L.splice_gen_buffer_info(h, i, C.byref(name), C.byref(off), C.byref(n)))
+            self.buffer_table[name.value.decode()] = (off.value, n.value)
         self._plans = {}
 
     def __del__(self):
@@ -57,11 +64,15 @@ class GeneratorEngine:
 
 
 class GeneratorPlan:
-    def __init__(self, engine, N, H, W, need_grad):
-        self.engine, self.N, self.H, self.W, self.need_grad = engine, N, H, W, need_grad
+    def __init__(self, engine, N, H, W, need_grad, arena_stride=0):
+        """``arena_stride`` > 0: the N images are INDEPENDENT generators -- image n uses ``params[n * stride:]`` and its
+        gradient goes to ``grads[n * stride:]`` (several pairs in one launch); 0: one generator applied to N images."""
+        self.engine, self.N, self.H, self.W, self.need_grad, self.arena_stride = engine, N, H, W, need_grad, arena_stride
         h = C.c_void_p()
         _lib.check(_lib.lib().splice_gen_plan_create(engine.handle, N, H, W, int(need_grad), C.byref(h)), "gen_plan_create")
         self.handle = h
+        if arena_stride:
+            _lib.check(_lib.lib().splice_gen_plan_set_arena_stride(h, arena_stride), "gen_plan_set_arena_stride")
 
     def __del__(self):
         try:
@@ -80,7 +91,7 @@ class GeneratorPlan:
     def backward(self, params, dy, grads=None, accumulate=False):
         assert dy.is_cuda and dy.dtype == torch.float32 and dy.is_contiguous() and tuple(dy.shape) == (self.N, 3, self.H, self.W)
         if grads is None:
-            grads = torch.zeros(self.engine.numel, device=self.engine.device)
+            grads = torch.zeros(self.N * self.arena_stride if self.arena_stride else self.engine.numel, device=self.engine.device)
         _lib.check(_lib.lib().splice_gen_backward(self.handle, _lib.ptr(params), _lib.ptr(dy), _lib.ptr(grads), int(accumulate),
                                                   _lib.current_stream()), "gen_backward")
         return grads

@@ -25,6 +25,8 @@ class _GenFn(torch.autograd.Function):
     def forward(ctx, x, net, need_grad, *params):
         plan = net._acquire(x.shape[0], x.shape[2], x.shape[3], need_grad)
         y = plan.forward(net.flat, x.contiguous().float())
+        if net.training:
+            net._track_running_stats(plan)
         ctx.net, ctx.plan, ctx.need_grad = net, plan, need_grad
         if not need_grad:
             net._release(plan)
@@ -52,7 +54,12 @@ class SkipGenerator(nn.Module):
         self.engine = GeneratorEngine(device=dev)
         from .synth import generator_param_specs
         self.flat = torch.zeros(self.engine.numel, device=dev)
+        # BatchNorm buffers (nn.BatchNorm2d keeps them in state_dict; train mode moves them with momentum 0.1 and nothing
+        # ever reads them): views of one flat arena the engine updates in ONE launch per forward
+        self.running = torch.zeros(self.engine.buffer_numel, device=dev)
+        self._batches = torch.zeros(len(self.engine.buffer_table) // 2, dtype=torch.long, device=dev)
         self._plist, self._slices, self._kinds = [], [], {}
+        self._bn_names = []
         for name, shape, kind in generator_param_specs():
             off, n = self.engine.table[name]
             p = nn.Parameter(self.flat[off:off + n].view(shape))
@@ -62,9 +69,13 @@ class SkipGenerator(nn.Module):
             self._kinds[name] = kind
             if kind == "bn_w":   # BatchNorm buffers exist in the reference state_dict (never consumed: train mode)
                 base = name[:-len(".weight")]
-                self._register_buffer(base + ".running_mean", torch.zeros(shape, device=dev))
-                self._register_buffer(base + ".running_var", torch.ones(shape, device=dev))
-                self._register_buffer(base + ".num_batches_tracked", torch.zeros((), dtype=torch.long, device=dev))
+                off, cnt = self.engine.buffer_table[base + ".running_mean"]
+                self._register_buffer(base + ".running_mean", self.running[off:off + cnt])
+                off, cnt = self.engine.buffer_table[base + ".running_var"]
+                self.running[off:off + cnt] = 1.0
+                self._register_buffer(base + ".running_var", self.running[off:off + cnt])
+                self._register_buffer(base + ".num_batches_tracked", self._batches[len(self._bn_names)])
+                self._bn_names.append(base)
         self._free = {}
 
     def _walk(self, dotted):
@@ -94,11 +105,23 @@ class SkipGenerator(nn.Module):
     def _release(self, plan):
         self._free.setdefault((plan.N, plan.H, plan.W, bool(plan.need_grad)), []).append(plan)
 
+    def _track_running_stats(self, plan):
+        import ctypes as C
+        from . import _lib
+        plans = (C.c_void_p * 1)(plan.handle)
+        _lib.check(_lib.lib().splice_gen_running_stats_update(plans, 1, _lib.ptr(self.running), 0, 0.1, _lib.current_stream()), "running_stats_update")
+        self._batches += 1
+
     def forward(self, x):
-        """x ``[N,3,H,W]`` in [0,1]; each image is an independent batch-1 call (per-image BN statistics),
-        exactly what the reference does by calling netG once per crop."""
+        """x ``[1,3,H,W]`` in [0,1].  The engine's BatchNorm takes its statistics per image, which IS the reference for the
+        batch-1 calls it makes with the default ``n_crops = 1`` (models/model.py:15-23).  A batch of several crops would be
+        normalised over the whole batch by the reference's ``nn.BatchNorm2d`` -- different numbers -- so it is refused here
+        rather than silently computed per image; call the generator once per image."""
         if not x.is_cuda:
             raise RuntimeError("SkipGenerator: input must be on the GPU")
+        if x.shape[0] != 1:
+            raise NotImplementedError("SkipGenerator: batch > 1 is normalised over the batch by the reference's BatchNorm; the HIP "
+                                      "engine normalises per image -- call it once per image (the reference default n_crops = 1 does)")
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._plist)
         return _GenFn.apply(x, self, need_grad, *self._plist)
 

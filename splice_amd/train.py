@@ -125,14 +125,19 @@ def train_model(dataroot, callback=None, cfg_overrides=None, vit_state=None, pro
     try:
         for epoch in range(1, cfg['n_epochs'] + 1):
             inputs = feed.next()
-            engine.step(inputs['A_global'], inputs['B_global'], inputs.get('A', [None])[0] if 'A' in inputs else None)
-            if progress and (epoch % 50 == 0 or epoch == 1):
-                print(f"Epoch {epoch}: loss={engine.losses()['loss']:.4f} lr={cfg['lr']}")
-            if epoch % cfg['log_images_freq'] == 0:
+            log = epoch % cfg['log_images_freq'] == 0
+            if log:
+                # train.py:70-76 generates the logged image between the loss and backward(): with the weights of epoch - 1
+                # updates.  The fused step updates in place, so the image is generated BEFORE it (same weights) ...
                 output = engine.generate(feed.get_A())
+            engine.step(inputs['A_global'], inputs['B_global'], inputs['A'][0] if 'A' in inputs else None)
+            if log:
+                engine.book_logged_forward()   # ... and its BatchNorm bookkeeping lands AFTER the step's, as in the reference
                 writer.submit(output[0])
                 if callback is not None:
                     callback(output[0])
+            if progress and (epoch % 50 == 0 or epoch == 1):
+                print(f"Epoch {epoch}: loss={engine.losses()['loss']:.4f} lr={cfg['lr']}")
     finally:
         writer.close()
     return engine
