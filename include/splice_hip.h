@@ -230,6 +230,10 @@ int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams)
  * runs train.py once per pair): image n reads params + n*stride, its gradient goes to grads + n*stride, BatchNorm and
  * launch policies are per image -- a pair's result is bit-identical to its N = 1 run.  0 (default): one generator. */
 int splice_gen_plan_set_arena_stride(void* plan, long long stride);
+/* on != 0: the plan is ONE netG call on a batch of N <= 8 images (n_crops > 1: models/model.py:15, data/transforms.py:19-27):
+ * BatchNorm statistics over the whole batch as nn.BatchNorm2d takes them; gradients summed over the images.  Default 0:
+ * N separate batch-1 calls. */
+int splice_gen_plan_set_batch_stats(void* plan, int on);
 /* re-target a plan to a smaller input without reallocating (per-step random crop sizes,
  * data/transforms.py:21-22) */
 int splice_gen_plan_resize(void* plan, int H, int W);
@@ -252,6 +256,10 @@ typedef struct splice_step_config {
     int pairs;                   /* P (0 or 1: one pair) */
     long long arena_stride;      /* P > 1: floats between the pairs' parameter / gradient / Adam-moment arenas (>= param count);
                                   * the generator plans must have been given the same stride (splice_gen_plan_set_arena_stride) */
+    int n_crops;                 /* > 1 (with pairs <= 1): global_{A,B}_crops_n_crops of conf/default/config.yaml -- the step works on
+                                  * n_crops crops of ONE pair: A_crop / B_crop are [n_crops][3][h][w], the generator plans hold n_crops
+                                  * images in batch-statistics mode (splice_gen_plan_set_batch_stats: netG sees the stacked crops,
+                                  * data/transforms.py:27), each loss term is summed over the crops (util/losses.py:75-105), one arena */
 } splice_step_config;
 /* gen_plan_a / gen_plan_b: N = P plans at the crop size for the A and the B crops; gen_plan_entire: N = P at the entire size
  * (NULL with ent_h == 0).  Contexts: need_grad, B = 4P / 2P. */
@@ -277,6 +285,10 @@ int splice_step_use_overlap(void* step, int on);
 /* per-step crop sizes (<= creation size) of the A and the B crops (the reference draws them independently,
  * data/Dataset.py:66-67); shared by all pairs of the batch */
 int splice_step_set_crops(void* step, int a_h, int a_w, int b_h, int b_w);
+/* skip_adam != 0: stop after backward -- `grads` = gradient of this step's loss (+= previous content when accumulate != 0),
+ * parameters untouched; several losses (the same crops at several ViT input scales) are summed that way before ONE
+ * splice_adam_step */
+int splice_step_set_mode(void* step, int skip_adam, int accumulate);
 /* BatchNorm running statistics of netG (models/unet/common.py:95-96, momentum 0.1): when `running` is set every step
  * applies the updates of its generator calls in the reference's order (A_global, A on entire steps, B_global) to the
  * caller's buffer arena(s): layout splice_gen_buffer_info, pair p at running + p * stride.  NULL = not tracked. */

@@ -35,7 +35,7 @@ class StepConfig(C.Structure):
         ("lambda_entire_cls", C.c_float), ("lambda_entire_ssim", C.c_float),
         ("entire_every", C.c_int), ("cls_warmup", C.c_int),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-        ("pairs", C.c_int), ("arena_stride", C.c_longlong),
+        ("pairs", C.c_int), ("arena_stride", C.c_longlong), ("n_crops", C.c_int),
     ]
 
 
@@ -107,12 +107,14 @@ _SIGNATURES = {
     "splice_step_output": ([_vp, _i, C.POINTER(_vp)], _i),
     "splice_step_set_crops": ([_vp, _i, _i, _i, _i], _i),
     "splice_step_set_running_stats": ([_vp, _vp, C.c_longlong], _i),
+    "splice_step_set_mode": ([_vp, _i, _i], _i),
     "splice_gen_buffer_count": ([_vp], C.c_longlong),
     "splice_gen_num_buffers": ([_vp], _i),
     "splice_gen_buffer_info": ([_vp, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], _i),
     "splice_gen_running_stats_update": ([C.POINTER(_vp), _i, _vp, C.c_longlong, _f, _vp], _i),
     "splice_gen_plan_resize": ([_vp, _i, _i], _i),
     "splice_gen_plan_set_arena_stride": ([_vp, C.c_longlong], _i),
+    "splice_gen_plan_set_batch_stats": ([_vp, _i], _i),
 }
 
 

@@ -201,6 +201,19 @@ def global_crop_box(h, w, min_cover):
     return top, left, size
 
 
+def global_crop_boxes(h, w, min_cover, n_crops):
+    """``Global_crops.forward`` with ``n_crops`` crops (data/transforms.py:19-27): ONE size draw, then one RandomCrop position
+    per crop.  Returns (size, [(top, left), ...])."""
+    size = min(int(round(np.random.uniform(min_cover * h, h))), w)
+    boxes = []
+    for _ in range(n_crops):
+        if size == h and size == w:
+            boxes.append((0, 0))
+        else:
+            boxes.append((int(torch.randint(0, h - size + 1, (1,)).item()), int(torch.randint(0, w - size + 1, (1,)).item())))
+    return size, boxes
+
+
 def blur_sigma_to_weights(sigma):
     """(centre, side) weights of the 1-D kernel -- handy closed form for tests."""
     e = math.exp(-0.5 / (sigma * sigma))

@@ -72,6 +72,7 @@ struct SpliceGenPlan {
     SpliceGen* gen = nullptr;
     int N = 0, H = 0, W = 0, need_grad = 0, maxH = 0, maxW = 0;
     size_t p_nstride = 0;                 // > 0: the N images are independent generators -- image n uses params / grads + n * p_nstride
+    int batch_stats = 0;                  // != 0: ONE netG call on a batch of N images -- BatchNorm statistics over the whole batch
     int h[6], w[6];                       // spatial size at scale i (h[0] = H)
     std::vector<void*> allocs;
     // per scale
@@ -219,7 +220,7 @@ static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* para
         a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2;
         a.ws = p->conv_ws; a.ws_floats = p->conv_ws_floats;
         // small planes: a split-K convolution leaves its slabs for the BatchNorm kernel, which adds them while it loads the plane
-        a.defer_reduce = u.Ho * u.Wo <= bn_small_hw();
+        a.defer_reduce = !p->batch_stats && u.Ho * u.Wo <= bn_small_hw();
         int ksplit = 1;
         RC(conv_launch(a, s, &ksplit));
         y = u.y; y_ns = u.y_ns;
@@ -229,8 +230,12 @@ static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* para
             return SPLICE_OK;
         }
     }
+    if (p->batch_stats && up) {   // batch statistics: the upsampled channels are materialised first (no fusion with the statistics pass)
+        RC(upsample2x_fwd_launch(up->src, up->src_ns, const_cast<float*>(y) + (size_t)up->c0 * u.Ho * u.Wo, y_ns, N, u.Cout - up->c0, up->h, up->w, up->Ho, up->Wo, s));
+        up = nullptr;
+    }
     RC(bn_fwd_launch(y, y_ns, u.out, u.out_ns, N, u.Cout, u.Ho * u.Wo, params + u.g_off, params + u.be_off, BN_EPS, u.s1, u.mean, u.rstd, u.slope, s, up,
-                     p->p_nstride));
+                     p->p_nstride, p->batch_stats));
     return SPLICE_OK;
 }
 
@@ -243,7 +248,7 @@ static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* par
     float* dy = u.ks ? u.dy : u.d_in;          // BN-only unit: dy IS the input gradient
     const size_t dy_ns = u.ks ? u.y_ns : u.d_in_ns;
     RC(bn_bwd_launch(u.d_out, u.d_out_ns, u.out, u.out_ns, y, y_ns, dy, dy_ns, N, u.Cout, HW, params + u.g_off, u.mean, u.rstd, u.slope,
-                     u.s1, grads + u.g_off, grads + u.be_off, acc, s, up, p->p_nstride));
+                     u.s1, grads + u.g_off, grads + u.be_off, acc, s, p->batch_stats ? nullptr : up, p->p_nstride, p->batch_stats));
     if (!u.ks) return SPLICE_OK;
     // The bias of a conv that feeds a train-mode BatchNorm has an analytically ZERO gradient (BN subtracts the
     // per-channel mean, sum_p dy = 0); the reference's autograd returns fp32 rounding noise there.  We write the
@@ -395,6 +400,19 @@ int splice_gen_plan_set_arena_stride(void* plan, long long stride) {
     return SPLICE_OK;
 }
 
+// on != 0: the plan stands for ONE netG call on a batch of N images (netG(A_global) with n_crops > 1 crops, models/model.py:15
+// + data/transforms.py:19-27): train-mode BatchNorm takes its statistics over the whole batch (N <= 8), gradients are
+// summed over the images.  0 (default): N separate batch-1 calls (per-image statistics).
+int splice_gen_plan_set_batch_stats(void* plan, int on) {
+    SpliceGenPlan* p = (SpliceGenPlan*)plan;
+    if (!p || (on && (p->N > 8 || p->p_nstride))) {
+        splice_set_error("splice_gen_plan_set_batch_stats: batch statistics need N <= 8 images of one generator");
+        return SPLICE_ERR_ARG;
+    }
+    p->batch_stats = on ? 1 : 0;
+    return SPLICE_OK;
+}
+
 int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams) {
     SpliceGenPlan* p = (SpliceGenPlan*)plan;
     if (!p) return SPLICE_ERR_ARG;
@@ -428,13 +446,13 @@ int splice_gen_running_stats_update(void* const* plans, int n_plans, float* runn
     for (int k = 0; k < n_plans; ++k) {
         SpliceGenPlan* p = (SpliceGenPlan*)plans[k];
         if (!p) return SPLICE_ERR_ARG;
-        t.N[k] = p->N; t.indep[k] = p->p_nstride ? 1 : 0;
+        t.N[k] = p->batch_stats ? 1 : p->N; t.indep[k] = p->p_nstride ? 1 : 0;   // a batch call is ONE update with the batch statistics
         if (t.indep[k] && p->N > max_images) max_images = p->N;
         int bn = 0;
         for (int i = 0; i < 5; ++i)
             for (Unit* u : {&p->u_skip[i], &p->u_da[i], &p->u_db[i], &p->u_cat[i], &p->u_up3[i], &p->u_up1[i]}) {
                 if (k == 0) { t.C[bn] = u->Cout; t.r_off[bn] = (int)u->r_off; }
-                t.HW[k][bn] = u->Ho * u->Wo; t.mean[k][bn] = u->mean; t.rstd[k][bn] = u->rstd;
+                t.HW[k][bn] = u->Ho * u->Wo * (p->batch_stats ? p->N : 1); t.mean[k][bn] = u->mean; t.rstd[k][bn] = u->rstd;
                 ++bn;
             }
     }
@@ -523,7 +541,7 @@ static int scale_backward(SpliceGenPlan* p, int i, const float* params, float* g
     BnUpsample up;
     up.d_src = deep.d_out; up.d_src_ns = deep.d_out_ns; up.c0 = SKIPC; up.h = p->h[i + 1]; up.w = p->w[i + 1]; up.Ho = hi; up.Wo = wi;
     RC(unit_backward(p, p->u_cat[i], params, grads, acc, s, &up));   // -> d_cat[i]
-    if (!bn_bwd_fuses_upsample(hi * wi, up.h, up.w))
+    if (p->batch_stats || !bn_bwd_fuses_upsample(hi * wi, up.h, up.w))
         RC(upsample2x_bwd_launch(p->d_cat[i] + (size_t)SKIPC * hi * wi, p->u_skip[i].d_out_ns, deep.d_out, deep.d_out_ns, p->N, p->kch[i],
                                  p->h[i + 1], p->w[i + 1], hi, wi, s));
     if (i < 4) RC(scale_backward(p, i + 1, params, grads, acc, s));   // leaves d x_{i+1} in u_db[i].d_out

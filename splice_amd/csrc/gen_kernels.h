@@ -72,7 +72,7 @@ struct BnUpsample {
 bool bn_bwd_fuses_upsample(int HW, int h, int w);
 int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
                   const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s, const BnUpsample* up = nullptr,
-                  size_t p_nstride = 0);
+                  size_t p_nstride = 0, int batch = 0);   // batch != 0: statistics over all N images (nn.BatchNorm2d on a batch), N <= 8
 // same, fused with the split-K reduction of the convolution that feeds it (small planes only: HW <= bn_small_hw()):
 // y = bias + sum_k slabs[k] is formed, stored (the backward reads it) and normalised in one launch
 int bn_small_hw();
@@ -81,7 +81,8 @@ int bn_fwd_slabs_launch(const float* slabs, int ksplit, const float* bias, float
                         size_t p_nstride = 0);
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
-                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up = nullptr, size_t p_nstride = 0);
+                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up = nullptr, size_t p_nstride = 0,
+                  int batch = 0);
 int fill_zero_launch(float* p, int n, hipStream_t s);
 int channel_sum_launch(const float* dy, size_t nstride, int N, int C, int HW, float* db, int accumulate, hipStream_t s);
 int upsample2x_fwd_launch(const float* in, size_t in_nstride, float* out, size_t out_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s);

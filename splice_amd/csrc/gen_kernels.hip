@@ -627,7 +627,14 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* y, s
 // Chan et al. pairwise combination of the <= 64 segment statistics by ONE wave: lane b holds segment b, a fixed
 // binary tree (lane l absorbs lane l + off, off = 32 .. 1) leaves the plane's (mean, M2) in lane 0.  Deterministic, and
 // ~100 cycles instead of a 49-step dependent chain in front of every workgroup of the apply kernel.
+__device__ __forceinline__ void bn_combine_wave_raw(const float* part, int PB, int HW, float& mean, float& M2out);
 __device__ __forceinline__ void bn_combine_wave(const float* part, int PB, int HW, float eps, float& mean, float& rstd) {
+    float M2;
+    bn_combine_wave_raw(part, PB, HW, mean, M2);
+    rstd = rsqrtf(M2 / (float)HW + eps);
+}
+// (mean, M2) of one plane from its <= 64 segment statistics; every lane returns lane 0's result
+__device__ __forceinline__ void bn_combine_wave_raw(const float* part, int PB, int HW, float& mean, float& M2out) {
     const int lane = threadIdx.x & 63;
     const int seg = seg_len(HW, PB), lo = lane * seg;
     int cnt = lane < PB ? min(lo + seg, HW) - lo : 0;
@@ -644,21 +651,38 @@ __device__ __forceinline__ void bn_combine_wave(const float* part, int PB, int H
             n = nt;
         }
     }
+    mean = __shfl(m, 0, 64);
+    M2out = __shfl(M2, 0, 64);
+}
+// batch statistics (nn.BatchNorm2d over a batch of N images, models/unet/common.py:95-96 when netG is fed n_crops > 1
+// crops at once): Chan merge of the N planes' (mean, M2) in image order
+__device__ __forceinline__ void bn_combine_batch(const float* part_c0 /* image 0, channel c */, size_t img_stride, int N, int PB, int HW, float eps,
+                                                 float& mean, float& rstd) {
+    float n = 0.f, m = 0.f, M2 = 0.f;
+    for (int i = 0; i < N; ++i) {
+        float mb, Mb;
+        bn_combine_wave_raw(part_c0 + (size_t)i * img_stride, PB, HW, mb, Mb);
+        const float nb = (float)HW, nt = n + nb, d = mb - m, w = nb / nt;
+        m += d * w;
+        M2 += Mb + d * d * n * w;
+        n = nt;
+    }
     mean = m;
-    rstd = rsqrtf(M2 / (float)HW + eps);
+    rstd = rsqrtf(M2 / n + eps);
 }
 
 // stage 2 + apply: a = act(gamma * (y - mean) * rstd + beta), written to a channel slice of `out`
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y, size_t y_nstride, float* __restrict__ out,
                                                      size_t out_nstride, int C, int HW, int PB, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, const float* __restrict__ part, float eps,
-                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o, float slope, size_t p_nstride) {
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o, float slope, size_t p_nstride, int batch) {
     __shared__ float st[2];
     const int c = blockIdx.y, img = blockIdx.z;
     gamma += (size_t)img * p_nstride; beta += (size_t)img * p_nstride;
     if (threadIdx.x < 64) {
         float m, r;
-        bn_combine_wave(part + ((size_t)img * C + c) * PB * 2, PB, HW, eps, m, r);
+        if (batch) bn_combine_batch(part + (size_t)c * PB * 2, (size_t)C * PB * 2, gridDim.z, PB, HW, eps, m, r);
+        else bn_combine_wave(part + ((size_t)img * C + c) * PB * 2, PB, HW, eps, m, r);
         if (threadIdx.x == 0) {
             st[0] = m; st[1] = r;
             if (blockIdx.x == 0) { mean_o[img * C + c] = m; rstd_o[img * C + c] = r; }
@@ -708,7 +732,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dy, size_t dy_nstride, int C, int HW, int N, int PB,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, float slope, const float* __restrict__ part,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, size_t p_nstride) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, size_t p_nstride, int batch) {
     __shared__ float st[2];
     const int c = blockIdx.y, img = blockIdx.z;
     gamma += (size_t)img * p_nstride;
@@ -738,9 +762,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             }
         }
     }
+    if (batch && threadIdx.x < 64) {   // batch statistics: the two sums run over every image of the batch (image order)
+        const int lane = threadIdx.x;
+        float a = 0.f, b = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float* pn = part + ((size_t)n * C + c) * PB * 2;
+            a += wave_sum(lane < PB ? pn[2 * lane] : 0.f);
+            b += wave_sum(lane < PB ? pn[2 * lane + 1] : 0.f);
+        }
+        if (lane == 0) { st[0] = a; st[1] = b; }
+    }
     __syncthreads();
     const float m = mean[img * C + c], r = rstd[img * C + c];
-    const float k1 = st[0] / (float)HW, k2 = st[1] / (float)HW;
+    const float cnt = batch ? (float)HW * (float)N : (float)HW;
+    const float k1 = st[0] / cnt, k2 = st[1] / cnt;
     const float gr = gamma[c] * r;
     const float* pd = da + (size_t)img * da_nstride + (size_t)c * HW;
     const float* pa = aout + (size_t)img * a_nstride + (size_t)c * HW;
@@ -771,6 +806,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 // (image, channel) plane, so statistics + apply are a single launch (the plane is re-read from L1/L2).  These layers are
 // pure launch latency -- a kernel boundary costs more than the work.
 constexpr int BN_SMALL_HW = 4096;
+constexpr int BN_MAX_BATCH = 8;               // images per batch-statistics call (n_crops)
 constexpr int BN_SMALL_PER = BN_SMALL_HW / 256;   // plane elements a thread keeps in registers
 constexpr int BN_UP_SRC = 34 * 34;            // low-resolution plane of a fused upsampling staged in LDS (else read from global)
 // slabs != null: the plane is first formed as bias + sum of the feeding convolution's split-K slabs (slice order) and stored to y
@@ -779,7 +815,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
                                                            const float* __restrict__ beta, float eps, float* __restrict__ mean_o,
                                                            float* __restrict__ rstd_o, float slope, const float* __restrict__ slabs,
                                                            int ksplit, const float* __restrict__ bias, float* __restrict__ y_out, BnUpsample up,
-                                                           size_t p_nstride) {
+                                                           size_t p_nstride, int batch) {
     __shared__ float red[8];
     __shared__ float up_src_s[BN_UP_SRC];
     const int c = blockIdx.x, img = blockIdx.y;
@@ -864,16 +900,48 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
         }
     }
     block_sum2(s, dummy, red);
-    const float m = s / (float)HW;
+    float m = s / (float)HW;
     float sq = 0.f;
     dummy = 0.f;
+    float cnt = (float)HW;
+    if (batch) {
+        // batch statistics: every workgroup of channel c walks all N planes in image order (same bits in each); the other
+        // planes are re-read (small, L2-resident); slabs / fused upsampling are not combined with this mode
+        const int N = gridDim.y;
+        float tot = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const float* pn = y + (size_t)n * y_nstride + (size_t)c * HW;
+            float sn = 0.f, d2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < BN_SMALL_PER; ++k) {
-        const float d = threadIdx.x + k * 256 < HW ? v[k] - m : 0.f;
-        sq += d * d;
+            for (int k = 0; k < BN_SMALL_PER; ++k) {
+                const int i = threadIdx.x + k * 256;
+                if (k * 256 < HW) sn += i < HW ? pn[i] : 0.f;
+            }
+            block_sum2(sn, d2, red);
+            tot += sn;
+        }
+        cnt = (float)HW * (float)N;
+        m = tot / cnt;
+        for (int n = 0; n < N; ++n) {
+            const float* pn = y + (size_t)n * y_nstride + (size_t)c * HW;
+            float qn = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < BN_SMALL_PER; ++k) {
+                const int i = threadIdx.x + k * 256;
+                if (k * 256 < HW) { const float d = i < HW ? pn[i] - m : 0.f; qn += d * d; }
+            }
+            block_sum2(qn, d2, red);
+            sq += qn;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < BN_SMALL_PER; ++k) {
+            const float d = threadIdx.x + k * 256 < HW ? v[k] - m : 0.f;
+            sq += d * d;
+        }
+        block_sum2(sq, dummy, red);
     }
-    block_sum2(sq, dummy, red);
-    const float r = rsqrtf(sq / (float)HW + eps);
+    const float r = rsqrtf(sq / cnt + eps);
     if (threadIdx.x == 0) { mean_o[img * C + c] = m; rstd_o[img * C + c] = r; }
     const float sc = gamma[c] * r;
     const float sh = beta[c] - m * sc;
@@ -925,7 +993,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
                                                            float* __restrict__ dy, size_t dy_nstride, int C, int HW, int N,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, float slope, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int accumulate, BnUpsample up, size_t p_nstride) {
+                                                           float* __restrict__ dbeta, int accumulate, BnUpsample up, size_t p_nstride, int batch) {
     __shared__ float red[8];
     __shared__ float up_grad_s[BN_SMALL_HW];   // fused upsampling adjoint: this plane's input gradient
     const int c = blockIdx.x, img = blockIdx.y;
@@ -934,9 +1002,28 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
     float s1, s2;
     {
         const float m = mean[img * C + c], r = rstd[img * C + c];
-        bn_small_bwd_sums(da + (size_t)img * da_nstride + (size_t)c * HW, aout + (size_t)img * a_nstride + (size_t)c * HW,
-                          y + (size_t)img * y_nstride + (size_t)c * HW, HW, m, r, slope, dz, xh, s1, s2, red);
-        const float k1 = s1 / (float)HW, k2 = s2 / (float)HW;
+        float b1 = 0.f, b2 = 0.f;   // batch statistics: sums over every image of the batch, in image order; the own plane last (dz / xh stay)
+        if (batch) {
+            float t1s[BN_MAX_BATCH], t2s[BN_MAX_BATCH];
+#pragma unroll
+            for (int n = 0; n < BN_MAX_BATCH; ++n) {
+                t1s[n] = 0.f; t2s[n] = 0.f;
+                if (n < N && n != img)
+                    bn_small_bwd_sums(da + (size_t)n * da_nstride + (size_t)c * HW, aout + (size_t)n * a_nstride + (size_t)c * HW,
+                                      y + (size_t)n * y_nstride + (size_t)c * HW, HW, mean[n * C + c], rstd[n * C + c], slope, dz, xh, t1s[n], t2s[n], red);
+            }
+            bn_small_bwd_sums(da + (size_t)img * da_nstride + (size_t)c * HW, aout + (size_t)img * a_nstride + (size_t)c * HW,
+                              y + (size_t)img * y_nstride + (size_t)c * HW, HW, m, r, slope, dz, xh, s1, s2, red);
+#pragma unroll
+            for (int n = 0; n < BN_MAX_BATCH; ++n)
+                if (n < N) { b1 += n == img ? s1 : t1s[n]; b2 += n == img ? s2 : t2s[n]; }
+        } else {
+            bn_small_bwd_sums(da + (size_t)img * da_nstride + (size_t)c * HW, aout + (size_t)img * a_nstride + (size_t)c * HW,
+                              y + (size_t)img * y_nstride + (size_t)c * HW, HW, m, r, slope, dz, xh, s1, s2, red);
+        }
+        const float cnt = batch ? (float)HW * (float)N : (float)HW;
+        const float k1 = (batch ? b1 : s1) / cnt, k2 = (batch ? b2 : s2) / cnt;
+        if (batch) { s1 = b1; s2 = b2; }   // the parameter gradients are exactly these sums
         const float gr = gamma[c] * r;
         float* po = dy + (size_t)img * dy_nstride + (size_t)c * HW;
         const bool through_adjoint = up.d_src && c >= up.c0;   // workgroup-uniform
@@ -968,7 +1055,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
     }
     if (img != 0) return;
     float g = s2, be = s1;
-    for (int n = 1; n < N; ++n) {
+    for (int n = 1; n < (batch ? 0 : N); ++n) {
         float t1, t2;
         bn_small_bwd_sums(da + (size_t)n * da_nstride + (size_t)c * HW, aout + (size_t)n * a_nstride + (size_t)c * HW,
                           y + (size_t)n * y_nstride + (size_t)c * HW, HW, mean[n * C + c], rstd[n * C + c], slope, dz, xh, t1, t2, red);
@@ -985,16 +1072,18 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
 static inline int plane_blocks(int HW) { int b = cdiv(HW, 512); return b < 1 ? 1 : (b > MAX_PB ? MAX_PB : b); }
 int bn_part_floats(int N, int C) { return N * C * MAX_PB * 2; }
 int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
-                  const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s, const BnUpsample* up, size_t p_nstride) {
+                  const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s, const BnUpsample* up, size_t p_nstride,
+                  int batch) {
     const BnUpsample u = up ? *up : BnUpsample{};
+    if (batch && (N > BN_MAX_BATCH || u.src || p_nstride)) return SPLICE_ERR_ARG;
     if (HW <= BN_SMALL_HW) {
         hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd, slope,
-                           (const float*)nullptr, 0, (const float*)nullptr, (float*)nullptr, u, p_nstride);
+                           (const float*)nullptr, 0, (const float*)nullptr, (float*)nullptr, u, p_nstride, batch);
         return SPLICE_OK;
     }
     const int PB = plane_blocks(HW);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, C, HW, PB, part, u);
-    hipLaunchKernelGGL(bn_act_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, PB, gamma, beta, part, eps, mean, rstd, slope, p_nstride);
+    hipLaunchKernelGGL(bn_act_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, PB, gamma, beta, part, eps, mean, rstd, slope, p_nstride, batch);
     return SPLICE_OK;
 }
 bool bn_bwd_fuses_upsample(int HW, int h, int w) { return HW <= BN_SMALL_HW && h > 0 && w > 0; }
@@ -1003,23 +1092,24 @@ int bn_fwd_slabs_launch(const float* slabs, int ksplit, const float* bias, float
                         int C, int HW, const float* gamma, const float* beta, float eps, float* mean, float* rstd, float slope, hipStream_t s, size_t p_nstride) {
     if (HW > BN_SMALL_HW || ksplit < 2 || !slabs) return SPLICE_ERR_ARG;
     hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C, N), dim3(256), 0, s, (const float*)y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd,
-                       slope, slabs, ksplit, bias, y, BnUpsample{}, p_nstride);
+                       slope, slabs, ksplit, bias, y, BnUpsample{}, p_nstride, 0);
     return SPLICE_OK;
 }
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
-                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up, size_t p_nstride) {
+                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up, size_t p_nstride, int batch) {
+    if (batch && (N > BN_MAX_BATCH || p_nstride)) return SPLICE_ERR_ARG;
     if (HW <= BN_SMALL_HW) {
         BnUpsample u = up ? *up : BnUpsample{};
         if (!bn_bwd_fuses_upsample(HW, u.h, u.w)) u.d_src = nullptr;
         hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy, dy_nstride, C, HW, N,
-                           gamma, mean, rstd, slope, dgamma, dbeta, accumulate, u, p_nstride);
+                           gamma, mean, rstd, slope, dgamma, dbeta, accumulate, u, p_nstride, batch);
         return SPLICE_OK;
     }
     const int PB = plane_blocks(HW);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, C, HW, PB, mean, rstd, slope, part);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy,
-                       dy_nstride, C, HW, N, PB, gamma, mean, rstd, slope, part, dgamma, dbeta, accumulate, p_nstride);
+                       dy_nstride, C, HW, N, PB, gamma, mean, rstd, slope, part, dgamma, dbeta, accumulate, p_nstride, batch);
     return SPLICE_OK;
 }
 __global__ void fill_zero_kernel(float* p, int n) {

@@ -76,8 +76,10 @@ struct VitView {
 
 struct SpliceStep {
     splice_step_config cfg;
-    int P = 1;                   // pairs optimised side by side
-    size_t astride = 0;          // floats between the pairs' parameter / gradient / moment arenas (P > 1)
+    int P = 1;                   // pairs optimised side by side -- or, in crops mode, the n_crops global crops of ONE pair
+    int Pe = 1;                  // images of the entire-image branch: P in pairs mode, 1 in crops mode (netG(A) is one image there)
+    int crops_mode = 0;          // the P slots are crops of one pair: one generator (batch-statistics plans), losses summed over the crops
+    size_t astride = 0;          // floats between the pairs' parameter / gradient / moment arenas (P > 1, pairs mode)
     VitView vg, ve;
     void *plan_a = nullptr, *plan_b = nullptr, *plan_e = nullptr;   // generator plans: P independent images each
     int cropb_h = 0, cropb_w = 0;
@@ -113,6 +115,7 @@ struct SpliceStep {
     int use_graph = 1;
     int dbg_sync = 0, dbg_own_eager = 0;
     int ssim_id_on = 0;          // lambda_global_ssim / lambda_global_identity switched on (util/losses.py:35-37)
+    int skip_adam = 0, accumulate = 0;   // splice_step_set_mode: leave the summed gradient in `grads` (optionally += ) and do not update
     float* running = nullptr;    // BatchNorm running statistics arena(s) of the caller (null: not tracked)
     long long running_stride = 0;
 };
@@ -152,15 +155,20 @@ static int view_init(SpliceStep* st, VitView& v, void* ctx, int want_B) {
 
 // blockIdx.x = pair.  raw_k = fixed-order sum of term k's workgroup partials (no float atomics anywhere: replicas are
 // bit-reproducible); total = sum_k lambda_k * raw_k   (util/losses.py:53-71)
+// n_slots > 1 (crops mode, grid 1): the terms of the n_crops crops are added in crop order (util/losses.py:75-82 `loss +=`).
 __global__ __launch_bounds__(320) void total_loss_kernel(float* lbase, size_t lstride, int lp, float w_ssim, float w_essim, float w_ecls, float w_cls,
-                                                         float w_id, float* out8) {
+                                                         float w_id, float* out8, int n_slots) {
     __shared__ float raw[8];
     float* l = lbase + (size_t)blockIdx.x * lstride;
     const int k = 1 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave k-1 owns term k (5 waves)
-    const float* part = l + 8 + (size_t)k * lp;
-    float acc = 0.f;
-    for (int i = lane; i < lp; i += 64) acc += part[i];
-    acc = wave_sum(acc);
+    float tot = 0.f;
+    for (int slot = 0; slot < n_slots; ++slot) {
+        const float* part = l + (size_t)slot * lstride + 8 + (size_t)k * lp;
+        float acc = 0.f;
+        for (int i = lane; i < lp; i += 64) acc += part[i];
+        tot += wave_sum(acc);
+    }
+    const float acc = tot;
     if (lane == 0) raw[k] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -218,11 +226,11 @@ static const float* keys_ptr(const VitView& v, const float* qkv_last, int pass) 
 
 // The structure term of P pairs (util/losses.py:74-83): targets = passes [pass_tgt, pass_tgt + P), generated = passes
 // [pass_x, pass_x + P) of view v.  `b` is carved over st->ssim_ws for v's token count.
-static int ssim_batch(SpliceStep* st, VitView& v, int pass_tgt, int pass_x, float lambda, int slot, SelfSimBatch* b) {
+static int ssim_batch(SpliceStep* st, VitView& v, int pass_tgt, int pass_x, int count, float lambda, int slot, SelfSimBatch* b) {
     bf16_t *qkv = nullptr, *qkvT = nullptr;
     RC(splice_vit_get_tensor(v.ctx, 1, v.depth - 1, (void**)&qkv));
     RC(splice_vit_get_tensor(v.ctx, 6, v.depth - 1, (void**)&qkvT));
-    selfsim_batch_carve(st->ssim_ws, v.T, v.D, st->P, b);
+    selfsim_batch_carve(st->ssim_ws, v.T, v.D, count, b);
     const size_t pass_rows = (size_t)v.Tld * 3 * v.D;
     b->ldk = 3 * v.D; b->ldt = v.rows; b->k_pstride = pass_rows; b->kT_pstride = (size_t)v.Tld;
     b->k_tgt = qkv + (size_t)pass_tgt * pass_rows + v.D;
@@ -243,7 +251,10 @@ int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void
     if (!cfg || !vit_ctx_global || !gen_plan_a || !gen_plan_b || !out) return SPLICE_ERR_ARG;
     SpliceStep* st = new SpliceStep();
     st->cfg = *cfg;
-    const int P = st->P = cfg->pairs > 1 ? cfg->pairs : 1;
+    if (cfg->n_crops > 1 && cfg->pairs > 1) { splice_set_error("splice_step_create: n_crops > 1 and pairs > 1 cannot be combined"); delete st; return SPLICE_ERR_ARG; }
+    st->crops_mode = cfg->n_crops > 1;
+    const int P = st->P = st->crops_mode ? cfg->n_crops : cfg->pairs > 1 ? cfg->pairs : 1;
+    const int Pe = st->Pe = st->crops_mode ? 1 : P;
     st->max_crop_h = cfg->crop_h; st->max_crop_w = cfg->crop_w;
     st->cropb_h = cfg->crop_h; st->cropb_w = cfg->crop_w;
     int rc = SPLICE_OK;
@@ -256,25 +267,25 @@ int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void
         if (n != P || h != cfg->crop_h || w != cfg->crop_w) { splice_set_error("splice_step_create: the crop generator plans must hold %d image(s) at the crop size", P); return fail(SPLICE_ERR_ARG); }
     }
     st->plan_a = gen_plan_a; st->plan_b = gen_plan_b;
-    if (P > 1) {
+    if (P > 1 && !st->crops_mode) {
         if (cfg->arena_stride < st->nparams) { splice_set_error("splice_step_create: pairs > 1 needs arena_stride >= the parameter count"); return fail(SPLICE_ERR_ARG); }
         st->astride = (size_t)cfg->arena_stride;
     }
     const size_t crop = (size_t)3 * cfg->crop_h * cfg->crop_w;
     for (float** q : {&st->gen_in, &st->in_b, &st->gen_out, &st->gen_out_b, &st->d_gen_out, &st->d_gen_out_b})
         if ((rc = salloc(st, q, P * crop)) != SPLICE_OK) return fail(rc);
-    if ((rc = salloc(st, &st->grads_b, P > 1 ? P * st->astride : (size_t)st->nparams)) != SPLICE_OK) return fail(rc);
+    if ((rc = salloc(st, &st->grads_b, st->astride ? P * st->astride : (size_t)st->nparams)) != SPLICE_OK) return fail(rc);
     int Tmax = st->vg.T;
     if (cfg->ent_h > 0) {
         if (!vit_ctx_entire || !gen_plan_entire) { splice_set_error("splice_step_create: entire-image branch needs its ViT context and generator plan"); return fail(SPLICE_ERR_ARG); }
-        if ((rc = view_init(st, st->ve, vit_ctx_entire, 2 * P)) != SPLICE_OK) return fail(rc);
+        if ((rc = view_init(st, st->ve, vit_ctx_entire, 2 * Pe)) != SPLICE_OK) return fail(rc);
         if (st->ve.H != cfg->ent_vit_h || st->ve.W != cfg->ent_vit_w) { splice_set_error("splice_step_create: entire ViT context shape mismatch"); return fail(SPLICE_ERR_ARG); }
         if ((rc = splice_gen_plan_dims(gen_plan_entire, &n, &h, &w, nullptr)) != SPLICE_OK) return fail(rc);
-        if (n != P || h != cfg->ent_h || w != cfg->ent_w) { splice_set_error("splice_step_create: the entire generator plan must hold %d image(s) at the entire-image size", P); return fail(SPLICE_ERR_ARG); }
+        if (n != Pe || h != cfg->ent_h || w != cfg->ent_w) { splice_set_error("splice_step_create: the entire generator plan must hold %d image(s) at the entire-image size", Pe); return fail(SPLICE_ERR_ARG); }
         st->plan_e = gen_plan_entire;
         const size_t ent = (size_t)3 * cfg->ent_h * cfg->ent_w;
         for (float** q : {&st->ent_in, &st->ent_out, &st->d_ent_out})
-            if ((rc = salloc(st, q, P * ent)) != SPLICE_OK) return fail(rc);
+            if ((rc = salloc(st, q, Pe * ent)) != SPLICE_OK) return fail(rc);
         if (st->ve.T > Tmax) Tmax = st->ve.T;
     }
     char* wsb = nullptr;
@@ -343,6 +354,17 @@ int splice_step_set_crops(void* h, int a_h, int a_w, int b_h, int b_w) {
     return SPLICE_OK;
 }
 
+// skip_adam != 0: the step stops after backward -- `grads` holds the gradient of this step's loss (+= its previous content
+// when accumulate != 0) and the parameters are untouched; the caller sums several losses that way (e.g. the same crops seen
+// at several ViT input scales) and applies splice_adam_step once.
+int splice_step_set_mode(void* h, int skip_adam, int accumulate) {
+    SpliceStep* st = (SpliceStep*)h;
+    if (!st || (accumulate && !skip_adam)) return SPLICE_ERR_ARG;
+    if (st->skip_adam != (skip_adam ? 1 : 0) || st->accumulate != (accumulate ? 1 : 0)) drop_graphs(st);
+    st->skip_adam = skip_adam ? 1 : 0; st->accumulate = accumulate ? 1 : 0;
+    return SPLICE_OK;
+}
+
 // BatchNorm running statistics (models/unet/common.py:95-96): when set, every step applies the momentum-0.1 update of its
 // netG calls in the reference's order (A_global, A on entire steps, B_global; models/model.py:15-23) to the caller's
 // buffer arena(s) (layout: splice_gen_buffer_info; pair p at running + p * stride).  NULL switches tracking off.
@@ -396,7 +418,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     RC(dev_zero_launch(vg.d_keys + pX * passD, (size_t)2 * P * passD * sizeof(float), s2));
     SelfSimBatch sb = {};
     if (l_ssim > 0.f) {   // target self-similarity S* of A' (util/losses.py:79)
-        RC(ssim_batch(st, vg, pA, pX, l_ssim, L_GLOBAL_SSIM, &sb));
+        RC(ssim_batch(st, vg, pA, pX, P, l_ssim, L_GLOBAL_SSIM, &sb));
         RC(selfsim_target_launch(sb, s2));
     }
     if (overlap) HIPCHK(hipEventRecord(st->ev_join, s2));
@@ -417,35 +439,37 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     if (l_id > 0.f)    // keys of y' against keys of B' (util/losses.py:96-105): mean over h*T*d = T*D
         RC(mse_batched_launch(keys_ptr(vg, qkv_g, pY), 3 * vg.D, 3 * passD, keys_ptr(vg, qkv_g, pB), 3 * vg.D, 3 * passD, vg.T, vg.D, 1.0f, l_id,
                               loss_part(st, L_GLOBAL_ID), st->lstride, vg.d_keys + pY * passD, vg.D, passD, P, s));
-    // ---- entire-image branch (every entire_every-th step): passes [0, P) A_entire', [P, 2P) x_entire'
+    // ---- entire-image branch (every entire_every-th step): passes [0, Pe) A_entire', [Pe, 2 Pe) x_entire'
+    const int Pe = st->Pe;
     if (entire) {
         VitView& ve = st->ve;
         const size_t eimg = (size_t)3 * ve.H * ve.W;
         RC(splice_gen_forward_borrowed(st->plan_e, params, A_entire, st->ent_out, s));
-        RC(place_images(A_entire, c.ent_h, c.ent_w, ve.imgs, ve.H, ve.W, P, s));
-        RC(place_images(st->ent_out, c.ent_h, c.ent_w, ve.imgs + P * eimg, ve.H, ve.W, P, s));
-        RC(splice_vit_forward_ex(ve.ctx, ve.imgs, 1, P, s));
+        RC(place_images(A_entire, c.ent_h, c.ent_w, ve.imgs, ve.H, ve.W, Pe, s));
+        RC(place_images(st->ent_out, c.ent_h, c.ent_w, ve.imgs + Pe * eimg, ve.H, ve.W, Pe, s));
+        RC(splice_vit_forward_ex(ve.ctx, ve.imgs, 1, Pe, s));
         float* blk_e = nullptr;
         RC(splice_vit_get_tensor(ve.ctx, 0, ve.depth - 1, (void**)&blk_e));
         const size_t epassD = (size_t)ve.Tld * ve.D;
-        RC(dev_zero_launch(ve.d_block + P * epassD, (size_t)P * epassD * sizeof(float), s));
-        RC(dev_zero_launch(ve.d_keys + P * epassD, (size_t)P * epassD * sizeof(float), s));
+        RC(dev_zero_launch(ve.d_block + Pe * epassD, (size_t)Pe * epassD * sizeof(float), s));
+        RC(dev_zero_launch(ve.d_keys + Pe * epassD, (size_t)Pe * epassD * sizeof(float), s));
         if (l_essim > 0.f) {
             SelfSimBatch se = {};
-            RC(ssim_batch(st, ve, 0, P, l_essim, L_ENTIRE_SSIM, &se));
+            RC(ssim_batch(st, ve, 0, Pe, Pe, l_essim, L_ENTIRE_SSIM, &se));
             RC(selfsim_target_launch(se, s));
             RC(selfsim_loss_launch(se, s));
         }
-        if (l_ecls > 0.f)   // target is the B_global crop's CLS (util/losses.py:60)
-            RC(mse_batched_launch(blk_e + P * epassD, ve.D, epassD, blk_g + pB * passD, vg.D, passD, 1, ve.D, 1.0f, l_ecls, loss_part(st, L_ENTIRE_CLS),
-                                  st->lstride, ve.d_block + P * epassD, ve.D, epassD, P, s));
+        if (l_ecls > 0.f)   // target is the B_global crop's CLS (util/losses.py:60; with n_crops > 1 the zip pairs x_entire with the FIRST crop)
+            RC(mse_batched_launch(blk_e + Pe * epassD, ve.D, epassD, blk_g + pB * passD, vg.D, passD, 1, ve.D, 1.0f, l_ecls, loss_part(st, L_ENTIRE_CLS),
+                                  st->lstride, ve.d_block + Pe * epassD, ve.D, epassD, Pe, s));
     }
     // ---- backward (train.py:78): ViT dgrad for the generated images only, then the generator
     // the x' and y' passes are independent chains until the generator: one per stream (every launch of a
     // dependent chain pays ~8 us of fixed latency; two chains in flight hide each other's)
     bool loss_summed = false;
     auto sum_losses = [&](hipStream_t q) {
-        hipLaunchKernelGGL(total_loss_kernel, dim3(P), dim3(320), 0, q, st->losses, st->lstride, (int)st->lp, l_ssim, l_essim, l_ecls, l_cls, l_id, st->losses_out);
+        hipLaunchKernelGGL(total_loss_kernel, dim3(st->crops_mode ? 1 : P), dim3(320), 0, q, st->losses, st->lstride, (int)st->lp, l_ssim, l_essim, l_ecls, l_cls, l_id,
+                           st->losses_out, st->crops_mode ? P : 1);
     };
     auto track_running = [&](hipStream_t q) -> int {   // BatchNorm running statistics in the reference's call order
         if (!st->running || (st->ablate & 1)) return SPLICE_OK;
@@ -476,25 +500,25 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         }
         RC(splice_vit_backward(vg.ctx, pX, pY, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
         RC(unplace_grads(vg.d_imgs + pX * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, P, s));
-        if (!(st->ablate & 2)) RC(splice_gen_backward(st->plan_a, params, st->d_gen_out, grads, 0, s));
+        if (!(st->ablate & 2)) RC(splice_gen_backward(st->plan_a, params, st->d_gen_out, grads, st->accumulate, s));
         if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
         // grads = g(A) + g(B): folded into the Adam kernel on ordinary steps; a separate add when the entire-image branch
         // still has to accumulate into the sum (same association order either way)
         if (!(st->ablate & 2)) {
-            if (entire) RC(add_f32_launch(grads, st->grads_b, P > 1 ? P * st->astride : (size_t)st->nparams, s));
+            if (entire || st->skip_adam) RC(add_f32_launch(grads, st->grads_b, st->astride ? P * st->astride : (size_t)st->nparams, s));
             else adam_g2 = st->grads_b;
         }
     }
     if (entire) {
         VitView& ve = st->ve;
         const size_t eimg = (size_t)3 * ve.H * ve.W;
-        RC(splice_vit_backward(ve.ctx, P, 2 * P, ve.pb.data(), nullptr, ve.pk.data(), ve.d_imgs, 1, s));
-        RC(unplace_grads(ve.d_imgs + P * eimg, ve.H, ve.W, st->d_ent_out, c.ent_h, c.ent_w, P, s));
+        RC(splice_vit_backward(ve.ctx, Pe, 2 * Pe, ve.pb.data(), nullptr, ve.pk.data(), ve.d_imgs, 1, s));
+        RC(unplace_grads(ve.d_imgs + Pe * eimg, ve.H, ve.W, st->d_ent_out, c.ent_h, c.ent_w, Pe, s));
         RC(splice_gen_backward(st->plan_e, params, st->d_ent_out, grads, 1, s));
     }
     if (!loss_summed) { sum_losses(s); RC(track_running(s)); }
     // ---- optimizer.step() (train.py:79) over every pair's arena; Adam's step count (>= 1) is read from the device at execution time
-    RC(adam_launch_dev(params, grads, m, v, P > 1 ? P * st->astride : (size_t)st->nparams, c.lr, c.beta1, c.beta2, c.eps, st->dev_t, 0, s, adam_g2));
+    if (!st->skip_adam) RC(adam_launch_dev(params, grads, m, v, st->astride ? P * st->astride : (size_t)st->nparams, c.lr, c.beta1, c.beta2, c.eps, st->dev_t, 0, s, adam_g2));
     return SPLICE_OK;
 }
 
@@ -555,7 +579,7 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
         StageArgs sa = {};
         sa.src[0] = A_crop; sa.dst[0] = st->gen_in; sa.n[0] = (size_t)P * 3 * c.crop_h * c.crop_w;
         sa.src[1] = B_crop; sa.dst[1] = st->in_b; sa.n[1] = (size_t)P * 3 * st->cropb_h * st->cropb_w;
-        if (entire) { sa.src[2] = A_entire; sa.dst[2] = st->ent_in; sa.n[2] = (size_t)P * 3 * c.ent_h * c.ent_w; }
+        if (entire) { sa.src[2] = A_entire; sa.dst[2] = st->ent_in; sa.n[2] = (size_t)st->Pe * 3 * c.ent_h * c.ent_w; }
         sa.ip = st->dev_t; sa.iv = step_idx + 1;
         hipLaunchKernelGGL(stage_inputs_kernel, dim3(128 * (P > 4 ? 4 : P)), dim3(256), 0, s, sa);
     }

@@ -47,12 +47,17 @@ class MultiPairEngine:
     bit-identical whichever batch it rides in (tests/test_multipair_gpu.py).  All pairs of a batch share the image and
     crop sizes."""
 
-    def __init__(self, cfg, vit_state, gen_states, crop_hw, entire_hw=None, device="cuda", vit_engine=None):
+    def __init__(self, cfg, vit_state, gen_states, crop_hw, entire_hw=None, device="cuda", vit_engine=None, n_crops=1):
         """cfg: reference config keys (conf/default/config.yaml); vit_state: DINO state dict; gen_states: list of P generator
         state dicts (reference names); crop_hw: (h, w) of the (largest) global crops; entire_hw: (H, W) of the whole
-        structure image or None to disable the entire branch."""
+        structure image or None to disable the entire branch.  ``n_crops`` > 1 (one pair only): the reference's
+        ``global_{A,B}_crops_n_crops`` -- every step takes ``[n_crops,3,h,w]`` crops of the pair, netG sees them as ONE batch
+        (BatchNorm statistics over the crops), every loss term is summed over the crops."""
         self.cfg = dict(DEFAULT_CFG, **cfg)
         c = self.cfg
+        self.n_crops = int(n_crops)
+        if self.n_crops > 1 and len(gen_states) != 1:
+            raise ValueError("n_crops > 1 is a property of ONE pair: pass a single generator state")
         if c["optimizer"] != "adam" or c["scheduler_policy"] != "none":
             raise NotImplementedError("the fused step implements the reference's default optimizer 'adam' with scheduler 'none'")
         self.device = torch.device(device)
@@ -77,21 +82,23 @@ class MultiPairEngine:
         ch, cw = crop_hw
         vh, vw = resize_output_size(ch, cw, Pz, 480)
         self.crop_hw, self.vit_hw = (ch, cw), (vh, vw)
-        self.ctx_g = self.vit.context(4 * P, vh, vw, need_grad=True)
+        slots = self.slots = self.n_crops if self.n_crops > 1 else P    # images per generator plan / per ViT pass group
+        batch = self.n_crops > 1
+        self.ctx_g = self.vit.context(4 * slots, vh, vw, need_grad=True)
         arena_stride = self.stride if P > 1 else 0
         # private plan objects (the shape-keyed plan cache could hand out one plan twice)
-        self.plan_a = GeneratorPlan(self.gen, P, ch, cw, True, arena_stride)
-        self.plan_b = GeneratorPlan(self.gen, P, ch, cw, True, arena_stride)
+        self.plan_a = GeneratorPlan(self.gen, slots, ch, cw, True, arena_stride, batch_stats=batch)
+        self.plan_b = GeneratorPlan(self.gen, slots, ch, cw, True, arena_stride, batch_stats=batch)
         sc = _lib.StepConfig()
         sc.crop_h, sc.crop_w, sc.vit_h, sc.vit_w = ch, cw, vh, vw
-        sc.pairs, sc.arena_stride = P, arena_stride
+        sc.pairs, sc.arena_stride, sc.n_crops = P, arena_stride, self.n_crops
         self.ctx_e = self.plan_e = None
         self.entire_hw = entire_hw
         use_entire = entire_hw is not None and (c["lambda_entire_ssim"] > 0 or c["lambda_entire_cls"] > 0)
         if use_entire:
             eh, ew = entire_hw
             evh, evw = resize_output_size(eh, ew, Pz, 480)
-            self.ctx_e = self.vit.context(2 * P, evh, evw, need_grad=True)
+            self.ctx_e = self.vit.context(2 * P, evh, evw, need_grad=True)     # (P = 1 in crops mode: netG(A) is one image)
             self.plan_e = GeneratorPlan(self.gen, P, eh, ew, True, arena_stride)
             sc.ent_h, sc.ent_w, sc.ent_vit_h, sc.ent_vit_w = eh, ew, evh, evw
         sc.lambda_global_cls, sc.lambda_global_ssim = c["lambda_global_cls"], c["lambda_global_ssim"]
@@ -124,7 +131,7 @@ class MultiPairEngine:
         self.step_idx += 1
         for t in (A_crop, B_crop):
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
-            assert t.numel() == self.P * 3 * t.shape[-2] * t.shape[-1], (tuple(t.shape), self.P)
+            assert t.numel() == self.slots * 3 * t.shape[-2] * t.shape[-1], (tuple(t.shape), self.slots)
         crops = tuple(A_crop.shape[-2:]) + tuple(B_crop.shape[-2:])
         if crops != self._cur_crops:   # per-step random crop sizes (data/transforms.py:21-22)
             _lib.check(_lib.lib().splice_step_set_crops(self.handle, *crops), "step_set_crops")
@@ -198,11 +205,51 @@ class MultiPairEngine:
 class SpliceEngine(MultiPairEngine):
     """The per-pair optimisation loop of ``train.py:34-80`` for ONE pair (P = 1): the reference's unit of work."""
 
-    def __init__(self, cfg, vit_state, gen_state, crop_hw, entire_hw=None, device="cuda", vit_engine=None):
-        super().__init__(cfg, vit_state, [gen_state], crop_hw, entire_hw, device=device, vit_engine=vit_engine)
+    def __init__(self, cfg, vit_state, gen_state, crop_hw, entire_hw=None, device="cuda", vit_engine=None, n_crops=1):
+        super().__init__(cfg, vit_state, [gen_state], crop_hw, entire_hw, device=device, vit_engine=vit_engine, n_crops=n_crops)
 
     def losses(self):
         return super().losses(0)
+
+
+class MultiScaleEngine:
+    """One pair, every loss term evaluated at SEVERAL ViT input scales (BASELINE configs[4]: 224 / 320 / 448): the same global
+    crops are resized to each ``dino_global_patch_size`` in ``scales`` and the reference loss (util/losses.py:46-72) of every
+    scale is summed; one Adam update per step on the summed gradient.  An extension beyond the reference (it has one
+    scale); built from one fused step per scale in gradient-only mode (``splice_step_set_mode``) sharing the parameter /
+    gradient / moment arenas, followed by the fused Adam launch."""
+
+    def __init__(self, cfg, vit_state, gen_state, crop_hw, entire_hw=None, scales=(224, 320, 448), device="cuda", vit_engine=None, n_crops=1):
+        self.cfg = dict(DEFAULT_CFG, **cfg)
+        self.scales = tuple(scales)
+        self.engines = []
+        for k, sz in enumerate(self.scales):
+            e = SpliceEngine(dict(self.cfg, dino_global_patch_size=sz), vit_state if k == 0 else None, gen_state, crop_hw, entire_hw, device=device,
+                             vit_engine=vit_engine if k == 0 else self.engines[0].vit, n_crops=n_crops)
+            _lib.check(_lib.lib().splice_step_set_mode(e.handle, 1, int(k > 0)), "step_set_mode")
+            if k > 0:   # one parameter set: every scale reads / writes the arenas of the first engine; netG bookkeeping once
+                e.params, e.grads, e.m, e.v = self.engines[0].params, self.engines[0].grads, self.engines[0].m, self.engines[0].v
+                _lib.check(_lib.lib().splice_step_set_running_stats(e.handle, None, 0), "step_set_running_stats")
+            self.engines.append(e)
+        self.vit, self.gen = self.engines[0].vit, self.engines[0].gen
+        self.params, self.grads = self.engines[0].params, self.engines[0].grads
+        self.step_idx = -1
+
+    def step(self, A_crop, B_crop, A_entire=None):
+        from .generator import adam_step
+        self.step_idx += 1
+        for e in self.engines:
+            e.step(A_crop, B_crop, A_entire)
+        e0, c = self.engines[0], self.cfg
+        adam_step(e0.params, e0.grads, e0.m, e0.v, c["lr"], c["optimizer_beta1"], c["optimizer_beta2"], 1e-8, self.step_idx + 1)
+
+    def losses(self):
+        """Per-scale loss dicts and their sum: ``{"loss": total, "scales": {224: {...}, ...}}``."""
+        per = {sz: e.losses() for sz, e in zip(self.scales, self.engines)}
+        return {"loss": sum(d["loss"] for d in per.values()), "scales": per}
+
+    def generate(self, img):
+        return self.engines[0].generate(img)
 
 
 def synthetic_engine(cfg, pair_id=0, hw=(224, 224), seed=1234, device="cuda", vit_engine=None, entire=True, pairs=1):

@@ -64,7 +64,7 @@ class GeneratorEngine:
 
 
 class GeneratorPlan:
-    def __init__(self, engine, N, H, W, need_grad, arena_stride=0):
+    def __init__(self, engine, N, H, W, need_grad, arena_stride=0, batch_stats=False):
         """``arena_stride`` > 0: the N images are INDEPENDENT generators -- image n uses ``params[n * stride:]`` and its
         gradient goes to ``grads[n * stride:]`` (several pairs in one launch); 0: one generator applied to N images."""
         self.engine, self.N, self.H, self.W, self.need_grad, self.arena_stride = engine, N, H, W, need_grad, arena_stride
@@ -73,6 +73,9 @@ class GeneratorPlan:
         self.handle = h
         if arena_stride:
             _lib.check(_lib.lib().splice_gen_plan_set_arena_stride(h, arena_stride), "gen_plan_set_arena_stride")
+        self.batch_stats = bool(batch_stats)
+        if batch_stats:   # ONE netG call on the batch: BatchNorm statistics over all N images (the reference with n_crops > 1)
+            _lib.check(_lib.lib().splice_gen_plan_set_batch_stats(h, 1), "gen_plan_set_batch_stats")
 
     def __del__(self):
         try:

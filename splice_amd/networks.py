@@ -100,7 +100,8 @@ class SkipGenerator(nn.Module):
         if pool:
             return pool.pop()
         from .generator import GeneratorPlan
-        return GeneratorPlan(self.engine, N, H, W, need_grad)
+        # a batch is ONE call of the reference's net: nn.BatchNorm2d statistics over all N images
+        return GeneratorPlan(self.engine, N, H, W, need_grad, batch_stats=N > 1)
 
     def _release(self, plan):
         self._free.setdefault((plan.N, plan.H, plan.W, bool(plan.need_grad)), []).append(plan)
@@ -113,15 +114,11 @@ class SkipGenerator(nn.Module):
         self._batches += 1
 
     def forward(self, x):
-        """x ``[1,3,H,W]`` in [0,1].  The engine's BatchNorm takes its statistics per image, which IS the reference for the
-        batch-1 calls it makes with the default ``n_crops = 1`` (models/model.py:15-23).  A batch of several crops would be
-        normalised over the whole batch by the reference's ``nn.BatchNorm2d`` -- different numbers -- so it is refused here
-        rather than silently computed per image; call the generator once per image."""
+        """x ``[N,3,H,W]`` in [0,1]: ONE call of the net, as ``netG(input['A_global'])`` (models/model.py:15).  With N > 1
+        (``n_crops`` > 1 crops stacked by data/transforms.py:27) the train-mode BatchNorm layers take their statistics over
+        the whole batch, as the reference's ``nn.BatchNorm2d`` does (N <= 8)."""
         if not x.is_cuda:
             raise RuntimeError("SkipGenerator: input must be on the GPU")
-        if x.shape[0] != 1:
-            raise NotImplementedError("SkipGenerator: batch > 1 is normalised over the batch by the reference's BatchNorm; the HIP "
-                                      "engine normalises per image -- call it once per image (the reference default n_crops = 1 does)")
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._plist)
         return _GenFn.apply(x, self, need_grad, *self._plist)
 

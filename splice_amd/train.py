@@ -56,10 +56,11 @@ class DeviceDataFeed:
         return self.A[None]
 
     @staticmethod
-    def _crop(img, min_cover):
+    def _crops(img, min_cover, n_crops):
+        """``[n_crops,3,s,s]``: one size per call, one position per crop (data/transforms.py:19-27)."""
         _, h, w = img.shape
-        top, left, size = augment.global_crop_box(h, w, min_cover)
-        return img[:, top:top + size, left:left + size].contiguous()
+        size, boxes = augment.global_crop_boxes(h, w, min_cover, n_crops)
+        return torch.stack([img[:, top:top + size, left:left + size] for top, left in boxes]).contiguous()
 
     def next(self):
         self.step += 1
@@ -69,9 +70,9 @@ class DeviceDataFeed:
             sample['A'] = self.get_A()
         # data/Dataset.py:67-68: augment the whole image, then crop
         A = augment.structure_transforms(self.A) if aug else self.A
-        sample['A_global'] = self._crop(A, self.cfg['global_A_crops_min_cover'])
+        sample['A_global'] = self._crops(A, self.cfg['global_A_crops_min_cover'], self.cfg['global_A_crops_n_crops'])
         B = augment.texture_transforms(self.B) if aug else self.B
-        sample['B_global'] = self._crop(B, self.cfg['global_B_crops_min_cover'])
+        sample['B_global'] = self._crops(B, self.cfg['global_B_crops_min_cover'], self.cfg['global_B_crops_n_crops'])
         return sample
 
 
@@ -82,8 +83,11 @@ def train_model(dataroot, callback=None, cfg_overrides=None, vit_state=None, pro
     if dataroot is not None:
         cfg['dataroot'] = dataroot
     cfg.update(cfg_overrides or {})
-    if cfg['global_A_crops_n_crops'] != 1 or cfg['global_B_crops_n_crops'] != 1:
-        raise NotImplementedError("the fused engine implements the reference default of one global crop per image")
+    n_crops = int(cfg['global_A_crops_n_crops'])
+    if n_crops != int(cfg['global_B_crops_n_crops']) or not 1 <= n_crops <= 8:
+        # (the reference zips the two crop lists: with unequal counts the surplus crops of one side only feed the generator's
+        # BatchNorm statistics; not supported by the fused step)
+        raise NotImplementedError("the fused engine takes global_A_crops_n_crops == global_B_crops_n_crops in 1..8")
     if device.type != 'cuda':
         raise RuntimeError("train_model needs an MI355X: the product path has no CPU fallback")
 
@@ -118,7 +122,7 @@ def train_model(dataroot, callback=None, cfg_overrides=None, vit_state=None, pro
     netG = define_G(cfg['init_type'], cfg['init_gain'], device=device)
     gen_state = {k: v.detach() for k, v in netG.state_dict().items() if k in netG.engine.table}
     crop_max = max(min(A.shape[1], A.shape[2]), min(B.shape[1], B.shape[2]))   # crops are squares of side <= min(h, w)
-    engine = SpliceEngine(cfg, vit_state, gen_state, (crop_max, crop_max), tuple(A.shape[1:]), device=device)
+    engine = SpliceEngine(cfg, vit_state, gen_state, (crop_max, crop_max), tuple(A.shape[1:]), device=device, n_crops=n_crops)
     del netG
 
     writer = AsyncResultWriter(cfg['dataroot'])   # PNG encode + disk write happen on a worker thread

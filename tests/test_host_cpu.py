@@ -55,7 +55,8 @@ def test_device_data_feed_crop_law():
     """crop side ~ round(U(min_cover*h, h)) clipped to the width, square, inside the image
     (data/transforms.py:19-27); step counter and the every-75th 'A' entry (data/Dataset.py:62-70)."""
     from splice_amd import train
-    cfg = dict(use_augmentations=True, entire_A_every=75, global_A_crops_min_cover=0.95, global_B_crops_min_cover=0.95)
+    cfg = dict(use_augmentations=True, entire_A_every=75, global_A_crops_min_cover=0.95, global_B_crops_min_cover=0.95,
+               global_A_crops_n_crops=1, global_B_crops_n_crops=3)
     A = torch.rand(3, 100, 140)
     B = torch.rand(3, 120, 90)
     np.random.seed(0)
@@ -66,17 +67,18 @@ def test_device_data_feed_crop_law():
         s = feed.next()
         assert int(s['step']) == i
         assert ('A' in s) == (i % 75 == 0)
-        a, b = s['A_global'], s['B_global']
-        assert a.shape[1] == a.shape[2] and b.shape[1] == b.shape[2]
-        sides_a.append(a.shape[1])
-        sides_b.append(b.shape[1])
+        a, b = s['A_global'], s['B_global']          # [n_crops, 3, side, side]: one side per call, one position per crop
+        assert a.shape[:2] == (1, 3) and b.shape[:2] == (3, 3)
+        assert a.shape[2] == a.shape[3] and b.shape[2] == b.shape[3]
+        sides_a.append(a.shape[2])
+        sides_b.append(b.shape[2])
     assert min(sides_a) >= 95 and max(sides_a) <= 100 and len(set(sides_a)) > 3
     assert set(sides_b) == {90}   # U(114,120) clipped to the width 90
     cfg['use_augmentations'] = False
     cfg['global_A_crops_min_cover'] = 1.0
     feed = train.DeviceDataFeed(cfg, A, A)
     s = feed.next()
-    assert torch.equal(s['A_global'], A[:, :, :100]) or s['A_global'].shape == (3, 100, 100)
+    assert s['A_global'].shape == (1, 3, 100, 100)
 
 
 # ---- device augmentations (splice_amd/augment.py) against PIL / colorsys: the arithmetic the reference's PIL pipeline
