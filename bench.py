@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--model", default="dino_vitb8")
     ap.add_argument("--pairs", type=int, default=1, help="pairs optimised side by side per GPU in the timed region (1 = the reference's unit: the latency form of the metric)")
     ap.add_argument("--pairs-sweep", default="2,4,8", help="additional pairs-per-GPU settings timed briefly after the main region (throughput form: pairs/hr); '' = off")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4] operand path: QKV projections + key self-similarity Gram on the fp8 MFMA (own tolerance table)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-kernels", default="4,5,3,6", help="kernel families timed live with HIP events for the roofline leg ('' = off): 4 fc2 fwd, 1 fc1 fwd, 2 qkv fwd, 3 attention fwd, 5 split-K dgrads, 6 attention bwd")
     args = ap.parse_args()
@@ -172,7 +173,7 @@ def main():
     cfg = dict(dino_model_name=args.model, dino_global_patch_size=args.size)
     hw = (args.size, args.size)
     P = max(1, args.pairs)
-    eng, A, B = synthetic_engine(cfg, pair_id=rep.pair_id() * P, hw=hw, seed=1234, device=dev, pairs=P)
+    eng, A, B = synthetic_engine(cfg, pair_id=rep.pair_id() * P, hw=hw, seed=1234, device=dev, pairs=P, fp8=args.fp8)
     K, W = args.steps, args.warmup
 
     def barrier():
@@ -215,7 +216,7 @@ def main():
     vit = eng.vit
     for Ps in sweep_ids:
         try:
-            e2, A2, B2 = synthetic_engine(cfg, pair_id=0, hw=hw, seed=1234, device=dev, pairs=Ps, vit_engine=vit)
+            e2, A2, B2 = synthetic_engine(cfg, pair_id=0, hw=hw, seed=1234, device=dev, pairs=Ps, vit_engine=vit, fp8=args.fp8)
             k2 = max(20, K // 4)
             sweep[Ps] = k2 / time_steps(e2, A2, B2, k2, max(5, W // 2), barrier)
             del e2, A2, B2
@@ -265,7 +266,7 @@ def main():
     out = {
         "metric": "opt_steps_per_sec", "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "fp8(e4m3 qkv+selfsim)/bf16" if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"Splice pair {hw[0]}x{hw[1]}, {args.model} (T={T}), {P} pair(s) per GPU per step, "
                                f"{n_entire} of {K} timed steps include the entire-image branch",
                    "gpus": world, "pairs_per_gpu": P, "pair_steps_per_s": round(value * P, 3),

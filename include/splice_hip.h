@@ -69,17 +69,30 @@ typedef struct splice_gemm_epilogue {
     const splice_bf16* rd_other;   /* [M][ld_rd] */
     int ld_rd, rd_rows;
     float* rowdot;
+    /* SPLICE_EPI_SCALE_RC (fp8 operands): C[m][n] *= row_scale[m] * col_scale[n] before the bias -- the per-token scale of the
+     * quantised activations times the per-output-channel scale of the quantised weights */
+    const float* row_scale;        /* [M] */
+    const float* col_scale;        /* [N] */
 } splice_gemm_epilogue;
 
 enum {
     SPLICE_EPI_BIAS = 1, SPLICE_EPI_RESID = 2, SPLICE_EPI_OUT_F32 = 4, SPLICE_EPI_OUT_BF = 8,
     SPLICE_EPI_OUT_T = 16, SPLICE_EPI_GELU = 32, SPLICE_EPI_GELU_GRAD = 64,
-    SPLICE_EPI_COLS_F32 = 128, SPLICE_EPI_ALPHA = 256, SPLICE_EPI_ROWDOT = 512
+    SPLICE_EPI_COLS_F32 = 128, SPLICE_EPI_ALPHA = 256, SPLICE_EPI_ROWDOT = 512, SPLICE_EPI_SCALE_RC = 1024
 };
 
 int splice_gemm_nt_bf16(unsigned flags, const splice_bf16* A, int lda, const splice_bf16* B, int ldb,
                         int M, int N, int K, const splice_gemm_epilogue* epi, splice_stream_t stream);
 
+/* The same product with e4m3 (OCP fp8) operands on the gfx950 fp8 MFMA (v_mfma_f32_16x16x32_fp8_fp8, non-scaled: bf16 issue
+ * rate, half the operand bytes): A [M][K] and B [N][K] are bytes, lda / ldb in bytes (multiples of 16), K % 128 == 0.
+ * BASELINE configs[4] ("fp8 MFMA attention + self-sim path"): used for the QKV projection when the ViT engine runs in
+ * fp8 mode (splice_vit_enable_fp8).  flags must contain SPLICE_EPI_SCALE_RC or SPLICE_EPI_ALPHA for the de-quantisation. */
+int splice_gemm_nt_fp8(unsigned flags, const uint8_t* A, int lda, const uint8_t* B, int ldb, int M, int N, int K,
+                       const splice_gemm_epilogue* epi, splice_stream_t stream);
+/* Row-wise e4m3 quantisation: q[r][:] = fp8(x[r][:] * 448 / amax_r), scale[r] = amax_r / 448 (x ~= q * scale[r]).
+ * x fp32 [rows][ldx] (cols % 8 == 0), q bytes [rows][ldq].  Packs the frozen weights per output channel. */
+int splice_quantize_rows_fp8(const float* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int cols, splice_stream_t stream);
 /* benchmarking hook (tools/gemm_bench.py): force the tile shape, 0 = automatic */
 int splice_gemm_force_tile(int tile);
 /* benchmarking hook (tools/attn_bench.py): pick an attention kernel variant, 0 = default */
@@ -154,6 +167,10 @@ int splice_vit_create(int patch, int dim, int depth, int heads, void** out_handl
 void splice_vit_destroy(void* vit);
 int splice_vit_set_param(void* vit, const char* name, const float* data, long long numel, splice_stream_t stream);
 int splice_vit_params_complete(void* vit);
+/* BASELINE configs[4] fp8 path: contexts created AFTER this call run their QKV projections on the fp8 MFMA (e4m3 LayerNorm
+ * output with per-token scales x e4m3 weights with per-output-channel scales, de-quantised in the GEMM epilogue).
+ * dim % 128 == 0.  The backward (dgrad through bf16 weights) is unchanged. */
+int splice_vit_enable_fp8(void* vit, splice_stream_t stream);
 /* A context = one (batch, image shape): owns the activations of the last forward.
  * pos_TD: position table for this token grid, fp32 [T][dim] (interpolate_pos_encoding done
  * once per shape by the host). need_grad != 0 also allocates the backward workspace. */
@@ -256,6 +273,7 @@ typedef struct splice_step_config {
     int pairs;                   /* P (0 or 1: one pair) */
     long long arena_stride;      /* P > 1: floats between the pairs' parameter / gradient / Adam-moment arenas (>= param count);
                                   * the generator plans must have been given the same stride (splice_gen_plan_set_arena_stride) */
+    int fp8_selfsim;             /* != 0: the key self-similarity Gram matrices on the fp8 MFMA (per-row e4m3 keys; dim % 128 == 0) */
     int n_crops;                 /* > 1 (with pairs <= 1): global_{A,B}_crops_n_crops of conf/default/config.yaml -- the step works on
                                   * n_crops crops of ONE pair: A_crop / B_crop are [n_crops][3][h][w], the generator plans hold n_crops
                                   * images in batch-statistics mode (splice_gen_plan_set_batch_stats: netG sees the stacked crops,

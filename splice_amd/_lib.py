@@ -24,6 +24,7 @@ class GemmEpilogue(C.Structure):
         ("out_f32_cols", C.c_void_p), ("ld_cols", C.c_int), ("col_lo", C.c_int), ("col_hi", C.c_int),
         ("alpha", C.c_float), ("ksplit", C.c_int), ("slab_stride", C.c_longlong),
         ("rd_other", C.c_void_p), ("ld_rd", C.c_int), ("rd_rows", C.c_int), ("rowdot", C.c_void_p),
+        ("row_scale", C.c_void_p), ("col_scale", C.c_void_p),
     ]
 
 
@@ -35,12 +36,12 @@ class StepConfig(C.Structure):
         ("lambda_entire_cls", C.c_float), ("lambda_entire_ssim", C.c_float),
         ("entire_every", C.c_int), ("cls_warmup", C.c_int),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-        ("pairs", C.c_int), ("arena_stride", C.c_longlong), ("n_crops", C.c_int),
+        ("pairs", C.c_int), ("arena_stride", C.c_longlong), ("fp8_selfsim", C.c_int), ("n_crops", C.c_int),
     ]
 
 
 EPI_BIAS, EPI_RESID, EPI_OUT_F32, EPI_OUT_BF, EPI_OUT_T = 1, 2, 4, 8, 16
-EPI_GELU, EPI_GELU_GRAD, EPI_COLS_F32, EPI_ALPHA, EPI_ROWDOT = 32, 64, 128, 256, 512
+EPI_GELU, EPI_GELU_GRAD, EPI_COLS_F32, EPI_ALPHA, EPI_ROWDOT, EPI_SCALE_RC = 32, 64, 128, 256, 512, 1024
 
 _vp, _i, _f, _sz, _u = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint
 
@@ -48,6 +49,8 @@ _SIGNATURES = {
     "splice_version": ([], C.c_int),
     "splice_last_error": ([], C.c_char_p),
     "splice_gemm_nt_bf16": ([_u, _vp, _i, _vp, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _vp], _i),
+    "splice_gemm_nt_fp8": ([_u, _vp, _i, _vp, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _vp], _i),
+    "splice_quantize_rows_fp8": ([_vp, _i, _vp, _i, _vp, _i, _i, _vp], _i),
     "splice_gemm_force_tile": ([_i], _i),
     "splice_attention_variant": ([_i], _i),
     "splice_layernorm_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
@@ -72,6 +75,7 @@ _SIGNATURES = {
     "splice_vit_destroy": ([_vp], None),
     "splice_vit_set_param": ([_vp, C.c_char_p, _vp, C.c_longlong, _vp], _i),
     "splice_vit_params_complete": ([_vp], _i),
+    "splice_vit_enable_fp8": ([_vp, _vp], _i),
     "splice_vit_ctx_create": ([_vp, _i, _i, _i, _vp, _i, _vp, C.POINTER(_vp)], _i),
     "splice_vit_ctx_destroy": ([_vp], None),
     "splice_vit_ctx_info": ([_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _i),

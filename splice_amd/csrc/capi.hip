@@ -39,6 +39,16 @@ int splice_gemm_nt_bf16(unsigned flags, const splice_bf16* A, int lda, const spl
     return finish(gemm_nt_launch(flags, A, lda, B, ldb, M, N, K, *epi, ST(stream)), "splice_gemm_nt_bf16");
 }
 
+int splice_gemm_nt_fp8(unsigned flags, const uint8_t* A, int lda, const uint8_t* B, int ldb, int M, int N, int K,
+                       const splice_gemm_epilogue* epi, splice_stream_t stream) {
+    if (!A || !B || !epi) return finish(SPLICE_ERR_ARG, "splice_gemm_nt_fp8");
+    return finish(gemm_nt_fp8_launch(flags, A, lda, B, ldb, M, N, K, *epi, ST(stream)), "splice_gemm_nt_fp8");
+}
+int splice_quantize_rows_fp8(const float* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int cols, splice_stream_t stream) {
+    if (!x || !q || !scale) return finish(SPLICE_ERR_ARG, "splice_quantize_rows_fp8");
+    return finish(quantize_rows_fp8_launch(x, ldx, q, ldq, scale, rows, cols, ST(stream)), "splice_quantize_rows_fp8");
+}
+
 /* benchmarking hook: force the GEMM tile (0 auto, 1 128x128, 2 128x64, 3 64x64) */
 int splice_gemm_force_tile(int tile) { gemm_force_tile(tile); return SPLICE_OK; }
 int splice_attention_variant(int variant) { attn_set_variant(variant); return SPLICE_OK; }

@@ -17,7 +17,19 @@ constexpr int GEMM_BK = 64;
 
 // SWAP = true computes the transposed fragments (MFMA operands exchanged): each lane then owns 4 consecutive
 // COLUMNS of one output row, so the epilogue moves 8/16-byte vectors instead of scalar elements.
-template <int BM, int BN, bool SWAP = false>
+// FP8 = true: the operands are e4m3 bytes (OCP fp8, the gfx950 MFMA format) instead of bf16 pairs.  The byte geometry of a
+// slice is unchanged (rows of 128 B, XOR-swizzled 16-B chunks, the same LDS-DMA), so the loaders run as they are with
+// K, lda, ldb given in 2-byte units; only the contraction differs: a 16-byte fragment now holds 16 k-values = TWO
+// 16x16x32 fp8 MFMAs (low / high 8 bytes) where it fed one bf16 MFMA -- half the LDS and HBM bytes per FLOP.  A and B use
+// the same k permutation inside a slice, so the sum is unaffected.
+typedef long fp8x8x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 mfma16_fp8_pair(const u32x4& a, const u32x4& b, f32x4 c) {
+    const fp8x8x2_t av = __builtin_bit_cast(fp8x8x2_t, a), bv = __builtin_bit_cast(fp8x8x2_t, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(av[0], bv[0], c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(av[1], bv[1], c, 0, 0, 0);
+}
+
+template <int BM, int BN, bool SWAP = false, bool FP8 = false>
 struct GemmTile {
     static constexpr int FM = BM / 32;  // 16-row fragments per wave along M
     static constexpr int FN = BN / 32;
@@ -93,7 +105,9 @@ struct GemmTile {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] = SWAP ? mfma16(bf[j], af[i], acc[i][j]) : mfma16(af[i], bf[j], acc[i][j]);
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = FP8 ? (SWAP ? mfma16_fp8_pair(bf[j], af[i], acc[i][j]) : mfma16_fp8_pair(af[i], bf[j], acc[i][j]))
+                                        : (SWAP ? mfma16(bf[j], af[i], acc[i][j]) : mfma16(af[i], bf[j], acc[i][j]));
             }
         }
     }
@@ -174,7 +188,9 @@ struct GemmTile {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] = SWAP ? mfma16(bf[j], af[i], acc[i][j]) : mfma16(af[i], bf[j], acc[i][j]);
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = FP8 ? (SWAP ? mfma16_fp8_pair(bf[j], af[i], acc[i][j]) : mfma16_fp8_pair(af[i], bf[j], acc[i][j]))
+                                        : (SWAP ? mfma16(bf[j], af[i], acc[i][j]) : mfma16(af[i], bf[j], acc[i][j]));
             }
             stage = stage + 1 == NS ? 0 : stage + 1;
             nstage = nstage + 1 == NS ? 0 : nstage + 1;
@@ -213,7 +229,7 @@ enum : unsigned {
     EPI_BIAS = SPLICE_EPI_BIAS, EPI_RESID = SPLICE_EPI_RESID, EPI_OUT_F32 = SPLICE_EPI_OUT_F32,
     EPI_OUT_BF = SPLICE_EPI_OUT_BF, EPI_OUT_T = SPLICE_EPI_OUT_T, EPI_GELU = SPLICE_EPI_GELU,
     EPI_GELU_GRAD = SPLICE_EPI_GELU_GRAD, EPI_COLS_F32 = SPLICE_EPI_COLS_F32, EPI_ALPHA = SPLICE_EPI_ALPHA,
-    EPI_ROWDOT = SPLICE_EPI_ROWDOT
+    EPI_ROWDOT = SPLICE_EPI_ROWDOT, EPI_SCALE_RC = SPLICE_EPI_SCALE_RC
 };
 
 template <unsigned FLAGS>
@@ -293,6 +309,11 @@ __device__ __forceinline__ void gemm_epilogue_cols(const GemmEpi& e, int M, int 
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] *= e.alpha;
     }
+    if (FLAGS & EPI_SCALE_RC) {   // de-quantisation of an fp8 product: per-row scale of A x per-column scale of B
+        const float rs = e.row_scale[row];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] *= rs * e.col_scale[min(col0 + r, N - 1)];
+    }
     if (FLAGS & EPI_BIAS) {
         if (full) {
             const float4 b = PRE ? pre_bias : *reinterpret_cast<const float4*>(e.bias + col0);
@@ -360,7 +381,7 @@ __device__ __forceinline__ void gemm_epilogue_cols(const GemmEpi& e, int M, int 
     }
 }
 
-template <int BM, int BN, unsigned FLAGS, int NS>
+template <int BM, int BN, unsigned FLAGS, int NS, bool FP8 = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
                                                       int ldb, int M, int N, int K, GemmEpi e, int gm, int ksplit) {
     extern __shared__ __attribute__((aligned(16))) bf16_t gemm_smem[];   // NS * LDS_ELEMS
@@ -378,7 +399,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
     int tm, tn;
     grouped_tile(t, tiles_m, tiles_n, gm, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
-    GemmTile<BM, BN, true> tile;
+    GemmTile<BM, BN, true, FP8> tile;
     if (NS == 2) tile.run_glds(A, lda, B, ldb, M, N, K, m0, n0, gemm_smem, kbeg);
     else tile.template run_ring<(NS < 3 ? 3 : NS)>(A, lda, B, ldb, M, N, K, m0, n0, gemm_smem, kbeg);
     // Epilogue operands: lane-guarded loads inside the per-fragment epilogue compile to load + s_waitcnt per fragment,
@@ -458,7 +479,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
     }
 }
 
-template <int BM, int BN, unsigned FLAGS, int NS>
+template <int BM, int BN, unsigned FLAGS, int NS, bool FP8 = false>
 static inline void launch_gemm_nt(hipStream_t s, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K,
                                   const GemmEpi& e) {
     const int tm = cdiv(M, BM), tn = cdiv(N, BN);
@@ -474,9 +495,9 @@ static inline void launch_gemm_nt(hipStream_t s, const bf16_t* A, int lda, const
         static std::atomic<unsigned long long> done_mask{0};
         const unsigned long long bit = 1ull << (dev & 63);
         if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
-            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, FLAGS, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<BM, BN, FLAGS, NS, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             done_mask.fetch_or(bit, std::memory_order_relaxed);
         }
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, FLAGS, NS>), dim3(grid), dim3(256), lds, s, A, lda, B, ldb, M, N, K, e, gm, ksplit);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, FLAGS, NS, FP8>), dim3(grid), dim3(256), lds, s, A, lda, B, ldb, M, N, K, e, gm, ksplit);
 }

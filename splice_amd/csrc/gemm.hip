@@ -91,3 +91,29 @@ int gemm_nt_launch(unsigned flags, const bf16_t* A, int lda, const bf16_t* B, in
     }
 #undef CASE
 }
+
+// ---- e4m3 operands (BASELINE configs[4]): the QKV projection of the fp8 ViT mode.  Same tile engine, loaders fed with the
+// byte geometry in 2-byte units; tile choice as for bf16 (the LDS footprint per slice is the same, the work per slice doubles).
+template <unsigned FLAGS>
+static int dispatch_fp8(const uint8_t* A, int lda, const uint8_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
+    const bf16_t* a = reinterpret_cast<const bf16_t*>(A);
+    const bf16_t* b = reinterpret_cast<const bf16_t*>(B);
+    const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t12864 = (long)cdiv(M, 128) * cdiv(N, 64);
+    if (t128 >= 420) launch_gemm_nt<128, 128, FLAGS, 2, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
+    else if (t12864 >= 400) launch_gemm_nt<128, 64, FLAGS, 3, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
+    else launch_gemm_nt<64, 64, FLAGS, 3, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
+    return SPLICE_OK;
+}
+int gemm_nt_fp8_launch(unsigned flags, const uint8_t* A, int lda, const uint8_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
+    if (M < 1 || N < 1 || K < 128 || K % 128 || lda % 16 || ldb % 16) return SPLICE_ERR_ARG;
+    if ((size_t)M * lda >= (1ull << 32) || (size_t)N * ldb >= (1ull << 32)) return SPLICE_ERR_ARG;
+    if (!(flags & EPI_SCALE_RC) || !e.row_scale || !e.col_scale) return SPLICE_ERR_ARG;
+    if ((flags & EPI_OUT_T) && (e.ldt % 4)) return SPLICE_ERR_ARG;
+    switch (flags) {
+        case EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T: return dispatch_fp8<EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T>(A, lda, B, ldb, M, N, K, e, s);
+        case EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T | EPI_COLS_F32:
+            return dispatch_fp8<EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T | EPI_COLS_F32>(A, lda, B, ldb, M, N, K, e, s);
+        case EPI_SCALE_RC | EPI_OUT_F32: return dispatch_fp8<EPI_SCALE_RC | EPI_OUT_F32>(A, lda, B, ldb, M, N, K, e, s);
+        default: return SPLICE_ERR_ARG;
+    }
+}

@@ -31,11 +31,20 @@ int gemm_nt_launch(unsigned flags, const bf16_t* A, int lda, const bf16_t* B, in
                    const GemmEpi& e, hipStream_t s);
 
 void gemm_force_tile(int t);   // benchmarking hook: 0 auto, 1 128x128, 2 128x64, 3 64x64
+// e4m3 operands (bytes; lda / ldb / K in elements = bytes): flags must include EPI_SCALE_RC
+int gemm_nt_fp8_launch(unsigned flags, const uint8_t* A, int lda, const uint8_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t s);
 
 // ---- vit_ops.hip -----------------------------------------------------------------------
 // LayerNorm over the last dim (D % 256 == 0 handled generally), one wave per row.
 int layernorm_fwd_launch(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
                          int rows, int D, float eps, hipStream_t s);
+// fp8 (e4m3) operand path: LayerNorm output quantised per token (y bytes [rows][D], yscale[rows]: y_true ~= y * yscale[row])
+int layernorm_fwd_fp8_launch(const float* x, const float* gamma, const float* beta, uint8_t* y, float* yscale, float* mean, float* rstd,
+                             int rows, int D, float eps, hipStream_t s);
+int quantize_rows_fp8_launch(const float* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int cols, hipStream_t s);
+int quantize_rows_bf16_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int cols, hipStream_t s);
+int quantize_keys_fp8_launch(const bf16_t* k, int ldk, size_t k_pstride, uint8_t* q, int ldq, size_t q_pstride, float* qnorm, int T, int Tp, int D,
+                             int pairs, hipStream_t s);
 // g_out = g_in + LN_backward(dy); also emits bf16(g_out).  dy is fp32 [rows][D].
 int layernorm_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                          const float* g_in, float* g_out, bf16_t* g_out_bf, int rows, int D, hipStream_t s);
@@ -100,6 +109,9 @@ struct SelfSimBatch {
     float* dk;                      // d keys fp32: pair p at + p * dk_pstride, [T][lddk]
     size_t dk_pstride; int lddk;
     float eps, e_scale, loss_scale; // e_scale = 4 lambda / T^2 ; loss_scale = 1 / T^2
+    int fp8;                        // != 0: the two Gram matrices run on the fp8 MFMA from per-row quantised keys (D % 128 == 0)
+    uint8_t *k8_tgt, *k8_x;         // [pairs][Tp][D] e4m3 rows (workspace)
+    float *qnorm_tgt, *qnorm_x;     // [pairs][Tp] norms of the quantised rows
 };
 size_t selfsim_batch_ws_bytes(int T, int D, int pairs);
 void selfsim_batch_carve(void* base, int T, int D, int pairs, SelfSimBatch* b);   // fills T, Tp, D, pairs and the workspace pointers

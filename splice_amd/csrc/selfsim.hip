@@ -258,26 +258,36 @@ __device__ __forceinline__ void tri_tile(int t, int nt, int& tm, int& tn) {
 }
 
 // upper-triangular tiles of S* = cos-sim(target keys) into the full-layout fp32 [T][T] buffer of each pair
+// FP8: the Gram matrix on the fp8 MFMA from per-row quantised keys (k8, e4m3; BASELINE configs[4]).  The cosine is scale
+// invariant per row, so the quantisation scales cancel against the norms of the QUANTISED rows (qnorm) exactly.
+template <bool FP8>
 __global__ __launch_bounds__(256) void selfsim_tgt_kernel(SelfSimBatch b) {
     extern __shared__ __attribute__((aligned(16))) bf16_t selfsim_smem[];
     const int T = b.T, nt = (T + 63) / 64, pair = blockIdx.y;
     int tm, tn;
     tri_tile(xcd_remap(blockIdx.x, gridDim.x), nt, tm, tn);
     const int m0 = tm * 64, n0 = tn * 64;
-    const bf16_t* K = b.k_tgt + (size_t)pair * b.k_pstride;
-    const float* norm = b.norm_tgt + (size_t)pair * b.Tp;
+    const float* norm = (FP8 ? b.qnorm_tgt : b.norm_tgt) + (size_t)pair * b.Tp;
     float* S = b.S_tgt + (size_t)pair * T * T;
-    GemmTile<64, 64> tile;
-    tile.template run_ring<SS_RING>(K, b.ldk, K, b.ldk, T, T, b.D, m0, n0, selfsim_smem);
+    GemmTile<64, 64, false, FP8> tile;
+    if (FP8) {
+        const bf16_t* K8 = reinterpret_cast<const bf16_t*>(b.k8_tgt + (size_t)pair * b.Tp * b.D);
+        tile.template run_ring<SS_RING>(K8, b.D / 2, K8, b.D / 2, T, T, b.D / 2, m0, n0, selfsim_smem);
+    } else {
+        const bf16_t* K = b.k_tgt + (size_t)pair * b.k_pstride;
+        tile.template run_ring<SS_RING>(K, b.ldk, K, b.ldk, T, T, b.D, m0, n0, selfsim_smem);
+    }
+    const float floor_ = FP8 ? 1e-30f : b.eps;
     tile.for_each(m0, n0, [&](int row0, int col, f32x4 v) {
         if (col >= T) return;
         const float nj = norm[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (row0 + r < T) S[(size_t)(row0 + r) * T + col] = v[r] / fmaxf(norm[row0 + r] * nj, b.eps);
+            if (row0 + r < T) S[(size_t)(row0 + r) * T + col] = v[r] / fmaxf(norm[row0 + r] * nj, floor_);
     });
 }
 
+template <bool FP8>
 __global__ __launch_bounds__(256) void selfsim_loss_kernel(SelfSimBatch b) {
     extern __shared__ __attribute__((aligned(16))) bf16_t selfsim_smem[];
     const int T = b.T, Tp = b.Tp, nt = Tp / 64, pair = blockIdx.y;
@@ -290,18 +300,30 @@ __global__ __launch_bounds__(256) void selfsim_loss_kernel(SelfSimBatch b) {
     const float* norm = b.norm_x + (size_t)pair * Tp;
     const float* St = b.S_tgt + (size_t)pair * T * T;
     bf16_t* W = b.wmat + (size_t)pair * Tp * Tp;
-    GemmTile<64, 64> tile;
-    tile.template run_ring<SS_RING>(K, b.ldk, K, b.ldk, T, T, b.D, m0, n0, selfsim_smem);
+    GemmTile<64, 64, false, FP8> tile;
+    if (FP8) {
+        const bf16_t* K8 = reinterpret_cast<const bf16_t*>(b.k8_x + (size_t)pair * Tp * b.D);
+        tile.template run_ring<SS_RING>(K8, b.D / 2, K8, b.D / 2, T, T, b.D / 2, m0, n0, selfsim_smem);
+    } else {
+        tile.template run_ring<SS_RING>(K, b.ldk, K, b.ldk, T, T, b.D, m0, n0, selfsim_smem);
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
     constexpr int FM = 2, FN = 2;
     // operands of every fragment first (clamped, always-valid addresses), arithmetic after
-    float nr[FM][4], nc[FN], st[FM][FN][4];
+    float nr[FM][4], nc[FN], st[FM][FN][4], qr[FM][4], qc[FN];
+    const float* qnorm = FP8 ? b.qnorm_x + (size_t)pair * Tp : norm;
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) nr[i][r] = norm[min(m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r, T - 1)];
+        for (int r = 0; r < 4; ++r) {
+            nr[i][r] = norm[min(m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r, T - 1)];
+            qr[i][r] = qnorm[min(m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r, T - 1)];
+        }
 #pragma unroll
-    for (int j = 0; j < FN; ++j) nc[j] = norm[min(n0 + wn * 32 + j * 16 + (lane & 15), T - 1)];
+    for (int j = 0; j < FN; ++j) {
+        nc[j] = norm[min(n0 + wn * 32 + j * 16 + (lane & 15), T - 1)];
+        qc[j] = qnorm[min(n0 + wn * 32 + j * 16 + (lane & 15), T - 1)];
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -328,7 +350,7 @@ __global__ __launch_bounds__(256) void selfsim_loss_kernel(SelfSimBatch b) {
                 const bool valid = row0 + r < T && col < T;
                 const float nn = nr[i][r] * nc[j];
                 const float c = fmaxf(nn, b.eps);
-                const float s = tile.acc[i][j][r] / c;
+                const float s = FP8 ? tile.acc[i][j][r] / fmaxf(qr[i][r] * qc[j], 1e-30f) : tile.acc[i][j][r] / c;
                 const float d = valid ? s - st[i][j][r] : 0.f;
                 lsum += d * d;
                 const float e = b.e_scale * d;                 // (dS + dS^T)_ij = 4 lambda d / T^2
@@ -410,21 +432,33 @@ int selfsim_norms_launch(const bf16_t* k, int ldk, size_t k_pstride, int T, int 
 }
 int selfsim_target_launch(const SelfSimBatch& b, hipStream_t s) {
     const int nt = b.Tp / 64;
+    if (b.fp8) {
+        if (b.D % 128) return SPLICE_ERR_ARG;
+        RC_SS(quantize_keys_fp8_launch(b.k_tgt, b.ldk, b.k_pstride, b.k8_tgt, b.D, (size_t)b.Tp * b.D, b.qnorm_tgt, b.T, b.Tp, b.D, b.pairs, s));
+        hipLaunchKernelGGL(selfsim_tgt_kernel<true>, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
+        return SPLICE_OK;
+    }
     RC_SS(selfsim_norms_launch(b.k_tgt, b.ldk, b.k_pstride, b.T, b.D, b.norm_tgt, b.pairs, s));
-    hipLaunchKernelGGL(selfsim_tgt_kernel, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
+    hipLaunchKernelGGL(selfsim_tgt_kernel<false>, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
     return SPLICE_OK;
 }
 int selfsim_loss_launch(const SelfSimBatch& b, hipStream_t s) {
     const int nt = b.Tp / 64;
     if (nt * (nt + 1) / 2 > (int)b.part_pstride) return SPLICE_ERR_ARG;
-    RC_SS(selfsim_norms_launch(b.k_x, b.ldk, b.k_pstride, b.T, b.D, b.norm_x, b.pairs, s));
-    hipLaunchKernelGGL(selfsim_loss_kernel, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
+    RC_SS(selfsim_norms_launch(b.k_x, b.ldk, b.k_pstride, b.T, b.D, b.norm_x, b.pairs, s));   // true norms: W and r are in key units either way
+    if (b.fp8) {
+        if (b.D % 128) return SPLICE_ERR_ARG;
+        RC_SS(quantize_keys_fp8_launch(b.k_x, b.ldk, b.k_pstride, b.k8_x, b.D, (size_t)b.Tp * b.D, b.qnorm_x, b.T, b.Tp, b.D, b.pairs, s));
+        hipLaunchKernelGGL(selfsim_loss_kernel<true>, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
+    } else {
+        hipLaunchKernelGGL(selfsim_loss_kernel<false>, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
+    }
     hipLaunchKernelGGL(selfsim_dk_kernel, dim3(nt * (b.D / 64), b.pairs), dim3(256), SS_LDS, s, b);
     return SPLICE_OK;
 }
 size_t selfsim_batch_ws_bytes(int T, int D, int pairs) {
     const size_t Tp = round_up(T, 64), nt = Tp / 64;
-    return (size_t)pairs * (2 * Tp * 4 + nt * Tp * 4 + Tp * Tp * 2 + (size_t)T * T * 4) + 1024;
+    return (size_t)pairs * (4 * Tp * 4 + nt * Tp * 4 + Tp * Tp * 2 + (size_t)T * T * 4 + 2 * Tp * D) + 2048;
 }
 void selfsim_batch_carve(void* base, int T, int D, int pairs, SelfSimBatch* b) {
     const size_t Tp = round_up(T, 64), nt = Tp / 64;
@@ -434,7 +468,11 @@ void selfsim_batch_carve(void* base, int T, int D, int pairs, SelfSimBatch* b) {
     b->wmat = (bf16_t*)p; p += (size_t)pairs * Tp * Tp * 2;
     b->norm_tgt = (float*)p; p += (size_t)pairs * Tp * 4;
     b->norm_x = (float*)p; p += (size_t)pairs * Tp * 4;
-    b->rpart = (float*)p;
+    b->qnorm_tgt = (float*)p; p += (size_t)pairs * Tp * 4;
+    b->qnorm_x = (float*)p; p += (size_t)pairs * Tp * 4;
+    b->rpart = (float*)p; p += (size_t)pairs * nt * Tp * 4; p = (char*)(((size_t)p + 255) & ~(size_t)255);
+    b->k8_tgt = (uint8_t*)p; p += (size_t)pairs * Tp * D;
+    b->k8_x = (uint8_t*)p;
 }
 
 // ---- batched strided MSE (blockIdx.y = pair): the [CLS] and key-identity terms of P pairs in one launch each

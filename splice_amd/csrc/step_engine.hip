@@ -239,6 +239,7 @@ static int ssim_batch(SpliceStep* st, VitView& v, int pass_tgt, int pass_x, int 
     b->loss_part = loss_part(st, slot); b->part_pstride = st->lstride;
     b->dk = v.d_keys + (size_t)pass_x * v.Tld * v.D; b->dk_pstride = (size_t)v.Tld * v.D; b->lddk = v.D;
     b->eps = 1e-8f;
+    b->fp8 = st->cfg.fp8_selfsim && v.D % 128 == 0;
     b->loss_scale = 1.0f / ((float)v.T * (float)v.T);
     b->e_scale = 4.0f * lambda * b->loss_scale;
     return SPLICE_OK;

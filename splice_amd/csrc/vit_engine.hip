@@ -15,6 +15,7 @@
 #include "kernels.h"
 
 void splice_set_error(const char* fmt, ...);
+extern "C" int splice_vit_params_complete(void* vit);
 
 #define HIPCHK(x)                                                                                 \
     do {                                                                                          \
@@ -64,6 +65,8 @@ struct Linear {
     bf16_t* wT = nullptr;   // [in][out]
     float* b = nullptr;     // [out]
     int out = 0, in = 0;
+    uint8_t* w8 = nullptr;  // [out][in] e4m3, quantised per output channel (fp8 mode, qkv only)
+    float* w8_scale = nullptr;   // [out]
 };
 struct LayerW {
     float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
@@ -81,6 +84,7 @@ struct SpliceVit {
     float *norm_g = nullptr, *norm_b = nullptr;
     std::vector<void*> allocs;
     int n_set = 0;
+    int fp8 = 0;            // QKV projection on the fp8 MFMA (splice_vit_enable_fp8)
 };
 
 struct SpliceVitCtx {
@@ -96,6 +100,8 @@ struct SpliceVitCtx {
     std::vector<float*> lse;               // depth x [B][H][Tld]
     float* qkv_last_f32 = nullptr;         // [rows][3D]
     bf16_t* ln_out = nullptr;              // [rows][D]   transient
+    uint8_t* ln_out8 = nullptr;            // [rows][D]   e4m3 LayerNorm output (fp8 mode)
+    float* ln_scale = nullptr;             // [rows]      its per-token scales
     bf16_t* hact = nullptr;                // [rows][4D]  transient
     // backward temporaries (sized for all rows)
     float* g = nullptr;                    // [rows][D]
@@ -223,6 +229,23 @@ int splice_vit_set_param(void* h, const char* name, const float* data, long long
     return SPLICE_OK;
 }
 
+// BASELINE configs[4] ("fp8 MFMA attention + self-sim path"): from now on every context created on this engine runs its
+// QKV projections on the fp8 MFMA -- LayerNorm output quantised per token to e4m3 where it is produced, weights quantised
+// once per output channel here, de-quantisation in the GEMM epilogue.  Needs dim % 128 == 0.  The dgrad path is unchanged.
+int splice_vit_enable_fp8(void* h, splice_stream_t stream) {
+    SpliceVit* v = (SpliceVit*)h;
+    if (!v || !splice_vit_params_complete(h) || v->dim % 128) { splice_set_error("splice_vit_enable_fp8: incomplete weights or dim %% 128 != 0"); return SPLICE_ERR_STATE; }
+    hipStream_t s = (hipStream_t)stream;
+    for (auto& L : v->layers) {
+        if (L.qkv.w8) continue;
+        RC(dev_alloc(v->allocs, &L.qkv.w8, (size_t)L.qkv.out * L.qkv.in));
+        RC(dev_alloc(v->allocs, &L.qkv.w8_scale, (size_t)L.qkv.out));
+        RC(quantize_rows_bf16_fp8_launch(L.qkv.w, L.qkv.in, L.qkv.w8, L.qkv.in, L.qkv.w8_scale, L.qkv.out, L.qkv.in, s));
+    }
+    v->fp8 = 1;
+    return SPLICE_OK;
+}
+
 int splice_vit_params_complete(void* h) {
     SpliceVit* v = (SpliceVit*)h;
     if (!v) return 0;
@@ -285,6 +308,7 @@ int splice_vit_ctx_create(void* h, int B, int H, int W, const float* pos_TD, int
     }
     A(c->qkv_last_f32, rows * 3 * D);
     A(c->ln_out, rows * D);
+    if (v->fp8) { A(c->ln_out8, rows * D); A(c->ln_scale, rows); }
     A(c->hact, rows * Hd);
     if (need_grad) {
         A(c->g, rows * D); A(c->g_bf, rows * D); A(c->dh, rows * Hd); A(c->dln, rows * D * 4);   // dln: up to 4 split-K slabs
@@ -396,14 +420,21 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
         const LayerW& W = v->layers[l];
         float* x_in = c->xs[l] + r0 * D;
         float* x_mid = c->xmid[l] + r0 * D;
-        RC(layernorm_fwd_launch(x_in, W.ln1_g, W.ln1_b, ln_out, c->mean1[l] + r0, c->rstd1[l] + r0, R, D, 1e-6f, s));
+        const bool fp8 = v->fp8 && c->ln_out8 && W.qkv.w8;
+        if (fp8) RC(layernorm_fwd_fp8_launch(x_in, W.ln1_g, W.ln1_b, c->ln_out8 + r0 * D, c->ln_scale + r0, c->mean1[l] + r0, c->rstd1[l] + r0, R, D, 1e-6f, s));
+        else RC(layernorm_fwd_launch(x_in, W.ln1_g, W.ln1_b, ln_out, c->mean1[l] + r0, c->rstd1[l] + r0, R, D, 1e-6f, s));
         {
             GemmEpi e = {};
             e.bias = W.qkv.b; e.out_bf = c->qkv[l] + r0 * 3 * D; e.ldbf = 3 * D; e.out_bf_t = c->qkvT[l] + r0; e.ldt = c->rows;
             unsigned fl = EPI_BIAS | EPI_OUT_BF | EPI_OUT_T;
             if (l == L - 1) { fl |= EPI_COLS_F32; e.out_f32_cols = c->qkv_last_f32 + r0 * 3 * D; e.ld_cols = 3 * D; e.col_lo = 0; e.col_hi = 3 * D; }
             ProfScope ps(l == L - 1 ? 0 : 2, s);
-            RC(gemm_nt_launch(fl, ln_out, D, W.qkv.w, D, R, 3 * D, D, e, s));
+            if (fp8) {   // e4m3 LayerNorm output (per-token scale) x e4m3 weights (per-channel scale) on the fp8 MFMA
+                e.row_scale = c->ln_scale + r0; e.col_scale = W.qkv.w8_scale;
+                RC(gemm_nt_fp8_launch(fl | EPI_SCALE_RC, c->ln_out8 + r0 * D, D, W.qkv.w8, D, R, 3 * D, D, e, s));
+            } else {
+                RC(gemm_nt_launch(fl, ln_out, D, W.qkv.w, D, R, 3 * D, D, e, s));
+            }
         }
         {
             AttnArgs a = {};

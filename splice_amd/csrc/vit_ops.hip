@@ -62,6 +62,126 @@ int layernorm_fwd_launch(const float* x, const float* gamma, const float* beta, 
     return SPLICE_OK;
 }
 
+// ---- fp8 (e4m3, OCP) operand path: the LayerNorm output quantised per TOKEN where it is produced (the row is in
+// registers: its amax is one wave reduction), q = fp8(y * 448 / amax), scale = amax / 448
+__device__ __forceinline__ uint32_t pack4fp8(float a, float b, float c, float d) {
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (uint32_t)v;
+}
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_fwd_fp8_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, uint8_t* __restrict__ y, float* __restrict__ yscale,
+                                                                float* __restrict__ mean_o, float* __restrict__ rstd_o, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = D >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+    float4 v[MAXV], gv[MAXV], bv[MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (64 * i >= nv) continue;
+        const int j = min(lane + 64 * i, nv - 1);
+        v[i] = xr[j]; gv[i] = g4[j]; bv[i] = b4[j];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (!(64 * i < nv && lane + 64 * i < nv)) v[i] = float4{0.f, 0.f, 0.f, 0.f};
+        sum += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (lane + 64 * i < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            sq += a * a + b * b + c * c + d * d;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+    if (lane == 0 && mean_o) { mean_o[row] = mean; rstd_o[row] = rstd; }
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (lane + 64 * i < nv) {
+            const float4 g = gv[i], b = bv[i];
+            v[i] = float4{(v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y, (v[i].z - mean) * rstd * g.z + b.z,
+                          (v[i].w - mean) * rstd * g.w + b.w};
+            amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+        }
+    }
+    amax = fmaxf(wave_max(amax), 1e-20f);
+    const float q = 448.0f / amax;
+    if (lane == 0) yscale[row] = amax / 448.0f;
+    uint32_t* yr = reinterpret_cast<uint32_t*>(y + (size_t)row * D);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nv) yr[lane + 64 * i] = pack4fp8(v[i].x * q, v[i].y * q, v[i].z * q, v[i].w * q);
+}
+int layernorm_fwd_fp8_launch(const float* x, const float* gamma, const float* beta, uint8_t* y, float* yscale, float* mean, float* rstd,
+                             int rows, int D, float eps, hipStream_t s) {
+    if (D % 4 || D > 64 * 4 * 4) return SPLICE_ERR_ARG;
+    hipLaunchKernelGGL(layernorm_fwd_fp8_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, gamma, beta, y, yscale, mean, rstd, rows, D, eps);
+    return SPLICE_OK;
+}
+// q[r][:] = fp8(x[r][:] * 448 / amax_r), scale[r] = amax_r / 448; x fp32 or bf16 rows; one wave per row
+template <class T>
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const T* __restrict__ x, int ldx, uint8_t* __restrict__ q, int ldq, float* __restrict__ scale,
+                                                                float* __restrict__ qnorm, int rows, int cols, size_t x_pstride, size_t q_pstride, int rows_alloc) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows_alloc) return;
+    const T* xr = x + (size_t)blockIdx.y * x_pstride + (size_t)row * ldx;
+    auto ld = [&](int c) -> float {
+        if constexpr (sizeof(T) == 2) return bf2f(xr[c]);
+        else return xr[c];
+    };
+    float amax = 0.f;
+    if (row < rows)
+        for (int c = lane; c < cols; c += 64) amax = fmaxf(amax, fabsf(ld(c)));
+    amax = fmaxf(wave_max(amax), 1e-20f);
+    const float sc = 448.0f / amax;
+    uint32_t* qr = reinterpret_cast<uint32_t*>(q + (size_t)blockIdx.y * q_pstride + (size_t)row * ldq);
+    float sq = 0.f;
+    for (int c4 = lane; c4 < cols / 4; c4 += 64) {
+        uint32_t pk = 0;
+        if (row < rows) {
+            pk = pack4fp8(ld(4 * c4) * sc, ld(4 * c4 + 1) * sc, ld(4 * c4 + 2) * sc, ld(4 * c4 + 3) * sc);
+            const float f0 = __builtin_amdgcn_cvt_f32_fp8((int)pk, 0), f1 = __builtin_amdgcn_cvt_f32_fp8((int)pk, 1),
+                        f2 = __builtin_amdgcn_cvt_f32_fp8((int)pk, 2), f3 = __builtin_amdgcn_cvt_f32_fp8((int)pk, 3);
+            sq += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+        }
+        qr[c4] = pk;
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) {
+        if (scale) scale[(size_t)blockIdx.y * rows_alloc + row] = row < rows ? amax / 448.0f : 0.f;
+        if (qnorm) qnorm[(size_t)blockIdx.y * rows_alloc + row] = sqrtf(sq);   // L2 norm of the QUANTISED row (in quantised units)
+    }
+}
+int quantize_rows_fp8_launch(const float* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int cols, hipStream_t s) {
+    if (cols % 4 || ldq % 4) return SPLICE_ERR_ARG;
+    hipLaunchKernelGGL(quantize_rows_fp8_kernel<float>, dim3(cdiv(rows, 4), 1), dim3(256), 0, s, x, ldx, q, ldq, scale, (float*)nullptr, rows, cols, (size_t)0, (size_t)0, rows);
+    return SPLICE_OK;
+}
+// bf16 rows -> fp8 rows of `pairs` problems at once (+ the norm of every quantised row): the keys of the structure loss
+int quantize_keys_fp8_launch(const bf16_t* k, int ldk, size_t k_pstride, uint8_t* q, int ldq, size_t q_pstride, float* qnorm, int T, int Tp, int D,
+                             int pairs, hipStream_t s) {
+    if (D % 4 || ldq % 4) return SPLICE_ERR_ARG;
+    hipLaunchKernelGGL(quantize_rows_fp8_kernel<bf16_t>, dim3(cdiv(Tp, 4), pairs), dim3(256), 0, s, k, ldk, q, ldq, (float*)nullptr, qnorm, T, D, k_pstride, q_pstride, Tp);
+    return SPLICE_OK;
+}
+int quantize_rows_bf16_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int cols, hipStream_t s) {
+    if (cols % 4 || ldq % 4) return SPLICE_ERR_ARG;
+    hipLaunchKernelGGL(quantize_rows_fp8_kernel<bf16_t>, dim3(cdiv(rows, 4), 1), dim3(256), 0, s, x, ldx, q, ldq, scale, (float*)nullptr, rows, cols, (size_t)0, (size_t)0, rows);
+    return SPLICE_OK;
+}
+
 // dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)),  dxhat = dy * gamma
 constexpr int LN_MAX_SLABS = 4;
 template <int MAXV>

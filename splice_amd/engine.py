@@ -47,7 +47,7 @@ class MultiPairEngine:
     bit-identical whichever batch it rides in (tests/test_multipair_gpu.py).  All pairs of a batch share the image and
     crop sizes."""
 
-    def __init__(self, cfg, vit_state, gen_states, crop_hw, entire_hw=None, device="cuda", vit_engine=None, n_crops=1):
+    def __init__(self, cfg, vit_state, gen_states, crop_hw, entire_hw=None, device="cuda", vit_engine=None, n_crops=1, fp8=False):
         """cfg: reference config keys (conf/default/config.yaml); vit_state: DINO state dict; gen_states: list of P generator
         state dicts (reference names); crop_hw: (h, w) of the (largest) global crops; entire_hw: (H, W) of the whole
         structure image or None to disable the entire branch.  ``n_crops`` > 1 (one pair only): the reference's
@@ -63,6 +63,11 @@ class MultiPairEngine:
         self.device = torch.device(device)
         self.P = P = len(gen_states)
         self.vit = vit_engine or VitEngine(c["dino_model_name"], device=device).load_state_dict(vit_state)
+        # fp8=True (BASELINE configs[4]): QKV projections and the key self-similarity Gram matrices on the fp8 MFMA; everything
+        # else (attention, MLP, the whole backward) stays bf16 / fp32.  Own tolerance table: tests/test_fp8_gpu.py.
+        self.fp8 = bool(fp8)
+        if self.fp8 and not getattr(self.vit, "fp8", False):
+            self.vit.enable_fp8()
         self.gen = GeneratorEngine(device=device)
         n = self.gen.numel
         self.stride = n if P == 1 else (n + 63) // 64 * 64
@@ -91,7 +96,7 @@ class MultiPairEngine:
         self.plan_b = GeneratorPlan(self.gen, slots, ch, cw, True, arena_stride, batch_stats=batch)
         sc = _lib.StepConfig()
         sc.crop_h, sc.crop_w, sc.vit_h, sc.vit_w = ch, cw, vh, vw
-        sc.pairs, sc.arena_stride, sc.n_crops = P, arena_stride, self.n_crops
+        sc.pairs, sc.arena_stride, sc.n_crops, sc.fp8_selfsim = P, arena_stride, self.n_crops, int(self.fp8)
         self.ctx_e = self.plan_e = None
         self.entire_hw = entire_hw
         use_entire = entire_hw is not None and (c["lambda_entire_ssim"] > 0 or c["lambda_entire_cls"] > 0)
@@ -205,8 +210,8 @@ class MultiPairEngine:
 class SpliceEngine(MultiPairEngine):
     """The per-pair optimisation loop of ``train.py:34-80`` for ONE pair (P = 1): the reference's unit of work."""
 
-    def __init__(self, cfg, vit_state, gen_state, crop_hw, entire_hw=None, device="cuda", vit_engine=None, n_crops=1):
-        super().__init__(cfg, vit_state, [gen_state], crop_hw, entire_hw, device=device, vit_engine=vit_engine, n_crops=n_crops)
+    def __init__(self, cfg, vit_state, gen_state, crop_hw, entire_hw=None, device="cuda", vit_engine=None, n_crops=1, fp8=False):
+        super().__init__(cfg, vit_state, [gen_state], crop_hw, entire_hw, device=device, vit_engine=vit_engine, n_crops=n_crops, fp8=fp8)
 
     def losses(self):
         return super().losses(0)
@@ -219,13 +224,14 @@ class MultiScaleEngine:
     scale); built from one fused step per scale in gradient-only mode (``splice_step_set_mode``) sharing the parameter /
     gradient / moment arenas, followed by the fused Adam launch."""
 
-    def __init__(self, cfg, vit_state, gen_state, crop_hw, entire_hw=None, scales=(224, 320, 448), device="cuda", vit_engine=None, n_crops=1):
+    def __init__(self, cfg, vit_state, gen_state, crop_hw, entire_hw=None, scales=(224, 320, 448), device="cuda", vit_engine=None, n_crops=1,
+                 fp8=False):
         self.cfg = dict(DEFAULT_CFG, **cfg)
         self.scales = tuple(scales)
         self.engines = []
         for k, sz in enumerate(self.scales):
             e = SpliceEngine(dict(self.cfg, dino_global_patch_size=sz), vit_state if k == 0 else None, gen_state, crop_hw, entire_hw, device=device,
-                             vit_engine=vit_engine if k == 0 else self.engines[0].vit, n_crops=n_crops)
+                             vit_engine=vit_engine if k == 0 else self.engines[0].vit, n_crops=n_crops, fp8=fp8)
             _lib.check(_lib.lib().splice_step_set_mode(e.handle, 1, int(k > 0)), "step_set_mode")
             if k > 0:   # one parameter set: every scale reads / writes the arenas of the first engine; netG bookkeeping once
                 e.params, e.grads, e.m, e.v = self.engines[0].params, self.engines[0].grads, self.engines[0].m, self.engines[0].v
@@ -252,7 +258,7 @@ class MultiScaleEngine:
         return self.engines[0].generate(img)
 
 
-def synthetic_engine(cfg, pair_id=0, hw=(224, 224), seed=1234, device="cuda", vit_engine=None, entire=True, pairs=1):
+def synthetic_engine(cfg, pair_id=0, hw=(224, 224), seed=1234, device="cuda", vit_engine=None, entire=True, pairs=1, fp8=False):
     """Engine + inputs for the BASELINE benchmark configs: seeded synthetic ViT weights, xavier generator init and U[0,1)
     pairs.  ``pairs`` > 1: pairs ``pair_id .. pair_id + pairs - 1`` side by side on one engine
     (inputs ``[P,3,h,w]``); ``pairs == 1``: the single-pair ``SpliceEngine`` with ``[3,h,w]`` inputs."""
@@ -265,9 +271,9 @@ def synthetic_engine(cfg, pair_id=0, hw=(224, 224), seed=1234, device="cuda", vi
     gen_states = [synth.generator_params(seed + 1 + i, c["init_gain"]) for i in ids]
     imgs = [synth.image_pair(seed, i, hw[0], hw[1]) for i in ids]
     if pairs == 1:
-        eng = SpliceEngine(c, vit_state, gen_states[0], hw, hw if entire else None, device=device, vit_engine=vit_engine)
+        eng = SpliceEngine(c, vit_state, gen_states[0], hw, hw if entire else None, device=device, vit_engine=vit_engine, fp8=fp8)
         return eng, torch.from_numpy(imgs[0][0]).to(device), torch.from_numpy(imgs[0][1]).to(device)
-    eng = MultiPairEngine(c, vit_state, gen_states, hw, hw if entire else None, device=device, vit_engine=vit_engine)
+    eng = MultiPairEngine(c, vit_state, gen_states, hw, hw if entire else None, device=device, vit_engine=vit_engine, fp8=fp8)
     A = torch.from_numpy(np.stack([a for a, _ in imgs])).to(device)
     B = torch.from_numpy(np.stack([b for _, b in imgs])).to(device)
     return eng, A, B

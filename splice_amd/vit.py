@@ -136,6 +136,15 @@ class VitEngine:
             raise RuntimeError("VitEngine.load_state_dict: state dict is missing DINO ViT entries")
         return self
 
+    def enable_fp8(self):
+        """BASELINE configs[4]: QKV projections of every context created FROM NOW ON run on the fp8 MFMA (e4m3 operands,
+        per-token x per-channel scales).  Cached contexts are dropped so that none keeps the bf16 path."""
+        _lib.check(_lib.lib().splice_vit_enable_fp8(self.handle, _lib.current_stream()), "vit_enable_fp8")
+        torch.cuda.current_stream().synchronize()
+        self._ctx.clear()
+        self.fp8 = True
+        return self
+
     def context(self, B, H, W, need_grad=True):
         key = (B, H, W, bool(need_grad))
         if key not in self._ctx:
