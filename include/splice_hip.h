@@ -207,6 +207,20 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
  * ONE flat fp32 arena in netG.parameters() order; splice_gen_tensor_info gives the per-tensor
  * (state_dict name, offset, numel) table.  A plan = (N side-by-side generator calls, H, W). */
 int splice_gen_create(void** out_handle);
+/* Any skip() the kernels cover (models/unet/skip.py:4-11): e.g. the feature-inversion net of inversion.py:21-25 -- 6 scales,
+ * 32 noise input channels, filter_size_down = filter_size_up = {7,7,5,5,3,3}, pad = 'reflection'.  Same engine, same plans,
+ * same flat parameter arena (state_dict names follow the reference's numbering, incl. the ".1" Conv2d index behind a
+ * ReflectionPad2d).  Fixed: stride-2 'stride' down-sampling, bilinear up-sampling, LeakyReLU(0.2), 1x1 skip and post-up
+ * filters, sigmoid head, every scale with skip channels.  NULL = the default architecture of define_G. */
+#define SPLICE_GEN_MAX_SCALES 6
+typedef struct splice_gen_arch {
+    int n_scales, in_channels, out_channels;
+    int down[SPLICE_GEN_MAX_SCALES], up[SPLICE_GEN_MAX_SCALES], skip[SPLICE_GEN_MAX_SCALES];   /* channels (<= 128) */
+    int filter_down[SPLICE_GEN_MAX_SCALES], filter_up[SPLICE_GEN_MAX_SCALES];                  /* 1 / 3 / 5 / 7 */
+    int filter_skip;                                                                          /* 1 */
+    int reflect;                                                                              /* pad = 'reflection' (else 'zero') */
+} splice_gen_arch;
+int splice_gen_create_arch(const splice_gen_arch* arch, void** out_handle);
 void splice_gen_destroy(void* gen);
 long long splice_gen_param_count(void* gen);
 int splice_gen_num_tensors(void* gen);

@@ -28,6 +28,12 @@ class GemmEpilogue(C.Structure):
     ]
 
 
+class GenArch(C.Structure):
+    _fields_ = [("n_scales", C.c_int), ("in_channels", C.c_int), ("out_channels", C.c_int),
+                ("down", C.c_int * 6), ("up", C.c_int * 6), ("skip", C.c_int * 6),
+                ("filter_down", C.c_int * 6), ("filter_up", C.c_int * 6), ("filter_skip", C.c_int), ("reflect", C.c_int)]
+
+
 class StepConfig(C.Structure):
     _fields_ = [
         ("crop_h", C.c_int), ("crop_w", C.c_int), ("vit_h", C.c_int), ("vit_w", C.c_int),
@@ -87,6 +93,7 @@ _SIGNATURES = {
     "splice_vit_backward": ([_vp, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp, _i, _vp], _i),
     # generator engine
     "splice_gen_create": ([C.POINTER(_vp)], _i),
+    "splice_gen_create_arch": ([C.POINTER(GenArch), C.POINTER(_vp)], _i),
     "splice_gen_destroy": ([_vp], None),
     "splice_gen_param_count": ([_vp], C.c_longlong),
     "splice_gen_num_tensors": ([_vp], _i),

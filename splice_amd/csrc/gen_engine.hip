@@ -25,9 +25,17 @@ void splice_set_error(const char* fmt, ...);
         }                                                                                         \
     } while (0)
 
-static const int DOWN[5] = {16, 32, 64, 128, 128};
-static const int UP[5] = {16, 32, 64, 128, 128};
-static const int SKIPC = 4;
+// Architecture of a skip() network (models/unet/skip.py:4-11): define_G builds the default one; the feature-inversion
+// experiment (inversion.py:21-25) asks for 6 scales, 7/7/5/5/3/3 filters, reflection padding and 32 input channels.
+constexpr int MAXS = SPLICE_GEN_MAX_SCALES;
+typedef splice_gen_arch GenArch;
+static GenArch default_arch() {
+    GenArch a = {};
+    a.n_scales = 5; a.in_channels = 3; a.out_channels = 3; a.filter_skip = 1; a.reflect = 0;
+    const int ch[5] = {16, 32, 64, 128, 128};
+    for (int i = 0; i < 5; ++i) { a.down[i] = ch[i]; a.up[i] = ch[i]; a.skip[i] = 4; a.filter_down[i] = 3; a.filter_up[i] = 3; }
+    return a;
+}
 static const float BN_EPS = 1e-5f;
 static const float LRELU = 0.2f;
 
@@ -64,6 +72,7 @@ struct Unit {
 };
 
 struct SpliceGen {
+    GenArch arch;
     ParamTable table;
     ParamTable buffers;   // BatchNorm running statistics in state_dict order: "<bn>.running_mean" (C floats) then "<bn>.running_var" (C floats)
 };
@@ -73,12 +82,13 @@ struct SpliceGenPlan {
     int N = 0, H = 0, W = 0, need_grad = 0, maxH = 0, maxW = 0;
     size_t p_nstride = 0;                 // > 0: the N images are independent generators -- image n uses params / grads + n * p_nstride
     int batch_stats = 0;                  // != 0: ONE netG call on a batch of N images -- BatchNorm statistics over the whole batch
-    int h[6], w[6];                       // spatial size at scale i (h[0] = H)
+    int h[MAXS + 1], w[MAXS + 1];         // spatial size at scale i (h[0] = H)
     std::vector<void*> allocs;
     // per scale
-    Unit u_skip[5], u_da[5], u_db[5], u_cat[5], u_up3[5], u_up1[5];
-    float* cat[5]; float* d_cat[5];       // [N][4+k][h][w]
-    int kch[5];
+    Unit u_skip[MAXS], u_da[MAXS], u_db[MAXS], u_cat[MAXS], u_up3[MAXS], u_up1[MAXS];
+    float* cat[MAXS]; float* d_cat[MAXS]; // [N][skip+k][h][w]
+    int kch[MAXS];
+    float* pad_scratch = nullptr;         // reflection padding: padded-domain data gradient of one layer (largest layer)
     float* head_y = nullptr;              // unused (sigmoid fused)
     size_t head_w = 0, head_b = 0;
     float* d_head_pre = nullptr;          // [N][3][H][W]
@@ -96,7 +106,10 @@ struct SpliceGenPlan {
     int forward_saved = 0;
 };
 
-static void build_table(ParamTable& t, size_t* offs /* [5][6 units][4] */, size_t* head, ParamTable* bufs = nullptr, size_t* roffs /* [5][6] */ = nullptr) {
+static void build_table(const GenArch& A, ParamTable& t, size_t* offs /* [MAXS][6 units][4] */, size_t* head, ParamTable* bufs = nullptr,
+                        size_t* roffs /* [MAXS][6] */ = nullptr) {
+    // a conv is nn.Sequential([ReflectionPad2d,] Conv2d): the Conv2d is child "1" behind a padder, child "0" otherwise (models/unet/common.py:113-124)
+    const std::string cv = A.reflect ? ".1" : ".0";
     auto conv = [&](const std::string& n, int co, int ci, int k, size_t* o) {
         o[0] = t.add(n + ".weight", (size_t)co * ci * k * k);
         o[1] = t.add(n + ".bias", co);
@@ -111,28 +124,28 @@ static void build_table(ParamTable& t, size_t* offs /* [5][6 units][4] */, size_
             if (cur_r) *cur_r = r;
         }
     };
-    std::string prefix[5];
-    for (int i = 1; i < 5; ++i) prefix[i] = prefix[i - 1] + "1.1.7.";
+    std::string prefix[MAXS];
+    for (int i = 1; i < A.n_scales; ++i) prefix[i] = prefix[i - 1] + "1.1.7.";
     // registration order is recursive (skip.py:46-99): skip, down-a, down-b of scale i, then all of scale
     // i+1, then cat-BN, up3, up1 of scale i.
     struct Rec {
-        static void go(int i, int cin, ParamTable& t, size_t* offs, std::string* prefix,
+        static void go(const GenArch& A, const std::string& cv, int i, int cin, ParamTable& t, size_t* offs, std::string* prefix,
                        decltype(conv)& conv, decltype(bn)& bn, size_t*& cur_r, size_t* roffs) {
             const std::string p = prefix[i];
             size_t* o = offs + (size_t)i * 6 * 4;
             auto at = [&](int unit) { cur_r = roffs ? roffs + i * 6 + unit : nullptr; };
-            conv(p + "1.0.1.0", SKIPC, cin, 1, o + 0 * 4); at(0); bn(p + "1.0.2", SKIPC, o + 0 * 4);
-            conv(p + "1.1.1.0", DOWN[i], cin, 3, o + 1 * 4); at(1); bn(p + "1.1.2", DOWN[i], o + 1 * 4);
-            conv(p + "1.1.4.0", DOWN[i], DOWN[i], 3, o + 2 * 4); at(2); bn(p + "1.1.5", DOWN[i], o + 2 * 4);
-            int k = DOWN[i];
-            if (i < 4) { go(i + 1, DOWN[i], t, offs, prefix, conv, bn, cur_r, roffs); k = UP[i + 1]; }
-            at(3); bn(p + "2", SKIPC + k, o + 3 * 4);
-            conv(p + "3.0", UP[i], SKIPC + k, 3, o + 4 * 4); at(4); bn(p + "4", UP[i], o + 4 * 4);
-            conv(p + "6.0", UP[i], UP[i], 1, o + 5 * 4); at(5); bn(p + "7", UP[i], o + 5 * 4);
+            conv(p + "1.0.1" + cv, A.skip[i], cin, A.filter_skip, o + 0 * 4); at(0); bn(p + "1.0.2", A.skip[i], o + 0 * 4);
+            conv(p + "1.1.1" + cv, A.down[i], cin, A.filter_down[i], o + 1 * 4); at(1); bn(p + "1.1.2", A.down[i], o + 1 * 4);
+            conv(p + "1.1.4" + cv, A.down[i], A.down[i], A.filter_down[i], o + 2 * 4); at(2); bn(p + "1.1.5", A.down[i], o + 2 * 4);
+            int k = A.down[i];
+            if (i < A.n_scales - 1) { go(A, cv, i + 1, A.down[i], t, offs, prefix, conv, bn, cur_r, roffs); k = A.up[i + 1]; }
+            at(3); bn(p + "2", A.skip[i] + k, o + 3 * 4);
+            conv(p + "3" + cv, A.up[i], A.skip[i] + k, A.filter_up[i], o + 4 * 4); at(4); bn(p + "4", A.up[i], o + 4 * 4);
+            conv(p + "6" + cv, A.up[i], A.up[i], 1, o + 5 * 4); at(5); bn(p + "7", A.up[i], o + 5 * 4);
         }
     };
-    Rec::go(0, 3, t, offs, prefix, conv, bn, cur_r, roffs);
-    conv("9.0", 3, UP[0], 1, head);
+    Rec::go(A, cv, 0, A.in_channels, t, offs, prefix, conv, bn, cur_r, roffs);
+    conv("9" + cv, A.out_channels, A.up[0], 1, head);
 }
 
 template <class T>
@@ -168,12 +181,14 @@ static int unit_alloc(SpliceGenPlan* p, Unit& u, bool own_out) {
 static void plan_configure(SpliceGenPlan* p, int H, int W) {
     p->H = H; p->W = W;
     p->h[0] = H; p->w[0] = W;
-    for (int i = 1; i <= 5; ++i) { p->h[i] = (p->h[i - 1] + 1) / 2; p->w[i] = (p->w[i - 1] + 1) / 2; }
+    const GenArch& A = p->gen->arch;
+    const int S = A.n_scales;
+    for (int i = 1; i <= S; ++i) { p->h[i] = (p->h[i - 1] + 1) / 2; p->w[i] = (p->w[i - 1] + 1) / 2; }
     const bool ng = p->need_grad;
-    for (int i = 0; i < 5; ++i) {
-        const int cin = i == 0 ? 3 : DOWN[i - 1];
+    for (int i = 0; i < S; ++i) {
+        const int cin = i == 0 ? A.in_channels : A.down[i - 1];
         const int hi = p->h[i], wi = p->w[i], hd = p->h[i + 1], wd = p->w[i + 1];
-        const size_t catC = SKIPC + p->kch[i];
+        const size_t catC = A.skip[i] + p->kch[i];
         const size_t cat_ns = catC * hi * wi;
         Unit &sk = p->u_skip[i], &da = p->u_da[i], &db = p->u_db[i], &ct = p->u_cat[i], &u3 = p->u_up3[i], &u1 = p->u_up1[i];
         auto dims = [](Unit& u, int Hi, int Wi, int Ho, int Wo) {
@@ -197,7 +212,7 @@ static void plan_configure(SpliceGenPlan* p, int H, int W) {
             u1.d_in = u3.d_out; u1.d_in_ns = u3.d_out_ns;
         }
     }
-    for (int i = 1; i < 5; ++i) {   // x_{i+1} = db_i.out ; d x_{i+1} = db_i.d_out
+    for (int i = 1; i < S; ++i) {   // x_{i+1} = db_i.out ; d x_{i+1} = db_i.d_out
         p->u_skip[i].in = p->u_db[i - 1].out; p->u_da[i].in = p->u_db[i - 1].out;
         if (ng) {
             p->u_da[i].d_in = p->u_db[i - 1].d_out; p->u_da[i].d_in_ns = p->u_db[i - 1].d_out_ns; p->u_da[i].d_in_accumulate = 0;  // first writer
@@ -217,7 +232,7 @@ static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* para
         a.in_nstride = u.in_ns; a.in_cstride = (size_t)u.Hi * u.Wi; a.out_nstride = u.y_ns; a.out_cstride = (size_t)u.Ho * u.Wo;
         a.w_jstride = (size_t)u.Cin * u.ks * u.ks; a.w_cstride = (size_t)u.ks * u.ks; a.p_nstride = p->p_nstride;
         a.N = N; a.Cin = u.Cin; a.Hi = u.Hi; a.Wi = u.Wi; a.Cout = u.Cout; a.Ho = u.Ho; a.Wo = u.Wo;
-        a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2;
+        a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2; a.reflect = p->gen->arch.reflect && u.ks > 1;
         a.ws = p->conv_ws; a.ws_floats = p->conv_ws_floats;
         // small planes: a split-K convolution leaves its slabs for the BatchNorm kernel, which adds them while it loads the plane
         a.defer_reduce = !p->batch_stats && u.Ho * u.Wo <= bn_small_hw();
@@ -263,7 +278,7 @@ static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* par
         a.x = u.in; a.dy = u.dy;
         a.x_nstride = u.in_ns; a.x_cstride = (size_t)u.Hi * u.Wi; a.dy_nstride = u.y_ns; a.dy_cstride = (size_t)HW;
         a.N = N; a.Cin = u.Cin; a.Hi = u.Hi; a.Wi = u.Wi; a.Cout = u.Cout; a.Ho = u.Ho; a.Wo = u.Wo;
-        a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2;
+        a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2; a.reflect = p->gen->arch.reflect && u.ks > 1;
         a.ws = p->wgrad_ws + u.wg_off;
         int chunks = 0;
         RC(conv_wgrad_add(&const_cast<SpliceGenPlan*>(p)->wg, a, &chunks));
@@ -279,7 +294,8 @@ static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* par
         a.N = N; a.Cin = u.Cout; a.Hi = u.Ho; a.Wi = u.Wo; a.Cout = u.Cin; a.Ho = u.Hi; a.Wo = u.Wi;
         a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2; a.transposed = 1; a.accumulate = u.d_in_accumulate;
         a.ws = p->conv_ws; a.ws_floats = p->conv_ws_floats;
-        RC(conv_launch(a, s));
+        if (p->gen->arch.reflect && u.ks > 1) RC(conv_reflect_dgrad_launch(a, p->pad_scratch, s));
+        else RC(conv_launch(a, s));
     }
     return SPLICE_OK;
 }
@@ -293,14 +309,30 @@ static size_t wgrad_ws_need(const SpliceGenPlan* p, const Unit& u) {
 
 extern "C" {
 
-int splice_gen_create(void** out) {
+static int arch_check(const GenArch& a) {
+    if (a.n_scales < 1 || a.n_scales > MAXS || a.in_channels < 1 || a.in_channels > 128 || a.out_channels < 1 || a.out_channels > 16 || a.filter_skip != 1) return 0;
+    for (int i = 0; i < a.n_scales; ++i) {
+        if (a.down[i] < 1 || a.down[i] > 128 || a.up[i] < 1 || a.up[i] > 128 || a.skip[i] < 1 || a.skip[i] > 128) return 0;
+        for (int k : {a.filter_down[i], a.filter_up[i]})
+            if (k != 1 && k != 3 && k != 5 && k != 7) return 0;
+    }
+    return 1;
+}
+int splice_gen_create_arch(const splice_gen_arch* arch, void** out) {
     if (!out) return SPLICE_ERR_ARG;
     SpliceGen* g = new SpliceGen();
-    size_t offs[5 * 6 * 4], head[4], roffs[5 * 6];
-    build_table(g->table, offs, head, &g->buffers, roffs);
+    g->arch = arch ? *arch : default_arch();
+    if (!arch_check(g->arch)) {
+        splice_set_error("splice_gen_create_arch: unsupported skip() architecture (1..%d scales, channels <= 128, filters 1/3/5/7, 1x1 skip filter, skip channels > 0)", MAXS);
+        delete g;
+        return SPLICE_ERR_ARG;
+    }
+    size_t offs[MAXS * 6 * 4], head[4], roffs[MAXS * 6];
+    build_table(g->arch, g->table, offs, head, &g->buffers, roffs);
     *out = g;
     return SPLICE_OK;
 }
+int splice_gen_create(void** out) { return splice_gen_create_arch(nullptr, out); }
 void splice_gen_destroy(void* h) { delete (SpliceGen*)h; }
 
 long long splice_gen_param_count(void* h) { return h ? (long long)((SpliceGen*)h)->table.total : -1; }
@@ -317,27 +349,37 @@ int splice_gen_tensor_info(void* h, int i, const char** name, long long* offset,
 
 int splice_gen_plan_create(void* h, int N, int H, int W, int need_grad, void** out) {
     SpliceGen* g = (SpliceGen*)h;
-    if (!g || !out || N < 1 || H < 33 || W < 33) {
-        splice_set_error("splice_gen_plan_create: need N>=1 and H,W >= 33 (train-mode BatchNorm needs >1 value per channel at the 5th scale)");
+    if (!g || !out) return SPLICE_ERR_ARG;
+    const GenArch& A = g->arch;
+    const int S = A.n_scales, min_hw = (1 << S) + 1;
+    if (N < 1 || H < min_hw || W < min_hw) {
+        splice_set_error("splice_gen_plan_create: need N>=1 and H,W >= %d (train-mode BatchNorm needs >1 value per channel at the deepest scale)", min_hw);
         return SPLICE_ERR_ARG;
     }
     SpliceGenPlan* p = new SpliceGenPlan();
     p->gen = g; p->N = N; p->H = H; p->W = W; p->maxH = H; p->maxW = W; p->need_grad = need_grad;
     p->h[0] = H; p->w[0] = W;
-    for (int i = 1; i <= 5; ++i) { p->h[i] = (p->h[i - 1] + 1) / 2; p->w[i] = (p->w[i - 1] + 1) / 2; }
-    size_t offs[5 * 6 * 4], head[4], roffs[5 * 6];
+    for (int i = 1; i <= S; ++i) { p->h[i] = (p->h[i - 1] + 1) / 2; p->w[i] = (p->w[i - 1] + 1) / 2; }
+    size_t offs[MAXS * 6 * 4], head[4], roffs[MAXS * 6];
     ParamTable tmp, tmpb;
-    build_table(tmp, offs, head, &tmpb, roffs);
+    build_table(A, tmp, offs, head, &tmpb, roffs);
     p->head_w = head[0]; p->head_b = head[1];
     int rc = SPLICE_OK;
     auto fail = [&]() { for (void* q : p->allocs) (void)hipFree(q); delete p; return rc; };
-    size_t ws_need = 0;
-    for (int i = 0; i < 5 && rc == SPLICE_OK; ++i) {
-        const int cin = i == 0 ? 3 : DOWN[i - 1];
+    size_t ws_need = 0, pad_need = 0;
+    int max_c = A.in_channels;
+    for (int i = 0; i < S && rc == SPLICE_OK; ++i) {
+        const int cin = i == 0 ? A.in_channels : A.down[i - 1];
         const int hi = p->h[i], wi = p->w[i], hd = p->h[i + 1], wd = p->w[i + 1];
-        const int k = i < 4 ? UP[i + 1] : DOWN[i];
+        const int k = i < S - 1 ? A.up[i + 1] : A.down[i];
         p->kch[i] = k;
-        const size_t catC = SKIPC + k;
+        const size_t catC = A.skip[i] + k;
+        if ((int)catC > max_c) max_c = (int)catC;
+        if (A.reflect) {   // largest padded-domain gradient: N * Cin * (H + 2 pad) * (W + 2 pad) over the layers with a filter > 1
+            const size_t pd = A.filter_down[i] / 2, pu = A.filter_up[i] / 2;
+            const size_t cand[3] = {(size_t)cin * (hi + 2 * pd) * (wi + 2 * pd), (size_t)A.down[i] * (hd + 2 * pd) * (wd + 2 * pd), catC * (hi + 2 * pu) * (wi + 2 * pu)};
+            for (size_t c : cand) if (N * c > pad_need) pad_need = N * c;
+        }
         if ((rc = palloc(p, &p->cat[i], (size_t)N * catC * hi * wi)) != SPLICE_OK) break;
         if (need_grad && (rc = palloc(p, &p->d_cat[i], (size_t)N * catC * hi * wi)) != SPLICE_OK) break;
         size_t* o = offs + (size_t)i * 6 * 4;
@@ -347,27 +389,28 @@ int splice_gen_plan_create(void* h, int N, int H, int W, int need_grad, void** o
             setp(u, idx);
             return unit_alloc(p, u, own);
         };
-        if ((rc = mk(p->u_skip[i], 0, 1, 1, cin, SKIPC, hi, wi, hi, wi, false)) != SPLICE_OK) break;
-        if ((rc = mk(p->u_da[i], 1, 3, 2, cin, DOWN[i], hi, wi, hd, wd, true)) != SPLICE_OK) break;
-        if ((rc = mk(p->u_db[i], 2, 3, 1, DOWN[i], DOWN[i], hd, wd, hd, wd, true)) != SPLICE_OK) break;
+        if ((rc = mk(p->u_skip[i], 0, A.filter_skip, 1, cin, A.skip[i], hi, wi, hi, wi, false)) != SPLICE_OK) break;
+        if ((rc = mk(p->u_da[i], 1, A.filter_down[i], 2, cin, A.down[i], hi, wi, hd, wd, true)) != SPLICE_OK) break;
+        if ((rc = mk(p->u_db[i], 2, A.filter_down[i], 1, A.down[i], A.down[i], hd, wd, hd, wd, true)) != SPLICE_OK) break;
         p->u_cat[i].slope = 1.0f;
         if ((rc = mk(p->u_cat[i], 3, 0, 1, (int)catC, (int)catC, hi, wi, hi, wi, true)) != SPLICE_OK) break;
-        if ((rc = mk(p->u_up3[i], 4, 3, 1, (int)catC, UP[i], hi, wi, hi, wi, true)) != SPLICE_OK) break;
-        if ((rc = mk(p->u_up1[i], 5, 1, 1, UP[i], UP[i], hi, wi, hi, wi, true)) != SPLICE_OK) break;
+        if ((rc = mk(p->u_up3[i], 4, A.filter_up[i], 1, (int)catC, A.up[i], hi, wi, hi, wi, true)) != SPLICE_OK) break;
+        if ((rc = mk(p->u_up1[i], 5, 1, 1, A.up[i], A.up[i], hi, wi, hi, wi, true)) != SPLICE_OK) break;
         for (Unit* u : {&p->u_skip[i], &p->u_da[i], &p->u_db[i], &p->u_up3[i], &p->u_up1[i]}) { u->wg_off = ws_need; ws_need += wgrad_ws_need(p, *u); }
     }
     if (rc != SPLICE_OK) return fail();
     {
         p->head_wg_off = ws_need;
-        ws_need += (size_t)N * ((H * W + 63) / 64) * 3 * UP[0];
+        ws_need += (size_t)N * ((H * W + 63) / 64) * A.out_channels * A.up[0];
     }
-    if ((rc = palloc(p, &p->x_copy, (size_t)N * 3 * H * W)) != SPLICE_OK) return fail();
-    p->conv_ws_floats = (size_t)16 * N * 132 * 8192;   // split-K is only chosen for layers with < 128 tiles (<= 8192 pixels)
+    if ((rc = palloc(p, &p->x_copy, (size_t)N * A.in_channels * H * W)) != SPLICE_OK) return fail();
+    if (pad_need && need_grad && (rc = palloc(p, &p->pad_scratch, pad_need)) != SPLICE_OK) return fail();
+    p->conv_ws_floats = (size_t)16 * N * max_c * 8192;   // split-K is only chosen for layers with < 128 tiles (<= 8192 pixels)
     if ((rc = palloc(p, &p->conv_ws, p->conv_ws_floats)) != SPLICE_OK) return fail();
     if (need_grad) {
         if ((rc = palloc(p, &p->wgrad_ws, ws_need)) != SPLICE_OK) return fail();
-        if ((rc = palloc(p, &p->d_head_pre, (size_t)N * 3 * H * W)) != SPLICE_OK) return fail();
-        if ((rc = palloc(p, &p->out_copy, (size_t)N * 3 * H * W)) != SPLICE_OK) return fail();
+        if ((rc = palloc(p, &p->d_head_pre, (size_t)N * A.out_channels * H * W)) != SPLICE_OK) return fail();
+        if ((rc = palloc(p, &p->out_copy, (size_t)N * A.out_channels * H * W)) != SPLICE_OK) return fail();
     }
     plan_configure(p, H, W);
     *out = p;
@@ -378,8 +421,9 @@ int splice_gen_plan_create(void* h, int N, int H, int W, int need_grad, void** o
 // feed draws a different crop size every step (data/transforms.py:21-22).
 int splice_gen_plan_resize(void* plan, int H, int W) {
     SpliceGenPlan* p = (SpliceGenPlan*)plan;
-    if (!p || H < 33 || W < 33 || H > p->maxH || W > p->maxW) {
-        splice_set_error("splice_gen_plan_resize: %dx%d outside [33, plan maximum]", H, W);
+    const int min_hw = p ? (1 << p->gen->arch.n_scales) + 1 : 33;
+    if (!p || H < min_hw || W < min_hw || H > p->maxH || W > p->maxW) {
+        splice_set_error("splice_gen_plan_resize: %dx%d outside [%d, plan maximum]", H, W, min_hw);
         return SPLICE_ERR_ARG;
     }
     if (H != p->H || W != p->W) plan_configure(p, H, W);
@@ -441,7 +485,7 @@ int splice_gen_running_stats_update(void* const* plans, int n_plans, float* runn
                                     splice_stream_t stream) {
     if (!plans || n_plans < 1 || n_plans > RUNSTAT_MAX_PLANS || !running) return SPLICE_ERR_ARG;
     RunStatTable t = {};
-    t.n_plans = n_plans; t.n_bn = 30;
+    t.n_plans = n_plans; t.n_bn = 6 * ((SpliceGenPlan*)plans[0])->gen->arch.n_scales;
     int max_images = 1;
     for (int k = 0; k < n_plans; ++k) {
         SpliceGenPlan* p = (SpliceGenPlan*)plans[k];
@@ -449,7 +493,7 @@ int splice_gen_running_stats_update(void* const* plans, int n_plans, float* runn
         t.N[k] = p->batch_stats ? 1 : p->N; t.indep[k] = p->p_nstride ? 1 : 0;   // a batch call is ONE update with the batch statistics
         if (t.indep[k] && p->N > max_images) max_images = p->N;
         int bn = 0;
-        for (int i = 0; i < 5; ++i)
+        for (int i = 0; i < p->gen->arch.n_scales; ++i)
             for (Unit* u : {&p->u_skip[i], &p->u_da[i], &p->u_db[i], &p->u_cat[i], &p->u_up3[i], &p->u_up1[i]}) {
                 if (k == 0) { t.C[bn] = u->Cout; t.r_off[bn] = (int)u->r_off; }
                 t.HW[k][bn] = u->Ho * u->Wo * (p->batch_stats ? p->N : 1); t.mean[k][bn] = u->mean; t.rstd[k][bn] = u->rstd;
@@ -473,7 +517,9 @@ static int scale_forward(SpliceGenPlan* p, int i, const float* params, hipStream
     RC(unit_forward(p, p->u_db[i], params, s));
     const float* deep = p->u_db[i].out;
     size_t deep_ns = p->u_db[i].out_ns;
-    if (i < 4) {
+    const GenArch& A = p->gen->arch;
+    const int SKIPC = A.skip[i];
+    if (i < A.n_scales - 1) {
         RC(scale_forward(p, i + 1, params, s));
         deep = p->u_up1[i + 1].out; deep_ns = p->u_up1[i + 1].out_ns;
     }
@@ -496,7 +542,7 @@ static int gen_forward_impl(void* plan, const float* params, const float* x, flo
     if (borrowed) {
         p->x_in = x;
     } else {
-        RC(dev_copy_launch(p->x_copy, x, (size_t)p->N * 3 * p->H * p->W * sizeof(float), s));
+        RC(dev_copy_launch(p->x_copy, x, (size_t)p->N * p->gen->arch.in_channels * p->H * p->W * sizeof(float), s));
         p->x_in = p->x_copy;
     }
     p->u_skip[0].in = p->x_in; p->u_da[0].in = p->x_in;
@@ -505,16 +551,17 @@ static int gen_forward_impl(void* plan, const float* params, const float* x, flo
         const Unit& u = p->u_up1[0];
         ConvArgs a = {};
         a.in = u.out; a.w = params + p->head_w; a.bias = params + p->head_b; a.out = y;
-        a.in_nstride = u.out_ns; a.in_cstride = (size_t)p->H * p->W; a.out_nstride = (size_t)3 * p->H * p->W; a.out_cstride = (size_t)p->H * p->W;
-        a.w_jstride = UP[0]; a.w_cstride = 1; a.p_nstride = p->p_nstride;
-        a.N = p->N; a.Cin = UP[0]; a.Hi = p->H; a.Wi = p->W; a.Cout = 3; a.Ho = p->H; a.Wo = p->W; a.ks = 1; a.stride = 1; a.pad = 0; a.act = 1;
+        const int OC = p->gen->arch.out_channels, U0 = p->gen->arch.up[0];
+        a.in_nstride = u.out_ns; a.in_cstride = (size_t)p->H * p->W; a.out_nstride = (size_t)OC * p->H * p->W; a.out_cstride = (size_t)p->H * p->W;
+        a.w_jstride = U0; a.w_cstride = 1; a.p_nstride = p->p_nstride;
+        a.N = p->N; a.Cin = U0; a.Hi = p->H; a.Wi = p->W; a.Cout = OC; a.Ho = p->H; a.Wo = p->W; a.ks = 1; a.stride = 1; a.pad = 0; a.act = 1;
         RC(conv_launch(a, s));
     }
     if (p->need_grad) {
         if (borrowed) {
             p->y_saved = y;
         } else {
-            RC(dev_copy_launch(p->out_copy, y, (size_t)p->N * 3 * p->H * p->W * sizeof(float), s));
+            RC(dev_copy_launch(p->out_copy, y, (size_t)p->N * p->gen->arch.out_channels * p->H * p->W * sizeof(float), s));
             p->y_saved = p->out_copy;
         }
         p->forward_saved = 1;
@@ -536,7 +583,9 @@ static int scale_backward(SpliceGenPlan* p, int i, const float* params, float* g
     RC(unit_backward(p, p->u_up1[i], params, grads, acc, s));
     RC(unit_backward(p, p->u_up3[i], params, grads, acc, s));
     const int hi = p->h[i], wi = p->w[i];
-    Unit& deep = i < 4 ? p->u_up1[i + 1] : p->u_db[i];
+    const GenArch& A = p->gen->arch;
+    const int SKIPC = A.skip[i];
+    Unit& deep = i < A.n_scales - 1 ? p->u_up1[i + 1] : p->u_db[i];
     // small planes: the upsampled channels' gradient goes through the adjoint inside the concat's BatchNorm backward
     BnUpsample up;
     up.d_src = deep.d_out; up.d_src_ns = deep.d_out_ns; up.c0 = SKIPC; up.h = p->h[i + 1]; up.w = p->w[i + 1]; up.Ho = hi; up.Wo = wi;
@@ -544,7 +593,7 @@ static int scale_backward(SpliceGenPlan* p, int i, const float* params, float* g
     if (p->batch_stats || !bn_bwd_fuses_upsample(hi * wi, up.h, up.w))
         RC(upsample2x_bwd_launch(p->d_cat[i] + (size_t)SKIPC * hi * wi, p->u_skip[i].d_out_ns, deep.d_out, deep.d_out_ns, p->N, p->kch[i],
                                  p->h[i + 1], p->w[i + 1], hi, wi, s));
-    if (i < 4) RC(scale_backward(p, i + 1, params, grads, acc, s));   // leaves d x_{i+1} in u_db[i].d_out
+    if (i < A.n_scales - 1) RC(scale_backward(p, i + 1, params, grads, acc, s));   // leaves d x_{i+1} in u_db[i].d_out
     RC(unit_backward(p, p->u_db[i], params, grads, acc, s));
     RC(unit_backward(p, p->u_da[i], params, grads, acc, s));
     RC(unit_backward(p, p->u_skip[i], params, grads, acc, s));
@@ -559,32 +608,33 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
         return SPLICE_ERR_STATE;
     }
     hipStream_t s = (hipStream_t)stream;
-    const size_t npix = (size_t)p->N * 3 * p->H * p->W;
+    const int OC = p->gen->arch.out_channels, U0 = p->gen->arch.up[0];
+    const size_t npix = (size_t)p->N * OC * p->H * p->W;
     p->red.count = 0;
     p->wg.small.count = p->wg.small.total_wgs = 0;
     p->wg.big.count = p->wg.big.total_wgs = 0;
     const Unit& u = p->u_up1[0];
     const int HW = p->H * p->W;
     (void)npix;
-    RC(sigmoid_bwd_bias_launch(dy, p->y_saved, p->d_head_pre, p->N, 3, HW, p->u_up1[0].s1, grads + p->head_b, accumulate, s, p->p_nstride));
+    RC(sigmoid_bwd_bias_launch(dy, p->y_saved, p->d_head_pre, p->N, OC, HW, p->u_up1[0].s1, grads + p->head_b, accumulate, s, p->p_nstride));
     {
         WgradArgs a = {};
         a.x = u.out; a.dy = p->d_head_pre;
-        a.x_nstride = u.out_ns; a.x_cstride = (size_t)HW; a.dy_nstride = (size_t)3 * HW; a.dy_cstride = (size_t)HW;
-        a.N = p->N; a.Cin = UP[0]; a.Hi = p->H; a.Wi = p->W; a.Cout = 3; a.Ho = p->H; a.Wo = p->W; a.ks = 1; a.stride = 1; a.pad = 0;
+        a.x_nstride = u.out_ns; a.x_cstride = (size_t)HW; a.dy_nstride = (size_t)OC * HW; a.dy_cstride = (size_t)HW;
+        a.N = p->N; a.Cin = U0; a.Hi = p->H; a.Wi = p->W; a.Cout = OC; a.Ho = p->H; a.Wo = p->W; a.ks = 1; a.stride = 1; a.pad = 0;
         a.ws = p->wgrad_ws + p->head_wg_off;
         int chunks = 0;
         RC(conv_wgrad_add(&p->wg, a, &chunks));
         WgradReduceAll& r = p->red;
         const int li = r.count++;
-        r.n[li] = 3 * UP[0]; r.chunks[li] = chunks; r.ws_off[li] = (long long)p->head_wg_off; r.dw_off[li] = (long long)p->head_w;
+        r.n[li] = OC * U0; r.chunks[li] = chunks; r.ws_off[li] = (long long)p->head_wg_off; r.dw_off[li] = (long long)p->head_w;
     }
     {
         ConvArgs a = {};
         a.in = p->d_head_pre; a.w = params + p->head_w; a.out = u.d_out;
-        a.in_nstride = (size_t)3 * HW; a.in_cstride = (size_t)HW; a.out_nstride = u.d_out_ns; a.out_cstride = (size_t)HW;
-        a.w_jstride = 1; a.w_cstride = UP[0]; a.p_nstride = p->p_nstride;
-        a.N = p->N; a.Cin = 3; a.Hi = p->H; a.Wi = p->W; a.Cout = UP[0]; a.Ho = p->H; a.Wo = p->W; a.ks = 1; a.stride = 1; a.pad = 0; a.transposed = 1;
+        a.in_nstride = (size_t)OC * HW; a.in_cstride = (size_t)HW; a.out_nstride = u.d_out_ns; a.out_cstride = (size_t)HW;
+        a.w_jstride = 1; a.w_cstride = U0; a.p_nstride = p->p_nstride;
+        a.N = p->N; a.Cin = OC; a.Hi = p->H; a.Wi = p->W; a.Cout = U0; a.Ho = p->H; a.Wo = p->W; a.ks = 1; a.stride = 1; a.pad = 0; a.transposed = 1;
         RC(conv_launch(a, s));
     }
     RC(scale_backward(p, 0, params, grads, accumulate, s));

@@ -12,6 +12,7 @@ struct ConvArgs {
     size_t p_nstride;     // > 0: independent images -- image n reads w / bias at + n * p_nstride (its own parameter arena)
     int N, Cin, Hi, Wi, Cout, Ho, Wo;   // Cin = reduction channels, Cout = output columns
     int ks, stride, pad;
+    int reflect;      // forward only: reflection padding (nn.ReflectionPad2d) instead of zero padding
     int act;          // 1 = sigmoid
     int transposed;   // data-gradient form
     int accumulate;   // out += result
@@ -21,6 +22,8 @@ struct ConvArgs {
     int defer_reduce; // split-K: leave the raw slabs in ws (ksplit_out tells how many); the consumer adds bias + slabs in slice order
 };
 int conv_launch(const ConvArgs& a, hipStream_t s, int* ksplit_out = nullptr);
+// data gradient of a reflection-padded convolution (transposed conv on the padded domain + mirror fold); see gen_kernels.hip
+int conv_reflect_dgrad_launch(ConvArgs a, float* pad_scratch, hipStream_t s);
 
 struct WgradArgs {
     const float* x;       // layer input  [N][*][Hi][Wi]
@@ -29,6 +32,7 @@ struct WgradArgs {
     size_t x_nstride, x_cstride, dy_nstride, dy_cstride;
     int N, Cin, Hi, Wi, Cout, Ho, Wo, ks, stride, pad;
     int pix_per_chunk, chunks_per_img;   // filled by the launcher
+    int reflect;                         // reflection padding of the forward convolution
 };
 int wgrad_chunks(int N, int Ho, int Wo, int* pix_per_chunk, int* chunks_per_img);
 constexpr int WGRAD_BATCH_MAX = 32;
@@ -39,6 +43,7 @@ struct WgradDesc {           // compact per-layer descriptor of the batched weig
     uint8_t ks, stride, pad, variant;
     uint16_t pix_per_chunk, chunks_per_img;
     uint32_t wg_begin, chunks;
+    uint32_t reflect;
 };
 struct WgradBatch { int count; int total_wgs; WgradDesc d[WGRAD_BATCH_MAX]; };   // by-value kernel argument
 struct WgradBatchPair { WgradBatch small, big; };   // layers with <= 32 / > 32 output channels (different kernel occupancy)

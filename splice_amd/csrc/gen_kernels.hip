@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256 * NG) void conv_igemm_kernel(ConvArgs a) {
     constexpr int T = KS * KS;
     constexpr int KT = CK * T;          // k extent of one LDS tile (multiple of 4)
     constexpr int BM = 64;
-    constexpr int LDA = BM + 16;        // 80: k-rows 16 banks apart -> conflict-free ds_read_b32
+    constexpr int LDA = KS == 7 ? BM + 1 : BM + 16;   // 80: k-rows 16 banks apart -> conflict-free ds_read_b32 (7x7: 65, the 196-row tile must fit 64 KB)
     constexpr int LDW = KT + 2;         // 2*odd -> conflict-free
     constexpr int BN = 16 * FN;
     constexpr int NTH = 256 * NG;
@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256 * NG) void conv_igemm_kernel(ConvArgs a) {
     const int Kc = min(a.Cin, cbeg + cper);  // reduction channels [cbeg, Kc)
     // ---- per-thread gather descriptors (k = wave + NWV*i is wave-uniform)
     int a_off[NA], a_cl[NA];
-    unsigned a_ok = 0;
+    unsigned long long a_ok = 0;   // (7x7: 49 gathered elements per thread)
+    static_assert(NA <= 64, "gather mask");
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int k = wave + NWV * i;
@@ -74,6 +75,10 @@ __global__ __launch_bounds__(256 * NG) void conv_igemm_kernel(ConvArgs a) {
         if (!TRANSPOSED) {
             sy = oy * a.stride + ky - a.pad;
             sx = ox * a.stride + kx - a.pad;
+            if (a.reflect) {   // nn.ReflectionPad2d in front of the convolution (models/unet/common.py:113-118): mirror without the edge
+                sy = sy < 0 ? -sy : (sy >= a.Hi ? 2 * (a.Hi - 1) - sy : sy);
+                sx = sx < 0 ? -sx : (sx >= a.Wi ? 2 * (a.Wi - 1) - sx : sx);
+            }
             ok = sy >= 0 && sy < a.Hi && sx >= 0 && sx < a.Wi;
         } else {
             const int ty = oy + a.pad - ky, tx = ox + a.pad - kx;
@@ -89,8 +94,9 @@ __global__ __launch_bounds__(256 * NG) void conv_igemm_kernel(ConvArgs a) {
         ok = ok && pvalid;
         a_cl[i] = cl;
         a_off[i] = ok ? (int)(cl * a.in_cstride) + sy * a.Wi + sx : 0;
-        if (ok) a_ok |= 1u << i;
+        if (ok) a_ok |= 1ull << i;
     }
+    static_assert(NW <= 32, "weight mask");
     int w_off[NW], w_cl[NW], w_lds[NW];
     unsigned w_ok = 0;
 #pragma unroll
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(256 * NG) void conv_igemm_kernel(ConvArgs a) {
         const float* inc = in + (size_t)c0 * a.in_cstride;
         const float* wc = wgt + (size_t)c0 * a.w_cstride;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) av[i] = ((a_ok >> i) & 1u) && (c0 + a_cl[i] < Kc) ? inc[a_off[i]] : 0.f;
+        for (int i = 0; i < NA; ++i) av[i] = ((a_ok >> i) & 1ull) && (c0 + a_cl[i] < Kc) ? inc[a_off[i]] : 0.f;
 #pragma unroll
         for (int t = 0; t < NW; ++t) wv[t] = ((w_ok >> t) & 1u) && (c0 + w_cl[t] < Kc) ? wc[w_off[t]] : 0.f;
     };
@@ -227,7 +233,7 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
     // output-channel fragments per workgroup, tuned in-step with alternating runs: the 64 / 128-channel layers of the deep
     // scales run fastest with ONE 16-channel fragment per workgroup (FN = 4: +2.2 %, FN = 2: +0.6 %) -- these launches are
     // latency-bound and more, smaller workgroups shorten them; the 32-channel layers are indifferent (2 kept)
-    const int fn = (a.Cout > 16 && a.Cout <= 32) ? 2 : 1;
+    const int fn = (KS < 5 && a.Cout > 16 && a.Cout <= 32) ? 2 : 1;
     const int nt = cdiv(a.Cout, 16 * fn);
     // launch policy (split-K, 8-wave workgroups) from the workgroups of ONE image when the images are independent pairs:
     // split-K changes the summation order, and a pair's result must not depend on how many pairs share the launch
@@ -246,18 +252,23 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
     a.ksplit = ksplit;
     dim3 grid(mt, nt * ksplit, a.N);
     // 8-wave workgroups while the chip holds at most ~2 workgroups per CU (the serial K walk is the run time then)
-    constexpr bool CAN8 = KS == 3 && CK == 8;   // (K tile of 72: 9 steps per wave group; the A tile is big enough for the exchange)
-    const bool ng2 = CAN8 && (long)mt * nt * ksplit * npol <= 2048 && cdiv(a.Cin, CK) >= 2;
-    if (ng2) {
-        if constexpr (CAN8) {
-            if (fn == 1) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1, CK, 2>), grid, dim3(512), 0, s, a);
-            else if (fn == 2) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 2, CK, 2>), grid, dim3(512), 0, s, a);
-            else hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 4, CK, 2>), grid, dim3(512), 0, s, a);
-        }
+    constexpr bool CAN8 = KS == 3 && CK == 8;
+    if constexpr (KS >= 5) {   // 5x5 / 7x7 (the inversion experiment's generator): one fragment per workgroup, 4 waves
+        hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1, CK, 1>), dim3(mt, cdiv(a.Cout, 16) * ksplit, a.N), dim3(256), 0, s, a);
     } else {
-        if (fn == 1) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1, CK, 1>), grid, dim3(256), 0, s, a);
-        else if (fn == 2) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 2, CK, 1>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 4, CK, 1>), grid, dim3(256), 0, s, a);
+        // (K tile of 72: 9 steps per wave group; the A tile is big enough for the exchange)
+        const bool ng2 = CAN8 && (long)mt * nt * ksplit * npol <= 2048 && cdiv(a.Cin, CK) >= 2;
+        if (ng2) {
+            if constexpr (CAN8) {
+                if (fn == 1) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1, CK, 2>), grid, dim3(512), 0, s, a);
+                else if (fn == 2) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 2, CK, 2>), grid, dim3(512), 0, s, a);
+                else hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 4, CK, 2>), grid, dim3(512), 0, s, a);
+            }
+        } else {
+            if (fn == 1) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1, CK, 1>), grid, dim3(256), 0, s, a);
+            else if (fn == 2) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 2, CK, 1>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 4, CK, 1>), grid, dim3(256), 0, s, a);
+        }
     }
     if (ksplit_out) *ksplit_out = ksplit;
     if (ksplit > 1 && !a.defer_reduce) {
@@ -269,7 +280,13 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
 }
 
 int conv_launch(const ConvArgs& a, hipStream_t s, int* ksplit_out) {
-    if (a.ks != 1 && a.ks != 3) return SPLICE_ERR_ARG;
+    if (a.ks != 1 && a.ks != 3 && a.ks != 5 && a.ks != 7) return SPLICE_ERR_ARG;
+    if (a.reflect && a.transposed) return SPLICE_ERR_ARG;   // the data gradient of a reflection-padded conv goes through conv_reflect_dgrad_launch
+    if (a.ks >= 5) {
+        if (a.ks == 5) { if (a.transposed) conv_launch_fn<5, true, 4>(a, s, ksplit_out); else conv_launch_fn<5, false, 4>(a, s, ksplit_out); }
+        else { if (a.transposed) conv_launch_fn<7, true, 4>(a, s, ksplit_out); else conv_launch_fn<7, false, 4>(a, s, ksplit_out); }
+        return SPLICE_OK;
+    }
     if (a.stride != 1 && a.stride != 2) return SPLICE_ERR_ARG;
     if ((size_t)a.Cin * a.in_cstride > 0x7fffffffULL) return SPLICE_ERR_ARG;   // 32-bit gather offsets
     // deeper channel tiles where the reduction is long (fewer barrier rounds on the small, deep layers)
@@ -283,6 +300,48 @@ int conv_launch(const ConvArgs& a, hipStream_t s, int* ksplit_out) {
     return SPLICE_OK;
 }
 
+// Data gradient of a reflection-padded convolution: y = conv(pad_reflect(x)), so dL/dx = fold(dL/dx_pad) where dL/dx_pad is the
+// plain transposed convolution on the PADDED domain (Hi + 2p) x (Wi + 2p) -- conv_launch in data-gradient form with pad 0 --
+// and fold adds every padded position into the interior pixel it mirrors (separable: up to 3 source rows x 3 source
+// columns per pixel, fixed order).
+__global__ __launch_bounds__(256) void reflect_fold_kernel(const float* __restrict__ dpad, float* __restrict__ dx, size_t dx_nstride, size_t dx_cstride,
+                                                           int C, int H, int W, int p, int accumulate) {
+    const int Hp = H + 2 * p, Wp = W + 2 * p;
+    const int c = blockIdx.y, img = blockIdx.z;
+    const float* src = dpad + ((size_t)img * C + c) * Hp * Wp;
+    float* dst = dx + (size_t)img * dx_nstride + (size_t)c * dx_cstride;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < H * W; i += gridDim.x * 256) {
+        const int y = i / W, x = i % W;
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = y + p;
+        if (y >= 1 && y <= p) ys[ny++] = p - y;                               // top border mirrors rows 1..p
+        if (y <= H - 2 && y >= H - 1 - p) ys[ny++] = p + 2 * (H - 1) - y;     // bottom border mirrors rows H-1-p..H-2
+        xs[nx++] = x + p;
+        if (x >= 1 && x <= p) xs[nx++] = p - x;
+        if (x <= W - 2 && x >= W - 1 - p) xs[nx++] = p + 2 * (W - 1) - x;
+        float acc = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) acc += src[(size_t)ys[a] * Wp + xs[b]];
+        dst[i] = accumulate ? dst[i] + acc : acc;
+    }
+}
+// a: the layer in data-gradient form as for the zero-padded case (in = dy, out = d_in [N][Cout][Ho][Wo], pad = the layer's
+// padding); pad_scratch: N * Cout * (Ho + 2 pad) * (Wo + 2 pad) floats
+int conv_reflect_dgrad_launch(ConvArgs a, float* pad_scratch, hipStream_t s) {
+    const int p = a.pad, Hp = a.Ho + 2 * p, Wp = a.Wo + 2 * p;
+    float* out = a.out;
+    const size_t out_ns = a.out_nstride, out_cs = a.out_cstride;
+    const int acc = a.accumulate, H = a.Ho, W = a.Wo;
+    a.out = pad_scratch; a.out_nstride = (size_t)a.Cout * Hp * Wp; a.out_cstride = (size_t)Hp * Wp;
+    a.Ho = Hp; a.Wo = Wp; a.pad = 0; a.accumulate = 0; a.reflect = 0; a.transposed = 1; a.ws = nullptr;
+    const int rc = conv_launch(a, s);
+    if (rc != SPLICE_OK) return rc;
+    int gx = cdiv(H * W, 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(reflect_fold_kernel, dim3(gx, a.Cout, a.N), dim3(256), 0, s, pad_scratch, out, out_ns, out_cs, a.Cout, H, W, p, acc);
+    return SPLICE_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // Weight gradient: dW[n][c][tap] = sum_{img,pixel} dy[n][pixel] * x[c][tap-shifted pixel].
 // Workgroup = (pixel chunk, 4-or-16-channel K tile); MFMA reduces over pixels (64 per LDS fill, the next
@@ -292,11 +351,15 @@ constexpr int WG_PC = 64;                      // pixels per LDS fill
 constexpr int WG_LD = WG_PC + 2;               // 66 = 2*33
 constexpr int WG_XS_FLOATS = 3 * 16 * WG_LD;   // [k][pixel], largest variant (3x3: 36 -> 48 k rows)
 constexpr int WG_DS_FLOATS = 8 * 16 * WG_LD;   // [n][pixel], largest variant (128 output channels)
-template <int KS, int NI>   // NI = 16-row fragments of output channels
-__device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, int chunk, int ktile, float* Xs, float* Ds) {
-    constexpr int T = KS * KS;
-    constexpr int CK = (KS == 3) ? 4 : 16;
-    constexpr int KT = CK * T;                 // 36 / 16
+// ROWS (5x5 / 7x7 filters): a K tile is 4 channels x ONE filter row (KS taps), ktile = channel_tile * KS + ky -- keeps the
+// tile at 20 / 28 k-values instead of 100 / 196.
+template <int KS, int NI, bool ROWS = false>   // NI = 16-row fragments of output channels
+__device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, int chunk, int ktile_in, float* Xs, float* Ds) {
+    constexpr int T = ROWS ? KS : KS * KS;     // taps per channel inside one K tile
+    constexpr int CK = (ROWS || KS == 3) ? 4 : 16;
+    constexpr int KT = CK * T;                 // 36 / 16 / 20 / 28
+    const int ktile = ROWS ? ktile_in / KS : ktile_in;
+    const int krow = ROWS ? ktile_in % KS : 0;
     constexpr int NJ = (KT + 15) / 16;         // 3 / 1
     constexpr int PC = WG_PC;
     constexpr int LD = WG_LD;
@@ -325,8 +388,8 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, int chunk, i
         const int k = wave + 4 * i;
         const int cl = k / T, tap = k % T;
         g_coff[i] = (int)(cl * a.x_cstride);
-        g_dy[i] = tap / KS - a.pad;
-        g_dx[i] = tap % KS - a.pad;
+        g_dy[i] = (ROWS ? krow : tap / KS) - a.pad;
+        g_dx[i] = (ROWS ? tap : tap % KS) - a.pad;
         if (c0 + cl < a.Cin) g_cok |= 1u << i;
     }
     float xv[NA], dv[ND];
@@ -337,7 +400,11 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, int chunk, i
         const int by = oy * a.stride, bx = ox * a.stride;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int sy = by + g_dy[i], sx = bx + g_dx[i];
+            int sy = by + g_dy[i], sx = bx + g_dx[i];
+            if (a.reflect) {
+                sy = sy < 0 ? -sy : (sy >= a.Hi ? 2 * (a.Hi - 1) - sy : sy);
+                sx = sx < 0 ? -sx : (sx >= a.Wi ? 2 * (a.Wi - 1) - sx : sx);
+            }
             const bool ok = pvalid && ((g_cok >> i) & 1u) && sy >= 0 && sy < a.Hi && sx >= 0 && sx < a.Wi;
             xv[i] = ok ? x[g_coff[i] + sy * a.Wi + sx] : 0.f;
         }
@@ -376,7 +443,8 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, int chunk, i
         }
     }
     // partial[chunk][n][c][tap]: layout identical to the weight tensor
-    float* ws = a.ws + (size_t)chunk * a.Cout * a.Cin * T;
+    constexpr int TT = KS * KS;   // taps of the full filter (the layout of the partial = the weight tensor's)
+    float* ws = a.ws + (size_t)chunk * a.Cout * a.Cin * TT;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int pair = wave + 4 * q;
@@ -388,7 +456,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, int chunk, i
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n = fi * 16 + (lane >> 4) * 4 + r;
-                    if (n < a.Cout) ws[((size_t)n * a.Cin + c0 + cl) * T + tap] = acc[q][r];
+                    if (n < a.Cout) ws[((size_t)n * a.Cin + c0 + cl) * TT + (ROWS ? krow * KS + tap : tap)] = acc[q][r];
                 }
             }
         }
@@ -467,6 +535,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_batched_kernel(WgradBatch b) {
     a.x_nstride = d.x_nstride; a.x_cstride = d.x_cstride; a.dy_nstride = d.dy_nstride; a.dy_cstride = d.dy_cstride;
     a.N = 0; a.Cin = d.Cin; a.Hi = d.Hi; a.Wi = d.Wi; a.Cout = d.Cout; a.Ho = d.Ho; a.Wo = d.Wo;
     a.ks = d.ks; a.stride = d.stride; a.pad = d.pad; a.pix_per_chunk = d.pix_per_chunk; a.chunks_per_img = d.chunks_per_img;
+    a.reflect = (int)d.reflect;
     const int local = blockIdx.x - d.wg_begin;
     const int chunk = local % d.chunks, ktile = local / d.chunks;
     if (BIG) {
@@ -474,14 +543,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_batched_kernel(WgradBatch b) {
             case 2: conv_wgrad_body<1, 4>(a, chunk, ktile, Xs, Ds); break;
             case 3: conv_wgrad_body<1, 8>(a, chunk, ktile, Xs, Ds); break;
             case 6: conv_wgrad_body<3, 4>(a, chunk, ktile, Xs, Ds); break;
-            default: conv_wgrad_body<3, 8>(a, chunk, ktile, Xs, Ds); break;
+            case 7: conv_wgrad_body<3, 8>(a, chunk, ktile, Xs, Ds); break;
+            case 10: conv_wgrad_body<5, 4, true>(a, chunk, ktile, Xs, Ds); break;
+            case 11: conv_wgrad_body<5, 8, true>(a, chunk, ktile, Xs, Ds); break;
+            case 14: conv_wgrad_body<7, 4, true>(a, chunk, ktile, Xs, Ds); break;
+            default: conv_wgrad_body<7, 8, true>(a, chunk, ktile, Xs, Ds); break;
         }
     } else {
         switch (d.variant) {
             case 0: conv_wgrad_body<1, 1>(a, chunk, ktile, Xs, Ds); break;
             case 1: conv_wgrad_body<1, 2>(a, chunk, ktile, Xs, Ds); break;
             case 4: conv_wgrad_body<3, 1>(a, chunk, ktile, Xs, Ds); break;
-            default: conv_wgrad_body<3, 2>(a, chunk, ktile, Xs, Ds); break;
+            case 5: conv_wgrad_body<3, 2>(a, chunk, ktile, Xs, Ds); break;
+            case 8: conv_wgrad_body<5, 1, true>(a, chunk, ktile, Xs, Ds); break;
+            case 9: conv_wgrad_body<5, 2, true>(a, chunk, ktile, Xs, Ds); break;
+            case 12: conv_wgrad_body<7, 1, true>(a, chunk, ktile, Xs, Ds); break;
+            default: conv_wgrad_body<7, 2, true>(a, chunk, ktile, Xs, Ds); break;
         }
     }
 }
@@ -489,19 +566,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_batched_kernel(WgradBatch b) {
 // append one layer to a batch (partial sums only: ws gets chunks * Cout*Cin*ks*ks floats); returns the number of chunks
 int conv_wgrad_add(WgradBatchPair* pair, WgradArgs a, int* chunks_out) {
     WgradBatch* b = a.Cout > 32 ? &pair->big : &pair->small;
-    if (a.Cout > 128 || (a.ks != 1 && a.ks != 3) || b->count >= WGRAD_BATCH_MAX) return SPLICE_ERR_ARG;
+    if (a.Cout > 128 || (a.ks != 1 && a.ks != 3 && a.ks != 5 && a.ks != 7) || b->count >= WGRAD_BATCH_MAX) return SPLICE_ERR_ARG;
     if ((size_t)a.Cin * a.x_cstride > 0x7fffffffULL || a.x_nstride > 0xffffffffULL || a.dy_nstride > 0xffffffffULL) return SPLICE_ERR_ARG;
     if (a.Hi > 65535 || a.Wi > 65535 || a.Cin > 65535) return SPLICE_ERR_ARG;
     const int chunks = wgrad_chunks(a.N, a.Ho, a.Wo, &a.pix_per_chunk, &a.chunks_per_img);
-    const int CK = a.ks == 3 ? 4 : 16;
-    const int ktiles = cdiv(a.Cin, CK);
+    const int CK = a.ks == 1 ? 16 : 4;
+    const int ktiles = cdiv(a.Cin, CK) * (a.ks >= 5 ? a.ks : 1);   // 5x5 / 7x7: one K tile per (channel tile, filter row)
     const int ni = cdiv(a.Cout, 16);
     WgradDesc& d = b->d[b->count++];
     d.x = a.x; d.dy = a.dy; d.ws = a.ws;
     d.x_nstride = (uint32_t)a.x_nstride; d.x_cstride = (uint32_t)a.x_cstride; d.dy_nstride = (uint32_t)a.dy_nstride; d.dy_cstride = (uint32_t)a.dy_cstride;
     d.Cin = (uint16_t)a.Cin; d.Cout = (uint16_t)a.Cout; d.Hi = (uint16_t)a.Hi; d.Wi = (uint16_t)a.Wi; d.Ho = (uint16_t)a.Ho; d.Wo = (uint16_t)a.Wo;
     d.ks = (uint8_t)a.ks; d.stride = (uint8_t)a.stride; d.pad = (uint8_t)a.pad;
-    d.variant = (uint8_t)((a.ks == 3 ? 4 : 0) + (ni <= 1 ? 0 : ni <= 2 ? 1 : ni <= 4 ? 2 : 3));
+    d.variant = (uint8_t)((a.ks == 3 ? 4 : a.ks == 5 ? 8 : a.ks == 7 ? 12 : 0) + (ni <= 1 ? 0 : ni <= 2 ? 1 : ni <= 4 ? 2 : 3));
+    d.reflect = (uint32_t)(a.reflect ? 1 : 0);
     d.pix_per_chunk = (uint16_t)a.pix_per_chunk; d.chunks_per_img = (uint16_t)a.chunks_per_img;
     d.wg_begin = (uint32_t)b->total_wgs; d.chunks = (uint32_t)chunks;
     b->total_wgs += chunks * ktiles;

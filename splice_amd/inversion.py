@@ -4,8 +4,10 @@ Feature inversion (paper section 3 / ``inversion.py:12-74``): optimise a 6-scale
 that the DINO feature of its output -- the layer-``L`` [CLS] token or the layer-``L`` keys -- matches the feature of a
 reference image; for the [CLS] inversion the input noise is perturbed every iteration with a decaying amplitude
 (x10 -> x2 -> x0.5, ``inversion.py:55-62``).  Every iteration is one ViT forward + backward through
-``VitExtractor`` (the HIP engine, ``torch.autograd.Function`` around ``splice_vit_forward/backward``); the small
-generator of this experiment is a stock-PyTorch ``skip(...)`` (``splice_amd/unet_general.py``).
+``VitExtractor`` (the HIP engine, ``torch.autograd.Function`` around ``splice_vit_forward/backward``) and one forward +
+backward of the experiment's own generator -- ``skip()`` with 6 scales, 7/7/5/5/3/3 filters, reflection padding and noise
+input -- on the HIP generator engine (``splice_gen_create_arch``; pinned against the reference's module in
+tests/test_generator_gpu.py::test_inversion_net_on_hip_matches_reference_golden).
 
     python -m splice_amd.inversion --feature cls|keys --image_path img.jpg --save_path out.png
         [--layer 11] [--dino_model_name dino_vitb8] [--n_iter 20000] [--checkpoint dino.pth | --synthetic]

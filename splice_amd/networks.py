@@ -46,13 +46,13 @@ class _GenFn(torch.autograd.Function):
 class SkipGenerator(nn.Module):
     """The reference generator (``skip()`` defaults) backed by ``splice_gen_*``."""
 
-    def __init__(self, device="cuda"):
+    def __init__(self, device="cuda", arch=None):
         super().__init__()
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("SkipGenerator (HIP engine) needs a GPU device; there is no CPU fallback")
-        self.engine = GeneratorEngine(device=dev)
-        from .synth import generator_param_specs
+        self.engine = GeneratorEngine(device=dev, arch=arch)
+        generator_param_specs = lambda: self.engine.param_specs
         self.flat = torch.zeros(self.engine.numel, device=dev)
         # BatchNorm buffers (nn.BatchNorm2d keeps them in state_dict; train mode moves them with momentum 0.1 and nothing
         # ever reads them): views of one flat arena the engine updates in ONE launch per forward
@@ -127,21 +127,32 @@ def skip(num_input_channels=3, num_output_channels=3, num_channels_down=[16, 32,
          num_channels_up=[16, 32, 64, 128, 128], num_channels_skip=[4, 4, 4, 4, 4], filter_size_down=3, filter_size_up=3,
          filter_skip_size=1, need_sigmoid=True, need_tanh=False, need_bias=True, pad='zero', upsample_mode='bilinear',
          downsample_mode='stride', act_fun='LeakyReLU', need1x1_up=True, device="cuda"):
-    """``models/unet/skip.py:4-11``: the default arguments give the fused HIP generator, anything else a PyTorch module."""
-    default = (3, 3, [16, 32, 64, 128, 128], [16, 32, 64, 128, 128], [4, 4, 4, 4, 4], 3, 3, 1, True, False, True, 'zero',
-               'bilinear', 'stride', 'LeakyReLU', True)
-    given = (num_input_channels, num_output_channels, list(num_channels_down), list(num_channels_up), list(num_channels_skip),
-             filter_size_down, filter_size_up, filter_skip_size, need_sigmoid, need_tanh, need_bias, pad, upsample_mode,
-             downsample_mode, act_fun, need1x1_up)
-    if given != default:
-        # any other architecture (e.g. the 6-scale reflection-padded net of inversion.py:21-25) is outside the Splice hot
-        # path: assembled from stock PyTorch-ROCm modules (splice_amd/unet_general.py)
+    """``models/unet/skip.py:4-11`` on the HIP generator engine: the default arguments (``define_G``) and every other
+    architecture the kernels cover (up to 6 scales, 1/3/5/7 filters, zero or reflection padding, stride-2 down-sampling,
+    bilinear up-sampling, LeakyReLU, sigmoid head) -- in particular the feature-inversion net of inversion.py:21-25."""
+    n = len(num_channels_down)
+    as_list = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * n
+    arch = dict(num_input_channels=num_input_channels, num_output_channels=num_output_channels, num_channels_down=list(num_channels_down),
+                num_channels_up=list(num_channels_up), num_channels_skip=list(num_channels_skip), filter_size_down=as_list(filter_size_down),
+                filter_size_up=as_list(filter_size_up), filter_skip_size=filter_skip_size, pad=pad)
+    on_hip = (torch.device(device).type == "cuda" and n <= 6 and len(num_channels_up) == n and len(num_channels_skip) == n
+              and need_sigmoid and need_bias and need1x1_up and pad in ('zero', 'reflection') and filter_skip_size == 1
+              and all(m == 'bilinear' for m in as_list(upsample_mode)) and all(m == 'stride' for m in as_list(downsample_mode))
+              and act_fun == 'LeakyReLU' and all(k in (1, 3, 5, 7) for k in arch["filter_size_down"] + arch["filter_size_up"])
+              and all(0 < c <= 128 for c in arch["num_channels_down"] + arch["num_channels_up"] + arch["num_channels_skip"])
+              and 0 < num_input_channels <= 128 and 0 < num_output_channels <= 16)
+    if not on_hip:
+        # what the kernels do not cover (other down-samplers / activations / no sigmoid, or a CPU device): stock PyTorch modules
         from .unet_general import GeneralSkip
         return GeneralSkip(num_input_channels, num_output_channels, num_channels_down, num_channels_up, num_channels_skip,
                            filter_size_down, filter_size_up, filter_skip_size, need_sigmoid, need_tanh, need_bias, pad,
                            upsample_mode, downsample_mode, act_fun, need1x1_up).to(device)
-    _burn_constructor_draws()
-    return SkipGenerator(device=device)
+    from .generator import DEFAULT_ARCH
+    if arch == DEFAULT_ARCH:
+        _burn_constructor_draws()
+        return SkipGenerator(device=device)
+    # e.g. the 6-scale reflection-padded 7/7/5/5/3/3 net of inversion.py:21-25: same HIP engine, its own architecture table
+    return SkipGenerator(device=device, arch=arch)
 
 
 def _burn_constructor_draws():
@@ -167,13 +178,15 @@ _CONV_INIT = {  # init_type -> in-place initialiser of a conv weight (models/net
 }
 
 
-def _draw_initial_state(init_type, init_gain):
+def _draw_initial_state(init_type, init_gain, specs=None):
     """{state_dict name: CPU tensor} drawn from the global CPU generator in the reference's module order."""
     if init_type not in _CONV_INIT:
         raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
-    from .synth import generator_param_specs
+    if specs is None:
+        from .synth import generator_param_specs
+        specs = generator_param_specs()
     state = {}
-    for name, shape, kind in generator_param_specs():
+    for name, shape, kind in specs:
         host = torch.zeros(shape)
         if kind == "conv_w":
             _CONV_INIT[init_type](host, init_gain)
@@ -187,7 +200,7 @@ def init_weights(net, init_type='normal', init_gain=0.02, debug=False):
     """``models/networks.py:24-47``: conv weights by ``init_type``, conv bias 0, BN gamma ~ N(1, gain), beta 0.  Values are
     drawn on the CPU in module order (the reference initialises on the CPU and moves the net afterwards), then uploaded
     into the arena."""
-    state = _draw_initial_state(init_type, init_gain)
+    state = _draw_initial_state(init_type, init_gain, net.engine.param_specs)
     with torch.no_grad():
         for name, p in zip(net._kinds, net._plist):
             p.copy_(state[name])

@@ -54,7 +54,8 @@ def test_struct_layouts_match_header(tmp_path):
     """The ctypes mirrors of the public structs agree with the C compiler's layout of the header: same size, same
     offset for every field, and no field of the header missing from the binding (or vice versa)."""
     src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "splice_hip.h")).read(), flags=re.S)
-    for cname, mirror in (("splice_gemm_epilogue", _lib.GemmEpilogue), ("splice_step_config", _lib.StepConfig)):
+    src = re.sub(r"\[[A-Za-z_0-9]+\]", "", src)   # array extents (int down[SPLICE_GEN_MAX_SCALES]) do not matter for the field list
+    for cname, mirror in (("splice_gemm_epilogue", _lib.GemmEpilogue), ("splice_step_config", _lib.StepConfig), ("splice_gen_arch", _lib.GenArch)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
         header_fields = []
         for decl in body.split(";"):
