@@ -130,6 +130,40 @@ def time_steps(eng, A, B, K, W, barrier):
     return time.perf_counter() - t0
 
 
+def train_regime_leg(eng, A, B, steps=120):
+    """the headline regime (fixed full crops: identity Resize, graph replay every step) is the BASELINE config, but
+    ``train_model`` with the reference's default config draws a new crop size nearly every step (data/transforms.py:21: eager
+    launches, bilinear Resize forward + adjoint), augments the structure image on the device (data/transforms.py:30-37) and
+    runs a logging forward every ``log_images_freq`` = 10 steps.  The same engine is driven that way for ``steps`` steps
+    (no PNG encode: that runs on a worker thread in train_model) and the rate is reported beside the headline."""
+    import numpy as np
+    import torch
+    from splice_amd.train import DeviceDataFeed
+    cfg = dict(eng.cfg, use_augmentations=True, global_A_crops_min_cover=0.95, global_B_crops_min_cover=0.95,
+               global_A_crops_n_crops=1, global_B_crops_n_crops=1)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    feed = DeviceDataFeed(cfg, A.cpu(), B.cpu())
+    feed.step = eng.step_idx          # keep the entire-image cadence aligned with the engine's step counter
+    def run(n):
+        for _ in range(n):
+            inp = feed.next()
+            log = (eng.step_idx + 2) % cfg["log_images_freq"] == 0
+            if log:
+                eng.generate(feed.get_A())
+            eng.step(inp["A_global"], inp["B_global"], inp["A"][0] if "A" in inp else None)
+            if log:
+                eng.book_logged_forward()
+    run(10)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"steps_per_s": round(steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+            "regime": "random >= 95 % crops per step (new shapes: eager launches, bilinear Resize + adjoint), device augmentations, logging forward every 10 steps"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,6 +175,7 @@ def main():
     ap.add_argument("--pairs-sweep", default="2,4,8", help="additional pairs-per-GPU settings timed briefly after the main region (throughput form: pairs/hr); '' = off")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4] operand path: QKV projections + key self-similarity Gram on the fp8 MFMA (own tolerance table)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-regime", action="store_true", help="skip the train_model-shaped leg (random crops + augmentations + logging)")
     ap.add_argument("--prof-kernels", default="4,5,3,6", help="kernel families timed live with HIP events for the roofline leg ('' = off): 4 fc2 fwd, 1 fc1 fwd, 2 qkv fwd, 3 attention fwd, 5 split-K dgrads, 6 attention bwd")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -224,6 +259,12 @@ def main():
         except Exception as e:   # the sweep must never take the headline number down
             sweep[Ps] = None
             print(f"[bench] pairs={Ps} sweep leg failed: {e}", file=sys.stderr)
+    train_leg = None
+    if world == 1 and P == 1 and args.size >= 64 and not args.no_train_regime:
+        try:
+            train_leg = train_regime_leg(eng, A, B)
+        except Exception as e:
+            train_leg = {"steps_per_s": None, "regime": f"failed: {e}"}
     if rank != 0:
         rep.close()
         return
@@ -275,6 +316,7 @@ def main():
                    "throughput_by_pairs_per_gpu": {str(k): (None if v is None else {"steps_per_s": round(v, 2), "pair_steps_per_s": round(v * k, 2),
                                                                                     "pairs_per_hour_at_2000_steps": round(v * k * 3600 / 2000, 1)})
                                                    for k, v in sorted(sweep.items())},
+                   "train_model_regime": train_leg,
                    "generator_dtype": "f32", "last_loss": round(losses["loss"], 5)},
         "roofline": roof, "cpu_baseline": cpu,
     }
