@@ -9,7 +9,7 @@ for r in $(seq 1 $REPS); do
     IFS=, read -ra VALS <<< "$set"
     envs=()
     for i in "${!VARS[@]}"; do envs+=("${VARS[$i]}=${VALS[$i]}"); done
-    ms=$(env "${envs[@]}" python bench.py --steps $STEPS --warmup $((STEPS / 10)) --no-cpu-baseline --prof-kernel 0 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])" 2>/dev/null || echo FAIL)
+    ms=$(env "${envs[@]}" python bench.py --steps $STEPS --warmup $((STEPS / 10)) --no-cpu-baseline --prof-kernels "" --pairs-sweep "" --no-train-regime 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])" 2>/dev/null || echo FAIL)
     echo "${envs[*]} -> $ms"
   done
 done | sort | awk '{k=$0; sub(/ -> .*/, "", k); v=$NF; if (v != "FAIL") {s[k]+=v; n[k]++}; print} END {print "-- means"; for (k in s) printf "%s -> %.4f ms (n=%d)\n", k, s[k]/n[k], n[k]}'
