@@ -35,26 +35,40 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// erf-form GELU (torch.nn.GELU default) and its derivative.  erf by Abramowitz-Stegun 7.1.26
-// (|abs err| <= 1.5e-7, far below the bf16 output rounding) sharing one exp(-x^2/2) between the
-// cdf and the pdf term: ~12 VALU ops instead of libm's erff.
-__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& ex) {
-    const float ax = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
-    ex = __expf(-0.5f * x * x);
-    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
-    const float erf_abs = 1.0f - poly * ex;
-    cdf = 0.5f * (1.0f + (x < 0.f ? -erf_abs : erf_abs));
+// erf-form GELU (torch.nn.GELU default) x * Phi(x) and its derivative Phi(x) + x phi(x), WITHOUT transcendentals: both
+// Phi(x) - 1/2 and gelu'(x) - 1/2 are odd functions, fitted on [-4, 4] by odd polynomials in x (least squares on Chebyshev
+// nodes; max error in fp32 Horner form 6e-6 / 5e-5 absolute -- the outputs are rounded to bf16, eps 4e-3) and saturated
+// outside (Phi(4) = 1 - 3e-5).  10 / 11 full-rate FMAs instead of the Abramowitz-Stegun form's rcp + exp + 14 ops: the GELU
+// epilogues of fc1 / fc2^T cost 21 % / 33 % of those GEMMs at M = 1600 (tools/gelu_cost.py).
+__device__ __forceinline__ float gelu_cdf_f(float x) {
+    const float xc = fminf(fmaxf(x, -4.0f), 4.0f), u = xc * xc;
+    float p = 7.804400182e-11f;
+    p = __builtin_fmaf(p, u, -6.827484800e-09f);
+    p = __builtin_fmaf(p, u, 2.666929504e-07f);
+    p = __builtin_fmaf(p, u, -6.221946023e-06f);
+    p = __builtin_fmaf(p, u, 9.829076589e-05f);
+    p = __builtin_fmaf(p, u, -1.130963792e-03f);
+    p = __builtin_fmaf(p, u, 9.869961999e-03f);
+    p = __builtin_fmaf(p, u, -6.640202552e-02f);
+    p = __builtin_fmaf(p, u, 3.989198506e-01f);
+    const float cdf = __builtin_fmaf(xc, p, 0.5f);
+    return x >= 4.0f ? 1.0f : (x <= -4.0f ? 0.0f : cdf);
 }
-__device__ __forceinline__ float gelu_f(float x) {
-    float cdf, ex;
-    gelu_parts(x, cdf, ex);
-    return x * cdf;
-}
+__device__ __forceinline__ float gelu_f(float x) { return x * gelu_cdf_f(x); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    float cdf, ex;
-    gelu_parts(x, cdf, ex);
-    return cdf + x * 0.3989422804014327f * ex;
+    const float xc = fminf(fmaxf(x, -4.0f), 4.0f), u = xc * xc;
+    float p = -5.066447262e-11f;
+    p = __builtin_fmaf(p, u, 4.789254326e-09f);
+    p = __builtin_fmaf(p, u, -2.026289394e-07f);
+    p = __builtin_fmaf(p, u, 5.107016932e-06f);
+    p = __builtin_fmaf(p, u, -8.623141184e-05f);
+    p = __builtin_fmaf(p, u, 1.038558665e-03f);
+    p = __builtin_fmaf(p, u, -9.190188721e-03f);
+    p = __builtin_fmaf(p, u, 5.937872082e-02f);
+    p = __builtin_fmaf(p, u, -2.656380534e-01f);
+    p = __builtin_fmaf(p, u, 7.978171706e-01f);
+    const float d = __builtin_fmaf(xc, p, 0.5f);
+    return x >= 4.0f ? 1.0f : (x <= -4.0f ? 0.0f : d);
 }
 
 // D = A(16xK32) * B(K32x16) + C on one wave.  Operand layout (gfx950, 16x16x32 bf16):
