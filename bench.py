@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=1, help="pairs optimised side by side per GPU in the timed region (1 = the reference's unit: the latency form of the metric)")
     ap.add_argument("--pairs-sweep", default="2,4,8", help="additional pairs-per-GPU settings timed briefly after the main region (throughput form: pairs/hr); '' = off")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4] operand path: QKV projections + key self-similarity Gram on the fp8 MFMA (own tolerance table)")
+    ap.add_argument("--scales", default="", help="BASELINE configs[4]: comma list of ViT input scales evaluated per step on the same crops (e.g. 224,320,448); "
+                                                 "one fused step per scale + one Adam (MultiScaleEngine); disables the sweep / roofline / train-regime legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-regime", action="store_true", help="skip the train_model-shaped leg (random crops + augmentations + logging)")
     ap.add_argument("--prof-kernels", default="4,5,3,6", help="kernel families timed live with HIP events for the roofline leg ('' = off): 4 fc2 fwd, 1 fc1 fwd, 2 qkv fwd, 3 attention fwd, 5 split-K dgrads, 6 attention bwd")
@@ -208,7 +210,18 @@ def main():
     cfg = dict(dino_model_name=args.model, dino_global_patch_size=args.size)
     hw = (args.size, args.size)
     P = max(1, args.pairs)
-    eng, A, B = synthetic_engine(cfg, pair_id=rep.pair_id() * P, hw=hw, seed=1234, device=dev, pairs=P, fp8=args.fp8)
+    scales = [int(x) for x in args.scales.split(",") if x.strip()]
+    if scales:
+        from splice_amd import synth
+        from splice_amd.engine import MultiScaleEngine
+        P = 1
+        args.pairs_sweep, args.prof_kernels, args.no_train_regime, args.no_cpu_baseline = "", "", True, True
+        Ai, Bi = synth.image_pair(1234, rep.pair_id(), hw[0], hw[1])
+        eng = MultiScaleEngine(cfg, synth.vit_params(1234, args.model, img_size=224), synth.generator_params(1235 + rep.pair_id(), 0.02), hw, hw,
+                               scales=scales, device=dev, fp8=args.fp8)
+        A, B = torch.from_numpy(Ai).to(dev), torch.from_numpy(Bi).to(dev)
+    else:
+        eng, A, B = synthetic_engine(cfg, pair_id=rep.pair_id() * P, hw=hw, seed=1234, device=dev, pairs=P, fp8=args.fp8)
     K, W = args.steps, args.warmup
 
     def barrier():
@@ -217,7 +230,7 @@ def main():
         torch.cuda.synchronize()
 
     elapsed = time_steps(eng, A, B, K, W, barrier)
-    losses = eng.losses() if P == 1 else eng.losses(0)
+    losses = eng.losses() if (P == 1 or scales) else eng.losses(0)
     # roofline leg: the timed region replays captured hipGraphs (event records cannot be threaded through a
     # replay), so the SAME steps continue for short instrumented stretches with every launch of one kernel family
     # bracketed by HIP events on its own stream (eager launches; the kernels themselves are identical).
@@ -242,12 +255,12 @@ def main():
                 prof[fam] = (ms.value, n.value, min(K, 20))
     per_rank_elapsed = rep.gather_floats(elapsed)
     elapsed = rep.max_over_ranks(elapsed)
-    T = eng.ctx_g.T
+    T = eng.ctx_g.T if not scales else [e.ctx_g.T for e in eng.engines]
     D = eng.vit.dim
     n_entire = sum(1 for s in range(W, W + K) if s % eng.cfg["entire_A_every"] == 0)
     # ---- throughput form of the metric: P pairs per GPU through the shared ViT (same barrier-bracketed timing, fewer steps)
     sweep = {P: K / elapsed}
-    sweep_ids = [int(x) for x in args.pairs_sweep.split(",") if x.strip()] if (world == 1 and P == 1) else []
+    sweep_ids = [int(x) for x in args.pairs_sweep.split(",") if x.strip()] if (world == 1 and P == 1 and not scales) else []
     vit = eng.vit
     for Ps in sweep_ids:
         try:
@@ -269,7 +282,7 @@ def main():
         rep.close()
         return
 
-    fams = kernel_families(T, D, eng.vit.heads, P)
+    fams = kernel_families(T if not scales else T[0], D, eng.vit.heads, P)
     roofs = []
     traffic_file = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     static_traffic = {}
@@ -309,7 +322,8 @@ def main():
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "fp8(e4m3 qkv+selfsim)/bf16" if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"Splice pair {hw[0]}x{hw[1]}, {args.model} (T={T}), {P} pair(s) per GPU per step, "
-                               f"{n_entire} of {K} timed steps include the entire-image branch",
+                               f"{n_entire} of {K} timed steps include the entire-image branch"
+                               + (f"; loss evaluated at the ViT input scales {scales} every step (configs[4])" if scales else ""),
                    "gpus": world, "pairs_per_gpu": P, "pair_steps_per_s": round(value * P, 3),
                    "pairs_per_hour_at_2000_steps": round(value * P * 3600 / 2000, 2),
                    "per_rank_steps_per_s": [round(K / t, 2) for t in per_rank_elapsed],
