@@ -381,6 +381,120 @@ __device__ __forceinline__ void gemm_epilogue_cols(const GemmEpi& e, int M, int 
     }
 }
 
+// ---- bf16 outputs through LDS ---------------------------------------------------------------------------------------
+// In the swapped fragment layout a lane owns 4 consecutive columns of one row: a direct bf16 store is 8 bytes per lane and
+// reaches memory as 32-byte row segments (2-byte elements for the transposed copy).  With P pairs per step the QKV launch
+// (bf16 + transposed bf16) and fc1 (GELU + saved pre-activation) lost a third of their time to that.  The tile is staged
+// in the ring buffers, idle after the K loop, and leaves as 16 bytes per lane along full rows (256 threads x 16 B = 4 KB of
+// complete 128 / 256-byte lines per instruction); one pass per output tensor.
+// Value of one fragment BEFORE the activation: alpha / fp8 scales / bias / residual / GELU' applied; the fp32 outputs (which
+// keep their direct 16-byte stores) are written here.
+template <unsigned FLAGS, bool PRE, bool STORE_F32 = true>
+__device__ __forceinline__ f32x4 gemm_frag_value(const GemmEpi& e, int M, int N, int row, int col0, f32x4 v, float4 pre_bias, float4 pre_resid,
+                                                 uint2 pre_aux) {
+    const bool inb = row < M && col0 < N;
+    const int rowc = min(row, M - 1), colc = min(col0, N - 4);   // N % 4 == 0 on this path
+    float x[4] = {v[0], v[1], v[2], v[3]};
+    if (FLAGS & EPI_ALPHA) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] *= e.alpha;
+    }
+    if (FLAGS & EPI_SCALE_RC) {
+        const float rs = e.row_scale[rowc];
+        const float4 cs = *reinterpret_cast<const float4*>(e.col_scale + colc);
+        x[0] *= rs * cs.x; x[1] *= rs * cs.y; x[2] *= rs * cs.z; x[3] *= rs * cs.w;
+    }
+    if (FLAGS & EPI_BIAS) {
+        const float4 b = PRE ? pre_bias : *reinterpret_cast<const float4*>(e.bias + colc);
+        x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w;
+    }
+    if (FLAGS & EPI_RESID) {
+        const int rr = e.resid_mod ? rowc % e.resid_mod : rowc;
+        const float4 b = PRE ? pre_resid : *reinterpret_cast<const float4*>(e.resid + (size_t)rr * e.ldr + colc);
+        x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w;
+    }
+    if (FLAGS & EPI_GELU_GRAD) {
+        const uint2 u = PRE ? pre_aux : *reinterpret_cast<const uint2*>(e.aux + (size_t)rowc * e.ldaux + colc);
+        x[0] *= gelu_grad_f(bf2f((bf16_t)(u.x & 0xFFFF))); x[1] *= gelu_grad_f(bf2f((bf16_t)(u.x >> 16)));
+        x[2] *= gelu_grad_f(bf2f((bf16_t)(u.y & 0xFFFF))); x[3] *= gelu_grad_f(bf2f((bf16_t)(u.y >> 16)));
+    }
+    if (inb) {
+        if ((FLAGS & EPI_OUT_F32) && STORE_F32) *reinterpret_cast<float4*>(e.out_f32 + (size_t)row * e.ldo + col0) = float4{x[0], x[1], x[2], x[3]};
+        if (FLAGS & EPI_COLS_F32) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = col0 + r;
+                if (c >= e.col_lo && c < e.col_hi) e.out_f32_cols[(size_t)row * e.ld_cols + (c - e.col_lo)] = x[r];
+            }
+        }
+    }
+    return f32x4{x[0], x[1], x[2], x[3]};
+}
+// one staged pass: every wave writes its fragments (bf16) into cs [BM][BN + 8] (or transposed [BN][BM + 8]), then the
+// workgroup stores the tile with 16-byte chunks along the rows of `out` (row stride ld); rows < row_lo are not stored
+template <int BM, int BN, bool TRANSPOSED>
+__device__ __forceinline__ void gemm_stage_store(const f32x4 (&acc)[BM / 32][BN / 32], bf16_t* cs, bf16_t* out, int ld, int M, int N, int m0, int n0,
+                                                 int row_lo) {
+    constexpr int FMt = BM / 32, FNt = BN / 32;
+    constexpr int R = TRANSPOSED ? BN : BM, Cc = TRANSPOSED ? BM : BN, PITCH = Cc + 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    __syncthreads();   // the ring (or the previous pass) is no longer read
+#pragma unroll
+    for (int i = 0; i < FMt; ++i)
+#pragma unroll
+        for (int j = 0; j < FNt; ++j) {
+            const int lr = wm * (BM / 2) + i * 16 + (lane & 15), lc = wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+            const f32x4 v = acc[i][j];
+            if (!TRANSPOSED) {
+                *reinterpret_cast<uint2*>(cs + lr * PITCH + lc) = uint2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cs[(lc + r) * PITCH + lr] = f2bf(v[r]);
+            }
+        }
+    __syncthreads();
+    // tile coordinates in the OUTPUT's frame: rows r0.., columns c0.. ; limits Rm, Cm
+    const int r0 = TRANSPOSED ? n0 : m0, c0 = TRANSPOSED ? m0 : n0, Rm = TRANSPOSED ? N : M, Cm = TRANSPOSED ? M : N;
+    constexpr int CH = Cc / 8;   // 16-byte chunks per tile row
+    for (int c = threadIdx.x; c < R * CH; c += 256) {
+        const int r = c / CH, k = (c % CH) * 8;
+        const int gr = r0 + r, gc = c0 + k;
+        if (gr >= Rm || gc >= Cm) continue;
+        if (!TRANSPOSED && gr < row_lo) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(cs + r * PITCH + k);
+        bf16_t* q = out + (size_t)gr * ld + gc;
+        if (gc + 7 < Cm && !(ld & 7)) *reinterpret_cast<u32x4*>(q) = v;
+        else {
+            const bf16_t* h = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (gc + t < Cm) q[t] = h[t];
+        }
+    }
+}
+
+// the same for an fp32 output tile: cs [BM][BN + 4] floats; a lane's float4 becomes part of a full 256-byte row line
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_stage_store_f32(const f32x4 (&acc)[BM / 32][BN / 32], float* cs, float* out, int ld, int M, int N, int m0, int n0) {
+    constexpr int FMt = BM / 32, FNt = BN / 32, PITCH = BN + 4, CH = BN / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FMt; ++i)
+#pragma unroll
+        for (int j = 0; j < FNt; ++j) {
+            const int lr = wm * (BM / 2) + i * 16 + (lane & 15), lc = wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+            *reinterpret_cast<f32x4*>(cs + lr * PITCH + lc) = acc[i][j];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < BM * CH; c += 256) {
+        const int r = c / CH, k = (c % CH) * 4;
+        const int gr = m0 + r, gc = n0 + k;
+        if (gr >= M || gc >= N) continue;   // N % 4 == 0: a chunk is inside or outside as a whole
+        *reinterpret_cast<f32x4*>(out + (size_t)gr * ld + gc) = *reinterpret_cast<const f32x4*>(cs + r * PITCH + k);
+    }
+}
+
 template <int BM, int BN, unsigned FLAGS, int NS, bool FP8 = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
                                                       int ldb, int M, int N, int K, GemmEpi e, int gm, int ksplit) {
@@ -406,8 +520,83 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
     // one memory round trip each (4 ... 16 per lane, the residual usually an L2 miss).  With N and the leading dimensions
     // multiples of 4 every fragment's operands are loaded first, from clamped (always valid) addresses.
     constexpr bool HAS_OPERANDS = (FLAGS & (EPI_BIAS | EPI_RESID | EPI_GELU_GRAD)) != 0;
+    constexpr bool STAGE_F32_FITS = (size_t)NS * GemmTile<BM, BN>::LDS_ELEMS * 2 >= (size_t)BM * (BN + 4) * 4;
     const bool pre_ok = HAS_OPERANDS && !(N & 3) && (!(FLAGS & EPI_RESID) || !(e.ldr & 3)) && (!(FLAGS & EPI_GELU_GRAD) || !(e.ldaux & 3));
-    if (pre_ok) {
+    // staged bf16 outputs (see gemm_stage_store): every vector access of gemm_frag_value must be aligned
+    const bool stage_ok = (FLAGS & EPI_OUT_BF) && !(N & 3) && (!(FLAGS & EPI_RESID) || !(e.ldr & 3)) && (!(FLAGS & EPI_GELU_GRAD) || !(e.ldaux & 3)) &&
+                          (!(FLAGS & EPI_OUT_F32) || !(e.ldo & 3)) && (!(FLAGS & EPI_OUT_T) || !(e.ldt & 7));
+    if ((FLAGS & EPI_OUT_BF) && stage_ok) {
+        constexpr int FMt = GemmTile<BM, BN>::FM, FNt = GemmTile<BM, BN>::FN;
+        static_assert((size_t)NS * GemmTile<BM, BN>::LDS_ELEMS >= (size_t)BM * (BN + 8) && (size_t)NS * GemmTile<BM, BN>::LDS_ELEMS >= (size_t)BN * (BM + 8),
+                      "the ring must hold one staged output tile");
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+        float4 pb[FNt], pr[FMt][FNt];
+        uint2 pa[FMt][FNt];
+        if (HAS_OPERANDS) {   // operands of every fragment before the first use (clamped addresses)
+#pragma unroll
+            for (int j = 0; j < FNt; ++j) {
+                const int colc = min(n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4, N - 4);
+                if (FLAGS & EPI_BIAS) pb[j] = *reinterpret_cast<const float4*>(e.bias + colc);
+#pragma unroll
+                for (int i = 0; i < FMt; ++i) {
+                    const int rowc = min(m0 + wm * (BM / 2) + i * 16 + (lane & 15), M - 1);
+                    const int rr = e.resid_mod ? rowc % e.resid_mod : rowc;
+                    if (FLAGS & EPI_RESID) pr[i][j] = *reinterpret_cast<const float4*>(e.resid + (size_t)rr * e.ldr + colc);
+                    if (FLAGS & EPI_GELU_GRAD) pa[i][j] = *reinterpret_cast<const uint2*>(e.aux + (size_t)rowc * e.ldaux + colc);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FMt; ++i)
+#pragma unroll
+            for (int j = 0; j < FNt; ++j)
+                tile.acc[i][j] = gemm_frag_value<FLAGS, HAS_OPERANDS>(e, M, N, m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4,
+                                                                      tile.acc[i][j], pb[j], pr[i][j], pa[i][j]);
+        if (FLAGS & EPI_GELU) {
+            if (e.out_pre) gemm_stage_store<BM, BN, false>(tile.acc, gemm_smem, e.out_pre, e.ldp, M, N, m0, n0, e.pre_row_lo);   // only gradient-carrying rows need it
+#pragma unroll
+            for (int i = 0; i < FMt; ++i)
+#pragma unroll
+                for (int j = 0; j < FNt; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tile.acc[i][j][r] = gelu_f(tile.acc[i][j][r]);
+        }
+        gemm_stage_store<BM, BN, false>(tile.acc, gemm_smem, e.out_bf, e.ldbf, M, N, m0, n0, 0);
+        if (FLAGS & EPI_OUT_T) gemm_stage_store<BM, BN, true>(tile.acc, gemm_smem, e.out_bf_t, e.ldt, M, N, m0, n0, 0);
+        if (FLAGS & EPI_ROWDOT) {   // the row dots below use the bf16-ROUNDED result: round the accumulators in place
+#pragma unroll
+            for (int i = 0; i < FMt; ++i)
+#pragma unroll
+                for (int j = 0; j < FNt; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tile.acc[i][j][r] = bf2f(f2bf(tile.acc[i][j][r]));
+        }
+    } else if (STAGE_F32_FITS && (FLAGS & EPI_OUT_F32) && !(FLAGS & (EPI_OUT_BF | EPI_COLS_F32)) && !(N & 3) && !(e.ldo & 3) && (!(FLAGS & EPI_RESID) || !(e.ldr & 3))) {
+        // fp32 output (proj / fc2 forward, the dgrads into LayerNorm backward): staged like the bf16 tiles (where the ring holds the tile)
+        constexpr int FMt = GemmTile<BM, BN>::FM, FNt = GemmTile<BM, BN>::FN;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+        float4 pb[FNt], pr[FMt][FNt];
+        if (HAS_OPERANDS) {
+#pragma unroll
+            for (int j = 0; j < FNt; ++j) {
+                const int colc = min(n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4, N - 4);
+                if (FLAGS & EPI_BIAS) pb[j] = *reinterpret_cast<const float4*>(e.bias + colc);
+#pragma unroll
+                for (int i = 0; i < FMt; ++i) {
+                    const int rowc = min(m0 + wm * (BM / 2) + i * 16 + (lane & 15), M - 1);
+                    const int rr = e.resid_mod ? rowc % e.resid_mod : rowc;
+                    if (FLAGS & EPI_RESID) pr[i][j] = *reinterpret_cast<const float4*>(e.resid + (size_t)rr * e.ldr + colc);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FMt; ++i)
+#pragma unroll
+            for (int j = 0; j < FNt; ++j)
+                tile.acc[i][j] = gemm_frag_value<FLAGS, HAS_OPERANDS, false>(e, M, N, m0 + wm * (BM / 2) + i * 16 + (lane & 15),
+                                                                             n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4, tile.acc[i][j], pb[j], pr[i][j], uint2{});
+        if constexpr (STAGE_F32_FITS) gemm_stage_store_f32<BM, BN>(tile.acc, reinterpret_cast<float*>(gemm_smem), e.out_f32, e.ldo, M, N, m0, n0);
+    } else if (pre_ok) {
         constexpr int FMt = GemmTile<BM, BN>::FM, FNt = GemmTile<BM, BN>::FN;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
         float4 pb[FNt], pr[FMt][FNt];
