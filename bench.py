@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4] operand path: QKV projections + key self-similarity Gram on the fp8 MFMA (own tolerance table)")
     ap.add_argument("--scales", default="", help="BASELINE configs[4]: comma list of ViT input scales evaluated per step on the same crops (e.g. 224,320,448); "
                                                  "one fused step per scale + one Adam (MultiScaleEngine); disables the sweep / roofline / train-regime legs")
+    ap.add_argument("--full-top-block", action="store_true", help="compute the whole top ViT block (default: behind its QKV projection only the [CLS] rows, "
+                                                                  "all the losses read besides the keys)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-regime", action="store_true", help="skip the train_model-shaped leg (random crops + augmentations + logging)")
     ap.add_argument("--prof-kernels", default="4,5,3,6", help="kernel families timed live with HIP events for the roofline leg ('' = off): 4 fc2 fwd, 1 fc1 fwd, 2 qkv fwd, 3 attention fwd, 5 split-K dgrads, 6 attention bwd")
@@ -221,7 +223,7 @@ def main():
                                scales=scales, device=dev, fp8=args.fp8)
         A, B = torch.from_numpy(Ai).to(dev), torch.from_numpy(Bi).to(dev)
     else:
-        eng, A, B = synthetic_engine(cfg, pair_id=rep.pair_id() * P, hw=hw, seed=1234, device=dev, pairs=P, fp8=args.fp8)
+        eng, A, B = synthetic_engine(cfg, pair_id=rep.pair_id() * P, hw=hw, seed=1234, device=dev, pairs=P, fp8=args.fp8, top_cls_only=not args.full_top_block)
     K, W = args.steps, args.warmup
 
     def barrier():
@@ -264,7 +266,7 @@ def main():
     vit = eng.vit
     for Ps in sweep_ids:
         try:
-            e2, A2, B2 = synthetic_engine(cfg, pair_id=0, hw=hw, seed=1234, device=dev, pairs=Ps, vit_engine=vit, fp8=args.fp8)
+            e2, A2, B2 = synthetic_engine(cfg, pair_id=0, hw=hw, seed=1234, device=dev, pairs=Ps, vit_engine=vit, fp8=args.fp8, top_cls_only=not args.full_top_block)
             k2 = max(20, K // 4)
             sweep[Ps] = k2 / time_steps(e2, A2, B2, k2, max(5, W // 2), barrier)
             del e2, A2, B2

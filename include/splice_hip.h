@@ -178,6 +178,11 @@ int splice_vit_ctx_create(void* vit, int B, int H, int W, const float* pos_TD, i
                           splice_stream_t stream, void** out_ctx);
 void splice_vit_ctx_destroy(void* ctx);
 int splice_vit_ctx_info(void* ctx, int* T, int* Tld, int* rows);
+/* on != 0: behind the QKV projection of the TOP block only the [CLS] row of every pass is computed -- all the Splice losses
+ * read of that block besides its keys (util/losses.py:90: [CLS] of block 11).  Then kind-0 rows other than [CLS] are
+ * undefined for layer depth-1, and d_block[depth-1] must be zero outside the [CLS] rows.  splice_step_create switches its
+ * contexts to this mode; the extractor API (models/extractor.py:81-103 hands out every token) never does. */
+int splice_vit_ctx_set_top_cls_only(void* ctx, int on);
 /* img fp32 [B][3][H][W]; normalize != 0 fuses transforms.Normalize (util/losses.py:19). */
 int splice_vit_forward(void* ctx, const float* img, int normalize, splice_stream_t stream);
 /* same; passes [0, grad_pass_begin) are no-grad targets (util/losses.py:79,91,101 `with torch.no_grad()`):
@@ -288,6 +293,8 @@ typedef struct splice_step_config {
     long long arena_stride;      /* P > 1: floats between the pairs' parameter / gradient / Adam-moment arenas (>= param count);
                                   * the generator plans must have been given the same stride (splice_gen_plan_set_arena_stride) */
     int fp8_selfsim;             /* != 0: the key self-similarity Gram matrices on the fp8 MFMA (per-row e4m3 keys; dim % 128 == 0) */
+    int top_cls_only;            /* != 0: the step switches its ViT contexts to splice_vit_ctx_set_top_cls_only (the Python engine's default;
+                                  * results differ from the full top block by rounding only) */
     int n_crops;                 /* > 1 (with pairs <= 1): global_{A,B}_crops_n_crops of conf/default/config.yaml -- the step works on
                                   * n_crops crops of ONE pair: A_crop / B_crop are [n_crops][3][h][w], the generator plans hold n_crops
                                   * images in batch-statistics mode (splice_gen_plan_set_batch_stats: netG sees the stacked crops,

@@ -42,7 +42,7 @@ class StepConfig(C.Structure):
         ("lambda_entire_cls", C.c_float), ("lambda_entire_ssim", C.c_float),
         ("entire_every", C.c_int), ("cls_warmup", C.c_int),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-        ("pairs", C.c_int), ("arena_stride", C.c_longlong), ("fp8_selfsim", C.c_int), ("n_crops", C.c_int),
+        ("pairs", C.c_int), ("arena_stride", C.c_longlong), ("fp8_selfsim", C.c_int), ("top_cls_only", C.c_int), ("n_crops", C.c_int),
     ]
 
 
@@ -85,6 +85,7 @@ _SIGNATURES = {
     "splice_vit_ctx_create": ([_vp, _i, _i, _i, _vp, _i, _vp, C.POINTER(_vp)], _i),
     "splice_vit_ctx_destroy": ([_vp], None),
     "splice_vit_ctx_info": ([_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _i),
+    "splice_vit_ctx_set_top_cls_only": ([_vp, _i], _i),
     "splice_vit_forward": ([_vp, _vp, _i, _vp], _i),
     "splice_vit_forward_ex": ([_vp, _vp, _i, _i, _vp], _i),
     "splice_vit_forward_passes": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),

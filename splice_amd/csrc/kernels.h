@@ -25,6 +25,18 @@ int attn_bwd_launch(const AttnArgs* a, hipStream_t s);
 int attn_probs_launch(const AttnArgs* a, float* probs, hipStream_t s);
 void attn_set_variant(int v);   // benchmarking hook
 
+// ---- vit_cls.hip: the tail of the top block on the [CLS] rows only ---------------------------
+int attn_cls_fwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, int T, int Tld, int D, int H, float scale, bf16_t* out, float* probs,
+                        hipStream_t s);
+int attn_cls_bwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, int T, int Tld, int D, int H, float scale, const float* probs,
+                        const float* dout_slabs, int n_slabs, size_t slab_stride, bf16_t* dqkv, hipStream_t s);
+int ln_rows_fwd_launch(float* x, size_t xs, const float* gamma, const float* beta, bf16_t* y, size_t ys, float* mean, float* rstd, size_t ss, int rows,
+                       int D, float eps, const float* slabs, int n_slabs, size_t slab_stride, const float* bias, const float* resid, size_t rs, hipStream_t s);
+int ln_rows_bwd_launch(float* dy, size_t dys, const float* x, size_t xs, const float* gamma, const float* mean, const float* rstd, size_t ss, float* g,
+                       bf16_t* g_bf, int rows, int D, int n_slabs, size_t slab_stride, hipStream_t s);
+int rows_finish_launch(int mode, const float* slabs, int n_slabs, size_t slab_stride, int rows, int N, const float* bias, const float* resid, size_t rs,
+                       float* out_f32, size_t os, bf16_t* out_bf, bf16_t* pre_bf, const bf16_t* aux, size_t ps, int pre_lo, hipStream_t s);
+
 // ---- gemm.hip --------------------------------------------------------------------------
 // Runtime dispatch over the instantiated (tile, epilogue-flag) combinations.
 int gemm_nt_launch(unsigned flags, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K,

@@ -26,6 +26,7 @@ void splice_set_error(const char* fmt, ...);
 extern "C" {
 int splice_vit_ctx_info(void* ctx, int* T, int* Tld, int* rows);
 int splice_vit_ctx_dims(void* ctx, int* B, int* H, int* W, int* D, int* depth, int* heads, int* patch);
+int splice_vit_ctx_set_top_cls_only(void* ctx, int on);
 int splice_vit_forward(void* ctx, const float* img, int normalize, splice_stream_t stream);
 int splice_vit_forward_ex(void* ctx, const float* img, int normalize, int grad_pass_begin, splice_stream_t stream);
 int splice_vit_get_tensor(void* ctx, int kind, int layer, void** out);
@@ -138,6 +139,10 @@ static int view_init(SpliceStep* st, VitView& v, void* ctx, int want_B) {
     v.ctx = ctx;
     RC(splice_vit_ctx_dims(ctx, &v.B, &v.H, &v.W, &v.D, &v.depth, &v.heads, &v.patch));
     RC(splice_vit_ctx_info(ctx, &v.T, &v.Tld, &v.rows));
+    // Of the top block the losses read the keys and the [CLS] row (util/losses.py:90); cfg.top_cls_only skips the rest of it
+    // (vit_cls.hip): +2.7 % / +5.2 % pair-steps/s at 4 / 8 pairs per GPU, neutral at one pair (the M = passes kernels of the tail
+    // are as latency-bound as the full-size ones they replace), DESIGN.md section 8.
+    RC(splice_vit_ctx_set_top_cls_only(ctx, st->cfg.top_cls_only));
     if (v.B != want_B) { splice_set_error("splice_step_create: ViT context has batch %d, need %d", v.B, want_B); return SPLICE_ERR_ARG; }
     RC(salloc(st, &v.d_block, (size_t)v.rows * v.D));
     RC(salloc(st, &v.d_keys, (size_t)v.rows * v.D));

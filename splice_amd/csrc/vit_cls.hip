@@ -1,0 +1,279 @@
+// The top ViT block computed only where the Splice losses read it (DESIGN.md section 10 of round 1).
+//
+// util/losses.py uses two things of the last block: the KEYS of every token (qkv of layer 11: structure + identity terms) and
+// the [CLS] row of its output (appearance term, util/losses.py:90).  Everything of layer 11 behind the QKV projection --
+// attention, proj, LayerNorm, fc1, fc2 -- is therefore needed for ONE query row per pass; the reference computes all T rows
+// because a hooked nn.Module cannot do less.  The fused step runs that tail on the [CLS] rows only:
+//   forward : attention of the [CLS] query over all keys (this file) -> proj / fc1 / fc2 GEMMs with M = passes on strided rows
+//             (the GEMM takes any row stride) -> LayerNorm of the strided rows (this file);
+//   backward: the same chain on one row per pass; the attention backward for a single query is a rank-1 update of dK / dV
+//             plus one dQ row (this file).
+// The façade (VitExtractor) keeps the full layer: its callers may read any token of block 11.
+#include "kernels.h"
+
+#define LOG2E 1.4426950408889634f
+
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max256(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// grid (H, B): softmax(q_cls . k_j * scale) v over the T keys of one (pass, head), fp32 statistics.
+//   qkv  bf16 [B*Tld][3D]; qkvT bf16 [3D][ldt] (token-contiguous V for the second product)
+//   out  bf16 [B][D] (compact: one row per pass); probs fp32 [B][H][Tld] (saved for the backward; 0 beyond T)
+__global__ __launch_bounds__(256) void attn_cls_fwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qkvT, int ldt, int T, int Tld, int D,
+                                                           float scale, bf16_t* __restrict__ out, float* __restrict__ probs) {
+    extern __shared__ float cls_smem[];   // [Tld] probabilities | [64] q | [256] partial o | [4] reductions
+    float* p = cls_smem;
+    float* q = p + Tld;
+    float* po = q + 64;
+    float* red = po + 256;
+    const int h = blockIdx.x, b = blockIdx.y, H = gridDim.x;
+    const size_t row0 = (size_t)b * Tld;
+    if (threadIdx.x < 64) q[threadIdx.x] = bf2f(qkv[row0 * 3 * D + h * 64 + threadIdx.x]) * scale;
+    __syncthreads();
+    float mx = -1e30f;
+    for (int j = threadIdx.x; j < T; j += 256) {
+        const u32x4* kr = reinterpret_cast<const u32x4*>(qkv + (row0 + j) * 3 * D + D + h * 64);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const u32x4 v = kr[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                s += q[c * 8 + 2 * e] * __uint_as_float(v[e] << 16) + q[c * 8 + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
+        }
+        p[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = block_max256(mx, red);
+    float sum = 0.f;
+    for (int j = threadIdx.x; j < Tld; j += 256) {
+        const float e = j < T ? __builtin_amdgcn_exp2f((p[j] - mx) * LOG2E) : 0.f;
+        p[j] = e;
+        sum += e;
+    }
+    sum = block_sum256(sum, red);
+    const float inv = 1.0f / sum;
+    float* pg = probs + ((size_t)b * H + h) * Tld;
+    for (int j = threadIdx.x; j < Tld; j += 256) {
+        const float v = p[j] * inv;
+        p[j] = v;
+        pg[j] = v;
+    }
+    __syncthreads();
+    // o[d] = sum_j p_j v_j[d]: thread = (d, quarter of the tokens), token-contiguous reads from the transposed copy
+    const int d = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const bf16_t* vt = qkvT + (size_t)(2 * D + h * 64 + d) * ldt + row0;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int j = 8 * part; j < Tld; j += 32) {   // 8 tokens (16 bytes) per load; p is zero beyond T and the padding columns are finite
+        const u32x4 v = *reinterpret_cast<const u32x4*>(vt + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += p[j + 2 * e] * __uint_as_float(v[e] << 16) + p[j + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
+    }
+    po[part * 64 + d] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) out[(size_t)b * D + h * 64 + threadIdx.x] = f2bf((po[threadIdx.x] + po[64 + threadIdx.x]) + (po[128 + threadIdx.x] + po[192 + threadIdx.x]));
+}
+
+// grid (H, B): backward of the above for dO given at the [CLS] query only.  Writes the WHOLE [Tld] x (q | k | v head slices) block
+// of dqkv bf16 [B*Tld][3D]: dq on the [CLS] row (zero elsewhere), dk_j = ds_j q_cls, dv_j = p_j dO, zero rows beyond T.
+__global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qkvT, int ldt, int T, int Tld, int D,
+                                                           float scale, const float* __restrict__ probs, const float* __restrict__ dout /* n_slabs x [*][D] fp32 */,
+                                                           int n_slabs, size_t slab_stride, bf16_t* __restrict__ dqkv) {
+    extern __shared__ float cls_smem[];   // [Tld] ds | [64] q | [64] dO | [256] partial dq | [4]
+    float* ds = cls_smem;
+    float* q = ds + Tld;
+    float* dO = q + 64;
+    float* pq = dO + 64;
+    float* red = pq + 256;
+    const int h = blockIdx.x, b = blockIdx.y, H = gridDim.x;
+    const size_t row0 = (size_t)b * Tld;
+    const float* pg = probs + ((size_t)b * H + h) * Tld;
+    if (threadIdx.x < 64) {
+        q[threadIdx.x] = bf2f(qkv[row0 * 3 * D + h * 64 + threadIdx.x]);
+        float v = 0.f;   // the proj^T GEMM ran split-K over many workgroups (M = passes: the K walk is its whole run time): slabs summed here, in order
+        for (int sl = 0; sl < n_slabs; ++sl) v += dout[(size_t)sl * slab_stride + (size_t)b * D + h * 64 + threadIdx.x];
+        dO[threadIdx.x] = bf2f(f2bf(v));   // (bf16 like the full path's dout)
+    }
+    __syncthreads();
+    // dP_j = dO . v_j ; delta = sum_j p_j dP_j
+    float dl = 0.f;
+    for (int j = threadIdx.x; j < T; j += 256) {
+        const u32x4* vr = reinterpret_cast<const u32x4*>(qkv + (row0 + j) * 3 * D + 2 * D + h * 64);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const u32x4 v = vr[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                s += dO[c * 8 + 2 * e] * __uint_as_float(v[e] << 16) + dO[c * 8 + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
+        }
+        ds[j] = s;
+        dl += pg[j] * s;
+    }
+    const float delta = block_sum256(dl, red);
+    // ds_j = p_j (dP_j - delta) * scale ; rows: dk_j = ds_j q, dv_j = p_j dO, dq_j = 0 (j > 0)
+    for (int j = threadIdx.x; j < Tld; j += 256) {
+        const float pj = j < T ? pg[j] : 0.f;
+        const float dsj = j < T ? pj * (ds[j] - delta) * scale : 0.f;
+        ds[j] = dsj;
+        bf16_t* r = dqkv + (row0 + j) * 3 * D + h * 64;
+        u32x4* rq = reinterpret_cast<u32x4*>(r);
+        u32x4* rk = reinterpret_cast<u32x4*>(r + D);
+        u32x4* rv = reinterpret_cast<u32x4*>(r + 2 * D);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {   // 16-byte stores: 8 per 64-wide head slice
+            if (j != 0) rq[c] = u32x4{0u, 0u, 0u, 0u};
+            rk[c] = u32x4{pack2bf(dsj * q[8 * c], dsj * q[8 * c + 1]), pack2bf(dsj * q[8 * c + 2], dsj * q[8 * c + 3]),
+                          pack2bf(dsj * q[8 * c + 4], dsj * q[8 * c + 5]), pack2bf(dsj * q[8 * c + 6], dsj * q[8 * c + 7])};
+            rv[c] = u32x4{pack2bf(pj * dO[8 * c], pj * dO[8 * c + 1]), pack2bf(pj * dO[8 * c + 2], pj * dO[8 * c + 3]),
+                          pack2bf(pj * dO[8 * c + 4], pj * dO[8 * c + 5]), pack2bf(pj * dO[8 * c + 6], pj * dO[8 * c + 7])};
+        }
+    }
+    __syncthreads();
+    // dq_cls[d] = sum_j ds_j k_j[d]
+    const int d = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const bf16_t* kt = qkvT + (size_t)(D + h * 64 + d) * ldt + row0;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int j = 8 * part; j < Tld; j += 32) {   // ds is zero beyond T
+        const u32x4 v = *reinterpret_cast<const u32x4*>(kt + j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc += ds[j + 2 * e] * __uint_as_float(v[e] << 16) + ds[j + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
+    }
+    pq[part * 64 + d] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64)
+        dqkv[row0 * 3 * D + h * 64 + threadIdx.x] = f2bf((pq[threadIdx.x] + pq[64 + threadIdx.x]) + (pq[128 + threadIdx.x] + pq[192 + threadIdx.x]));
+}
+
+int attn_cls_fwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, int T, int Tld, int D, int H, float scale, bf16_t* out, float* probs,
+                        hipStream_t s) {
+    if (D / 64 != H || D % 64) return SPLICE_ERR_ARG;
+    const size_t lds = (size_t)(Tld + 64 + 256 + 8) * sizeof(float);
+    hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(H, B), dim3(256), lds, s, qkv, qkvT, ldt, T, Tld, D, scale, out, probs);
+    return SPLICE_OK;
+}
+int attn_cls_bwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, int T, int Tld, int D, int H, float scale, const float* probs,
+                        const float* dout_slabs, int n_slabs, size_t slab_stride, bf16_t* dqkv, hipStream_t s) {
+    if (D / 64 != H || D % 64) return SPLICE_ERR_ARG;
+    const size_t lds = (size_t)(Tld + 64 + 64 + 256 + 8) * sizeof(float);
+    hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(H, B), dim3(256), lds, s, qkv, qkvT, ldt, T, Tld, D, scale, probs, dout_slabs, n_slabs, slab_stride, dqkv);
+    return SPLICE_OK;
+}
+
+// ---- LayerNorm on a few strided rows (one wave per row): row r at x + r * xs; statistics at [r * ss]
+// slabs != null: the row is first FORMED as bias + resid_row + sum of the n_slabs split-K slabs of the producing GEMM
+// (slabs[s * slab_stride + row * D + c], in slab order) and stored to x -- the M = passes GEMMs of the [CLS] tail run
+// split-K over many workgroups because their run time is the serial K walk, not the rows.
+__global__ __launch_bounds__(256) void ln_rows_fwd_kernel(float* __restrict__ x, size_t xs, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          bf16_t* __restrict__ y, size_t ys, float* __restrict__ mean_o, float* __restrict__ rstd_o, size_t ss,
+                                                          int rows, int D, float eps, const float* __restrict__ slabs, int n_slabs, size_t slab_stride,
+                                                          const float* __restrict__ bias, const float* __restrict__ resid, size_t rs) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* xr = x + (size_t)row * xs;
+    if (slabs) {
+        for (int c = lane; c < D; c += 64) {
+            float v = bias[c] + resid[(size_t)row * rs + c];
+            for (int sl = 0; sl < n_slabs; ++sl) v += slabs[(size_t)sl * slab_stride + (size_t)row * D + c];
+            xr[c] = v;
+        }
+    }
+    float sum = 0.f;
+    for (int c = lane; c < D; c += 64) sum += xr[c];
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+    for (int c = lane; c < D; c += 64) { const float d = xr[c] - mean; sq += d * d; }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+    if (lane == 0) { mean_o[(size_t)row * ss] = mean; rstd_o[(size_t)row * ss] = rstd; }
+    bf16_t* yr = y + (size_t)row * ys;
+    for (int c = lane; c < D; c += 64) yr[c] = f2bf((xr[c] - mean) * rstd * gamma[c] + beta[c]);
+}
+// g (strided like x, in place) += LN_backward(dy); g_bf = bf16(g).  dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)), dxhat = dy gamma
+// n_slabs > 1: dy is given as split-K slabs (dy + s * slab_stride), summed in place into slab 0 first
+__global__ __launch_bounds__(256) void ln_rows_bwd_kernel(float* __restrict__ dy, size_t dys, const float* __restrict__ x, size_t xs,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                          size_t ss, float* __restrict__ g, bf16_t* __restrict__ g_bf, int rows, int D, int n_slabs,
+                                                          size_t slab_stride) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * xs;
+    float* dr = dy + (size_t)row * dys;
+    if (n_slabs > 1) {
+        for (int c = lane; c < D; c += 64) {
+            float v = dr[c];
+            for (int sl = 1; sl < n_slabs; ++sl) v += dr[(size_t)sl * slab_stride + c];
+            dr[c] = v;
+        }
+    }
+    const float mean = mean_i[(size_t)row * ss], rstd = rstd_i[(size_t)row * ss];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float dh = dr[c] * gamma[c], xh = (xr[c] - mean) * rstd;
+        s1 += dh;
+        s2 += dh * xh;
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+    float* gr = g + (size_t)row * xs;
+    bf16_t* gb = g_bf + (size_t)row * xs;
+    for (int c = lane; c < D; c += 64) {
+        const float dh = dr[c] * gamma[c], xh = (xr[c] - mean) * rstd;
+        const float v = gr[c] + rstd * (dh - s1 - xh * s2);
+        gr[c] = v;
+        gb[c] = f2bf(v);
+    }
+}
+int ln_rows_fwd_launch(float* x, size_t xs, const float* gamma, const float* beta, bf16_t* y, size_t ys, float* mean, float* rstd, size_t ss, int rows,
+                       int D, float eps, const float* slabs, int n_slabs, size_t slab_stride, const float* bias, const float* resid, size_t rs, hipStream_t s) {
+    hipLaunchKernelGGL(ln_rows_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, xs, gamma, beta, y, ys, mean, rstd, ss, rows, D, eps, slabs, n_slabs, slab_stride,
+                       bias, resid, rs);
+    return SPLICE_OK;
+}
+int ln_rows_bwd_launch(float* dy, size_t dys, const float* x, size_t xs, const float* gamma, const float* mean, const float* rstd, size_t ss, float* g,
+                       bf16_t* g_bf, int rows, int D, int n_slabs, size_t slab_stride, hipStream_t s) {
+    hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, dy, dys, x, xs, gamma, mean, rstd, ss, g, g_bf, rows, D, n_slabs, slab_stride);
+    return SPLICE_OK;
+}
+
+// ---- finishers of the split-K [CLS]-row GEMMs: out = f(bias + sum of slabs); one thread per element (rows x N is tiny)
+// mode 0: out_f32[row * os + n] = v + resid[row * rs + n]                      (fc2: the block output rows)
+// mode 1: pre = v; out_bf[row * N + n] = gelu(v); pre_bf[row * ps + n] = bf16(v) for rows >= pre_lo   (fc1)
+// mode 2: out_bf[row * N + n] = v * gelu'(aux[row * ps + n])  (no bias)        (fc2^T)
+__global__ __launch_bounds__(256) void rows_finish_kernel(int mode, const float* __restrict__ slabs, int n_slabs, size_t slab_stride, int rows, int N,
+                                                          const float* __restrict__ bias, const float* __restrict__ resid, size_t rs, float* __restrict__ out_f32,
+                                                          size_t os, bf16_t* __restrict__ out_bf, bf16_t* __restrict__ pre_bf, const bf16_t* __restrict__ aux,
+                                                          size_t ps, int pre_lo) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * N) return;
+    const int row = i / N, n = i % N;
+    float v = (mode != 2 && bias) ? bias[n] : 0.f;
+    for (int sl = 0; sl < n_slabs; ++sl) v += slabs[(size_t)sl * slab_stride + (size_t)row * N + n];
+    if (mode == 0) {
+        out_f32[(size_t)row * os + n] = v + resid[(size_t)row * rs + n];
+    } else if (mode == 1) {
+        if (pre_bf && row >= pre_lo) pre_bf[(size_t)row * ps + n] = f2bf(v);
+        out_bf[(size_t)row * N + n] = f2bf(gelu_f(v));
+    } else {
+        out_bf[(size_t)row * N + n] = f2bf(v * gelu_grad_f(bf2f(aux[(size_t)row * ps + n])));
+    }
+}
+int rows_finish_launch(int mode, const float* slabs, int n_slabs, size_t slab_stride, int rows, int N, const float* bias, const float* resid, size_t rs,
+                       float* out_f32, size_t os, bf16_t* out_bf, bf16_t* pre_bf, const bf16_t* aux, size_t ps, int pre_lo, hipStream_t s) {
+    hipLaunchKernelGGL(rows_finish_kernel, dim3(cdiv(rows * N, 256)), dim3(256), 0, s, mode, slabs, n_slabs, slab_stride, rows, N, bias, resid, rs, out_f32, os, out_bf,
+                       pre_bf, aux, ps, pre_lo);
+    return SPLICE_OK;
+}

@@ -113,6 +113,11 @@ struct SpliceVitCtx {
     float* dpatches = nullptr;             // [rows][3pp]
     std::vector<void*> allocs;
     int forward_done = 0;
+    // top block only where the Splice losses read it (vit_cls.hip): behind the last QKV projection only the [CLS] row of a pass goes on
+    int top_cls_only = 0;
+    bf16_t *cls_attn = nullptr, *cls_ln = nullptr, *cls_h = nullptr, *cls_dh = nullptr, *cls_dout = nullptr;   // [B][D] / [B][4D], one row per pass
+    float *cls_probs = nullptr, *cls_dln = nullptr;                                                            // [B][H][Tld], [B][D]
+    float* cls_slabs = nullptr;            // [16][B][4D] split-K slabs of the M = passes GEMMs of that tail
 };
 
 template <class T>
@@ -309,6 +314,9 @@ int splice_vit_ctx_create(void* h, int B, int H, int W, const float* pos_TD, int
     A(c->qkv_last_f32, rows * 3 * D);
     A(c->ln_out, rows * D);
     if (v->fp8) { A(c->ln_out8, rows * D); A(c->ln_scale, rows); }
+    A(c->cls_attn, (size_t)B * D); A(c->cls_ln, (size_t)B * D); A(c->cls_h, (size_t)B * Hd); A(c->cls_probs, (size_t)B * v->heads * c->Tld);
+    A(c->cls_slabs, (size_t)16 * B * Hd);
+    if (need_grad) { A(c->cls_dh, (size_t)B * Hd); A(c->cls_dout, (size_t)B * D); A(c->cls_dln, (size_t)B * D); }
     A(c->hact, rows * Hd);
     if (need_grad) {
         A(c->g, rows * D); A(c->g_bf, rows * D); A(c->dh, rows * Hd); A(c->dln, rows * D * 4);   // dln: up to 4 split-K slabs
@@ -364,6 +372,17 @@ int splice_prof_end(float* total_ms, int* launches) {
     if (launches) *launches = (int)(g_prof.used / 2);
     g_prof.which = 0;
     g_prof.used = 0;
+    return SPLICE_OK;
+}
+
+// on != 0: behind the QKV projection of the TOP block only the [CLS] row of every pass is computed (attention for one query,
+// proj / LayerNorm / fc1 / fc2 on one row) -- all the Splice losses read of that block besides its keys (util/losses.py:90).
+// Block-output rows other than [CLS] are then undefined for layer depth-1, and a gradient injected at that block output
+// must be zero outside the [CLS] rows.  The fused step switches its contexts to this mode; the extractor API never does.
+int splice_vit_ctx_set_top_cls_only(void* ctx, int on) {
+    SpliceVitCtx* c = (SpliceVitCtx*)ctx;
+    if (!c) return SPLICE_ERR_ARG;
+    c->top_cls_only = on ? 1 : 0;
     return SPLICE_OK;
 }
 
@@ -435,6 +454,43 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
             } else {
                 RC(gemm_nt_launch(fl, ln_out, D, W.qkv.w, D, R, 3 * D, D, e, s));
             }
+        }
+        if (l == L - 1 && c->top_cls_only) {
+            // the tail of the top block on the [CLS] row of every pass only (vit_cls.hip): M = passes, rows Tld apart
+            const int rs = c->Tld * D, hs = c->Tld * Hd;   // element strides between the [CLS] rows of consecutive passes
+            bf16_t* cattn = c->cls_attn + (size_t)pass_begin * D;
+            bf16_t* cln = c->cls_ln + (size_t)pass_begin * D;
+            bf16_t* ch = c->cls_h + (size_t)pass_begin * Hd;
+            RC(attn_cls_fwd_launch(c->qkv[l] + r0 * 3 * D, c->qkvT[l] + r0, c->rows, Bp, c->T, c->Tld, D, v->heads, 0.125f, cattn,
+                                   c->cls_probs + (size_t)pass_begin * v->heads * c->Tld, s));
+            // The GEMMs of this tail have M = passes rows: their run time is the serial K walk of a workgroup, not the rows, so
+            // they run split-K over many workgroups (plain fp32 slabs) and the next kernel of the chain sums the slabs.
+            const size_t sstr = (size_t)c->B * Hd;                  // slab stride (floats): room for the widest output
+            float* slabs = c->cls_slabs + (size_t)pass_begin * Hd;  // this call's rows inside every slab
+            auto ks_of = [](int K) { int n = K / 64, k = 16; while (k > 1 && n % k) --k; return k; };
+            {
+                GemmEpi e = {};
+                e.out_f32 = slabs; e.ldo = D; e.ksplit = ks_of(D); e.slab_stride = (long long)sstr;
+                RC(gemm_nt_launch(EPI_OUT_F32, cattn, D, W.proj.w, D, Bp, D, D, e, s));
+                // x_mid rows = bias + x_in rows + slabs, then LayerNorm of those rows
+                RC(ln_rows_fwd_launch(x_mid, rs, W.ln2_g, W.ln2_b, cln, D, c->mean2[l] + r0, c->rstd2[l] + r0, c->Tld, Bp, D, 1e-6f, slabs, e.ksplit, sstr,
+                                      W.proj.b, x_in, rs, s));
+            }
+            {
+                GemmEpi e = {};
+                e.out_f32 = slabs; e.ldo = Hd; e.ksplit = ks_of(D); e.slab_stride = (long long)sstr;
+                RC(gemm_nt_launch(EPI_OUT_F32, cln, D, W.fc1.w, D, Bp, Hd, D, e, s));
+                const int lo = c->grad_pass_begin - pass_begin;   // first row (= pass) whose pre-activation is kept
+                RC(rows_finish_launch(1, slabs, e.ksplit, sstr, Bp, Hd, W.fc1.b, nullptr, 0, nullptr, 0, ch, c->need_grad ? c->hpre[l] + r0 * Hd : nullptr, nullptr, hs,
+                                      lo > 0 ? lo : 0, s));
+            }
+            {
+                GemmEpi e = {};
+                e.out_f32 = slabs; e.ldo = D; e.ksplit = ks_of(Hd); e.slab_stride = (long long)sstr;
+                RC(gemm_nt_launch(EPI_OUT_F32, ch, Hd, W.fc2.w, Hd, Bp, D, Hd, e, s));
+                RC(rows_finish_launch(0, slabs, e.ksplit, sstr, Bp, D, W.fc2.b, x_mid, rs, c->xs[l + 1] + r0 * D, rs, nullptr, nullptr, nullptr, 0, 0, s));
+            }
+            continue;
         }
         {
             AttnArgs a = {};
@@ -543,7 +599,35 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
         if (!g_live && !dq && !dk) continue;
         bf16_t* dqkv = c->dqkv + r0 * 3 * D;
         const float* g_after_mlp = nullptr;  // g_in for LN1 backward
-        if (g_live) {
+        if (g_live && l == L - 1 && c->top_cls_only) {
+            // the forward ran the tail of this block on the [CLS] rows only: so does the backward (the gradient injected at the
+            // block output must be zero outside the [CLS] rows -- the Splice appearance term, util/losses.py:90)
+            const int rs = c->Tld * D, hs = c->Tld * Hd;
+            bf16_t* cdh = c->cls_dh + (size_t)pass_begin * Hd;
+            const size_t sstr = (size_t)c->B * Hd;
+            float* slabs = c->cls_slabs + (size_t)pass_begin * Hd;
+            auto ks_of = [](int K) { int n = K / 64, k = 16; while (k > 1 && n % k) --k; return k; };
+            {   // fc2^T: split-K slabs, then dh = bf16(sum * gelu'(pre))
+                GemmEpi e = {};
+                e.out_f32 = slabs; e.ldo = Hd; e.ksplit = ks_of(D); e.slab_stride = (long long)sstr;
+                RC(gemm_nt_launch(EPI_OUT_F32, g_bf, rs, W.fc2.wT, D, Bp, Hd, D, e, s));
+                RC(rows_finish_launch(2, slabs, e.ksplit, sstr, Bp, Hd, nullptr, nullptr, 0, nullptr, 0, cdh, nullptr, c->hpre[l] + r0 * Hd, hs, 0, s));
+            }
+            {   // fc1^T: slabs summed by the LayerNorm backward of the [CLS] rows
+                GemmEpi e = {};
+                e.out_f32 = slabs; e.ldo = D; e.ksplit = ks_of(Hd); e.slab_stride = (long long)sstr;
+                RC(gemm_nt_launch(EPI_OUT_F32, cdh, Hd, W.fc1.wT, Hd, Bp, D, Hd, e, s));
+                RC(ln_rows_bwd_launch(slabs, D, c->xmid[l] + r0 * D, rs, W.ln2_g, c->mean2[l] + r0, c->rstd2[l] + r0, c->Tld, g, g_bf, Bp, D, e.ksplit, sstr, s));
+            }
+            {   // proj^T: slabs summed by the single-query attention backward
+                GemmEpi e = {};
+                e.out_f32 = slabs; e.ldo = D; e.ksplit = ks_of(D); e.slab_stride = (long long)sstr;
+                RC(gemm_nt_launch(EPI_OUT_F32, g_bf, rs, W.proj.wT, D, Bp, D, D, e, s));
+                RC(attn_cls_bwd_launch(c->qkv[l] + r0 * 3 * D, c->qkvT[l] + r0, c->rows, Bp, c->T, c->Tld, D, v->heads, 0.125f,
+                                       c->cls_probs + (size_t)pass_begin * v->heads * c->Tld, slabs, e.ksplit, sstr, dqkv, s));
+            }
+            g_after_mlp = g;
+        } else if (g_live) {
             // MLP branch
             {
                 GemmEpi e = {};

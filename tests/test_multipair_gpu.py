@@ -158,3 +158,47 @@ def test_multipair_full_size_bit_identical_and_graph_modes(P):
         assert torch.equal(single.losses_dev[0], ref[1][p]), (p, single.losses_dev[0], ref[1][p])
         assert torch.equal(single.params, ref[0][p * stride: p * stride + n]), (p, (single.params - ref[0][p * stride: p * stride + n]).abs().max().item())
         del single
+
+
+@pytest.mark.parametrize("mode", [True, False])
+def test_top_block_modes_vs_oracle_and_batching(mode):
+    """Engine option ``top_cls_only`` (default True; False = the whole top block as the reference computes it): behind the QKV projection of block 11 only the [CLS] row of every pass is computed
+    (single-query attention, split-K GEMMs on one row per pass) -- all util/losses.py reads of that block besides its keys.
+    Teacher-forced steps 0-2 against the fp32 oracle (same bars as the full block), and 2 pairs batched == their own
+    single-pair runs bit for bit in this mode too."""
+    from oracle import dino_vit
+    from oracle.step import SpliceOracle
+    cfg = _cfg(entire_A_every=2)
+    vit_state = synth.vit_params(7, "dino_vits8", img_size=64, w_std=0.05)
+    gens = [synth.generator_params(60 + p, 0.02) for p in range(2)]
+    A, B = _pair_inputs(2, 64, 64, seed=72)
+    eng = MultiPairEngine(cfg, vit_state, gens[:1], (64, 64), (64, 64), top_cls_only=mode)
+    m = dino_vit.VisionTransformer(8, 384, 12, 6, img_size=64).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in vit_state.items()})
+    orc = SpliceOracle(m, {k: torch.from_numpy(v) for k, v in gens[0].items()}, cfg)
+    for step in range(3):
+        eng.params.copy_(eng.gen.flatten({k: v.detach() for k, v in orc.params.items()}))
+        lo, _, og = orc.step(A[:1].cpu(), B[:1].cpu(), A[:1].cpu())
+        eng.step(A[:1].contiguous(), B[:1].contiguous(), A[:1].contiguous())
+        le = eng.losses(0)
+        assert set(le) == set(lo)
+        for k in lo:
+            assert abs(le[k] - lo[k]) / abs(lo[k]) < 3e-2, (step, k, le[k], lo[k])
+        num = den = 0.0
+        for (name, gt), go in zip(eng.gen.unflatten(eng.grads).items(), og):
+            if name.endswith("0.bias") and name != "9.0.bias":
+                continue
+            num += (gt.cpu().double() - go.reshape(-1).double()).norm().item() ** 2
+            den += go.double().norm().item() ** 2
+        assert (num / den) ** 0.5 < 5e-2, (step, (num / den) ** 0.5)
+    multi = MultiPairEngine(cfg, None, gens, (64, 64), (64, 64), vit_engine=eng.vit, top_cls_only=mode)
+    for _ in range(4):
+        multi.step(A, B, A)
+    torch.cuda.synchronize()
+    for p in range(2):
+        single = MultiPairEngine(cfg, None, gens[p:p + 1], (64, 64), (64, 64), vit_engine=eng.vit, top_cls_only=mode)
+        for _ in range(4):
+            single.step(A[p:p + 1].contiguous(), B[p:p + 1].contiguous(), A[p:p + 1].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(single.params, multi.pair_params(p))
+        assert torch.equal(single.losses_dev[0], multi.losses_dev[p])
