@@ -110,12 +110,13 @@ def visible_gpu_count():
 def kernel_families(T, D, heads, P):
     hidden = 4 * D
     return {
-        4: ("gemm_nt_kernel<64,64,BIAS|RESID|OUT_F32,4> (fc2 fwd)", 2 * P, 2.0 * T * hidden * D),
-        1: ("gemm_nt_kernel<128,64|128,BIAS|GELU|OUT_BF,*> (fc1 fwd)", 2 * P, 2.0 * T * hidden * D),
-        2: ("gemm_nt_kernel<128,64,BIAS|OUT_BF|OUT_T,3> (qkv fwd)", 2 * P, 2.0 * T * 3 * D * D),
+        # (tile / pipeline template arguments depend on the rows of a launch: <64,64,..,4> at one pair, <128,64,..,2> from 4 pairs on)
+        4: ("gemm_nt_kernel<BIAS|RESID|OUT_F32> fc2 forward", 2 * P, 2.0 * T * hidden * D),
+        1: ("gemm_nt_kernel<BIAS|GELU|OUT_BF> fc1 forward", 2 * P, 2.0 * T * hidden * D),
+        2: ("gemm_nt_kernel<BIAS|OUT_BF|OUT_T> qkv forward", 2 * P, 2.0 * T * 3 * D * D),
         3: ("attn_fwd_kernel", 2 * P, 4.0 * T * T * D),
-        5: ("gemm_nt_kernel<64,64,OUT_F32,4> split-K (fc1^T and qkv^T dgrads, mean of both)", P, 2.0 * T * D * (hidden + 3 * D) / 2),
-        6: ("attn_bwd_kernel", P, 10.0 * T * T * D),
+        5: ("gemm_nt_kernel<OUT_F32> split-K dgrads (fc1^T and qkv^T, mean of both)", P, 2.0 * T * D * (hidden + 3 * D) / 2),
+        6: ("attn_bwd_kernel (merged, or dQ + dK/dV launches)", P, 10.0 * T * T * D),
     }
 
 
