@@ -62,7 +62,9 @@ typedef struct splice_gemm_epilogue {
     int ld_cols, col_lo, col_hi;
     float alpha;
     int ksplit;               /* > 1 with flags == SPLICE_EPI_OUT_F32 only: K is cut into ksplit slices, slice s writes */
-    long long slab_stride;    /* out_f32 + s * slab_stride; the consumer adds the slabs (deterministic split-K)       */
+    long long slab_stride;    /* out_f32 + s * slab_stride; the consumer adds the slabs in order (deterministic split-K).
+                               * With splice_gemm_splitk_slabs(M, ksplit) == 1 (many rows) the slices are summed IN the kernel,
+                               * in the same order -- the same bits -- and only slab 0 is written */
     /* SPLICE_EPI_ROWDOT (with OUT_BF): rowdot[(row / rd_rows) * (N/64) * rd_rows + (col/64) * rd_rows + row % rd_rows]
      * = sum over the 64 columns [col, col+64) of bf16(C[row][c]) * rd_other[row][c] -- the attention backward's
      * delta = rowsum(dO * O) per (pass, head, query), formed where dO is produced (proj dgrad).  N % 64 == 0. */
@@ -93,6 +95,8 @@ int splice_gemm_nt_fp8(unsigned flags, const uint8_t* A, int lda, const uint8_t*
 /* Row-wise e4m3 quantisation: q[r][:] = fp8(x[r][:] * 448 / amax_r), scale[r] = amax_r / 448 (x ~= q * scale[r]).
  * x fp32 [rows][ldx] (cols % 8 == 0), q bytes [rows][ldq].  Packs the frozen weights per output channel. */
 int splice_quantize_rows_fp8(const float* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int cols, splice_stream_t stream);
+/* number of slabs a split-K call with M rows leaves for its consumer: ksplit (few rows) or 1 (the sum formed in the kernel) */
+int splice_gemm_splitk_slabs(int M, int ksplit);
 /* benchmarking hook (tools/gemm_bench.py): force the tile shape, 0 = automatic */
 int splice_gemm_force_tile(int tile);
 /* benchmarking hook (tools/attn_bench.py): pick an attention kernel variant, 0 = default */

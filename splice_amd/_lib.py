@@ -57,6 +57,7 @@ _SIGNATURES = {
     "splice_gemm_nt_bf16": ([_u, _vp, _i, _vp, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _vp], _i),
     "splice_gemm_nt_fp8": ([_u, _vp, _i, _vp, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _vp], _i),
     "splice_quantize_rows_fp8": ([_vp, _i, _vp, _i, _vp, _i, _i, _vp], _i),
+    "splice_gemm_splitk_slabs": ([_i, _i], _i),
     "splice_gemm_force_tile": ([_i], _i),
     "splice_attention_variant": ([_i], _i),
     "splice_layernorm_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),

@@ -49,6 +49,8 @@ int splice_quantize_rows_fp8(const float* x, int ldx, uint8_t* q, int ldq, float
     return finish(quantize_rows_fp8_launch(x, ldx, q, ldq, scale, rows, cols, ST(stream)), "splice_quantize_rows_fp8");
 }
 
+int splice_gemm_splitk_slabs(int M, int ksplit) { return gemm_splitk_slabs(M, ksplit); }
+
 /* benchmarking hook: force the GEMM tile (0 auto, 1 128x128, 2 128x64, 3 64x64) */
 int splice_gemm_force_tile(int tile) { gemm_force_tile(tile); return SPLICE_OK; }
 int splice_attention_variant(int variant) { attn_set_variant(variant); return SPLICE_OK; }

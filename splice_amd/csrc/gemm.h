@@ -223,6 +223,11 @@ struct GemmTile {
     }
 };
 
+// Slabs a split-K GEMM (plain fp32 output, e.ksplit = ks) leaves for its consumer: ks for the few-row shapes (real split-K:
+// parallelism), 1 from GEMM_VSPLIT_ROWS rows on (the workgroups keep the slab sums apart internally: same bits, see the kernel).
+constexpr int GEMM_VSPLIT_ROWS = 2401;   // = the row count from which the dispatcher uses the 2-stage pipelines
+static inline int gemm_splitk_slabs(int M, int ks) { return (ks > 1 && M >= GEMM_VSPLIT_ROWS) ? 1 : ks; }
+
 // Fused epilogue description shared by every ViT GEMM: the public splice_gemm_epilogue.
 typedef splice_gemm_epilogue GemmEpi;
 enum : unsigned {
@@ -514,7 +519,32 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
     grouped_tile(t, tiles_m, tiles_n, gm, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     GemmTile<BM, BN, true, FP8> tile;
-    if (NS == 2) tile.run_glds(A, lda, B, ldb, M, N, K, m0, n0, gemm_smem, kbeg);
+    bool walked = false;
+    if constexpr (FLAGS == EPI_OUT_F32 && NS == 2) {
+        if (ksplit < -1) {
+            // "virtual" split-K for many rows: ONE workgroup walks the whole K but keeps the -ksplit slab sums apart and adds them in
+            // slab order -- bit for bit what the real split-K (needed by the few-row shapes for parallelism) plus the consumer's
+            // in-order slab sum produce, without writing and re-reading the slabs.  A pair's gradient does not depend on which
+            // form a batch size selects.
+            const int vs = -ksplit, Kp = K / vs;
+            f32x4 tot[GemmTile<BM, BN>::FM][GemmTile<BM, BN>::FN];
+            for (int sl = 0; sl < vs; ++sl) {
+                if (sl) __syncthreads();   // the previous walk's last slice is still being read
+                tile.run_glds(A, lda, B, ldb, M, N, Kp, m0, n0, gemm_smem, sl * Kp);
+#pragma unroll
+                for (int i = 0; i < GemmTile<BM, BN>::FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < GemmTile<BM, BN>::FN; ++j) tot[i][j] = sl ? tot[i][j] + tile.acc[i][j] : tile.acc[i][j];
+            }
+#pragma unroll
+            for (int i = 0; i < GemmTile<BM, BN>::FM; ++i)
+#pragma unroll
+                for (int j = 0; j < GemmTile<BM, BN>::FN; ++j) tile.acc[i][j] = tot[i][j];
+            walked = true;
+        }
+    }
+    if (walked) {
+    } else if (NS == 2) tile.run_glds(A, lda, B, ldb, M, N, K, m0, n0, gemm_smem, kbeg);
     else tile.template run_ring<(NS < 3 ? 3 : NS)>(A, lda, B, ldb, M, N, K, m0, n0, gemm_smem, kbeg);
     // Epilogue operands: lane-guarded loads inside the per-fragment epilogue compile to load + s_waitcnt per fragment,
     // one memory round trip each (4 ... 16 per lane, the residual usually an L2 miss).  With N and the leading dimensions
@@ -672,8 +702,9 @@ template <int BM, int BN, unsigned FLAGS, int NS, bool FP8 = false>
 static inline void launch_gemm_nt(hipStream_t s, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K,
                                   const GemmEpi& e) {
     const int tm = cdiv(M, BM), tn = cdiv(N, BN);
-    const int ksplit = (FLAGS == EPI_OUT_F32 && e.ksplit > 1 && K % (e.ksplit * GEMM_BK) == 0) ? e.ksplit : 1;
-    const int grid = tm * tn * ksplit;
+    int ksplit = (FLAGS == EPI_OUT_F32 && e.ksplit > 1 && K % (e.ksplit * GEMM_BK) == 0) ? e.ksplit : 1;
+    if (NS == 2 && ksplit > 1 && gemm_splitk_slabs(M, ksplit) == 1) ksplit = -ksplit;   // virtual: one slab, the split happens inside the workgroup
+    const int grid = tm * tn * (ksplit > 1 ? ksplit : 1);
     // group height ~ sqrt(tiles per XCD), weighted by the tile aspect so the block is square in elements
     int gm = 1;
     while ((gm + 1) * (gm + 1) * BM <= (tm * tn / 8 + 1) * BN && gm + 1 <= tm) ++gm;

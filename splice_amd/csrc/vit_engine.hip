@@ -640,7 +640,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
                 ProfScope ps(5, s);
                 RC(gemm_nt_launch(EPI_OUT_F32, c->dh + r0 * Hd, Hd, W.fc1.wT, Hd, R, D, Hd, e, s));
             }
-            RC(layernorm_bwd_slabs_launch(c->dln + r0 * D, ks, slab, c->xmid[l] + r0 * D, W.ln2_g, c->mean2[l] + r0, c->rstd2[l] + r0, g, g, g_bf, R, D, s));
+            RC(layernorm_bwd_slabs_launch(c->dln + r0 * D, gemm_splitk_slabs(R, ks), slab, c->xmid[l] + r0 * D, W.ln2_g, c->mean2[l] + r0, c->rstd2[l] + r0, g, g, g_bf, R, D, s));
             // attention branch
             {
                 GemmEpi e = {};
@@ -673,7 +673,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
             ProfScope ps(5, s);
             RC(gemm_nt_launch(EPI_OUT_F32, dqkv, 3 * D, W.qkv.wT, 3 * D, R, D, 3 * D, e, s));
         }
-        RC(layernorm_bwd_slabs_launch(c->dln + r0 * D, ks, slab, c->xs[l] + r0 * D, W.ln1_g, c->mean1[l] + r0, c->rstd1[l] + r0, g_after_mlp, g, g_bf, R, D, s));
+        RC(layernorm_bwd_slabs_launch(c->dln + r0 * D, gemm_splitk_slabs(R, ks), slab, c->xs[l] + r0 * D, W.ln1_g, c->mean1[l] + r0, c->rstd1[l] + r0, g_after_mlp, g, g_bf, R, D, s));
         g_live = true;
     }
     if (!g_live) {

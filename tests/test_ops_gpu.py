@@ -317,3 +317,27 @@ def test_augment_structure_hip_vs_torch():
         jitter = (order, (1.3, 0.7, 1.15, -0.08))
         err = (augment.apply_structure_hip(img, True, jitter, 1.1) - augment.apply_structure_torch(img, True, jitter, 1.1)).abs().max().item()
         assert err < 2e-5, (order, err)
+
+
+def test_splitk_virtual_equals_real_bitwise():
+    """Split-K dgrads: the few-row shapes write ks slabs that the consumer adds in order; from 2401 rows on ONE workgroup walks
+    the whole K, keeps the ks slab sums apart and adds them in the same order.  Row r of a big call must equal, bit for bit,
+    the in-order slab sum of the same row computed in a small call (this is what keeps a pair's gradient independent of the
+    number of pairs per step)."""
+    L = _lib.lib()
+    N, K, ks = 768, 3072, 3
+    A = _bf(_rand(3200, K, seed=40))
+    B = _bf(_rand(N, K, seed=41, std=0.05))
+    assert L.splice_gemm_splitk_slabs(800, ks) == ks and L.splice_gemm_splitk_slabs(3200, ks) == 1
+    big = torch.zeros(3200, N, device=DEV)
+    e = _lib.GemmEpilogue(); e.out_f32 = big.data_ptr(); e.ldo = N; e.ksplit = ks; e.slab_stride = 3200 * N
+    _lib.check(L.splice_gemm_nt_bf16(_lib.EPI_OUT_F32, _lib.ptr(A), K, _lib.ptr(B), K, 3200, N, K, C.byref(e), _st()))
+    for r0 in (0, 1600, 2400):
+        Ar = A[r0:r0 + 800].contiguous()
+        slabs = torch.zeros(ks, 800, N, device=DEV)
+        e2 = _lib.GemmEpilogue(); e2.out_f32 = slabs.data_ptr(); e2.ldo = N; e2.ksplit = ks; e2.slab_stride = 800 * N
+        _lib.check(L.splice_gemm_nt_bf16(_lib.EPI_OUT_F32, _lib.ptr(Ar), K, _lib.ptr(B), K, 800, N, K, C.byref(e2), _st()))
+        torch.cuda.synchronize()
+        ref = (slabs[0] + slabs[1]) + slabs[2]
+        assert torch.equal(big[r0:r0 + 800], ref), (r0, (big[r0:r0 + 800] - ref).abs().max().item())
+    assert _relerr(big, A.float() @ B.float().T) < 1e-5
