@@ -147,6 +147,108 @@ def train_model(dataroot, callback=None, cfg_overrides=None, vit_state=None, pro
     return engine
 
 
+class PairBatchFeed:
+    """Device data feed of P pairs that share image sizes: per step ONE crop size per side (A / B), as ``Global_crops`` draws it
+    (data/transforms.py:21), and one random position per pair; augmentations per pair.  Every pair sees the reference's marginal
+    distribution of crops; the sizes are shared so that the P crops stack into one ``[P,3,s,s]`` batch."""
+
+    def __init__(self, cfg, As, Bs):
+        if len({tuple(a.shape) for a in As}) != 1 or len({tuple(b.shape) for b in Bs}) != 1:
+            raise ValueError("pairs optimised side by side must share the structure-image size and the appearance-image size")
+        self.cfg, self.A, self.B = cfg, [a.to(device) for a in As], [b.to(device) for b in Bs]
+        self.step = -1
+
+    def get_A(self, pair):
+        return self.A[pair][None]
+
+    def _crops(self, imgs, min_cover):
+        _, h, w = imgs[0].shape
+        size, boxes = augment.global_crop_boxes(h, w, min_cover, len(imgs))
+        return torch.stack([im[:, t:t + size, l:l + size] for im, (t, l) in zip(imgs, boxes)]).contiguous()
+
+    def next(self):
+        self.step += 1
+        aug = bool(self.cfg['use_augmentations'])
+        sample = {'step': self.step}
+        if self.step % self.cfg['entire_A_every'] == 0:
+            sample['A'] = torch.stack(self.A).contiguous()
+        sample['A_global'] = self._crops([augment.structure_transforms(a) if aug else a for a in self.A], self.cfg['global_A_crops_min_cover'])
+        sample['B_global'] = self._crops([augment.texture_transforms(b) if aug else b for b in self.B], self.cfg['global_B_crops_min_cover'])
+        return sample
+
+
+def train_pairs(dataroots, callback=None, cfg_overrides=None, vit_state=None, progress=True):
+    """``train_model`` for P pairs on ONE GPU in the same kernel launches (``MultiPairEngine``): P independent optimisations that
+    share only the frozen ViT -- the throughput form of the reference's one-pair-per-process loop (train.py:34-80).  ``dataroots``:
+    P directories with ``A/`` and ``B/``; all structure images must share one size and all appearance images one size
+    (``A_resize`` / ``B_resize`` apply).  Every pair's generator is initialised as its own ``train_model`` run would
+    (the seed is re-applied before each ``define_G``); writes ``<dataroot>/out/output.png`` per pair; ``callback(pair, image)``.
+    With deterministic full crops (``use_augmentations: False``, ``min_cover: 1``) the result of every pair is bit-identical to
+    its single ``train_model`` run."""
+    from .engine import MultiPairEngine
+    cfg_path = "conf/default/config.yaml" if os.path.exists("conf/default/config.yaml") else _PKG_CFG
+    with open(cfg_path, "r") as f:
+        cfg = yaml.safe_load(f)
+    cfg.update(cfg_overrides or {})
+    if int(cfg['global_A_crops_n_crops']) != 1 or int(cfg['global_B_crops_n_crops']) != 1:
+        raise NotImplementedError("train_pairs: several pairs per step take one global crop per image (n_crops is a single-pair option)")
+    if device.type != 'cuda':
+        raise RuntimeError("train_pairs needs an MI355X: the product path has no CPU fallback")
+    seed = cfg['seed']
+    if seed == -1:
+        seed = np.random.randint(2 ** 32 - 1, dtype=np.int64)
+    random.seed(int(seed))
+    np.random.seed(int(seed) % (2 ** 32))
+    print(f'running {len(dataroots)} pairs with seed: {seed}.')
+    As, Bs = [], []
+    for root in dataroots:
+        A = _load_image(_first_file(os.path.join(root, 'A')), cfg['A_resize'])
+        B = _load_image(_first_file(os.path.join(root, 'B')), cfg['B_resize'])
+        if cfg['direction'] == 'BtoA':
+            A, B = B, A
+        As.append(A); Bs.append(B)
+    feed = PairBatchFeed(cfg, As, Bs)
+    if vit_state is None:
+        ckpt = os.environ.get("SPLICE_DINO_CHECKPOINT")
+        if ckpt:
+            from .checkpoint import load_dino_checkpoint
+            _, vit_state = load_dino_checkpoint(ckpt, cfg['dino_model_name'])
+        elif os.environ.get("SPLICE_SYNTHETIC_WEIGHTS") == "1":
+            from . import synth
+            vit_state = synth.vit_params(1234, cfg['dino_model_name'], img_size=224)
+        else:
+            raise RuntimeError("train_pairs: no DINO weights (set SPLICE_DINO_CHECKPOINT=<dino .pth>, pass vit_state=..., or SPLICE_SYNTHETIC_WEIGHTS=1)")
+    from .networks import define_G
+    gen_states = []
+    for _ in dataroots:
+        torch.manual_seed(int(seed))     # every pair starts as its own train_model run would
+        netG = define_G(cfg['init_type'], cfg['init_gain'], device=device)
+        gen_states.append({k: v.detach().clone() for k, v in netG.state_dict().items() if k in netG.engine.table})
+        del netG
+    torch.manual_seed(int(seed))
+    A0, B0 = As[0], Bs[0]
+    crop_max = max(min(A0.shape[1], A0.shape[2]), min(B0.shape[1], B0.shape[2]))
+    engine = MultiPairEngine(cfg, vit_state, gen_states, (crop_max, crop_max), tuple(A0.shape[1:]), device=device)
+    writers = [AsyncResultWriter(root) for root in dataroots]
+    try:
+        for epoch in range(1, cfg['n_epochs'] + 1):
+            inputs = feed.next()
+            log = epoch % cfg['log_images_freq'] == 0
+            outputs = [engine.generate(feed.get_A(p), pair=p) for p in range(len(dataroots))] if log else None
+            engine.step(inputs['A_global'], inputs['B_global'], inputs.get('A'))
+            if log:
+                for p, out in enumerate(outputs):
+                    writers[p].submit(out[0])
+                    if callback is not None:
+                        callback(p, out[0])
+            if progress and (epoch % 50 == 0 or epoch == 1):
+                print(f"Epoch {epoch}: loss=" + ", ".join(f"{d['loss']:.4f}" for d in engine.losses()) + f" lr={cfg['lr']}")
+    finally:
+        for w in writers:
+            w.close()
+    return engine
+
+
 if __name__ == '__main__':
     parser = ArgumentParser()
     parser.add_argument("--dataroot", type=str)

@@ -11,10 +11,10 @@ pytestmark = pytest.mark.gpu
 OVER = dict(seed=3, n_epochs=12, dino_model_name="dino_vits8", dino_global_patch_size=64, log_images_freq=6)
 
 
-def _write_pairs(root, k):
+def _write_pairs(root, k, h=64, w=80):
     from PIL import Image
     for i in range(k):
-        A, B = synth.smooth_image_pair(60, i, 64, 80)
+        A, B = synth.smooth_image_pair(60, i, h, w)
         for side, img in (("A", A), ("B", B)):
             d = root / f"p{i}" / side
             d.mkdir(parents=True)
@@ -36,3 +36,23 @@ def test_batch_queue_equals_serial_runs(tmp_path, monkeypatch):
         assert eng.losses()["loss"] == r["loss"]                     # same kernels, same order: bit-identical
         assert (ser / f"p{i}" / "out" / "output.png").read_bytes() == (q / f"p{i}" / "out" / "output.png").read_bytes()
     assert res[0]["loss"] != res[1]["loss"]
+
+
+def test_pairs_in_one_step_equal_single_runs(tmp_path, monkeypatch):
+    """``run_batch(pairs_per_gpu=2)`` / ``train_pairs``: two pairs in the same launches.  With deterministic full crops
+    (use_augmentations False, min_cover 1) every pair's image and loss are bit-identical to its own ``train_model`` run."""
+    from splice_amd import batch
+    from splice_amd.train import train_model
+    monkeypatch.setenv("SPLICE_SYNTHETIC_WEIGHTS", "1")
+    over = dict(OVER, use_augmentations=False, global_A_crops_min_cover=1.0, global_B_crops_min_cover=1.0)
+    q, ser = tmp_path / "grouped", tmp_path / "serial"
+    for r in (q, ser):
+        r.mkdir()
+        _write_pairs(r, 3, 72, 72)       # square: the full-cover crop has no position draw, the run is deterministic
+    res = batch.run_batch(str(q), 1, over, pairs_per_gpu=2)
+    assert [r["pair"] for r in res] == ["p0", "p1", "p2"]
+    assert [r.get("pairs_in_step", 1) for r in res] == [2, 2, 1]          # two ride together, the odd one runs alone
+    for i, r in enumerate(res):
+        eng = train_model(str(ser / f"p{i}"), cfg_overrides=over, progress=False)
+        assert eng.losses()["loss"] == r["loss"], (i, eng.losses()["loss"], r["loss"])
+        assert (ser / f"p{i}" / "out" / "output.png").read_bytes() == (q / f"p{i}" / "out" / "output.png").read_bytes()
