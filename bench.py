@@ -289,9 +289,9 @@ def main():
     roofs = []
     traffic_file = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     static_traffic = {}
-    if os.path.exists(traffic_file) and args.size == 224 and args.model == "dino_vitb8" and P == 1:
+    if os.path.exists(traffic_file) and args.size == 224 and args.model == "dino_vitb8" and not scales and not args.fp8:
         try:
-            static_traffic = json.load(open(traffic_file))
+            static_traffic = json.load(open(traffic_file)).get(f"P{P}", {})
         except Exception:
             static_traffic = {}
     for fam, (tot_ms, n, steps) in prof.items():
@@ -302,7 +302,7 @@ def main():
         traffic = static_traffic.get(str(fam))
         roofs.append({"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": 2500.0, "unit": "TFLOP/s",
                       "frac": round(ach / 2500.0, 4), "traffic": traffic,
-                      "traffic_source": None if traffic is None else "static: profiles/roofline_traffic.json (PMC passes of an earlier run, not re-measured by this command)",
+                      "traffic_source": None if traffic is None else "static: profiles/roofline_traffic.json (FETCH_SIZE x2 + WRITE_SIZE from separate --pmc passes of tools/pmc_traffic.sh on this workload, round 2; not re-measured by this command)",
                       "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": round(n / steps, 1),
                       "share_of_step_ms": round((tot_ms - n * ev_overhead_ms) / steps, 4), "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2)})
     roofs.sort(key=lambda r: -r["share_of_step_ms"])
