@@ -45,6 +45,34 @@ def _first_file(d):
     return os.path.join(d, os.listdir(d)[0])
 
 
+_VIT_ENGINES = {}
+
+
+def _shared_vit_engine(model_name, who):
+    """The frozen DINO ViT of this process: loaded / packed once per (weight source, model) and shared by every run that follows
+    (a batch worker optimises many pairs; reading and packing 86 M parameters per pair was 2 s of a 12 s run).  Weight
+    source: ``SPLICE_DINO_CHECKPOINT=<dino .pth>`` or ``SPLICE_SYNTHETIC_WEIGHTS=1`` (seeded stand-in weights)."""
+    from .vit import VitEngine
+    ckpt = os.environ.get("SPLICE_DINO_CHECKPOINT")
+    if ckpt:
+        key = ("checkpoint", os.path.abspath(ckpt), os.path.getmtime(ckpt), model_name)
+    elif os.environ.get("SPLICE_SYNTHETIC_WEIGHTS") == "1":
+        key = ("synthetic", model_name)
+    else:
+        raise RuntimeError(f"{who}: no DINO weights (set SPLICE_DINO_CHECKPOINT=<dino .pth>, pass vit_state=..., "
+                           "or SPLICE_SYNTHETIC_WEIGHTS=1); the reference's torch.hub download is not available here")
+    if key not in _VIT_ENGINES:
+        if ckpt:
+            from .checkpoint import load_dino_checkpoint
+            _, state = load_dino_checkpoint(ckpt, model_name)
+        else:
+            from . import synth
+            state = synth.vit_params(1234, model_name, img_size=224)
+        _VIT_ENGINES.clear()   # one resident weight set per process
+        _VIT_ENGINES[key] = VitEngine(model_name, device=device).load_state_dict(state)
+    return _VIT_ENGINES[key]
+
+
 class DeviceDataFeed:
     """GPU-side counterpart of ``SingleImageDataset`` (data/Dataset.py:12-73)."""
 
@@ -106,23 +134,13 @@ def train_model(dataroot, callback=None, cfg_overrides=None, vit_state=None, pro
     print("Image sizes %s and %s" % (str((A.shape[2], A.shape[1])), str((B.shape[2], B.shape[1]))))
     feed = DeviceDataFeed(cfg, A, B)
 
-    if vit_state is None:
-        ckpt = os.environ.get("SPLICE_DINO_CHECKPOINT")
-        if ckpt:
-            from .checkpoint import load_dino_checkpoint
-            _, vit_state = load_dino_checkpoint(ckpt, cfg['dino_model_name'])
-        elif os.environ.get("SPLICE_SYNTHETIC_WEIGHTS") == "1":
-            from . import synth
-            vit_state = synth.vit_params(1234, cfg['dino_model_name'], img_size=224)
-        else:
-            raise RuntimeError("train_model: no DINO weights (set SPLICE_DINO_CHECKPOINT=<dino .pth>, pass vit_state=..., "
-                               "or SPLICE_SYNTHETIC_WEIGHTS=1); the reference's torch.hub download is not available here")
+    vit_engine = None if vit_state is not None else _shared_vit_engine(cfg['dino_model_name'], "train_model")
     # generator initialised exactly as define_G(init_type, init_gain): xavier-normal from the torch RNG seeded above
     from .networks import define_G
     netG = define_G(cfg['init_type'], cfg['init_gain'], device=device)
     gen_state = {k: v.detach() for k, v in netG.state_dict().items() if k in netG.engine.table}
     crop_max = max(min(A.shape[1], A.shape[2]), min(B.shape[1], B.shape[2]))   # crops are squares of side <= min(h, w)
-    engine = SpliceEngine(cfg, vit_state, gen_state, (crop_max, crop_max), tuple(A.shape[1:]), device=device, n_crops=n_crops)
+    engine = SpliceEngine(cfg, vit_state, gen_state, (crop_max, crop_max), tuple(A.shape[1:]), device=device, n_crops=n_crops, vit_engine=vit_engine)
     del netG
 
     writer = AsyncResultWriter(cfg['dataroot'])   # PNG encode + disk write happen on a worker thread
@@ -208,16 +226,7 @@ def train_pairs(dataroots, callback=None, cfg_overrides=None, vit_state=None, pr
             A, B = B, A
         As.append(A); Bs.append(B)
     feed = PairBatchFeed(cfg, As, Bs)
-    if vit_state is None:
-        ckpt = os.environ.get("SPLICE_DINO_CHECKPOINT")
-        if ckpt:
-            from .checkpoint import load_dino_checkpoint
-            _, vit_state = load_dino_checkpoint(ckpt, cfg['dino_model_name'])
-        elif os.environ.get("SPLICE_SYNTHETIC_WEIGHTS") == "1":
-            from . import synth
-            vit_state = synth.vit_params(1234, cfg['dino_model_name'], img_size=224)
-        else:
-            raise RuntimeError("train_pairs: no DINO weights (set SPLICE_DINO_CHECKPOINT=<dino .pth>, pass vit_state=..., or SPLICE_SYNTHETIC_WEIGHTS=1)")
+    vit_engine = None if vit_state is not None else _shared_vit_engine(cfg['dino_model_name'], "train_pairs")
     from .networks import define_G
     gen_states = []
     for _ in dataroots:
@@ -228,7 +237,7 @@ def train_pairs(dataroots, callback=None, cfg_overrides=None, vit_state=None, pr
     torch.manual_seed(int(seed))
     A0, B0 = As[0], Bs[0]
     crop_max = max(min(A0.shape[1], A0.shape[2]), min(B0.shape[1], B0.shape[2]))
-    engine = MultiPairEngine(cfg, vit_state, gen_states, (crop_max, crop_max), tuple(A0.shape[1:]), device=device)
+    engine = MultiPairEngine(cfg, vit_state, gen_states, (crop_max, crop_max), tuple(A0.shape[1:]), device=device, vit_engine=vit_engine)
     writers = [AsyncResultWriter(root) for root in dataroots]
     try:
         for epoch in range(1, cfg['n_epochs'] + 1):
