@@ -334,6 +334,27 @@ def test_config0_128px_vitb16_resize_vs_oracle():
     _teacher_forced(eng, orc, A, B, A, 2, tag="128->224/B16")
 
 
+def test_entire_image_hits_max_size_cap_and_ragged_patch_grid_vs_oracle():
+    """Edge of util/losses.py:19-24: ``Resize(224, max_size=480)`` on a WIDE entire image -- 64x150 -> 224x525 exceeds the cap
+    and becomes 204x480, which is not a multiple of the patch size either (DINO's patch-embed convolution floors: 25 x 60
+    patches, position embedding interpolated to that non-square grid).  Crops are 64x64 up-sampled to 224.  Steps 0 (entire
+    self-similarity + entire / global CLS on the capped input) and 1 (ordinary) against the fp32 oracle, teacher-forced."""
+    from splice_amd.engine import resize_output_size
+    assert resize_output_size(64, 150, 224, 480) == (204, 480)
+    name = "dino_vits8"
+    cfg = dict(dino_model_name=name, dino_global_patch_size=224)
+    vit_state = synth.vit_params(7, name, img_size=224, w_std=0.05)
+    gen_state = synth.generator_params(9, 0.02)
+    A = synth.uniform(41, "cap/A", (3, 64, 64))
+    B = synth.uniform(41, "cap/B", (3, 64, 64))
+    E = synth.uniform(41, "cap/E", (3, 64, 150))
+    eng = SpliceEngine(cfg, vit_state, gen_state, (64, 64), (64, 150))
+    assert eng.ctx_e.T == 25 * 60 + 1
+    orc = _oracle_for(name, 224, vit_state, gen_state, cfg)
+    wl, wg = _teacher_forced(eng, orc, A, B, E, 2, tag="max_size cap")
+    print(f"    max_size-cap edge: worst loss rel {wl:.3e}, worst gradient rel {wg:.3e}")
+
+
 @pytest.mark.parametrize("term", ["cls", "ssim", "id"])
 def test_448_step_loss_and_gradient_vs_oracle(term):
     """BASELINE configs[3] (448x448 pair, ViT-B/8, T = 3137: attn_fwd_kernel<2>, the two-launch attention backward, the
