@@ -9,6 +9,28 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// Write-through stores (sc0 sc1) for kernel OUTPUTS that leave as FULL cache lines (the staged GEMM tiles, LayerNorm rows).
+// A kernel's dirty L2 lines are written back when it ends, before the next kernel of the stream may start; with several
+// hundred short launches per step that drain sits on the critical chain.  Written through, the lines go to memory while the
+// kernel is still computing.  Measured (tools/ab_so.sh, same box, alternating): GEMM + LayerNorm +1.1 % steps/s at one pair
+// per GPU, +0.7 % at eight.  NOT for partial-line stores: the attention outputs (8 bytes per lane, one row per lane) lose
+// 1.7 % this way, the generator's scalar stores 1.5 %; `nt` on the GEMM tiles loses 2 %.  WT_STORES 0 = plain stores.
+#ifndef WT_STORES
+#define WT_STORES 1
+#endif
+template <class V>
+__device__ __forceinline__ void st_out(V* p, const V& v) {
+    static_assert(sizeof(V) == 16 || sizeof(V) == 8 || sizeof(V) == 4, "4-, 8- or 16-byte values");
+#if WT_STORES
+    if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+    else if constexpr (sizeof(V) == 8) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(__builtin_bit_cast(u32x2, v)) : "memory");
+    else asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(__builtin_bit_cast(unsigned int, v)) : "memory");
+#else
+    *p = v;
+#endif
+}
 
 
 // fp32 -> bf16, round-to-nearest-even, on gfx950's hardware converter (v_cvt_pk_bf16_f32: one instruction per

@@ -468,7 +468,7 @@ __device__ __forceinline__ void gemm_stage_store(const f32x4 (&acc)[BM / 32][BN 
         if (!TRANSPOSED && gr < row_lo) continue;
         const u32x4 v = *reinterpret_cast<const u32x4*>(cs + r * PITCH + k);
         bf16_t* q = out + (size_t)gr * ld + gc;
-        if (gc + 7 < Cm && !(ld & 7)) *reinterpret_cast<u32x4*>(q) = v;
+        if (gc + 7 < Cm && !(ld & 7)) st_out(reinterpret_cast<u32x4*>(q), v);
         else {
             const bf16_t* h = reinterpret_cast<const bf16_t*>(&v);
 #pragma unroll
@@ -496,7 +496,7 @@ __device__ __forceinline__ void gemm_stage_store_f32(const f32x4 (&acc)[BM / 32]
         const int r = c / CH, k = (c % CH) * 4;
         const int gr = m0 + r, gc = n0 + k;
         if (gr >= M || gc >= N) continue;   // N % 4 == 0: a chunk is inside or outside as a whole
-        *reinterpret_cast<f32x4*>(out + (size_t)gr * ld + gc) = *reinterpret_cast<const f32x4*>(cs + r * PITCH + k);
+        st_out(reinterpret_cast<f32x4*>(out + (size_t)gr * ld + gc), *reinterpret_cast<const f32x4*>(cs + r * PITCH + k));
     }
 }
 

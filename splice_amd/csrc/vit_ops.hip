@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         const int idx = lane + 64 * i;
         if (idx < nv) {
             const float4 g = gv[i], b = bv[i];
-            yr[idx] = uint2{pack2bf((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y),
-                            pack2bf((v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w)};
+            st_out(yr + idx, uint2{pack2bf((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y),
+                                   pack2bf((v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w)});
         }
     }
 }
@@ -241,8 +241,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             float4 r = float4{rstd * (dh[i].x - m1 - xh[i].x * m2), rstd * (dh[i].y - m1 - xh[i].y * m2),
                               rstd * (dh[i].z - m1 - xh[i].z * m2), rstd * (dh[i].w - m1 - xh[i].w * m2)};
             if (gi) { const float4 a = av[i]; r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w; }
-            go[idx] = r;
-            if (gb) gb[idx] = uint2{pack2bf(r.x, r.y), pack2bf(r.z, r.w)};
+            st_out(go + idx, r);
+            if (gb) st_out(gb + idx, uint2{pack2bf(r.x, r.y), pack2bf(r.z, r.w)});
         }
     }
 }
