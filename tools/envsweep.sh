@@ -1,4 +1,4 @@
-run() { echo -n "$* -> "; env "$@" timeout 150 python bench.py --steps 300 --warmup 30 --no-cpu-baseline --prof-kernel 0 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])" 2>/dev/null || echo FAIL; }
+run() { echo -n "$* -> "; env "$@" timeout 150 python bench.py --steps 300 --warmup 30 --no-cpu-baseline --prof-kernels '' --pairs-sweep '' --no-train-regime 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])" 2>/dev/null || echo FAIL; }
 run X=1
 run HIP_FORCE_DEV_KERNARG=0
 run HIP_FORCE_DEV_KERNARG=1

@@ -1,7 +1,7 @@
 # kernel-trace of a short bench run; reports, for the last steps, wall time vs union of kernel intervals vs sum of durations
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/trace
-rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --prof-kernel 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --prof-kernels '' --pairs-sweep '' --no-train-regime > /dev/null 2>&1
 python - <<'PY'
 import csv, glob, os
 f = glob.glob(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/trace/*/*kernel_trace.csv")[0]
