@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from splice_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -69,3 +71,28 @@ def test_struct_layouts_match_header(tmp_path):
         assert ctypes.sizeof(mirror) == c["sizeof"], (cname, ctypes.sizeof(mirror), c["sizeof"])
         for f in bound_fields:
             assert getattr(mirror, f).offset == c[f], (cname, f, getattr(mirror, f).offset, c[f])
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No CPU fallback: without the built HIP extension the binding raises and says what to do."""
+    from splice_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libsplice_hip.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_product_entry_points_refuse_a_cpu_only_box(tmp_path):
+    """train_model / train_pairs never route through the oracle or torch-CPU: on a box without a GPU they stop at once."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    from splice_amd.train import train_model, train_pairs
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        train_model(str(tmp_path), cfg_overrides=dict(seed=1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        train_pairs([str(tmp_path)], cfg_overrides=dict(seed=1))
+    import glob, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    offenders = [f for f in glob.glob(os.path.join(root, "splice_amd", "*.py")) if "import oracle" in open(f).read() or "from oracle" in open(f).read()]
+    assert offenders == []                       # the oracle is test infrastructure only
