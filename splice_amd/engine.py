@@ -82,7 +82,7 @@ class MultiPairEngine:
         for name, (off, cnt) in self.gen.buffer_table.items():
             if name.endswith("running_var"):
                 self.running[:, off:off + cnt] = 1.0
-        self.generator_calls = 0   # = every BatchNorm's num_batches_tracked
+        self.generator_calls = [0] * len(gen_states)   # per pair: every BatchNorm's num_batches_tracked (one per netG call)
         Pz = c["dino_global_patch_size"]
         ch, cw = crop_hw
         vh, vw = resize_output_size(ch, cw, Pz, 480)
@@ -152,7 +152,7 @@ class MultiPairEngine:
         _lib.check(_lib.lib().splice_step_run(self.handle, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.m), _lib.ptr(self.v),
                                               _lib.ptr(A_crop), _lib.ptr(B_crop), _lib.ptr(A_entire), self.step_idx,
                                               _lib.ptr(self.losses_dev), _lib.current_stream()), "step_run")
-        self.generator_calls += 3 if entire else 2   # models/model.py:15-23: G(A_global) [, G(A)], G(B_global)
+        self.generator_calls = [n + (3 if entire else 2) for n in self.generator_calls]   # models/model.py:15-23: G(A_global) [, G(A)], G(B_global)
         return self.losses_dev
 
     def losses(self, pair=None):
@@ -180,27 +180,29 @@ class MultiPairEngine:
         is in train mode there too, so the call also moves the BatchNorm running statistics: pass
         ``track_running_stats=True`` to book that (train_model does, after the step whose forwards precede it)."""
         n, _, h, w = img.shape
-        key = (n, h, w)
+        key = (pair, n, h, w)   # one plan per pair: a plan holds the BatchNorm statistics of its last forward until they are booked
         if key not in self._log_plans:
             self._log_plans[key] = GeneratorPlan(self.gen, n, h, w, False)
         plan = self._log_plans[key]
         out = plan.forward(self.pair_params(pair), img.contiguous())
-        self._last_logged = (plan, pair)
         if track_running_stats:
             self.book_running_stats(plan, pair)
+        else:
+            self._logged = [(q, k) for q, k in getattr(self, "_logged", []) if k != pair] + [(plan, pair)]
         return out
 
     def book_logged_forward(self):
         """Book the BatchNorm statistics of the last ``generate()`` call NOW: the reference's logging forward sits between
         the step's generator calls and the optimizer update (train.py:70-79), so ``train_model`` generates with the
         pre-update weights BEFORE the fused step and books the statistics AFTER it -- the reference's buffer order."""
-        plan, pair = self._last_logged
-        self.book_running_stats(plan, pair)
+        for plan, pair in getattr(self, "_logged", []):   # (every pair generated since the last booking, in call order)
+            self.book_running_stats(plan, pair)
+        self._logged = []
 
     def book_running_stats(self, plan, pair=0):
         plans = (C.c_void_p * 1)(plan.handle)
         _lib.check(_lib.lib().splice_gen_running_stats_update(plans, 1, _lib.ptr(self.running[pair]), 0, 0.1, _lib.current_stream()), "running_stats_update")
-        self.generator_calls += plan.N
+        self.generator_calls[pair] += 1
 
     def state_dict(self, pair=0):
         """``netG.state_dict()`` of one pair: parameters, BatchNorm running statistics and ``num_batches_tracked``."""
@@ -208,7 +210,7 @@ class MultiPairEngine:
         for name, (off, cnt) in self.gen.buffer_table.items():
             out[name] = self.running[pair, off:off + cnt].clone()
             if name.endswith("running_var"):
-                out[name[:-len("running_var")] + "num_batches_tracked"] = torch.tensor(self.generator_calls, dtype=torch.long, device=self.device)
+                out[name[:-len("running_var")] + "num_batches_tracked"] = torch.tensor(self.generator_calls[pair], dtype=torch.long, device=self.device)
         return out
 
 

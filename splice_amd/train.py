@@ -246,6 +246,7 @@ def train_pairs(dataroots, callback=None, cfg_overrides=None, vit_state=None, pr
             outputs = [engine.generate(feed.get_A(p), pair=p) for p in range(len(dataroots))] if log else None
             engine.step(inputs['A_global'], inputs['B_global'], inputs.get('A'))
             if log:
+                engine.book_logged_forward()   # BatchNorm bookkeeping of the P logging forwards, after the step's (train.py:70-79)
                 for p, out in enumerate(outputs):
                     writers[p].submit(out[0])
                     if callback is not None:

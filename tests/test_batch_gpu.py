@@ -56,3 +56,22 @@ def test_pairs_in_one_step_equal_single_runs(tmp_path, monkeypatch):
         eng = train_model(str(ser / f"p{i}"), cfg_overrides=over, progress=False)
         assert eng.losses()["loss"] == r["loss"], (i, eng.losses()["loss"], r["loss"])
         assert (ser / f"p{i}" / "out" / "output.png").read_bytes() == (q / f"p{i}" / "out" / "output.png").read_bytes()
+
+
+def test_train_pairs_state_dict_equals_single_runs(tmp_path, monkeypatch):
+    """Everything ``netG.state_dict()`` holds -- parameters, BatchNorm running statistics (incl. the logging forwards, booked in
+    the reference's order) and ``num_batches_tracked`` -- comes out of ``train_pairs`` as out of each pair's ``train_model``."""
+    import torch
+    from splice_amd.train import train_model, train_pairs
+    monkeypatch.setenv("SPLICE_SYNTHETIC_WEIGHTS", "1")
+    over = dict(OVER, use_augmentations=False, global_A_crops_min_cover=1.0, global_B_crops_min_cover=1.0, n_epochs=13, log_images_freq=4)
+    _write_pairs(tmp_path, 2, 72, 72)
+    roots = [str(tmp_path / f"p{i}") for i in range(2)]
+    both = train_pairs(roots, cfg_overrides=over, progress=False)
+    for i, r in enumerate(roots):
+        one = train_model(r, cfg_overrides=over, progress=False).state_dict()
+        got = both.state_dict(i)
+        assert list(got) == list(one)
+        for k in one:
+            assert torch.equal(got[k], one[k]), (i, k)
+        assert int(one["1.0.2.num_batches_tracked"]) == 2 * 13 + 1 + 3   # A and B crops every step, the entire image at step 0, three logged images

@@ -120,7 +120,7 @@ def test_multipair_steps_bit_identical_to_single_pair_runs():
         n = multi.gen.numel
         assert torch.equal(single.v, multi.v[p * multi.stride: p * multi.stride + n])
         assert torch.equal(single.running[0], multi.running[p])
-        assert single.generator_calls == multi.generator_calls == 2 * steps + 2
+        assert single.generator_calls[0] == multi.generator_calls[p] == 2 * steps + 2
     assert not torch.equal(multi.pair_params(0), multi.pair_params(1))
 
 
