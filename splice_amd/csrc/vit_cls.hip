@@ -12,6 +12,7 @@
 #include "kernels.h"
 
 #define LOG2E 1.4426950408889634f
+constexpr int CLS_NV = 26;   // token-contiguous 16-byte vectors a thread prefetches: 26 x 32 tokens covers Tld = 800 (ViT-B/8 @ 224)
 
 __device__ __forceinline__ float block_sum256(float v, float* red) {
     v = wave_sum(v);
@@ -41,20 +42,39 @@ __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(const bf16_t* __restr
     const int h = blockIdx.x, b = blockIdx.y, H = gridDim.x;
     const size_t row0 = (size_t)b * Tld;
     if (threadIdx.x < 64) q[threadIdx.x] = bf2f(qkv[row0 * 3 * D + h * 64 + threadIdx.x]) * scale;
+    // The kernel is a chain of memory round trips on the critical path of the step: everything that does not depend on a
+    // result is requested up front -- the first CLS_NV value vectors of this thread's (d, token quarter) now, the key rows four
+    // tokens at a time.  (Same arithmetic in the same order as the plain loops.)
+    const int d = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const bf16_t* vt = qkvT + (size_t)(2 * D + h * 64 + d) * ldt + row0;
+    u32x4 vpre[CLS_NV];
+#pragma unroll
+    for (int i = 0; i < CLS_NV; ++i) vpre[i] = *reinterpret_cast<const u32x4*>(vt + min(8 * part + 32 * i, Tld - 8));
     __syncthreads();
     float mx = -1e30f;
-    for (int j = threadIdx.x; j < T; j += 256) {
-        const u32x4* kr = reinterpret_cast<const u32x4*>(qkv + (row0 + j) * 3 * D + D + h * 64);
-        float s = 0.f;
+    for (int j0 = threadIdx.x; j0 < T; j0 += 4 * 256) {
+        u32x4 kv[4][8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const u32x4 v = kr[c];
+        for (int u = 0; u < 4; ++u) {
+            const u32x4* kr = reinterpret_cast<const u32x4*>(qkv + (row0 + min(j0 + 256 * u, T - 1)) * 3 * D + D + h * 64);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                s += q[c * 8 + 2 * e] * __uint_as_float(v[e] << 16) + q[c * 8 + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
+            for (int c = 0; c < 8; ++c) kv[u][c] = kr[c];
         }
-        p[j] = s;
-        mx = fmaxf(mx, s);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 256 * u;
+            if (j >= T) break;
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const u32x4 v = kv[u][c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    s += q[c * 8 + 2 * e] * __uint_as_float(v[e] << 16) + q[c * 8 + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
+            }
+            p[j] = s;
+            mx = fmaxf(mx, s);
+        }
     }
     mx = block_max256(mx, red);
     float sum = 0.f;
@@ -73,11 +93,18 @@ __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(const bf16_t* __restr
     }
     __syncthreads();
     // o[d] = sum_j p_j v_j[d]: thread = (d, quarter of the tokens), token-contiguous reads from the transposed copy
-    const int d = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const bf16_t* vt = qkvT + (size_t)(2 * D + h * 64 + d) * ldt + row0;
     float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < CLS_NV; ++i) {   // 8 tokens (16 bytes) per load; p is zero beyond T and the padding columns are finite
+        const int j = 8 * part + 32 * i;
+        if (j < Tld) {
+            const u32x4 v = vpre[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc += p[j + 2 * e] * __uint_as_float(v[e] << 16) + p[j + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
+        }
+    }
 #pragma unroll 4
-    for (int j = 8 * part; j < Tld; j += 32) {   // 8 tokens (16 bytes) per load; p is zero beyond T and the padding columns are finite
+    for (int j = 8 * part + 32 * CLS_NV; j < Tld; j += 32) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(vt + j);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc += p[j + 2 * e] * __uint_as_float(v[e] << 16) + p[j + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
@@ -103,25 +130,52 @@ __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const bf16_t* __restr
     const float* pg = probs + ((size_t)b * H + h) * Tld;
     if (threadIdx.x < 64) {
         q[threadIdx.x] = bf2f(qkv[row0 * 3 * D + h * 64 + threadIdx.x]);
-        float v = 0.f;   // the proj^T GEMM ran split-K over many workgroups (M = passes: the K walk is its whole run time): slabs summed here, in order
-        for (int sl = 0; sl < n_slabs; ++sl) v += dout[(size_t)sl * slab_stride + (size_t)b * D + h * 64 + threadIdx.x];
+        // the proj^T GEMM ran split-K over many workgroups (M = passes: the K walk is its whole run time): slabs summed here, in
+        // order, all of them requested first
+        float sv[16];
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) sv[sl] = dout[(size_t)min(sl, n_slabs - 1) * slab_stride + (size_t)b * D + h * 64 + threadIdx.x];
+        float v = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl)
+            if (sl < n_slabs) v += sv[sl];
         dO[threadIdx.x] = bf2f(f2bf(v));   // (bf16 like the full path's dout)
     }
+    // (requests that depend on nothing computed here go out first: see the forward)
+    const int d = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const bf16_t* kt = qkvT + (size_t)(D + h * 64 + d) * ldt + row0;
+    u32x4 kpre[CLS_NV];
+#pragma unroll
+    for (int i = 0; i < CLS_NV; ++i) kpre[i] = *reinterpret_cast<const u32x4*>(kt + min(8 * part + 32 * i, Tld - 8));
     __syncthreads();
     // dP_j = dO . v_j ; delta = sum_j p_j dP_j
     float dl = 0.f;
-    for (int j = threadIdx.x; j < T; j += 256) {
-        const u32x4* vr = reinterpret_cast<const u32x4*>(qkv + (row0 + j) * 3 * D + 2 * D + h * 64);
-        float s = 0.f;
+    for (int j0 = threadIdx.x; j0 < T; j0 += 4 * 256) {
+        u32x4 vv[4][8];
+        float pj4[4];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const u32x4 v = vr[c];
+        for (int u = 0; u < 4; ++u) {
+            const int jc = min(j0 + 256 * u, T - 1);
+            const u32x4* vr = reinterpret_cast<const u32x4*>(qkv + (row0 + jc) * 3 * D + 2 * D + h * 64);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                s += dO[c * 8 + 2 * e] * __uint_as_float(v[e] << 16) + dO[c * 8 + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
+            for (int c = 0; c < 8; ++c) vv[u][c] = vr[c];
+            pj4[u] = pg[jc];
         }
-        ds[j] = s;
-        dl += pg[j] * s;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 256 * u;
+            if (j >= T) break;
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const u32x4 v = vv[u][c];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    s += dO[c * 8 + 2 * e] * __uint_as_float(v[e] << 16) + dO[c * 8 + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
+            }
+            ds[j] = s;
+            dl += pj4[u] * s;
+        }
     }
     const float delta = block_sum256(dl, red);
     // ds_j = p_j (dP_j - delta) * scale ; rows: dk_j = ds_j q, dv_j = p_j dO, dq_j = 0 (j > 0)
@@ -144,11 +198,18 @@ __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const bf16_t* __restr
     }
     __syncthreads();
     // dq_cls[d] = sum_j ds_j k_j[d]
-    const int d = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const bf16_t* kt = qkvT + (size_t)(D + h * 64 + d) * ldt + row0;
     float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < CLS_NV; ++i) {   // ds is zero beyond T
+        const int j = 8 * part + 32 * i;
+        if (j < Tld) {
+            const u32x4 v = kpre[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc += ds[j + 2 * e] * __uint_as_float(v[e] << 16) + ds[j + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
+        }
+    }
 #pragma unroll 4
-    for (int j = 8 * part; j < Tld; j += 32) {   // ds is zero beyond T
+    for (int j = 8 * part + 32 * CLS_NV; j < Tld; j += 32) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(kt + j);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc += ds[j + 2 * e] * __uint_as_float(v[e] << 16) + ds[j + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
@@ -168,7 +229,7 @@ int attn_cls_fwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, i
 }
 int attn_cls_bwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, int T, int Tld, int D, int H, float scale, const float* probs,
                         const float* dout_slabs, int n_slabs, size_t slab_stride, bf16_t* dqkv, hipStream_t s) {
-    if (D / 64 != H || D % 64) return SPLICE_ERR_ARG;
+    if (D / 64 != H || D % 64 || n_slabs < 1 || n_slabs > 16) return SPLICE_ERR_ARG;
     const size_t lds = (size_t)(Tld + 64 + 64 + 256 + 8) * sizeof(float);
     hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(H, B), dim3(256), lds, s, qkv, qkvT, ldt, T, Tld, D, scale, probs, dout_slabs, n_slabs, slab_stride, dqkv);
     return SPLICE_OK;
@@ -178,6 +239,9 @@ int attn_cls_bwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, i
 // slabs != null: the row is first FORMED as bias + resid_row + sum of the n_slabs split-K slabs of the producing GEMM
 // (slabs[s * slab_stride + row * D + c], in slab order) and stored to x -- the M = passes GEMMs of the [CLS] tail run
 // split-K over many workgroups because their run time is the serial K walk, not the rows.
+// (Both kernels keep the row in registers and request every operand before the first use: they sit on the critical chain with
+// a few rows of work, so their run time is the number of dependent memory round trips -- one here, ~150 in a naive loop.)
+constexpr int LNR_MAXC = 16;   // columns per lane: D <= 1024
 __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(float* __restrict__ x, size_t xs, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           bf16_t* __restrict__ y, size_t ys, float* __restrict__ mean_o, float* __restrict__ rstd_o, size_t ss,
                                                           int rows, int D, float eps, const float* __restrict__ slabs, int n_slabs, size_t slab_stride,
@@ -185,22 +249,50 @@ __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(float* __restrict__ x,
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     float* xr = x + (size_t)row * xs;
+    float v[LNR_MAXC], gv[LNR_MAXC], bv[LNR_MAXC];
+#pragma unroll
+    for (int i = 0; i < LNR_MAXC; ++i) {
+        const int c = min(lane + 64 * i, D - 1);   // clamped: unconditional loads, the surplus lanes are dropped below
+        gv[i] = gamma[c]; bv[i] = beta[c];
+        v[i] = slabs ? bias[c] + resid[(size_t)row * rs + c] : xr[c];
+    }
     if (slabs) {
-        for (int c = lane; c < D; c += 64) {
-            float v = bias[c] + resid[(size_t)row * rs + c];
-            for (int sl = 0; sl < n_slabs; ++sl) v += slabs[(size_t)sl * slab_stride + (size_t)row * D + c];
-            xr[c] = v;
+        for (int s0 = 0; s0 < n_slabs; s0 += 4) {   // four slabs requested at a time, added in slab order
+            float t[4][LNR_MAXC];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int sl = min(s0 + k, n_slabs - 1);
+#pragma unroll
+                for (int i = 0; i < LNR_MAXC; ++i)
+                    if (64 * i < D) t[k][i] = slabs[(size_t)sl * slab_stride + (size_t)row * D + min(lane + 64 * i, D - 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (s0 + k < n_slabs) {
+#pragma unroll
+                    for (int i = 0; i < LNR_MAXC; ++i)
+                        if (64 * i < D) v[i] += t[k][i];
+                }
         }
+#pragma unroll
+        for (int i = 0; i < LNR_MAXC; ++i)
+            if (lane + 64 * i < D) xr[lane + 64 * i] = v[i];
     }
     float sum = 0.f;
-    for (int c = lane; c < D; c += 64) sum += xr[c];
+#pragma unroll
+    for (int i = 0; i < LNR_MAXC; ++i)
+        if (lane + 64 * i < D) sum += v[i];
     const float mean = wave_sum(sum) / (float)D;
     float sq = 0.f;
-    for (int c = lane; c < D; c += 64) { const float d = xr[c] - mean; sq += d * d; }
+#pragma unroll
+    for (int i = 0; i < LNR_MAXC; ++i)
+        if (lane + 64 * i < D) { const float d = v[i] - mean; sq += d * d; }
     const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
     if (lane == 0) { mean_o[(size_t)row * ss] = mean; rstd_o[(size_t)row * ss] = rstd; }
     bf16_t* yr = y + (size_t)row * ys;
-    for (int c = lane; c < D; c += 64) yr[c] = f2bf((xr[c] - mean) * rstd * gamma[c] + beta[c]);
+#pragma unroll
+    for (int i = 0; i < LNR_MAXC; ++i)
+        if (lane + 64 * i < D) yr[lane + 64 * i] = f2bf((v[i] - mean) * rstd * gv[i] + bv[i]);
 }
 // g (strided like x, in place) += LN_backward(dy); g_bf = bf16(g).  dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)), dxhat = dy gamma
 // n_slabs > 1: dy is given as split-K slabs (dy + s * slab_stride), summed in place into slab 0 first
@@ -212,39 +304,66 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(float* __restrict__ dy
     if (row >= rows) return;
     const float* xr = x + (size_t)row * xs;
     float* dr = dy + (size_t)row * dys;
-    if (n_slabs > 1) {
-        for (int c = lane; c < D; c += 64) {
-            float v = dr[c];
-            for (int sl = 1; sl < n_slabs; ++sl) v += dr[(size_t)sl * slab_stride + c];
-            dr[c] = v;
-        }
-    }
-    const float mean = mean_i[(size_t)row * ss], rstd = rstd_i[(size_t)row * ss];
-    float s1 = 0.f, s2 = 0.f;
-    for (int c = lane; c < D; c += 64) {
-        const float dh = dr[c] * gamma[c], xh = (xr[c] - mean) * rstd;
-        s1 += dh;
-        s2 += dh * xh;
-    }
-    s1 = wave_sum(s1) / (float)D;
-    s2 = wave_sum(s2) / (float)D;
     float* gr = g + (size_t)row * xs;
     bf16_t* gb = g_bf + (size_t)row * xs;
-    for (int c = lane; c < D; c += 64) {
-        const float dh = dr[c] * gamma[c], xh = (xr[c] - mean) * rstd;
-        const float v = gr[c] + rstd * (dh - s1 - xh * s2);
-        gr[c] = v;
-        gb[c] = f2bf(v);
+    const float mean = mean_i[(size_t)row * ss], rstd = rstd_i[(size_t)row * ss];
+    float v[LNR_MAXC], gv[LNR_MAXC], xv[LNR_MAXC], g0[LNR_MAXC];
+#pragma unroll
+    for (int i = 0; i < LNR_MAXC; ++i) {
+        const int c = min(lane + 64 * i, D - 1);
+        v[i] = dr[c]; gv[i] = gamma[c]; xv[i] = xr[c]; g0[i] = gr[c];
     }
+    if (n_slabs > 1) {
+        for (int s0 = 1; s0 < n_slabs; s0 += 4) {
+            float t[4][LNR_MAXC];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int sl = min(s0 + k, n_slabs - 1);
+#pragma unroll
+                for (int i = 0; i < LNR_MAXC; ++i)
+                    if (64 * i < D) t[k][i] = dr[(size_t)sl * slab_stride + min(lane + 64 * i, D - 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (s0 + k < n_slabs) {
+#pragma unroll
+                    for (int i = 0; i < LNR_MAXC; ++i)
+                        if (64 * i < D) v[i] += t[k][i];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < LNR_MAXC; ++i)
+            if (lane + 64 * i < D) dr[lane + 64 * i] = v[i];
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNR_MAXC; ++i)
+        if (lane + 64 * i < D) {
+            const float dh = v[i] * gv[i], xh = (xv[i] - mean) * rstd;
+            s1 += dh;
+            s2 += dh * xh;
+        }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < LNR_MAXC; ++i)
+        if (lane + 64 * i < D) {
+            const float dh = v[i] * gv[i], xh = (xv[i] - mean) * rstd;
+            const float o = g0[i] + rstd * (dh - s1 - xh * s2);
+            gr[lane + 64 * i] = o;
+            gb[lane + 64 * i] = f2bf(o);
+        }
 }
 int ln_rows_fwd_launch(float* x, size_t xs, const float* gamma, const float* beta, bf16_t* y, size_t ys, float* mean, float* rstd, size_t ss, int rows,
                        int D, float eps, const float* slabs, int n_slabs, size_t slab_stride, const float* bias, const float* resid, size_t rs, hipStream_t s) {
+    if (D > 64 * LNR_MAXC || D < 1) return SPLICE_ERR_ARG;
     hipLaunchKernelGGL(ln_rows_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, xs, gamma, beta, y, ys, mean, rstd, ss, rows, D, eps, slabs, n_slabs, slab_stride,
                        bias, resid, rs);
     return SPLICE_OK;
 }
 int ln_rows_bwd_launch(float* dy, size_t dys, const float* x, size_t xs, const float* gamma, const float* mean, const float* rstd, size_t ss, float* g,
                        bf16_t* g_bf, int rows, int D, int n_slabs, size_t slab_stride, hipStream_t s) {
+    if (D > 64 * LNR_MAXC || D < 1) return SPLICE_ERR_ARG;
     hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, dy, dys, x, xs, gamma, mean, rstd, ss, g, g_bf, rows, D, n_slabs, slab_stride);
     return SPLICE_OK;
 }
