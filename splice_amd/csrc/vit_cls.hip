@@ -241,7 +241,7 @@ int attn_cls_bwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, i
 // split-K over many workgroups because their run time is the serial K walk, not the rows.
 // (Both kernels keep the row in registers and request every operand before the first use: they sit on the critical chain with
 // a few rows of work, so their run time is the number of dependent memory round trips -- one here, ~150 in a naive loop.)
-constexpr int LNR_MAXC = 16;   // columns per lane: D <= 1024
+constexpr int LNR_MAXC = 12;   // columns per lane: D <= 768 (ViT-S / ViT-B)
 __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(float* __restrict__ x, size_t xs, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           bf16_t* __restrict__ y, size_t ys, float* __restrict__ mean_o, float* __restrict__ rstd_o, size_t ss,
                                                           int rows, int D, float eps, const float* __restrict__ slabs, int n_slabs, size_t slab_stride,
@@ -257,17 +257,17 @@ __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(float* __restrict__ x,
         v[i] = slabs ? bias[c] + resid[(size_t)row * rs + c] : xr[c];
     }
     if (slabs) {
-        for (int s0 = 0; s0 < n_slabs; s0 += 4) {   // four slabs requested at a time, added in slab order
-            float t[4][LNR_MAXC];
+        for (int s0 = 0; s0 < n_slabs; s0 += 8) {   // eight slabs requested at a time, added in slab order
+            float t[8][LNR_MAXC];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 const int sl = min(s0 + k, n_slabs - 1);
 #pragma unroll
                 for (int i = 0; i < LNR_MAXC; ++i)
                     if (64 * i < D) t[k][i] = slabs[(size_t)sl * slab_stride + (size_t)row * D + min(lane + 64 * i, D - 1)];
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 8; ++k)
                 if (s0 + k < n_slabs) {
 #pragma unroll
                     for (int i = 0; i < LNR_MAXC; ++i)
@@ -314,17 +314,17 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(float* __restrict__ dy
         v[i] = dr[c]; gv[i] = gamma[c]; xv[i] = xr[c]; g0[i] = gr[c];
     }
     if (n_slabs > 1) {
-        for (int s0 = 1; s0 < n_slabs; s0 += 4) {
-            float t[4][LNR_MAXC];
+        for (int s0 = 1; s0 < n_slabs; s0 += 8) {
+            float t[8][LNR_MAXC];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 const int sl = min(s0 + k, n_slabs - 1);
 #pragma unroll
                 for (int i = 0; i < LNR_MAXC; ++i)
                     if (64 * i < D) t[k][i] = dr[(size_t)sl * slab_stride + min(lane + 64 * i, D - 1)];
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 8; ++k)
                 if (s0 + k < n_slabs) {
 #pragma unroll
                     for (int i = 0; i < LNR_MAXC; ++i)
@@ -380,7 +380,14 @@ __global__ __launch_bounds__(256) void rows_finish_kernel(int mode, const float*
     if (i >= rows * N) return;
     const int row = i / N, n = i % N;
     float v = (mode != 2 && bias) ? bias[n] : 0.f;
-    for (int sl = 0; sl < n_slabs; ++sl) v += slabs[(size_t)sl * slab_stride + (size_t)row * N + n];
+    for (int s0 = 0; s0 < n_slabs; s0 += 8) {   // eight slabs requested at a time, added in slab order
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = slabs[(size_t)min(s0 + k, n_slabs - 1) * slab_stride + (size_t)row * N + n];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (s0 + k < n_slabs) v += t[k];
+    }
     if (mode == 0) {
         out_f32[(size_t)row * os + n] = v + resid[(size_t)row * rs + n];
     } else if (mode == 1) {
