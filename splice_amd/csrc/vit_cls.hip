@@ -125,7 +125,9 @@ __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const bf16_t* __restr
     float* dO = q + 64;
     float* pq = dO + 64;
     float* red = pq + 256;
-    const int h = blockIdx.x, b = blockIdx.y, H = gridDim.x;
+    // blockIdx.z: the token rows this workgroup WRITES (307 KB of dqkv rows per (pass, head) are the bulk of the kernel: spread over
+    // gridDim.z workgroups; each recomputes the cheap reductions, z = 0 also forms the dq row).  Same values whatever gridDim.z is.
+    const int h = blockIdx.x, b = blockIdx.y, H = gridDim.x, z = blockIdx.z, nz = gridDim.z;
     const size_t row0 = (size_t)b * Tld;
     const float* pg = probs + ((size_t)b * H + h) * Tld;
     if (threadIdx.x < 64) {
@@ -145,8 +147,10 @@ __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const bf16_t* __restr
     const int d = threadIdx.x & 63, part = threadIdx.x >> 6;
     const bf16_t* kt = qkvT + (size_t)(D + h * 64 + d) * ldt + row0;
     u32x4 kpre[CLS_NV];
+    if (z == 0) {
 #pragma unroll
-    for (int i = 0; i < CLS_NV; ++i) kpre[i] = *reinterpret_cast<const u32x4*>(kt + min(8 * part + 32 * i, Tld - 8));
+        for (int i = 0; i < CLS_NV; ++i) kpre[i] = *reinterpret_cast<const u32x4*>(kt + min(8 * part + 32 * i, Tld - 8));
+    }
     __syncthreads();
     // dP_j = dO . v_j ; delta = sum_j p_j dP_j
     float dl = 0.f;
@@ -183,6 +187,7 @@ __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const bf16_t* __restr
         const float pj = j < T ? pg[j] : 0.f;
         const float dsj = j < T ? pj * (ds[j] - delta) * scale : 0.f;
         ds[j] = dsj;
+        if ((j >> 8) % nz != z) continue;   // another workgroup writes these rows
         bf16_t* r = dqkv + (row0 + j) * 3 * D + h * 64;
         u32x4* rq = reinterpret_cast<u32x4*>(r);
         u32x4* rk = reinterpret_cast<u32x4*>(r + D);
@@ -196,6 +201,7 @@ __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const bf16_t* __restr
                           pack2bf(pj * dO[8 * c + 4], pj * dO[8 * c + 5]), pack2bf(pj * dO[8 * c + 6], pj * dO[8 * c + 7])};
         }
     }
+    if (z != 0) return;
     __syncthreads();
     // dq_cls[d] = sum_j ds_j k_j[d]
     float acc = 0.f;
@@ -231,7 +237,8 @@ int attn_cls_bwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, i
                         const float* dout_slabs, int n_slabs, size_t slab_stride, bf16_t* dqkv, hipStream_t s) {
     if (D / 64 != H || D % 64 || n_slabs < 1 || n_slabs > 16) return SPLICE_ERR_ARG;
     const size_t lds = (size_t)(Tld + 64 + 64 + 256 + 8) * sizeof(float);
-    hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(H, B), dim3(256), lds, s, qkv, qkvT, ldt, T, Tld, D, scale, probs, dout_slabs, n_slabs, slab_stride, dqkv);
+    const int nz = Tld > 768 ? 4 : Tld > 256 ? 2 : 1;   // one 256-row slice of the store loop per workgroup at ViT-B/8 @ 224
+    hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(H, B, nz), dim3(256), lds, s, qkv, qkvT, ldt, T, Tld, D, scale, probs, dout_slabs, n_slabs, slab_stride, dqkv);
     return SPLICE_OK;
 }
 
