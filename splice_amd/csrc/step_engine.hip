@@ -140,8 +140,8 @@ static int view_init(SpliceStep* st, VitView& v, void* ctx, int want_B) {
     RC(splice_vit_ctx_dims(ctx, &v.B, &v.H, &v.W, &v.D, &v.depth, &v.heads, &v.patch));
     RC(splice_vit_ctx_info(ctx, &v.T, &v.Tld, &v.rows));
     // Of the top block the losses read the keys and the [CLS] row (util/losses.py:90); cfg.top_cls_only skips the rest of it
-    // (vit_cls.hip): +2.7 % / +5.2 % pair-steps/s at 4 / 8 pairs per GPU, neutral at one pair (the M = passes kernels of the tail
-    // are as latency-bound as the full-size ones they replace), DESIGN.md section 8.
+    // (vit_cls.hip): +2.7 % / +5.2 % pair-steps/s at 4 / 8 pairs per GPU, +2.7 % at one pair once the few-row kernels of the tail
+    // request their operands in one round trip, DESIGN.md section 8.
     RC(splice_vit_ctx_set_top_cls_only(ctx, st->cfg.top_cls_only));
     if (v.B != want_B) { splice_set_error("splice_step_create: ViT context has batch %d, need %d", v.B, want_B); return SPLICE_ERR_ARG; }
     RC(salloc(st, &v.d_block, (size_t)v.rows * v.D));
