@@ -50,16 +50,20 @@ __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(const bf16_t* __restr
     u32x4 vpre[CLS_NV];
 #pragma unroll
     for (int i = 0; i < CLS_NV; ++i) vpre[i] = *reinterpret_cast<const u32x4*>(vt + min(8 * part + 32 * i, Tld - 8));
-    __syncthreads();
-    float mx = -1e30f;
-    for (int j0 = threadIdx.x; j0 < T; j0 += 4 * 256) {
-        u32x4 kv[4][8];
+    u32x4 kv[4][8];
+    auto load_keys = [&](int j0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const u32x4* kr = reinterpret_cast<const u32x4*>(qkv + (row0 + min(j0 + 256 * u, T - 1)) * 3 * D + D + h * 64);
 #pragma unroll
             for (int c = 0; c < 8; ++c) kv[u][c] = kr[c];
         }
+    };
+    load_keys(threadIdx.x);   // (before the barrier that publishes q: the keys do not depend on it)
+    __syncthreads();
+    float mx = -1e30f;
+    for (int j0 = threadIdx.x; j0 < T; j0 += 4 * 256) {
+        if (j0 != (int)threadIdx.x) load_keys(j0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = j0 + 256 * u;
@@ -249,6 +253,7 @@ int attn_cls_bwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, i
 // (Both kernels keep the row in registers and request every operand before the first use: they sit on the critical chain with
 // a few rows of work, so their run time is the number of dependent memory round trips -- one here, ~150 in a naive loop.)
 constexpr int LNR_MAXC = 12;   // columns per lane: D <= 768 (ViT-S / ViT-B)
+constexpr int LNR_SB = 8;      // split-K slabs requested per round trip (12 measured no faster: the kernels are at their launch + one-round-trip floor)
 __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(float* __restrict__ x, size_t xs, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           bf16_t* __restrict__ y, size_t ys, float* __restrict__ mean_o, float* __restrict__ rstd_o, size_t ss,
                                                           int rows, int D, float eps, const float* __restrict__ slabs, int n_slabs, size_t slab_stride,
@@ -264,17 +269,17 @@ __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(float* __restrict__ x,
         v[i] = slabs ? bias[c] + resid[(size_t)row * rs + c] : xr[c];
     }
     if (slabs) {
-        for (int s0 = 0; s0 < n_slabs; s0 += 8) {   // eight slabs requested at a time, added in slab order
-            float t[8][LNR_MAXC];
+        for (int s0 = 0; s0 < n_slabs; s0 += LNR_SB) {   // LNR_SB slabs requested at a time, added in slab order
+            float t[LNR_SB][LNR_MAXC];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < LNR_SB; ++k) {
                 const int sl = min(s0 + k, n_slabs - 1);
 #pragma unroll
                 for (int i = 0; i < LNR_MAXC; ++i)
                     if (64 * i < D) t[k][i] = slabs[(size_t)sl * slab_stride + (size_t)row * D + min(lane + 64 * i, D - 1)];
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
+            for (int k = 0; k < LNR_SB; ++k)
                 if (s0 + k < n_slabs) {
 #pragma unroll
                     for (int i = 0; i < LNR_MAXC; ++i)
@@ -321,17 +326,17 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(float* __restrict__ dy
         v[i] = dr[c]; gv[i] = gamma[c]; xv[i] = xr[c]; g0[i] = gr[c];
     }
     if (n_slabs > 1) {
-        for (int s0 = 1; s0 < n_slabs; s0 += 8) {
-            float t[8][LNR_MAXC];
+        for (int s0 = 1; s0 < n_slabs; s0 += LNR_SB) {
+            float t[LNR_SB][LNR_MAXC];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < LNR_SB; ++k) {
                 const int sl = min(s0 + k, n_slabs - 1);
 #pragma unroll
                 for (int i = 0; i < LNR_MAXC; ++i)
                     if (64 * i < D) t[k][i] = dr[(size_t)sl * slab_stride + min(lane + 64 * i, D - 1)];
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
+            for (int k = 0; k < LNR_SB; ++k)
                 if (s0 + k < n_slabs) {
 #pragma unroll
                     for (int i = 0; i < LNR_MAXC; ++i)
