@@ -1292,6 +1292,20 @@ int sigmoid_bwd_launch(const float* dout, const float* sout, float* dpre, size_t
     return SPLICE_OK;
 }
 
+// one element of the update; contraction is OFF so that the vector body and the scalar tail of the kernel round alike (an
+// element's result must not depend on where in an arena it sits: P pairs per step == P single runs, bit for bit)
+__device__ __forceinline__ void adam_update(float& pi, float& gi, float& mi_, float& vi_, float g2i, bool has_g2, float b1, float b2, float eps, float lr,
+                                            float bc1, float bc2_sqrt, int zero_grad) {
+#pragma clang fp contract(off)
+    if (has_g2) gi += g2i;   // second gradient arena (the B-crop plan): g = g + g2, as a separate add would leave it
+    const float mi = b1 * mi_ + (1.f - b1) * gi;
+    const float vi = b2 * vi_ + (1.f - b2) * gi * gi;
+    mi_ = mi;
+    vi_ = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    if (zero_grad) gi = 0.f;
+}
 // ---------------------------------------------------------------------------------------
 // Fused multi-tensor Adam over the flat parameter arena (K19; torch.optim.Adam as configured by
 // util/util.py:28-32: no weight decay / amsgrad, eps added after sqrt(v_hat)).  Also clears the
@@ -1304,23 +1318,32 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
         bc1 = 1.0f - powf(b1, t);
         bc2_sqrt = sqrtf(1.0f - powf(b2, t));
     }
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float gi = g[i];
-        if (g2) { gi += g2[i]; g[i] = gi; }   // second gradient arena (the B-crop plan): g = g + g2, as a separate add would leave it
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] -= (lr / bc1) * (mi / denom);
-        if (zero_grad) g[i] = 0.f;
+    // one float4 per thread and (at the generator's size) ONE pass: the five operand vectors of an element group are a single
+    // memory round trip; the kernel is the last node of the step's critical chain
+    auto upd = [&](float& pi, float& gi, float& mi_, float& vi_, float g2i) {
+        adam_update(pi, gi, mi_, vi_, g2i, g2 != nullptr, b1, b2, eps, lr, bc1, bc2_sqrt, zero_grad);
+    };
+    const size_t n4 = ((reinterpret_cast<size_t>(p) | reinterpret_cast<size_t>(g) | reinterpret_cast<size_t>(m) | reinterpret_cast<size_t>(v) |
+                        reinterpret_cast<size_t>(g2)) & 15) ? 0 : n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 pv = reinterpret_cast<float4*>(p)[i], gv = reinterpret_cast<float4*>(g)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        const float4 g2v = g2 ? reinterpret_cast<const float4*>(g2)[i] : float4{0.f, 0.f, 0.f, 0.f};
+        upd(pv.x, gv.x, mv.x, vv.x, g2v.x); upd(pv.y, gv.y, mv.y, vv.y, g2v.y); upd(pv.z, gv.z, mv.z, vv.z, g2v.z); upd(pv.w, gv.w, mv.w, vv.w, g2v.w);
+        reinterpret_cast<float4*>(p)[i] = pv; reinterpret_cast<float4*>(m)[i] = mv; reinterpret_cast<float4*>(v)[i] = vv;
+        if (g2 || zero_grad) reinterpret_cast<float4*>(g)[i] = gv;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float pi = p[i], gi = g[i], mi = m[i], vi = v[i];
+        upd(pi, gi, mi, vi, g2 ? g2[i] : 0.f);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (g2 || zero_grad) g[i] = gi;
     }
 }
 int adam_launch(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step, int zero_grad, hipStream_t s) {
     if (step < 1) return SPLICE_ERR_ARG;
     const float bc1 = 1.0f - powf(b1, (float)step);
     const float bc2 = 1.0f - powf(b2, (float)step);
-    size_t g_ = (n + 255) / 256;
+    size_t g_ = (n / 4 + 255) / 256 + 1;
     if (g_ > 2048) g_ = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g_), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), zero_grad, (const int*)nullptr, (const float*)nullptr);
     return SPLICE_OK;
@@ -1328,7 +1351,7 @@ int adam_launch(float* p, float* g, float* m, float* v, size_t n, float lr, floa
 // same, the step count t (>= 1) read from device memory at execution time
 int adam_launch_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, const int* step_dev,
                     int zero_grad, hipStream_t s, const float* g2) {
-    size_t g_ = (n + 255) / 256;
+    size_t g_ = (n / 4 + 255) / 256 + 1;
     if (g_ > 2048) g_ = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g_), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, 1.f, 1.f, zero_grad, step_dev, g2);
     return SPLICE_OK;
