@@ -21,7 +21,9 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
         static const int t1min = getenv("SPLICE_GEMM_T1MIN") ? atoi(getenv("SPLICE_GEMM_T1MIN")) : 420;
         // rows of a P-pair batch (tools/gemm_sweep.py, r2): with N <= 768 the 64x64 tile stops winning at ~4800 rows (fc2 at
         // M = 6400: 688 TF on 128x64 vs 554; M = 12800: 872 vs 656); N >= 2304 takes 128x128 from 3200 rows on (t1min 640 -> 420)
-        static const int bigm = getenv("SPLICE_GEMM_BIGM") ? atoi(getenv("SPLICE_GEMM_BIGM")) : 4800;
+        // (in-step at 2 / 3 / 4 pairs per GPU -- 3200 ... 6400 rows -- the 128x64 tile already wins from the first row count without
+        // a ring on: +0.9 / +0.3 / +0.8 % pair-steps/s against the stand-alone sweep's 4800, tools/gemm_thresh_sweep.sh)
+        static const int bigm = getenv("SPLICE_GEMM_BIGM") ? atoi(getenv("SPLICE_GEMM_BIGM")) : 2401;
         tile = (FLAGS & EPI_ROWDOT) ? 3 : N <= 768 ? (M >= bigm ? 2 : 3) : t128 >= t1min ? 1 : t12864 >= t2min ? 2 : 3;
         // few workgroups walking a long K (fc2, the fc1 / qkv dgrads): the per-slice DMA latency is exposed with 2 stages,
         // the 4-stage ring keeps 3 slices in flight (fc1T 800x768x3072: 23.4 -> 15.3 us); elsewhere its LDS footprint costs occupancy
