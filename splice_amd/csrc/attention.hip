@@ -16,6 +16,7 @@
 //                                 epilogue) -- supplies the token-contiguous operands.
 // Tokens t >= T inside a pass are padding: masked as keys, harmless as queries.
 #include "kernels.h"
+#include <cstdlib>
 
 
 #define NEG_BIG (-1.0e30f)
@@ -598,7 +599,8 @@ int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
     // 16 queries per wave while that still leaves fewer than ~3.5 waves per SIMD (latency hiding matters more than
     // fragment reuse at ViT-B/8 @ 224: 2400 wave tasks on 1024 SIMDs); 32 per wave for the long sequences.
     const long tasks = (long)a->B * a->H * cdiv(a->Tld, 16);
-    const int qb = g_attn_variant ? g_attn_variant : (tasks > 3600 ? 2 : 1);
+    static const long qb2_tasks = getenv("SPLICE_ATTN_QB2_TASKS") ? atol(getenv("SPLICE_ATTN_QB2_TASKS")) : 3600;
+    const int qb = g_attn_variant ? g_attn_variant : (tasks > qb2_tasks ? 2 : 1);
     const int nx = cdiv(a->Tld, 64 * qb);
     if (qb == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(nx * a->H * a->B), dim3(256), 0, s, *a, nx);
     else hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(nx * a->H * a->B), dim3(256), 0, s, *a, nx);
@@ -612,7 +614,8 @@ int attn_bwd_launch(const AttnArgs* a, hipStream_t s) {
     const int n = nx * a->H * a->B;
     // the two halves in one launch while the chip is not full anyway (a dependent launch costs more than the dQ half's
     // lower occupancy under the dK/dV half's LDS footprint); two launches once every CU has several workgroups
-    if (2 * n <= 768) {
+    static const int merge_max = getenv("SPLICE_ATTN_MERGE_MAX") ? atoi(getenv("SPLICE_ATTN_MERGE_MAX")) : 768;
+    if (2 * n <= merge_max) {
         hipLaunchKernelGGL(attn_bwd_kernel, dim3(2 * n), dim3(256), 0, s, *a, nx);
     } else {
         hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(n), dim3(256), 0, s, *a, nx);
