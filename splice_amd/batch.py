@@ -71,6 +71,21 @@ def _image_sizes(pair_dir):
     return tuple(out)
 
 
+def group_equal_sizes(indices, sizes, pairs_per_gpu):
+    """A worker's pairs -> (groups, singles): groups of 2 .. ``pairs_per_gpu`` pairs with identical image sizes (index order
+    inside a group, groups in order of their first pair), and what does not fill a group, in index order."""
+    by_size = {}
+    for i, sz in zip(indices, sizes):
+        by_size.setdefault(sz, []).append(i)
+    groups, singles = [], []
+    for idx in by_size.values():
+        while len(idx) >= 2:
+            groups.append(idx[:pairs_per_gpu])
+            idx = idx[pairs_per_gpu:]
+        singles += idx
+    return sorted(groups, key=lambda g: g[0]), sorted(singles)
+
+
 def _resolve(runner):
     if callable(runner):
         return runner
@@ -91,24 +106,10 @@ def _worker(gpu, visible_id, root, names, indices, runner, overrides, pin_gpu, p
     if pin_gpu:   # must happen before the HIP runtime starts in this process
         os.environ["HIP_VISIBLE_DEVICES"] = str(visible_id)
         os.environ.pop("CUDA_VISIBLE_DEVICES", None)
-    todo = list(indices)
-    if pairs_per_gpu > 1:
-        # this worker's pairs in groups of up to pairs_per_gpu with identical image sizes (index order inside a group): one
-        # MultiPairEngine per group; what does not fill a group runs alone below
-        by_size = {}
-        for i in todo:
-            by_size.setdefault(_image_sizes(os.path.join(root, names[i])), []).append(i)
-        todo = []
-        for idx in by_size.values():
-            while len(idx) >= 2:
-                grp, idx = idx[:pairs_per_gpu], idx[pairs_per_gpu:]
-                if len(grp) < 2:
-                    idx = grp + idx
-                    break
-                for i, res in zip(grp, train_group_runner([os.path.join(root, names[i]) for i in grp], dict(overrides))):
-                    _write_result(root, names[i], dict(res, pair=names[i], index=i, gpu=gpu))
-            todo += idx
-        todo.sort()
+    groups, todo = group_equal_sizes(indices, [_image_sizes(os.path.join(root, names[i])) for i in indices], pairs_per_gpu) if pairs_per_gpu > 1 else ([], list(indices))
+    for grp in groups:   # one MultiPairEngine per group
+        for i, res in zip(grp, train_group_runner([os.path.join(root, names[i]) for i in grp], dict(overrides))):
+            _write_result(root, names[i], dict(res, pair=names[i], index=i, gpu=gpu))
     run = _resolve(runner)
     for i in todo:
         res = dict(run(os.path.join(root, names[i]), dict(overrides)) or {})

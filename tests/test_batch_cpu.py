@@ -67,3 +67,16 @@ def test_worker_failure_is_reported(tmp_path):
     assert (tmp_path / "pair00" / "out" / "result.json").exists()      # the healthy worker finished its pairs
     with pytest.raises(ValueError):
         batch.run_batch(str(tmp_path / "not_a_pair"), 1, runner="test_batch_cpu:stub_runner", pin_gpu=False)
+
+
+def test_group_equal_sizes():
+    from splice_amd.batch import group_equal_sizes
+    a, b = ((224, 224), (224, 224)), ((320, 240), (224, 224))
+    # five pairs of size a, two of size b, one odd size; groups of up to 4
+    idx = [0, 1, 2, 3, 4, 5, 6, 7]
+    sizes = [a, b, a, a, ((1, 1), (1, 1)), a, b, a]
+    groups, singles = group_equal_sizes(idx, sizes, 4)
+    assert groups == [[0, 2, 3, 5], [1, 6]] and singles == [4, 7]
+    groups, singles = group_equal_sizes(idx, sizes, 2)
+    assert groups == [[0, 2], [1, 6], [3, 5]] and singles == [4, 7]
+    assert group_equal_sizes([3], [a], 8) == ([], [3])
