@@ -250,21 +250,22 @@ int attn_cls_bwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, i
 // slabs != null: the row is first FORMED as bias + resid_row + sum of the n_slabs split-K slabs of the producing GEMM
 // (slabs[s * slab_stride + row * D + c], in slab order) and stored to x -- the M = passes GEMMs of the [CLS] tail run
 // split-K over many workgroups because their run time is the serial K walk, not the rows.
-// (Both kernels keep the row in registers and request every operand before the first use: they sit on the critical chain with
-// a few rows of work, so their run time is the number of dependent memory round trips -- one here, ~150 in a naive loop.)
-constexpr int LNR_MAXC = 12;   // columns per lane: D <= 768 (ViT-S / ViT-B)
-constexpr int LNR_SB = 8;      // split-K slabs requested per round trip (12 measured no faster: the kernels are at their launch + one-round-trip floor)
+// Both kernels sit on the critical chain with a few rows of work: their run time is the number of dependent memory round trips
+// plus the instruction fetch of code that runs exactly once.  One WORKGROUP per row, three columns per thread: every operand
+// (all split-K slabs included) is requested before the first use -- one round trip -- and the body stays a few hundred instructions.
+constexpr int LNR_MAXC = 3;    // columns per thread: D <= 768 (ViT-S / ViT-B)
+constexpr int LNR_SB = 16;     // split-K slabs requested per round trip
 __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(float* __restrict__ x, size_t xs, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           bf16_t* __restrict__ y, size_t ys, float* __restrict__ mean_o, float* __restrict__ rstd_o, size_t ss,
                                                           int rows, int D, float eps, const float* __restrict__ slabs, int n_slabs, size_t slab_stride,
                                                           const float* __restrict__ bias, const float* __restrict__ resid, size_t rs) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    __shared__ float red[4];
+    const int row = blockIdx.x;
     float* xr = x + (size_t)row * xs;
     float v[LNR_MAXC], gv[LNR_MAXC], bv[LNR_MAXC];
 #pragma unroll
     for (int i = 0; i < LNR_MAXC; ++i) {
-        const int c = min(lane + 64 * i, D - 1);   // clamped: unconditional loads, the surplus lanes are dropped below
+        const int c = min((int)threadIdx.x + 256 * i, D - 1);   // clamped: unconditional loads, surplus threads are dropped below
         gv[i] = gamma[c]; bv[i] = beta[c];
         v[i] = slabs ? bias[c] + resid[(size_t)row * rs + c] : xr[c];
     }
@@ -275,36 +276,34 @@ __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(float* __restrict__ x,
             for (int k = 0; k < LNR_SB; ++k) {
                 const int sl = min(s0 + k, n_slabs - 1);
 #pragma unroll
-                for (int i = 0; i < LNR_MAXC; ++i)
-                    if (64 * i < D) t[k][i] = slabs[(size_t)sl * slab_stride + (size_t)row * D + min(lane + 64 * i, D - 1)];
+                for (int i = 0; i < LNR_MAXC; ++i) t[k][i] = slabs[(size_t)sl * slab_stride + (size_t)row * D + min((int)threadIdx.x + 256 * i, D - 1)];
             }
 #pragma unroll
             for (int k = 0; k < LNR_SB; ++k)
                 if (s0 + k < n_slabs) {
 #pragma unroll
-                    for (int i = 0; i < LNR_MAXC; ++i)
-                        if (64 * i < D) v[i] += t[k][i];
+                    for (int i = 0; i < LNR_MAXC; ++i) v[i] += t[k][i];
                 }
         }
 #pragma unroll
         for (int i = 0; i < LNR_MAXC; ++i)
-            if (lane + 64 * i < D) xr[lane + 64 * i] = v[i];
+            if ((int)threadIdx.x + 256 * i < D) xr[threadIdx.x + 256 * i] = v[i];
     }
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < LNR_MAXC; ++i)
-        if (lane + 64 * i < D) sum += v[i];
-    const float mean = wave_sum(sum) / (float)D;
+        if ((int)threadIdx.x + 256 * i < D) sum += v[i];
+    const float mean = block_sum256(sum, red) / (float)D;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < LNR_MAXC; ++i)
-        if (lane + 64 * i < D) { const float d = v[i] - mean; sq += d * d; }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
-    if (lane == 0) { mean_o[(size_t)row * ss] = mean; rstd_o[(size_t)row * ss] = rstd; }
+        if ((int)threadIdx.x + 256 * i < D) { const float d = v[i] - mean; sq += d * d; }
+    const float rstd = rsqrtf(block_sum256(sq, red) / (float)D + eps);
+    if (threadIdx.x == 0) { mean_o[(size_t)row * ss] = mean; rstd_o[(size_t)row * ss] = rstd; }
     bf16_t* yr = y + (size_t)row * ys;
 #pragma unroll
     for (int i = 0; i < LNR_MAXC; ++i)
-        if (lane + 64 * i < D) yr[lane + 64 * i] = f2bf((v[i] - mean) * rstd * gv[i] + bv[i]);
+        if ((int)threadIdx.x + 256 * i < D) yr[threadIdx.x + 256 * i] = f2bf((v[i] - mean) * rstd * gv[i] + bv[i]);
 }
 // g (strided like x, in place) += LN_backward(dy); g_bf = bf16(g).  dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)), dxhat = dy gamma
 // n_slabs > 1: dy is given as split-K slabs (dy + s * slab_stride), summed in place into slab 0 first
@@ -312,8 +311,8 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(float* __restrict__ dy
                                                           const float* __restrict__ gamma, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                           size_t ss, float* __restrict__ g, bf16_t* __restrict__ g_bf, int rows, int D, int n_slabs,
                                                           size_t slab_stride) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    __shared__ float red[4];
+    const int row = blockIdx.x;
     const float* xr = x + (size_t)row * xs;
     float* dr = dy + (size_t)row * dys;
     float* gr = g + (size_t)row * xs;
@@ -322,7 +321,7 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(float* __restrict__ dy
     float v[LNR_MAXC], gv[LNR_MAXC], xv[LNR_MAXC], g0[LNR_MAXC];
 #pragma unroll
     for (int i = 0; i < LNR_MAXC; ++i) {
-        const int c = min(lane + 64 * i, D - 1);
+        const int c = min((int)threadIdx.x + 256 * i, D - 1);
         v[i] = dr[c]; gv[i] = gamma[c]; xv[i] = xr[c]; g0[i] = gr[c];
     }
     if (n_slabs > 1) {
@@ -332,51 +331,49 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(float* __restrict__ dy
             for (int k = 0; k < LNR_SB; ++k) {
                 const int sl = min(s0 + k, n_slabs - 1);
 #pragma unroll
-                for (int i = 0; i < LNR_MAXC; ++i)
-                    if (64 * i < D) t[k][i] = dr[(size_t)sl * slab_stride + min(lane + 64 * i, D - 1)];
+                for (int i = 0; i < LNR_MAXC; ++i) t[k][i] = dr[(size_t)sl * slab_stride + min((int)threadIdx.x + 256 * i, D - 1)];
             }
 #pragma unroll
             for (int k = 0; k < LNR_SB; ++k)
                 if (s0 + k < n_slabs) {
 #pragma unroll
-                    for (int i = 0; i < LNR_MAXC; ++i)
-                        if (64 * i < D) v[i] += t[k][i];
+                    for (int i = 0; i < LNR_MAXC; ++i) v[i] += t[k][i];
                 }
         }
 #pragma unroll
         for (int i = 0; i < LNR_MAXC; ++i)
-            if (lane + 64 * i < D) dr[lane + 64 * i] = v[i];
+            if ((int)threadIdx.x + 256 * i < D) dr[threadIdx.x + 256 * i] = v[i];
     }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < LNR_MAXC; ++i)
-        if (lane + 64 * i < D) {
+        if ((int)threadIdx.x + 256 * i < D) {
             const float dh = v[i] * gv[i], xh = (xv[i] - mean) * rstd;
             s1 += dh;
             s2 += dh * xh;
         }
-    s1 = wave_sum(s1) / (float)D;
-    s2 = wave_sum(s2) / (float)D;
+    s1 = block_sum256(s1, red) / (float)D;
+    s2 = block_sum256(s2, red) / (float)D;
 #pragma unroll
     for (int i = 0; i < LNR_MAXC; ++i)
-        if (lane + 64 * i < D) {
+        if ((int)threadIdx.x + 256 * i < D) {
             const float dh = v[i] * gv[i], xh = (xv[i] - mean) * rstd;
             const float o = g0[i] + rstd * (dh - s1 - xh * s2);
-            gr[lane + 64 * i] = o;
-            gb[lane + 64 * i] = f2bf(o);
+            gr[threadIdx.x + 256 * i] = o;
+            gb[threadIdx.x + 256 * i] = f2bf(o);
         }
 }
 int ln_rows_fwd_launch(float* x, size_t xs, const float* gamma, const float* beta, bf16_t* y, size_t ys, float* mean, float* rstd, size_t ss, int rows,
                        int D, float eps, const float* slabs, int n_slabs, size_t slab_stride, const float* bias, const float* resid, size_t rs, hipStream_t s) {
-    if (D > 64 * LNR_MAXC || D < 1) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(ln_rows_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, xs, gamma, beta, y, ys, mean, rstd, ss, rows, D, eps, slabs, n_slabs, slab_stride,
+    if (D > 256 * LNR_MAXC || D < 1 || rows < 1) return SPLICE_ERR_ARG;
+    hipLaunchKernelGGL(ln_rows_fwd_kernel, dim3(rows), dim3(256), 0, s, x, xs, gamma, beta, y, ys, mean, rstd, ss, rows, D, eps, slabs, n_slabs, slab_stride,
                        bias, resid, rs);
     return SPLICE_OK;
 }
 int ln_rows_bwd_launch(float* dy, size_t dys, const float* x, size_t xs, const float* gamma, const float* mean, const float* rstd, size_t ss, float* g,
                        bf16_t* g_bf, int rows, int D, int n_slabs, size_t slab_stride, hipStream_t s) {
-    if (D > 64 * LNR_MAXC || D < 1) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, dy, dys, x, xs, gamma, mean, rstd, ss, g, g_bf, rows, D, n_slabs, slab_stride);
+    if (D > 256 * LNR_MAXC || D < 1 || rows < 1) return SPLICE_ERR_ARG;
+    hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3(rows), dim3(256), 0, s, dy, dys, x, xs, gamma, mean, rstd, ss, g, g_bf, rows, D, n_slabs, slab_stride);
     return SPLICE_OK;
 }
 
