@@ -29,28 +29,38 @@ __device__ __forceinline__ float block_max256(float v, float* red) {
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-// grid (H, B): softmax(q_cls . k_j * scale) v over the T keys of one (pass, head), fp32 statistics.
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+// acc + a.lo * b.lo + a.hi * b.hi on two packed bf16 pairs (v_dot2c_f32_bf16): one instruction where the unpack-and-FMA form
+// needs four -- these kernels run once per launch, their size is instruction fetch time on the critical chain
+__device__ __forceinline__ float dot2bf(uint32_t a, uint32_t b, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, a), __builtin_bit_cast(bf16x2v, b), acc, false);
+}
+
+// grid (H, B): softmax(q_cls . k_j * scale) v over the T keys of one (pass, head), fp32 statistics, bf16 probabilities in the
+// second product (as the full attention kernel).
 //   qkv  bf16 [B*Tld][3D]; qkvT bf16 [3D][ldt] (token-contiguous V for the second product)
 //   out  bf16 [B][D] (compact: one row per pass); probs fp32 [B][H][Tld] (saved for the backward; 0 beyond T)
 __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qkvT, int ldt, int T, int Tld, int D,
                                                            float scale, bf16_t* __restrict__ out, float* __restrict__ probs) {
-    extern __shared__ float cls_smem[];   // [Tld] probabilities | [64] q | [256] partial o | [4] reductions
+    extern __shared__ __attribute__((aligned(16))) float cls_smem[];   // [Tld] scores / probabilities | [Tld/2] packed bf16 probabilities | [256] partial o | [4]
     float* p = cls_smem;
-    float* q = p + Tld;
-    float* po = q + 64;
+    uint32_t* pb = reinterpret_cast<uint32_t*>(p + Tld);
+    float* po = reinterpret_cast<float*>(pb + Tld / 2);
     float* red = po + 256;
     const int h = blockIdx.x, b = blockIdx.y, H = gridDim.x;
     const size_t row0 = (size_t)b * Tld;
-    if (threadIdx.x < 64) q[threadIdx.x] = bf2f(qkv[row0 * 3 * D + h * 64 + threadIdx.x]) * scale;
-    // The kernel is a chain of memory round trips on the critical path of the step: everything that does not depend on a
-    // result is requested up front -- the first CLS_NV value vectors of this thread's (d, token quarter) now, the key rows four
-    // tokens at a time.  (Same arithmetic in the same order as the plain loops.)
+    // Everything that does not depend on a result is requested up front (the kernel is a chain of memory round trips on the
+    // critical path of the step): the query row, the first CLS_NV value vectors of this thread's (d, token quarter), four key rows.
     const int d = threadIdx.x & 63, part = threadIdx.x >> 6;
     const bf16_t* vt = qkvT + (size_t)(2 * D + h * 64 + d) * ldt + row0;
-    u32x4 vpre[CLS_NV];
+    u32x4 qv[8], vpre[CLS_NV], kv[4][8];
+    {
+        const u32x4* qr = reinterpret_cast<const u32x4*>(qkv + row0 * 3 * D + h * 64);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) qv[c] = qr[c];
+    }
 #pragma unroll
     for (int i = 0; i < CLS_NV; ++i) vpre[i] = *reinterpret_cast<const u32x4*>(vt + min(8 * part + 32 * i, Tld - 8));
-    u32x4 kv[4][8];
     auto load_keys = [&](int j0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -59,8 +69,7 @@ __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(const bf16_t* __restr
             for (int c = 0; c < 8; ++c) kv[u][c] = kr[c];
         }
     };
-    load_keys(threadIdx.x);   // (before the barrier that publishes q: the keys do not depend on it)
-    __syncthreads();
+    load_keys(threadIdx.x);
     float mx = -1e30f;
     for (int j0 = threadIdx.x; j0 < T; j0 += 4 * 256) {
         if (j0 != (int)threadIdx.x) load_keys(j0);
@@ -70,12 +79,10 @@ __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(const bf16_t* __restr
             if (j >= T) break;
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const u32x4 v = kv[u][c];
+            for (int c = 0; c < 8; ++c)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    s += q[c * 8 + 2 * e] * __uint_as_float(v[e] << 16) + q[c * 8 + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
-            }
+                for (int e = 0; e < 4; ++e) s = dot2bf(qv[c][e], kv[u][c][e], s);
+            s *= scale;
             p[j] = s;
             mx = fmaxf(mx, s);
         }
@@ -90,44 +97,48 @@ __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(const bf16_t* __restr
     sum = block_sum256(sum, red);
     const float inv = 1.0f / sum;
     float* pg = probs + ((size_t)b * H + h) * Tld;
-    for (int j = threadIdx.x; j < Tld; j += 256) {
-        const float v = p[j] * inv;
-        p[j] = v;
-        pg[j] = v;
+    for (int j2 = threadIdx.x; j2 < Tld / 2; j2 += 256) {   // two tokens per thread: fp32 for the backward, packed bf16 for the product
+        const float v0 = p[2 * j2] * inv, v1 = p[2 * j2 + 1] * inv;
+        *reinterpret_cast<float2*>(pg + 2 * j2) = float2{v0, v1};
+        pb[j2] = pack2bf(v0, v1);
     }
     __syncthreads();
-    // o[d] = sum_j p_j v_j[d]: thread = (d, quarter of the tokens), token-contiguous reads from the transposed copy
+    // o[d] = sum_j p_j v_j[d]: thread = (d, quarter of the tokens), token-contiguous reads from the transposed copy;
+    // 8 tokens (16 bytes) per load; p is zero beyond T and the padding columns are finite
     float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < CLS_NV; ++i) {   // 8 tokens (16 bytes) per load; p is zero beyond T and the padding columns are finite
+    for (int i = 0; i < CLS_NV; ++i) {
         const int j = 8 * part + 32 * i;
         if (j < Tld) {
-            const u32x4 v = vpre[i];
+            const u32x4 pv = *reinterpret_cast<const u32x4*>(pb + j / 2);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc += p[j + 2 * e] * __uint_as_float(v[e] << 16) + p[j + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
+            for (int e = 0; e < 4; ++e) acc = dot2bf(pv[e], vpre[i][e], acc);
         }
     }
-#pragma unroll 4
+#pragma unroll 2
     for (int j = 8 * part + 32 * CLS_NV; j < Tld; j += 32) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(vt + j);
+        const u32x4 pv = *reinterpret_cast<const u32x4*>(pb + j / 2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc += p[j + 2 * e] * __uint_as_float(v[e] << 16) + p[j + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
+        for (int e = 0; e < 4; ++e) acc = dot2bf(pv[e], v[e], acc);
     }
     po[part * 64 + d] = acc;
     __syncthreads();
     if (threadIdx.x < 64) out[(size_t)b * D + h * 64 + threadIdx.x] = f2bf((po[threadIdx.x] + po[64 + threadIdx.x]) + (po[128 + threadIdx.x] + po[192 + threadIdx.x]));
 }
 
-// grid (H, B): backward of the above for dO given at the [CLS] query only.  Writes the WHOLE [Tld] x (q | k | v head slices) block
+// grid (H, B, nz): backward of the above for dO given at the [CLS] query only.  Writes the WHOLE [Tld] x (q | k | v head slices) block
 // of dqkv bf16 [B*Tld][3D]: dq on the [CLS] row (zero elsewhere), dk_j = ds_j q_cls, dv_j = p_j dO, zero rows beyond T.
 __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qkvT, int ldt, int T, int Tld, int D,
                                                            float scale, const float* __restrict__ probs, const float* __restrict__ dout /* n_slabs x [*][D] fp32 */,
                                                            int n_slabs, size_t slab_stride, bf16_t* __restrict__ dqkv) {
-    extern __shared__ float cls_smem[];   // [Tld] ds | [64] q | [64] dO | [256] partial dq | [4]
+    extern __shared__ __attribute__((aligned(16))) float cls_smem[];   // [Tld] dP / ds | [Tld/2] packed bf16 ds | [64] q | [64] dO | [32] packed dO | [256] partial dq | [4]
     float* ds = cls_smem;
-    float* q = ds + Tld;
+    uint32_t* dsb = reinterpret_cast<uint32_t*>(ds + Tld);
+    float* q = reinterpret_cast<float*>(dsb + Tld / 2);
     float* dO = q + 64;
-    float* pq = dO + 64;
+    uint32_t* dOb = reinterpret_cast<uint32_t*>(dO + 64);
+    float* pq = reinterpret_cast<float*>(dOb + 32);
     float* red = pq + 256;
     // blockIdx.z: the token rows this workgroup WRITES (307 KB of dqkv rows per (pass, head) are the bulk of the kernel: spread over
     // gridDim.z workgroups; each recomputes the cheap reductions, z = 0 also forms the dq row).  Same values whatever gridDim.z is.
@@ -145,22 +156,20 @@ __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const bf16_t* __restr
 #pragma unroll
         for (int sl = 0; sl < 16; ++sl)
             if (sl < n_slabs) v += sv[sl];
-        dO[threadIdx.x] = bf2f(f2bf(v));   // (bf16 like the full path's dout)
+        const bf16_t vb = f2bf(v);   // (bf16 like the full path's dout)
+        dO[threadIdx.x] = bf2f(vb);
+        reinterpret_cast<bf16_t*>(dOb)[threadIdx.x] = vb;
     }
     // (requests that depend on nothing computed here go out first: see the forward)
     const int d = threadIdx.x & 63, part = threadIdx.x >> 6;
     const bf16_t* kt = qkvT + (size_t)(D + h * 64 + d) * ldt + row0;
-    u32x4 kpre[CLS_NV];
+    u32x4 kpre[CLS_NV], vv[4][8];
+    float pj4[4];
     if (z == 0) {
 #pragma unroll
         for (int i = 0; i < CLS_NV; ++i) kpre[i] = *reinterpret_cast<const u32x4*>(kt + min(8 * part + 32 * i, Tld - 8));
     }
-    __syncthreads();
-    // dP_j = dO . v_j ; delta = sum_j p_j dP_j
-    float dl = 0.f;
-    for (int j0 = threadIdx.x; j0 < T; j0 += 4 * 256) {
-        u32x4 vv[4][8];
-        float pj4[4];
+    auto load_values = [&](int j0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int jc = min(j0 + 256 * u, T - 1);
@@ -169,18 +178,25 @@ __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const bf16_t* __restr
             for (int c = 0; c < 8; ++c) vv[u][c] = vr[c];
             pj4[u] = pg[jc];
         }
+    };
+    load_values(threadIdx.x);
+    __syncthreads();
+    u32x4 dov[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dov[c] = *reinterpret_cast<const u32x4*>(dOb + 4 * c);
+    // dP_j = dO . v_j ; delta = sum_j p_j dP_j
+    float dl = 0.f;
+    for (int j0 = threadIdx.x; j0 < T; j0 += 4 * 256) {
+        if (j0 != (int)threadIdx.x) load_values(j0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = j0 + 256 * u;
             if (j >= T) break;
             float s = 0.f;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const u32x4 v = vv[u][c];
+            for (int c = 0; c < 8; ++c)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    s += dO[c * 8 + 2 * e] * __uint_as_float(v[e] << 16) + dO[c * 8 + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
-            }
+                for (int e = 0; e < 4; ++e) s = dot2bf(dov[c][e], vv[u][c][e], s);
             ds[j] = s;
             dl += pj4[u] * s;
         }
@@ -190,13 +206,13 @@ __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const bf16_t* __restr
     for (int j = threadIdx.x; j < Tld; j += 256) {
         const float pj = j < T ? pg[j] : 0.f;
         const float dsj = j < T ? pj * (ds[j] - delta) * scale : 0.f;
-        ds[j] = dsj;
+        reinterpret_cast<bf16_t*>(dsb)[j] = f2bf(dsj);
         if ((j >> 8) % nz != z) continue;   // another workgroup writes these rows
         bf16_t* r = dqkv + (row0 + j) * 3 * D + h * 64;
         u32x4* rq = reinterpret_cast<u32x4*>(r);
         u32x4* rk = reinterpret_cast<u32x4*>(r + D);
         u32x4* rv = reinterpret_cast<u32x4*>(r + 2 * D);
-#pragma unroll
+#pragma unroll 2
         for (int c = 0; c < 8; ++c) {   // 16-byte stores: 8 per 64-wide head slice
             if (j != 0) rq[c] = u32x4{0u, 0u, 0u, 0u};
             rk[c] = u32x4{pack2bf(dsj * q[8 * c], dsj * q[8 * c + 1]), pack2bf(dsj * q[8 * c + 2], dsj * q[8 * c + 3]),
@@ -207,22 +223,23 @@ __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const bf16_t* __restr
     }
     if (z != 0) return;
     __syncthreads();
-    // dq_cls[d] = sum_j ds_j k_j[d]
+    // dq_cls[d] = sum_j ds_j k_j[d]  (bf16 ds, as the full kernel packs it; ds is zero beyond T)
     float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < CLS_NV; ++i) {   // ds is zero beyond T
+    for (int i = 0; i < CLS_NV; ++i) {
         const int j = 8 * part + 32 * i;
         if (j < Tld) {
-            const u32x4 v = kpre[i];
+            const u32x4 dv4 = *reinterpret_cast<const u32x4*>(dsb + j / 2);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc += ds[j + 2 * e] * __uint_as_float(v[e] << 16) + ds[j + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
+            for (int e = 0; e < 4; ++e) acc = dot2bf(dv4[e], kpre[i][e], acc);
         }
     }
-#pragma unroll 4
+#pragma unroll 2
     for (int j = 8 * part + 32 * CLS_NV; j < Tld; j += 32) {
         const u32x4 v = *reinterpret_cast<const u32x4*>(kt + j);
+        const u32x4 dv4 = *reinterpret_cast<const u32x4*>(dsb + j / 2);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc += ds[j + 2 * e] * __uint_as_float(v[e] << 16) + ds[j + 2 * e + 1] * __uint_as_float(v[e] & 0xFFFF0000u);
+        for (int e = 0; e < 4; ++e) acc = dot2bf(dv4[e], v[e], acc);
     }
     pq[part * 64 + d] = acc;
     __syncthreads();
@@ -233,14 +250,14 @@ __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const bf16_t* __restr
 int attn_cls_fwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, int T, int Tld, int D, int H, float scale, bf16_t* out, float* probs,
                         hipStream_t s) {
     if (D / 64 != H || D % 64) return SPLICE_ERR_ARG;
-    const size_t lds = (size_t)(Tld + 64 + 256 + 8) * sizeof(float);
+    const size_t lds = (size_t)(Tld + Tld / 2 + 256 + 8) * sizeof(float);
     hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(H, B), dim3(256), lds, s, qkv, qkvT, ldt, T, Tld, D, scale, out, probs);
     return SPLICE_OK;
 }
 int attn_cls_bwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, int T, int Tld, int D, int H, float scale, const float* probs,
                         const float* dout_slabs, int n_slabs, size_t slab_stride, bf16_t* dqkv, hipStream_t s) {
     if (D / 64 != H || D % 64 || n_slabs < 1 || n_slabs > 16) return SPLICE_ERR_ARG;
-    const size_t lds = (size_t)(Tld + 64 + 64 + 256 + 8) * sizeof(float);
+    const size_t lds = (size_t)(Tld + Tld / 2 + 64 + 64 + 32 + 256 + 8) * sizeof(float);
     const int nz = Tld > 768 ? 4 : Tld > 256 ? 2 : 1;   // one 256-row slice of the store loop per workgroup at ViT-B/8 @ 224
     hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(H, B, nz), dim3(256), lds, s, qkv, qkvT, ldt, T, Tld, D, scale, probs, dout_slabs, n_slabs, slab_stride, dqkv);
     return SPLICE_OK;
