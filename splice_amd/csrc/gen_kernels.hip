@@ -885,9 +885,11 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 // pure launch latency -- a kernel boundary costs more than the work.
 constexpr int BN_SMALL_HW = 4096;
 constexpr int BN_MAX_BATCH = 8;               // images per batch-statistics call (n_crops)
-constexpr int BN_SMALL_PER = BN_SMALL_HW / 256;   // plane elements a thread keeps in registers
+constexpr int BN_SMALL_PER = BN_SMALL_HW / 256;   // most plane elements a thread keeps in registers (kernels are instantiated for 1, 4 and 16:
+                                                  // a 7x7 plane running the 16-element code fetched ten times the instructions it executed)
 constexpr int BN_UP_SRC = 34 * 34;            // low-resolution plane of a fused upsampling staged in LDS (else read from global)
 // slabs != null: the plane is first formed as bias + sum of the feeding convolution's split-K slabs (slice order) and stored to y
+template <int PER>   // plane elements a thread keeps in registers: 1, 4 or 16 (planes of <= 256, <= 1024, <= 4096 pixels)
 __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_t y_nstride, float* __restrict__ out,
                                                            size_t out_nstride, int C, int HW, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float* __restrict__ mean_o,
@@ -903,7 +905,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
     float* q = out + (size_t)img * out_nstride + (size_t)c * HW;
     // loads are issued branch-free (wave-uniform guards only; a thread past the end of the plane re-reads element 0 and
     // is masked afterwards): lane-guarded loads compile to load + s_waitcnt per element, i.e. one memory round trip each
-    float v[BN_SMALL_PER];
+    float v[PER];
     float s = 0.f, dummy = 0.f;
     if (slabs) {
         const size_t per = (size_t)gridDim.y * C * HW;
@@ -911,15 +913,15 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
         float* yo = y_out + (size_t)img * y_nstride + (size_t)c * HW;
         const float b = bias ? bias[c] : 0.f;
 #pragma unroll
-        for (int k = 0; k < BN_SMALL_PER; ++k) v[k] = b;
+        for (int k = 0; k < PER; ++k) v[k] = b;
         for (int ks = 0; ks < ksplit; ks += 4) {   // slice order (as conv_splitk_reduce_kernel); four slices of loads in flight
-            float t[4][BN_SMALL_PER];
+            float t[4][PER];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (ks + u >= ksplit) continue;
                 const float* sk = sp + (size_t)(ks + u) * per;
 #pragma unroll
-                for (int k = 0; k < BN_SMALL_PER; ++k) {
+                for (int k = 0; k < PER; ++k) {
                     if (k * 256 >= HW) continue;
                     const int i = threadIdx.x + k * 256;
                     t[u][k] = sk[i < HW ? i : 0];
@@ -929,12 +931,12 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
             for (int u = 0; u < 4; ++u) {
                 if (ks + u >= ksplit) continue;
 #pragma unroll
-                for (int k = 0; k < BN_SMALL_PER; ++k)
+                for (int k = 0; k < PER; ++k)
                     if (k * 256 < HW) v[k] += t[u][k];
             }
         }
 #pragma unroll
-        for (int k = 0; k < BN_SMALL_PER; ++k) {
+        for (int k = 0; k < PER; ++k) {
             const int i = threadIdx.x + k * 256;
             if (i < HW) yo[i] = v[k]; else v[k] = 0.f;
             s += v[k];
@@ -950,7 +952,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
             __syncthreads();
         }
 #pragma unroll
-        for (int k = 0; k < BN_SMALL_PER; ++k) {
+        for (int k = 0; k < PER; ++k) {
             const int i = threadIdx.x + k * 256;
             v[k] = 0.f;
             if (k * 256 < HW) {
@@ -961,18 +963,18 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
             }
         }
 #pragma unroll
-        for (int k = 0; k < BN_SMALL_PER; ++k) {
+        for (int k = 0; k < PER; ++k) {
             if (threadIdx.x + k * 256 >= HW) v[k] = 0.f;
             s += v[k];
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < BN_SMALL_PER; ++k) {
+        for (int k = 0; k < PER; ++k) {
             const int i = threadIdx.x + k * 256;
             v[k] = k * 256 < HW ? p[i < HW ? i : 0] : 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < BN_SMALL_PER; ++k) {
+        for (int k = 0; k < PER; ++k) {
             if (threadIdx.x + k * 256 >= HW) v[k] = 0.f;
             s += v[k];
         }
@@ -991,7 +993,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
             const float* pn = y + (size_t)n * y_nstride + (size_t)c * HW;
             float sn = 0.f, d2 = 0.f;
 #pragma unroll
-            for (int k = 0; k < BN_SMALL_PER; ++k) {
+            for (int k = 0; k < PER; ++k) {
                 const int i = threadIdx.x + k * 256;
                 if (k * 256 < HW) sn += i < HW ? pn[i] : 0.f;
             }
@@ -1004,7 +1006,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
             const float* pn = y + (size_t)n * y_nstride + (size_t)c * HW;
             float qn = 0.f, d2 = 0.f;
 #pragma unroll
-            for (int k = 0; k < BN_SMALL_PER; ++k) {
+            for (int k = 0; k < PER; ++k) {
                 const int i = threadIdx.x + k * 256;
                 if (k * 256 < HW) { const float d = i < HW ? pn[i] - m : 0.f; qn += d * d; }
             }
@@ -1013,7 +1015,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < BN_SMALL_PER; ++k) {
+        for (int k = 0; k < PER; ++k) {
             const float d = threadIdx.x + k * 256 < HW ? v[k] - m : 0.f;
             sq += d * d;
         }
@@ -1024,7 +1026,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
     const float sc = gamma[c] * r;
     const float sh = beta[c] - m * sc;
 #pragma unroll
-    for (int k = 0; k < BN_SMALL_PER; ++k) {
+    for (int k = 0; k < PER; ++k) {
         const int i = threadIdx.x + k * 256;
         if (i < HW) {
             const float t = v[k] * sc + sh;
@@ -1035,14 +1037,15 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
 // one workgroup per (channel, image); each plane is read once and kept in registers between the reduction and the apply
 // pass.  dgamma / dbeta need the sums of EVERY image: the workgroup of image 0 recomputes the other images' two sums
 // (reads only) and adds them in image order -- deterministic, no second launch, no cross-workgroup wait.
+template <int PER>
 __device__ __forceinline__ void bn_small_bwd_sums(const float* pd, const float* pa, const float* py, int HW, float m, float r, float slope,
-                                                  float (&dz)[BN_SMALL_PER], float (&xh)[BN_SMALL_PER], float& s1, float& s2, float* red) {
+                                                  float (&dz)[PER], float (&xh)[PER], float& s1, float& s2, float* red) {
     s1 = 0.f; s2 = 0.f;
     // branch-free loads first (see bn_small_fwd_kernel), arithmetic after
     const bool act = slope != 1.0f;
-    float vd[BN_SMALL_PER], va[BN_SMALL_PER], vy[BN_SMALL_PER];
+    float vd[PER], va[PER], vy[PER];
 #pragma unroll
-    for (int k = 0; k < BN_SMALL_PER; ++k) {
+    for (int k = 0; k < PER; ++k) {
         if (k * 256 >= HW) continue;
         const int i = threadIdx.x + k * 256;
         const int j = i < HW ? i : 0;
@@ -1051,7 +1054,7 @@ __device__ __forceinline__ void bn_small_bwd_sums(const float* pd, const float* 
         va[k] = act ? pa[j] : 1.f;
     }
 #pragma unroll
-    for (int k = 0; k < BN_SMALL_PER; ++k) {
+    for (int k = 0; k < PER; ++k) {
         const int i = threadIdx.x + k * 256;
         float d = 0.f, x = 0.f;
         if (k * 256 < HW) {
@@ -1066,6 +1069,7 @@ __device__ __forceinline__ void bn_small_bwd_sums(const float* pd, const float* 
     }
     block_sum2(s1, s2, red);
 }
+template <int PER>
 __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restrict__ da, size_t da_nstride, const float* __restrict__ aout,
                                                            size_t a_nstride, const float* __restrict__ y, size_t y_nstride,
                                                            float* __restrict__ dy, size_t dy_nstride, int C, int HW, int N,
@@ -1076,7 +1080,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
     __shared__ float up_grad_s[BN_SMALL_HW];   // fused upsampling adjoint: this plane's input gradient
     const int c = blockIdx.x, img = blockIdx.y;
     gamma += (size_t)img * p_nstride;
-    float dz[BN_SMALL_PER], xh[BN_SMALL_PER];
+    float dz[PER], xh[PER];
     float s1, s2;
     {
         const float m = mean[img * C + c], r = rstd[img * C + c];
@@ -1087,16 +1091,16 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
             for (int n = 0; n < BN_MAX_BATCH; ++n) {
                 t1s[n] = 0.f; t2s[n] = 0.f;
                 if (n < N && n != img)
-                    bn_small_bwd_sums(da + (size_t)n * da_nstride + (size_t)c * HW, aout + (size_t)n * a_nstride + (size_t)c * HW,
+                    bn_small_bwd_sums<PER>(da + (size_t)n * da_nstride + (size_t)c * HW, aout + (size_t)n * a_nstride + (size_t)c * HW,
                                       y + (size_t)n * y_nstride + (size_t)c * HW, HW, mean[n * C + c], rstd[n * C + c], slope, dz, xh, t1s[n], t2s[n], red);
             }
-            bn_small_bwd_sums(da + (size_t)img * da_nstride + (size_t)c * HW, aout + (size_t)img * a_nstride + (size_t)c * HW,
+            bn_small_bwd_sums<PER>(da + (size_t)img * da_nstride + (size_t)c * HW, aout + (size_t)img * a_nstride + (size_t)c * HW,
                               y + (size_t)img * y_nstride + (size_t)c * HW, HW, m, r, slope, dz, xh, s1, s2, red);
 #pragma unroll
             for (int n = 0; n < BN_MAX_BATCH; ++n)
                 if (n < N) { b1 += n == img ? s1 : t1s[n]; b2 += n == img ? s2 : t2s[n]; }
         } else {
-            bn_small_bwd_sums(da + (size_t)img * da_nstride + (size_t)c * HW, aout + (size_t)img * a_nstride + (size_t)c * HW,
+            bn_small_bwd_sums<PER>(da + (size_t)img * da_nstride + (size_t)c * HW, aout + (size_t)img * a_nstride + (size_t)c * HW,
                               y + (size_t)img * y_nstride + (size_t)c * HW, HW, m, r, slope, dz, xh, s1, s2, red);
         }
         const float cnt = batch ? (float)HW * (float)N : (float)HW;
@@ -1106,7 +1110,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
         float* po = dy + (size_t)img * dy_nstride + (size_t)c * HW;
         const bool through_adjoint = up.d_src && c >= up.c0;   // workgroup-uniform
 #pragma unroll
-        for (int k = 0; k < BN_SMALL_PER; ++k) {
+        for (int k = 0; k < PER; ++k) {
             const int i = threadIdx.x + k * 256;
             if (i < HW) {
                 const float gv = gr * (dz[k] - k1 - xh[k] * k2);
@@ -1135,7 +1139,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
     float g = s2, be = s1;
     for (int n = 1; n < (batch ? 0 : N); ++n) {
         float t1, t2;
-        bn_small_bwd_sums(da + (size_t)n * da_nstride + (size_t)c * HW, aout + (size_t)n * a_nstride + (size_t)c * HW,
+        bn_small_bwd_sums<PER>(da + (size_t)n * da_nstride + (size_t)c * HW, aout + (size_t)n * a_nstride + (size_t)c * HW,
                           y + (size_t)n * y_nstride + (size_t)c * HW, HW, mean[n * C + c], rstd[n * C + c], slope, dz, xh, t1, t2, red);
         be += t1;
         g += t2;
@@ -1146,6 +1150,14 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
     }
 }
 
+// the instantiation whose register tile just covers the plane (same arithmetic in the same order: the surplus elements of a
+// bigger tile only ever added zeros)
+#define BN_SMALL_DISPATCH(HW_, KERNEL, GRID, STREAM, ...)                                                         \
+    do {                                                                                                          \
+        if ((HW_) <= 256) hipLaunchKernelGGL(KERNEL<1>, GRID, dim3(256), 0, STREAM, __VA_ARGS__);                  \
+        else if ((HW_) <= 1024) hipLaunchKernelGGL(KERNEL<4>, GRID, dim3(256), 0, STREAM, __VA_ARGS__);            \
+        else hipLaunchKernelGGL(KERNEL<16>, GRID, dim3(256), 0, STREAM, __VA_ARGS__);                              \
+    } while (0)
 // 512-pixel segments (tuned in-step with alternating runs: 1024 +0.45 %, 256 / 384 +0.1 %, 2048 +1.3 %)
 static inline int plane_blocks(int HW) { int b = cdiv(HW, 512); return b < 1 ? 1 : (b > MAX_PB ? MAX_PB : b); }
 int bn_part_floats(int N, int C) { return N * C * MAX_PB * 2; }
@@ -1155,8 +1167,8 @@ int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstri
     const BnUpsample u = up ? *up : BnUpsample{};
     if (batch && (N > BN_MAX_BATCH || u.src || p_nstride)) return SPLICE_ERR_ARG;
     if (HW <= BN_SMALL_HW) {
-        hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd, slope,
-                           (const float*)nullptr, 0, (const float*)nullptr, (float*)nullptr, u, p_nstride, batch);
+        BN_SMALL_DISPATCH(HW, bn_small_fwd_kernel, dim3(C, N), s, y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd, slope,
+                          (const float*)nullptr, 0, (const float*)nullptr, (float*)nullptr, u, p_nstride, batch);
         return SPLICE_OK;
     }
     const int PB = plane_blocks(HW);
@@ -1169,8 +1181,8 @@ int bn_small_hw() { return BN_SMALL_HW; }
 int bn_fwd_slabs_launch(const float* slabs, int ksplit, const float* bias, float* y, size_t y_nstride, float* out, size_t out_nstride, int N,
                         int C, int HW, const float* gamma, const float* beta, float eps, float* mean, float* rstd, float slope, hipStream_t s, size_t p_nstride) {
     if (HW > BN_SMALL_HW || ksplit < 2 || !slabs) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C, N), dim3(256), 0, s, (const float*)y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd,
-                       slope, slabs, ksplit, bias, y, BnUpsample{}, p_nstride, 0);
+    BN_SMALL_DISPATCH(HW, bn_small_fwd_kernel, dim3(C, N), s, (const float*)y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd,
+                      slope, slabs, ksplit, bias, y, BnUpsample{}, p_nstride, 0);
     return SPLICE_OK;
 }
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
@@ -1180,8 +1192,8 @@ int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t 
     if (HW <= BN_SMALL_HW) {
         BnUpsample u = up ? *up : BnUpsample{};
         if (!bn_bwd_fuses_upsample(HW, u.h, u.w)) u.d_src = nullptr;
-        hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy, dy_nstride, C, HW, N,
-                           gamma, mean, rstd, slope, dgamma, dbeta, accumulate, u, p_nstride, batch);
+        BN_SMALL_DISPATCH(HW, bn_small_bwd_kernel, dim3(C, N), s, da, da_nstride, aout, a_nstride, y, y_nstride, dy, dy_nstride, C, HW, N,
+                          gamma, mean, rstd, slope, dgamma, dbeta, accumulate, u, p_nstride, batch);
         return SPLICE_OK;
     }
     const int PB = plane_blocks(HW);
