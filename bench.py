@@ -18,6 +18,13 @@ Printed JSON (one line, rank 0) additionally carries
                  FLOPs per launch / live HIP-event duration of its launches inside the timed region
   cpu_baseline : the fp32 CPU oracle (a port of the reference-shaped loop: 6 ViT forwards + 3
                  backwards per step) timed on this host's cores on a bounded sample.
+
+Hygiene: every SPLICE_* environment variable that changes what the library launches is echoed under config.env; the run is
+REFUSED when one of them removes work or the default execution form (SPLICE_STEP_ABLATE, SPLICE_STEP_GRAPH=0,
+SPLICE_STEP_OVERLAP=0, a library built with make DEV=1) unless --allow-dev-env is given, and then the line says so.
+
+SPLICE_BENCH_STUB=<ms>: launcher self-test without a GPU (tests/test_bench_spawn_cpu.py) -- the engine is replaced by a fake
+whose step sleeps <ms>; metric / data are renamed so that such a line can never be mistaken for a measurement.
 """
 import argparse
 import ctypes as C
@@ -40,6 +47,68 @@ def host_threads():
     except Exception:
         pass
     return max(1, min(n, 64))
+
+
+def library_env():
+    """SPLICE_* variables the library reads (launch policies, debugging switches), minus bench.py's own plumbing."""
+    own = {"SPLICE_BENCH_SPAWNED", "SPLICE_BENCH_STUB", "SPLICE_BENCH_STUB_GPUS"}
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("SPLICE_") and k not in own}
+
+
+def dev_env_violations(dev_build):
+    """Settings under which a timed step is not the product's step (the bench must refuse them)."""
+    env, bad = library_env(), []
+    for k in ("SPLICE_STEP_ABLATE", "SPLICE_STEP_SYNC", "SPLICE_STEP_OWN_EAGER"):   # on when non-zero
+        if env.get(k, "0").strip() not in ("", "0"):
+            bad.append(f"{k}={env[k]}")
+    for k in ("SPLICE_STEP_GRAPH", "SPLICE_STEP_OVERLAP"):                         # the default execution form, off when 0
+        if env.get(k, "1").strip() == "0":
+            bad.append(f"{k}=0")
+    if dev_build:
+        bad.append("libsplice_hip.so built with make DEV=1 (timing-only switches compiled in)")
+    return bad
+
+
+class StubEngine:
+    """Launcher self-test (SPLICE_BENCH_STUB): stands where synthetic_engine's result stands, does no GPU work."""
+    def __init__(self, ms):
+        self.ms = float(ms)
+        self.step_idx = 0
+        self.cfg = {"entire_A_every": 75}
+
+    def step(self, A, B, E):
+        time.sleep(self.ms * 1e-3)
+        self.step_idx += 1
+
+    def losses(self, *_):
+        return {"loss": 0.0}
+
+
+def pin_worker(rank, world, dev_index):
+    """Host side of "within 5 % of linear" (SURVEY 8d): N workers share the node's cores -- each gets cores / N torch threads
+    and, when the topology is readable, the CPUs of its GPU's NUMA node.  Best effort; what was done is reported per rank."""
+    info = {"threads": None, "numa_node": None}
+    try:
+        import torch
+        n = max(1, host_threads() // max(1, world))
+        torch.set_num_threads(n)
+        info["threads"] = n
+        if world > 1 and torch.cuda.is_available():
+            pr = torch.cuda.get_device_properties(dev_index)
+            bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
+            if node >= 0:
+                cpus = set()
+                for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+                    lo, _, hi = part.partition("-")
+                    cpus.update(range(int(lo), int(hi or lo) + 1))
+                cpus &= os.sched_getaffinity(0)
+                if cpus:
+                    os.sched_setaffinity(0, cpus)
+                    info["numa_node"] = node
+    except Exception:
+        pass
+    return info
 
 
 def cpu_baseline(cfg, hw, seed, budget_s=25.0):
@@ -99,6 +168,8 @@ def spawn_workers(n, argv):
 def visible_gpu_count():
     """GPUs this process could use, WITHOUT initialising the HIP runtime in the parent (the workers own the devices)."""
     import subprocess
+    if os.environ.get("SPLICE_BENCH_STUB"):   # launcher self-test: pretend this many devices
+        return int(os.environ.get("SPLICE_BENCH_STUB_GPUS", "0"))
     code = "import torch; print(torch.cuda.device_count() if torch.cuda.is_available() else 0)"
     try:
         return int(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1])
@@ -106,17 +177,32 @@ def visible_gpu_count():
         return 0
 
 
-# live-timed kernel families (splice_prof_begin): name, launches cover `passes(P)` ViT passes, FLOPs per pass
-def kernel_families(T, D, heads, P):
+# live-timed kernel families (splice_prof_begin): id -> (name, peak key, algorithmic FLOPs of the family's launches per step)
+F32_MFMA_PEAK = 157.3     # TFLOP/s, exact-f32 MFMA = the f32 vector rate (MI355X_MICROARCH.md)
+BF16_MFMA_PEAK = 2500.0   # TFLOP/s dense
+HBM_PEAK = 8000.0         # GB/s
+
+
+def kernel_families(T, D, heads, P, size, depth=12):
+    """FLOPs are per host CALL of the family (one launch, or the launches of one call): a forward call covers 2 P passes
+    (one of the two concurrent forward chains), a backward call P passes.  SURVEY.md 8d per-unit figures."""
     hidden = 4 * D
+    g = (size / 224.0) ** 2
     return {
         # (tile / pipeline template arguments depend on the rows of a launch: <64,64,..,4> at one pair, <128,64,..,2> from 4 pairs on)
-        4: ("gemm_nt_kernel<BIAS|RESID|OUT_F32> fc2 forward", 2 * P, 2.0 * T * hidden * D),
-        1: ("gemm_nt_kernel<BIAS|GELU|OUT_BF> fc1 forward", 2 * P, 2.0 * T * hidden * D),
-        2: ("gemm_nt_kernel<BIAS|OUT_BF|OUT_T> qkv forward", 2 * P, 2.0 * T * 3 * D * D),
-        3: ("attn_fwd_kernel", 2 * P, 4.0 * T * T * D),
-        5: ("gemm_nt_kernel<OUT_F32> split-K dgrads (fc1^T and qkv^T, mean of both)", P, 2.0 * T * D * (hidden + 3 * D) / 2),
-        6: ("attn_bwd_kernel (merged, or dQ + dK/dV launches)", P, 10.0 * T * T * D),
+        4: ("gemm_nt_kernel<BIAS|RESID|OUT_F32> fc2 forward", "bf16", 2 * P * 2.0 * T * hidden * D),
+        1: ("gemm_nt_kernel<BIAS|GELU|OUT_BF> fc1 forward", "bf16", 2 * P * 2.0 * T * hidden * D),
+        2: ("gemm_nt_kernel<BIAS|OUT_BF|OUT_T> qkv forward", "bf16", 2 * P * 2.0 * T * 3 * D * D),
+        9: ("gemm_nt_kernel<BIAS|RESID|OUT_F32> proj forward", "bf16", 2 * P * 2.0 * T * D * D),
+        3: ("attn_fwd_kernel", "bf16", 2 * P * 4.0 * T * T * D),
+        5: ("gemm_nt_kernel<OUT_F32> split-K dgrads (fc1^T and qkv^T, mean of both)", "bf16", P * 2.0 * T * D * (hidden + 3 * D) / 2),
+        6: ("attn_bwd_kernel (merged, or dQ + dK/dV launches)", "bf16", P * 10.0 * T * T * D),
+        # generator: one call = splice_gen_forward (2.262 GFLOP per 224^2 image) or splice_gen_backward (dgrad + wgrad = 2 x forward);
+        # four calls per ordinary step (A plan, B plan; forward, backward) -> mean FLOPs per call = 1.5 x forward x P images
+        7: ("generator chain: conv_igemm / BatchNorm / upsample / conv_wgrad kernels of one splice_gen_forward or _backward call", "f32",
+            P * 1.5 * 2.2623e9 * g),
+        # key self-similarity: S* (upper tiles, 0.47 of T^2 D x 2), S + loss (same), dK = W K (2 T^2 D); two calls per step (target | loss + dK)
+        8: ("selfsim kernels (norms, S*, fused S / MSE / W, dK) per call", "bf16", P * (0.5 * 2.0 * T * T * D * 2 + 2.0 * T * T * D) / 2),
     }
 
 
@@ -165,6 +251,30 @@ def train_regime_leg(eng, A, B, steps=120):
             "regime": "random >= 95 % crops per step (new shapes: eager launches, bilinear Resize + adjoint), device augmentations, logging forward every 10 steps"}
 
 
+def stub_main(args, ms, world):
+    """Launcher self-test (no GPU): the same rendezvous, barrier, max-over-ranks timing and JSON assembly as the real run,
+    around an engine whose step sleeps.  The line is labelled so it cannot pass for a measurement."""
+    from splice_amd.dist import Replicas, aggregate_throughput
+    rep = Replicas(backend="gloo", device=None)
+    host = pin_worker(rep.local_rank, world, 0)
+    eng = StubEngine(ms * (1.0 + 0.5 * rep.rank))   # rank r is slower: the max over ranks must show it
+    elapsed = time_steps(eng, None, None, args.steps, args.warmup, rep.barrier)
+    per_rank = rep.gather_floats(elapsed)
+    hip_vis = os.environ.get("HIP_VISIBLE_DEVICES", "")
+    # every rank's device binding, gathered through the same process group (as floats: device ordinals)
+    devs = rep.gather_floats(float(hip_vis.split(",")[0]) if hip_vis.split(",")[0].strip().isdigit() else -1.0)
+    elapsed = rep.max_over_ranks(elapsed)
+    if rep.rank == 0:
+        value = aggregate_throughput(args.steps, world, elapsed)
+        print(json.dumps({"metric": "stub_steps_per_sec", "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "none", "data": "stub (launcher self-test: no GPU work, SPLICE_BENCH_STUB)",
+                          "config": {"workload": f"STUB: sleep {ms} ms per step (+50 % per rank)", "gpus": world, "per_rank_steps_per_s": [round(args.steps / t, 2) for t in per_rank],
+                                     "per_rank_device": [int(d) for d in devs], "host": host, "env": library_env()},
+                          "roofline": None, "cpu_baseline": None}), flush=True)
+    rep.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,29 +291,37 @@ def main():
                                                                   "all the losses read besides the keys)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-regime", action="store_true", help="skip the train_model-shaped leg (random crops + augmentations + logging)")
-    ap.add_argument("--prof-kernels", default="4,5,3,6", help="kernel families timed live with HIP events for the roofline leg ('' = off): 4 fc2 fwd, 1 fc1 fwd, 2 qkv fwd, 3 attention fwd, 5 split-K dgrads, 6 attention bwd")
+    ap.add_argument("--prof-kernels", default="4,5,3,6,7,8", help="kernel families timed live for the roofline leg ('' = off): 4 fc2 fwd, 1 fc1 fwd, 2 qkv fwd, 9 proj fwd, "
+                                                                  "3 attention fwd, 5 split-K dgrads, 6 attention bwd, 7 generator chain, 8 key self-similarity")
+    ap.add_argument("--allow-dev-env", action="store_true", help="run although a debugging / work-skipping SPLICE_* switch is set (the JSON line then carries config.dev_env)")
     args = ap.parse_args()
+    stub_ms = os.environ.get("SPLICE_BENCH_STUB")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_workers(args.gpus, sys.argv[1:])
 
     import torch
-    from splice_amd import _lib
-    from splice_amd.engine import synthetic_engine
-
     from splice_amd.dist import Replicas, aggregate_throughput
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
                          f"(or without a launcher: bench.py spawns its own workers)")
+    if stub_ms:
+        return stub_main(args, float(stub_ms), world)
+    from splice_amd import _lib
+    from splice_amd.engine import synthetic_engine
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    bad = dev_env_violations(bool(_lib.lib().splice_dev_switches()))
+    if bad and not args.allow_dev_env:
+        raise SystemExit("bench.py: refusing to time a step under " + "; ".join(bad) + " (debugging / work-skipping switches; --allow-dev-env overrides and marks the line)")
     # self-spawned workers see exactly one GPU each (HIP_VISIBLE_DEVICES); torchrun workers see all and pick LOCAL_RANK
     dev_index = 0 if os.environ.get("SPLICE_BENCH_SPAWNED") == "1" else local_rank
     if dev_index >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {local_rank} has no GPU (visible devices: {torch.cuda.device_count()})")
     torch.cuda.set_device(dev_index)
     dev = f"cuda:{dev_index}"
+    host = pin_worker(local_rank, world, dev_index)
     # The replicas exchange NO data (independent pairs): the process group exists only for the start/stop barrier and the
     # max-over-ranks of one float, so it runs over gloo on the host -- an RCCL communicator would add an xGMI bootstrap that
     # can only hurt (north_star: "no RCCL required").
@@ -238,24 +356,18 @@ def main():
     # replay), so the SAME steps continue for short instrumented stretches with every launch of one kernel family
     # bracketed by HIP events on its own stream (eager launches; the kernels themselves are identical).
     prof = {}
-    ev_overhead_ms = 0.0
     fam_ids = [int(x) for x in args.prof_kernels.split(",") if x.strip()] if rank == 0 else []
-    if fam_ids:
-        # an event pair costs time by itself: calibrate on empty pairs (same stream) and subtract
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
-        for a_, b_ in evs:
-            a_.record(); b_.record()
+    for fam in fam_ids:
+        ms, calls, kernels = C.c_float(0), C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib().splice_prof_begin(fam))
+        nprof = min(K, 20)
+        for _ in range(nprof):
+            eng.step(A, B, A)
         torch.cuda.synchronize()
-        ev_overhead_ms = sorted(a_.elapsed_time(b_) for a_, b_ in evs)[len(evs) // 2]
-        for fam in fam_ids:
-            ms, n = C.c_float(0), C.c_int(0)
-            _lib.check(_lib.lib().splice_prof_begin(fam))
-            for _ in range(min(K, 20)):
-                eng.step(A, B, A)
-            torch.cuda.synchronize()
-            _lib.check(_lib.lib().splice_prof_end(C.byref(ms), C.byref(n)))
-            if n.value:
-                prof[fam] = (ms.value, n.value, min(K, 20))
+        _lib.check(_lib.lib().splice_prof_end_ex(C.byref(ms), C.byref(calls), C.byref(kernels)))
+        if calls.value:
+            n_ent = sum(1 for st_ in range(eng.step_idx - nprof, eng.step_idx) if st_ % eng.cfg["entire_A_every"] == 0)
+            prof[fam] = (ms.value, calls.value, kernels.value, nprof, n_ent)
     per_rank_elapsed = rep.gather_floats(elapsed)
     elapsed = rep.max_over_ranks(elapsed)
     T = eng.ctx_g.T if not scales else [e.ctx_g.T for e in eng.engines]
@@ -285,7 +397,7 @@ def main():
         rep.close()
         return
 
-    fams = kernel_families(T if not scales else T[0], D, eng.vit.heads, P)
+    fams = kernel_families(T if not scales else T[0], D, eng.vit.heads, P, args.size)
     roofs = []
     traffic_file = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     static_traffic = {}
@@ -294,25 +406,39 @@ def main():
             static_traffic = json.load(open(traffic_file)).get(f"P{P}", {})
         except Exception:
             static_traffic = {}
-    for fam, (tot_ms, n, steps) in prof.items():
-        kname, passes, flops_per_pass = fams[fam]
-        flops = flops_per_pass * passes
-        avg_ms = max(tot_ms / n - ev_overhead_ms, 1e-6)
+    for fam, (tot_ms, calls, kernels, steps, n_ent) in prof.items():
+        kname, cls, flops = fams[fam]
+        avg_ms = max(tot_ms / calls, 1e-6)
         ach = flops / (avg_ms * 1e-3) / 1e12
+        peak = BF16_MFMA_PEAK if cls == "bf16" else F32_MFMA_PEAK
         traffic = static_traffic.get(str(fam))
-        roofs.append({"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                      "frac": round(ach / 2500.0, 4), "traffic": traffic,
-                      "traffic_source": None if traffic is None else "static: profiles/roofline_traffic.json (FETCH_SIZE x2 + WRITE_SIZE from separate --pmc passes of tools/pmc_traffic.sh on this workload, round 2; not re-measured by this command)",
-                      "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": round(n / steps, 1),
-                      "share_of_step_ms": round((tot_ms - n * ev_overhead_ms) / steps, 4), "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2)})
+        r = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+             "frac": round(ach / peak, 4), "traffic": traffic,
+             "traffic_source": None if traffic is None else "static: profiles/roofline_traffic.json (FETCH_SIZE x2 + WRITE_SIZE from separate --pmc passes of tools/pmc_traffic.sh on this workload; not re-measured by this command)",
+             "avg_launch_us": round(avg_ms * 1e3, 2), "calls_per_step": round(calls / steps, 1), "kernels_per_step": round(kernels / steps, 1),
+             "share_of_step_ms": round(tot_ms / steps, 4)}
+        if n_ent:
+            r["note_entire"] = f"{n_ent} of the {steps} instrumented steps ran the entire-image branch (its launches are in the averages)"
+        if fam == 7:   # also against the HBM roofline: SURVEY 8d floor of 11.54 M fp32 activation elements per image forward, backward 2x
+            g = (args.size / 224.0) ** 2
+            bytes_call = P * 1.5 * 11.54e6 * 4 * g
+            r["hbm"] = {"bound": "hbm", "algorithmic_bytes_per_call": round(bytes_call), "achieved": round(bytes_call / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK,
+                        "unit": "GB/s", "frac": round(bytes_call / (avg_ms * 1e-3) / 1e9 / HBM_PEAK, 4)}
+        roofs.append(r)
     roofs.sort(key=lambda r: -r["share_of_step_ms"])
     roof = None
     if roofs:
-        roof = dict(roofs[0])
+        # dominant = the single KERNEL family with the largest total time per step (the generator entry is a chain of ~70 kernels
+        # per call and is listed with the others; `furthest_below_roofline` names the family with the lowest fraction)
+        singles = [r for r in roofs if not r["kernel"].startswith("generator chain") and not r["kernel"].startswith("selfsim kernels")] or roofs
+        roof = dict(singles[0])
         roof["note"] = ("dominant = the live-timed kernel family with the largest total time per step; achieved = algorithmic FLOPs of one "
-                        "launch / mean HIP-event duration of its launches, measured on the launch stream over an instrumented continuation "
-                        "of the timed steps (the timed region itself replays hipGraphs), minus the median cost of an empty event pair")
-        roof["other_kernels"] = roofs[1:]
+                        "call / mean kernel duration of its launches; the duration is the kernel's own begin / end time stamp pair "
+                        "(hipExtLaunchKernelGGL start / stop events on the launch stream, nothing subtracted), taken over an instrumented "
+                        "continuation of the timed steps (the timed region itself replays hipGraphs)")
+        roof["other_kernels"] = [r for r in roofs if r is not singles[0]]
+        worst = min(roofs, key=lambda r: r["frac"])
+        roof["furthest_below_roofline"] = {"kernel": worst["kernel"], "frac": worst["frac"], "share_of_step_ms": worst["share_of_step_ms"]}
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         try:
@@ -334,9 +460,12 @@ def main():
                                                                                     "pairs_per_hour_at_2000_steps": round(v * k * 3600 / 2000, 1)})
                                                    for k, v in sorted(sweep.items())},
                    "train_model_regime": train_leg,
-                   "generator_dtype": "f32", "last_loss": round(losses["loss"], 5)},
+                   "generator_dtype": "f32", "last_loss": round(losses["loss"], 5),
+                   "env": library_env(), "host": host},
         "roofline": roof, "cpu_baseline": cpu,
     }
+    if bad:
+        out["config"]["dev_env"] = bad   # --allow-dev-env: NOT a measurement of the product's step
     print(json.dumps(out), flush=True)
     rep.close()
 

@@ -37,6 +37,9 @@ typedef void* splice_stream_t;
 #define SPLICE_ERR_NOMEM -4
 
 int splice_version(void);
+/* 1 when the library was built with the timing-only experiment switches (make DEV=1: SPLICE_STEP_ABLATE skips work, results
+ * are garbage); 0 for the product build.  bench.py refuses to run on a 1. */
+int splice_dev_switches(void);
 const char* splice_last_error(void);
 
 /* ------------------------------------------------------------------ op level: ViT GEMMs
@@ -258,11 +261,14 @@ int splice_gen_running_stats_update(void* const* plans, int n_plans, float* runn
 int splice_adam_step(float* params, float* grads, float* m, float* v, long long n, float lr, float beta1,
                      float beta2, float eps, int step, int zero_grad, splice_stream_t stream);
 
-/* live HIP-event timing of one kernel family on its launch stream (bench.py roofline leg):
+/* live timing of one kernel family (bench.py roofline leg, prof.hip): while a family is armed its kernels are launched with
+ * a start / stop event pair each (hipExtLaunchKernelGGL: the kernel's own begin / end time stamps, as rocprofv3 reports them).
  * which 1 = fc1 GEMM fwd, 2 = qkv GEMM fwd (layers 0..depth-2), 3 = attention fwd, 4 = fc2 GEMM fwd, 5 = split-K dgrad GEMMs
- * (fc1^T, qkv^T), 6 = attention bwd */
+ * (fc1^T, qkv^T), 6 = attention bwd, 7 = generator (all kernels of splice_gen_forward* / splice_gen_backward), 8 = key
+ * self-similarity loss kernels, 9 = proj GEMM fwd.  end: summed kernel time, host calls of the family, kernels launched. */
 int splice_prof_begin(int which);
 int splice_prof_end(float* total_ms, int* launches);
+int splice_prof_end_ex(float* total_ms, int* calls, int* kernels);
 int splice_prof_active(void);
 int splice_vit_ctx_dims(void* ctx, int* B, int* H, int* W, int* D, int* depth, int* heads, int* patch);
 int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams);

@@ -33,6 +33,7 @@ REF = "/root/reference"
 sys.path.insert(0, REPO)
 
 from oracle import dino_vit, losses as olosses  # noqa: E402
+from oracle.fixtures import INVERSION_NET, sample, stats  # noqa: E402
 from splice_amd import synth  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
@@ -102,18 +103,6 @@ def install_hub_stub():
     torch.hub.load = fake_load
 
 
-def sample(t, n=257):
-    """Deterministic strided subsample of a tensor (keeps fixtures small)."""
-    f = t.detach().reshape(-1)
-    step = max(1, f.numel() // n)
-    return f[::step][:n].numpy().copy()
-
-
-def stats(t):
-    t = t.detach().double()
-    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], np.float64)
-
-
 # --------------------------------------------------------------------------- fixtures
 def golden_extractor(ref_extractor_mod):
     out = {}
@@ -179,11 +168,6 @@ def golden_generator(ref_networks_mod):
     print("generator.npz", len(out))
 
 
-INVERSION_NET = dict(num_channels_down=[16, 32, 64, 128, 128, 128], num_channels_up=[16, 32, 64, 128, 128, 128],
-                     num_channels_skip=[4, 4, 4, 4, 4, 4], filter_size_down=[7, 7, 5, 5, 3, 3], filter_size_up=[7, 7, 5, 5, 3, 3],
-                     downsample_mode='stride', pad='reflection')
-
-
 def golden_inversion_net():
     """The 6-scale reflection-padded skip() of inversion.py:21-25 (reference module), parameters seeded BY POSITION in
     parameters() order (conv weights N(0, 0.05), everything else 1 + N(0, 0.05) / N(0, 0.05)), forward + backward."""
@@ -218,6 +202,24 @@ def golden_define_g_init(ref_networks_mod):
         out[f"{init_type}/{seed}/samples"] = np.stack([np.resize(sample(p, 8), 8) for p in net.parameters()])
     np.savez_compressed(os.path.join(OUT, "define_g_init.npz"), **out)
     print("define_g_init.npz", len(out))
+
+
+def golden_skip_constructor_init():
+    """``torch.manual_seed(s); skip(...)`` as the reference leaves it WITHOUT init_weights (inversion.py:21-25 trains from this
+    state): PyTorch's constructor initialisation of every nn.Conv2d / nn.BatchNorm2d, in the reference's construction order.
+    Per-tensor (sum, |sum|, sum sq) + a strided sample, for the inversion net (32 noise channels) and the default arguments."""
+    from models.unet.skip import skip as ref_skip
+    out = {}
+    for tag, seed, build in (("inversion", 2, lambda: ref_skip(32, 3, **INVERSION_NET)), ("inversion", 9, lambda: ref_skip(32, 3, **INVERSION_NET)),
+                             ("default", 4, lambda: ref_skip())):
+        torch.manual_seed(seed)
+        net = build()
+        ps = list(net.parameters())
+        out[f"{tag}/{seed}/stats"] = np.stack([stats(p) for p in ps])
+        out[f"{tag}/{seed}/samples"] = np.stack([np.resize(sample(p, 8), 8) for p in ps])
+        out[f"{tag}/{seed}/next_draw"] = torch.rand(4).numpy()   # where the global generator stands afterwards
+    np.savez_compressed(os.path.join(OUT, "skip_constructor_init.npz"), **out)
+    print("skip_constructor_init.npz", len(out))
 
 
 def run_reference_loop(cfg, A, B, n_steps, ref, A_entire=None, record_grads_at=()):
@@ -322,6 +324,8 @@ def main():
         golden_inversion_net()
     if not only or "define_g_init" in only:
         golden_define_g_init(ref_networks)
+    if not only or "skip_constructor_init" in only:
+        golden_skip_constructor_init()
 
 
 if __name__ == "__main__":

@@ -53,6 +53,7 @@ _vp, _i, _f, _sz, _u = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint
 
 _SIGNATURES = {
     "splice_version": ([], C.c_int),
+    "splice_dev_switches": ([], C.c_int),
     "splice_last_error": ([], C.c_char_p),
     "splice_gemm_nt_bf16": ([_u, _vp, _i, _vp, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _vp], _i),
     "splice_gemm_nt_fp8": ([_u, _vp, _i, _vp, _i, _i, _i, _i, C.POINTER(GemmEpilogue), _vp], _i),
@@ -108,6 +109,7 @@ _SIGNATURES = {
     "splice_adam_step": ([_vp, _vp, _vp, _vp, C.c_longlong, _f, _f, _f, _f, _i, _i, _vp], _i),
     "splice_prof_begin": ([_i], _i),
     "splice_prof_end": ([C.POINTER(_f), C.POINTER(_i)], _i),
+    "splice_prof_end_ex": ([C.POINTER(_f), C.POINTER(_i), C.POINTER(_i)], _i),
     "splice_prof_active": ([], _i),
     "splice_step_use_graph": ([_vp, _i], _i),
     "splice_step_use_overlap": ([_vp, _i], _i),

@@ -102,13 +102,14 @@ def _write_result(root, name, res):
     os.replace(tmp, os.path.join(pair_dir, "out", "result.json"))
 
 
-def _worker(gpu, visible_id, root, names, indices, runner, overrides, pin_gpu, pairs_per_gpu=1):
+def _worker(gpu, visible_id, root, names, indices, runner, overrides, pin_gpu, pairs_per_gpu=1, group_runner="splice_amd.batch:train_group_runner"):
     if pin_gpu:   # must happen before the HIP runtime starts in this process
         os.environ["HIP_VISIBLE_DEVICES"] = str(visible_id)
         os.environ.pop("CUDA_VISIBLE_DEVICES", None)
     groups, todo = group_equal_sizes(indices, [_image_sizes(os.path.join(root, names[i])) for i in indices], pairs_per_gpu) if pairs_per_gpu > 1 else ([], list(indices))
+    run_group = _resolve(group_runner)
     for grp in groups:   # one MultiPairEngine per group
-        for i, res in zip(grp, train_group_runner([os.path.join(root, names[i]) for i in grp], dict(overrides))):
+        for i, res in zip(grp, run_group([os.path.join(root, names[i]) for i in grp], dict(overrides))):
             _write_result(root, names[i], dict(res, pair=names[i], index=i, gpu=gpu))
     run = _resolve(runner)
     for i in todo:
@@ -116,14 +117,27 @@ def _worker(gpu, visible_id, root, names, indices, runner, overrides, pin_gpu, p
         _write_result(root, names[i], dict(res, pair=names[i], index=i, gpu=gpu))
 
 
-def run_batch(root, n_gpus=1, overrides=None, runner="splice_amd.batch:train_runner", pin_gpu=True, visible_ids=None, pairs_per_gpu=1):
+def run_batch(root, n_gpus=1, overrides=None, runner="splice_amd.batch:train_runner", pin_gpu=True, visible_ids=None, pairs_per_gpu=1,
+              group_runner=None):
     """Optimise every pair under ``root`` on ``n_gpus`` worker processes; returns the per-pair result dicts in pair order.
 
     ``runner``: ``"module:function"`` (or a picklable callable) ``(pair_dir, overrides) -> dict``; the default trains the
-    pair.  ``pairs_per_gpu`` > 1: a worker optimises up to that many of ITS pairs in the same launches (``train_pairs``;
-    pairs of equal image sizes only) -- 1.6x the pairs/hr of one pair at a time at 8 pairs per GPU.  ``pin_gpu=False`` leaves device visibility alone (CPU tests).  A worker that dies takes the batch down with a
-    RuntimeError naming its pairs; finished pairs keep their ``result.json``."""
+    pair.  ``pairs_per_gpu`` > 1: a worker optimises up to that many of ITS pairs in the same launches (pairs of equal image
+    sizes only; 1.6x the pairs/hr of one pair at a time at 8 pairs per GPU) through ``group_runner``
+    ``(pair_dirs, overrides) -> [dict per pair]`` (default: ``train_group_runner`` = ``train_pairs``); pairs that fill no group
+    go through ``runner``.  A custom ``runner`` without a matching ``group_runner`` is rejected when ``pairs_per_gpu`` > 1 --
+    grouped pairs would otherwise silently run the default training.  Two things differ from K single runs in a group: the
+    pairs of a group share one crop SIZE per step (``PairBatchFeed``: positions and augmentations stay per pair), so under
+    random crops a pair's RNG stream is not the one of its single run (with deterministic full crops the results are
+    bit-identical, tests/test_batch_gpu.py); and "the result does not depend on N" holds for the grouping, which is per worker.
+    ``pin_gpu=False`` leaves device visibility alone (CPU tests).  A worker that dies takes the batch down with a RuntimeError
+    naming its pairs; finished pairs keep their ``result.json``."""
     import multiprocessing as mp
+    if int(pairs_per_gpu) > 1 and group_runner is None:
+        if runner != "splice_amd.batch:train_runner":
+            raise ValueError("run_batch: pairs_per_gpu > 1 with a custom runner needs a group_runner (pair_dirs, overrides) -> [dict per pair]")
+        group_runner = "splice_amd.batch:train_group_runner"
+    group_runner = group_runner or "splice_amd.batch:train_group_runner"
     names = discover_pairs(root)
     if not names:
         raise ValueError(f"{root}: no <pair>/A + <pair>/B directories found")
@@ -135,7 +149,7 @@ def run_batch(root, n_gpus=1, overrides=None, runner="splice_amd.batch:train_run
     if pin_gpu and len(visible_ids) < n_gpus:
         raise ValueError(f"run_batch: {n_gpus} workers requested, {len(visible_ids)} visible GPUs")
     ctx = mp.get_context("spawn")   # fresh interpreters: the HIP runtime must not be inherited through fork
-    procs = [ctx.Process(target=_worker, args=(g, visible_ids[g] if pin_gpu else g, root, names, plan[g], runner, dict(overrides or {}), pin_gpu, int(pairs_per_gpu)))
+    procs = [ctx.Process(target=_worker, args=(g, visible_ids[g] if pin_gpu else g, root, names, plan[g], runner, dict(overrides or {}), pin_gpu, int(pairs_per_gpu), group_runner))
              for g in range(n_gpus)]
     for p in procs:
         p.start()

@@ -602,30 +602,30 @@ int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
     static const long qb2_tasks = getenv("SPLICE_ATTN_QB2_TASKS") ? atol(getenv("SPLICE_ATTN_QB2_TASKS")) : 3600;
     const int qb = g_attn_variant ? g_attn_variant : (tasks > qb2_tasks ? 2 : 1);
     const int nx = cdiv(a->Tld, 64 * qb);
-    if (qb == 2) hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3(nx * a->H * a->B), dim3(256), 0, s, *a, nx);
-    else hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(nx * a->H * a->B), dim3(256), 0, s, *a, nx);
+    if (qb == 2) SPLICE_LAUNCH(attn_fwd_kernel<2>, dim3(nx * a->H * a->B), dim3(256), 0, s, *a, nx);
+    else SPLICE_LAUNCH(attn_fwd_kernel<1>, dim3(nx * a->H * a->B), dim3(256), 0, s, *a, nx);
     return SPLICE_OK;
 }
 
 int attn_bwd_launch(const AttnArgs* a, hipStream_t s) {
     if (a->Tld % 32 || a->D % 64 || a->D / 64 != a->H || a->ldt % 4) return SPLICE_ERR_ARG;
     const int nx = cdiv(a->Tld, 64);
-    if (!a->delta_ready) hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(a->B * a->Tld * a->H, 256)), dim3(256), 0, s, *a);
+    if (!a->delta_ready) SPLICE_LAUNCH(attn_delta_kernel, dim3(cdiv(a->B * a->Tld * a->H, 256)), dim3(256), 0, s, *a);
     const int n = nx * a->H * a->B;
     // the two halves in one launch while the chip is not full anyway (a dependent launch costs more than the dQ half's
     // lower occupancy under the dK/dV half's LDS footprint); two launches once every CU has several workgroups
     static const int merge_max = getenv("SPLICE_ATTN_MERGE_MAX") ? atoi(getenv("SPLICE_ATTN_MERGE_MAX")) : 768;
     if (2 * n <= merge_max) {
-        hipLaunchKernelGGL(attn_bwd_kernel, dim3(2 * n), dim3(256), 0, s, *a, nx);
+        SPLICE_LAUNCH(attn_bwd_kernel, dim3(2 * n), dim3(256), 0, s, *a, nx);
     } else {
-        hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(n), dim3(256), 0, s, *a, nx);
-        hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3(n), dim3(256), 0, s, *a, nx);
+        SPLICE_LAUNCH(attn_bwd_q_kernel, dim3(n), dim3(256), 0, s, *a, nx);
+        SPLICE_LAUNCH(attn_bwd_kv_kernel, dim3(n), dim3(256), 0, s, *a, nx);
     }
     return SPLICE_OK;
 }
 
 int attn_probs_launch(const AttnArgs* a, float* probs, hipStream_t s) {
     dim3 grid(a->T, a->H, a->B);
-    hipLaunchKernelGGL(attn_probs_kernel, grid, dim3(128), 0, s, *a, probs);
+    SPLICE_LAUNCH(attn_probs_kernel, grid, dim3(128), 0, s, *a, probs);
     return SPLICE_OK;
 }

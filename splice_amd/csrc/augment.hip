@@ -135,19 +135,19 @@ int augment_structure_launch(const float* img, float* out, float* scratch, int H
     // destination juggling so that the final result lands in `out`: stages write tmp / out alternately
     const int n_stage = 1 + (cpos >= 0 ? 1 : 0) + (blur ? 1 : 0);
     float* dst = (n_stage & 1) ? out : tmp;
-    hipLaunchKernelGGL(aug_ops_kernel, dim3(grid), dim3(256), 0, s, img, dst, H, W, flip, first, (const float*)nullptr, 0,
+    SPLICE_LAUNCH(aug_ops_kernel, dim3(grid), dim3(256), 0, s, img, dst, H, W, flip, first, (const float*)nullptr, 0,
                        cpos >= 0 ? part : (float*)nullptr);
     const float* cur = dst;
     if (cpos >= 0) {
         dst = cur == out ? tmp : out;
-        hipLaunchKernelGGL(aug_ops_kernel, dim3(grid), dim3(256), 0, s, cur, dst, H, W, 0, second, (const float*)part, grid, (float*)nullptr);
+        SPLICE_LAUNCH(aug_ops_kernel, dim3(grid), dim3(256), 0, s, cur, dst, H, W, 0, second, (const float*)part, grid, (float*)nullptr);
         cur = dst;
     }
     if (blur) {
         const float e = expf(-0.5f / (blur_sigma * blur_sigma));
         const float wc = 1.0f / (1.0f + 2.0f * e), ws = e / (1.0f + 2.0f * e);
         dst = cur == out ? tmp : out;
-        hipLaunchKernelGGL(aug_blur3_kernel, dim3(cdiv(3 * HW, 256)), dim3(256), 0, s, cur, dst, H, W, wc, ws);
+        SPLICE_LAUNCH(aug_blur3_kernel, dim3(cdiv(3 * HW, 256)), dim3(256), 0, s, cur, dst, H, W, wc, ws);
         cur = dst;
     }
     return cur == out ? SPLICE_OK : SPLICE_ERR_STATE;

@@ -31,6 +31,13 @@ static int finish(int rc, const char* what) {
 extern "C" {
 
 int splice_version(void) { return 100; }
+int splice_dev_switches(void) {
+#ifdef SPLICE_DEV_SWITCHES
+    return 1;
+#else
+    return 0;
+#endif
+}
 const char* splice_last_error(void) { return g_err; }
 
 int splice_gemm_nt_bf16(unsigned flags, const splice_bf16* A, int lda, const splice_bf16* B, int ldb, int M, int N, int K,

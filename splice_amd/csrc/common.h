@@ -1,10 +1,31 @@
 // Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.  wave = 64 lanes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "splice_hip.h"
 
 typedef uint16_t bf16_t;  // raw bf16 storage
+
+// ---- every kernel launch of the library goes through SPLICE_LAUNCH.  While bench.py's roofline leg has a kernel family
+// armed (splice_prof_begin) and one of its host calls is open (SpliceProfScope), the launch goes out as hipExtLaunchKernelGGL
+// with a start / stop event pair of its own: the pair carries the kernel's begin and end time stamps (what rocprofv3's
+// kernel trace reports), not the cost of two event records queued around it.  Otherwise: a plain launch.
+bool splice_prof_take(hipEvent_t* start, hipEvent_t* stop);
+extern int g_splice_prof_open;   // > 0: a scope of the armed family is open (prof.hip)
+struct SpliceProfScope {
+    bool on;
+    explicit SpliceProfScope(int which);
+    ~SpliceProfScope();
+};
+#define SPLICE_LAUNCH(kernel, grid, block, lds, stream, ...)                                                       \
+    do {                                                                                                           \
+        hipEvent_t pa_, pb_;                                                                                       \
+        if (g_splice_prof_open > 0 && splice_prof_take(&pa_, &pb_))                                                \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, pa_, pb_, 0, __VA_ARGS__);                     \
+        else                                                                                                       \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                     \
+    } while (0)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;

@@ -719,5 +719,5 @@ static inline void launch_gemm_nt(hipStream_t s, const bf16_t* A, int lda, const
             done_mask.fetch_or(bit, std::memory_order_relaxed);
         }
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, FLAGS, NS, FP8>), dim3(grid), dim3(256), lds, s, A, lda, B, ldb, M, N, K, e, gm, ksplit);
+    SPLICE_LAUNCH((gemm_nt_kernel<BM, BN, FLAGS, NS, FP8>), dim3(grid), dim3(256), lds, s, A, lda, B, ldb, M, N, K, e, gm, ksplit);
 }

@@ -539,6 +539,7 @@ static int gen_forward_impl(void* plan, const float* params, const float* x, flo
     SpliceGenPlan* p = (SpliceGenPlan*)plan;
     if (!p || !params || !x || !y) return SPLICE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    SpliceProfScope prof_scope(7);
     if (borrowed) {
         p->x_in = x;
     } else {
@@ -608,6 +609,7 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
         return SPLICE_ERR_STATE;
     }
     hipStream_t s = (hipStream_t)stream;
+    SpliceProfScope prof_scope(7);
     const int OC = p->gen->arch.out_channels, U0 = p->gen->arch.up[0];
     const size_t npix = (size_t)p->N * OC * p->H * p->W;
     p->red.count = 0;

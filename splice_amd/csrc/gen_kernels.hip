@@ -254,20 +254,20 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
     // 8-wave workgroups while the chip holds at most ~2 workgroups per CU (the serial K walk is the run time then)
     constexpr bool CAN8 = KS == 3 && CK == 8;
     if constexpr (KS >= 5) {   // 5x5 / 7x7 (the inversion experiment's generator): one fragment per workgroup, 4 waves
-        hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1, CK, 1>), dim3(mt, cdiv(a.Cout, 16) * ksplit, a.N), dim3(256), 0, s, a);
+        SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 1, CK, 1>), dim3(mt, cdiv(a.Cout, 16) * ksplit, a.N), dim3(256), 0, s, a);
     } else {
         // (K tile of 72: 9 steps per wave group; the A tile is big enough for the exchange)
         const bool ng2 = CAN8 && (long)mt * nt * ksplit * npol <= 2048 && cdiv(a.Cin, CK) >= 2;
         if (ng2) {
             if constexpr (CAN8) {
-                if (fn == 1) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1, CK, 2>), grid, dim3(512), 0, s, a);
-                else if (fn == 2) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 2, CK, 2>), grid, dim3(512), 0, s, a);
-                else hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 4, CK, 2>), grid, dim3(512), 0, s, a);
+                if (fn == 1) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 1, CK, 2>), grid, dim3(512), 0, s, a);
+                else if (fn == 2) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 2, CK, 2>), grid, dim3(512), 0, s, a);
+                else SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 4, CK, 2>), grid, dim3(512), 0, s, a);
             }
         } else {
-            if (fn == 1) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 1, CK, 1>), grid, dim3(256), 0, s, a);
-            else if (fn == 2) hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 2, CK, 1>), grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((conv_igemm_kernel<KS, TR, 4, CK, 1>), grid, dim3(256), 0, s, a);
+            if (fn == 1) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 1, CK, 1>), grid, dim3(256), 0, s, a);
+            else if (fn == 2) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 2, CK, 1>), grid, dim3(256), 0, s, a);
+            else SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 4, CK, 1>), grid, dim3(256), 0, s, a);
         }
     }
     if (ksplit_out) *ksplit_out = ksplit;
@@ -275,7 +275,7 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
         const size_t per = (size_t)a.N * a.Cout * HWo;
         size_t g = (per + 255) / 256;
         if (g > 1024) g = 1024;
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, a, ksplit);
+        SPLICE_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, a, ksplit);
     }
 }
 
@@ -338,7 +338,7 @@ int conv_reflect_dgrad_launch(ConvArgs a, float* pad_scratch, hipStream_t s) {
     if (rc != SPLICE_OK) return rc;
     int gx = cdiv(H * W, 256);
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(reflect_fold_kernel, dim3(gx, a.Cout, a.N), dim3(256), 0, s, pad_scratch, out, out_ns, out_cs, a.Cout, H, W, p, acc);
+    SPLICE_LAUNCH(reflect_fold_kernel, dim3(gx, a.Cout, a.N), dim3(256), 0, s, pad_scratch, out, out_ns, out_cs, a.Cout, H, W, p, acc);
     return SPLICE_OK;
 }
 
@@ -587,14 +587,14 @@ int conv_wgrad_add(WgradBatchPair* pair, WgradArgs a, int* chunks_out) {
     return SPLICE_OK;
 }
 int conv_wgrad_batched_launch(const WgradBatchPair& p, hipStream_t s) {
-    if (p.big.count > 0) hipLaunchKernelGGL(conv_wgrad_batched_kernel<true>, dim3((unsigned)p.big.total_wgs), dim3(256), 0, s, p.big);
-    if (p.small.count > 0) hipLaunchKernelGGL(conv_wgrad_batched_kernel<false>, dim3((unsigned)p.small.total_wgs), dim3(256), 0, s, p.small);
+    if (p.big.count > 0) SPLICE_LAUNCH(conv_wgrad_batched_kernel<true>, dim3((unsigned)p.big.total_wgs), dim3(256), 0, s, p.big);
+    if (p.small.count > 0) SPLICE_LAUNCH(conv_wgrad_batched_kernel<false>, dim3((unsigned)p.small.total_wgs), dim3(256), 0, s, p.small);
     return SPLICE_OK;
 }
 
 int wgrad_reduce_all_launch(const WgradReduceAll& d, const float* ws, float* grads, int accumulate, hipStream_t s, int n_img, size_t p_nstride) {
     if (d.count < 1 || d.count > WGRAD_MAX_LAYERS) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(wgrad_reduce_all_kernel, dim3((unsigned)((d.total + 255) / 256), p_nstride ? n_img : 1), dim3(256), 0, s, d, ws, grads, accumulate,
+    SPLICE_LAUNCH(wgrad_reduce_all_kernel, dim3((unsigned)((d.total + 255) / 256), p_nstride ? n_img : 1), dim3(256), 0, s, d, ws, grads, accumulate,
                        n_img, p_nstride);
     return SPLICE_OK;
 }
@@ -1154,9 +1154,9 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
 // bigger tile only ever added zeros)
 #define BN_SMALL_DISPATCH(HW_, KERNEL, GRID, STREAM, ...)                                                         \
     do {                                                                                                          \
-        if ((HW_) <= 256) hipLaunchKernelGGL(KERNEL<1>, GRID, dim3(256), 0, STREAM, __VA_ARGS__);                  \
-        else if ((HW_) <= 1024) hipLaunchKernelGGL(KERNEL<4>, GRID, dim3(256), 0, STREAM, __VA_ARGS__);            \
-        else hipLaunchKernelGGL(KERNEL<16>, GRID, dim3(256), 0, STREAM, __VA_ARGS__);                              \
+        if ((HW_) <= 256) SPLICE_LAUNCH(KERNEL<1>, GRID, dim3(256), 0, STREAM, __VA_ARGS__);                  \
+        else if ((HW_) <= 1024) SPLICE_LAUNCH(KERNEL<4>, GRID, dim3(256), 0, STREAM, __VA_ARGS__);            \
+        else SPLICE_LAUNCH(KERNEL<16>, GRID, dim3(256), 0, STREAM, __VA_ARGS__);                              \
     } while (0)
 // 512-pixel segments (tuned in-step with alternating runs: 1024 +0.45 %, 256 / 384 +0.1 %, 2048 +1.3 %)
 static inline int plane_blocks(int HW) { int b = cdiv(HW, 512); return b < 1 ? 1 : (b > MAX_PB ? MAX_PB : b); }
@@ -1172,8 +1172,8 @@ int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstri
         return SPLICE_OK;
     }
     const int PB = plane_blocks(HW);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, C, HW, PB, part, u);
-    hipLaunchKernelGGL(bn_act_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, PB, gamma, beta, part, eps, mean, rstd, slope, p_nstride, batch);
+    SPLICE_LAUNCH(bn_stats_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, C, HW, PB, part, u);
+    SPLICE_LAUNCH(bn_act_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, PB, gamma, beta, part, eps, mean, rstd, slope, p_nstride, batch);
     return SPLICE_OK;
 }
 bool bn_bwd_fuses_upsample(int HW, int h, int w) { return HW <= BN_SMALL_HW && h > 0 && w > 0; }
@@ -1197,8 +1197,8 @@ int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t 
         return SPLICE_OK;
     }
     const int PB = plane_blocks(HW);
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, C, HW, PB, mean, rstd, slope, part);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy,
+    SPLICE_LAUNCH(bn_bwd_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, C, HW, PB, mean, rstd, slope, part);
+    SPLICE_LAUNCH(bn_bwd_apply_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy,
                        dy_nstride, C, HW, N, PB, gamma, mean, rstd, slope, part, dgamma, dbeta, accumulate, p_nstride, batch);
     return SPLICE_OK;
 }
@@ -1207,11 +1207,11 @@ __global__ void fill_zero_kernel(float* p, int n) {
     if (i < n) p[i] = 0.f;
 }
 int fill_zero_launch(float* p, int n, hipStream_t s) {
-    hipLaunchKernelGGL(fill_zero_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, n);
+    SPLICE_LAUNCH(fill_zero_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, p, n);
     return SPLICE_OK;
 }
 int channel_sum_launch(const float* dy, size_t nstride, int N, int C, int HW, float* db, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, s, dy, nstride, HW, N, db, accumulate);
+    SPLICE_LAUNCH(channel_sum_kernel, dim3(C), dim3(256), 0, s, dy, nstride, HW, N, db, accumulate);
     return SPLICE_OK;
 }
 
@@ -1241,11 +1241,11 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
     }
 }
 int upsample2x_fwd_launch(const float* in, size_t in_nstride, float* out, size_t out_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s) {
-    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(plane_blocks(Ho * Wo), C, N), dim3(256), 0, s, in, in_nstride, out, out_nstride, C, h, w, Ho, Wo);
+    SPLICE_LAUNCH(upsample2x_fwd_kernel, dim3(plane_blocks(Ho * Wo), C, N), dim3(256), 0, s, in, in_nstride, out, out_nstride, C, h, w, Ho, Wo);
     return SPLICE_OK;
 }
 int upsample2x_bwd_launch(const float* dout, size_t dout_nstride, float* din, size_t din_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s) {
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(cdiv(h * w, 256), C, N), dim3(256), 0, s, dout, dout_nstride, din, din_nstride, C, h, w, Ho, Wo);
+    SPLICE_LAUNCH(upsample2x_bwd_kernel, dim3(cdiv(h * w, 256), C, N), dim3(256), 0, s, dout, dout_nstride, din, din_nstride, C, h, w, Ho, Wo);
     return SPLICE_OK;
 }
 
@@ -1293,14 +1293,14 @@ int sigmoid_bwd_bias_launch(const float* dout, const float* sout, float* dpre, i
                             int accumulate, hipStream_t s, size_t p_nstride) {
     const int PB = plane_blocks(HW);
     const int nz = p_nstride ? N : 1;
-    hipLaunchKernelGGL(sigmoid_bwd_bias_kernel, dim3(PB, C, nz), dim3(256), 0, s, dout, sout, dpre, N, C, HW, PB, part);
-    hipLaunchKernelGGL(bias_part_reduce_kernel, dim3(nz), dim3(64), 0, s, part, C, PB, db, accumulate, p_nstride);
+    SPLICE_LAUNCH(sigmoid_bwd_bias_kernel, dim3(PB, C, nz), dim3(256), 0, s, dout, sout, dpre, N, C, HW, PB, part);
+    SPLICE_LAUNCH(bias_part_reduce_kernel, dim3(nz), dim3(64), 0, s, part, C, PB, db, accumulate, p_nstride);
     return SPLICE_OK;
 }
 int sigmoid_bwd_launch(const float* dout, const float* sout, float* dpre, size_t n, hipStream_t s) {
     size_t g = (n + 255) / 256;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3((unsigned)g), dim3(256), 0, s, dout, sout, dpre, n);
+    SPLICE_LAUNCH(sigmoid_bwd_kernel, dim3((unsigned)g), dim3(256), 0, s, dout, sout, dpre, n);
     return SPLICE_OK;
 }
 
@@ -1357,7 +1357,7 @@ int adam_launch(float* p, float* g, float* m, float* v, size_t n, float lr, floa
     const float bc2 = 1.0f - powf(b2, (float)step);
     size_t g_ = (n / 4 + 255) / 256 + 1;
     if (g_ > 2048) g_ = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g_), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), zero_grad, (const int*)nullptr, (const float*)nullptr);
+    SPLICE_LAUNCH(adam_kernel, dim3((unsigned)g_), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), zero_grad, (const int*)nullptr, (const float*)nullptr);
     return SPLICE_OK;
 }
 // same, the step count t (>= 1) read from device memory at execution time
@@ -1365,7 +1365,7 @@ int adam_launch_dev(float* p, float* g, float* m, float* v, size_t n, float lr, 
                     int zero_grad, hipStream_t s, const float* g2) {
     size_t g_ = (n / 4 + 255) / 256 + 1;
     if (g_ > 2048) g_ = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g_), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, 1.f, 1.f, zero_grad, step_dev, g2);
+    SPLICE_LAUNCH(adam_kernel, dim3((unsigned)g_), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, 1.f, 1.f, zero_grad, step_dev, g2);
     return SPLICE_OK;
 }
 // ---------------------------------------------------------------------------------------
@@ -1374,7 +1374,7 @@ int adam_launch_dev(float* p, float* g, float* m, float* v, size_t n, float lr, 
 // BatchNorm of up to RUNSTAT_MAX_PLANS generator calls IN CALL ORDER: thread (bn, channel) walks the plans in order (the
 // updates of one buffer do not commute exactly), and the images of a plan in order unless they are independent
 // generators (blockIdx.y = image = its own buffer arena).  var_unbiased is rebuilt from the saved rstd.
-__global__ __launch_bounds__(192) void bn_running_update_kernel(RunStatTable t, float* __restrict__ running, size_t r_nstride, float momentum, float eps) {
+__global__ __launch_bounds__(256) void bn_running_update_kernel(RunStatTable t, float* __restrict__ running, size_t r_nstride, float momentum, float eps) {
     const int bn = blockIdx.x, c = threadIdx.x;
     if (c >= t.C[bn]) return;
     for (int p = 0; p < t.n_plans; ++p) {
@@ -1395,12 +1395,13 @@ __global__ __launch_bounds__(192) void bn_running_update_kernel(RunStatTable t, 
 }
 int bn_running_update_launch(const RunStatTable& t, float* running, size_t r_nstride, float momentum, float eps, int max_images, hipStream_t s) {
     if (t.n_plans < 1 || t.n_plans > RUNSTAT_MAX_PLANS || t.n_bn < 1 || t.n_bn > RUNSTAT_MAX_BN) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(bn_running_update_kernel, dim3(t.n_bn, max_images), dim3(192), 0, s, t, running, r_nstride, momentum, eps);
+    // one thread per channel: the concat BatchNorm of an architecture within arch_check has up to 128 + 128 = 256 channels
+    SPLICE_LAUNCH(bn_running_update_kernel, dim3(t.n_bn, max_images), dim3(256), 0, s, t, running, r_nstride, momentum, eps);
     return SPLICE_OK;
 }
 
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
 int set_int_launch(int* p, int v, hipStream_t s) {
-    hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, s, p, v);
+    SPLICE_LAUNCH(set_int_kernel, dim3(1), dim3(1), 0, s, p, v);
     return SPLICE_OK;
 }

@@ -71,9 +71,9 @@ __global__ __launch_bounds__(256) void selfsim_gemm_kernel(const bf16_t* __restr
 
 int selfsim_fwd_launch(const float* K, int ldk, int T, int D, float eps, float* S, const SelfSimWs& ws, hipStream_t s) {
     if (D % 64) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(selfsim_prep_kernel, dim3(cdiv(ws.Tp, 4)), dim3(256), 0, s, K, ldk, T, D, ws);
+    SPLICE_LAUNCH(selfsim_prep_kernel, dim3(cdiv(ws.Tp, 4)), dim3(256), 0, s, K, ldk, T, D, ws);
     const int grid = cdiv(T, 64) * cdiv(T, 64);
-    hipLaunchKernelGGL((selfsim_gemm_kernel<64, 64>), dim3(grid), dim3(256), SS_LDS, s, ws.kbf, T, D, ws.norm, eps, S);
+    SPLICE_LAUNCH((selfsim_gemm_kernel<64, 64>), dim3(grid), dim3(256), SS_LDS, s, ws.kbf, T, D, ws.norm, eps, S);
     return SPLICE_OK;
 }
 
@@ -132,9 +132,9 @@ __global__ __launch_bounds__(256) void selfsim_bwd_gemm_kernel(SelfSimWs ws, int
 int selfsim_bwd_launch(const float* dS, const float* S, int T, int D, float eps, float* dK, int lddk, int accumulate,
                        const SelfSimWs& ws, hipStream_t s) {
     if (D % 64) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(selfsim_wmat_kernel, dim3(ws.Tp), dim3(256), 0, s, dS, S, T, eps, ws);
+    SPLICE_LAUNCH(selfsim_wmat_kernel, dim3(ws.Tp), dim3(256), 0, s, dS, S, T, eps, ws);
     const int grid = cdiv(T, 64) * cdiv(D, 64);
-    hipLaunchKernelGGL((selfsim_bwd_gemm_kernel<64, 64>), dim3(grid), dim3(256), SS_LDS, s, ws, T, D, dK, lddk, accumulate);
+    SPLICE_LAUNCH((selfsim_bwd_gemm_kernel<64, 64>), dim3(grid), dim3(256), SS_LDS, s, ws, T, D, dK, lddk, accumulate);
     return SPLICE_OK;
 }
 
@@ -184,7 +184,7 @@ int mse_partials_launch(const float* a, int lda, const float* b, int ldb, int ro
     if (!n || !part) return SPLICE_ERR_ARG;
     size_t g = (n + 255) / 256;
     if (g > MSE_MAX_WG) g = MSE_MAX_WG;
-    hipLaunchKernelGGL(mse_kernel, dim3((unsigned)g), dim3(256), 0, s, a, lda, b, ldb, rows, cols, loss_weight / (float)n,
+    SPLICE_LAUNCH(mse_kernel, dim3((unsigned)g), dim3(256), 0, s, a, lda, b, ldb, rows, cols, loss_weight / (float)n,
                        grad_weight / (float)n, part, grad, ldg);
     return SPLICE_OK;
 }
@@ -210,7 +210,7 @@ int mse2_launch(const float* a, int lda, const float* b, int ldb, int rows, int 
     if (!scratch) return SPLICE_ERR_HIP;
     const int rc = mse_partials_launch(a, lda, b, ldb, rows, cols, loss_weight, grad_weight, scratch, grad, ldg, s);
     if (rc != SPLICE_OK) return rc;
-    hipLaunchKernelGGL(mse_sum_kernel, dim3(1), dim3(256), 0, s, scratch, loss_accum);
+    SPLICE_LAUNCH(mse_sum_kernel, dim3(1), dim3(256), 0, s, scratch, loss_accum);
     return SPLICE_OK;
 }
 int mse_launch(const float* a, int lda, const float* b, int ldb, int rows, int cols, float weight, float* loss_accum,
@@ -427,33 +427,35 @@ __global__ __launch_bounds__(256) void selfsim_dk_kernel(SelfSimBatch b) {
 int selfsim_norms_launch(const bf16_t* k, int ldk, size_t k_pstride, int T, int D, float* norm, int pairs, hipStream_t s) {
     if (D % 64 || ldk % 8) return SPLICE_ERR_ARG;
     const int Tp = round_up(T, 64);
-    hipLaunchKernelGGL(selfsim_rownorm_kernel, dim3(cdiv(Tp, 4), pairs), dim3(256), 0, s, k, ldk, k_pstride, T, Tp, D, norm);
+    SPLICE_LAUNCH(selfsim_rownorm_kernel, dim3(cdiv(Tp, 4), pairs), dim3(256), 0, s, k, ldk, k_pstride, T, Tp, D, norm);
     return SPLICE_OK;
 }
 int selfsim_target_launch(const SelfSimBatch& b, hipStream_t s) {
+    SpliceProfScope prof_scope(8);
     const int nt = b.Tp / 64;
     if (b.fp8) {
         if (b.D % 128) return SPLICE_ERR_ARG;
         RC_SS(quantize_keys_fp8_launch(b.k_tgt, b.ldk, b.k_pstride, b.k8_tgt, b.D, (size_t)b.Tp * b.D, b.qnorm_tgt, b.T, b.Tp, b.D, b.pairs, s));
-        hipLaunchKernelGGL(selfsim_tgt_kernel<true>, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
+        SPLICE_LAUNCH(selfsim_tgt_kernel<true>, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
         return SPLICE_OK;
     }
     RC_SS(selfsim_norms_launch(b.k_tgt, b.ldk, b.k_pstride, b.T, b.D, b.norm_tgt, b.pairs, s));
-    hipLaunchKernelGGL(selfsim_tgt_kernel<false>, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
+    SPLICE_LAUNCH(selfsim_tgt_kernel<false>, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
     return SPLICE_OK;
 }
 int selfsim_loss_launch(const SelfSimBatch& b, hipStream_t s) {
+    SpliceProfScope prof_scope(8);
     const int nt = b.Tp / 64;
     if (nt * (nt + 1) / 2 > (int)b.part_pstride) return SPLICE_ERR_ARG;
     RC_SS(selfsim_norms_launch(b.k_x, b.ldk, b.k_pstride, b.T, b.D, b.norm_x, b.pairs, s));   // true norms: W and r are in key units either way
     if (b.fp8) {
         if (b.D % 128) return SPLICE_ERR_ARG;
         RC_SS(quantize_keys_fp8_launch(b.k_x, b.ldk, b.k_pstride, b.k8_x, b.D, (size_t)b.Tp * b.D, b.qnorm_x, b.T, b.Tp, b.D, b.pairs, s));
-        hipLaunchKernelGGL(selfsim_loss_kernel<true>, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
+        SPLICE_LAUNCH(selfsim_loss_kernel<true>, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
     } else {
-        hipLaunchKernelGGL(selfsim_loss_kernel<false>, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
+        SPLICE_LAUNCH(selfsim_loss_kernel<false>, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
     }
-    hipLaunchKernelGGL(selfsim_dk_kernel, dim3(nt * (b.D / 64), b.pairs), dim3(256), SS_LDS, s, b);
+    SPLICE_LAUNCH(selfsim_dk_kernel, dim3(nt * (b.D / 64), b.pairs), dim3(256), SS_LDS, s, b);
     return SPLICE_OK;
 }
 size_t selfsim_batch_ws_bytes(int T, int D, int pairs) {
@@ -502,7 +504,7 @@ int mse_batched_launch(const float* a, int lda, size_t a_ps, const float* b, int
     if (!n || !part || pairs < 1) return SPLICE_ERR_ARG;
     size_t g = (n + 255) / 256;
     if (g > MSE_MAX_WG) g = MSE_MAX_WG;
-    hipLaunchKernelGGL(mse_batched_kernel, dim3((unsigned)g, pairs), dim3(256), 0, s, a, lda, a_ps, b, ldb, b_ps, rows, cols, loss_weight / (float)n,
+    SPLICE_LAUNCH(mse_batched_kernel, dim3((unsigned)g, pairs), dim3(256), 0, s, a, lda, a_ps, b, ldb, b_ps, rows, cols, loss_weight / (float)n,
                        grad_weight / (float)n, part, part_ps, grad, ldg, g_ps);
     return SPLICE_OK;
 }

@@ -104,7 +104,7 @@ struct SpliceStep {
     hipStream_t side_stream = nullptr;               // target-pass ViT forward beside the generator forward
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int overlap = 1;                                 // SPLICE_STEP_OVERLAP=0 serialises (debugging)
-    int ablate = 0;                                  // SPLICE_STEP_ABLATE bitmask: TIMING experiments only (results are garbage):
+    int ablate = 0;                                  // always 0 in the product build.  Scratch builds (-DSPLICE_DEV_SWITCHES) read the SPLICE_STEP_ABLATE bitmask, TIMING experiments only (results are garbage):
                                                      // 1 skip G fwd, 2 skip G bwd, 4 skip ViT bwd, 8 skip target ViT fwd, 16 skip generated ViT fwd, 32 skip the y' chain of the ViT bwd
     std::map<int, hipGraphExec_t> graphs;
     void* graph_ptrs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // arenas + the caller's losses / running buffers a captured graph is bound to
@@ -281,6 +281,9 @@ int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void
     for (float** q : {&st->gen_in, &st->in_b, &st->gen_out, &st->gen_out_b, &st->d_gen_out, &st->d_gen_out_b})
         if ((rc = salloc(st, q, P * crop)) != SPLICE_OK) return fail(rc);
     if ((rc = salloc(st, &st->grads_b, st->astride ? P * st->astride : (size_t)st->nparams)) != SPLICE_OK) return fail(rc);
+    // the backward writes nparams floats per pair; the <= 63 floats of padding between two arenas are read by the whole-range
+    // add / Adam and must never hold garbage
+    if (hipMemset(st->grads_b, 0, (st->astride ? P * st->astride : (size_t)st->nparams) * sizeof(float)) != hipSuccess) return fail(SPLICE_ERR_HIP);
     int Tmax = st->vg.T;
     if (cfg->ent_h > 0) {
         if (!vit_ctx_entire || !gen_plan_entire) { splice_set_error("splice_step_create: entire-image branch needs its ViT context and generator plan"); return fail(SPLICE_ERR_ARG); }
@@ -308,7 +311,9 @@ int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void
     if (const char* e = getenv("SPLICE_STEP_SYNC")) st->dbg_sync = atoi(e);
     if (const char* e = getenv("SPLICE_STEP_OWN_EAGER")) st->dbg_own_eager = atoi(e);
     if (const char* e = getenv("SPLICE_STEP_OVERLAP")) st->overlap = atoi(e);
+#ifdef SPLICE_DEV_SWITCHES   // scratch builds only (make DEV=1): the work-skipping timing switch is not part of the product library
     if (const char* e = getenv("SPLICE_STEP_ABLATE")) st->ablate = atoi(e);
+#endif
     if (hipStreamCreateWithFlags(&st->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&st->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -474,7 +479,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     // dependent chain pays ~8 us of fixed latency; two chains in flight hide each other's)
     bool loss_summed = false;
     auto sum_losses = [&](hipStream_t q) {
-        hipLaunchKernelGGL(total_loss_kernel, dim3(st->crops_mode ? 1 : P), dim3(320), 0, q, st->losses, st->lstride, (int)st->lp, l_ssim, l_essim, l_ecls, l_cls, l_id,
+        SPLICE_LAUNCH(total_loss_kernel, dim3(st->crops_mode ? 1 : P), dim3(320), 0, q, st->losses, st->lstride, (int)st->lp, l_ssim, l_essim, l_ecls, l_cls, l_id,
                            st->losses_out, st->crops_mode ? P : 1);
     };
     auto track_running = [&](hipStream_t q) -> int {   // BatchNorm running statistics in the reference's call order
@@ -587,7 +592,7 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
         sa.src[1] = B_crop; sa.dst[1] = st->in_b; sa.n[1] = (size_t)P * 3 * st->cropb_h * st->cropb_w;
         if (entire) { sa.src[2] = A_entire; sa.dst[2] = st->ent_in; sa.n[2] = (size_t)st->Pe * 3 * c.ent_h * c.ent_w; }
         sa.ip = st->dev_t; sa.iv = step_idx + 1;
-        hipLaunchKernelGGL(stage_inputs_kernel, dim3(128 * (P > 4 ? 4 : P)), dim3(256), 0, s, sa);
+        SPLICE_LAUNCH(stage_inputs_kernel, dim3(128 * (P > 4 ? 4 : P)), dim3(256), 0, s, sa);
     }
     if (!graph) {
         RC(step_body(st, params, grads, m, v, st->ssim_id_on != 0, entire, s));

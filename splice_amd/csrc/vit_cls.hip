@@ -251,7 +251,7 @@ int attn_cls_fwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, i
                         hipStream_t s) {
     if (D / 64 != H || D % 64) return SPLICE_ERR_ARG;
     const size_t lds = (size_t)(Tld + Tld / 2 + 256 + 8) * sizeof(float);
-    hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(H, B), dim3(256), lds, s, qkv, qkvT, ldt, T, Tld, D, scale, out, probs);
+    SPLICE_LAUNCH(attn_cls_fwd_kernel, dim3(H, B), dim3(256), lds, s, qkv, qkvT, ldt, T, Tld, D, scale, out, probs);
     return SPLICE_OK;
 }
 int attn_cls_bwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, int T, int Tld, int D, int H, float scale, const float* probs,
@@ -259,7 +259,7 @@ int attn_cls_bwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, i
     if (D / 64 != H || D % 64 || n_slabs < 1 || n_slabs > 16) return SPLICE_ERR_ARG;
     const size_t lds = (size_t)(Tld + Tld / 2 + 64 + 64 + 32 + 256 + 8) * sizeof(float);
     const int nz = Tld > 768 ? 4 : Tld > 256 ? 2 : 1;   // one 256-row slice of the store loop per workgroup at ViT-B/8 @ 224
-    hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(H, B, nz), dim3(256), lds, s, qkv, qkvT, ldt, T, Tld, D, scale, probs, dout_slabs, n_slabs, slab_stride, dqkv);
+    SPLICE_LAUNCH(attn_cls_bwd_kernel, dim3(H, B, nz), dim3(256), lds, s, qkv, qkvT, ldt, T, Tld, D, scale, probs, dout_slabs, n_slabs, slab_stride, dqkv);
     return SPLICE_OK;
 }
 
@@ -383,14 +383,14 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(float* __restrict__ dy
 int ln_rows_fwd_launch(float* x, size_t xs, const float* gamma, const float* beta, bf16_t* y, size_t ys, float* mean, float* rstd, size_t ss, int rows,
                        int D, float eps, const float* slabs, int n_slabs, size_t slab_stride, const float* bias, const float* resid, size_t rs, hipStream_t s) {
     if (D > 256 * LNR_MAXC || D < 1 || rows < 1) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(ln_rows_fwd_kernel, dim3(rows), dim3(256), 0, s, x, xs, gamma, beta, y, ys, mean, rstd, ss, rows, D, eps, slabs, n_slabs, slab_stride,
+    SPLICE_LAUNCH(ln_rows_fwd_kernel, dim3(rows), dim3(256), 0, s, x, xs, gamma, beta, y, ys, mean, rstd, ss, rows, D, eps, slabs, n_slabs, slab_stride,
                        bias, resid, rs);
     return SPLICE_OK;
 }
 int ln_rows_bwd_launch(float* dy, size_t dys, const float* x, size_t xs, const float* gamma, const float* mean, const float* rstd, size_t ss, float* g,
                        bf16_t* g_bf, int rows, int D, int n_slabs, size_t slab_stride, hipStream_t s) {
     if (D > 256 * LNR_MAXC || D < 1 || rows < 1) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(ln_rows_bwd_kernel, dim3(rows), dim3(256), 0, s, dy, dys, x, xs, gamma, mean, rstd, ss, g, g_bf, rows, D, n_slabs, slab_stride);
+    SPLICE_LAUNCH(ln_rows_bwd_kernel, dim3(rows), dim3(256), 0, s, dy, dys, x, xs, gamma, mean, rstd, ss, g, g_bf, rows, D, n_slabs, slab_stride);
     return SPLICE_OK;
 }
 
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void rows_finish_kernel(int mode, const float*
 }
 int rows_finish_launch(int mode, const float* slabs, int n_slabs, size_t slab_stride, int rows, int N, const float* bias, const float* resid, size_t rs,
                        float* out_f32, size_t os, bf16_t* out_bf, bf16_t* pre_bf, const bf16_t* aux, size_t ps, int pre_lo, hipStream_t s) {
-    hipLaunchKernelGGL(rows_finish_kernel, dim3(cdiv(rows * N, 256)), dim3(256), 0, s, mode, slabs, n_slabs, slab_stride, rows, N, bias, resid, rs, out_f32, os, out_bf,
+    SPLICE_LAUNCH(rows_finish_kernel, dim3(cdiv(rows * N, 256)), dim3(256), 0, s, mode, slabs, n_slabs, slab_stride, rows, N, bias, resid, rs, out_f32, os, out_bf,
                        pre_bf, aux, ps, pre_lo);
     return SPLICE_OK;
 }

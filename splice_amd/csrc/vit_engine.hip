@@ -34,31 +34,7 @@ extern "C" int splice_vit_params_complete(void* vit);
         }                                                                                         \
     } while (0)
 
-// ---- optional live timing of ONE kernel family with HIP events on the launch stream (bench.py's
-// roofline leg).  which: 1 = fc1 GEMM (forward), 2 = qkv GEMM (forward), 3 = attention forward, 4 = fc2 GEMM (forward),
-// 5 = the split-K dgrad GEMMs (fc1^T and qkv^T), 6 = attention backward.
-struct ProfState {
-    int which = 0;
-    std::vector<hipEvent_t> ev;   // start/stop pairs
-    size_t used = 0;
-};
-static ProfState g_prof;
-struct ProfScope {
-    bool on;
-    hipStream_t s;
-    ProfScope(int which, hipStream_t st) : on(g_prof.which == which), s(st) {
-        if (!on) return;
-        if (g_prof.used + 2 > g_prof.ev.size()) {
-            for (int i = 0; i < 256; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } g_prof.ev.push_back(e); }
-        }
-        (void)hipEventRecord(g_prof.ev[g_prof.used], s);
-    }
-    ~ProfScope() {
-        if (!on) return;
-        (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s);
-        g_prof.used += 2;
-    }
-};
+// (live timing of one kernel family for the roofline leg: SpliceProfScope, prof.hip)
 
 struct Linear {
     bf16_t* w = nullptr;    // [out][in]
@@ -330,7 +306,7 @@ int splice_vit_ctx_create(void* h, int B, int H, int W, const float* pos_TD, int
         delete c;
         return rc;
     }
-    hipLaunchKernelGGL(pos_eff_kernel, dim3(grid_n((size_t)c->Tld * D)), dim3(256), 0, s, c->pos_eff, pos_TD, v->cls, v->pe.b, c->T, c->Tld, D);
+    SPLICE_LAUNCH(pos_eff_kernel, dim3(grid_n((size_t)c->Tld * D)), dim3(256), 0, s, c->pos_eff, pos_TD, v->cls, v->pe.b, c->T, c->Tld, D);
     *out = c;
     return SPLICE_OK;
 }
@@ -348,30 +324,6 @@ int splice_vit_ctx_info(void* ctx, int* T, int* Tld, int* rows) {
     if (T) *T = c->T;
     if (Tld) *Tld = c->Tld;
     if (rows) *rows = c->rows;
-    return SPLICE_OK;
-}
-
-// Live kernel timing for the roofline report: begin(which) arms HIP-event pairs around every launch
-// of the chosen kernel family on its own stream; end() synchronises those events and returns the
-// summed duration and the launch count.
-int splice_prof_begin(int which) {
-    g_prof.which = which;
-    g_prof.used = 0;
-    return SPLICE_OK;
-}
-int splice_prof_active(void) { return g_prof.which != 0; }
-int splice_prof_end(float* total_ms, int* launches) {
-    float tot = 0.f;
-    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
-        float ms = 0.f;
-        if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) return SPLICE_ERR_HIP;
-        if (hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) != hipSuccess) return SPLICE_ERR_HIP;
-        tot += ms;
-    }
-    if (total_ms) *total_ms = tot;
-    if (launches) *launches = (int)(g_prof.used / 2);
-    g_prof.which = 0;
-    g_prof.used = 0;
     return SPLICE_OK;
 }
 
@@ -447,7 +399,7 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
             e.bias = W.qkv.b; e.out_bf = c->qkv[l] + r0 * 3 * D; e.ldbf = 3 * D; e.out_bf_t = c->qkvT[l] + r0; e.ldt = c->rows;
             unsigned fl = EPI_BIAS | EPI_OUT_BF | EPI_OUT_T;
             if (l == L - 1) { fl |= EPI_COLS_F32; e.out_f32_cols = c->qkv_last_f32 + r0 * 3 * D; e.ld_cols = 3 * D; e.col_lo = 0; e.col_hi = 3 * D; }
-            ProfScope ps(l == L - 1 ? 0 : 2, s);
+            SpliceProfScope ps(l == L - 1 ? 0 : 2);
             if (fp8) {   // e4m3 LayerNorm output (per-token scale) x e4m3 weights (per-channel scale) on the fp8 MFMA
                 e.row_scale = c->ln_scale + r0; e.col_scale = W.qkv.w8_scale;
                 RC(gemm_nt_fp8_launch(fl | EPI_SCALE_RC, c->ln_out8 + r0 * D, D, W.qkv.w8, D, R, 3 * D, D, e, s));
@@ -496,12 +448,13 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
             AttnArgs a = {};
             a.qkv = c->qkv[l] + r0 * 3 * D; a.qkvT = c->qkvT[l] + r0; a.ldt = c->rows; a.B = Bp; a.T = c->T; a.Tld = c->Tld; a.D = D; a.H = v->heads;
             a.scale = 0.125f; a.out = c->attn_out[l] + r0 * D; a.lse = c->lse[l] + (size_t)pass_begin * v->heads * c->Tld;
-            ProfScope ps(3, s);
+            SpliceProfScope ps(3);
             RC(attn_fwd_launch(&a, s));
         }
         {
             GemmEpi e = {};
             e.bias = W.proj.b; e.resid = x_in; e.ldr = D; e.out_f32 = x_mid; e.ldo = D;
+            SpliceProfScope ps(9);
             RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, c->attn_out[l] + r0 * D, D, W.proj.w, D, R, D, D, e, s));
         }
         RC(layernorm_fwd_launch(x_mid, W.ln2_g, W.ln2_b, ln_out, c->mean2[l] + r0, c->rstd2[l] + r0, R, D, 1e-6f, s));
@@ -510,13 +463,13 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
             e.bias = W.fc1.b; e.out_bf = hact; e.ldbf = Hd; e.out_pre = c->need_grad ? c->hpre[l] + r0 * Hd : nullptr; e.ldp = Hd;
             const long lo = (long)c->grad_pass_begin * c->Tld - (long)r0;   // first local row whose pre-activation is kept
             e.pre_row_lo = lo > 0 ? (int)lo : 0;
-            ProfScope ps(1, s);
+            SpliceProfScope ps(1);
             RC(gemm_nt_launch(EPI_BIAS | EPI_GELU | EPI_OUT_BF, ln_out, D, W.fc1.w, D, R, Hd, D, e, s));
         }
         {
             GemmEpi e = {};
             e.bias = W.fc2.b; e.resid = x_mid; e.ldr = D; e.out_f32 = c->xs[l + 1] + r0 * D; e.ldo = D;
-            ProfScope ps(4, s);
+            SpliceProfScope ps(4);
             RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, hact, Hd, W.fc2.w, Hd, R, D, Hd, e, s));
         }
     }
@@ -593,7 +546,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
         const float* dq = d_qkv ? d_qkv[l] : nullptr;
         const float* dk = d_keys ? d_keys[l] : nullptr;
         if (db) {
-            hipLaunchKernelGGL(grad_stream_kernel, dim3(grid_n((size_t)R * D)), dim3(256), 0, s, g, g_bf, db + r0 * D, (size_t)R * D, g_live ? 0 : 1);
+            SPLICE_LAUNCH(grad_stream_kernel, dim3(grid_n((size_t)R * D)), dim3(256), 0, s, g, g_bf, db + r0 * D, (size_t)R * D, g_live ? 0 : 1);
             g_live = true;
         }
         if (!g_live && !dq && !dk) continue;
@@ -637,7 +590,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
             {
                 GemmEpi e = {};
                 e.out_f32 = c->dln + r0 * D; e.ldo = D; e.ksplit = ks; e.slab_stride = (long long)slab;
-                ProfScope ps(5, s);
+                SpliceProfScope ps(5);
                 RC(gemm_nt_launch(EPI_OUT_F32, c->dh + r0 * Hd, Hd, W.fc1.wT, Hd, R, D, Hd, e, s));
             }
             RC(layernorm_bwd_slabs_launch(c->dln + r0 * D, gemm_splitk_slabs(R, ks), slab, c->xmid[l] + r0 * D, W.ln2_g, c->mean2[l] + r0, c->rstd2[l] + r0, g, g, g_bf, R, D, s));
@@ -658,19 +611,19 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
                 a.D = D; a.H = v->heads; a.scale = 0.125f; a.out = c->attn_out[l] + r0 * D;
                 a.lse = c->lse[l] + (size_t)pass_begin * v->heads * c->Tld;
                 a.dout = c->dout + r0 * D; a.doutT = c->doutT + r0; a.delta = c->delta + (size_t)pass_begin * v->heads * c->Tld; a.delta_ready = 1; a.dqkv = dqkv;
-                ProfScope ps(6, s);
+                SpliceProfScope ps(6);
                 RC(attn_bwd_launch(&a, s));
             }
             g_after_mlp = g;
         } else {
             RC(dev_zero_launch(dqkv, (size_t)R * 3 * D * sizeof(bf16_t), s));
         }
-        if (dq) hipLaunchKernelGGL(add_f32_into_bf16_kernel, dim3(grid_n((size_t)R * 3 * D)), dim3(256), 0, s, dqkv, 3 * D, 0, dq + r0 * 3 * D, 3 * D, R, 3 * D);
-        if (dk) hipLaunchKernelGGL(add_f32_into_bf16_kernel, dim3(grid_n((size_t)R * D)), dim3(256), 0, s, dqkv, 3 * D, D, dk + r0 * D, D, R, D);
+        if (dq) SPLICE_LAUNCH(add_f32_into_bf16_kernel, dim3(grid_n((size_t)R * 3 * D)), dim3(256), 0, s, dqkv, 3 * D, 0, dq + r0 * 3 * D, 3 * D, R, 3 * D);
+        if (dk) SPLICE_LAUNCH(add_f32_into_bf16_kernel, dim3(grid_n((size_t)R * D)), dim3(256), 0, s, dqkv, 3 * D, D, dk + r0 * D, D, R, D);
         {
             GemmEpi e = {};
             e.out_f32 = c->dln + r0 * D; e.ldo = D; e.ksplit = ks; e.slab_stride = (long long)slab;
-            ProfScope ps(5, s);
+            SpliceProfScope ps(5);
             RC(gemm_nt_launch(EPI_OUT_F32, dqkv, 3 * D, W.qkv.wT, 3 * D, R, D, 3 * D, e, s));
         }
         RC(layernorm_bwd_slabs_launch(c->dln + r0 * D, gemm_splitk_slabs(R, ks), slab, c->xs[l] + r0 * D, W.ln1_g, c->mean1[l] + r0, c->rstd1[l] + r0, g_after_mlp, g, g_bf, R, D, s));

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 int layernorm_fwd_launch(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
                          int rows, int D, float eps, hipStream_t s) {
     if (D % 4 || D > 64 * 4 * 4) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(layernorm_fwd_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, D, eps);
+    SPLICE_LAUNCH(layernorm_fwd_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, D, eps);
     return SPLICE_OK;
 }
 
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_fp8_kernel(const float* __r
 int layernorm_fwd_fp8_launch(const float* x, const float* gamma, const float* beta, uint8_t* y, float* yscale, float* mean, float* rstd,
                              int rows, int D, float eps, hipStream_t s) {
     if (D % 4 || D > 64 * 4 * 4) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(layernorm_fwd_fp8_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, gamma, beta, y, yscale, mean, rstd, rows, D, eps);
+    SPLICE_LAUNCH(layernorm_fwd_fp8_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, gamma, beta, y, yscale, mean, rstd, rows, D, eps);
     return SPLICE_OK;
 }
 // q[r][:] = fp8(x[r][:] * 448 / amax_r), scale[r] = amax_r / 448; x fp32 or bf16 rows; one wave per row
@@ -166,19 +166,19 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const T* __restr
 }
 int quantize_rows_fp8_launch(const float* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int cols, hipStream_t s) {
     if (cols % 4 || ldq % 4) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(quantize_rows_fp8_kernel<float>, dim3(cdiv(rows, 4), 1), dim3(256), 0, s, x, ldx, q, ldq, scale, (float*)nullptr, rows, cols, (size_t)0, (size_t)0, rows);
+    SPLICE_LAUNCH(quantize_rows_fp8_kernel<float>, dim3(cdiv(rows, 4), 1), dim3(256), 0, s, x, ldx, q, ldq, scale, (float*)nullptr, rows, cols, (size_t)0, (size_t)0, rows);
     return SPLICE_OK;
 }
 // bf16 rows -> fp8 rows of `pairs` problems at once (+ the norm of every quantised row): the keys of the structure loss
 int quantize_keys_fp8_launch(const bf16_t* k, int ldk, size_t k_pstride, uint8_t* q, int ldq, size_t q_pstride, float* qnorm, int T, int Tp, int D,
                              int pairs, hipStream_t s) {
     if (D % 4 || ldq % 4) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(quantize_rows_fp8_kernel<bf16_t>, dim3(cdiv(Tp, 4), pairs), dim3(256), 0, s, k, ldk, q, ldq, (float*)nullptr, qnorm, T, D, k_pstride, q_pstride, Tp);
+    SPLICE_LAUNCH(quantize_rows_fp8_kernel<bf16_t>, dim3(cdiv(Tp, 4), pairs), dim3(256), 0, s, k, ldk, q, ldq, (float*)nullptr, qnorm, T, D, k_pstride, q_pstride, Tp);
     return SPLICE_OK;
 }
 int quantize_rows_bf16_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int cols, hipStream_t s) {
     if (cols % 4 || ldq % 4) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(quantize_rows_fp8_kernel<bf16_t>, dim3(cdiv(rows, 4), 1), dim3(256), 0, s, x, ldx, q, ldq, scale, (float*)nullptr, rows, cols, (size_t)0, (size_t)0, rows);
+    SPLICE_LAUNCH(quantize_rows_fp8_kernel<bf16_t>, dim3(cdiv(rows, 4), 1), dim3(256), 0, s, x, ldx, q, ldq, scale, (float*)nullptr, rows, cols, (size_t)0, (size_t)0, rows);
     return SPLICE_OK;
 }
 
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 int layernorm_bwd_slabs_launch(const float* dy, int n_slabs, size_t slab_stride, const float* x, const float* gamma, const float* mean,
                                const float* rstd, const float* g_in, float* g_out, bf16_t* g_out_bf, int rows, int D, hipStream_t s) {
     if (D % 4 || D > 64 * 4 * 4 || n_slabs < 1 || n_slabs > LN_MAX_SLABS) return SPLICE_ERR_ARG;
-    hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, dy, x, gamma, mean, rstd, g_in, g_out, g_out_bf, rows, D,
+    SPLICE_LAUNCH(layernorm_bwd_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, s, dy, x, gamma, mean, rstd, g_in, g_out, g_out_bf, rows, D,
                        n_slabs, slab_stride);
     return SPLICE_OK;
 }
@@ -289,7 +289,7 @@ __global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restric
 
 int patchify_launch(const float* img, bf16_t* patches, int B, int H, int W, int p, int Tld, int normalize, hipStream_t s) {
     const size_t total = (size_t)B * Tld * 3 * p;
-    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, patches, B, H, W, p, Tld, normalize);
+    SPLICE_LAUNCH(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, patches, B, H, W, p, Tld, normalize);
     return SPLICE_OK;
 }
 
@@ -312,7 +312,7 @@ __global__ void unpatchify_kernel(const float* __restrict__ dp, float* __restric
 
 int unpatchify_launch(const float* dpatches, float* dimg, int B, int H, int W, int p, int Tld, int normalize, hipStream_t s) {
     const size_t total = (size_t)B * 3 * H * W;
-    hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dpatches, dimg, B, H, W, p, Tld, normalize);
+    SPLICE_LAUNCH(unpatchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dpatches, dimg, B, H, W, p, Tld, normalize);
     return SPLICE_OK;
 }
 
@@ -355,23 +355,23 @@ __global__ void transpose_f32_to_bf16_kernel(const float* __restrict__ x, bf16_t
 static inline unsigned grid_for(size_t n) { size_t g = (n + 255) / 256; return (unsigned)(g > 4096 ? 4096 : (g ? g : 1)); }
 
 int cast_f32_bf16_launch(const float* x, bf16_t* y, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n);
+    SPLICE_LAUNCH(cast_f32_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n);
     return SPLICE_OK;
 }
 int cast_bf16_f32_launch(const bf16_t* x, float* y, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n);
+    SPLICE_LAUNCH(cast_bf16_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, y, n);
     return SPLICE_OK;
 }
 int fill_f32_launch(float* x, float v, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, v, n);
+    SPLICE_LAUNCH(fill_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, x, v, n);
     return SPLICE_OK;
 }
 int add_f32_launch(float* y, const float* x, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, x, n);
+    SPLICE_LAUNCH(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, y, x, n);
     return SPLICE_OK;
 }
 int transpose_f32_to_bf16_launch(const float* x, bf16_t* y, int rows, int cols, int ldy, hipStream_t s) {
-    hipLaunchKernelGGL(transpose_f32_to_bf16_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, s, x, y, rows, cols, ldy);
+    SPLICE_LAUNCH(transpose_f32_to_bf16_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, s, x, y, rows, cols, ldy);
     return SPLICE_OK;
 }
 
@@ -441,12 +441,12 @@ __global__ void resize_bwd_kernel(const float* __restrict__ dout, float* __restr
 }
 int resize_bilinear_fwd_launch(const float* in, float* out, int planes, int h, int w, int oh, int ow, hipStream_t s) {
     const size_t n = (size_t)planes * oh * ow;
-    hipLaunchKernelGGL(resize_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, planes, h, w, oh, ow, (float)h / (float)oh, (float)w / (float)ow);
+    SPLICE_LAUNCH(resize_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, planes, h, w, oh, ow, (float)h / (float)oh, (float)w / (float)ow);
     return SPLICE_OK;
 }
 int resize_bilinear_bwd_launch(const float* dout, float* din, int planes, int h, int w, int oh, int ow, hipStream_t s) {
     const size_t n = (size_t)planes * h * w;
-    hipLaunchKernelGGL(resize_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, dout, din, planes, h, w, oh, ow, (float)h / (float)oh, (float)w / (float)ow);
+    SPLICE_LAUNCH(resize_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, dout, din, planes, h, w, oh, ow, (float)h / (float)oh, (float)w / (float)ow);
     return SPLICE_OK;
 }
 
@@ -464,13 +464,13 @@ int dev_copy_launch(void* dst, const void* src, size_t bytes, hipStream_t s) {
     if (bytes & 3) return SPLICE_ERR_ARG;
     const size_t n = bytes >> 2;
     if (!n) return SPLICE_OK;
-    hipLaunchKernelGGL(dev_copy_kernel, dim3(grid_for(n)), dim3(256), 0, s, (uint32_t*)dst, (const uint32_t*)src, n);
+    SPLICE_LAUNCH(dev_copy_kernel, dim3(grid_for(n)), dim3(256), 0, s, (uint32_t*)dst, (const uint32_t*)src, n);
     return SPLICE_OK;
 }
 int dev_zero_launch(void* dst, size_t bytes, hipStream_t s) {
     if (bytes & 3) return SPLICE_ERR_ARG;
     const size_t n = bytes >> 2;
     if (!n) return SPLICE_OK;
-    hipLaunchKernelGGL(dev_zero_kernel, dim3(grid_for(n)), dim3(256), 0, s, (uint32_t*)dst, n);
+    SPLICE_LAUNCH(dev_zero_kernel, dim3(grid_for(n)), dim3(256), 0, s, (uint32_t*)dst, n);
     return SPLICE_OK;
 }

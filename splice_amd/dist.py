@@ -1,7 +1,8 @@
 """Process-per-GPU replica helpers: independent image pairs, one
-optimisation loop per GPU, NO data-path collective.  torch.distributed (backend "nccl" = RCCL on
-ROCm, "gloo" in the CPU tests) is used only for the start/stop barrier and the max-over-ranks
-reduction of the elapsed time that bench.py reports."""
+optimisation loop per GPU, NO data-path collective.  torch.distributed is used only for the start/stop
+barrier and the max-over-ranks reduction of the elapsed time that bench.py reports: the default backend
+is gloo on the host (north_star: "no RCCL required" -- an RCCL communicator is only created when a caller
+asks for backend "nccl" explicitly)."""
 import os
 
 
@@ -19,7 +20,7 @@ class Replicas:
                 if backend == "nccl" and device is not None:
                     import torch
                     kw["device_id"] = torch.device(device)
-                dist.init_process_group(backend or "nccl", **kw)
+                dist.init_process_group(backend or "gloo", **kw)
             self.dist = dist
 
     def pair_id(self):

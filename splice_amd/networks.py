@@ -5,8 +5,9 @@
 (``1.0.1.0.weight`` ... ``9.0.bias``, the numbering of ``models/unet/common.py:6-9``) and are
 VIEWS into one flat fp32 arena, so ``torch.optim`` / ``state_dict`` / ``load_state_dict`` work
 unchanged while the engine reads and writes the arena directly.  The fused engine implements the reference's
-default architecture (``skip()`` with its default arguments, which is all ``define_G`` ever builds); any other
-``skip(...)`` arguments return a stock-PyTorch module (``unet_general.GeneralSkip``, used by ``inversion.py``).
+default architecture (``skip()`` with its default arguments, which is all ``define_G`` ever builds) and every other
+architecture its kernels cover (e.g. the 6-scale reflection-padded net of ``inversion.py``); what they do not cover returns a
+stock-PyTorch module (``unet_general.GeneralSkip``).  A fresh ``skip()`` carries PyTorch's constructor initialisation.
 """
 import math
 
@@ -148,26 +149,49 @@ def skip(num_input_channels=3, num_output_channels=3, num_channels_down=[16, 32,
                            filter_size_down, filter_size_up, filter_skip_size, need_sigmoid, need_tanh, need_bias, pad,
                            upsample_mode, downsample_mode, act_fun, need1x1_up).to(device)
     from .generator import DEFAULT_ARCH
-    if arch == DEFAULT_ARCH:
-        _burn_constructor_draws()
-        return SkipGenerator(device=device)
-    # e.g. the 6-scale reflection-padded 7/7/5/5/3/3 net of inversion.py:21-25: same HIP engine, its own architecture table
-    return SkipGenerator(device=device, arch=arch)
+    # The reference's skip() returns modules carrying PyTorch's CONSTRUCTOR initialisation (kaiming-uniform conv weights,
+    # uniform biases, BatchNorm gamma 1 / beta 0); define_G overwrites it through init_weights, inversion.py:21-25 trains
+    # from it as it is.  Same values here, drawn from the global CPU generator in the reference's construction order.
+    net = SkipGenerator(device=device, arch=None if arch == DEFAULT_ARCH else arch)
+    state = _constructor_state(arch)
+    with torch.no_grad():
+        for name, p in zip(net._kinds, net._plist):
+            p.copy_(state[name])
+    return net
 
 
-def _burn_constructor_draws():
-    """The reference builds ``skip()`` out of ``nn.Conv2d`` modules on the CPU; every constructor draws its default
-    (kaiming-uniform) weights and bias from the global CPU generator BEFORE ``init_weights`` overwrites them
-    (models/unet/skip.py:46-97, models/unet/common.py:121).  Consuming the same draws in the same order keeps
-    ``torch.manual_seed(s); define_G(...)`` on the reference's random stream, so a fixed seed gives the reference's
-    initial generator."""
-    down = up = [16, 32, 64, 128, 128]
-    for i, d in enumerate(down):
-        cin = 3 if i == 0 else down[i - 1]
-        k = up[i + 1] if i + 1 < len(down) else d
-        for ci, co, ks in ((cin, 4, 1), (cin, d, 3), (d, d, 3), (4 + k, up[i], 3), (up[i], up[i], 1)):
-            nn.Conv2d(ci, co, ks)
-    nn.Conv2d(up[0], 3, 1)
+def _constructor_state(arch):
+    """{state_dict name: CPU tensor} of a freshly CONSTRUCTED ``skip()`` net.  The reference builds it out of ``nn.Conv2d`` /
+    ``nn.BatchNorm2d`` modules on the CPU, scale by scale (models/unet/skip.py:46-97: skip conv, the two down convs, the two up
+    convs of scale i, then scale i + 1, ..., the head last; models/unet/common.py:121); every ``nn.Conv2d`` constructor draws its
+    default weights and bias from the global CPU generator.  Building the same modules in the same order gives the same
+    tensors for a fixed ``torch.manual_seed`` -- and leaves the generator where the reference leaves it, so that
+    ``torch.manual_seed(s); define_G(...)`` continues on the reference's random stream."""
+    down, up, skipc = arch["num_channels_down"], arch["num_channels_up"], arch["num_channels_skip"]
+    kd, ku, ks = arch["filter_size_down"], arch["filter_size_up"], arch["filter_skip_size"]
+    cv = ".1" if arch["pad"] == "reflection" else ".0"
+    n, state, prefix = len(down), {}, ""
+
+    def conv(name, cin, cout, k):
+        m = nn.Conv2d(cin, cout, k)
+        state[name + cv + ".weight"], state[name + cv + ".bias"] = m.weight.detach().clone(), m.bias.detach().clone()
+
+    def bn(name, c):
+        state[name + ".weight"], state[name + ".bias"] = torch.ones(c), torch.zeros(c)
+
+    for i in range(n):
+        cin = arch["num_input_channels"] if i == 0 else down[i - 1]
+        k = up[i + 1] if i + 1 < n else down[i]
+        p = prefix
+        conv(p + "1.0.1", cin, skipc[i], ks); bn(p + "1.0.2", skipc[i])
+        conv(p + "1.1.1", cin, down[i], kd[i]); bn(p + "1.1.2", down[i])
+        conv(p + "1.1.4", down[i], down[i], kd[i]); bn(p + "1.1.5", down[i])
+        bn(p + "2", skipc[i] + k)
+        conv(p + "3", skipc[i] + k, up[i], ku[i]); bn(p + "4", up[i])
+        conv(p + "6", up[i], up[i], 1); bn(p + "7", up[i])
+        prefix += "1.1.7."
+    conv("9", up[0], arch["num_output_channels"], 1)
+    return state
 
 
 _CONV_INIT = {  # init_type -> in-place initialiser of a conv weight (models/networks.py:30-39)

@@ -80,3 +80,11 @@ def test_group_equal_sizes():
     groups, singles = group_equal_sizes(idx, sizes, 2)
     assert groups == [[0, 2], [1, 6], [3, 5]] and singles == [4, 7]
     assert group_equal_sizes([3], [a], 8) == ([], [3])
+
+
+def test_custom_runner_needs_a_group_runner_when_pairs_share_launches(tmp_path):
+    """with pairs_per_gpu > 1 the grouped pairs go through the GROUP runner; a custom runner alone is rejected
+    (it used to be ignored silently for them)."""
+    _make_pairs(tmp_path, 2)
+    with pytest.raises(ValueError, match="group_runner"):
+        batch.run_batch(str(tmp_path), 1, runner="test_batch_cpu:stub_runner", pin_gpu=False, pairs_per_gpu=2)

@@ -117,7 +117,7 @@ def test_inversion_net_on_hip_matches_reference_golden(golden_dir):
     instantiations, reflected gather, padded-domain data gradient + mirror fold, row-tiled weight gradient), against the
     outputs and parameter gradients recorded from the REFERENCE's models/unet/skip.py (tests/golden/inversion_net.npz, the
     fixture that also pins the CPU GeneralSkip).  96x72 and 100x84 (the second exercises Concat's centre crop on odd sizes)."""
-    from oracle.make_golden import INVERSION_NET, sample, stats
+    from oracle.fixtures import INVERSION_NET, sample, stats
     from splice_amd.networks import SkipGenerator, skip
     from splice_amd.unet_general import GeneralSkip
     g = np.load(os.path.join(golden_dir, "inversion_net.npz"))
@@ -144,11 +144,12 @@ def test_inversion_net_on_hip_matches_reference_golden(golden_dir):
         kinds = [k for _, _, k in net.engine.param_specs]
         live = np.array([not (k == "conv_b" and n != params[-1][0]) for (n, _), k in zip(params, kinds)])
         assert (gs[~live, 1] == 0).all()
-        # per tensor: sum |g| and sum g^2 (the fixture stores no more); fp32 summation order differs from ATen's and is amplified
-        # by the train-mode BatchNorm of the 2x2 planes at the 6th scale, so tiny-gradient tensors carry percent-level noise:
-        # 7e-2 per tensor above 1e-6, and the whole-arena sums to 1e-2
-        big = live & (ref[:, 1] > 1e-6)
-        np.testing.assert_allclose(gs[big, 1:], ref[big, 1:], rtol=7e-2)   # worst measured 5.1e-2 (one tensor with sum g^2 = 7e-11; the bar was 5e-2 until the BatchNorm kernels got their per-plane-size instantiations: rounding-level changes move this tensor by a few per cent)
+        # per tensor: sum |g| and sum g^2 (the fixture stores no more) at 5e-2.  Tensors whose whole gradient is rounding-level
+        # (sum g^2 < 1e-9: behind the train-mode BatchNorm of the 2x2 planes at the 6th scale) are excluded from THIS check by
+        # that explicit rule -- they are covered element-wise by the fp64 comparison below -- instead of a bar that follows them.
+        big = live & (ref[:, 1] > 1e-6) & (ref[:, 2] >= 1e-9)
+        assert big.sum() >= 0.8 * live.sum()
+        np.testing.assert_allclose(gs[big, 1:], ref[big, 1:], rtol=5e-2)
         np.testing.assert_allclose(gs[live, 1:].sum(0), ref[live, 1:].sum(0), rtol=1e-2)
         # element-wise: every parameter gradient against the same architecture in fp64 (stock PyTorch modules, CPU) -- the fp32
         # reference itself sits 3e-3..6e-3 from fp64 on these ill-conditioned sums
@@ -167,3 +168,29 @@ def test_inversion_net_on_hip_matches_reference_golden(golden_dir):
         rel = (num / den) ** 0.5
         print(f"    inversion net {tag}: whole-arena gradient rel-L2 vs fp64 = {rel:.3e}")
         assert rel < 1e-2, rel
+
+
+def test_fresh_inversion_net_is_initialised_and_trainable():
+    """``inversion.make_net()`` -- ``skip()`` of a non-default architecture WITHOUT init_weights, as
+    inversion.py:21-25 uses it -- must carry PyTorch's constructor initialisation (the reference's modules do), not an all-zero
+    arena: non-zero conv weights / BatchNorm gains, and non-zero gradients on the conv weights after one backward."""
+    from splice_amd import inversion
+    from splice_amd.networks import SkipGenerator
+    torch.manual_seed(5)
+    net = inversion.make_net(8)
+    assert isinstance(net, SkipGenerator)
+    kinds = {n: k for n, _, k in net.engine.param_specs}
+    for n, p in net.named_parameters():
+        if kinds[n] == "conv_w":
+            bound = 1.0 / (p.shape[1] * p.shape[2] * p.shape[3]) ** 0.5        # kaiming_uniform(a = sqrt 5): U(-1/sqrt(fan_in), +)
+            assert 0.3 * bound < p.abs().mean().item() < bound and p.abs().max().item() <= bound * (1 + 1e-6), n
+        elif kinds[n] == "bn_w":
+            assert (p == 1).all(), n
+        elif kinds[n] == "bn_b":
+            assert (p == 0).all(), n
+    x = torch.randn(1, 8, 64, 64, device=DEV)
+    y = net(x)
+    assert y.std().item() > 1e-4                                     # not a constant colour
+    (y - torch.rand_like(y)).pow(2).mean().backward()
+    live = [n for n, p in net.named_parameters() if kinds[n] == "conv_w" and p.grad.abs().sum().item() > 0]
+    assert len(live) == sum(1 for k in kinds.values() if k == "conv_w"), "every conv weight must receive gradient"

@@ -146,7 +146,7 @@ def test_general_skip_matches_reference_inversion_net(golden_dir):
     """splice_amd.unet_general.GeneralSkip (the non-default skip() used by inversion.py) against outputs and parameter
     gradients recorded from the reference's models/unet/skip.py with the same position-seeded parameters."""
     from splice_amd.networks import skip
-    from oracle.make_golden import INVERSION_NET, sample, stats
+    from oracle.fixtures import INVERSION_NET, sample, stats
     g = np.load(os.path.join(golden_dir, "inversion_net.npz"))
     net = skip(8, 3, device="cpu", **INVERSION_NET)
     params = list(net.named_parameters())
@@ -177,9 +177,38 @@ def test_define_g_seed_parity(golden_dir):
     for key in [k for k in g.files if k.endswith("/stats")]:
         init_type, seed, _ = key.split("/")
         torch.manual_seed(int(seed))
-        networks._burn_constructor_draws()
+        from splice_amd.generator import DEFAULT_ARCH
+        networks._constructor_state(DEFAULT_ARCH)      # what skip() draws while it builds the modules
         state = networks._draw_initial_state(init_type, 0.02)
         got_stats = np.stack([[t.double().sum().item(), t.double().abs().sum().item(), (t.double() ** 2).sum().item()] for t in state.values()])
         got_samples = np.stack([sample(t) for t in state.values()])
         assert np.array_equal(got_samples, g[f"{init_type}/{seed}/samples"]), key
         np.testing.assert_allclose(got_stats, g[key], rtol=1e-12, atol=0)
+
+
+def test_skip_constructor_init_parity(golden_dir):
+    """A fresh ``skip(...)`` (no init_weights: what inversion.py:21-25 trains from) carries the reference's constructor
+    initialisation for a fixed seed -- kaiming-uniform conv weights, uniform biases, BatchNorm 1 / 0 -- and leaves the global
+    generator where the reference leaves it.  Fixture recorded from models/unet/skip.py by oracle/make_golden.py.  (ADVICE r2:
+    the HIP path used to return an all-zero arena for non-default architectures.)"""
+    from oracle.fixtures import INVERSION_NET
+    from splice_amd import networks
+    from splice_amd.generator import DEFAULT_ARCH, arch_param_specs
+    g = np.load(os.path.join(golden_dir, "skip_constructor_init.npz"))
+    inv = dict(num_input_channels=32, num_output_channels=3, num_channels_down=INVERSION_NET["num_channels_down"], num_channels_up=INVERSION_NET["num_channels_up"],
+               num_channels_skip=INVERSION_NET["num_channels_skip"], filter_size_down=INVERSION_NET["filter_size_down"], filter_size_up=INVERSION_NET["filter_size_up"],
+               filter_skip_size=1, pad="reflection")
+    sample = lambda t, n=8: np.resize(t.reshape(-1)[::max(1, t.numel() // n)][:n].numpy(), n)
+    for key in [k for k in g.files if k.endswith("/stats")]:
+        tag, seed, _ = key.split("/")
+        arch = inv if tag == "inversion" else DEFAULT_ARCH
+        torch.manual_seed(int(seed))
+        state = networks._constructor_state(arch)
+        nxt = torch.rand(4).numpy()
+        ordered = [state[name] for name, _, _ in arch_param_specs(arch)]          # parameters() order
+        assert len(ordered) == len(state)
+        got_stats = np.stack([[t.double().sum().item(), t.double().abs().sum().item(), (t.double() ** 2).sum().item()] for t in ordered])
+        assert np.array_equal(np.stack([sample(t) for t in ordered]), g[f"{tag}/{seed}/samples"]), key
+        np.testing.assert_allclose(got_stats, g[key], rtol=1e-12, atol=0)
+        assert np.array_equal(nxt, g[f"{tag}/{seed}/next_draw"]), key
+        assert all(float(t.abs().sum()) > 0 for (name, _, kind), t in zip(arch_param_specs(arch), ordered) if kind in ("conv_w", "bn_w"))
