@@ -96,6 +96,62 @@ class _VitFeatures(torch.autograd.Function):
         return d_img, None, None
 
 
+class _VitProbs(torch.autograd.Function):
+    """img [1,3,H,W] (normalised) -> attention probabilities [L, heads, T, T] fp32 (softmax(q k^T / sqrt d), the tensor the
+    reference hooks behind ``attn_drop``, models/extractor.py:44-45,62-66).  The engine's fused attention never materialises
+    them; ``splice_attention_probs`` rebuilds a layer's matrix from its saved q, k and log-sum-exp.  Backward: the softmax
+    adjoint dS = P * (dP - rowsum(dP * P)) and the two score products dq = dS k / sqrt d, dk = dS^T q / sqrt d as plain device
+    matmuls (this API is off the optimisation path: nothing in train.py reads the probabilities), then the engine's dgrad
+    from the layer's qkv down to the image."""
+
+    @staticmethod
+    def forward(ctx, img, extractor, need_grad):
+        eng = extractor.engine
+        _, _, H, W = img.shape
+        vctx = extractor._acquire(H, W, need_grad)
+        vctx.forward(img.contiguous().float(), normalize=False)
+        T = vctx.T
+        L = _lib.lib()
+        probs = torch.empty(eng.depth, eng.heads, T, T, device=img.device)
+        for l in range(eng.depth):
+            qkv = vctx.read(KIND_QKV, l)
+            lse = vctx.read(KIND_LSE, l)
+            _lib.check(L.splice_attention_probs(_lib.ptr(qkv), 1, T, vctx.Tld, eng.dim, eng.heads, 0.125, _lib.ptr(lse),
+                                                _lib.ptr(probs[l]), _lib.current_stream()), "attention_probs")
+        ctx.vctx, ctx.extractor, ctx.need_grad = vctx, extractor, need_grad
+        if need_grad:
+            ctx.save_for_backward(probs)
+        else:
+            extractor._release(vctx)
+        return probs
+
+    @staticmethod
+    def backward(ctx, d_probs):
+        if not ctx.need_grad:
+            return None, None, None
+        vctx, ext = ctx.vctx, ctx.extractor
+        (probs,) = ctx.saved_tensors
+        eng = ext.engine
+        T, Tld, D, H = vctx.T, vctx.Tld, eng.dim, eng.heads
+        d = D // H
+        dq_all = {}
+        for l in range(eng.depth):
+            dP = d_probs[l]
+            if not bool(dP.any()):
+                continue
+            P = probs[l]
+            dS = P * (dP - (dP * P).sum(-1, keepdim=True))                       # [H, T, T]
+            qkv = vctx.read(KIND_QKV, l)[0, :T].float().reshape(T, 3, H, d)
+            q, k = qkv[:, 0].transpose(0, 1), qkv[:, 1].transpose(0, 1)          # [H, T, d]
+            g = torch.zeros(1, Tld, 3 * D, device=dP.device)
+            g[0, :T, :D] = (0.125 * torch.bmm(dS, k)).transpose(0, 1).reshape(T, D)
+            g[0, :T, D:2 * D] = (0.125 * torch.bmm(dS.transpose(1, 2), q)).transpose(0, 1).reshape(T, D)
+            dq_all[l] = g
+        d_img = vctx.backward(0, 1, None, dq_all or None, None, normalize=False) if dq_all else torch.zeros(1, 3, vctx.H, vctx.W, device=d_probs.device)
+        ext._release(vctx)
+        return d_img, None, None
+
+
 class VitExtractor:
     BLOCK_KEY = 'block'
     ATTN_KEY = 'attn'
@@ -152,22 +208,13 @@ class VitExtractor:
         return [qkv[l][None] for l in range(qkv.shape[0])]
 
     def get_attn_feature_from_input(self, input_img):
-        eng = self.engine
-        img = input_img.to(self.device).detach().contiguous().float()
-        _, _, H, W = img.shape
-        vctx = self._acquire(H, W, False)
-        vctx.forward(img, normalize=False)
-        out = []
-        L = _lib.lib()
-        for l in range(eng.depth):
-            qkv = vctx.read(KIND_QKV, l)
-            lse = vctx.read(KIND_LSE, l)
-            probs = torch.empty(1, eng.heads, vctx.T, vctx.T, device=self.device)
-            _lib.check(L.splice_attention_probs(_lib.ptr(qkv), 1, vctx.T, vctx.Tld, eng.dim, eng.heads, 0.125, _lib.ptr(lse),
-                                                _lib.ptr(probs), _lib.current_stream()), "attention_probs")
-            out.append(probs)
-        self._release(vctx)
-        return out
+        """The hooked attention probabilities of every layer, List([1, heads, T, T]) (models/extractor.py:97-103).  Like the
+        reference's hooked ``attn_drop`` outputs they carry grad with respect to the input image when it requires grad."""
+        if input_img.dim() != 4 or input_img.shape[0] != 1:
+            raise ValueError("VitExtractor expects a [1,3,H,W] image (the reference's key slicing is batch-1 only)")
+        img = input_img.to(self.device)
+        probs = _VitProbs.apply(img, self, bool(torch.is_grad_enabled() and img.requires_grad))
+        return [probs[l][None] for l in range(probs.shape[0])]
 
     # ---- shape helpers + q/k/v slicing (models/extractor.py:105-156) -------------------------------------------------
     # The reference derives (patch, heads, width) from sub-strings of the model name on every call; the four DINO names it

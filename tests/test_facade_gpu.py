@@ -176,3 +176,39 @@ def test_inversion_script_smoke(tmp_path):
         assert np.mean(losses[-5:]) < np.mean(losses[:5])
         assert (tmp_path / f"inv_{feature}.png").exists()
     assert inversion.noise_scale(0, 10, 20) == 10.0 and inversion.noise_scale(10, 10, 20) == 2.0 and inversion.noise_scale(20, 10, 20) == 0.5
+
+
+def test_attn_probabilities_carry_grad():
+    """models/extractor.py:97-103: the hooked attention probabilities are part of the autograd graph of the input image.
+    d/d img of <W, probs[l]> summed over two layers, against the fp32 oracle (oracle/dino_vit.py forward_features) --
+    values 1e-2 (bf16 scores), image gradient 6e-2 rel-L2 / cos > 0.995 (bf16 ViT dgrad behind an fp32 softmax adjoint)."""
+    from oracle import dino_vit
+    from splice_amd.extractor import VitExtractor
+    name, S = "dino_vits8", 32
+    sd = synth.vit_params(7, name, img_size=S, w_std=0.05)
+    patch, dim, depth, heads = dino_vit.DINO_CONFIGS[name]
+    m = dino_vit.VisionTransformer(patch, dim, depth, heads, img_size=S).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    for p in m.parameters():
+        p.requires_grad_(False)
+    ext = VitExtractor(name, DEV, state_dict=sd)
+    x0 = torch.from_numpy(synth.normal(13, "img32", (1, 3, S, S)))
+    T = 1 + (S // 8) ** 2
+    W = {l: torch.from_numpy(synth.normal(14, f"wp{l}", (1, heads, T, T))) for l in (3, 11)}
+    xo = x0.clone().requires_grad_(True)
+    fo = dino_vit.forward_features(m, xo)
+    sum(((fo["attn"][l] * W[l]).sum() for l in W)).backward()
+    xg = x0.clone().to(DEV).requires_grad_(True)
+    probs = ext.get_attn_feature_from_input(xg)
+    assert len(probs) == 12 and probs[0].shape == (1, heads, T, T) and probs[3].requires_grad
+    for l in W:
+        assert (probs[l].detach().cpu() - fo["attn"][l].detach()).abs().max().item() < 1e-2
+        assert abs(probs[l].detach().sum(-1) - 1).max().item() < 1e-4
+    sum(((probs[l] * W[l].to(DEV)).sum() for l in W)).backward()
+    g, go = xg.grad.cpu().double(), xo.grad.double()
+    rel = ((g - go).norm() / go.norm()).item()
+    cos = (g.flatten() @ go.flatten() / (g.norm() * go.norm())).item()
+    print(f"    d<W,probs>/d img: rel-L2 {rel:.3e} cos {cos:.5f}")
+    assert rel < 6e-2 and cos > 0.995
+    with torch.no_grad():                       # no graph, no saved context
+        assert not ext.get_attn_feature_from_input(x0.to(DEV))[0].requires_grad

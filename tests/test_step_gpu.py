@@ -389,3 +389,23 @@ def test_outlier_weights_step_vs_oracle(name, size):
     orc = _oracle_for(name, size, vit_state, gen_state, cfg)
     wl, wg = _teacher_forced(eng, orc, A, B, A, 3, loss_tol=2e-2, grad_tol=3e-2, tag=f"outlier/{name}")
     print(f"    outlier-weight {name}: worst loss rel err {wl:.3e}, worst gradient rel err {wg:.3e}")
+
+
+@pytest.mark.skipif(not os.environ.get("SPLICE_DINO_CHECKPOINT"), reason="SPLICE_DINO_CHECKPOINT unset: no trained DINO .pth on this box (none can be fetched offline)")
+def test_real_dino_checkpoint_steps_vs_oracle():
+    """every ViT in the other tests is synthetic (incl. the outlier-statistics stand-in).  With a real DINO
+    checkpoint at hand -- ``SPLICE_DINO_CHECKPOINT=/path/dino_vitbase8_pretrain.pth`` (any of the four variants; the variant is
+    read from ``SPLICE_DINO_MODEL``, default dino_vitb8) -- the teacher-forced steps 0, 1, 2 of a 224x224 pair run against the
+    fp32 CPU oracle loaded from the SAME file, at the bars of the outlier-weights test (losses 2e-2, whole-arena gradient 3e-2)."""
+    from splice_amd.checkpoint import load_dino_checkpoint
+    from splice_amd.engine import SpliceEngine
+    name = os.environ.get("SPLICE_DINO_MODEL", "dino_vitb8")
+    got_name, vit_state = load_dino_checkpoint(os.environ["SPLICE_DINO_CHECKPOINT"], name)
+    assert got_name == name
+    vit_state = {k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in vit_state.items()}
+    cfg = dict(dino_model_name=name, dino_global_patch_size=224)
+    A, B = synth.smooth_image_pair(123, 0, 224, 224)
+    gen_state = synth.generator_params(9, 0.02)
+    eng = SpliceEngine(cfg, vit_state, gen_state, (224, 224), (224, 224))
+    orc = _oracle_for(name, 224, vit_state, gen_state, cfg)
+    _teacher_forced(eng, orc, A, B, A, 3, loss_tol=2e-2, grad_tol=3e-2, tag="real checkpoint")
