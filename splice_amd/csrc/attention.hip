@@ -63,9 +63,10 @@ typedef __attribute__((address_space(1))) const void glb_void;
 struct TileDma {
     int wave;                 // scalar
     int lrow, tchunk, dchunk;
+    // w4 = index of the wave inside its group of 4 (a group moves one tile set; 8-wave workgroups hold two groups)
     __device__ __forceinline__ TileDma() {
         const int lane = threadIdx.x & 63;
-        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3;
         lrow = lane >> 3;
         tchunk = (lane & 7) ^ ((wave << 1) | ((lrow >> 1) & 1));   // token tile: row = piece*8 + lrow, piece & 3 == wave
         dchunk = (lane & 7) ^ lrow;                                // dim tile:   row & 7 == lrow
@@ -224,11 +225,19 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
     }
 }
 
-template <int QB>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, int nx) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * 4096];   // [stage][K | V^T] tiles
+// KS = 2: the workgroup holds TWO groups of 4 waves that own the SAME queries; group 0 walks the first half of the key tiles,
+// group 1 the second half (own LDS ring each), and group 0 merges the two partial softmax states (m, l, O) at the end -- the
+// exact online-softmax merge, through LDS.  At one pair per GPU a (pass, head) offers 13 blocks of 64 queries: 312 workgroups
+// = 1.2 waves per SIMD that each walk 13 key tiles one after the other with nothing to overlap their LDS / MFMA / exp
+// latencies (profiles/r02_pmc_attn_selfsim_p1.txt: 47 % of the wave cycles parked).  Two groups give every SIMD a second
+// wave and halve the serial walk.  Every launch uses the same split (it does not depend on the batch), so a pass's output
+// bits do not depend on how many passes share the launch.
+template <int QB, int KS>
+__global__ __launch_bounds__(256 * KS) void attn_fwd_kernel(AttnArgs a, int nx) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[KS * 2 * 2 * 4096];   // [group][stage][K | V^T] tiles
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
+    const int grp = KS > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
     int xb, h, b;
     attn_block_coords(nx, a.H, a.B, xb, h, b);
     const int ld = 3 * a.D;
@@ -260,7 +269,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, int nx) {
             dma.dim_tile(vT, a.ldt, kt, a.Tld, st + 4096);
         }
     };
-    issue(0, smem);
+    // key tiles with at least one valid key: [0, nt); group grp owns [t0, t1)
+    const int nt = (a.T + 63) / 64, per = (nt + 1) / 2;    // the key range is ALWAYS split in two (same bits for every launch form)
+    const int t0 = KS > 1 ? grp * per : 0, t1 = KS > 1 ? min(nt, t0 + per) : nt;
+    bf16_t* ring = smem + grp * (2 * 8192);
+    if (t0 < t1) issue(t0 * 64, ring);
     float m[QB], l[QB];
     f32x4 o[QB][4];
 #pragma unroll
@@ -271,23 +284,85 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, int nx) {
         for (int nd = 0; nd < 4; ++nd) o[qb][nd] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float c2 = a.scale * LOG2E;
-    const int nfull = a.T / 64;   // tiles without padding keys
-    for (int it = 0; it < nfull; ++it) {
-        dma_wait_barrier();   // tile `it` has landed; tile it-1 fully consumed
-        const int kn = it * 64 + 64;
-        if (kn < a.Tld) issue(kn, smem + ((it + 1) & 1) * 8192);
-        if (active) {
-            const bf16_t* cur = smem + (it & 1) * 8192;
-            attn_fwd_tile<QB, 2, false>(cur, cur + 4096, fa, qf, m, l, o, c2, it * 64, a.T, g);
+    auto run_tile = [&](int tile, const bf16_t* cur) {
+        const int kt = tile * 64;
+        if (kt + 64 <= a.T) attn_fwd_tile<QB, 2, false>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g);
+        // last tile: padding keys masked, second sub-tile skipped when it is all padding
+        else if (kt + 32 < a.T) attn_fwd_tile<QB, 2, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g);
+        else attn_fwd_tile<QB, 1, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g);
+    };
+    if (KS == 1) {
+        // One group walks BOTH key ranges, one after the other, with a softmax state of its own for each, and merges them
+        // with the arithmetic of the two-group form below: bit for bit the same output (the batched launches keep their
+        // 4-wave workgroups -- many waves per SIMD anyway -- without making a pass's result depend on the batch size).
+        const int per2 = (nt + 1) / 2;
+        float m0[QB], l0[QB];
+        f32x4 o0[QB][4];
+        for (int it = 0; it < nt; ++it) {
+            dma_wait_barrier();
+            if (it + 1 < nt) issue((it + 1) * 64, ring + ((it + 1) & 1) * 8192);
+            if (it == per2) {   // second range: park the first state
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    m0[qb] = m[qb]; l0[qb] = l[qb];
+                    m[qb] = NEG_BIG; l[qb] = 0.f;
+#pragma unroll
+                    for (int nd = 0; nd < 4; ++nd) { o0[qb][nd] = o[qb][nd]; o[qb][nd] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                }
+            }
+            if (active) run_tile(it, ring + (it & 1) * 8192);
+        }
+        if (nt > per2) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float m1 = m[qb], l1 = l[qb];
+                const float mn = fmaxf(m0[qb], m1);
+                const float a0 = __builtin_amdgcn_exp2f(m0[qb] - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
+                m[qb] = mn;
+                l[qb] = l0[qb] * a0 + l1 * a1;
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[qb][nd][r] = o0[qb][nd][r] * a0 + o[qb][nd][r] * a1;
+            }
+        }
+    } else {
+        for (int it = 0; it < per; ++it) {
+            dma_wait_barrier();   // tile `it` of every group has landed; tile it-1 fully consumed
+            const int tile = t0 + it;
+            if (tile + 1 < t1) issue((tile + 1) * 64, ring + ((it + 1) & 1) * 8192);
+            if (active && tile < t1) run_tile(tile, ring + (it & 1) * 8192);
         }
     }
-    if (nfull * 64 < a.T) {   // last tile: padding keys masked, second sub-tile skipped when it is all padding
-        dma_wait_barrier();
-        const int kt = nfull * 64;
-        if (active) {
-            const bf16_t* cur = smem + (nfull & 1) * 8192;
-            if (kt + 32 < a.T) attn_fwd_tile<QB, 2, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g);
-            else attn_fwd_tile<QB, 1, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g);
+    if (KS > 1) {   // merge the groups' partial states: lane for lane (same query, same output columns in both groups)
+        float* ex = reinterpret_cast<float*>(smem);   // [wave4][QB][18][64]
+        __syncthreads();                              // every ring is idle
+        if (grp == 1) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float* e = ex + ((dma.wave * QB + qb) * 18) * 64 + lane;
+                e[0] = m[qb];
+                e[64] = l[qb];
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e[(2 + nd * 4 + r) * 64] = o[qb][nd][r];
+            }
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const float* e = ex + ((dma.wave * QB + qb) * 18) * 64 + lane;
+            const float m1 = e[0], l1 = e[64];
+            const float mn = fmaxf(m[qb], m1);
+            const float a0 = __builtin_amdgcn_exp2f(m[qb] - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
+            m[qb] = mn;
+            l[qb] = l[qb] * a0 + l1 * a1;
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[qb][nd][r] = o[qb][nd][r] * a0 + e[(2 + nd * 4 + r) * 64] * a1;
         }
     }
     if (!active) return;
@@ -600,10 +675,22 @@ int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
     // fragment reuse at ViT-B/8 @ 224: 2400 wave tasks on 1024 SIMDs); 32 per wave for the long sequences.
     const long tasks = (long)a->B * a->H * cdiv(a->Tld, 16);
     static const long qb2_tasks = getenv("SPLICE_ATTN_QB2_TASKS") ? atol(getenv("SPLICE_ATTN_QB2_TASKS")) : 3600;
-    const int qb = g_attn_variant ? g_attn_variant : (tasks > qb2_tasks ? 2 : 1);
+    // variant (benchmarking hook): queries per wave / 16 + 10 * (key groups - 1); 0 = automatic
+    const int qb = g_attn_variant ? g_attn_variant % 10 : (tasks > qb2_tasks ? 2 : 1);
+    // two wave groups per workgroup (key range halves side by side) while the launch leaves SIMDs short of waves; the batched
+    // launches walk the two halves in one group (same arithmetic, same bits).  In-step A/B, same box: -0.9 % step time at one
+    // pair per GPU with two groups, +1.0 % at eight (profiles/r03_ab_preload.txt).
+    static const long ks2_tasks = getenv("SPLICE_ATTN_KS2_TASKS") ? atol(getenv("SPLICE_ATTN_KS2_TASKS")) : 3600;
+    const int ks = g_attn_variant ? g_attn_variant / 10 + 1 : (tasks > ks2_tasks ? 1 : 2);
     const int nx = cdiv(a->Tld, 64 * qb);
-    if (qb == 2) SPLICE_LAUNCH(attn_fwd_kernel<2>, dim3(nx * a->H * a->B), dim3(256), 0, s, *a, nx);
-    else SPLICE_LAUNCH(attn_fwd_kernel<1>, dim3(nx * a->H * a->B), dim3(256), 0, s, *a, nx);
+    const dim3 grid(nx * a->H * a->B);
+    if (ks == 2) {
+        if (qb == 2) SPLICE_LAUNCH((attn_fwd_kernel<2, 2>), grid, dim3(512), 0, s, *a, nx);
+        else SPLICE_LAUNCH((attn_fwd_kernel<1, 2>), grid, dim3(512), 0, s, *a, nx);
+    } else {
+        if (qb == 2) SPLICE_LAUNCH((attn_fwd_kernel<2, 1>), grid, dim3(256), 0, s, *a, nx);
+        else SPLICE_LAUNCH((attn_fwd_kernel<1, 1>), grid, dim3(256), 0, s, *a, nx);
+    }
     return SPLICE_OK;
 }
 

@@ -502,7 +502,9 @@ __device__ __forceinline__ void gemm_stage_store_f32(const f32x4 (&acc)[BM / 32]
 
 template <int BM, int BN, unsigned FLAGS, int NS, bool FP8 = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
-                                                      int ldb, int M, int N, int K, GemmEpi e, int gm, int ksplit) {
+                                                      int ldb, int M, int N, int K, int gm, int ksplit, GemmEpi e) {
+    // (argument order: what the tile mapping and the K loop need comes first, as scalars -- the leading kernel arguments are
+    // preloaded into SGPRs by the dispatcher (-amdgpu-kernarg-preload-count), the epilogue description is fetched meanwhile)
     extern __shared__ __attribute__((aligned(16))) bf16_t gemm_smem[];   // NS * LDS_ELEMS
     const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
     const int nwg = gridDim.x;
@@ -719,5 +721,5 @@ static inline void launch_gemm_nt(hipStream_t s, const bf16_t* A, int lda, const
             done_mask.fetch_or(bit, std::memory_order_relaxed);
         }
     }
-    SPLICE_LAUNCH((gemm_nt_kernel<BM, BN, FLAGS, NS, FP8>), dim3(grid), dim3(256), lds, s, A, lda, B, ldb, M, N, K, e, gm, ksplit);
+    SPLICE_LAUNCH((gemm_nt_kernel<BM, BN, FLAGS, NS, FP8>), dim3(grid), dim3(256), lds, s, A, lda, B, ldb, M, N, K, gm, ksplit, e);
 }
