@@ -76,23 +76,27 @@ typedef struct splice_gemm_epilogue {
     float* rowdot;
     /* SPLICE_EPI_SCALE_RC (fp8 operands): C[m][n] *= row_scale[m] * col_scale[n] before the bias -- the per-token scale of the
      * quantised activations times the per-output-channel scale of the quantised weights */
-    const float* row_scale;        /* [M] */
+    const float* row_scale;        /* [M]; NULL = 1 (unscaled e4m3 activations) */
     const float* col_scale;        /* [N] */
+    /* SPLICE_EPI_OUT_F8: the result as e4m3 bytes [M][ld8] (saturated at +-448, no scale: the format's relative precision holds
+     * over 2^-9 .. 448) -- the GELU output of fc1 as the operand of the fp8 fc2.  N % 16 == 0, ld8 % 16 == 0. */
+    uint8_t* out_f8;
+    int ld8;
 } splice_gemm_epilogue;
 
 enum {
     SPLICE_EPI_BIAS = 1, SPLICE_EPI_RESID = 2, SPLICE_EPI_OUT_F32 = 4, SPLICE_EPI_OUT_BF = 8,
     SPLICE_EPI_OUT_T = 16, SPLICE_EPI_GELU = 32, SPLICE_EPI_GELU_GRAD = 64,
-    SPLICE_EPI_COLS_F32 = 128, SPLICE_EPI_ALPHA = 256, SPLICE_EPI_ROWDOT = 512, SPLICE_EPI_SCALE_RC = 1024
+    SPLICE_EPI_COLS_F32 = 128, SPLICE_EPI_ALPHA = 256, SPLICE_EPI_ROWDOT = 512, SPLICE_EPI_SCALE_RC = 1024, SPLICE_EPI_OUT_F8 = 2048
 };
 
 int splice_gemm_nt_bf16(unsigned flags, const splice_bf16* A, int lda, const splice_bf16* B, int ldb,
                         int M, int N, int K, const splice_gemm_epilogue* epi, splice_stream_t stream);
 
-/* The same product with e4m3 (OCP fp8) operands on the gfx950 fp8 MFMA (v_mfma_f32_16x16x32_fp8_fp8, non-scaled: bf16 issue
- * rate, half the operand bytes): A [M][K] and B [N][K] are bytes, lda / ldb in bytes (multiples of 16), K % 128 == 0.
- * BASELINE configs[4] ("fp8 MFMA attention + self-sim path"): used for the QKV projection when the ViT engine runs in
- * fp8 mode (splice_vit_enable_fp8).  flags must contain SPLICE_EPI_SCALE_RC or SPLICE_EPI_ALPHA for the de-quantisation. */
+/* The same product with e4m3 (OCP fp8) operands on the gfx950 block-scaled K = 128 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4
+ * with unit block scales: twice the bf16 issue rate, half the operand bytes): A [M][K] and B [N][K] are bytes, lda / ldb in
+ * bytes (multiples of 16), K % 128 == 0.  BASELINE configs[4] ("fp8 MFMA attention + self-sim path"): the QKV, fc1 and fc2
+ * projections of a ViT context in fp8 mode (splice_vit_ctx_set_fp8).  flags must contain SPLICE_EPI_SCALE_RC. */
 int splice_gemm_nt_fp8(unsigned flags, const uint8_t* A, int lda, const uint8_t* B, int ldb, int M, int N, int K,
                        const splice_gemm_epilogue* epi, splice_stream_t stream);
 /* Row-wise e4m3 quantisation: q[r][:] = fp8(x[r][:] * 448 / amax_r), scale[r] = amax_r / 448 (x ~= q * scale[r]).
@@ -174,9 +178,10 @@ int splice_vit_create(int patch, int dim, int depth, int heads, void** out_handl
 void splice_vit_destroy(void* vit);
 int splice_vit_set_param(void* vit, const char* name, const float* data, long long numel, splice_stream_t stream);
 int splice_vit_params_complete(void* vit);
-/* BASELINE configs[4] fp8 path: contexts created AFTER this call run their QKV projections on the fp8 MFMA (e4m3 LayerNorm
- * output with per-token scales x e4m3 weights with per-output-channel scales, de-quantised in the GEMM epilogue).
- * dim % 128 == 0.  The backward (dgrad through bf16 weights) is unchanged. */
+/* BASELINE configs[4] fp8 path: prepares e4m3 copies of the QKV / fc1 / fc2 weights (per-output-channel scales).  A context
+ * opts in with splice_vit_ctx_set_fp8: its three big forward projections then run on the fp8 MFMA (e4m3 LayerNorm outputs with
+ * per-token scales, e4m3 GELU output), de-quantised in the GEMM epilogues.  dim % 128 == 0.  The backward (dgrad through bf16
+ * weights) is unchanged. */
 int splice_vit_enable_fp8(void* vit, splice_stream_t stream);
 /* A context = one (batch, image shape): owns the activations of the last forward.
  * pos_TD: position table for this token grid, fp32 [T][dim] (interpolate_pos_encoding done
@@ -190,6 +195,8 @@ int splice_vit_ctx_info(void* ctx, int* T, int* Tld, int* rows);
  * undefined for layer depth-1, and d_block[depth-1] must be zero outside the [CLS] rows.  splice_step_create switches its
  * contexts to this mode; the extractor API (models/extractor.py:81-103 hands out every token) never does. */
 int splice_vit_ctx_set_top_cls_only(void* ctx, int on);
+/* precision of THIS context's QKV / fc1 / fc2 forward projections: 0 bf16 (default), 1 fp8 (needs splice_vit_enable_fp8) */
+int splice_vit_ctx_set_fp8(void* ctx, int on);
 /* img fp32 [B][3][H][W]; normalize != 0 fuses transforms.Normalize (util/losses.py:19). */
 int splice_vit_forward(void* ctx, const float* img, int normalize, splice_stream_t stream);
 /* same; passes [0, grad_pass_begin) are no-grad targets (util/losses.py:79,91,101 `with torch.no_grad()`):

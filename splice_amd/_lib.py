@@ -25,6 +25,7 @@ class GemmEpilogue(C.Structure):
         ("alpha", C.c_float), ("ksplit", C.c_int), ("slab_stride", C.c_longlong),
         ("rd_other", C.c_void_p), ("ld_rd", C.c_int), ("rd_rows", C.c_int), ("rowdot", C.c_void_p),
         ("row_scale", C.c_void_p), ("col_scale", C.c_void_p),
+        ("out_f8", C.c_void_p), ("ld8", C.c_int),
     ]
 
 
@@ -47,7 +48,7 @@ class StepConfig(C.Structure):
 
 
 EPI_BIAS, EPI_RESID, EPI_OUT_F32, EPI_OUT_BF, EPI_OUT_T = 1, 2, 4, 8, 16
-EPI_GELU, EPI_GELU_GRAD, EPI_COLS_F32, EPI_ALPHA, EPI_ROWDOT, EPI_SCALE_RC = 32, 64, 128, 256, 512, 1024
+EPI_GELU, EPI_GELU_GRAD, EPI_COLS_F32, EPI_ALPHA, EPI_ROWDOT, EPI_SCALE_RC, EPI_OUT_F8 = 32, 64, 128, 256, 512, 1024, 2048
 
 _vp, _i, _f, _sz, _u = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint
 
@@ -88,6 +89,7 @@ _SIGNATURES = {
     "splice_vit_ctx_destroy": ([_vp], None),
     "splice_vit_ctx_info": ([_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)], _i),
     "splice_vit_ctx_set_top_cls_only": ([_vp, _i], _i),
+    "splice_vit_ctx_set_fp8": ([_vp, _i], _i),
     "splice_vit_forward": ([_vp, _vp, _i, _vp], _i),
     "splice_vit_forward_ex": ([_vp, _vp, _i, _i, _vp], _i),
     "splice_vit_forward_passes": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),

@@ -680,8 +680,10 @@ int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
     // two wave groups per workgroup (key range halves side by side) while the launch leaves SIMDs short of waves; the batched
     // launches walk the two halves in one group (same arithmetic, same bits).  In-step A/B, same box: -0.9 % step time at one
     // pair per GPU with two groups, +1.0 % at eight (profiles/r03_ab_preload.txt).
-    static const long ks2_tasks = getenv("SPLICE_ATTN_KS2_TASKS") ? atol(getenv("SPLICE_ATTN_KS2_TASKS")) : 3600;
-    const int ks = g_attn_variant ? g_attn_variant / 10 + 1 : (tasks > ks2_tasks ? 1 : 2);
+    // (two 8-wave workgroups of 64 KB fit a CU: beyond 512 workgroups the two-group form would run in rounds -- measured
+    // -6 % pair-steps/s at two pairs per GPU with 624 of them)
+    static const long ks2_wgs = getenv("SPLICE_ATTN_KS2_WGS") ? atol(getenv("SPLICE_ATTN_KS2_WGS")) : 512;
+    const int ks = g_attn_variant ? g_attn_variant / 10 + 1 : ((long)cdiv(a->Tld, 64 * qb) * a->H * a->B > ks2_wgs ? 1 : 2);
     const int nx = cdiv(a->Tld, 64 * qb);
     const dim3 grid(nx * a->H * a->B);
     if (ks == 2) {

@@ -20,13 +20,18 @@ constexpr int GEMM_BK = 64;
 // FP8 = true: the operands are e4m3 bytes (OCP fp8, the gfx950 MFMA format) instead of bf16 pairs.  The byte geometry of a
 // slice is unchanged (rows of 128 B, XOR-swizzled 16-B chunks, the same LDS-DMA), so the loaders run as they are with
 // K, lda, ldb given in 2-byte units; only the contraction differs: a 16-byte fragment now holds 16 k-values = TWO
-// 16x16x32 fp8 MFMAs (low / high 8 bytes) where it fed one bf16 MFMA -- half the LDS and HBM bytes per FLOP.  A and B use
-// the same k permutation inside a slice, so the sum is unaffected.
-typedef long fp8x8x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x4 mfma16_fp8_pair(const u32x4& a, const u32x4& b, f32x4 c) {
-    const fp8x8x2_t av = __builtin_bit_cast(fp8x8x2_t, a), bv = __builtin_bit_cast(fp8x8x2_t, b);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(av[0], bv[0], c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(av[1], bv[1], c, 0, 0, 0);
+// k-values where it fed one bf16 MFMA -- half the LDS and HBM bytes per FLOP.  A and B use the same k permutation inside a
+// slice, so the sum is unaffected.
+// The fp8 contraction runs on the block-scaled K = 128 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, both operands e4m3, every
+// block scale 2^0 = E8M0 127): twice the issue rate of the non-scaled 16x16x32 fp8 form, which runs at the bf16 rate.  A lane's
+// 32 k-values of a slice are its two 16-byte LDS fragments (the kk = 0 / 1 chunks the bf16 path feeds to two MFMAs); A and B
+// are assembled the same way, so whatever k order the instruction uses inside a lane's 32 bytes, the products pair up.  The
+// per-token / per-channel scales stay in the epilogue (fp32): block scales of 1 make the instruction a plain fp8 dot product.
+typedef int mx8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma16_fp8_mx(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1, f32x4 c) {
+    const mx8_t av = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+    const mx8_t bv = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, c, 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
 
 template <int BM, int BN, bool SWAP = false, bool FP8 = false>
@@ -37,6 +42,52 @@ struct GemmTile {
     static constexpr int B_LOADS = BN * 8 / 256;
     static constexpr int LDS_ELEMS = (BM + BN) * GEMM_BK;
     f32x4 acc[FM][FN];
+
+    // the MFMAs of one BK slice staged at As / Bs
+    __device__ __forceinline__ void slice_mfma(const bf16_t* As, const bf16_t* Bs, int wm, int wn, int frow, int fchunk) {
+        if constexpr (FP8) {
+            u32x4 af[FM][2], bf[FN][2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int chunk = kk * 4 + fchunk;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int row = wm * (BM / 2) + i * 16 + frow;
+                    af[i][kk] = *reinterpret_cast<const u32x4*>(As + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int row = wn * (BN / 2) + j * 16 + frow;
+                    bf[j][kk] = *reinterpret_cast<const u32x4*>(Bs + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = SWAP ? mfma16_fp8_mx(bf[j][0], bf[j][1], af[i][0], af[i][1], acc[i][j]) : mfma16_fp8_mx(af[i][0], af[i][1], bf[j][0], bf[j][1], acc[i][j]);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4 af[FM], bf[FN];
+                const int chunk = kk * 4 + fchunk;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int row = wm * (BM / 2) + i * 16 + frow;
+                    af[i] = *reinterpret_cast<const u32x4*>(As + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int row = wn * (BN / 2) + j * 16 + frow;
+                    bf[j] = *reinterpret_cast<const u32x4*>(Bs + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = SWAP ? mfma16(bf[j], af[i], acc[i][j]) : mfma16(af[i], bf[j], acc[i][j]);
+            }
+        }
+    }
 
     // Direct-to-LDS staging (global_load_lds, 16 B per lane): no VGPR round trip, no ds_write pass.  A wave-instruction fills 8 rows x 128 B of LDS linearly (dest = wave base + lane*16), so the
     // XOR swizzle is applied on the SOURCE chunk each lane fetches.  Two LDS stages; the loads of slice t+1 are
@@ -88,27 +139,7 @@ struct GemmTile {
             if (k0 + GEMM_BK < K) issue(k0 + GEMM_BK, (it + 1) & 1);
             const bf16_t* As = smem + (it & 1) * LDS_ELEMS;
             const bf16_t* Bs = As + BM * GEMM_BK;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                u32x4 af[FM], bf[FN];
-                const int chunk = kk * 4 + fchunk;
-#pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    const int row = wm * (BM / 2) + i * 16 + frow;
-                    af[i] = *reinterpret_cast<const u32x4*>(As + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
-                }
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const int row = wn * (BN / 2) + j * 16 + frow;
-                    bf[j] = *reinterpret_cast<const u32x4*>(Bs + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
-                }
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        acc[i][j] = FP8 ? (SWAP ? mfma16_fp8_pair(bf[j], af[i], acc[i][j]) : mfma16_fp8_pair(af[i], bf[j], acc[i][j]))
-                                        : (SWAP ? mfma16(bf[j], af[i], acc[i][j]) : mfma16(af[i], bf[j], acc[i][j]));
-            }
+            slice_mfma(As, Bs, wm, wn, frow, fchunk);
         }
     }
 
@@ -171,27 +202,7 @@ struct GemmTile {
             if (t + NS - 1 < nsl) issue(t + NS - 1, nstage);
             const bf16_t* As = smem + stage * LDS_ELEMS;
             const bf16_t* Bs = As + BM * GEMM_BK;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                u32x4 af[FM], bf[FN];
-                const int chunk = kk * 4 + fchunk;
-#pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    const int row = wm * (BM / 2) + i * 16 + frow;
-                    af[i] = *reinterpret_cast<const u32x4*>(As + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
-                }
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const int row = wn * (BN / 2) + j * 16 + frow;
-                    bf[j] = *reinterpret_cast<const u32x4*>(Bs + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
-                }
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        acc[i][j] = FP8 ? (SWAP ? mfma16_fp8_pair(bf[j], af[i], acc[i][j]) : mfma16_fp8_pair(af[i], bf[j], acc[i][j]))
-                                        : (SWAP ? mfma16(bf[j], af[i], acc[i][j]) : mfma16(af[i], bf[j], acc[i][j]));
-            }
+            slice_mfma(As, Bs, wm, wn, frow, fchunk);
             stage = stage + 1 == NS ? 0 : stage + 1;
             nstage = nstage + 1 == NS ? 0 : nstage + 1;
         }
@@ -234,7 +245,7 @@ enum : unsigned {
     EPI_BIAS = SPLICE_EPI_BIAS, EPI_RESID = SPLICE_EPI_RESID, EPI_OUT_F32 = SPLICE_EPI_OUT_F32,
     EPI_OUT_BF = SPLICE_EPI_OUT_BF, EPI_OUT_T = SPLICE_EPI_OUT_T, EPI_GELU = SPLICE_EPI_GELU,
     EPI_GELU_GRAD = SPLICE_EPI_GELU_GRAD, EPI_COLS_F32 = SPLICE_EPI_COLS_F32, EPI_ALPHA = SPLICE_EPI_ALPHA,
-    EPI_ROWDOT = SPLICE_EPI_ROWDOT, EPI_SCALE_RC = SPLICE_EPI_SCALE_RC
+    EPI_ROWDOT = SPLICE_EPI_ROWDOT, EPI_SCALE_RC = SPLICE_EPI_SCALE_RC, EPI_OUT_F8 = SPLICE_EPI_OUT_F8
 };
 
 template <unsigned FLAGS>
@@ -315,7 +326,7 @@ __device__ __forceinline__ void gemm_epilogue_cols(const GemmEpi& e, int M, int 
         for (int r = 0; r < 4; ++r) x[r] *= e.alpha;
     }
     if (FLAGS & EPI_SCALE_RC) {   // de-quantisation of an fp8 product: per-row scale of A x per-column scale of B
-        const float rs = e.row_scale[row];
+        const float rs = e.row_scale ? e.row_scale[row] : 1.0f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] *= rs * e.col_scale[min(col0 + r, N - 1)];
     }
@@ -405,7 +416,7 @@ __device__ __forceinline__ f32x4 gemm_frag_value(const GemmEpi& e, int M, int N,
         for (int r = 0; r < 4; ++r) x[r] *= e.alpha;
     }
     if (FLAGS & EPI_SCALE_RC) {
-        const float rs = e.row_scale[rowc];
+        const float rs = e.row_scale ? e.row_scale[rowc] : 1.0f;
         const float4 cs = *reinterpret_cast<const float4*>(e.col_scale + colc);
         x[0] *= rs * cs.x; x[1] *= rs * cs.y; x[2] *= rs * cs.z; x[3] *= rs * cs.w;
     }
@@ -475,6 +486,34 @@ __device__ __forceinline__ void gemm_stage_store(const f32x4 (&acc)[BM / 32][BN 
             for (int t = 0; t < 8; ++t)
                 if (gc + t < Cm) q[t] = h[t];
         }
+    }
+}
+
+// e4m3 output tile: cs bytes [BM][BN + 16]; a lane's 4 columns are one dword, the tile leaves as 16 bytes per lane along rows
+__device__ __forceinline__ uint32_t pack4_e4m3_sat(const f32x4& v) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[0], -448.f), 448.f), fminf(fmaxf(v[1], -448.f), 448.f), w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v[2], -448.f), 448.f), fminf(fmaxf(v[3], -448.f), 448.f), w, true);
+    return (uint32_t)w;
+}
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_stage_store_f8(const f32x4 (&acc)[BM / 32][BN / 32], uint8_t* cs, uint8_t* out, int ld, int M, int N, int m0, int n0) {
+    constexpr int FMt = BM / 32, FNt = BN / 32, PITCH = BN + 16, CH = BN / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FMt; ++i)
+#pragma unroll
+        for (int j = 0; j < FNt; ++j) {
+            const int lr = wm * (BM / 2) + i * 16 + (lane & 15), lc = wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+            *reinterpret_cast<uint32_t*>(cs + lr * PITCH + lc) = pack4_e4m3_sat(acc[i][j]);
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < BM * CH; c += 256) {
+        const int r = c / CH, k = (c % CH) * 16;
+        const int gr = m0 + r, gc = n0 + k;
+        if (gr >= M || gc >= N) continue;   // N % 16 == 0: a chunk is inside or outside as a whole
+        st_out(reinterpret_cast<u32x4*>(out + (size_t)gr * ld + gc), *reinterpret_cast<const u32x4*>(cs + r * PITCH + k));
     }
 }
 
@@ -557,7 +596,32 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
     // staged bf16 outputs (see gemm_stage_store): every vector access of gemm_frag_value must be aligned
     const bool stage_ok = (FLAGS & EPI_OUT_BF) && !(N & 3) && (!(FLAGS & EPI_RESID) || !(e.ldr & 3)) && (!(FLAGS & EPI_GELU_GRAD) || !(e.ldaux & 3)) &&
                           (!(FLAGS & EPI_OUT_F32) || !(e.ldo & 3)) && (!(FLAGS & EPI_OUT_T) || !(e.ldt & 7));
-    if ((FLAGS & EPI_OUT_BF) && stage_ok) {
+    if constexpr ((FLAGS & EPI_OUT_F8) != 0) {
+        // e4m3 output (fc1 of the fp8 MLP): [bf16 pre-activation of the gradient-carrying rows,] GELU, saturated e4m3 tile
+        constexpr int FMt = GemmTile<BM, BN>::FM, FNt = GemmTile<BM, BN>::FN;
+        static_assert((size_t)NS * GemmTile<BM, BN>::LDS_ELEMS >= (size_t)BM * (BN + 8), "the ring must hold one staged output tile");
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+        float4 pb[FNt];
+#pragma unroll
+        for (int j = 0; j < FNt; ++j)
+            if (FLAGS & EPI_BIAS) pb[j] = *reinterpret_cast<const float4*>(e.bias + min(n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4, N - 4));
+#pragma unroll
+        for (int i = 0; i < FMt; ++i)
+#pragma unroll
+            for (int j = 0; j < FNt; ++j)
+                tile.acc[i][j] = gemm_frag_value<FLAGS, true>(e, M, N, m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4,
+                                                              tile.acc[i][j], pb[j], float4{}, uint2{});
+        if (FLAGS & EPI_GELU) {
+            if (e.out_pre) gemm_stage_store<BM, BN, false>(tile.acc, gemm_smem, e.out_pre, e.ldp, M, N, m0, n0, e.pre_row_lo);
+#pragma unroll
+            for (int i = 0; i < FMt; ++i)
+#pragma unroll
+                for (int j = 0; j < FNt; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tile.acc[i][j][r] = gelu_f(tile.acc[i][j][r]);
+        }
+        gemm_stage_store_f8<BM, BN>(tile.acc, reinterpret_cast<uint8_t*>(gemm_smem), e.out_f8, e.ld8, M, N, m0, n0);
+    } else if ((FLAGS & EPI_OUT_BF) && stage_ok) {
         constexpr int FMt = GemmTile<BM, BN>::FM, FNt = GemmTile<BM, BN>::FN;
         static_assert((size_t)NS * GemmTile<BM, BN>::LDS_ELEMS >= (size_t)BM * (BN + 8) && (size_t)NS * GemmTile<BM, BN>::LDS_ELEMS >= (size_t)BN * (BM + 8),
                       "the ring must hold one staged output tile");

@@ -101,7 +101,10 @@ static int dispatch_fp8(const uint8_t* A, int lda, const uint8_t* B, int ldb, in
     const bf16_t* a = reinterpret_cast<const bf16_t*>(A);
     const bf16_t* b = reinterpret_cast<const bf16_t*>(B);
     const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t12864 = (long)cdiv(M, 128) * cdiv(N, 64);
-    if (t128 >= 420) launch_gemm_nt<128, 128, FLAGS, 2, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
+    if (N <= 768) {   // fc2: as the bf16 dispatcher -- 64x64 tiles on the deep ring for the few-row shapes, 128x64 from the batched row counts on
+        if (M >= 2401) launch_gemm_nt<128, 64, FLAGS, 2, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
+        else launch_gemm_nt<64, 64, FLAGS, 4, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
+    } else if (t128 >= 420) launch_gemm_nt<128, 128, FLAGS, 2, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
     else if (t12864 >= 400) launch_gemm_nt<128, 64, FLAGS, 3, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
     else launch_gemm_nt<64, 64, FLAGS, 3, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
     return SPLICE_OK;
@@ -109,13 +112,17 @@ static int dispatch_fp8(const uint8_t* A, int lda, const uint8_t* B, int ldb, in
 int gemm_nt_fp8_launch(unsigned flags, const uint8_t* A, int lda, const uint8_t* B, int ldb, int M, int N, int K, const GemmEpi& e, hipStream_t s) {
     if (M < 1 || N < 1 || K < 128 || K % 128 || lda % 16 || ldb % 16) return SPLICE_ERR_ARG;
     if ((size_t)M * lda >= (1ull << 32) || (size_t)N * ldb >= (1ull << 32)) return SPLICE_ERR_ARG;
-    if (!(flags & EPI_SCALE_RC) || !e.row_scale || !e.col_scale) return SPLICE_ERR_ARG;
+    if (!(flags & EPI_SCALE_RC) || !e.col_scale) return SPLICE_ERR_ARG;   // (row_scale may be NULL: unscaled e4m3 activations)
     if ((flags & EPI_OUT_T) && (e.ldt % 4)) return SPLICE_ERR_ARG;
+    if ((flags & EPI_OUT_F8) && (!e.out_f8 || N % 16 || e.ld8 % 16 || (e.out_pre && e.ldp % 8))) return SPLICE_ERR_ARG;
+#define CASE8(F) case (F): return dispatch_fp8<(F)>(A, lda, B, ldb, M, N, K, e, s)
     switch (flags) {
-        case EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T: return dispatch_fp8<EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T>(A, lda, B, ldb, M, N, K, e, s);
-        case EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T | EPI_COLS_F32:
-            return dispatch_fp8<EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T | EPI_COLS_F32>(A, lda, B, ldb, M, N, K, e, s);
-        case EPI_SCALE_RC | EPI_OUT_F32: return dispatch_fp8<EPI_SCALE_RC | EPI_OUT_F32>(A, lda, B, ldb, M, N, K, e, s);
+        CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T);                  // qkv
+        CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T | EPI_COLS_F32);   // qkv, last layer
+        CASE8(EPI_SCALE_RC | EPI_OUT_F32);
+        CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_GELU | EPI_OUT_F8);                   // fc1: e4m3 GELU output (+ bf16 pre-activation)
+        CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_RESID | EPI_OUT_F32);                 // fc2
         default: return SPLICE_ERR_ARG;
     }
+#undef CASE8
 }

@@ -41,7 +41,7 @@ struct Linear {
     bf16_t* wT = nullptr;   // [in][out]
     float* b = nullptr;     // [out]
     int out = 0, in = 0;
-    uint8_t* w8 = nullptr;  // [out][in] e4m3, quantised per output channel (fp8 mode, qkv only)
+    uint8_t* w8 = nullptr;  // [out][in] e4m3, quantised per output channel (fp8 mode: qkv, fc1, fc2)
     float* w8_scale = nullptr;   // [out]
 };
 struct LayerW {
@@ -60,7 +60,7 @@ struct SpliceVit {
     float *norm_g = nullptr, *norm_b = nullptr;
     std::vector<void*> allocs;
     int n_set = 0;
-    int fp8 = 0;            // QKV projection on the fp8 MFMA (splice_vit_enable_fp8)
+    int fp8 = 0;            // e4m3 copies of the qkv / fc1 / fc2 weights exist (splice_vit_enable_fp8); contexts opt in (splice_vit_ctx_set_fp8)
 };
 
 struct SpliceVitCtx {
@@ -76,8 +76,10 @@ struct SpliceVitCtx {
     std::vector<float*> lse;               // depth x [B][H][Tld]
     float* qkv_last_f32 = nullptr;         // [rows][3D]
     bf16_t* ln_out = nullptr;              // [rows][D]   transient
+    int fp8 = 0;                           // this context's QKV / fc1 / fc2 forward projections run on the fp8 MFMA
     uint8_t* ln_out8 = nullptr;            // [rows][D]   e4m3 LayerNorm output (fp8 mode)
     float* ln_scale = nullptr;             // [rows]      its per-token scales
+    uint8_t* hact8 = nullptr;              // [rows][4D]  e4m3 GELU output of fc1 = operand of fc2 (fp8 mode; unscaled)
     bf16_t* hact = nullptr;                // [rows][4D]  transient
     // backward temporaries (sized for all rows)
     float* g = nullptr;                    // [rows][D]
@@ -210,18 +212,21 @@ int splice_vit_set_param(void* h, const char* name, const float* data, long long
     return SPLICE_OK;
 }
 
-// BASELINE configs[4] ("fp8 MFMA attention + self-sim path"): from now on every context created on this engine runs its
-// QKV projections on the fp8 MFMA -- LayerNorm output quantised per token to e4m3 where it is produced, weights quantised
-// once per output channel here, de-quantisation in the GEMM epilogue.  Needs dim % 128 == 0.  The dgrad path is unchanged.
+// BASELINE configs[4] ("fp8 MFMA attention + self-sim path"): prepares the e4m3 copies of the QKV, fc1 and fc2 weights
+// (quantised once per output channel).  A context created afterwards runs those three forward projections on the fp8 MFMA
+// when it opts in (splice_vit_ctx_set_fp8) -- the mode is a property of the CONTEXT, so engines that share one frozen ViT
+// keep their own precision.  Needs dim % 128 == 0.  The dgrad path (bf16 weights) is unchanged.
 int splice_vit_enable_fp8(void* h, splice_stream_t stream) {
     SpliceVit* v = (SpliceVit*)h;
     if (!v || !splice_vit_params_complete(h) || v->dim % 128) { splice_set_error("splice_vit_enable_fp8: incomplete weights or dim %% 128 != 0"); return SPLICE_ERR_STATE; }
     hipStream_t s = (hipStream_t)stream;
     for (auto& L : v->layers) {
-        if (L.qkv.w8) continue;
-        RC(dev_alloc(v->allocs, &L.qkv.w8, (size_t)L.qkv.out * L.qkv.in));
-        RC(dev_alloc(v->allocs, &L.qkv.w8_scale, (size_t)L.qkv.out));
-        RC(quantize_rows_bf16_fp8_launch(L.qkv.w, L.qkv.in, L.qkv.w8, L.qkv.in, L.qkv.w8_scale, L.qkv.out, L.qkv.in, s));
+        for (Linear* lin : {&L.qkv, &L.fc1, &L.fc2}) {
+            if (lin->w8) continue;
+            RC(dev_alloc(v->allocs, &lin->w8, (size_t)lin->out * lin->in));
+            RC(dev_alloc(v->allocs, &lin->w8_scale, (size_t)lin->out));
+            RC(quantize_rows_bf16_fp8_launch(lin->w, lin->in, lin->w8, lin->in, lin->w8_scale, lin->out, lin->in, s));
+        }
     }
     v->fp8 = 1;
     return SPLICE_OK;
@@ -289,7 +294,6 @@ int splice_vit_ctx_create(void* h, int B, int H, int W, const float* pos_TD, int
     }
     A(c->qkv_last_f32, rows * 3 * D);
     A(c->ln_out, rows * D);
-    if (v->fp8) { A(c->ln_out8, rows * D); A(c->ln_scale, rows); }
     A(c->cls_attn, (size_t)B * D); A(c->cls_ln, (size_t)B * D); A(c->cls_h, (size_t)B * Hd); A(c->cls_probs, (size_t)B * v->heads * c->Tld);
     A(c->cls_slabs, (size_t)16 * B * Hd);
     if (need_grad) { A(c->cls_dh, (size_t)B * Hd); A(c->cls_dout, (size_t)B * D); A(c->cls_dln, (size_t)B * D); }
@@ -335,6 +339,22 @@ int splice_vit_ctx_set_top_cls_only(void* ctx, int on) {
     SpliceVitCtx* c = (SpliceVitCtx*)ctx;
     if (!c) return SPLICE_ERR_ARG;
     c->top_cls_only = on ? 1 : 0;
+    return SPLICE_OK;
+}
+
+// on != 0: this context's QKV, fc1 and fc2 forward projections run on the fp8 MFMA (e4m3 LayerNorm outputs with per-token
+// scales, e4m3 GELU output, e4m3 weights with per-channel scales); needs splice_vit_enable_fp8 on its engine first.
+int splice_vit_ctx_set_fp8(void* ctx, int on) {
+    SpliceVitCtx* c = (SpliceVitCtx*)ctx;
+    if (!c) return SPLICE_ERR_ARG;
+    if (on && !c->vit->fp8) { splice_set_error("splice_vit_ctx_set_fp8: the engine has no e4m3 weights (splice_vit_enable_fp8 first)"); return SPLICE_ERR_STATE; }
+    if (on && !c->ln_out8) {
+        const size_t rows = c->rows;
+        RC(dev_alloc(c->allocs, &c->ln_out8, rows * c->vit->dim));
+        RC(dev_alloc(c->allocs, &c->ln_scale, rows));
+        RC(dev_alloc(c->allocs, &c->hact8, rows * c->vit->hidden));
+    }
+    c->fp8 = on ? 1 : 0;
     return SPLICE_OK;
 }
 
@@ -391,7 +411,7 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
         const LayerW& W = v->layers[l];
         float* x_in = c->xs[l] + r0 * D;
         float* x_mid = c->xmid[l] + r0 * D;
-        const bool fp8 = v->fp8 && c->ln_out8 && W.qkv.w8;
+        const bool fp8 = c->fp8 && c->ln_out8 && W.qkv.w8;
         if (fp8) RC(layernorm_fwd_fp8_launch(x_in, W.ln1_g, W.ln1_b, c->ln_out8 + r0 * D, c->ln_scale + r0, c->mean1[l] + r0, c->rstd1[l] + r0, R, D, 1e-6f, s));
         else RC(layernorm_fwd_launch(x_in, W.ln1_g, W.ln1_b, ln_out, c->mean1[l] + r0, c->rstd1[l] + r0, R, D, 1e-6f, s));
         {
@@ -457,20 +477,32 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
             SpliceProfScope ps(9);
             RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, c->attn_out[l] + r0 * D, D, W.proj.w, D, R, D, D, e, s));
         }
-        RC(layernorm_fwd_launch(x_mid, W.ln2_g, W.ln2_b, ln_out, c->mean2[l] + r0, c->rstd2[l] + r0, R, D, 1e-6f, s));
+        if (fp8) RC(layernorm_fwd_fp8_launch(x_mid, W.ln2_g, W.ln2_b, c->ln_out8 + r0 * D, c->ln_scale + r0, c->mean2[l] + r0, c->rstd2[l] + r0, R, D, 1e-6f, s));
+        else RC(layernorm_fwd_launch(x_mid, W.ln2_g, W.ln2_b, ln_out, c->mean2[l] + r0, c->rstd2[l] + r0, R, D, 1e-6f, s));
         {
             GemmEpi e = {};
             e.bias = W.fc1.b; e.out_bf = hact; e.ldbf = Hd; e.out_pre = c->need_grad ? c->hpre[l] + r0 * Hd : nullptr; e.ldp = Hd;
             const long lo = (long)c->grad_pass_begin * c->Tld - (long)r0;   // first local row whose pre-activation is kept
             e.pre_row_lo = lo > 0 ? (int)lo : 0;
             SpliceProfScope ps(1);
-            RC(gemm_nt_launch(EPI_BIAS | EPI_GELU | EPI_OUT_BF, ln_out, D, W.fc1.w, D, R, Hd, D, e, s));
+            if (fp8) {   // e4m3 LayerNorm output x e4m3 weights; GELU(x) leaves as e4m3 (the operand of fc2), the pre-activation as bf16
+                e.out_bf = nullptr; e.out_f8 = c->hact8 + r0 * Hd; e.ld8 = Hd;
+                e.row_scale = c->ln_scale + r0; e.col_scale = W.fc1.w8_scale;
+                RC(gemm_nt_fp8_launch(EPI_SCALE_RC | EPI_BIAS | EPI_GELU | EPI_OUT_F8, c->ln_out8 + r0 * D, D, W.fc1.w8, D, R, Hd, D, e, s));
+            } else {
+                RC(gemm_nt_launch(EPI_BIAS | EPI_GELU | EPI_OUT_BF, ln_out, D, W.fc1.w, D, R, Hd, D, e, s));
+            }
         }
         {
             GemmEpi e = {};
             e.bias = W.fc2.b; e.resid = x_mid; e.ldr = D; e.out_f32 = c->xs[l + 1] + r0 * D; e.ldo = D;
             SpliceProfScope ps(4);
-            RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, hact, Hd, W.fc2.w, Hd, R, D, Hd, e, s));
+            if (fp8) {
+                e.row_scale = nullptr; e.col_scale = W.fc2.w8_scale;
+                RC(gemm_nt_fp8_launch(EPI_SCALE_RC | EPI_BIAS | EPI_RESID | EPI_OUT_F32, c->hact8 + r0 * Hd, Hd, W.fc2.w8, Hd, R, D, Hd, e, s));
+            } else {
+                RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, hact, Hd, W.fc2.w, Hd, R, D, Hd, e, s));
+            }
         }
     }
     c->forward_done = 1;

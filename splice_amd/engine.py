@@ -63,11 +63,12 @@ class MultiPairEngine:
         self.device = torch.device(device)
         self.P = P = len(gen_states)
         self.vit = vit_engine or VitEngine(c["dino_model_name"], device=device).load_state_dict(vit_state)
-        # fp8=True (BASELINE configs[4]): QKV projections and the key self-similarity Gram matrices on the fp8 MFMA; everything
-        # else (attention, MLP, the whole backward) stays bf16 / fp32.  Own tolerance table: tests/test_fp8_gpu.py.
+        # fp8=True (BASELINE configs[4]): the QKV, fc1 and fc2 forward projections and the key self-similarity Gram matrices on
+        # the fp8 MFMA (e4m3, block-scaled K = 128 form); attention, proj and the whole backward stay bf16 / fp32.  The mode is a
+        # property of THIS engine's contexts: another engine sharing the frozen ViT keeps its own.  Tolerances: tests/test_fp8_gpu.py.
         self.fp8 = bool(fp8)
-        if self.fp8 and not getattr(self.vit, "fp8", False):
-            self.vit.enable_fp8()
+        if self.fp8:
+            self.vit.prepare_fp8()
         self.gen = GeneratorEngine(device=device)
         n = self.gen.numel
         self.stride = n if P == 1 else (n + 63) // 64 * 64
@@ -90,7 +91,7 @@ class MultiPairEngine:
         slots = self.slots = self.n_crops if self.n_crops > 1 else P    # images per generator plan / per ViT pass group
         batch = self.n_crops > 1
         # (the [CLS]-only mode is a property of the context: such contexts are private, never shared with the extractor API)
-        self.ctx_g = VitContext(self.vit, 4 * slots, vh, vw, True) if top_cls_only else self.vit.context(4 * slots, vh, vw, need_grad=True)
+        self.ctx_g = VitContext(self.vit, 4 * slots, vh, vw, True, fp8=self.fp8) if top_cls_only else self.vit.context(4 * slots, vh, vw, need_grad=True, fp8=self.fp8)
         arena_stride = self.stride if P > 1 else 0
         # private plan objects (the shape-keyed plan cache could hand out one plan twice)
         self.plan_a = GeneratorPlan(self.gen, slots, ch, cw, True, arena_stride, batch_stats=batch)
@@ -108,7 +109,8 @@ class MultiPairEngine:
         if use_entire:
             eh, ew = entire_hw
             evh, evw = resize_output_size(eh, ew, Pz, 480)
-            self.ctx_e = VitContext(self.vit, 2 * P, evh, evw, True) if top_cls_only else self.vit.context(2 * P, evh, evw, need_grad=True)   # (P = 1 in crops mode)
+            self.ctx_e = (VitContext(self.vit, 2 * P, evh, evw, True, fp8=self.fp8) if top_cls_only
+                          else self.vit.context(2 * P, evh, evw, need_grad=True, fp8=self.fp8))   # (P = 1 in crops mode)
             self.plan_e = GeneratorPlan(self.gen, P, eh, ew, True, arena_stride)
             sc.ent_h, sc.ent_w, sc.ent_vit_h, sc.ent_vit_w = eh, ew, evh, evw
         sc.lambda_global_cls, sc.lambda_global_ssim = c["lambda_global_cls"], c["lambda_global_ssim"]
@@ -182,7 +184,7 @@ class MultiPairEngine:
         n, _, h, w = img.shape
         key = (pair, n, h, w)   # one plan per pair: a plan holds the BatchNorm statistics of its last forward until they are booked
         if key not in self._log_plans:
-            self._log_plans[key] = GeneratorPlan(self.gen, n, h, w, False)
+            self._log_plans[key] = GeneratorPlan(self.gen, n, h, w, False, batch_stats=n > 1)   # ONE netG call on n images: batch statistics, as nn.BatchNorm2d
         plan = self._log_plans[key]
         out = plan.forward(self.pair_params(pair), img.contiguous())
         if track_running_stats:
@@ -261,8 +263,14 @@ class MultiScaleEngine:
         per = {sz: e.losses() for sz, e in zip(self.scales, self.engines)}
         return {"loss": sum(d["loss"] for d in per.values()), "scales": per}
 
-    def generate(self, img):
-        return self.engines[0].generate(img)
+    def generate(self, img, pair=0, track_running_stats=False):
+        return self.engines[0].generate(img, pair, track_running_stats)
+
+    def book_logged_forward(self):
+        self.engines[0].book_logged_forward()
+
+    def state_dict(self, pair=0):
+        return self.engines[0].state_dict(pair)
 
 
 def synthetic_engine(cfg, pair_id=0, hw=(224, 224), seed=1234, device="cuda", vit_engine=None, entire=True, pairs=1, fp8=False, top_cls_only=True):

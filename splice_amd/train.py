@@ -140,7 +140,19 @@ def train_model(dataroot, callback=None, cfg_overrides=None, vit_state=None, pro
     netG = define_G(cfg['init_type'], cfg['init_gain'], device=device)
     gen_state = {k: v.detach() for k, v in netG.state_dict().items() if k in netG.engine.table}
     crop_max = max(min(A.shape[1], A.shape[2]), min(B.shape[1], B.shape[2]))   # crops are squares of side <= min(h, w)
-    engine = SpliceEngine(cfg, vit_state, gen_state, (crop_max, crop_max), tuple(A.shape[1:]), device=device, n_crops=n_crops, vit_engine=vit_engine)
+    # Extensions beyond the reference's config (BASELINE configs[4]): `dino_global_scales` = list of ViT input sizes at which every
+    # loss term is evaluated each step (the reference has the single `dino_global_patch_size`), `fp8` = e4m3 operands for the
+    # QKV / fc1 / fc2 projections and the self-similarity Gram matrices.  Absent keys = the reference's behaviour.
+    scales = [int(x) for x in (cfg.get('dino_global_scales') or [])]
+    fp8 = bool(cfg.get('fp8', False))
+    crops, entire = (crop_max, crop_max), tuple(A.shape[1:])
+    if len(scales) > 1:
+        from .engine import MultiScaleEngine
+        engine = MultiScaleEngine(cfg, vit_state, gen_state, crops, entire, scales=scales, device=device, n_crops=n_crops, vit_engine=vit_engine, fp8=fp8)
+    else:
+        if scales:
+            cfg['dino_global_patch_size'] = scales[0]
+        engine = SpliceEngine(cfg, vit_state, gen_state, crops, entire, device=device, n_crops=n_crops, vit_engine=vit_engine, fp8=fp8)
     del netG
 
     writer = AsyncResultWriter(cfg['dataroot'])   # PNG encode + disk write happen on a worker thread
@@ -237,7 +249,7 @@ def train_pairs(dataroots, callback=None, cfg_overrides=None, vit_state=None, pr
     torch.manual_seed(int(seed))
     A0, B0 = As[0], Bs[0]
     crop_max = max(min(A0.shape[1], A0.shape[2]), min(B0.shape[1], B0.shape[2]))
-    engine = MultiPairEngine(cfg, vit_state, gen_states, (crop_max, crop_max), tuple(A0.shape[1:]), device=device, vit_engine=vit_engine)
+    engine = MultiPairEngine(cfg, vit_state, gen_states, (crop_max, crop_max), tuple(A0.shape[1:]), device=device, vit_engine=vit_engine, fp8=bool(cfg.get('fp8', False)))
     writers = [AsyncResultWriter(root) for root in dataroots]
     try:
         for epoch in range(1, cfg['n_epochs'] + 1):

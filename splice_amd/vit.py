@@ -35,8 +35,11 @@ def interpolate_pos_encoding(pos_embed, patch, h_px, w_px):
 class VitContext:
     """Activations of one (batch, image-shape) forward; see splice_vit_ctx_create."""
 
-    def __init__(self, engine, B, H, W, need_grad):
+    def __init__(self, engine, B, H, W, need_grad, fp8=None):
+        """``fp8``: this context's QKV / fc1 / fc2 forward projections on the fp8 MFMA (None: the engine's default, which
+        ``VitEngine.enable_fp8()`` switches on for contexts it hands out itself)."""
         self.engine, self.B, self.H, self.W, self.need_grad = engine, B, H, W, need_grad
+        self.fp8 = bool(getattr(engine, "fp8", False)) if fp8 is None else bool(fp8)
         pos = interpolate_pos_encoding(engine.pos_embed, engine.patch, H, W).contiguous().float()
         h = C.c_void_p()
         _lib.check(_lib.lib().splice_vit_ctx_create(engine.handle, B, H, W, _lib.ptr(pos), int(need_grad),
@@ -46,6 +49,8 @@ class VitContext:
         t, tld, rows = C.c_int(), C.c_int(), C.c_int()
         _lib.check(_lib.lib().splice_vit_ctx_info(h, C.byref(t), C.byref(tld), C.byref(rows)))
         self.T, self.Tld, self.rows = t.value, tld.value, rows.value
+        if self.fp8:
+            _lib.check(_lib.lib().splice_vit_ctx_set_fp8(h, 1), "vit_ctx_set_fp8")
 
     def __del__(self):
         try:
@@ -136,17 +141,26 @@ class VitEngine:
             raise RuntimeError("VitEngine.load_state_dict: state dict is missing DINO ViT entries")
         return self
 
+    def prepare_fp8(self):
+        """BASELINE configs[4]: build the e4m3 copies of the QKV / fc1 / fc2 weights (once).  Contexts opt in one by one
+        (``VitContext(..., fp8=True)``), so engines that share this frozen ViT keep their own precision."""
+        if not getattr(self, "_fp8_ready", False):
+            _lib.check(_lib.lib().splice_vit_enable_fp8(self.handle, _lib.current_stream()), "vit_enable_fp8")
+            torch.cuda.current_stream().synchronize()
+            self._fp8_ready = True
+        return self
+
     def enable_fp8(self):
-        """BASELINE configs[4]: QKV projections of every context created FROM NOW ON run on the fp8 MFMA (e4m3 operands,
-        per-token x per-channel scales).  Cached contexts are dropped so that none keeps the bf16 path."""
-        _lib.check(_lib.lib().splice_vit_enable_fp8(self.handle, _lib.current_stream()), "vit_enable_fp8")
-        torch.cuda.current_stream().synchronize()
+        """``prepare_fp8`` + make fp8 the DEFAULT of the contexts this engine hands out through ``context()`` from now on
+        (cached bf16 contexts are dropped).  Contexts built with an explicit ``fp8=`` argument are not affected."""
+        self.prepare_fp8()
         self._ctx.clear()
         self.fp8 = True
         return self
 
-    def context(self, B, H, W, need_grad=True):
-        key = (B, H, W, bool(need_grad))
+    def context(self, B, H, W, need_grad=True, fp8=None):
+        fp8 = bool(getattr(self, "fp8", False)) if fp8 is None else bool(fp8)
+        key = (B, H, W, bool(need_grad), fp8)
         if key not in self._ctx:
-            self._ctx[key] = VitContext(self, B, H, W, need_grad)
+            self._ctx[key] = VitContext(self, B, H, W, need_grad, fp8=fp8)
         return self._ctx[key]

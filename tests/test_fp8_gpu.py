@@ -1,5 +1,6 @@
 """GPU: the fp8 operand path of BASELINE configs[4] ("fp8 MFMA attention + self-sim path"): e4m3 (OCP fp8, the gfx950 MFMA
-format) operands on v_mfma_f32_16x16x32_fp8_fp8 for the QKV projection and for the key self-similarity Gram matrices.
+format) operands for the QKV / fc1 / fc2 forward projections (block-scaled K = 128 MFMA with unit block scales) and for the key
+self-similarity Gram matrices.
 
 Two layers of checks:
   * EXACTNESS of the machinery: the quantisers and the fp8 GEMM against a torch emulation that rounds through
@@ -10,6 +11,7 @@ Two layers of checks:
     mantissa bits), step losses / gradients teacher-forced as in tests/test_step_gpu.py.  Bars are set from the measured
     values printed by the test."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -80,7 +82,7 @@ def test_fp8_gemm_exact_vs_emulation(M, N, K):
 
 
 def test_fp8_vit_features_vs_oracle():
-    """ViT-B/8 layer-11 keys with fp8 QKV projections in all 12 layers against the fp32 oracle ViT (bf16 path: 2e-2), 224x224."""
+    """ViT-B/8 layer-11 keys with fp8 QKV / fc1 / fc2 projections in all 12 layers against the fp32 oracle ViT (bf16 path: 2e-2), 224x224."""
     from oracle import dino_vit
     from oracle import extractor as oext
     from splice_amd.vit import KIND_QKV_LAST_F32, VitEngine
@@ -101,15 +103,18 @@ def test_fp8_vit_features_vs_oracle():
         qkv = ctx.read(KIND_QKV_LAST_F32, 11)[0, : ctx.T].cpu()
         k_got = qkv[:, 768:1536].reshape(ctx.T, 12, 64).permute(1, 0, 2)
         rel[fp8] = ((k_got.double() - k_ref.double()).norm() / k_ref.double().norm()).item()
-    print(f"    layer-11 keys rel-L2 vs fp32 oracle: bf16 path {rel[False]:.3e}, fp8-QKV path {rel[True]:.3e}")
+    print(f"    layer-11 keys rel-L2 vs fp32 oracle: bf16 path {rel[False]:.3e}, fp8 path {rel[True]:.3e}")
     assert rel[False] < 2e-2 and rel[True] < FP8_KEYS_TOL, rel
 
 
-# ---- the fp8 path's own tolerance table (measured values are printed; bars ~2x the measurement)
-FP8_KEYS_TOL = 8e-2
-# measured r2 (worst over steps 0-2): keys 4.3e-2; losses <= 8.3e-3 (cls / id / total), <= 1.8e-2 (ssim); generator gradient 9.8e-2
-# (ViT-S/8 @ 64) / 3.7e-2 (ViT-B/8 @ 224) -- against 6e-3 / 3e-3 / 7e-3 on the bf16 path
-FP8_LOSS_TOL = {"loss": 2e-2, "loss_global_cls": 2e-2, "loss_entire_cls": 2e-2, "loss_global_ssim": 4e-2, "loss_entire_ssim": 4e-2, "loss_global_id_B": 2e-2}
+# ---- the fp8 path's own tolerance table: bars <= 1.3x the worst value measured in round 3 (printed by the tests)
+# measured r3, QKV + fc1 + fc2 forward projections and the Gram matrices in e4m3 (worst over steps 0-2): layer-11 keys 9.2e-2 (an
+# e4m3 GEMM of uncorrelated operands carries ~3.7e-2 relative error by itself, test_fp8_gemm_exact_vs_emulation prints it; three
+# of them per block accumulate through the residual stream); losses <= 1.84e-2 (cls / total), <= 2.56e-2 (ssim), <= 1.2e-2 (id);
+# generator gradient 1.54e-1 (ViT-S/8 @ 64) / 6.1e-2 (ViT-B/8 @ 224) / 1.7e-1 (configs[4] ssim term at 224 + 320 + 448) -- against
+# 6e-3 / 3e-3 / 7e-3 on the bf16 path.  What the optimisation makes of it: test_fp8_trajectory_reaches_reference_level.
+FP8_KEYS_TOL = 1.2e-1
+FP8_LOSS_TOL = {"loss": 2.4e-2, "loss_global_cls": 2.4e-2, "loss_entire_cls": 2.4e-2, "loss_global_ssim": 3.3e-2, "loss_entire_ssim": 3.3e-2, "loss_global_id_B": 1.6e-2}
 FP8_GRAD_TOL = 2e-1
 
 
@@ -147,3 +152,105 @@ def test_fp8_step_vs_oracle_tolerance_table(name, size):
     print(f"    fp8 path {name}@{size}: worst relative deviations over steps 0-2 vs fp32 oracle: " + ", ".join(f"{k} {v:.3e}" for k, v in worst.items()))
     for k, v in worst.items():
         assert v < (FP8_GRAD_TOL if k == "grad" else FP8_LOSS_TOL[k]), (k, v)
+
+
+# ---- BASELINE configs[4] at its own sizes: every loss term at the ViT input scales 224 / 320 / 448 with the fp8 operand path
+@pytest.mark.parametrize("term", ["cls", "ssim", "id"])
+def test_configs4_multiscale_224_320_448_fp8_vs_oracle(term):
+    """``MultiScaleEngine(scales=(224, 320, 448), fp8=True)`` on ViT-B/8 (T = 785 / 1601 / 3137; bilinear Resize 224 -> 320 / 448 and
+    its adjoint, interpolated position tables, 32-query attention waves and the two-launch attention backward at the large
+    scales, fp8 QKV / fc1 / fc2 + fp8 self-similarity Gram): summed loss and whole-arena generator gradient of one step against
+    the fp32 CPU oracle evaluated at the three ``dino_global_patch_size`` values on the same generator outputs.  One loss term per
+    case (the other lambdas are zero on both sides) so that the oracle's autograd holds one differentiated ViT pass per scale."""
+    from oracle import losses as OL
+    from oracle import dino_vit
+    from oracle.step import SpliceOracle
+    from splice_amd.engine import MultiScaleEngine
+    scales = (224, 320, 448)
+    lam = dict(lambda_global_cls=0.0, lambda_global_ssim=0.0, lambda_global_identity=0.0, lambda_entire_cls=0.0, lambda_entire_ssim=0.0)
+    lam[{"cls": "lambda_global_cls", "ssim": "lambda_global_ssim", "id": "lambda_global_identity"}[term]] = {"cls": 10.0, "ssim": 1.0, "id": 1.0}[term]
+    cfg = dict(dino_model_name="dino_vitb8", entire_A_every=10 ** 9, cls_warmup=0, **lam)
+    A, B = synth.smooth_image_pair(224, 3, 224, 224)
+    A, B = torch.from_numpy(A), torch.from_numpy(B)
+    vit_state = synth.vit_params(7, "dino_vitb8", img_size=224, w_std=0.03)
+    gen_state = synth.generator_params(9, 0.02)
+    eng = MultiScaleEngine(cfg, vit_state, gen_state, (224, 224), None, scales=scales, fp8=True)
+    assert [e.ctx_g.T for e in eng.engines] == [785, 1601, 3137] and all(e.ctx_g.fp8 for e in eng.engines)
+    m = dino_vit.VisionTransformer(8, 768, 12, 12, img_size=224).eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in vit_state.items()})
+    orcs = [SpliceOracle(m, {k: torch.from_numpy(v) for k, v in gen_state.items()}, dict(cfg, dino_global_patch_size=sz)) for sz in scales]
+    inputs = {"step": 0, "A_global": A[None], "B_global": B[None]}
+    outputs = orcs[0].model_forward(inputs)
+    og = [torch.zeros_like(p) for p in orcs[0].params.values()]
+    per = []
+    for o in orcs:                      # one scale at a time: its graph is freed before the next one is built
+        o.params = orcs[0].params
+        d = OL.loss_g(o.vit, o.cfg, o.lambdas, outputs, inputs)
+        g = torch.autograd.grad(d["loss"], list(orcs[0].params.values()), allow_unused=True, retain_graph=True)
+        for acc, gi in zip(og, g):
+            if gi is not None:
+                acc += gi
+        per.append({k: float(v.detach()) for k, v in d.items()})
+        del d, g
+    total = sum(d["loss"] for d in per)
+    eng.step(A.to(DEV), B.to(DEV), None)
+    le = eng.losses()
+    worst = abs(le["loss"] - total) / abs(total)
+    for sz, d in zip(scales, per):
+        for k, v in d.items():
+            worst = max(worst, abs(le["scales"][sz][k] - v) / abs(v))
+    num = den = 0.0
+    for (pname, gt), go in zip(eng.gen.unflatten(eng.grads).items(), og):
+        if pname.endswith("0.bias") and pname != "9.0.bias":
+            continue
+        num += (gt.cpu().double() - go.reshape(-1).double()).norm().item() ** 2
+        den += go.double().norm().item() ** 2
+    rel = (num / den) ** 0.5
+    print(f"    configs[4] {term}: summed loss {le['loss']:.4f} vs oracle {total:.4f} (worst per-scale term deviation {worst:.3e}); gradient rel err {rel:.3e}")
+    assert worst < FP8_LOSS_TOL["loss_global_ssim" if term == "ssim" else "loss"], worst
+    assert rel < FP8_GRAD_TOL, rel
+
+
+def test_fp8_trajectory_reaches_reference_level(golden_dir):
+    """VERDICT r2 #3d: the 78-step fixture recorded from the REFERENCE loop (tests/golden/steps.npz, 64x64 pair, ViT-S/8-shaped
+    stand-in) optimised with the fp8 operand path: steps 0-2 within the fp8 loss table, and the level reached over steps
+    60..74 not worse than 1.25x the reference's -- the bar the bf16 path is held to (tests/test_step_gpu.py)."""
+    g = np.load(os.path.join(golden_dir, "steps.npz"))
+    A, B = synth.smooth_image_pair(32, 0, 64, 64)
+    cfg = dict(dino_model_name="dino_vits8", dino_global_patch_size=64)
+    eng = SpliceEngine(cfg, synth.vit_params(7, "dino_vits8", img_size=64, w_std=0.05), synth.generator_params(31, 0.02), (64, 64), (64, 64), fp8=True)
+    At, Bt = torch.from_numpy(A).to(DEV), torch.from_numpy(B).to(DEV)
+    mine = []
+    for _ in range(78):
+        eng.step(At, Bt, At)
+        mine.append(eng.losses()["loss"])
+    mine, ref = np.array(mine), g["a/losses"][:, 0]
+    assert np.isfinite(mine).all()
+    for i in range(3):
+        assert abs(mine[i] - ref[i]) / ref[i] < 4e-2, (i, mine[i], ref[i])
+    tail_mine, tail_ref = np.sort(mine[60:75])[:5].mean(), np.sort(ref[60:75])[:5].mean()
+    print(f"    fp8 path, level reached (steps 60..74): {tail_mine:.1f} vs reference {tail_ref:.1f}; first steps {mine[:3]} vs {ref[:3]}")
+    assert tail_mine < 1.25 * tail_ref
+
+
+def test_fp8_is_a_property_of_the_context_not_of_the_shared_vit():
+    """engines that share one frozen ViT keep their own precision -- a bf16 engine built AFTER an fp8 engine on the
+    same VitEngine produces bit for bit what it produces on a ViT no fp8 engine ever touched."""
+    cfg = dict(dino_model_name="dino_vits8", dino_global_patch_size=64)
+    vit_state = synth.vit_params(7, "dino_vits8", img_size=64, w_std=0.05)
+    gen_state = synth.generator_params(9, 0.02)
+    A, B = synth.smooth_image_pair(123, 0, 64, 64)
+    At, Bt = torch.from_numpy(A).to(DEV), torch.from_numpy(B).to(DEV)
+
+    def run(eng):
+        for _ in range(3):
+            eng.step(At, Bt, At)
+        torch.cuda.synchronize()
+        return eng.params.clone()
+
+    clean = run(SpliceEngine(cfg, vit_state, gen_state, (64, 64), (64, 64)))
+    e8 = SpliceEngine(cfg, vit_state, gen_state, (64, 64), (64, 64), fp8=True)
+    p8 = run(e8)
+    shared = run(SpliceEngine(cfg, None, gen_state, (64, 64), (64, 64), vit_engine=e8.vit))
+    assert e8.ctx_g.fp8 and not torch.equal(p8, clean)
+    assert torch.equal(shared, clean)
