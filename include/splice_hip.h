@@ -82,12 +82,17 @@ typedef struct splice_gemm_epilogue {
      * over 2^-9 .. 448) -- the GELU output of fc1 as the operand of the fp8 fc2.  N % 16 == 0, ld8 % 16 == 0. */
     uint8_t* out_f8;
     int ld8;
+    /* SPLICE_EPI_OUT_F8T: the same e4m3 bytes transposed, [N][ldt8] (ldt8 % 16 == 0) -- the token-contiguous operands of the
+     * fp8 attention (V^T tiles), written next to the row-major copy by the QKV projection */
+    uint8_t* out_f8_t;
+    int ldt8;
 } splice_gemm_epilogue;
 
 enum {
     SPLICE_EPI_BIAS = 1, SPLICE_EPI_RESID = 2, SPLICE_EPI_OUT_F32 = 4, SPLICE_EPI_OUT_BF = 8,
     SPLICE_EPI_OUT_T = 16, SPLICE_EPI_GELU = 32, SPLICE_EPI_GELU_GRAD = 64,
-    SPLICE_EPI_COLS_F32 = 128, SPLICE_EPI_ALPHA = 256, SPLICE_EPI_ROWDOT = 512, SPLICE_EPI_SCALE_RC = 1024, SPLICE_EPI_OUT_F8 = 2048
+    SPLICE_EPI_COLS_F32 = 128, SPLICE_EPI_ALPHA = 256, SPLICE_EPI_ROWDOT = 512, SPLICE_EPI_SCALE_RC = 1024, SPLICE_EPI_OUT_F8 = 2048,
+    SPLICE_EPI_OUT_F8T = 4096
 };
 
 int splice_gemm_nt_bf16(unsigned flags, const splice_bf16* A, int lda, const splice_bf16* B, int ldb,
@@ -124,6 +129,11 @@ int splice_attention_fwd(const splice_bf16* qkv, const splice_bf16* qkvT, int ld
                          int D, int H, float scale, splice_bf16* out, float* lse, splice_stream_t stream);
 /* dqkv [B*Tld][3D] bf16 from dout [B*Tld][D] (+ its transpose doutT [D][ldt]); delta is
  * [B][H][Tld] fp32 scratch (rowsum(dO * O), formed by the call). */
+/* The forward with e4m3 operands (BASELINE configs[4]): Q K^T and P V on the fp8 MFMA from UNSCALED e4m3 copies of qkv --
+ * qkv8 bytes [B*Tld][3D] row-major and qkvT8 bytes [3D][ldt8] transposed (ldt8 % 16 == 0), as the fp8 QKV projection writes them
+ * (SPLICE_EPI_OUT_F8 | SPLICE_EPI_OUT_F8T).  Output / lse as splice_attention_fwd; the backward runs on the bf16 tensors. */
+int splice_attention_fwd_fp8(const uint8_t* qkv8, const uint8_t* qkvT8, int ldt8, int B, int T, int Tld, int D, int H, float scale,
+                             splice_bf16* out, float* lse, splice_stream_t stream);
 int splice_attention_bwd(const splice_bf16* qkv, const splice_bf16* qkvT, int ldt, int B, int T, int Tld,
                          int D, int H, float scale, const splice_bf16* out, const float* lse,
                          const splice_bf16* dout, const splice_bf16* doutT, float* delta,
@@ -195,8 +205,9 @@ int splice_vit_ctx_info(void* ctx, int* T, int* Tld, int* rows);
  * undefined for layer depth-1, and d_block[depth-1] must be zero outside the [CLS] rows.  splice_step_create switches its
  * contexts to this mode; the extractor API (models/extractor.py:81-103 hands out every token) never does. */
 int splice_vit_ctx_set_top_cls_only(void* ctx, int on);
-/* precision of THIS context's QKV / fc1 / fc2 forward projections: 0 bf16 (default), 1 fp8 (needs splice_vit_enable_fp8) */
-int splice_vit_ctx_set_fp8(void* ctx, int on);
+/* precision of THIS context's forward: 0 bf16 (default); 1 = QKV / fc1 / fc2 projections on the fp8 MFMA; 3 = those + the attention
+ * forward (Q K^T, P V) on the fp8 MFMA.  Needs splice_vit_enable_fp8 on the engine.  The backward is bf16 in every mode. */
+int splice_vit_ctx_set_fp8(void* ctx, int mode);
 /* img fp32 [B][3][H][W]; normalize != 0 fuses transforms.Normalize (util/losses.py:19). */
 int splice_vit_forward(void* ctx, const float* img, int normalize, splice_stream_t stream);
 /* same; passes [0, grad_pass_begin) are no-grad targets (util/losses.py:79,91,101 `with torch.no_grad()`):

@@ -26,6 +26,7 @@ class GemmEpilogue(C.Structure):
         ("rd_other", C.c_void_p), ("ld_rd", C.c_int), ("rd_rows", C.c_int), ("rowdot", C.c_void_p),
         ("row_scale", C.c_void_p), ("col_scale", C.c_void_p),
         ("out_f8", C.c_void_p), ("ld8", C.c_int),
+        ("out_f8_t", C.c_void_p), ("ldt8", C.c_int),
     ]
 
 
@@ -48,7 +49,7 @@ class StepConfig(C.Structure):
 
 
 EPI_BIAS, EPI_RESID, EPI_OUT_F32, EPI_OUT_BF, EPI_OUT_T = 1, 2, 4, 8, 16
-EPI_GELU, EPI_GELU_GRAD, EPI_COLS_F32, EPI_ALPHA, EPI_ROWDOT, EPI_SCALE_RC, EPI_OUT_F8 = 32, 64, 128, 256, 512, 1024, 2048
+EPI_GELU, EPI_GELU_GRAD, EPI_COLS_F32, EPI_ALPHA, EPI_ROWDOT, EPI_SCALE_RC, EPI_OUT_F8, EPI_OUT_F8T = 32, 64, 128, 256, 512, 1024, 2048, 4096
 
 _vp, _i, _f, _sz, _u = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint
 
@@ -65,6 +66,7 @@ _SIGNATURES = {
     "splice_layernorm_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
     "splice_layernorm_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
     "splice_attention_fwd": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
+    "splice_attention_fwd_fp8": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
     "splice_attention_bwd": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "splice_attention_probs": ([_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
     "splice_augment_structure": ([_vp, _vp, _vp, _i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_float), _f, _vp], _i),

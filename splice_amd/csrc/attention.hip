@@ -128,6 +128,14 @@ __device__ __forceinline__ void attn_block_coords(int nx, int H, int B, int& xb,
     h = bh % H;
     b = bh / H;
 }
+// x0 * a0 + x1 * a1 with a FIXED rounding sequence: round(x0 * a0), then one fused multiply-add.  The two launch forms of the
+// forward (two wave groups / one group walking both key ranges) merge their partial softmax states with this; left to the
+// compiler's contraction the two code contexts fused different products and the forms differed in the last bit.
+__device__ __forceinline__ float merge2(float x0, float a0, float x1, float a1) {
+#pragma clang fp contract(off)
+    const float t = x0 * a0;          // (not inline asm: an asm statement reading MFMA results gets no hazard wait states)
+    return __builtin_fmaf(x1, a1, t);
+}
 // all of this wave's LDS-DMA has landed, then the workgroup barrier (other waves' pieces + ring slot free)
 __device__ __forceinline__ void dma_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -319,11 +327,11 @@ __global__ __launch_bounds__(256 * KS) void attn_fwd_kernel(AttnArgs a, int nx) 
                 const float mn = fmaxf(m0[qb], m1);
                 const float a0 = __builtin_amdgcn_exp2f(m0[qb] - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
                 m[qb] = mn;
-                l[qb] = l0[qb] * a0 + l1 * a1;
+                l[qb] = merge2(l0[qb], a0, l1, a1);
 #pragma unroll
                 for (int nd = 0; nd < 4; ++nd)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[qb][nd][r] = o0[qb][nd][r] * a0 + o[qb][nd][r] * a1;
+                    for (int r = 0; r < 4; ++r) o[qb][nd][r] = merge2(o0[qb][nd][r], a0, o[qb][nd][r], a1);
             }
         }
     } else {
@@ -358,11 +366,292 @@ __global__ __launch_bounds__(256 * KS) void attn_fwd_kernel(AttnArgs a, int nx) 
             const float mn = fmaxf(m[qb], m1);
             const float a0 = __builtin_amdgcn_exp2f(m[qb] - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
             m[qb] = mn;
-            l[qb] = l[qb] * a0 + l1 * a1;
+            l[qb] = merge2(l[qb], a0, l1, a1);
 #pragma unroll
             for (int nd = 0; nd < 4; ++nd)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[qb][nd][r] = o[qb][nd][r] * a0 + e[(2 + nd * 4 + r) * 64] * a1;
+                for (int r = 0; r < 4; ++r) o[qb][nd][r] = merge2(o[qb][nd][r], a0, e[(2 + nd * 4 + r) * 64], a1);
+        }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float lt = group4_sum(l[qb]);
+        const int q = qidx[qb];
+        if (q < a.Tld) {
+            const float inv = 1.0f / lt;
+            bf16_t* op = a.out + ((size_t)b * a.Tld + q) * a.D + h * 64 + g * 4;
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd) st4bf(op + nd * 16, o[qb][nd], inv);
+            if (g == 0) a.lse[((size_t)b * a.H + h) * a.Tld + q] = m[qb] + __builtin_amdgcn_logf(lt);   // log2 units
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// e4m3 forward (BASELINE configs[4], "fp8 MFMA attention"): Q K^T and P V on v_mfma_f32_16x16x32_fp8_fp8 from the unscaled
+// e4m3 copies of q, k, v the fp8 QKV projection writes beside its bf16 outputs (e4m3 is a floating format: its relative
+// precision, 2^-4, holds over 2^-9 .. 448 without a scale).  Same structure as the bf16 kernel -- swapped MFMAs, one query per
+// lane column, permuted score rows so that a lane's 8 probabilities are 8 consecutive tokens, LDS-DMA ring, deferred max, key
+// range in two halves -- on tiles of HALF the bytes:
+//   K  tile [64 keys][64 B of d]: one ds_read_b128 per 16-key block = the operands of BOTH k = 32 MFMAs of a score block
+//      (a lane's 16 bytes are d = 16 g .. 16 g + 15: low half -> first MFMA, high half -> second; Q is cut the same way);
+//   V^T tile [64 d][64 B of tokens]: one ds_read_b64 per (d block, 32-key sub-tile).
+// Rows are 64 B, so four rows share a bank window: K chunks are stored at c ^ 3 * (row bit 4), V^T chunks at c ^ (row >> 2 & 3)
+// (source-side swizzle of the DMA, both conflict-free for the lane groups of b128 / b64 reads).
+// Probabilities are formed against a reference point 6 binary orders BELOW the running maximum (p = 64 at the maximum) so
+// that e4m3's subnormal floor sits at 2^-15 of the largest term; a lane whose partial row sum reaches 448 (the format's
+// maximum) takes the exact-maximum path.  The row sums l accumulate the unquantised fp32 probabilities.
+// The backward stays on the bf16 kernels (it re-forms P from the bf16 q, k and the log-sum-exp saved here).
+typedef long fp8x8_t;
+struct TileDma8 {
+    int wave, r16, c16;
+    __device__ __forceinline__ TileDma8() {
+        const int lane = threadIdx.x & 63;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3;
+        r16 = lane >> 2;
+        c16 = lane & 3;
+    }
+    // rows = tokens tok0 .. tok0 + 63 (clamped to tok_max), 64 contiguous bytes at base + tok * ld; wave w moves rows 16 w .. 16 w + 15
+    __device__ __forceinline__ void token_tile(const uint8_t* base, int ld, int tok0, int tok_max, uint8_t* lds) const {
+        int t = tok0 + wave * 16 + r16;
+        t = t < tok_max ? t : tok_max;
+        const uint8_t* src = base + (size_t)t * ld + ((c16 ^ ((wave & 1) * 3)) << 4);
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(lds + wave * 1024), 16, 0, 0);
+    }
+    // rows = d, 64 contiguous tokens from tok0 at baseT + d * ldt; a 16-token chunk starting past tok_lim - 16 is replaced by the
+    // last in-bounds chunk (masked keys)
+    __device__ __forceinline__ void dim_tile(const uint8_t* baseT, int ldt, int tok0, int tok_lim, uint8_t* lds) const {
+        int t = tok0 + ((c16 ^ ((r16 >> 2) & 3)) << 4);
+        t = t <= tok_lim - 16 ? t : tok_lim - 16;
+        const uint8_t* src = baseT + (size_t)(wave * 16 + r16) * ldt + t;
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(lds + wave * 1024), 16, 0, 0);
+    }
+};
+struct FragAddr8 {   // per-lane LDS BYTE offsets
+    int tok;         // K tile: block nb of sub-tile sub -> tok + sub * 2048 + nb * 256      (b128)
+    int dim[2];      // V^T tile: d block nd, sub-tile sub -> dim[sub] + nd * 1024          (b64)
+    __device__ __forceinline__ FragAddr8(int g, int c) {
+        tok = ((c >> 2) * 8 + (c & 3)) * 64 + ((g ^ (((c >> 3) & 1) * 3)) << 4);
+        dim[0] = c * 64 + ((((g >> 1)) ^ ((c >> 2) & 3)) << 4) + ((g & 1) << 3);
+        dim[1] = c * 64 + (((2 + (g >> 1)) ^ ((c >> 2) & 3)) << 4) + ((g & 1) << 3);
+    }
+};
+__device__ __forceinline__ f32x4 mfma8(fp8x8_t a, fp8x8_t b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ fp8x8_t pack8_e4m3(const f32x4& a, const f32x4& b) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(b[0], b[1], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(b[2], b[3], hi, true);
+    return (fp8x8_t)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+#define ATTN8_REF_SHIFT 6.0f      // p = 2^6 at the reference maximum
+#define ATTN8_RESCALE_LIMIT 448.0f
+template <int QB, int NSUB, bool MASK>
+__device__ __forceinline__ void attn_fwd8_tile(const uint8_t* Ks, const uint8_t* Vs, const FragAddr8& fa, const u32x4 (&qf)[QB], float (&m)[QB],
+                                               float (&l)[QB], f32x4 (&o)[QB][4], float c2, int kt, int T, int g) {
+    f32x4 s[QB][NSUB * 2];
+#pragma unroll
+    for (int nb = 0; nb < NSUB * 2; ++nb) {
+        const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + fa.tok + (nb >> 1) * 2048 + (nb & 1) * 256);
+        const fp8x8_t k0 = (fp8x8_t)(((unsigned long long)kf[1] << 32) | kf[0]), k1 = (fp8x8_t)(((unsigned long long)kf[3] << 32) | kf[2]);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const fp8x8_t q0 = (fp8x8_t)(((unsigned long long)qf[qb][1] << 32) | qf[qb][0]), q1 = (fp8x8_t)(((unsigned long long)qf[qb][3] << 32) | qf[qb][2]);
+            s[qb][nb] = mfma8(k0, q0, f32x4{0.f, 0.f, 0.f, 0.f});
+            s[qb][nb] = mfma8(k1, q1, s[qb][nb]);
+        }
+    }
+    if (MASK) {
+#pragma unroll
+        for (int nb = 0; nb < NSUB * 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool valid = kt + (nb >> 1) * 32 + g * 8 + (nb & 1) * 4 + r < T;
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) s[qb][nb][r] = valid ? s[qb][nb][r] : NEG_BIG;
+            }
+    }
+    f32x4 p[QB][NSUB * 2];
+    float ps[QB];
+    bool over[QB];
+    bool redo = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        ps[qb] = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NSUB * 2; ++nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[qb][nb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][nb][r], c2, -m[qb]));
+            ps[qb] += (p[qb][nb][0] + p[qb][nb][1]) + (p[qb][nb][2] + p[qb][nb][3]);
+        }
+        over[qb] = !(ps[qb] < ATTN8_RESCALE_LIMIT);
+        redo |= over[qb];
+    }
+    if (__any(redo)) {
+        // exact step, executed by the whole wave but taking effect PER QUERY: only a query one of whose four lanes ran over moves its
+        // reference point (to its maximum - 6 binary orders); for the others mn = m, alpha = 1 and the same p come out again.  With
+        // the 448 limit this path runs now and then on real data, and a query's result must not depend on which other queries share
+        // its wave (16 or 32 per wave, one or two key groups: the launch forms have to agree bit for bit).
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int nb = 0; nb < NSUB * 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qb][nb][r]);
+            mx = group4_max(mx) * c2 - ATTN8_REF_SHIFT;
+            const bool mine = group4_max(over[qb] ? 1.0f : 0.0f) > 0.f;
+            const float mn = mine ? fmaxf(m[qb], mx) : m[qb];
+            const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
+            m[qb] = mn;
+            l[qb] *= alpha;
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[qb][nd][r] *= alpha;
+            ps[qb] = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < NSUB * 2; ++nb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[qb][nb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][nb][r], c2, -mn));
+                ps[qb] += (p[qb][nb][0] + p[qb][nb][1]) + (p[qb][nb][2] + p[qb][nb][3]);   // (the summation order of the fast path: an unaffected query keeps its bits)
+            }
+        }
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) l[qb] += ps[qb];
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+        fp8x8_t pb[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) pb[qb] = pack8_e4m3(p[qb][sub * 2], p[qb][sub * 2 + 1]);
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) {
+            const fp8x8_t vf = *reinterpret_cast<const fp8x8_t*>(Vs + fa.dim[sub] + nd * 1024);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) o[qb][nd] = mfma8(vf, pb[qb], o[qb][nd]);
+        }
+    }
+}
+
+template <int QB, int KS>
+__global__ __launch_bounds__(256 * KS) void attn_fwd8_kernel(AttnArgs a, int nx) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[KS * 2 * 2 * 4096 > 4 * QB * 18 * 256 ? KS * 2 * 2 * 4096 : 4 * QB * 18 * 256];   // [group][stage][K | V^T]; the merge exchange at the end
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, c = lane & 15;
+    const int grp = KS > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
+    int xb, h, b;
+    attn_block_coords(nx, a.H, a.B, xb, h, b);
+    const int ld = 3 * a.D;
+    const TileDma8 dma;
+    const FragAddr8 fa(g, c);
+    const int qbase = xb * (64 * QB) + dma.wave * (16 * QB);
+    const bool active = qbase < a.Tld;
+    const uint8_t* qkv_b = a.qkv8 + (size_t)b * a.Tld * ld;
+    const uint8_t* kbase = qkv_b + a.D + h * 64;
+    const uint8_t* vT = a.qkvT8 + (size_t)(2 * a.D + h * 64) * a.ldt8 + (size_t)b * a.Tld;
+    u32x4 qf[QB];
+    int qidx[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        int q = qbase + qb * 16 + c;
+        qidx[qb] = q;
+        q = q < a.Tld ? q : a.Tld - 1;
+        qf[qb] = *reinterpret_cast<const u32x4*>(qkv_b + (size_t)q * ld + h * 64 + g * 16);
+    }
+    auto issue = [&](int kt, uint8_t* st) {
+        dma.token_tile(kbase, ld, kt, a.Tld - 1, st);
+        dma.dim_tile(vT, a.ldt8, kt, a.Tld, st + 4096);
+    };
+    const int nt = (a.T + 63) / 64, per = (nt + 1) / 2;
+    const int t0 = KS > 1 ? grp * per : 0, t1 = KS > 1 ? min(nt, t0 + per) : nt;
+    uint8_t* ring = smem + grp * (2 * 8192);
+    if (t0 < t1) issue(t0 * 64, ring);
+    float m[QB], l[QB];
+    f32x4 o[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        m[qb] = NEG_BIG;
+        l[qb] = 0.f;
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) o[qb][nd] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float c2 = a.scale * LOG2E;
+    auto run_tile = [&](int tile, const uint8_t* cur) {
+        const int kt = tile * 64;
+        if (kt + 64 <= a.T) attn_fwd8_tile<QB, 2, false>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g);
+        else if (kt + 32 < a.T) attn_fwd8_tile<QB, 2, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g);
+        else attn_fwd8_tile<QB, 1, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g);
+    };
+    if (KS == 1) {   // both key ranges in one group, states merged as the two-group form merges them (same bits)
+        const int per2 = (nt + 1) / 2;
+        float m0[QB], l0[QB];
+        f32x4 o0[QB][4];
+        for (int it = 0; it < nt; ++it) {
+            dma_wait_barrier();
+            if (it + 1 < nt) issue((it + 1) * 64, ring + ((it + 1) & 1) * 8192);
+            if (it == per2) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    m0[qb] = m[qb]; l0[qb] = l[qb];
+                    m[qb] = NEG_BIG; l[qb] = 0.f;
+#pragma unroll
+                    for (int nd = 0; nd < 4; ++nd) { o0[qb][nd] = o[qb][nd]; o[qb][nd] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                }
+            }
+            if (active) run_tile(it, ring + (it & 1) * 8192);
+        }
+        if (nt > per2) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float m1 = m[qb], l1 = l[qb];
+                const float mn = fmaxf(m0[qb], m1);
+                const float a0 = __builtin_amdgcn_exp2f(m0[qb] - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
+                m[qb] = mn;
+                l[qb] = merge2(l0[qb], a0, l1, a1);
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[qb][nd][r] = merge2(o0[qb][nd][r], a0, o[qb][nd][r], a1);
+            }
+        }
+    } else {
+        for (int it = 0; it < per; ++it) {
+            dma_wait_barrier();
+            const int tile = t0 + it;
+            if (tile + 1 < t1) issue((tile + 1) * 64, ring + ((it + 1) & 1) * 8192);
+            if (active && tile < t1) run_tile(tile, ring + (it & 1) * 8192);
+        }
+        float* ex = reinterpret_cast<float*>(smem);   // [wave4][QB][18][64]
+        __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float* e = ex + ((dma.wave * QB + qb) * 18) * 64 + lane;
+                e[0] = m[qb];
+                e[64] = l[qb];
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e[(2 + nd * 4 + r) * 64] = o[qb][nd][r];
+            }
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const float* e = ex + ((dma.wave * QB + qb) * 18) * 64 + lane;
+            const float m1 = e[0], l1 = e[64];
+            const float mn = fmaxf(m[qb], m1);
+            const float a0 = __builtin_amdgcn_exp2f(m[qb] - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
+            m[qb] = mn;
+            l[qb] = merge2(l[qb], a0, l1, a1);
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[qb][nd][r] = merge2(o[qb][nd][r], a0, e[(2 + nd * 4 + r) * 64], a1);
         }
     }
     if (!active) return;
@@ -686,6 +975,17 @@ int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
     const int ks = g_attn_variant ? g_attn_variant / 10 + 1 : ((long)cdiv(a->Tld, 64 * qb) * a->H * a->B > ks2_wgs ? 1 : 2);
     const int nx = cdiv(a->Tld, 64 * qb);
     const dim3 grid(nx * a->H * a->B);
+    if (a->qkv8) {   // e4m3 forward
+        if (!a->qkvT8 || a->ldt8 % 16 || a->D % 16) return SPLICE_ERR_ARG;
+        if (ks == 2) {
+            if (qb == 2) SPLICE_LAUNCH((attn_fwd8_kernel<2, 2>), grid, dim3(512), 0, s, *a, nx);
+            else SPLICE_LAUNCH((attn_fwd8_kernel<1, 2>), grid, dim3(512), 0, s, *a, nx);
+        } else {
+            if (qb == 2) SPLICE_LAUNCH((attn_fwd8_kernel<2, 1>), grid, dim3(256), 0, s, *a, nx);
+            else SPLICE_LAUNCH((attn_fwd8_kernel<1, 1>), grid, dim3(256), 0, s, *a, nx);
+        }
+        return SPLICE_OK;
+    }
     if (ks == 2) {
         if (qb == 2) SPLICE_LAUNCH((attn_fwd_kernel<2, 2>), grid, dim3(512), 0, s, *a, nx);
         else SPLICE_LAUNCH((attn_fwd_kernel<1, 2>), grid, dim3(512), 0, s, *a, nx);

@@ -78,6 +78,14 @@ int splice_attention_fwd(const splice_bf16* qkv, const splice_bf16* qkvT, int ld
     a.out = out; a.lse = lse;
     return finish(attn_fwd_launch(&a, ST(stream)), "splice_attention_fwd");
 }
+int splice_attention_fwd_fp8(const uint8_t* qkv8, const uint8_t* qkvT8, int ldt8, int B, int T, int Tld, int D, int H, float scale,
+                             splice_bf16* out, float* lse, splice_stream_t stream) {
+    if (!qkv8 || !qkvT8 || !out || !lse) return finish(SPLICE_ERR_ARG, "splice_attention_fwd_fp8");
+    AttnArgs a = {};
+    a.qkv8 = qkv8; a.qkvT8 = qkvT8; a.ldt8 = ldt8; a.ldt = 4; a.B = B; a.T = T; a.Tld = Tld; a.D = D; a.H = H; a.scale = scale;
+    a.out = out; a.lse = lse;
+    return finish(attn_fwd_launch(&a, ST(stream)), "splice_attention_fwd_fp8");
+}
 int splice_attention_bwd(const splice_bf16* qkv, const splice_bf16* qkvT, int ldt, int B, int T, int Tld, int D, int H,
                          float scale, const splice_bf16* out, const float* lse, const splice_bf16* dout,
                          const splice_bf16* doutT, float* delta, splice_bf16* dqkv, splice_stream_t stream) {

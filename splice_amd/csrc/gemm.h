@@ -245,7 +245,8 @@ enum : unsigned {
     EPI_BIAS = SPLICE_EPI_BIAS, EPI_RESID = SPLICE_EPI_RESID, EPI_OUT_F32 = SPLICE_EPI_OUT_F32,
     EPI_OUT_BF = SPLICE_EPI_OUT_BF, EPI_OUT_T = SPLICE_EPI_OUT_T, EPI_GELU = SPLICE_EPI_GELU,
     EPI_GELU_GRAD = SPLICE_EPI_GELU_GRAD, EPI_COLS_F32 = SPLICE_EPI_COLS_F32, EPI_ALPHA = SPLICE_EPI_ALPHA,
-    EPI_ROWDOT = SPLICE_EPI_ROWDOT, EPI_SCALE_RC = SPLICE_EPI_SCALE_RC, EPI_OUT_F8 = SPLICE_EPI_OUT_F8
+    EPI_ROWDOT = SPLICE_EPI_ROWDOT, EPI_SCALE_RC = SPLICE_EPI_SCALE_RC, EPI_OUT_F8 = SPLICE_EPI_OUT_F8,
+    EPI_OUT_F8T = SPLICE_EPI_OUT_F8T
 };
 
 template <unsigned FLAGS>
@@ -517,6 +518,33 @@ __device__ __forceinline__ void gemm_stage_store_f8(const f32x4 (&acc)[BM / 32][
     }
 }
 
+// the transposed e4m3 tile: cs bytes [BN][BM + 16] (row = output column), stored as 16 bytes per lane along the rows of out [N][ld]
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_stage_store_f8t(const f32x4 (&acc)[BM / 32][BN / 32], uint8_t* cs, uint8_t* out, int ld, int M, int N, int m0, int n0) {
+    constexpr int FMt = BM / 32, FNt = BN / 32, PITCH = BM + 16, CH = BM / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FMt; ++i)
+#pragma unroll
+        for (int j = 0; j < FNt; ++j) {
+            const int lr = wm * (BM / 2) + i * 16 + (lane & 15), lc = wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+            const uint32_t w = pack4_e4m3_sat(acc[i][j]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[(lc + r) * PITCH + lr] = (uint8_t)(w >> (8 * r));
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < BN * CH; c += 256) {
+        const int r = c / CH, k = (c % CH) * 16;
+        const int gr = n0 + r, gc = m0 + k;
+        if (gr >= N || gc >= M) continue;
+        uint8_t* q = out + (size_t)gr * ld + gc;
+        if (gc + 15 < M) st_out(reinterpret_cast<u32x4*>(q), *reinterpret_cast<const u32x4*>(cs + r * PITCH + k));
+        else
+            for (int t = 0; t < 16 && gc + t < M; ++t) q[t] = cs[r * PITCH + k + t];
+    }
+}
+
 // the same for an fp32 output tile: cs [BM][BN + 4] floats; a lane's float4 becomes part of a full 256-byte row line
 template <int BM, int BN>
 __device__ __forceinline__ void gemm_stage_store_f32(const f32x4 (&acc)[BM / 32][BN / 32], float* cs, float* out, int ld, int M, int N, int m0, int n0) {
@@ -596,7 +624,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
     // staged bf16 outputs (see gemm_stage_store): every vector access of gemm_frag_value must be aligned
     const bool stage_ok = (FLAGS & EPI_OUT_BF) && !(N & 3) && (!(FLAGS & EPI_RESID) || !(e.ldr & 3)) && (!(FLAGS & EPI_GELU_GRAD) || !(e.ldaux & 3)) &&
                           (!(FLAGS & EPI_OUT_F32) || !(e.ldo & 3)) && (!(FLAGS & EPI_OUT_T) || !(e.ldt & 7));
-    if constexpr ((FLAGS & EPI_OUT_F8) != 0) {
+    if constexpr ((FLAGS & EPI_OUT_F8) != 0 && (FLAGS & EPI_OUT_BF) == 0) {
         // e4m3 output (fc1 of the fp8 MLP): [bf16 pre-activation of the gradient-carrying rows,] GELU, saturated e4m3 tile
         constexpr int FMt = GemmTile<BM, BN>::FM, FNt = GemmTile<BM, BN>::FN;
         static_assert((size_t)NS * GemmTile<BM, BN>::LDS_ELEMS >= (size_t)BM * (BN + 8), "the ring must hold one staged output tile");
@@ -659,6 +687,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
         }
         gemm_stage_store<BM, BN, false>(tile.acc, gemm_smem, e.out_bf, e.ldbf, M, N, m0, n0, 0);
         if (FLAGS & EPI_OUT_T) gemm_stage_store<BM, BN, true>(tile.acc, gemm_smem, e.out_bf_t, e.ldt, M, N, m0, n0, 0);
+        if constexpr ((FLAGS & EPI_OUT_F8) != 0) gemm_stage_store_f8<BM, BN>(tile.acc, reinterpret_cast<uint8_t*>(gemm_smem), e.out_f8, e.ld8, M, N, m0, n0);
+        if constexpr ((FLAGS & EPI_OUT_F8T) != 0) gemm_stage_store_f8t<BM, BN>(tile.acc, reinterpret_cast<uint8_t*>(gemm_smem), e.out_f8_t, e.ldt8, M, N, m0, n0);
         if (FLAGS & EPI_ROWDOT) {   // the row dots below use the bf16-ROUNDED result: round the accumulators in place
 #pragma unroll
             for (int i = 0; i < FMt; ++i)

@@ -115,10 +115,15 @@ int gemm_nt_fp8_launch(unsigned flags, const uint8_t* A, int lda, const uint8_t*
     if (!(flags & EPI_SCALE_RC) || !e.col_scale) return SPLICE_ERR_ARG;   // (row_scale may be NULL: unscaled e4m3 activations)
     if ((flags & EPI_OUT_T) && (e.ldt % 4)) return SPLICE_ERR_ARG;
     if ((flags & EPI_OUT_F8) && (!e.out_f8 || N % 16 || e.ld8 % 16 || (e.out_pre && e.ldp % 8))) return SPLICE_ERR_ARG;
+    if ((flags & EPI_OUT_F8T) && (!e.out_f8_t || e.ldt8 % 16)) return SPLICE_ERR_ARG;
+    // e4m3 copies beside the bf16 outputs leave through the staged-tile path only: its alignment conditions must hold
+    if ((flags & (EPI_OUT_F8 | EPI_OUT_F8T)) && (flags & EPI_OUT_BF) && (N % 16 || e.ldbf % 8 || ((flags & EPI_OUT_T) && e.ldt % 8))) return SPLICE_ERR_ARG;
 #define CASE8(F) case (F): return dispatch_fp8<(F)>(A, lda, B, ldb, M, N, K, e, s)
     switch (flags) {
         CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T);                  // qkv
         CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T | EPI_COLS_F32);   // qkv, last layer
+        CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T | EPI_OUT_F8 | EPI_OUT_F8T);                  // qkv + e4m3 copies for the fp8 attention
+        CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T | EPI_COLS_F32 | EPI_OUT_F8 | EPI_OUT_F8T);   // the same, last layer
         CASE8(EPI_SCALE_RC | EPI_OUT_F32);
         CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_GELU | EPI_OUT_F8);                   // fc1: e4m3 GELU output (+ bf16 pre-activation)
         CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_RESID | EPI_OUT_F32);                 // fc2

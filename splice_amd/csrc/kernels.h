@@ -19,6 +19,10 @@ struct AttnArgs {
     float* delta;          // [B][H][Tld]  rowsum(dO * O)
     int delta_ready;       // != 0: the caller already filled delta (the ViT engine: proj-dgrad GEMM epilogue)
     bf16_t* dqkv;          // [B*Tld][3D]
+    // e4m3 forward (BASELINE configs[4]; null = bf16 forward): the same qkv as unscaled e4m3 bytes, row-major and transposed
+    const uint8_t* qkv8;   // [B*Tld][3D]
+    const uint8_t* qkvT8;  // [3D][ldt8]
+    int ldt8;
 };
 int attn_fwd_launch(const AttnArgs* a, hipStream_t s);
 int attn_bwd_launch(const AttnArgs* a, hipStream_t s);

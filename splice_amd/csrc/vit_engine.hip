@@ -76,10 +76,11 @@ struct SpliceVitCtx {
     std::vector<float*> lse;               // depth x [B][H][Tld]
     float* qkv_last_f32 = nullptr;         // [rows][3D]
     bf16_t* ln_out = nullptr;              // [rows][D]   transient
-    int fp8 = 0;                           // this context's QKV / fc1 / fc2 forward projections run on the fp8 MFMA
+    int fp8 = 0;                           // bit 0: this context's QKV / fc1 / fc2 forward projections run on the fp8 MFMA; bit 1: so does its attention forward
     uint8_t* ln_out8 = nullptr;            // [rows][D]   e4m3 LayerNorm output (fp8 mode)
     float* ln_scale = nullptr;             // [rows]      its per-token scales
     uint8_t* hact8 = nullptr;              // [rows][4D]  e4m3 GELU output of fc1 = operand of fc2 (fp8 mode; unscaled)
+    uint8_t *qkv8 = nullptr, *qkvT8 = nullptr;   // [rows][3D] / [3D][rows] unscaled e4m3 copies of the current layer's qkv (fp8 attention forward)
     bf16_t* hact = nullptr;                // [rows][4D]  transient
     // backward temporaries (sized for all rows)
     float* g = nullptr;                    // [rows][D]
@@ -342,19 +343,24 @@ int splice_vit_ctx_set_top_cls_only(void* ctx, int on) {
     return SPLICE_OK;
 }
 
-// on != 0: this context's QKV, fc1 and fc2 forward projections run on the fp8 MFMA (e4m3 LayerNorm outputs with per-token
-// scales, e4m3 GELU output, e4m3 weights with per-channel scales); needs splice_vit_enable_fp8 on its engine first.
-int splice_vit_ctx_set_fp8(void* ctx, int on) {
+// mode bit 0: this context's QKV, fc1 and fc2 forward projections run on the fp8 MFMA (e4m3 LayerNorm outputs with per-token
+// scales, e4m3 GELU output, e4m3 weights with per-channel scales); bit 1 (needs bit 0): its attention forward too (Q K^T and
+// P V from unscaled e4m3 copies of q, k, v written by the QKV projection).  0 = bf16.  Needs splice_vit_enable_fp8 on the engine.
+int splice_vit_ctx_set_fp8(void* ctx, int mode) {
     SpliceVitCtx* c = (SpliceVitCtx*)ctx;
-    if (!c) return SPLICE_ERR_ARG;
-    if (on && !c->vit->fp8) { splice_set_error("splice_vit_ctx_set_fp8: the engine has no e4m3 weights (splice_vit_enable_fp8 first)"); return SPLICE_ERR_STATE; }
-    if (on && !c->ln_out8) {
-        const size_t rows = c->rows;
+    if (!c || mode < 0 || mode > 3 || mode == 2) return SPLICE_ERR_ARG;
+    if (mode && !c->vit->fp8) { splice_set_error("splice_vit_ctx_set_fp8: the engine has no e4m3 weights (splice_vit_enable_fp8 first)"); return SPLICE_ERR_STATE; }
+    const size_t rows = c->rows;
+    if (mode && !c->ln_out8) {
         RC(dev_alloc(c->allocs, &c->ln_out8, rows * c->vit->dim));
         RC(dev_alloc(c->allocs, &c->ln_scale, rows));
         RC(dev_alloc(c->allocs, &c->hact8, rows * c->vit->hidden));
     }
-    c->fp8 = on ? 1 : 0;
+    if ((mode & 2) && !c->qkv8) {
+        RC(dev_alloc(c->allocs, &c->qkv8, rows * 3 * c->vit->dim));
+        RC(dev_alloc(c->allocs, &c->qkvT8, rows * 3 * c->vit->dim));
+    }
+    c->fp8 = mode;
     return SPLICE_OK;
 }
 
@@ -411,7 +417,8 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
         const LayerW& W = v->layers[l];
         float* x_in = c->xs[l] + r0 * D;
         float* x_mid = c->xmid[l] + r0 * D;
-        const bool fp8 = c->fp8 && c->ln_out8 && W.qkv.w8;
+        const bool fp8 = (c->fp8 & 1) && c->ln_out8 && W.qkv.w8;
+        const bool fp8_attn = fp8 && (c->fp8 & 2) && c->qkv8;
         if (fp8) RC(layernorm_fwd_fp8_launch(x_in, W.ln1_g, W.ln1_b, c->ln_out8 + r0 * D, c->ln_scale + r0, c->mean1[l] + r0, c->rstd1[l] + r0, R, D, 1e-6f, s));
         else RC(layernorm_fwd_launch(x_in, W.ln1_g, W.ln1_b, ln_out, c->mean1[l] + r0, c->rstd1[l] + r0, R, D, 1e-6f, s));
         {
@@ -422,6 +429,10 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
             SpliceProfScope ps(l == L - 1 ? 0 : 2);
             if (fp8) {   // e4m3 LayerNorm output (per-token scale) x e4m3 weights (per-channel scale) on the fp8 MFMA
                 e.row_scale = c->ln_scale + r0; e.col_scale = W.qkv.w8_scale;
+                if (fp8_attn && !(l == L - 1 && c->top_cls_only)) {   // e4m3 copies of q, k, v for the fp8 attention forward of this layer
+                    fl |= EPI_OUT_F8 | EPI_OUT_F8T;
+                    e.out_f8 = c->qkv8 + r0 * 3 * D; e.ld8 = 3 * D; e.out_f8_t = c->qkvT8 + r0; e.ldt8 = c->rows;
+                }
                 RC(gemm_nt_fp8_launch(fl | EPI_SCALE_RC, c->ln_out8 + r0 * D, D, W.qkv.w8, D, R, 3 * D, D, e, s));
             } else {
                 RC(gemm_nt_launch(fl, ln_out, D, W.qkv.w, D, R, 3 * D, D, e, s));
@@ -468,6 +479,7 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
             AttnArgs a = {};
             a.qkv = c->qkv[l] + r0 * 3 * D; a.qkvT = c->qkvT[l] + r0; a.ldt = c->rows; a.B = Bp; a.T = c->T; a.Tld = c->Tld; a.D = D; a.H = v->heads;
             a.scale = 0.125f; a.out = c->attn_out[l] + r0 * D; a.lse = c->lse[l] + (size_t)pass_begin * v->heads * c->Tld;
+            if (fp8_attn) { a.qkv8 = c->qkv8 + r0 * 3 * D; a.qkvT8 = c->qkvT8 + r0; a.ldt8 = c->rows; }
             SpliceProfScope ps(3);
             RC(attn_fwd_launch(&a, s));
         }

@@ -63,10 +63,10 @@ class MultiPairEngine:
         self.device = torch.device(device)
         self.P = P = len(gen_states)
         self.vit = vit_engine or VitEngine(c["dino_model_name"], device=device).load_state_dict(vit_state)
-        # fp8=True (BASELINE configs[4]): the QKV, fc1 and fc2 forward projections and the key self-similarity Gram matrices on
-        # the fp8 MFMA (e4m3, block-scaled K = 128 form); attention, proj and the whole backward stay bf16 / fp32.  The mode is a
+        # fp8=True (BASELINE configs[4]): the QKV, fc1 and fc2 forward projections (e4m3, block-scaled K = 128 MFMA), the attention
+        # forward (Q K^T and P V on the fp8 MFMA) and the key self-similarity Gram matrices; proj and the whole backward stay bf16 / fp32.  The mode is a
         # property of THIS engine's contexts: another engine sharing the frozen ViT keeps its own.  Tolerances: tests/test_fp8_gpu.py.
-        self.fp8 = bool(fp8)
+        self.fp8 = fp8 if fp8 == "gemm" else bool(fp8)   # True: projections + attention forward in e4m3; "gemm": the projections only
         if self.fp8:
             self.vit.prepare_fp8()
         self.gen = GeneratorEngine(device=device)
@@ -98,7 +98,7 @@ class MultiPairEngine:
         self.plan_b = GeneratorPlan(self.gen, slots, ch, cw, True, arena_stride, batch_stats=batch)
         sc = _lib.StepConfig()
         sc.crop_h, sc.crop_w, sc.vit_h, sc.vit_w = ch, cw, vh, vw
-        sc.pairs, sc.arena_stride, sc.n_crops, sc.fp8_selfsim = P, arena_stride, self.n_crops, int(self.fp8)
+        sc.pairs, sc.arena_stride, sc.n_crops, sc.fp8_selfsim = P, arena_stride, self.n_crops, int(bool(self.fp8))
         # behind the last QKV projection only the [CLS] rows go on (all the losses read of the top block besides its keys):
         # +2.7 % / +5.2 % pair-steps/s at 4 / 8 pairs per GPU, neutral at one pair; top_cls_only=False
         # computes the whole top block as the reference does

@@ -36,10 +36,11 @@ class VitContext:
     """Activations of one (batch, image-shape) forward; see splice_vit_ctx_create."""
 
     def __init__(self, engine, B, H, W, need_grad, fp8=None):
-        """``fp8``: this context's QKV / fc1 / fc2 forward projections on the fp8 MFMA (None: the engine's default, which
-        ``VitEngine.enable_fp8()`` switches on for contexts it hands out itself)."""
+        """``fp8``: True -- this context's QKV / fc1 / fc2 forward projections AND its attention forward on the fp8 MFMA;
+        ``"gemm"`` -- the projections only; False -- bf16.  None: the engine's default (``VitEngine.enable_fp8()`` switches it on
+        for the contexts the engine hands out itself)."""
         self.engine, self.B, self.H, self.W, self.need_grad = engine, B, H, W, need_grad
-        self.fp8 = bool(getattr(engine, "fp8", False)) if fp8 is None else bool(fp8)
+        self.fp8 = getattr(engine, "fp8", False) if fp8 is None else fp8
         pos = interpolate_pos_encoding(engine.pos_embed, engine.patch, H, W).contiguous().float()
         h = C.c_void_p()
         _lib.check(_lib.lib().splice_vit_ctx_create(engine.handle, B, H, W, _lib.ptr(pos), int(need_grad),
@@ -50,7 +51,7 @@ class VitContext:
         _lib.check(_lib.lib().splice_vit_ctx_info(h, C.byref(t), C.byref(tld), C.byref(rows)))
         self.T, self.Tld, self.rows = t.value, tld.value, rows.value
         if self.fp8:
-            _lib.check(_lib.lib().splice_vit_ctx_set_fp8(h, 1), "vit_ctx_set_fp8")
+            _lib.check(_lib.lib().splice_vit_ctx_set_fp8(h, 1 if self.fp8 == "gemm" else 3), "vit_ctx_set_fp8")
 
     def __del__(self):
         try:
@@ -159,7 +160,7 @@ class VitEngine:
         return self
 
     def context(self, B, H, W, need_grad=True, fp8=None):
-        fp8 = bool(getattr(self, "fp8", False)) if fp8 is None else bool(fp8)
+        fp8 = getattr(self, "fp8", False) if fp8 is None else fp8
         key = (B, H, W, bool(need_grad), fp8)
         if key not in self._ctx:
             self._ctx[key] = VitContext(self, B, H, W, need_grad, fp8=fp8)

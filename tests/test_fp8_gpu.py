@@ -108,14 +108,15 @@ def test_fp8_vit_features_vs_oracle():
 
 
 # ---- the fp8 path's own tolerance table: bars <= 1.3x the worst value measured in round 3 (printed by the tests)
-# measured r3, QKV + fc1 + fc2 forward projections and the Gram matrices in e4m3 (worst over steps 0-2): layer-11 keys 9.2e-2 (an
+# measured r3, QKV + fc1 + fc2 forward projections, the attention forward and the Gram matrices in e4m3 (worst over steps 0-2;
+# without the fp8 attention: cls 1.84e-2, gradient 1.54e-1): layer-11 keys 9.2e-2 (an
 # e4m3 GEMM of uncorrelated operands carries ~3.7e-2 relative error by itself, test_fp8_gemm_exact_vs_emulation prints it; three
-# of them per block accumulate through the residual stream); losses <= 1.84e-2 (cls / total), <= 2.56e-2 (ssim), <= 1.2e-2 (id);
-# generator gradient 1.54e-1 (ViT-S/8 @ 64) / 6.1e-2 (ViT-B/8 @ 224) / 1.7e-1 (configs[4] ssim term at 224 + 320 + 448) -- against
+# of them per block accumulate through the residual stream); losses <= 2.53e-2 (cls / total), <= 2.56e-2 (ssim), <= 1.2e-2 (id);
+# generator gradient 1.65e-1 (ViT-S/8 @ 64) / 9.8e-2 (ViT-B/8 @ 224) / 1.7e-1 (configs[4] ssim term at 224 + 320 + 448) -- against
 # 6e-3 / 3e-3 / 7e-3 on the bf16 path.  What the optimisation makes of it: test_fp8_trajectory_reaches_reference_level.
 FP8_KEYS_TOL = 1.2e-1
-FP8_LOSS_TOL = {"loss": 2.4e-2, "loss_global_cls": 2.4e-2, "loss_entire_cls": 2.4e-2, "loss_global_ssim": 3.3e-2, "loss_entire_ssim": 3.3e-2, "loss_global_id_B": 1.6e-2}
-FP8_GRAD_TOL = 2e-1
+FP8_LOSS_TOL = {"loss": 3.3e-2, "loss_global_cls": 3.3e-2, "loss_entire_cls": 3.3e-2, "loss_global_ssim": 3.3e-2, "loss_entire_ssim": 3.3e-2, "loss_global_id_B": 1.6e-2}
+FP8_GRAD_TOL = 2.1e-1
 
 
 @pytest.mark.parametrize("name,size", [("dino_vits8", 64), ("dino_vitb8", 224)])
@@ -227,7 +228,7 @@ def test_fp8_trajectory_reaches_reference_level(golden_dir):
     mine, ref = np.array(mine), g["a/losses"][:, 0]
     assert np.isfinite(mine).all()
     for i in range(3):
-        assert abs(mine[i] - ref[i]) / ref[i] < 4e-2, (i, mine[i], ref[i])
+        assert abs(mine[i] - ref[i]) / ref[i] < 6.2e-2, (i, mine[i], ref[i])     # measured 4.8e-2 at step 0 (the fp8 attention's share: 1.9e-2 without it)
     tail_mine, tail_ref = np.sort(mine[60:75])[:5].mean(), np.sort(ref[60:75])[:5].mean()
     print(f"    fp8 path, level reached (steps 60..74): {tail_mine:.1f} vs reference {tail_ref:.1f}; first steps {mine[:3]} vs {ref[:3]}")
     assert tail_mine < 1.25 * tail_ref
@@ -254,3 +255,83 @@ def test_fp8_is_a_property_of_the_context_not_of_the_shared_vit():
     shared = run(SpliceEngine(cfg, None, gen_state, (64, 64), (64, 64), vit_engine=e8.vit))
     assert e8.ctx_g.fp8 and not torch.equal(p8, clean)
     assert torch.equal(shared, clean)
+
+
+def _e4m3(x):
+    return x.clamp(-448, 448).to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("B,T,variant", [(2, 785, 0), (1, 785, 12), (3, 197, 1), (1, 1601, 0)])
+def test_fp8_attention_forward(B, T, variant):
+    """splice_attention_fwd_fp8 (Q K^T and P V on the fp8 MFMA from unscaled e4m3 q, k, v; e4m3 probabilities against a
+    reference point 2^-6 below the running maximum) against fp32 attention on the SAME e4m3-rounded operands -- isolates what the
+    kernel adds: the quantisation of P (measured 2.3e-2 rel-L2 on N(0, 1) operands; bar 3e-2) -- and, for the record, against fp32
+    attention on the unquantised operands.  Rows of padding tokens are masked keys; variants: automatic / 32 queries per wave in
+    two key groups / 16 queries in one group (the launch forms must agree bit for bit, as in the bf16 kernel)."""
+    D, H = 768, 12
+    Tld = (T + 31) // 32 * 32
+    rows = B * Tld
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(rows, 3 * D, generator=g)
+    qkv[:, D:2 * D] += 0.5                      # key bias: scores with a common offset (softmax is shift invariant)
+    q8 = _e4m3(qkv).to(DEV)
+    q8T = q8.view(torch.uint8).T.contiguous()
+    deq = q8.float().reshape(B, Tld, 3, H, 64)[:, :T]
+
+    def ref(x):
+        q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+        s = (q @ k.transpose(-1, -2)) * 0.125
+        return (s.softmax(-1) @ v).transpose(1, 2).reshape(B, T, D), torch.logsumexp(s, -1)
+
+    want, lse_want = ref(deq)
+    true, _ = ref(qkv.to(DEV).reshape(B, Tld, 3, H, 64)[:, :T])
+    L = _lib.lib()
+    outs = []
+    for v in ([variant] if variant else [0, 1, 11, 2]):
+        L.splice_attention_variant(v)
+        out = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
+        lse = torch.zeros(B, H, Tld, device=DEV)
+        _lib.check(L.splice_attention_fwd_fp8(_lib.ptr(q8.view(torch.uint8)), _lib.ptr(q8T), rows, B, T, Tld, D, H, 0.125, _lib.ptr(out), _lib.ptr(lse),
+                                              _lib.current_stream()))
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+    L.splice_attention_variant(0)
+    got = outs[0].float().reshape(B, Tld, D)[:, :T]
+    e_same = ((got - want).norm() / want.norm()).item()
+    e_true = ((got - true).norm() / true.norm()).item()
+    e_lse = (lse[:, :, :T] * 0.6931471805599453 - lse_want).abs().max().item()
+    print(f"    fp8 attention B{B} T{T}: rel-L2 vs fp32 attention on the e4m3 operands {e_same:.3e}, vs unquantised operands {e_true:.3e}; lse abs err {e_lse:.2e}")
+    assert e_same < 3e-2 and e_lse < 2e-3
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
+def test_fp8_gemm_transposed_e4m3_outputs():
+    """The QKV projection of the fp8 mode writes, beside its bf16 outputs, the unscaled e4m3 copies the fp8 attention reads:
+    row-major [M][N] and transposed [N][M] -- both must be the e4m3 rounding of the bf16-unrounded result."""
+    M, N, K = 800, 2304, 768
+    A = torch.from_numpy(synth.normal(4, "fp8t/A", (M, K), 1.0)).to(DEV)
+    Bm = torch.from_numpy(synth.normal(5, "fp8t/B", (N, K), 0.03)).to(DEV)
+    bias = torch.from_numpy(synth.normal(6, "fp8t/b", (N,), 0.1)).to(DEV)
+    qa, sa = _quant_ref(A)
+    qb, sb = _quant_ref(Bm)
+    out = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+    outT = torch.zeros(N, M, device=DEV, dtype=torch.bfloat16)
+    o8 = torch.zeros(M, N, device=DEV, dtype=torch.uint8)
+    o8T = torch.zeros(N, M, device=DEV, dtype=torch.uint8)
+    e = _lib.GemmEpilogue()
+    e.bias = bias.data_ptr(); e.out_bf = out.data_ptr(); e.ldbf = N; e.out_bf_t = outT.data_ptr(); e.ldt = M
+    e.row_scale = sa.data_ptr(); e.col_scale = sb.data_ptr()
+    e.out_f8 = o8.data_ptr(); e.ld8 = N; e.out_f8_t = o8T.data_ptr(); e.ldt8 = M
+    fl = _lib.EPI_SCALE_RC | _lib.EPI_BIAS | _lib.EPI_OUT_BF | _lib.EPI_OUT_T | _lib.EPI_OUT_F8 | _lib.EPI_OUT_F8T
+    _lib.check(_lib.lib().splice_gemm_nt_fp8(fl, _lib.ptr(qa.view(torch.uint8).contiguous()), K, _lib.ptr(qb.view(torch.uint8).contiguous()), K, M, N, K,
+                                              C.byref(e), _lib.current_stream()))
+    torch.cuda.synchronize()
+    ref = ((qa.double() @ qb.double().T) * sa.double()[:, None] * sb.double()[None, :] + bias.double()).float()
+    got8 = o8.view(torch.float8_e4m3fn).float()
+    want8 = _e4m3(ref).float()
+    # summation order moves a value across an e4m3 rounding boundary now and then: at most one ulp (2^-3 relative), rarely
+    assert ((got8 - want8).abs() <= want8.abs() * 0.126 + 2.1e-3).all()      # (2^-9 = e4m3's subnormal spacing)
+    assert (got8 != want8).float().mean().item() < 2e-3
+    assert torch.equal(o8T, o8.T)
+    assert torch.equal(outT, out.T)

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/gtrace
-SPLICE_STEP_ABLATE=${ABL:-30} rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/gtrace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-kernels '' --pairs-sweep '' --no-train-regime > /dev/null 2>&1
+SPLICE_STEP_ABLATE=${ABL:-30} rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/gtrace -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --prof-kernels '' --pairs-sweep '' --no-train-regime --allow-dev-env > /dev/null 2>&1
 python - <<'PY'
 import csv, glob, os
 f = glob.glob(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/gtrace/*/*kernel_trace.csv")[0]

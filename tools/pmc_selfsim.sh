@@ -7,7 +7,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
            "GRBM_GUI_ACTIVE GRBM_COUNT" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
   i=$((i+1))
-  SPLICE_STEP_GRAPH=0 SPLICE_STEP_OVERLAP=0 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmc_ss_$P/p$i -- python $GRAFT_REPO_ROOT/bench.py --pairs $P --steps 6 --warmup 2 --no-cpu-baseline --prof-kernels '' --pairs-sweep '' --no-train-regime > /dev/null 2>&1
+  SPLICE_STEP_GRAPH=0 SPLICE_STEP_OVERLAP=0 rocprofv3 --kernel-trace --pmc $set --output-format csv -d /tmp/pmc_ss_$P/p$i -- python $GRAFT_REPO_ROOT/bench.py --pairs $P --steps 6 --warmup 2 --no-cpu-baseline --prof-kernels '' --pairs-sweep '' --no-train-regime --allow-dev-env > /dev/null 2>&1
 done
 PMC_ROOT=/tmp/pmc_ss_$P PMC_MATCH="${2:-selfsim,attn_}" python - <<'PY'
 import csv, glob, collections, os
