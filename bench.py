@@ -284,9 +284,9 @@ def main():
     ap.add_argument("--model", default="dino_vitb8")
     ap.add_argument("--pairs", type=int, default=1, help="pairs optimised side by side per GPU in the timed region (1 = the reference's unit: the latency form of the metric)")
     ap.add_argument("--pairs-sweep", default="2,4,8", help="additional pairs-per-GPU settings timed briefly after the main region (throughput form: pairs/hr); '' = off")
-    ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4] operand path: QKV projections + key self-similarity Gram on the fp8 MFMA (own tolerance table)")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4] operand path: QKV / fc1 / fc2 projections, attention forward and key self-similarity Gram on the fp8 MFMA (own tolerance table)")
     ap.add_argument("--scales", default="", help="BASELINE configs[4]: comma list of ViT input scales evaluated per step on the same crops (e.g. 224,320,448); "
-                                                 "one fused step per scale + one Adam (MultiScaleEngine); disables the sweep / roofline / train-regime legs")
+                                                 "one fused step per scale + one Adam (MultiScaleEngine); disables the pairs sweep and the train-regime leg")
     ap.add_argument("--full-top-block", action="store_true", help="compute the whole top ViT block (default: behind its QKV projection only the [CLS] rows, "
                                                                   "all the losses read besides the keys)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -336,7 +336,7 @@ def main():
         from splice_amd import synth
         from splice_amd.engine import MultiScaleEngine
         P = 1
-        args.pairs_sweep, args.prof_kernels, args.no_train_regime, args.no_cpu_baseline = "", "", True, True
+        args.pairs_sweep, args.no_train_regime, args.no_cpu_baseline = "", True, True
         Ai, Bi = synth.image_pair(1234, rep.pair_id(), hw[0], hw[1])
         eng = MultiScaleEngine(cfg, synth.vit_params(1234, args.model, img_size=224), synth.generator_params(1235 + rep.pair_id(), 0.02), hw, hw,
                                scales=scales, device=dev, fp8=args.fp8)
@@ -366,7 +366,7 @@ def main():
         torch.cuda.synchronize()
         _lib.check(_lib.lib().splice_prof_end_ex(C.byref(ms), C.byref(calls), C.byref(kernels)))
         if calls.value:
-            n_ent = sum(1 for st_ in range(eng.step_idx - nprof, eng.step_idx) if st_ % eng.cfg["entire_A_every"] == 0)
+            n_ent = sum(1 for st_ in range(eng.step_idx - nprof + 1, eng.step_idx + 1) if st_ % eng.cfg["entire_A_every"] == 0)
             prof[fam] = (ms.value, calls.value, kernels.value, nprof, n_ent)
     per_rank_elapsed = rep.gather_floats(elapsed)
     elapsed = rep.max_over_ranks(elapsed)
@@ -397,7 +397,12 @@ def main():
         rep.close()
         return
 
-    fams = kernel_families(T if not scales else T[0], D, eng.vit.heads, P, args.size)
+    if scales:   # every scale makes the same host calls per step: a family's mean FLOPs per call = the mean over the scales
+        per = [kernel_families(t, D, eng.vit.heads, P, args.size) for t in T]
+        fams = {k: (per[0][k][0] + f" (mean over the ViT input scales {scales})", per[0][k][1], sum(f[k][2] for f in per) / len(per)) for k in per[0]}
+        fams[7] = per[0][7]   # (the generator works at the crop size at every scale)
+    else:
+        fams = kernel_families(T, D, eng.vit.heads, P, args.size)
     roofs = []
     traffic_file = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     static_traffic = {}
@@ -449,7 +454,7 @@ def main():
     out = {
         "metric": "opt_steps_per_sec", "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "fp8(e4m3 qkv+selfsim)/bf16" if args.fp8 else "bf16", "data": "synthetic",
+        "dtype": "fp8(e4m3 qkv/fc1/fc2 + attention fwd + selfsim Gram)/bf16" if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"Splice pair {hw[0]}x{hw[1]}, {args.model} (T={T}), {P} pair(s) per GPU per step, "
                                f"{n_entire} of {K} timed steps include the entire-image branch"
                                + (f"; loss evaluated at the ViT input scales {scales} every step (configs[4])" if scales else ""),

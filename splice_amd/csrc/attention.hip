@@ -177,6 +177,7 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
     }
     f32x4 p[QB][NSUB * 2];
     float ps[QB];
+    bool over[QB];
     bool redo = false;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -188,9 +189,14 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
             part[nb] = (p[qb][nb][0] + p[qb][nb][1]) + (p[qb][nb][2] + p[qb][nb][3]);
         }
         ps[qb] = NSUB == 2 ? (part[0] + part[1]) + (part[NSUB * 2 - 2] + part[NSUB * 2 - 1]) : part[0] + part[1];
-        redo |= !(ps[qb] < ATTN_RESCALE_LIMIT);
+        over[qb] = !(ps[qb] < ATTN_RESCALE_LIMIT);
+        redo |= over[qb];
     }
-    if (__any(redo)) {   // exact online-softmax step for the whole wave (rare)
+    if (__any(redo)) {
+        // exact online-softmax step (rare): executed by the whole wave, taking effect PER QUERY -- only a query one of whose four
+        // lanes ran over moves its reference maximum; for the others mn = m, alpha = 1 and the same p and row sum come out again
+        // (same summation order as above).  A query's bits must not depend on which other queries share its wave: the launch
+        // forms (16 / 32 queries per wave, one / two wave groups) have to agree exactly.
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             float mx = NEG_BIG;
@@ -199,7 +205,8 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qb][nb][r]);
             mx = group4_max(mx) * c2;
-            const float mn = fmaxf(m[qb], mx);
+            const bool mine = group4_max(over[qb] ? 1.0f : 0.0f) > 0.f;
+            const float mn = mine ? fmaxf(m[qb], mx) : m[qb];
             const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
             m[qb] = mn;
             l[qb] *= alpha;
@@ -207,14 +214,14 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
             for (int nd = 0; nd < 4; ++nd)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[qb][nd][r] *= alpha;
-            ps[qb] = 0.f;
+            float part[NSUB * 2];
 #pragma unroll
-            for (int nb = 0; nb < NSUB * 2; ++nb)
+            for (int nb = 0; nb < NSUB * 2; ++nb) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    p[qb][nb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][nb][r], c2, -mn));
-                    ps[qb] += p[qb][nb][r];
-                }
+                for (int r = 0; r < 4; ++r) p[qb][nb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][nb][r], c2, -mn));
+                part[nb] = (p[qb][nb][0] + p[qb][nb][1]) + (p[qb][nb][2] + p[qb][nb][3]);
+            }
+            ps[qb] = NSUB == 2 ? (part[0] + part[1]) + (part[NSUB * 2 - 2] + part[NSUB * 2 - 1]) : part[0] + part[1];
         }
     }
 #pragma unroll
@@ -242,7 +249,7 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
 // bits do not depend on how many passes share the launch.
 template <int QB, int KS>
 __global__ __launch_bounds__(256 * KS) void attn_fwd_kernel(AttnArgs a, int nx) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[KS * 2 * 2 * 4096];   // [group][stage][K | V^T] tiles
+    __shared__ __attribute__((aligned(16))) bf16_t smem[KS * 2 * 2 * 4096 + (KS == 1 ? 4 * QB * 18 * 64 * 2 : 0)];   // [group][stage][K | V^T] tiles (+ one group: the parked first state)
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
     const int grp = KS > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
@@ -300,38 +307,47 @@ __global__ __launch_bounds__(256 * KS) void attn_fwd_kernel(AttnArgs a, int nx) 
         else attn_fwd_tile<QB, 1, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g);
     };
     if (KS == 1) {
-        // One group walks BOTH key ranges, one after the other, with a softmax state of its own for each, and merges them
-        // with the arithmetic of the two-group form below: bit for bit the same output (the batched launches keep their
-        // 4-wave workgroups -- many waves per SIMD anyway -- without making a pass's result depend on the batch size).
+        // One group walks BOTH key ranges, one after the other, and merges the two softmax states with the arithmetic of the
+        // two-group form below: bit for bit the same output (the batched launches keep their 4-wave workgroups -- many waves per
+        // SIMD anyway -- without making a pass's result depend on the batch size).  The first state waits in LDS, lane for lane
+        // (kept in registers it cost 40 VGPRs and a third of the batched kernel's speed).
         const int per2 = (nt + 1) / 2;
-        float m0[QB], l0[QB];
-        f32x4 o0[QB][4];
-        for (int it = 0; it < nt; ++it) {
-            dma_wait_barrier();
-            if (it + 1 < nt) issue((it + 1) * 64, ring + ((it + 1) & 1) * 8192);
-            if (it == per2) {   // second range: park the first state
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) {
-                    m0[qb] = m[qb]; l0[qb] = l[qb];
-                    m[qb] = NEG_BIG; l[qb] = 0.f;
-#pragma unroll
-                    for (int nd = 0; nd < 4; ++nd) { o0[qb][nd] = o[qb][nd]; o[qb][nd] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                }
+        float* park = reinterpret_cast<float*>(smem + 2 * 2 * 4096);   // [wave][QB][18][64], behind the ring
+        auto walk = [&](int tb, int te) {
+            for (int it = tb; it < te; ++it) {
+                dma_wait_barrier();
+                if (it + 1 < nt) issue((it + 1) * 64, ring + ((it + 1) & 1) * 8192);
+                if (active) run_tile(it, ring + (it & 1) * 8192);
             }
-            if (active) run_tile(it, ring + (it & 1) * 8192);
-        }
+        };
+        walk(0, per2);
         if (nt > per2) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
-                const float m1 = m[qb], l1 = l[qb];
-                const float mn = fmaxf(m0[qb], m1);
-                const float a0 = __builtin_amdgcn_exp2f(m0[qb] - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
+                float* e = park + ((dma.wave * QB + qb) * 18) * 64 + lane;
+                e[0] = m[qb];
+                e[64] = l[qb];
+                m[qb] = NEG_BIG; l[qb] = 0.f;
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e[(2 + nd * 4 + r) * 64] = o[qb][nd][r];
+                    o[qb][nd] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            walk(per2, nt);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float* e = park + ((dma.wave * QB + qb) * 18) * 64 + lane;
+                const float m0 = e[0], l0 = e[64], m1 = m[qb], l1 = l[qb];
+                const float mn = fmaxf(m0, m1);
+                const float a0 = __builtin_amdgcn_exp2f(m0 - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
                 m[qb] = mn;
-                l[qb] = merge2(l0[qb], a0, l1, a1);
+                l[qb] = merge2(l0, a0, l1, a1);
 #pragma unroll
                 for (int nd = 0; nd < 4; ++nd)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[qb][nd][r] = merge2(o0[qb][nd][r], a0, o[qb][nd][r], a1);
+                    for (int r = 0; r < 4; ++r) o[qb][nd][r] = merge2(e[(2 + nd * 4 + r) * 64], a0, o[qb][nd][r], a1);
             }
         }
     } else {
@@ -538,7 +554,8 @@ __device__ __forceinline__ void attn_fwd8_tile(const uint8_t* Ks, const uint8_t*
 
 template <int QB, int KS>
 __global__ __launch_bounds__(256 * KS) void attn_fwd8_kernel(AttnArgs a, int nx) {
-    __shared__ __attribute__((aligned(16))) uint8_t smem[KS * 2 * 2 * 4096 > 4 * QB * 18 * 256 ? KS * 2 * 2 * 4096 : 4 * QB * 18 * 256];   // [group][stage][K | V^T]; the merge exchange at the end
+    // [group][stage][K | V^T]; two groups: the merge exchange reuses it at the end; one group: the parked first state sits behind the ring
+    __shared__ __attribute__((aligned(16))) uint8_t smem[KS == 1 ? 2 * 8192 + 4 * QB * 18 * 256 : (KS * 2 * 8192 > 4 * QB * 18 * 256 ? KS * 2 * 8192 : 4 * QB * 18 * 256)];
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
     const int grp = KS > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
@@ -585,36 +602,48 @@ __global__ __launch_bounds__(256 * KS) void attn_fwd8_kernel(AttnArgs a, int nx)
         else if (kt + 32 < a.T) attn_fwd8_tile<QB, 2, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g);
         else attn_fwd8_tile<QB, 1, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g);
     };
-    if (KS == 1) {   // both key ranges in one group, states merged as the two-group form merges them (same bits)
+    if (KS == 1) {
+        // One group walks BOTH key ranges, one after the other, and merges the two softmax states with the arithmetic of the
+        // two-group form below: bit for bit the same output (the batched launches keep their 4-wave workgroups -- many waves per
+        // SIMD anyway -- without making a pass's result depend on the batch size).  The first state waits in LDS, lane for lane
+        // (kept in registers it cost 40 VGPRs and a third of the batched kernel's speed).
         const int per2 = (nt + 1) / 2;
-        float m0[QB], l0[QB];
-        f32x4 o0[QB][4];
-        for (int it = 0; it < nt; ++it) {
-            dma_wait_barrier();
-            if (it + 1 < nt) issue((it + 1) * 64, ring + ((it + 1) & 1) * 8192);
-            if (it == per2) {
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) {
-                    m0[qb] = m[qb]; l0[qb] = l[qb];
-                    m[qb] = NEG_BIG; l[qb] = 0.f;
-#pragma unroll
-                    for (int nd = 0; nd < 4; ++nd) { o0[qb][nd] = o[qb][nd]; o[qb][nd] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                }
+        float* park = reinterpret_cast<float*>(smem + 2 * 8192);   // [wave][QB][18][64], behind the ring
+        auto walk = [&](int tb, int te) {
+            for (int it = tb; it < te; ++it) {
+                dma_wait_barrier();
+                if (it + 1 < nt) issue((it + 1) * 64, ring + ((it + 1) & 1) * 8192);
+                if (active) run_tile(it, ring + (it & 1) * 8192);
             }
-            if (active) run_tile(it, ring + (it & 1) * 8192);
-        }
+        };
+        walk(0, per2);
         if (nt > per2) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
-                const float m1 = m[qb], l1 = l[qb];
-                const float mn = fmaxf(m0[qb], m1);
-                const float a0 = __builtin_amdgcn_exp2f(m0[qb] - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
+                float* e = park + ((dma.wave * QB + qb) * 18) * 64 + lane;
+                e[0] = m[qb];
+                e[64] = l[qb];
+                m[qb] = NEG_BIG; l[qb] = 0.f;
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e[(2 + nd * 4 + r) * 64] = o[qb][nd][r];
+                    o[qb][nd] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            walk(per2, nt);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const float* e = park + ((dma.wave * QB + qb) * 18) * 64 + lane;
+                const float m0 = e[0], l0 = e[64], m1 = m[qb], l1 = l[qb];
+                const float mn = fmaxf(m0, m1);
+                const float a0 = __builtin_amdgcn_exp2f(m0 - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
                 m[qb] = mn;
-                l[qb] = merge2(l0[qb], a0, l1, a1);
+                l[qb] = merge2(l0, a0, l1, a1);
 #pragma unroll
                 for (int nd = 0; nd < 4; ++nd)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[qb][nd][r] = merge2(o0[qb][nd][r], a0, o[qb][nd][r], a1);
+                    for (int r = 0; r < 4; ++r) o[qb][nd][r] = merge2(e[(2 + nd * 4 + r) * 64], a0, o[qb][nd][r], a1);
             }
         }
     } else {
@@ -960,19 +989,17 @@ void attn_set_variant(int v) { g_attn_variant = v; }
 
 int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
     if (a->Tld % 32 || a->D % 64 || a->D / 64 != a->H || a->ldt % 4) return SPLICE_ERR_ARG;
-    // 16 queries per wave while that still leaves fewer than ~3.5 waves per SIMD (latency hiding matters more than
-    // fragment reuse at ViT-B/8 @ 224: 2400 wave tasks on 1024 SIMDs); 32 per wave for the long sequences.
+    // Launch form (measured, tools/attn_bench.py at 2 / 8 / 16 passes of T = 785 and 2 passes of T = 3137, profiles/r03_attn_forms.txt):
+    // 16 queries per wave and TWO wave groups per workgroup (key-range halves side by side) is the fastest form at every batch
+    // size -- 13.4 / 31.6 / 60.9 us against 15.8 / 34.2 / 66.2 for one group walking both halves -- except where its 8-wave,
+    // 64 KB workgroups just miss one round of the chip (two fit a CU: 513 .. 768 workgroups, e.g. two pairs per GPU), where the
+    // one-group form runs (three 4-wave workgroups per CU).  Both forms, and 32 queries per wave (very long batches), produce
+    // the same bits.  variant (benchmarking hook): queries per wave / 16 + 10 * (wave groups - 1); 0 = automatic.
     const long tasks = (long)a->B * a->H * cdiv(a->Tld, 16);
-    static const long qb2_tasks = getenv("SPLICE_ATTN_QB2_TASKS") ? atol(getenv("SPLICE_ATTN_QB2_TASKS")) : 3600;
-    // variant (benchmarking hook): queries per wave / 16 + 10 * (key groups - 1); 0 = automatic
+    static const long qb2_tasks = getenv("SPLICE_ATTN_QB2_TASKS") ? atol(getenv("SPLICE_ATTN_QB2_TASKS")) : 60000;
     const int qb = g_attn_variant ? g_attn_variant % 10 : (tasks > qb2_tasks ? 2 : 1);
-    // two wave groups per workgroup (key range halves side by side) while the launch leaves SIMDs short of waves; the batched
-    // launches walk the two halves in one group (same arithmetic, same bits).  In-step A/B, same box: -0.9 % step time at one
-    // pair per GPU with two groups, +1.0 % at eight (profiles/r03_ab_preload.txt).
-    // (two 8-wave workgroups of 64 KB fit a CU: beyond 512 workgroups the two-group form would run in rounds -- measured
-    // -6 % pair-steps/s at two pairs per GPU with 624 of them)
-    static const long ks2_wgs = getenv("SPLICE_ATTN_KS2_WGS") ? atol(getenv("SPLICE_ATTN_KS2_WGS")) : 512;
-    const int ks = g_attn_variant ? g_attn_variant / 10 + 1 : ((long)cdiv(a->Tld, 64 * qb) * a->H * a->B > ks2_wgs ? 1 : 2);
+    const long wgs = (long)cdiv(a->Tld, 64 * qb) * a->H * a->B;
+    const int ks = g_attn_variant ? g_attn_variant / 10 + 1 : ((wgs > 512 && wgs <= 768) ? 1 : 2);
     const int nx = cdiv(a->Tld, 64 * qb);
     const dim3 grid(nx * a->H * a->B);
     if (a->qkv8) {   // e4m3 forward

@@ -179,7 +179,7 @@ def _attn_ref(qkv, B, T, Tld, D, H, scale):
     return o, x, p
 
 
-# (1, 3137, ...) = the 448x448 sequence length of BASELINE configs[3]: attn_fwd_kernel<2> (32 queries per wave) and the
+# (1, 3137, ...) = the 448x448 sequence length of BASELINE configs[3]: 50 key tiles per query block and the
 # two-launch backward (attn_bwd_q_kernel + attn_bwd_kv_kernel), which the T <= 785 cases never reach
 @pytest.mark.parametrize("B,T,D,H,std", [(1, 17, 384, 6, 1.0), (2, 197, 768, 12, 1.0), (2, 785, 768, 12, 0.6), (1, 785, 768, 12, 2.5),
                                          (1, 3137, 768, 12, 0.6), (2, 1601, 768, 12, 1.0)])
@@ -199,6 +199,16 @@ def test_attention_fwd_bwd(B, T, D, H, std):
     got = out.float().reshape(B, Tld, D)[:, :T]
     assert torch.isfinite(out.float()).all()
     assert _relerr(got, ref) < 6e-3, _relerr(got, ref)
+    # launch forms: 16 / 32 queries per wave x one / two wave groups per workgroup (the dispatcher picks by workgroup count) must
+    # agree BIT FOR BIT -- a pass's attention output may not depend on how many passes share the launch
+    if T <= 1601:
+        for variant in (1, 2, 11, 12):
+            L.splice_attention_variant(variant)
+            out_v, lse_v = torch.zeros_like(out), torch.zeros_like(lse)
+            _lib.check(L.splice_attention_fwd(_lib.ptr(qkv), _lib.ptr(qkvT), rows, B, T, Tld, D, H, scale, _lib.ptr(out_v), _lib.ptr(lse_v), _st()))
+            torch.cuda.synchronize()
+            L.splice_attention_variant(0)
+            assert torch.equal(out_v, out) and torch.equal(lse_v, lse), variant
     # probabilities API
     probs = torch.empty(B, H, T, T, device=DEV)
     _lib.check(L.splice_attention_probs(_lib.ptr(qkv), B, T, Tld, D, H, scale, _lib.ptr(lse), _lib.ptr(probs), _st()))
