@@ -327,6 +327,9 @@ typedef struct splice_step_config {
                                   * n_crops crops of ONE pair: A_crop / B_crop are [n_crops][3][h][w], the generator plans hold n_crops
                                   * images in batch-statistics mode (splice_gen_plan_set_batch_stats: netG sees the stacked crops,
                                   * data/transforms.py:27), each loss term is summed over the crops (util/losses.py:75-105), one arena */
+    int n_crops_b;               /* 0: global_B_crops_n_crops == n_crops.  > 0: the B-crop plan holds n_crops_b images and n_crops counts
+                                  * the A crops only -- the reference zips the crop lists (util/losses.py:76,87,98): structure term over the
+                                  * A crops, identity term over the B crops, appearance term over min(n_crops, n_crops_b) pairs */
 } splice_step_config;
 /* gen_plan_a / gen_plan_b: N = P plans at the crop size for the A and the B crops; gen_plan_entire: N = P at the entire size
  * (NULL with ent_h == 0).  Contexts: need_grad, B = 4P / 2P. */

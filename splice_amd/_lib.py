@@ -44,7 +44,7 @@ class StepConfig(C.Structure):
         ("lambda_entire_cls", C.c_float), ("lambda_entire_ssim", C.c_float),
         ("entire_every", C.c_int), ("cls_warmup", C.c_int),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-        ("pairs", C.c_int), ("arena_stride", C.c_longlong), ("fp8_selfsim", C.c_int), ("top_cls_only", C.c_int), ("n_crops", C.c_int),
+        ("pairs", C.c_int), ("arena_stride", C.c_longlong), ("fp8_selfsim", C.c_int), ("top_cls_only", C.c_int), ("n_crops", C.c_int), ("n_crops_b", C.c_int),
     ]
 
 

@@ -77,7 +77,8 @@ struct VitView {
 
 struct SpliceStep {
     splice_step_config cfg;
-    int P = 1;                   // pairs optimised side by side -- or, in crops mode, the n_crops global crops of ONE pair
+    int P = 1;                   // pairs optimised side by side -- or, in crops mode, the n_crops global crops of ONE pair (max of the two counts)
+    int Pa = 1, Pb = 1;          // images of the A-crop / B-crop plans: P in pairs mode; global_A_crops_n_crops / global_B_crops_n_crops in crops mode
     int Pe = 1;                  // images of the entire-image branch: P in pairs mode, 1 in crops mode (netG(A) is one image there)
     int crops_mode = 0;          // the P slots are crops of one pair: one generator (batch-statistics plans), losses summed over the crops
     size_t astride = 0;          // floats between the pairs' parameter / gradient / moment arenas (P > 1, pairs mode)
@@ -257,20 +258,29 @@ int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void
     if (!cfg || !vit_ctx_global || !gen_plan_a || !gen_plan_b || !out) return SPLICE_ERR_ARG;
     SpliceStep* st = new SpliceStep();
     st->cfg = *cfg;
-    if (cfg->n_crops > 1 && cfg->pairs > 1) { splice_set_error("splice_step_create: n_crops > 1 and pairs > 1 cannot be combined"); delete st; return SPLICE_ERR_ARG; }
-    st->crops_mode = cfg->n_crops > 1;
-    const int P = st->P = st->crops_mode ? cfg->n_crops : cfg->pairs > 1 ? cfg->pairs : 1;
+    if ((cfg->n_crops > 1 || cfg->n_crops_b > 1) && cfg->pairs > 1) { splice_set_error("splice_step_create: n_crops > 1 and pairs > 1 cannot be combined"); delete st; return SPLICE_ERR_ARG; }
+    st->crops_mode = cfg->n_crops > 1 || cfg->n_crops_b > 1;
+    // crops mode: the reference zips the crop lists (util/losses.py:76,87,98) -- the structure term runs over the A crops, the
+    // identity term over the B crops, the appearance term over min(nA, nB) pairs -- while netG's BatchNorm sees every crop of
+    // its call (models/model.py:15-23): the two plans may hold different numbers of images
+    const int nb_crops = cfg->n_crops_b > 0 ? cfg->n_crops_b : cfg->n_crops;
+    if (st->crops_mode && (nb_crops < 1 || nb_crops > 8 || cfg->n_crops > 8)) { splice_set_error("splice_step_create: 1..8 crops per side"); delete st; return SPLICE_ERR_ARG; }
+    const int Pa = st->Pa = st->crops_mode ? cfg->n_crops : cfg->pairs > 1 ? cfg->pairs : 1;
+    const int Pb = st->Pb = st->crops_mode ? nb_crops : Pa;
+    const int P = st->P = Pa > Pb ? Pa : Pb;
     const int Pe = st->Pe = st->crops_mode ? 1 : P;
     st->max_crop_h = cfg->crop_h; st->max_crop_w = cfg->crop_w;
     st->cropb_h = cfg->crop_h; st->cropb_w = cfg->crop_w;
     int rc = SPLICE_OK;
     auto fail = [&](int code) { for (void* q : st->allocs) (void)hipFree(q); delete st; return code; };
-    if ((rc = view_init(st, st->vg, vit_ctx_global, 4 * P)) != SPLICE_OK) return fail(rc);
+    if ((rc = view_init(st, st->vg, vit_ctx_global, 2 * (Pa + Pb))) != SPLICE_OK) return fail(rc);
     if (st->vg.H != cfg->vit_h || st->vg.W != cfg->vit_w) { splice_set_error("splice_step_create: global ViT context shape mismatch"); return fail(SPLICE_ERR_ARG); }
     int n, h, w;
-    for (void* plan : {gen_plan_a, gen_plan_b}) {
+    for (int k = 0; k < 2; ++k) {
+        void* plan = k ? gen_plan_b : gen_plan_a;
+        const int want = k ? Pb : Pa;
         if ((rc = splice_gen_plan_dims(plan, &n, &h, &w, &st->nparams)) != SPLICE_OK) return fail(rc);
-        if (n != P || h != cfg->crop_h || w != cfg->crop_w) { splice_set_error("splice_step_create: the crop generator plans must hold %d image(s) at the crop size", P); return fail(SPLICE_ERR_ARG); }
+        if (n != want || h != cfg->crop_h || w != cfg->crop_w) { splice_set_error("splice_step_create: the crop generator plans must hold %d / %d image(s) at the crop size", Pa, Pb); return fail(SPLICE_ERR_ARG); }
     }
     st->plan_a = gen_plan_a; st->plan_b = gen_plan_b;
     if (P > 1 && !st->crops_mode) {
@@ -390,7 +400,7 @@ int splice_step_set_running_stats(void* h, float* running, long long stride) {
 static int step_body(SpliceStep* st, float* params, float* grads, float* m, float* v, bool ssim_on, bool entire, hipStream_t s) {
     const splice_step_config& c = st->cfg;
     VitView& vg = st->vg;
-    const int P = st->P;
+    const int P = st->P, Pa = st->Pa, Pb = st->Pb, Pc = Pa < Pb ? Pa : Pb;   // Pc: pairs of the appearance term (zip of x' and B')
     const float l_ssim = ssim_on ? c.lambda_global_ssim : 0.f, l_id = ssim_on ? c.lambda_global_identity : 0.f;
     const float l_cls = c.lambda_global_cls;
     const float l_essim = entire ? c.lambda_entire_ssim : 0.f, l_ecls = entire ? c.lambda_entire_cls : 0.f;
@@ -398,8 +408,8 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     const float* A_crop = st->gen_in;
     const float* B_crop = st->in_b;
     const float* A_entire = st->ent_in;
-    // pass layout of the global context: [0, P) A'   [P, 2P) B'   [2P, 3P) x' = G(A crop)   [3P, 4P) y' = G(B crop)
-    const int pA = 0, pB = P, pX = 2 * P, pY = 3 * P;
+    // pass layout of the global context: [0, Pa) A'   [Pa, Pa + Pb) B'   then x' = G(A crops) (Pa passes), y' = G(B crops) (Pb passes)
+    const int pA = 0, pB = Pa, pX = Pa + Pb, pY = 2 * Pa + Pb, pEnd = 2 * (Pa + Pb);
     // ---- the no-grad target passes A', B' (util/losses.py:79,91,101) do not depend on the generator: their ViT forward
     // runs on a side stream beside the generator forward (hundreds of small latency-bound launches that leave most
     // CUs idle); inside a capture this becomes a fork/join of the graph.  The instrumented (profiling) path stays serial.
@@ -416,8 +426,8 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         RC(splice_gen_forward_borrowed(st->plan_b, params, B_crop, st->gen_out_b, s2));
         if (overlap) HIPCHK(hipEventRecord(st->ev_gb, s2));
     }
-    RC(place_images(A_crop, c.crop_h, c.crop_w, vg.imgs + pA * vimg, vg.H, vg.W, P, s2));
-    RC(place_images(B_crop, st->cropb_h, st->cropb_w, vg.imgs + pB * vimg, vg.H, vg.W, P, s2));
+    RC(place_images(A_crop, c.crop_h, c.crop_w, vg.imgs + pA * vimg, vg.H, vg.W, Pa, s2));
+    RC(place_images(B_crop, st->cropb_h, st->cropb_w, vg.imgs + pB * vimg, vg.H, vg.W, Pb, s2));
     if (!(st->ablate & 8)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, pX, pA, pX, s2));
     float *blk_g = nullptr, *qkv_g = nullptr;
     RC(splice_vit_get_tensor(vg.ctx, 0, vg.depth - 1, (void**)&blk_g));
@@ -425,11 +435,11 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     // everything of the loss stage that does not need the generated images also runs here, off the critical path
     RC(dev_zero_launch(st->losses, (size_t)P * st->lstride * sizeof(float), s2));
     const size_t passD = (size_t)vg.Tld * vg.D;
-    RC(dev_zero_launch(vg.d_block + pX * passD, (size_t)2 * P * passD * sizeof(float), s2));
-    RC(dev_zero_launch(vg.d_keys + pX * passD, (size_t)2 * P * passD * sizeof(float), s2));
+    RC(dev_zero_launch(vg.d_block + pX * passD, (size_t)(Pa + Pb) * passD * sizeof(float), s2));
+    RC(dev_zero_launch(vg.d_keys + pX * passD, (size_t)(Pa + Pb) * passD * sizeof(float), s2));
     SelfSimBatch sb = {};
     if (l_ssim > 0.f) {   // target self-similarity S* of A' (util/losses.py:79)
-        RC(ssim_batch(st, vg, pA, pX, P, l_ssim, L_GLOBAL_SSIM, &sb));
+        RC(ssim_batch(st, vg, pA, pX, Pa, l_ssim, L_GLOBAL_SSIM, &sb));
         RC(selfsim_target_launch(sb, s2));
     }
     if (overlap) HIPCHK(hipEventRecord(st->ev_join, s2));
@@ -438,18 +448,18 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         RC(splice_gen_forward_borrowed(st->plan_a, params, A_crop, st->gen_out, s));
         if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_gb, 0));
     }
-    RC(place_images(st->gen_out, c.crop_h, c.crop_w, vg.imgs + pX * vimg, vg.H, vg.W, P, s));
-    RC(place_images(st->gen_out_b, st->cropb_h, st->cropb_w, vg.imgs + pY * vimg, vg.H, vg.W, P, s));
-    if (!(st->ablate & 16)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, pX, pX, 4 * P, s));
+    RC(place_images(st->gen_out, c.crop_h, c.crop_w, vg.imgs + pX * vimg, vg.H, vg.W, Pa, s));
+    RC(place_images(st->gen_out_b, st->cropb_h, st->cropb_w, vg.imgs + pY * vimg, vg.H, vg.W, Pb, s));
+    if (!(st->ablate & 16)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, pX, pX, pEnd, s));
     if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
     // ---- losses on the global batch
     if (l_ssim > 0.f) RC(selfsim_loss_launch(sb, s));
     if (l_cls > 0.f)   // [CLS] of block 11, before the final LayerNorm (util/losses.py:90-93)
         RC(mse_batched_launch(blk_g + pX * passD, vg.D, passD, blk_g + pB * passD, vg.D, passD, 1, vg.D, 1.0f, l_cls, loss_part(st, L_GLOBAL_CLS),
-                              st->lstride, vg.d_block + pX * passD, vg.D, passD, P, s));
+                              st->lstride, vg.d_block + pX * passD, vg.D, passD, Pc, s));
     if (l_id > 0.f)    // keys of y' against keys of B' (util/losses.py:96-105): mean over h*T*d = T*D
         RC(mse_batched_launch(keys_ptr(vg, qkv_g, pY), 3 * vg.D, 3 * passD, keys_ptr(vg, qkv_g, pB), 3 * vg.D, 3 * passD, vg.T, vg.D, 1.0f, l_id,
-                              loss_part(st, L_GLOBAL_ID), st->lstride, vg.d_keys + pY * passD, vg.D, passD, P, s));
+                              loss_part(st, L_GLOBAL_ID), st->lstride, vg.d_keys + pY * passD, vg.D, passD, Pb, s));
     // ---- entire-image branch (every entire_every-th step): passes [0, Pe) A_entire', [Pe, 2 Pe) x_entire'
     const int Pe = st->Pe;
     if (entire) {
@@ -497,8 +507,8 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
             HIPCHK(hipEventRecord(st->ev_fork, s));
             HIPCHK(hipStreamWaitEvent(s2, st->ev_fork, 0));
         }
-        if (!(st->ablate & 32)) RC(splice_vit_backward(vg.ctx, pY, 4 * P, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s2));
-        RC(unplace_grads(vg.d_imgs + pY * vimg, vg.H, vg.W, st->d_gen_out_b, st->cropb_h, st->cropb_w, P, s2));
+        if (!(st->ablate & 32)) RC(splice_vit_backward(vg.ctx, pY, pEnd, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s2));
+        RC(unplace_grads(vg.d_imgs + pY * vimg, vg.H, vg.W, st->d_gen_out_b, st->cropb_h, st->cropb_w, Pb, s2));
         // each chain continues into its own generator plan (own gradient arena: no cross-chain accumulation)
         if (!(st->ablate & 2)) RC(splice_gen_backward(st->plan_b, params, st->d_gen_out_b, st->grads_b, 0, s2));
         if (overlap) {
@@ -510,7 +520,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
             HIPCHK(hipEventRecord(st->ev_join, s2));
         }
         RC(splice_vit_backward(vg.ctx, pX, pY, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
-        RC(unplace_grads(vg.d_imgs + pX * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, P, s));
+        RC(unplace_grads(vg.d_imgs + pX * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, Pa, s));
         if (!(st->ablate & 2)) RC(splice_gen_backward(st->plan_a, params, st->d_gen_out, grads, st->accumulate, s));
         if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
         // grads = g(A) + g(B): folded into the Adam kernel on ordinary steps; a separate add when the entire-image branch
@@ -588,8 +598,8 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
     // ---- stage the inputs (eager)
     {
         StageArgs sa = {};
-        sa.src[0] = A_crop; sa.dst[0] = st->gen_in; sa.n[0] = (size_t)P * 3 * c.crop_h * c.crop_w;
-        sa.src[1] = B_crop; sa.dst[1] = st->in_b; sa.n[1] = (size_t)P * 3 * st->cropb_h * st->cropb_w;
+        sa.src[0] = A_crop; sa.dst[0] = st->gen_in; sa.n[0] = (size_t)st->Pa * 3 * c.crop_h * c.crop_w;
+        sa.src[1] = B_crop; sa.dst[1] = st->in_b; sa.n[1] = (size_t)st->Pb * 3 * st->cropb_h * st->cropb_w;
         if (entire) { sa.src[2] = A_entire; sa.dst[2] = st->ent_in; sa.n[2] = (size_t)st->Pe * 3 * c.ent_h * c.ent_w; }
         sa.ip = st->dev_t; sa.iv = step_idx + 1;
         SPLICE_LAUNCH(stage_inputs_kernel, dim3(128 * (P > 4 ? 4 : P)), dim3(256), 0, s, sa);

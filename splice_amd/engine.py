@@ -55,7 +55,11 @@ class MultiPairEngine:
         (BatchNorm statistics over the crops), every loss term is summed over the crops."""
         self.cfg = dict(DEFAULT_CFG, **cfg)
         c = self.cfg
-        self.n_crops = int(n_crops)
+        # n_crops: int, or (nA, nB) = (global_A_crops_n_crops, global_B_crops_n_crops) -- the reference zips the crop lists
+        # (util/losses.py:76,87,98): structure term over the A crops, identity term over the B crops, appearance term over min pairs
+        nA, nB = (int(n_crops), int(n_crops)) if isinstance(n_crops, int) else (int(n_crops[0]), int(n_crops[1]))
+        self.n_crops_ab = (nA, nB)
+        self.n_crops = max(nA, nB)
         if self.n_crops > 1 and len(gen_states) != 1:
             raise ValueError("n_crops > 1 is a property of ONE pair: pass a single generator state")
         if c["optimizer"] != "adam" or c["scheduler_policy"] != "none":
@@ -88,17 +92,20 @@ class MultiPairEngine:
         ch, cw = crop_hw
         vh, vw = resize_output_size(ch, cw, Pz, 480)
         self.crop_hw, self.vit_hw = (ch, cw), (vh, vw)
-        slots = self.slots = self.n_crops if self.n_crops > 1 else P    # images per generator plan / per ViT pass group
+        slots = self.slots = self.n_crops if self.n_crops > 1 else P    # images per generator plan / per ViT pass group (maximum of the two sides)
+        sa, sb = (nA, nB) if self.n_crops > 1 else (P, P)
+        self.slots_ab = (sa, sb)
         batch = self.n_crops > 1
         # (the [CLS]-only mode is a property of the context: such contexts are private, never shared with the extractor API)
-        self.ctx_g = VitContext(self.vit, 4 * slots, vh, vw, True, fp8=self.fp8) if top_cls_only else self.vit.context(4 * slots, vh, vw, need_grad=True, fp8=self.fp8)
+        self.ctx_g = VitContext(self.vit, 2 * (sa + sb), vh, vw, True, fp8=self.fp8) if top_cls_only else self.vit.context(2 * (sa + sb), vh, vw, need_grad=True, fp8=self.fp8)
         arena_stride = self.stride if P > 1 else 0
         # private plan objects (the shape-keyed plan cache could hand out one plan twice)
-        self.plan_a = GeneratorPlan(self.gen, slots, ch, cw, True, arena_stride, batch_stats=batch)
-        self.plan_b = GeneratorPlan(self.gen, slots, ch, cw, True, arena_stride, batch_stats=batch)
+        self.plan_a = GeneratorPlan(self.gen, sa, ch, cw, True, arena_stride, batch_stats=batch and sa > 1)
+        self.plan_b = GeneratorPlan(self.gen, sb, ch, cw, True, arena_stride, batch_stats=batch and sb > 1)
         sc = _lib.StepConfig()
         sc.crop_h, sc.crop_w, sc.vit_h, sc.vit_w = ch, cw, vh, vw
-        sc.pairs, sc.arena_stride, sc.n_crops, sc.fp8_selfsim = P, arena_stride, self.n_crops, int(bool(self.fp8))
+        sc.pairs, sc.arena_stride, sc.fp8_selfsim = P, arena_stride, int(bool(self.fp8))
+        sc.n_crops, sc.n_crops_b = (nA, nB) if self.n_crops > 1 else (1, 0)
         # behind the last QKV projection only the [CLS] rows go on (all the losses read of the top block besides its keys):
         # +2.7 % / +5.2 % pair-steps/s at 4 / 8 pairs per GPU, neutral at one pair; top_cls_only=False
         # computes the whole top block as the reference does
@@ -141,9 +148,9 @@ class MultiPairEngine:
         """One optimisation step of every pair, asynchronous on the current stream.  Tensors: fp32 CUDA ``[P,3,h,w]`` in
         [0,1] (``[3,h,w]`` accepted for P = 1).  Returns the device tensor ``[P,8]`` of losses (see LOSS_KEYS)."""
         self.step_idx += 1
-        for t in (A_crop, B_crop):
+        for t, n in ((A_crop, self.slots_ab[0]), (B_crop, self.slots_ab[1])):
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
-            assert t.numel() == self.slots * 3 * t.shape[-2] * t.shape[-1], (tuple(t.shape), self.slots)
+            assert t.numel() == n * 3 * t.shape[-2] * t.shape[-1], (tuple(t.shape), n)
         crops = tuple(A_crop.shape[-2:]) + tuple(B_crop.shape[-2:])
         if crops != self._cur_crops:   # per-step random crop sizes (data/transforms.py:21-22)
             _lib.check(_lib.lib().splice_step_set_crops(self.handle, *crops), "step_set_crops")

@@ -111,11 +111,11 @@ def train_model(dataroot, callback=None, cfg_overrides=None, vit_state=None, pro
     if dataroot is not None:
         cfg['dataroot'] = dataroot
     cfg.update(cfg_overrides or {})
-    n_crops = int(cfg['global_A_crops_n_crops'])
-    if n_crops != int(cfg['global_B_crops_n_crops']) or not 1 <= n_crops <= 8:
-        # (the reference zips the two crop lists: with unequal counts the surplus crops of one side only feed the generator's
-        # BatchNorm statistics; not supported by the fused step)
-        raise NotImplementedError("the fused engine takes global_A_crops_n_crops == global_B_crops_n_crops in 1..8")
+    n_crops = (int(cfg['global_A_crops_n_crops']), int(cfg['global_B_crops_n_crops']))
+    if not all(1 <= n <= 8 for n in n_crops):
+        raise NotImplementedError("the fused engine takes 1..8 global crops per image (global_{A,B}_crops_n_crops)")
+    if n_crops[0] == n_crops[1]:
+        n_crops = n_crops[0]   # (unequal counts: the reference zips the crop lists, util/losses.py:76,87,98 -- so does the engine)
     if device.type != 'cuda':
         raise RuntimeError("train_model needs an MI355X: the product path has no CPU fallback")
 

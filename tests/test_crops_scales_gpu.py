@@ -66,7 +66,7 @@ def _oracle(cfg, vit_state, gen_state, img_size=64):
     return SpliceOracle(m, {k: torch.from_numpy(v) for k, v in gen_state.items()}, cfg)
 
 
-@pytest.mark.parametrize("n_crops", [2, 3])
+@pytest.mark.parametrize("n_crops", [2, 3, (3, 2), (1, 3)])
 def test_n_crops_step_vs_oracle(n_crops):
     """global_A_crops_n_crops = global_B_crops_n_crops = n (conf/default/config.yaml): A_global / B_global are [n,3,s,s] stacks
     (data/transforms.py:27), netG normalises over the stack, util/losses.py:74-105 sums each term over the crops, the entire
@@ -77,9 +77,12 @@ def test_n_crops_step_vs_oracle(n_crops):
     gen_state = synth.generator_params(41, 0.02)
     A, B = synth.smooth_image_pair(44, 0, 72, 80)
     A, B = torch.from_numpy(A), torch.from_numpy(B)
-    offs = [(0, 0), (8, 16), (4, 9)][:n_crops]
+    # (nA, nB) unequal: the reference zips the crop lists (util/losses.py:76,87,98) -- structure term over the nA crops, identity
+    # term over the nB crops, appearance term over min(nA, nB) pairs -- while netG's BatchNorm sees all crops of its call
+    nA, nB = (n_crops, n_crops) if isinstance(n_crops, int) else n_crops
+    offs = [(0, 0), (8, 16), (4, 9)][:nA]
     Ac = torch.stack([A[:, t:t + 64, l:l + 64] for t, l in offs]).contiguous()
-    Bc = torch.stack([B[:, t:t + 64, l:l + 64] for t, l in [(8, 0), (0, 16), (3, 7)][:n_crops]]).contiguous()
+    Bc = torch.stack([B[:, t:t + 64, l:l + 64] for t, l in [(8, 0), (0, 16), (3, 7)][:nB]]).contiguous()
     eng = SpliceEngine(cfg, vit_state, gen_state, (64, 64), (72, 80), n_crops=n_crops)
     orc = _oracle(cfg, vit_state, gen_state)
     for step in range(4):
