@@ -179,22 +179,24 @@ def visible_gpu_count():
 
 # live-timed kernel families (splice_prof_begin): id -> (name, peak key, algorithmic FLOPs of the family's launches per step)
 F32_MFMA_PEAK = 157.3     # TFLOP/s, exact-f32 MFMA = the f32 vector rate (MI355X_MICROARCH.md)
-BF16_MFMA_PEAK = 2500.0   # TFLOP/s dense
+BF16_MFMA_PEAK = 2500.0   # TFLOP/s dense (also the rate of the non-scaled k = 32 fp8 MFMA)
+FP8_MX_MFMA_PEAK = 5000.0 # TFLOP/s dense, block-scaled K = 128 e4m3 MFMA
 HBM_PEAK = 8000.0         # GB/s
 
 
-def kernel_families(T, D, heads, P, size, depth=12):
+def kernel_families(T, D, heads, P, size, depth=12, fp8=False):
     """FLOPs are per host CALL of the family (one launch, or the launches of one call): a forward call covers 2 P passes
     (one of the two concurrent forward chains), a backward call P passes.  SURVEY.md 8d per-unit figures."""
     hidden = 4 * D
     g = (size / 224.0) ** 2
     return {
         # (tile / pipeline template arguments depend on the rows of a launch: <64,64,..,4> at one pair, <128,64,..,2> from 4 pairs on)
-        4: ("gemm_nt_kernel<BIAS|RESID|OUT_F32> fc2 forward", "bf16", 2 * P * 2.0 * T * hidden * D),
-        1: ("gemm_nt_kernel<BIAS|GELU|OUT_BF> fc1 forward", "bf16", 2 * P * 2.0 * T * hidden * D),
-        2: ("gemm_nt_kernel<BIAS|OUT_BF|OUT_T> qkv forward", "bf16", 2 * P * 2.0 * T * 3 * D * D),
+        # (--fp8: these three run on the block-scaled K = 128 e4m3 MFMA -- priced against ITS dense peak, 5 PFLOP/s)
+        4: ("gemm_nt_kernel<BIAS|RESID|OUT_F32> fc2 forward" + (" [e4m3, scaled K=128 MFMA]" if fp8 else ""), "fp8mx" if fp8 else "bf16", 2 * P * 2.0 * T * hidden * D),
+        1: ("gemm_nt_kernel<BIAS|GELU|OUT_BF> fc1 forward" + (" [e4m3, scaled K=128 MFMA]" if fp8 else ""), "fp8mx" if fp8 else "bf16", 2 * P * 2.0 * T * hidden * D),
+        2: ("gemm_nt_kernel<BIAS|OUT_BF|OUT_T> qkv forward" + (" [e4m3, scaled K=128 MFMA]" if fp8 else ""), "fp8mx" if fp8 else "bf16", 2 * P * 2.0 * T * 3 * D * D),
         9: ("gemm_nt_kernel<BIAS|RESID|OUT_F32> proj forward", "bf16", 2 * P * 2.0 * T * D * D),
-        3: ("attn_fwd_kernel", "bf16", 2 * P * 4.0 * T * T * D),
+        3: ("attn_fwd8_kernel [e4m3 operands, k = 32 fp8 MFMA: bf16 rate]" if fp8 else "attn_fwd_kernel", "bf16", 2 * P * 4.0 * T * T * D),
         5: ("gemm_nt_kernel<OUT_F32> split-K dgrads (fc1^T and qkv^T, mean of both)", "bf16", P * 2.0 * T * D * (hidden + 3 * D) / 2),
         6: ("attn_bwd_kernel (merged, or dQ + dK/dV launches)", "bf16", P * 10.0 * T * T * D),
         # generator: one call = splice_gen_forward (2.262 GFLOP per 224^2 image) or splice_gen_backward (dgrad + wgrad = 2 x forward);
@@ -398,11 +400,11 @@ def main():
         return
 
     if scales:   # every scale makes the same host calls per step: a family's mean FLOPs per call = the mean over the scales
-        per = [kernel_families(t, D, eng.vit.heads, P, args.size) for t in T]
+        per = [kernel_families(t, D, eng.vit.heads, P, args.size, fp8=args.fp8) for t in T]
         fams = {k: (per[0][k][0] + f" (mean over the ViT input scales {scales})", per[0][k][1], sum(f[k][2] for f in per) / len(per)) for k in per[0]}
         fams[7] = per[0][7]   # (the generator works at the crop size at every scale)
     else:
-        fams = kernel_families(T, D, eng.vit.heads, P, args.size)
+        fams = kernel_families(T, D, eng.vit.heads, P, args.size, fp8=args.fp8)
     roofs = []
     traffic_file = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     static_traffic = {}
@@ -415,11 +417,11 @@ def main():
         kname, cls, flops = fams[fam]
         avg_ms = max(tot_ms / calls, 1e-6)
         ach = flops / (avg_ms * 1e-3) / 1e12
-        peak = BF16_MFMA_PEAK if cls == "bf16" else F32_MFMA_PEAK
+        peak = {"bf16": BF16_MFMA_PEAK, "fp8mx": FP8_MX_MFMA_PEAK}.get(cls, F32_MFMA_PEAK)
         traffic = static_traffic.get(str(fam))
         r = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
              "frac": round(ach / peak, 4), "traffic": traffic,
-             "traffic_source": None if traffic is None else "static: profiles/roofline_traffic.json (FETCH_SIZE x2 + WRITE_SIZE from separate --pmc passes of tools/pmc_traffic.sh on this workload; not re-measured by this command)",
+             "traffic_source": None if traffic is None else "static: profiles/roofline_traffic.json (FETCH_SIZE x2 + WRITE_SIZE from separate --pmc passes of tools/pmc_traffic.sh on this workload, re-measured in round 3; not re-measured by this command)",
              "avg_launch_us": round(avg_ms * 1e3, 2), "calls_per_step": round(calls / steps, 1), "kernels_per_step": round(kernels / steps, 1),
              "share_of_step_ms": round(tot_ms / steps, 4)}
         if n_ent:

@@ -213,6 +213,7 @@ static float* loss_part(SpliceStep* st, int slot) { return st->losses + 8 + (siz
 
 // `n_img` images [3][h][w] -> [3][oh][ow] each (contiguous batches on both sides)
 static int place_images(const float* src, int h, int w, float* dst, int oh, int ow, int n_img, hipStream_t s) {
+    if (src == dst) return SPLICE_OK;   // identity Resize with the producer writing the ViT context's image slot itself (step_ptrs)
     if (h == oh && w == ow) {   // Resize returns its input when the shorter edge already matches
         RC(dev_copy_launch(dst, src, (size_t)n_img * 3 * h * w * sizeof(float), s));
         return SPLICE_OK;
@@ -220,11 +221,41 @@ static int place_images(const float* src, int h, int w, float* dst, int oh, int 
     return resize_bilinear_fwd_launch(src, dst, 3 * n_img, h, w, oh, ow, s);
 }
 static int unplace_grads(const float* dsrc, int oh, int ow, float* ddst, int h, int w, int n_img, hipStream_t s) {
+    if (dsrc == ddst) return SPLICE_OK;
     if (h == oh && w == ow) {
         RC(dev_copy_launch(ddst, dsrc, (size_t)n_img * 3 * h * w * sizeof(float), s));
         return SPLICE_OK;
     }
     return resize_bilinear_bwd_launch(dsrc, ddst, 3 * n_img, h, w, oh, ow, s);
+}
+
+// Where the step's images live.  With an identity Resize (crop size == ViT input size: the benchmark's 224 x 224 pair, and
+// every size-matched crop of train_model) the staged inputs, the generator outputs and their gradients ARE the image slots
+// of the ViT context -- the generator reads and writes them in place, no copy kernels on either chain (4 + 2 launches per
+// step, 3 of them on the critical chain).  Otherwise the private buffers + resize_bilinear_* as before.
+struct StepPtrs { float *a_in, *b_in, *e_in, *x, *y, *xe, *dx, *dy, *dxe; };
+static StepPtrs step_ptrs(SpliceStep* st) {
+    const splice_step_config& c = st->cfg;
+    VitView& vg = st->vg;
+    const size_t vimg = (size_t)3 * vg.H * vg.W;
+    const int pA = 0, pB = st->Pa, pX = st->Pa + st->Pb, pY = 2 * st->Pa + st->Pb;
+    const bool ida = c.crop_h == vg.H && c.crop_w == vg.W, idb = st->cropb_h == vg.H && st->cropb_w == vg.W;
+    StepPtrs p;
+    p.a_in = ida ? vg.imgs + pA * vimg : st->gen_in;
+    p.x = ida ? vg.imgs + pX * vimg : st->gen_out;
+    p.dx = ida ? vg.d_imgs + pX * vimg : st->d_gen_out;
+    p.b_in = idb ? vg.imgs + pB * vimg : st->in_b;
+    p.y = idb ? vg.imgs + pY * vimg : st->gen_out_b;
+    p.dy = idb ? vg.d_imgs + pY * vimg : st->d_gen_out_b;
+    p.e_in = st->ent_in; p.xe = st->ent_out; p.dxe = st->d_ent_out;
+    if (st->plan_e) {
+        VitView& ve = st->ve;
+        if (c.ent_h == ve.H && c.ent_w == ve.W) {
+            const size_t eimg = (size_t)3 * ve.H * ve.W;
+            p.e_in = ve.imgs; p.xe = ve.imgs + st->Pe * eimg; p.dxe = ve.d_imgs + st->Pe * eimg;
+        }
+    }
+    return p;
 }
 
 // fp32 keys of pass b (view into the last layer's raw qkv): pointer + leading dimension 3D
@@ -358,7 +389,8 @@ void splice_step_destroy(void* h) {
 int splice_step_output(void* h, int which, float** out) {
     SpliceStep* st = (SpliceStep*)h;
     if (!st || !out) return SPLICE_ERR_ARG;
-    *out = which == 0 ? st->gen_out : which == 1 ? st->ent_out : which == 2 ? st->gen_out_b : nullptr;
+    const StepPtrs p = step_ptrs(st);
+    *out = which == 0 ? p.x : which == 1 ? p.xe : which == 2 ? p.y : nullptr;
     return *out ? SPLICE_OK : SPLICE_ERR_STATE;
 }
 
@@ -405,9 +437,10 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     const float l_cls = c.lambda_global_cls;
     const float l_essim = entire ? c.lambda_entire_ssim : 0.f, l_ecls = entire ? c.lambda_entire_cls : 0.f;
     const size_t vimg = (size_t)3 * vg.H * vg.W;
-    const float* A_crop = st->gen_in;
-    const float* B_crop = st->in_b;
-    const float* A_entire = st->ent_in;
+    const StepPtrs ip = step_ptrs(st);
+    const float* A_crop = ip.a_in;
+    const float* B_crop = ip.b_in;
+    const float* A_entire = ip.e_in;
     // pass layout of the global context: [0, Pa) A'   [Pa, Pa + Pb) B'   then x' = G(A crops) (Pa passes), y' = G(B crops) (Pb passes)
     const int pA = 0, pB = Pa, pX = Pa + Pb, pY = 2 * Pa + Pb, pEnd = 2 * (Pa + Pb);
     // ---- the no-grad target passes A', B' (util/losses.py:79,91,101) do not depend on the generator: their ViT forward
@@ -423,7 +456,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     // plan per crop kind (A crops | B crops: the reference draws their sizes independently, data/Dataset.py:66-67);
     // G(B_crop) goes first on the side stream so that it runs beside G(A_crop) instead of behind it
     if (!(st->ablate & 1)) {
-        RC(splice_gen_forward_borrowed(st->plan_b, params, B_crop, st->gen_out_b, s2));
+        RC(splice_gen_forward_borrowed(st->plan_b, params, B_crop, ip.y, s2));
         if (overlap) HIPCHK(hipEventRecord(st->ev_gb, s2));
     }
     RC(place_images(A_crop, c.crop_h, c.crop_w, vg.imgs + pA * vimg, vg.H, vg.W, Pa, s2));
@@ -445,11 +478,11 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     if (overlap) HIPCHK(hipEventRecord(st->ev_join, s2));
     // ---- Model.forward: x_global = G(A_crop), y_global = G(B_crop) [, x_entire = G(A)]
     if (!(st->ablate & 1)) {
-        RC(splice_gen_forward_borrowed(st->plan_a, params, A_crop, st->gen_out, s));
+        RC(splice_gen_forward_borrowed(st->plan_a, params, A_crop, ip.x, s));
         if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_gb, 0));
     }
-    RC(place_images(st->gen_out, c.crop_h, c.crop_w, vg.imgs + pX * vimg, vg.H, vg.W, Pa, s));
-    RC(place_images(st->gen_out_b, st->cropb_h, st->cropb_w, vg.imgs + pY * vimg, vg.H, vg.W, Pb, s));
+    RC(place_images(ip.x, c.crop_h, c.crop_w, vg.imgs + pX * vimg, vg.H, vg.W, Pa, s));
+    RC(place_images(ip.y, st->cropb_h, st->cropb_w, vg.imgs + pY * vimg, vg.H, vg.W, Pb, s));
     if (!(st->ablate & 16)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, pX, pX, pEnd, s));
     if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
     // ---- losses on the global batch
@@ -465,9 +498,9 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     if (entire) {
         VitView& ve = st->ve;
         const size_t eimg = (size_t)3 * ve.H * ve.W;
-        RC(splice_gen_forward_borrowed(st->plan_e, params, A_entire, st->ent_out, s));
+        RC(splice_gen_forward_borrowed(st->plan_e, params, A_entire, ip.xe, s));
         RC(place_images(A_entire, c.ent_h, c.ent_w, ve.imgs, ve.H, ve.W, Pe, s));
-        RC(place_images(st->ent_out, c.ent_h, c.ent_w, ve.imgs + Pe * eimg, ve.H, ve.W, Pe, s));
+        RC(place_images(ip.xe, c.ent_h, c.ent_w, ve.imgs + Pe * eimg, ve.H, ve.W, Pe, s));
         RC(splice_vit_forward_ex(ve.ctx, ve.imgs, 1, Pe, s));
         float* blk_e = nullptr;
         RC(splice_vit_get_tensor(ve.ctx, 0, ve.depth - 1, (void**)&blk_e));
@@ -508,9 +541,9 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
             HIPCHK(hipStreamWaitEvent(s2, st->ev_fork, 0));
         }
         if (!(st->ablate & 32)) RC(splice_vit_backward(vg.ctx, pY, pEnd, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s2));
-        RC(unplace_grads(vg.d_imgs + pY * vimg, vg.H, vg.W, st->d_gen_out_b, st->cropb_h, st->cropb_w, Pb, s2));
+        RC(unplace_grads(vg.d_imgs + pY * vimg, vg.H, vg.W, ip.dy, st->cropb_h, st->cropb_w, Pb, s2));
         // each chain continues into its own generator plan (own gradient arena: no cross-chain accumulation)
-        if (!(st->ablate & 2)) RC(splice_gen_backward(st->plan_b, params, st->d_gen_out_b, st->grads_b, 0, s2));
+        if (!(st->ablate & 2)) RC(splice_gen_backward(st->plan_b, params, ip.dy, st->grads_b, 0, s2));
         if (overlap) {
             // the reported loss values and the BatchNorm bookkeeping depend on nothing downstream: they run at the tail of
             // the side chain instead of between the generator backward and Adam on the critical one
@@ -520,8 +553,8 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
             HIPCHK(hipEventRecord(st->ev_join, s2));
         }
         RC(splice_vit_backward(vg.ctx, pX, pY, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
-        RC(unplace_grads(vg.d_imgs + pX * vimg, vg.H, vg.W, st->d_gen_out, c.crop_h, c.crop_w, Pa, s));
-        if (!(st->ablate & 2)) RC(splice_gen_backward(st->plan_a, params, st->d_gen_out, grads, st->accumulate, s));
+        RC(unplace_grads(vg.d_imgs + pX * vimg, vg.H, vg.W, ip.dx, c.crop_h, c.crop_w, Pa, s));
+        if (!(st->ablate & 2)) RC(splice_gen_backward(st->plan_a, params, ip.dx, grads, st->accumulate, s));
         if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
         // grads = g(A) + g(B): folded into the Adam kernel on ordinary steps; a separate add when the entire-image branch
         // still has to accumulate into the sum (same association order either way)
@@ -534,8 +567,8 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
         VitView& ve = st->ve;
         const size_t eimg = (size_t)3 * ve.H * ve.W;
         RC(splice_vit_backward(ve.ctx, Pe, 2 * Pe, ve.pb.data(), nullptr, ve.pk.data(), ve.d_imgs, 1, s));
-        RC(unplace_grads(ve.d_imgs + Pe * eimg, ve.H, ve.W, st->d_ent_out, c.ent_h, c.ent_w, Pe, s));
-        RC(splice_gen_backward(st->plan_e, params, st->d_ent_out, grads, 1, s));
+        RC(unplace_grads(ve.d_imgs + Pe * eimg, ve.H, ve.W, ip.dxe, c.ent_h, c.ent_w, Pe, s));
+        RC(splice_gen_backward(st->plan_e, params, ip.dxe, grads, 1, s));
     }
     if (!loss_summed) { sum_losses(s); RC(track_running(s)); }
     // ---- optimizer.step() (train.py:79) over every pair's arena; Adam's step count (>= 1) is read from the device at execution time
@@ -598,9 +631,10 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
     // ---- stage the inputs (eager)
     {
         StageArgs sa = {};
-        sa.src[0] = A_crop; sa.dst[0] = st->gen_in; sa.n[0] = (size_t)st->Pa * 3 * c.crop_h * c.crop_w;
-        sa.src[1] = B_crop; sa.dst[1] = st->in_b; sa.n[1] = (size_t)st->Pb * 3 * st->cropb_h * st->cropb_w;
-        if (entire) { sa.src[2] = A_entire; sa.dst[2] = st->ent_in; sa.n[2] = (size_t)st->Pe * 3 * c.ent_h * c.ent_w; }
+        const StepPtrs ip = step_ptrs(st);
+        sa.src[0] = A_crop; sa.dst[0] = ip.a_in; sa.n[0] = (size_t)st->Pa * 3 * c.crop_h * c.crop_w;
+        sa.src[1] = B_crop; sa.dst[1] = ip.b_in; sa.n[1] = (size_t)st->Pb * 3 * st->cropb_h * st->cropb_w;
+        if (entire) { sa.src[2] = A_entire; sa.dst[2] = ip.e_in; sa.n[2] = (size_t)st->Pe * 3 * c.ent_h * c.ent_w; }
         sa.ip = st->dev_t; sa.iv = step_idx + 1;
         SPLICE_LAUNCH(stage_inputs_kernel, dim3(128 * (P > 4 ? 4 : P)), dim3(256), 0, s, sa);
     }
