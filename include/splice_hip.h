@@ -359,6 +359,13 @@ int splice_step_set_crops(void* step, int a_h, int a_w, int b_h, int b_w);
  * parameters untouched; several losses (the same crops at several ViT input scales) are summed that way before ONE
  * splice_adam_step */
 int splice_step_set_mode(void* step, int skip_adam, int accumulate);
+/* Run part of a step: phases = mask of 1 generator forward (+ input staging), 2 ViT forward / losses / ViT backward down to
+ * the gradient of the generated images, 4 generator backward (+ Adam unless splice_step_set_mode disables it); default 7.
+ * leader != NULL (phases must be 2; another step handle with the same image shapes): this handle reads the leader's staged
+ * inputs and generator outputs and ADDS its image gradients to the leader's.  The several-scales step (the reference has
+ * one scale, util/losses.py:22-27; BASELINE configs[4] asks for three) is leader 1|2, followers 2, leader 4: one generator
+ * pass per step whatever the number of scales. */
+int splice_step_set_phases(void* step, int phases, void* leader);
 /* BatchNorm running statistics of netG (models/unet/common.py:95-96, momentum 0.1): when `running` is set every step
  * applies the updates of its generator calls in the reference's order (A_global, A on entire steps, B_global) to the
  * caller's buffer arena(s): layout splice_gen_buffer_info, pair p at running + p * stride.  NULL = not tracked. */

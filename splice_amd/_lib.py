@@ -127,6 +127,7 @@ _SIGNATURES = {
     "splice_step_set_crops": ([_vp, _i, _i, _i, _i], _i),
     "splice_step_set_running_stats": ([_vp, _vp, C.c_longlong], _i),
     "splice_step_set_mode": ([_vp, _i, _i], _i),
+    "splice_step_set_phases": ([_vp, _i, _vp], _i),
     "splice_gen_buffer_count": ([_vp], C.c_longlong),
     "splice_gen_num_buffers": ([_vp], _i),
     "splice_gen_buffer_info": ([_vp, _i, C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)], _i),

@@ -120,6 +120,8 @@ struct SpliceStep {
     int skip_adam = 0, accumulate = 0;   // splice_step_set_mode: leave the summed gradient in `grads` (optionally += ) and do not update
     float* running = nullptr;    // BatchNorm running statistics arena(s) of the caller (null: not tracked)
     long long running_stride = 0;
+    int phases = 7;              // splice_step_set_phases: 1 generator forward, 2 ViT forward / losses / ViT backward, 4 generator backward (+ Adam)
+    SpliceStep* leader = nullptr;   // the handle whose staged inputs / generator outputs this one reads and whose image gradients it adds to
 };
 
 static void drop_graphs(SpliceStep* st);
@@ -417,6 +419,20 @@ int splice_step_set_mode(void* h, int skip_adam, int accumulate) {
     st->skip_adam = skip_adam ? 1 : 0; st->accumulate = accumulate ? 1 : 0;
     return SPLICE_OK;
 }
+// Run only part of a step: phases is a mask of 1 = generator forward (and input staging), 2 = ViT forward, losses and ViT backward
+// down to the gradient of the generated images, 4 = generator backward (+ Adam unless splice_step_set_mode says otherwise).
+// With `leader` (another step handle, same image shapes; phases must be 2) this handle is a FOLLOWER: it reads the leader's
+// staged inputs and generator outputs instead of running the generator, and ADDS its image gradients to the leader's.  That
+// is the several-scales step (BASELINE configs[4]) with one generator pass: leader 1|2, followers 2, leader 4 -- the generator
+// backward is linear in the image gradient, so backpropagating the sum equals summing the backpropagations.
+int splice_step_set_phases(void* h, int phases, void* leader) {
+    SpliceStep* st = (SpliceStep*)h;
+    if (!st || phases <= 0 || phases > 7 || leader == h || (leader && phases != 2) || (leader && ((SpliceStep*)leader)->leader)) return SPLICE_ERR_ARG;
+    if (st->leader != (SpliceStep*)leader) drop_graphs(st);
+    st->phases = phases;
+    st->leader = (SpliceStep*)leader;
+    return SPLICE_OK;
+}
 
 // BatchNorm running statistics (models/unet/common.py:95-96): when set, every step applies the momentum-0.1 update of its
 // netG calls in the reference's order (A_global, A on entire steps, B_global; models/model.py:15-23) to the caller's
@@ -438,9 +454,15 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     const float l_essim = entire ? c.lambda_entire_ssim : 0.f, l_ecls = entire ? c.lambda_entire_cls : 0.f;
     const size_t vimg = (size_t)3 * vg.H * vg.W;
     const StepPtrs ip = step_ptrs(st);
-    const float* A_crop = ip.a_in;
-    const float* B_crop = ip.b_in;
-    const float* A_entire = ip.e_in;
+    // a follower (splice_step_set_phases) sees the leader's images and adds its image gradients to the leader's
+    const StepPtrs src = st->leader ? step_ptrs(st->leader) : ip;
+    const bool do_gf = (st->phases & 1) != 0, do_v = (st->phases & 2) != 0, do_gb = (st->phases & 4) != 0;
+    const float* A_crop = src.a_in;
+    const float* B_crop = src.b_in;
+    const float* A_entire = src.e_in;
+    auto to_leader = [&](float* lead, const float* own, size_t n, hipStream_t q) -> int {   // d(leader's image) += d(this scale's view of it)
+        return st->leader ? add_f32_launch(lead, own, n, q) : SPLICE_OK;
+    };
     // pass layout of the global context: [0, Pa) A'   [Pa, Pa + Pb) B'   then x' = G(A crops) (Pa passes), y' = G(B crops) (Pb passes)
     const int pA = 0, pB = Pa, pX = Pa + Pb, pY = 2 * Pa + Pb, pEnd = 2 * (Pa + Pb);
     // ---- the no-grad target passes A', B' (util/losses.py:79,91,101) do not depend on the generator: their ViT forward
@@ -455,78 +477,87 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     // global_transform (Resize -> Normalize; the Normalize is fused into the ViT patch gather).  The generator runs as one
     // plan per crop kind (A crops | B crops: the reference draws their sizes independently, data/Dataset.py:66-67);
     // G(B_crop) goes first on the side stream so that it runs beside G(A_crop) instead of behind it
-    if (!(st->ablate & 1)) {
+    if (do_gf && !(st->ablate & 1)) {
         RC(splice_gen_forward_borrowed(st->plan_b, params, B_crop, ip.y, s2));
         if (overlap) HIPCHK(hipEventRecord(st->ev_gb, s2));
     }
-    RC(place_images(A_crop, c.crop_h, c.crop_w, vg.imgs + pA * vimg, vg.H, vg.W, Pa, s2));
-    RC(place_images(B_crop, st->cropb_h, st->cropb_w, vg.imgs + pB * vimg, vg.H, vg.W, Pb, s2));
-    if (!(st->ablate & 8)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, pX, pA, pX, s2));
     float *blk_g = nullptr, *qkv_g = nullptr;
     RC(splice_vit_get_tensor(vg.ctx, 0, vg.depth - 1, (void**)&blk_g));
     RC(splice_vit_get_tensor(vg.ctx, 3, vg.depth - 1, (void**)&qkv_g));
-    // everything of the loss stage that does not need the generated images also runs here, off the critical path
-    RC(dev_zero_launch(st->losses, (size_t)P * st->lstride * sizeof(float), s2));
     const size_t passD = (size_t)vg.Tld * vg.D;
-    RC(dev_zero_launch(vg.d_block + pX * passD, (size_t)(Pa + Pb) * passD * sizeof(float), s2));
-    RC(dev_zero_launch(vg.d_keys + pX * passD, (size_t)(Pa + Pb) * passD * sizeof(float), s2));
     SelfSimBatch sb = {};
-    if (l_ssim > 0.f) {   // target self-similarity S* of A' (util/losses.py:79)
-        RC(ssim_batch(st, vg, pA, pX, Pa, l_ssim, L_GLOBAL_SSIM, &sb));
-        RC(selfsim_target_launch(sb, s2));
+    if (do_v) {
+        RC(place_images(A_crop, c.crop_h, c.crop_w, vg.imgs + pA * vimg, vg.H, vg.W, Pa, s2));
+        RC(place_images(B_crop, st->cropb_h, st->cropb_w, vg.imgs + pB * vimg, vg.H, vg.W, Pb, s2));
+        if (!(st->ablate & 8)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, pX, pA, pX, s2));
+        // everything of the loss stage that does not need the generated images also runs here, off the critical path
+        RC(dev_zero_launch(st->losses, (size_t)P * st->lstride * sizeof(float), s2));
+        RC(dev_zero_launch(vg.d_block + pX * passD, (size_t)(Pa + Pb) * passD * sizeof(float), s2));
+        RC(dev_zero_launch(vg.d_keys + pX * passD, (size_t)(Pa + Pb) * passD * sizeof(float), s2));
+        if (l_ssim > 0.f) {   // target self-similarity S* of A' (util/losses.py:79)
+            RC(ssim_batch(st, vg, pA, pX, Pa, l_ssim, L_GLOBAL_SSIM, &sb));
+            RC(selfsim_target_launch(sb, s2));
+        }
     }
     if (overlap) HIPCHK(hipEventRecord(st->ev_join, s2));
     // ---- Model.forward: x_global = G(A_crop), y_global = G(B_crop) [, x_entire = G(A)]
-    if (!(st->ablate & 1)) {
+    if (do_gf && !(st->ablate & 1)) {
         RC(splice_gen_forward_borrowed(st->plan_a, params, A_crop, ip.x, s));
         if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_gb, 0));
     }
-    RC(place_images(ip.x, c.crop_h, c.crop_w, vg.imgs + pX * vimg, vg.H, vg.W, Pa, s));
-    RC(place_images(ip.y, st->cropb_h, st->cropb_w, vg.imgs + pY * vimg, vg.H, vg.W, Pb, s));
-    if (!(st->ablate & 16)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, pX, pX, pEnd, s));
+    if (do_v) {
+        RC(place_images(src.x, c.crop_h, c.crop_w, vg.imgs + pX * vimg, vg.H, vg.W, Pa, s));
+        RC(place_images(src.y, st->cropb_h, st->cropb_w, vg.imgs + pY * vimg, vg.H, vg.W, Pb, s));
+        if (!(st->ablate & 16)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, pX, pX, pEnd, s));
+    }
     if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
     // ---- losses on the global batch
-    if (l_ssim > 0.f) RC(selfsim_loss_launch(sb, s));
-    if (l_cls > 0.f)   // [CLS] of block 11, before the final LayerNorm (util/losses.py:90-93)
-        RC(mse_batched_launch(blk_g + pX * passD, vg.D, passD, blk_g + pB * passD, vg.D, passD, 1, vg.D, 1.0f, l_cls, loss_part(st, L_GLOBAL_CLS),
-                              st->lstride, vg.d_block + pX * passD, vg.D, passD, Pc, s));
-    if (l_id > 0.f)    // keys of y' against keys of B' (util/losses.py:96-105): mean over h*T*d = T*D
-        RC(mse_batched_launch(keys_ptr(vg, qkv_g, pY), 3 * vg.D, 3 * passD, keys_ptr(vg, qkv_g, pB), 3 * vg.D, 3 * passD, vg.T, vg.D, 1.0f, l_id,
-                              loss_part(st, L_GLOBAL_ID), st->lstride, vg.d_keys + pY * passD, vg.D, passD, Pb, s));
+    if (do_v) {
+        if (l_ssim > 0.f) RC(selfsim_loss_launch(sb, s));
+        if (l_cls > 0.f)   // [CLS] of block 11, before the final LayerNorm (util/losses.py:90-93)
+            RC(mse_batched_launch(blk_g + pX * passD, vg.D, passD, blk_g + pB * passD, vg.D, passD, 1, vg.D, 1.0f, l_cls, loss_part(st, L_GLOBAL_CLS),
+                                  st->lstride, vg.d_block + pX * passD, vg.D, passD, Pc, s));
+        if (l_id > 0.f)    // keys of y' against keys of B' (util/losses.py:96-105): mean over h*T*d = T*D
+            RC(mse_batched_launch(keys_ptr(vg, qkv_g, pY), 3 * vg.D, 3 * passD, keys_ptr(vg, qkv_g, pB), 3 * vg.D, 3 * passD, vg.T, vg.D, 1.0f, l_id,
+                                  loss_part(st, L_GLOBAL_ID), st->lstride, vg.d_keys + pY * passD, vg.D, passD, Pb, s));
+    }
     // ---- entire-image branch (every entire_every-th step): passes [0, Pe) A_entire', [Pe, 2 Pe) x_entire'
     const int Pe = st->Pe;
     if (entire) {
         VitView& ve = st->ve;
         const size_t eimg = (size_t)3 * ve.H * ve.W;
-        RC(splice_gen_forward_borrowed(st->plan_e, params, A_entire, ip.xe, s));
-        RC(place_images(A_entire, c.ent_h, c.ent_w, ve.imgs, ve.H, ve.W, Pe, s));
-        RC(place_images(ip.xe, c.ent_h, c.ent_w, ve.imgs + Pe * eimg, ve.H, ve.W, Pe, s));
-        RC(splice_vit_forward_ex(ve.ctx, ve.imgs, 1, Pe, s));
-        float* blk_e = nullptr;
-        RC(splice_vit_get_tensor(ve.ctx, 0, ve.depth - 1, (void**)&blk_e));
-        const size_t epassD = (size_t)ve.Tld * ve.D;
-        RC(dev_zero_launch(ve.d_block + Pe * epassD, (size_t)Pe * epassD * sizeof(float), s));
-        RC(dev_zero_launch(ve.d_keys + Pe * epassD, (size_t)Pe * epassD * sizeof(float), s));
-        if (l_essim > 0.f) {
-            SelfSimBatch se = {};
-            RC(ssim_batch(st, ve, 0, Pe, Pe, l_essim, L_ENTIRE_SSIM, &se));
-            RC(selfsim_target_launch(se, s));
-            RC(selfsim_loss_launch(se, s));
+        if (do_gf) RC(splice_gen_forward_borrowed(st->plan_e, params, A_entire, ip.xe, s));
+        if (do_v) {
+            RC(place_images(A_entire, c.ent_h, c.ent_w, ve.imgs, ve.H, ve.W, Pe, s));
+            RC(place_images(src.xe, c.ent_h, c.ent_w, ve.imgs + Pe * eimg, ve.H, ve.W, Pe, s));
+            RC(splice_vit_forward_ex(ve.ctx, ve.imgs, 1, Pe, s));
+            float* blk_e = nullptr;
+            RC(splice_vit_get_tensor(ve.ctx, 0, ve.depth - 1, (void**)&blk_e));
+            const size_t epassD = (size_t)ve.Tld * ve.D;
+            RC(dev_zero_launch(ve.d_block + Pe * epassD, (size_t)Pe * epassD * sizeof(float), s));
+            RC(dev_zero_launch(ve.d_keys + Pe * epassD, (size_t)Pe * epassD * sizeof(float), s));
+            if (l_essim > 0.f) {
+                SelfSimBatch se = {};
+                RC(ssim_batch(st, ve, 0, Pe, Pe, l_essim, L_ENTIRE_SSIM, &se));
+                RC(selfsim_target_launch(se, s));
+                RC(selfsim_loss_launch(se, s));
+            }
+            if (l_ecls > 0.f)   // target is the B_global crop's CLS (util/losses.py:60; with n_crops > 1 the zip pairs x_entire with the FIRST crop)
+                RC(mse_batched_launch(blk_e + Pe * epassD, ve.D, epassD, blk_g + pB * passD, vg.D, passD, 1, ve.D, 1.0f, l_ecls, loss_part(st, L_ENTIRE_CLS),
+                                      st->lstride, ve.d_block + Pe * epassD, ve.D, epassD, Pe, s));
         }
-        if (l_ecls > 0.f)   // target is the B_global crop's CLS (util/losses.py:60; with n_crops > 1 the zip pairs x_entire with the FIRST crop)
-            RC(mse_batched_launch(blk_e + Pe * epassD, ve.D, epassD, blk_g + pB * passD, vg.D, passD, 1, ve.D, 1.0f, l_ecls, loss_part(st, L_ENTIRE_CLS),
-                                  st->lstride, ve.d_block + Pe * epassD, ve.D, epassD, Pe, s));
     }
     // ---- backward (train.py:78): ViT dgrad for the generated images only, then the generator
     // the x' and y' passes are independent chains until the generator: one per stream (every launch of a
     // dependent chain pays ~8 us of fixed latency; two chains in flight hide each other's)
     bool loss_summed = false;
     auto sum_losses = [&](hipStream_t q) {
+        if (!do_v) return;
         SPLICE_LAUNCH(total_loss_kernel, dim3(st->crops_mode ? 1 : P), dim3(320), 0, q, st->losses, st->lstride, (int)st->lp, l_ssim, l_essim, l_ecls, l_cls, l_id,
                            st->losses_out, st->crops_mode ? P : 1);
     };
     auto track_running = [&](hipStream_t q) -> int {   // BatchNorm running statistics in the reference's call order
-        if (!st->running || (st->ablate & 1)) return SPLICE_OK;
+        if (!st->running || (st->ablate & 1) || !do_gf) return SPLICE_OK;
         void* plans[3];
         int np = 0;
         plans[np++] = st->plan_a;
@@ -540,10 +571,13 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
             HIPCHK(hipEventRecord(st->ev_fork, s));
             HIPCHK(hipStreamWaitEvent(s2, st->ev_fork, 0));
         }
-        if (!(st->ablate & 32)) RC(splice_vit_backward(vg.ctx, pY, pEnd, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s2));
-        RC(unplace_grads(vg.d_imgs + pY * vimg, vg.H, vg.W, ip.dy, st->cropb_h, st->cropb_w, Pb, s2));
+        if (do_v) {
+            if (!(st->ablate & 32)) RC(splice_vit_backward(vg.ctx, pY, pEnd, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s2));
+            RC(unplace_grads(vg.d_imgs + pY * vimg, vg.H, vg.W, ip.dy, st->cropb_h, st->cropb_w, Pb, s2));
+            RC(to_leader(src.dy, ip.dy, (size_t)Pb * 3 * st->cropb_h * st->cropb_w, s2));
+        }
         // each chain continues into its own generator plan (own gradient arena: no cross-chain accumulation)
-        if (!(st->ablate & 2)) RC(splice_gen_backward(st->plan_b, params, ip.dy, st->grads_b, 0, s2));
+        if (do_gb && !(st->ablate & 2)) RC(splice_gen_backward(st->plan_b, params, ip.dy, st->grads_b, 0, s2));
         if (overlap) {
             // the reported loss values and the BatchNorm bookkeeping depend on nothing downstream: they run at the tail of
             // the side chain instead of between the generator backward and Adam on the critical one
@@ -552,13 +586,16 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
             RC(track_running(s2));
             HIPCHK(hipEventRecord(st->ev_join, s2));
         }
-        RC(splice_vit_backward(vg.ctx, pX, pY, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
-        RC(unplace_grads(vg.d_imgs + pX * vimg, vg.H, vg.W, ip.dx, c.crop_h, c.crop_w, Pa, s));
-        if (!(st->ablate & 2)) RC(splice_gen_backward(st->plan_a, params, ip.dx, grads, st->accumulate, s));
+        if (do_v) {
+            RC(splice_vit_backward(vg.ctx, pX, pY, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
+            RC(unplace_grads(vg.d_imgs + pX * vimg, vg.H, vg.W, ip.dx, c.crop_h, c.crop_w, Pa, s));
+            RC(to_leader(src.dx, ip.dx, (size_t)Pa * 3 * c.crop_h * c.crop_w, s));
+        }
+        if (do_gb && !(st->ablate & 2)) RC(splice_gen_backward(st->plan_a, params, ip.dx, grads, st->accumulate, s));
         if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
         // grads = g(A) + g(B): folded into the Adam kernel on ordinary steps; a separate add when the entire-image branch
         // still has to accumulate into the sum (same association order either way)
-        if (!(st->ablate & 2)) {
+        if (do_gb && !(st->ablate & 2)) {
             if (entire || st->skip_adam) RC(add_f32_launch(grads, st->grads_b, st->astride ? P * st->astride : (size_t)st->nparams, s));
             else adam_g2 = st->grads_b;
         }
@@ -566,13 +603,16 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     if (entire) {
         VitView& ve = st->ve;
         const size_t eimg = (size_t)3 * ve.H * ve.W;
-        RC(splice_vit_backward(ve.ctx, Pe, 2 * Pe, ve.pb.data(), nullptr, ve.pk.data(), ve.d_imgs, 1, s));
-        RC(unplace_grads(ve.d_imgs + Pe * eimg, ve.H, ve.W, ip.dxe, c.ent_h, c.ent_w, Pe, s));
-        RC(splice_gen_backward(st->plan_e, params, ip.dxe, grads, 1, s));
+        if (do_v) {
+            RC(splice_vit_backward(ve.ctx, Pe, 2 * Pe, ve.pb.data(), nullptr, ve.pk.data(), ve.d_imgs, 1, s));
+            RC(unplace_grads(ve.d_imgs + Pe * eimg, ve.H, ve.W, ip.dxe, c.ent_h, c.ent_w, Pe, s));
+            RC(to_leader(src.dxe, ip.dxe, (size_t)Pe * 3 * c.ent_h * c.ent_w, s));
+        }
+        if (do_gb) RC(splice_gen_backward(st->plan_e, params, ip.dxe, grads, 1, s));
     }
     if (!loss_summed) { sum_losses(s); RC(track_running(s)); }
     // ---- optimizer.step() (train.py:79) over every pair's arena; Adam's step count (>= 1) is read from the device at execution time
-    if (!st->skip_adam) RC(adam_launch_dev(params, grads, m, v, st->astride ? P * st->astride : (size_t)st->nparams, c.lr, c.beta1, c.beta2, c.eps, st->dev_t, 0, s, adam_g2));
+    if (do_gb && !st->skip_adam) RC(adam_launch_dev(params, grads, m, v, st->astride ? P * st->astride : (size_t)st->nparams, c.lr, c.beta1, c.beta2, c.eps, st->dev_t, 0, s, adam_g2));
     return SPLICE_OK;
 }
 
@@ -628,8 +668,16 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
         HIPCHK(hipEventRecord(st->ev_in, caller));
         HIPCHK(hipStreamWaitEvent(s, st->ev_in, 0));
     }
-    // ---- stage the inputs (eager)
-    {
+    if (st->leader) {
+        const SpliceStep* ld = st->leader;
+        if (ld->P != P || ld->Pa != st->Pa || ld->Pb != st->Pb || ld->Pe != st->Pe || ld->cfg.crop_h != c.crop_h || ld->cfg.crop_w != c.crop_w ||
+            ld->cropb_h != st->cropb_h || ld->cropb_w != st->cropb_w || ld->cfg.ent_h != c.ent_h || ld->cfg.ent_w != c.ent_w) {
+            splice_set_error("splice_step_run: a follower's images must have the leader's shapes");
+            return SPLICE_ERR_ARG;
+        }
+    }
+    // ---- stage the inputs (eager; with the generator forward: the other phases of the step see the same staged images)
+    if (st->phases & 1) {
         StageArgs sa = {};
         const StepPtrs ip = step_ptrs(st);
         sa.src[0] = A_crop; sa.dst[0] = ip.a_in; sa.n[0] = (size_t)st->Pa * 3 * c.crop_h * c.crop_w;
@@ -641,7 +689,7 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
     if (!graph) {
         RC(step_body(st, params, grads, m, v, st->ssim_id_on != 0, entire, s));
     } else {
-        const int variant = (st->ssim_id_on ? 1 : 0) | (entire ? 2 : 0);
+        const int variant = (st->ssim_id_on ? 1 : 0) | (entire ? 2 : 0) | (st->phases << 2);
         auto it = st->graphs.find(variant);
         if (it == st->graphs.end()) {
             hipGraph_t g = nullptr;

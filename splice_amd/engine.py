@@ -144,10 +144,12 @@ class MultiPairEngine:
         except Exception:
             pass
 
-    def step(self, A_crop, B_crop, A_entire=None):
+    def step(self, A_crop, B_crop, A_entire=None, _repeat=False):
         """One optimisation step of every pair, asynchronous on the current stream.  Tensors: fp32 CUDA ``[P,3,h,w]`` in
-        [0,1] (``[3,h,w]`` accepted for P = 1).  Returns the device tensor ``[P,8]`` of losses (see LOSS_KEYS)."""
-        self.step_idx += 1
+        [0,1] (``[3,h,w]`` accepted for P = 1).  Returns the device tensor ``[P,8]`` of losses (see LOSS_KEYS).
+        ``_repeat``: another phase of the step just run (``splice_step_set_phases``): no bookkeeping."""
+        if not _repeat:
+            self.step_idx += 1
         for t, n in ((A_crop, self.slots_ab[0]), (B_crop, self.slots_ab[1])):
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
             assert t.numel() == n * 3 * t.shape[-2] * t.shape[-1], (tuple(t.shape), n)
@@ -161,7 +163,8 @@ class MultiPairEngine:
         _lib.check(_lib.lib().splice_step_run(self.handle, _lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.m), _lib.ptr(self.v),
                                               _lib.ptr(A_crop), _lib.ptr(B_crop), _lib.ptr(A_entire), self.step_idx,
                                               _lib.ptr(self.losses_dev), _lib.current_stream()), "step_run")
-        self.generator_calls = [n + (3 if entire else 2) for n in self.generator_calls]   # models/model.py:15-23: G(A_global) [, G(A)], G(B_global)
+        if not _repeat:
+            self.generator_calls = [n + (3 if entire else 2) for n in self.generator_calls]   # models/model.py:15-23: G(A_global) [, G(A)], G(B_global)
         return self.losses_dev
 
     def losses(self, pair=None):
@@ -237,8 +240,10 @@ class MultiScaleEngine:
     """One pair, every loss term evaluated at SEVERAL ViT input scales (BASELINE configs[4]: 224 / 320 / 448): the same global
     crops are resized to each ``dino_global_patch_size`` in ``scales`` and the reference loss (util/losses.py:46-72) of every
     scale is summed; one Adam update per step on the summed gradient.  An extension beyond the reference (it has one
-    scale); built from one fused step per scale in gradient-only mode (``splice_step_set_mode``) sharing the parameter /
-    gradient / moment arenas, followed by the fused Adam launch."""
+    scale).  The generator runs ONCE per step: the first scale's engine (the leader) does the generator forward and its own
+    ViT part, the other scales (followers, ``splice_step_set_phases``) run only their ViT part on the leader's images and add
+    their image gradients to the leader's, then the leader backpropagates the summed image gradient through the generator
+    (linear in it, so this equals the sum of the per-scale backpropagations) and the fused Adam launch follows."""
 
     def __init__(self, cfg, vit_state, gen_state, crop_hw, entire_hw=None, scales=(224, 320, 448), device="cuda", vit_engine=None, n_crops=1,
                  fp8=False):
@@ -248,10 +253,11 @@ class MultiScaleEngine:
         for k, sz in enumerate(self.scales):
             e = SpliceEngine(dict(self.cfg, dino_global_patch_size=sz), vit_state if k == 0 else None, gen_state, crop_hw, entire_hw, device=device,
                              vit_engine=vit_engine if k == 0 else self.engines[0].vit, n_crops=n_crops, fp8=fp8)
-            _lib.check(_lib.lib().splice_step_set_mode(e.handle, 1, int(k > 0)), "step_set_mode")
-            if k > 0:   # one parameter set: every scale reads / writes the arenas of the first engine; netG bookkeeping once
+            _lib.check(_lib.lib().splice_step_set_mode(e.handle, 1, 0), "step_set_mode")
+            if k > 0:   # one parameter set: every scale sees the arenas of the first engine; netG bookkeeping once
                 e.params, e.grads, e.m, e.v = self.engines[0].params, self.engines[0].grads, self.engines[0].m, self.engines[0].v
                 _lib.check(_lib.lib().splice_step_set_running_stats(e.handle, None, 0), "step_set_running_stats")
+                _lib.check(_lib.lib().splice_step_set_phases(e.handle, 2, self.engines[0].handle), "step_set_phases")
             self.engines.append(e)
         self.vit, self.gen = self.engines[0].vit, self.engines[0].gen
         self.params, self.grads = self.engines[0].params, self.engines[0].grads
@@ -260,9 +266,13 @@ class MultiScaleEngine:
     def step(self, A_crop, B_crop, A_entire=None):
         from .generator import adam_step
         self.step_idx += 1
-        for e in self.engines:
-            e.step(A_crop, B_crop, A_entire)
-        e0, c = self.engines[0], self.cfg
+        e0, c, L = self.engines[0], self.cfg, _lib.lib()
+        _lib.check(L.splice_step_set_phases(e0.handle, 1 | 2, None), "step_set_phases")
+        e0.step(A_crop, B_crop, A_entire)                    # G forward, the leader's ViT part
+        for e in self.engines[1:]:
+            e.step(A_crop, B_crop, A_entire)                 # the other scales' ViT parts: d(images) += ...
+        _lib.check(L.splice_step_set_phases(e0.handle, 4, None), "step_set_phases")
+        e0.step(A_crop, B_crop, A_entire, _repeat=True)      # G backward of the summed image gradient
         adam_step(e0.params, e0.grads, e0.m, e0.v, c["lr"], c["optimizer_beta1"], c["optimizer_beta2"], 1e-8, self.step_idx + 1)
 
     def losses(self):

@@ -208,6 +208,53 @@ def test_streams_and_graph_do_not_change_results():
         assert torch.equal(p, outs[0][0]), (p - outs[0][0]).abs().max()
 
 
+def test_step_phases_and_follower_are_exact():
+    """splice_step_set_phases: (a) a step run as two calls (generator forward + ViT part, then generator backward + Adam)
+    launches the same kernels as the one-call step: parameters and losses agree BIT FOR BIT over 5 steps (entire-image
+    branch, warm-up switch); (b) a follower at the leader's own scale adds the same image gradient again, and every
+    backward kernel of the generator is linear in it: the summed parameter gradient is exactly twice the single one."""
+    from splice_amd import _lib
+    L = _lib.lib()
+    A, B = synth.smooth_image_pair(78, 0, 64, 64)
+    At, Bt = (torch.from_numpy(x).to(DEV) for x in (A, B))
+    cfg = dict(cls_warmup=2, entire_A_every=4)
+    outs = []
+    for split in (False, True):
+        eng = _engine(cfg, A, B, gen_seed=6, img_size=64)
+        for i in range(5):
+            if split:
+                _lib.check(L.splice_step_set_phases(eng.handle, 3, None))
+                eng.step(At, Bt, At)
+                _lib.check(L.splice_step_set_phases(eng.handle, 4, None))
+                eng.step(At, Bt, At, _repeat=True)
+            else:
+                eng.step(At, Bt, At)
+        torch.cuda.synchronize()
+        outs.append((eng.params.clone(), eng.losses_dev.clone()))
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0], outs[1][0]), (outs[0][0] - outs[1][0]).abs().max()
+    # (b) leader + follower at one scale: gradient-only mode, warm-up over (every term on), entire-image step
+    cfg = dict(cls_warmup=0, entire_A_every=4)
+    single = _engine(cfg, A, B, gen_seed=6, img_size=64)
+    _lib.check(L.splice_step_set_mode(single.handle, 1, 0))
+    single.step(At, Bt, At)
+    lead, foll = _engine(cfg, A, B, gen_seed=6, img_size=64), _engine(cfg, A, B, gen_seed=6, img_size=64)
+    _lib.check(L.splice_step_set_mode(lead.handle, 1, 0))
+    _lib.check(L.splice_step_set_mode(foll.handle, 1, 0))
+    _lib.check(L.splice_step_set_phases(foll.handle, 2, lead.handle))
+    assert L.splice_step_set_phases(foll.handle, 3, lead.handle) != 0      # a follower runs the ViT part only
+    assert L.splice_step_set_phases(lead.handle, 2, foll.handle) != 0      # no chains of followers
+    _lib.check(L.splice_step_set_phases(lead.handle, 3, None))
+    lead.step(At, Bt, At)
+    foll.step(At, Bt, At)
+    _lib.check(L.splice_step_set_phases(lead.handle, 4, None))
+    lead.step(At, Bt, At, _repeat=True)
+    torch.cuda.synchronize()
+    assert torch.equal(foll.losses_dev, single.losses_dev) and torch.equal(lead.losses_dev, single.losses_dev)
+    assert float(single.grads.abs().sum()) > 0
+    assert torch.equal(lead.grads, 2 * single.grads), (lead.grads - 2 * single.grads).abs().max()
+
+
 def test_full_size_step_vs_oracle_and_replay_modes():
     """BASELINE configs[1] at full size (224x224 pair, ViT-B/8, T = 785), teacher-forced steps 0, 1, 2 against the fp32 CPU
     oracle: step 0 is the CLS warm-up regime + the entire-image branch, steps 1-2 are the ORDINARY regime every timed step
