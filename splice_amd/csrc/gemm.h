@@ -34,12 +34,16 @@ __device__ __forceinline__ f32x4 mfma16_fp8_mx(const u32x4& a0, const u32x4& a1,
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, c, 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
 
-template <int BM, int BN, bool SWAP = false, bool FP8 = false>
+// WGM = waves along M (the wave grid is WGM x 2): 2 = the 256-thread workgroup; 4 = 512 threads, e.g. a 256 x 256 tile of 64 x 128
+// wave tiles -- half the L2 -> LDS bytes per FLOP of the 128 x 128 tile
+template <int BM, int BN, bool SWAP = false, bool FP8 = false, int WGM = 2>
 struct GemmTile {
-    static constexpr int FM = BM / 32;  // 16-row fragments per wave along M
+    static constexpr int NW = 2 * WGM;      // waves per workgroup
+    static constexpr int WROWS = BM / WGM;  // rows of a wave's sub-tile
+    static constexpr int FM = WROWS / 16;   // 16-row fragments per wave along M
     static constexpr int FN = BN / 32;
-    static constexpr int A_LOADS = BM * 8 / 256;  // 16-byte chunks per thread per slice
-    static constexpr int B_LOADS = BN * 8 / 256;
+    static constexpr int A_LOADS = BM * 8 / (64 * NW);  // 16-byte chunks per thread per slice
+    static constexpr int B_LOADS = BN * 8 / (64 * NW);
     static constexpr int LDS_ELEMS = (BM + BN) * GEMM_BK;
     f32x4 acc[FM][FN];
 
@@ -52,7 +56,7 @@ struct GemmTile {
                 const int chunk = kk * 4 + fchunk;
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
-                    const int row = wm * (BM / 2) + i * 16 + frow;
+                    const int row = wm * WROWS + i * 16 + frow;
                     af[i][kk] = *reinterpret_cast<const u32x4*>(As + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
                 }
 #pragma unroll
@@ -73,7 +77,7 @@ struct GemmTile {
                 const int chunk = kk * 4 + fchunk;
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
-                    const int row = wm * (BM / 2) + i * 16 + frow;
+                    const int row = wm * WROWS + i * 16 + frow;
                     af[i] = *reinterpret_cast<const u32x4*>(As + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
                 }
 #pragma unroll
@@ -109,13 +113,13 @@ struct GemmTile {
         uint32_t ao[A_LOADS], bo[B_LOADS];
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            int gr = m0 + wave * 8 + 32 * i + lrow;
+            int gr = m0 + wave * 8 + 8 * NW * i + lrow;
             gr = gr < M ? gr : M - 1;
             ao[i] = ((uint32_t)gr * (uint32_t)lda + gchunk * 8) * 2u;
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
-            int gr = n0 + wave * 8 + 32 * i + lrow;
+            int gr = n0 + wave * 8 + 8 * NW * i + lrow;
             gr = gr < N ? gr : N - 1;
             bo[i] = ((uint32_t)gr * (uint32_t)ldb + gchunk * 8) * 2u;
         }
@@ -126,10 +130,10 @@ struct GemmTile {
             asm volatile("" : "+s"(ab), "+s"(bb));   // keep the bases scalar (the loop optimiser would fold them into 8 vector pointers)
 #pragma unroll
             for (int i = 0; i < A_LOADS; ++i)
-                __builtin_amdgcn_global_load_lds((glb_void*)(ab + ao[i]), (lds_void*)(st + (wave * 8 + 32 * i) * GEMM_BK), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void*)(ab + ao[i]), (lds_void*)(st + (wave * 8 + 8 * NW * i) * GEMM_BK), 16, 0, 0);
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i)
-                __builtin_amdgcn_global_load_lds((glb_void*)(bb + bo[i]), (lds_void*)(st + BM * GEMM_BK + (wave * 8 + 32 * i) * GEMM_BK), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void*)(bb + bo[i]), (lds_void*)(st + BM * GEMM_BK + (wave * 8 + 8 * NW * i) * GEMM_BK), 16, 0, 0);
         };
         issue(0, 0);
         const int frow = lane & 15, fchunk = lane >> 4;
@@ -170,13 +174,13 @@ struct GemmTile {
         uint32_t ao[A_LOADS], bo[B_LOADS];
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            int gr = m0 + wave * 8 + 32 * i + lrow;
+            int gr = m0 + wave * 8 + 8 * NW * i + lrow;
             gr = gr < M ? gr : M - 1;
             ao[i] = ((uint32_t)gr * (uint32_t)lda + gchunk * 8) * 2u;
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
-            int gr = n0 + wave * 8 + 32 * i + lrow;
+            int gr = n0 + wave * 8 + 8 * NW * i + lrow;
             gr = gr < N ? gr : N - 1;
             bo[i] = ((uint32_t)gr * (uint32_t)ldb + gchunk * 8) * 2u;
         }
@@ -186,9 +190,9 @@ struct GemmTile {
             const bf16_t* ab = A + kbeg + sl * GEMM_BK;
             const bf16_t* bb = B + kbeg + sl * GEMM_BK;
 #pragma unroll
-            for (int i = 0; i < A_LOADS; ++i) dma16(st + i * (32 * GEMM_BK * 2), ao[i], ab);
+            for (int i = 0; i < A_LOADS; ++i) dma16(st + i * (8 * NW * GEMM_BK * 2), ao[i], ab);
 #pragma unroll
-            for (int i = 0; i < B_LOADS; ++i) dma16(st + (BM + 32 * i) * (GEMM_BK * 2), bo[i], bb);
+            for (int i = 0; i < B_LOADS; ++i) dma16(st + (BM + 8 * NW * i) * (GEMM_BK * 2), bo[i], bb);
         };
         const int nsl = K / GEMM_BK;
 #pragma unroll
@@ -218,7 +222,7 @@ struct GemmTile {
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-                f(m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4, acc[i][j]);
+                f(m0 + wm * WROWS + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4, acc[i][j]);
     }
 
     // Visit every accumulator fragment: f(row0, col, v) where v[r] is C[row0 + r][col].
@@ -230,7 +234,7 @@ struct GemmTile {
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-                f(m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4, n0 + wn * (BN / 2) + j * 16 + (lane & 15), acc[i][j]);
+                f(m0 + wm * WROWS + i * 16 + (lane >> 4) * 4, n0 + wn * (BN / 2) + j * 16 + (lane & 15), acc[i][j]);
     }
 };
 
