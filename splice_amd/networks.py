@@ -143,7 +143,16 @@ def skip(num_input_channels=3, num_output_channels=3, num_channels_down=[16, 32,
               and all(0 < c <= 128 for c in arch["num_channels_down"] + arch["num_channels_up"] + arch["num_channels_skip"])
               and 0 < num_input_channels <= 128 and 0 < num_output_channels <= 16)
     if not on_hip:
-        # what the kernels do not cover (other down-samplers / activations / no sigmoid, or a CPU device): stock PyTorch modules
+        # what the kernels do not cover (other down-samplers / activations / no sigmoid, or a CPU device): stock PyTorch modules --
+        # said out loud, so that nobody mistakes such a net for the HIP engine (SPLICE_STRICT_HIP=1 turns the notice into an error)
+        import os
+        import warnings
+        msg = ("splice_amd.networks.skip: this architecture / device is outside the HIP generator engine "
+               f"(device={device!r}, scales={n}, pad={pad!r}, act_fun={act_fun!r}, downsample_mode={downsample_mode!r}, "
+               f"upsample_mode={upsample_mode!r}, need_sigmoid={need_sigmoid}): building stock PyTorch modules instead")
+        if os.environ.get("SPLICE_STRICT_HIP") == "1":
+            raise RuntimeError(msg)
+        warnings.warn(msg, RuntimeWarning, stacklevel=2)
         from .unet_general import GeneralSkip
         return GeneralSkip(num_input_channels, num_output_channels, num_channels_down, num_channels_up, num_channels_skip,
                            filter_size_down, filter_size_up, filter_skip_size, need_sigmoid, need_tanh, need_bias, pad,

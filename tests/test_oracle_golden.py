@@ -148,7 +148,14 @@ def test_general_skip_matches_reference_inversion_net(golden_dir):
     from splice_amd.networks import skip
     from oracle.fixtures import INVERSION_NET, sample, stats
     g = np.load(os.path.join(golden_dir, "inversion_net.npz"))
-    net = skip(8, 3, device="cpu", **INVERSION_NET)
+    with pytest.warns(RuntimeWarning, match="outside the HIP generator engine"):   # the stock-PyTorch net announces itself
+        net = skip(8, 3, device="cpu", **INVERSION_NET)
+    os.environ["SPLICE_STRICT_HIP"] = "1"
+    try:
+        with pytest.raises(RuntimeError, match="outside the HIP generator engine"):
+            skip(8, 3, device="cpu", **INVERSION_NET)
+    finally:
+        del os.environ["SPLICE_STRICT_HIP"]
     params = list(net.named_parameters())
     assert len(params) == int(g["n_tensors"]) and sum(p.numel() for _, p in params) == int(g["n_params"])
     with torch.no_grad():
