@@ -196,7 +196,7 @@ def kernel_families(T, D, heads, P, size, depth=12, fp8=False):
         1: ("gemm_nt_kernel<BIAS|GELU|OUT_BF> fc1 forward" + (" [e4m3, scaled K=128 MFMA]" if fp8 else ""), "fp8mx" if fp8 else "bf16", 2 * P * 2.0 * T * hidden * D),
         2: ("gemm_nt_kernel<BIAS|OUT_BF|OUT_T> qkv forward" + (" [e4m3, scaled K=128 MFMA]" if fp8 else ""), "fp8mx" if fp8 else "bf16", 2 * P * 2.0 * T * 3 * D * D),
         9: ("gemm_nt_kernel<BIAS|RESID|OUT_F32> proj forward", "bf16", 2 * P * 2.0 * T * D * D),
-        3: ("attn_fwd8_kernel [e4m3 operands, k = 32 fp8 MFMA: bf16 rate]" if fp8 else "attn_fwd_kernel", "bf16", 2 * P * 4.0 * T * T * D),
+        3: ("attn_fwd8_kernel [e4m3 operands, k = 32 fp8 MFMA: bf16 rate]" if fp8 is True else "attn_fwd_kernel", "bf16", 2 * P * 4.0 * T * T * D),
         5: ("gemm_nt_kernel<OUT_F32> split-K dgrads (fc1^T and qkv^T, mean of both)", "bf16", P * 2.0 * T * D * (hidden + 3 * D) / 2),
         6: ("attn_bwd_kernel (merged, or dQ + dK/dV launches)", "bf16", P * 10.0 * T * T * D),
         # generator: one call = splice_gen_forward (2.262 GFLOP per 224^2 image) or splice_gen_backward (dgrad + wgrad = 2 x forward);
@@ -286,6 +286,8 @@ def main():
     ap.add_argument("--model", default="dino_vitb8")
     ap.add_argument("--pairs", type=int, default=1, help="pairs optimised side by side per GPU in the timed region (1 = the reference's unit: the latency form of the metric)")
     ap.add_argument("--pairs-sweep", default="2,4,8", help="additional pairs-per-GPU settings timed briefly after the main region (throughput form: pairs/hr); '' = off")
+    ap.add_argument("--fp8-attention", choices=("on", "off"), default="on",
+                    help="with --fp8: 'off' keeps the attention forward in bf16 (e4m3 projections + Gram only)")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4] operand path: QKV / fc1 / fc2 projections, attention forward and key self-similarity Gram on the fp8 MFMA (own tolerance table)")
     ap.add_argument("--scales", default="", help="BASELINE configs[4]: comma list of ViT input scales evaluated per step on the same crops (e.g. 224,320,448); "
                                                  "one fused step per scale + one Adam (MultiScaleEngine); disables the pairs sweep and the train-regime leg")
@@ -297,6 +299,7 @@ def main():
                                                                   "3 attention fwd, 5 split-K dgrads, 6 attention bwd, 7 generator chain, 8 key self-similarity")
     ap.add_argument("--allow-dev-env", action="store_true", help="run although a debugging / work-skipping SPLICE_* switch is set (the JSON line then carries config.dev_env)")
     args = ap.parse_args()
+    fp8_mode = False if not args.fp8 else (True if args.fp8_attention == "on" else "gemm")   # engine argument (splice_amd.engine: True / "gemm")
     stub_ms = os.environ.get("SPLICE_BENCH_STUB")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_workers(args.gpus, sys.argv[1:])
@@ -341,10 +344,10 @@ def main():
         args.pairs_sweep, args.no_train_regime, args.no_cpu_baseline = "", True, True
         Ai, Bi = synth.image_pair(1234, rep.pair_id(), hw[0], hw[1])
         eng = MultiScaleEngine(cfg, synth.vit_params(1234, args.model, img_size=224), synth.generator_params(1235 + rep.pair_id(), 0.02), hw, hw,
-                               scales=scales, device=dev, fp8=args.fp8)
+                               scales=scales, device=dev, fp8=fp8_mode)
         A, B = torch.from_numpy(Ai).to(dev), torch.from_numpy(Bi).to(dev)
     else:
-        eng, A, B = synthetic_engine(cfg, pair_id=rep.pair_id() * P, hw=hw, seed=1234, device=dev, pairs=P, fp8=args.fp8, top_cls_only=not args.full_top_block)
+        eng, A, B = synthetic_engine(cfg, pair_id=rep.pair_id() * P, hw=hw, seed=1234, device=dev, pairs=P, fp8=fp8_mode, top_cls_only=not args.full_top_block)
     K, W = args.steps, args.warmup
 
     def barrier():
@@ -381,7 +384,7 @@ def main():
     vit = eng.vit
     for Ps in sweep_ids:
         try:
-            e2, A2, B2 = synthetic_engine(cfg, pair_id=0, hw=hw, seed=1234, device=dev, pairs=Ps, vit_engine=vit, fp8=args.fp8, top_cls_only=not args.full_top_block)
+            e2, A2, B2 = synthetic_engine(cfg, pair_id=0, hw=hw, seed=1234, device=dev, pairs=Ps, vit_engine=vit, fp8=fp8_mode, top_cls_only=not args.full_top_block)
             k2 = max(20, K // 4)
             sweep[Ps] = k2 / time_steps(e2, A2, B2, k2, max(5, W // 2), barrier)
             del e2, A2, B2
@@ -400,11 +403,11 @@ def main():
         return
 
     if scales:   # every scale makes the same host calls per step: a family's mean FLOPs per call = the mean over the scales
-        per = [kernel_families(t, D, eng.vit.heads, P, args.size, fp8=args.fp8) for t in T]
+        per = [kernel_families(t, D, eng.vit.heads, P, args.size, fp8=fp8_mode) for t in T]
         fams = {k: (per[0][k][0] + f" (mean over the ViT input scales {scales})", per[0][k][1], sum(f[k][2] for f in per) / len(per)) for k in per[0]}
         fams[7] = per[0][7]   # (the generator works at the crop size at every scale)
     else:
-        fams = kernel_families(T, D, eng.vit.heads, P, args.size, fp8=args.fp8)
+        fams = kernel_families(T, D, eng.vit.heads, P, args.size, fp8=fp8_mode)
     roofs = []
     traffic_file = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     static_traffic = {}
@@ -456,7 +459,7 @@ def main():
     out = {
         "metric": "opt_steps_per_sec", "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "fp8(e4m3 qkv/fc1/fc2 + attention fwd + selfsim Gram)/bf16" if args.fp8 else "bf16", "data": "synthetic",
+        "dtype": ("fp8(e4m3 qkv/fc1/fc2 + attention fwd + selfsim Gram)/bf16" if fp8_mode is True else "fp8(e4m3 qkv/fc1/fc2 + selfsim Gram)/bf16") if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"Splice pair {hw[0]}x{hw[1]}, {args.model} (T={T}), {P} pair(s) per GPU per step, "
                                f"{n_entire} of {K} timed steps include the entire-image branch"
                                + (f"; loss evaluated at the ViT input scales {scales} every step (configs[4])" if scales else ""),

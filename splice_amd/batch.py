@@ -179,7 +179,9 @@ def main(argv=None):
     ap.add_argument("--pairs-per-gpu", type=int, default=1, help="pairs of equal image sizes optimised in the same launches on a GPU")
     ap.add_argument("--n_epochs", type=int, default=None, help="optimisation steps per pair (config default otherwise)")
     ap.add_argument("--scales", default="", help="comma list of ViT input sizes evaluated per step, e.g. 224,320,448 (config key dino_global_scales; BASELINE configs[4])")
-    ap.add_argument("--fp8", action="store_true", help="e4m3 operands for the QKV / fc1 / fc2 projections and the self-similarity Gram matrices (config key fp8)")
+    ap.add_argument("--fp8", nargs="?", const="gemm", default=None, choices=("gemm", "attention"),
+                    help="e4m3 operands for the QKV / fc1 / fc2 projections and the self-similarity Gram matrices (config key fp8); "
+                         "'--fp8 attention': the attention forward too")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="config override (conf/default/config.yaml keys)")
     args = ap.parse_args(argv)
     over = {}
@@ -190,7 +192,7 @@ def main(argv=None):
         if args.pairs_per_gpu > 1:
             raise SystemExit("--scales is a single-pair option (train_model); use --pairs-per-gpu 1")
     if args.fp8:
-        over["fp8"] = True
+        over["fp8"] = args.fp8
     for kv in args.set:
         k, _, v = kv.partition("=")
         over[k] = _parse_value(v)

@@ -28,6 +28,19 @@ device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
 _PKG_CFG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conf", "default", "config.yaml")
 
 
+
+def fp8_mode(cfg):
+    """Engine ``fp8`` argument of the config key ``fp8``: False -- bf16; True / ``"gemm"`` -- e4m3 operands for the QKV / fc1 / fc2
+    projections and the self-similarity Gram matrices (the fastest measured setting); ``"attention"`` / ``"all"`` -- the attention
+    forward in e4m3 as well (BASELINE configs[4] as written; measured 0.5 - 2.8 % SLOWER than ``"gemm"``, profiles/r03_fp8_attention_ab.txt)."""
+    v = cfg.get('fp8', False)
+    if isinstance(v, str):
+        v = v.strip().lower()
+        if v in ("", "false", "0", "off", "no"):
+            return False
+        return True if v in ("attention", "all") else "gemm"
+    return "gemm" if v else False
+
 def _load_image(path, resize):
     from PIL import Image
     img = Image.open(path).convert('RGB')
@@ -144,7 +157,7 @@ def train_model(dataroot, callback=None, cfg_overrides=None, vit_state=None, pro
     # loss term is evaluated each step (the reference has the single `dino_global_patch_size`), `fp8` = e4m3 operands for the
     # QKV / fc1 / fc2 projections and the self-similarity Gram matrices.  Absent keys = the reference's behaviour.
     scales = [int(x) for x in (cfg.get('dino_global_scales') or [])]
-    fp8 = bool(cfg.get('fp8', False))
+    fp8 = fp8_mode(cfg)
     crops, entire = (crop_max, crop_max), tuple(A.shape[1:])
     if len(scales) > 1:
         from .engine import MultiScaleEngine
@@ -249,7 +262,7 @@ def train_pairs(dataroots, callback=None, cfg_overrides=None, vit_state=None, pr
     torch.manual_seed(int(seed))
     A0, B0 = As[0], Bs[0]
     crop_max = max(min(A0.shape[1], A0.shape[2]), min(B0.shape[1], B0.shape[2]))
-    engine = MultiPairEngine(cfg, vit_state, gen_states, (crop_max, crop_max), tuple(A0.shape[1:]), device=device, vit_engine=vit_engine, fp8=bool(cfg.get('fp8', False)))
+    engine = MultiPairEngine(cfg, vit_state, gen_states, (crop_max, crop_max), tuple(A0.shape[1:]), device=device, vit_engine=vit_engine, fp8=fp8_mode(cfg))
     writers = [AsyncResultWriter(root) for root in dataroots]
     try:
         for epoch in range(1, cfg['n_epochs'] + 1):

@@ -88,3 +88,13 @@ def test_custom_runner_needs_a_group_runner_when_pairs_share_launches(tmp_path):
     _make_pairs(tmp_path, 2)
     with pytest.raises(ValueError, match="group_runner"):
         batch.run_batch(str(tmp_path), 1, runner="test_batch_cpu:stub_runner", pin_gpu=False, pairs_per_gpu=2)
+
+
+def test_fp8_config_key_maps_to_the_engine_mode():
+    """``fp8: True`` selects the fastest measured e4m3 setting (projections + Gram: engine mode "gemm"); the attention forward in
+    e4m3 is asked for by name."""
+    from splice_amd.train import fp8_mode
+    assert [fp8_mode({"fp8": v}) for v in (False, None, 0, "off", "False")] == [False] * 5
+    assert fp8_mode({}) is False
+    assert [fp8_mode({"fp8": v}) for v in (True, 1, "gemm", "True")] == ["gemm"] * 4
+    assert [fp8_mode({"fp8": v}) for v in ("attention", "all", " Attention ")] == [True] * 3
