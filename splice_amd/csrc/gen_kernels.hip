@@ -235,6 +235,15 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
     // latency-bound and more, smaller workgroups shorten them; the 32-channel layers are indifferent (2 kept)
     const int fn = (KS < 5 && a.Cout > 16 && a.Cout <= 32) ? 2 : 1;
     const int nt = cdiv(a.Cout, 16 * fn);
+    // Several images per launch (pairs side by side, or the crops of one pair): the chip is full anyway, and a workgroup that owns
+    // 32 output channels gathers its input tile once instead of twice (same-box A/B at 4 / 8 pairs per GPU: 2 fragments -1.0 % /
+    // -0.75 % step time, 4 fragments -0.3 % / 0; profiles/r03_conv_fn_ab.txt).  Which output channels share a workgroup does not
+    // touch any sum, so a pair's bits do not depend on it -- the split-K / wave-group policy below (which does change the
+    // summation order) keeps using the one-image fragment count.
+    static const int batch_fn = getenv("SPLICE_CONV_BATCH_FN") ? atoi(getenv("SPLICE_CONV_BATCH_FN")) : 2;
+    static const int batch_min = getenv("SPLICE_CONV_BATCH_MIN") ? atoi(getenv("SPLICE_CONV_BATCH_MIN")) : 4;
+    const int fn_run = (KS < 5 && fn == 1 && a.Cout >= 64 && a.N >= batch_min && (batch_fn == 2 || batch_fn == 4)) ? batch_fn : fn;
+    const int nt_run = cdiv(a.Cout, 16 * fn_run);
     // launch policy (split-K, 8-wave workgroups) from the workgroups of ONE image when the images are independent pairs:
     // split-K changes the summation order, and a pair's result must not depend on how many pairs share the launch
     const int npol = a.p_nstride ? 1 : a.N;
@@ -250,7 +259,7 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
         if (ksplit < 2) ksplit = 1;
     }
     a.ksplit = ksplit;
-    dim3 grid(mt, nt * ksplit, a.N);
+    dim3 grid(mt, nt_run * ksplit, a.N);
     // 8-wave workgroups while the chip holds at most ~2 workgroups per CU (the serial K walk is the run time then)
     constexpr bool CAN8 = KS == 3 && CK == 8;
     if constexpr (KS >= 5) {   // 5x5 / 7x7 (the inversion experiment's generator): one fragment per workgroup, 4 waves
@@ -260,13 +269,13 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
         const bool ng2 = CAN8 && (long)mt * nt * ksplit * npol <= 2048 && cdiv(a.Cin, CK) >= 2;
         if (ng2) {
             if constexpr (CAN8) {
-                if (fn == 1) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 1, CK, 2>), grid, dim3(512), 0, s, a);
-                else if (fn == 2) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 2, CK, 2>), grid, dim3(512), 0, s, a);
+                if (fn_run == 1) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 1, CK, 2>), grid, dim3(512), 0, s, a);
+                else if (fn_run == 2) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 2, CK, 2>), grid, dim3(512), 0, s, a);
                 else SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 4, CK, 2>), grid, dim3(512), 0, s, a);
             }
         } else {
-            if (fn == 1) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 1, CK, 1>), grid, dim3(256), 0, s, a);
-            else if (fn == 2) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 2, CK, 1>), grid, dim3(256), 0, s, a);
+            if (fn_run == 1) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 1, CK, 1>), grid, dim3(256), 0, s, a);
+            else if (fn_run == 2) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 2, CK, 1>), grid, dim3(256), 0, s, a);
             else SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 4, CK, 1>), grid, dim3(256), 0, s, a);
         }
     }
