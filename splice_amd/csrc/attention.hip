@@ -56,7 +56,12 @@ __device__ __forceinline__ float group4_sum(float v) {
 //      it feeds to the second MFMA -- whose other operand becomes a single 16-byte read of the
 //   "dim" tile [64 d][64 tokens] (transposed copy, from qkvT / doutT).
 //   16-byte chunk c of a row is stored at position c ^ swz(row): dim tile swz = row & 7; token tile
-//   swz = ((row >> 3) & 3) << 1 | (row >> 1) & 1  (conflict-free for the permuted row set above, b128 lane groups).
+//   swz = (row bit 1) << 1 | (row bit 3) << 2 -- conflict-free for the permuted row set above under the b128 lane groups AND for
+//   the transposing reads below (SQ_LDS_BANK_CONFLICT = 0 for both, tools/micro/tr_conflict.hip).
+//   The backward kernels take the TRANSPOSED operand of their second matrix product (dO^T, Q^T, K^T: rows = head dimension, k =
+//   token) out of the same token tile with ds_read_b64_tr_b16 instead of staging a second, d-major copy: within a 16-lane group
+//   lane m points at the 4 consecutive d values (m & 3) of token row (m >> 2), and lane i receives the column d0 + i of that
+//   4 x 16 block -- 4 consecutive tokens at one d (tools/micro/tr_read.hip); two such reads are one 16 x 32 MFMA operand.
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
@@ -68,7 +73,7 @@ struct TileDma {
         const int lane = threadIdx.x & 63;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3;
         lrow = lane >> 3;
-        tchunk = (lane & 7) ^ ((wave << 1) | ((lrow >> 1) & 1));   // token tile: row = piece*8 + lrow, piece & 3 == wave
+        tchunk = (lane & 7) ^ ((((lrow >> 1) & 1) << 1) | ((wave & 1) << 2));   // token tile: row = piece*8 + lrow, piece & 1 == wave & 1
         dchunk = (lane & 7) ^ lrow;                                // dim tile:   row & 7 == lrow
     }
     __device__ __forceinline__ void piece(const bf16_t* src, bf16_t* lds, int i) const {
@@ -108,15 +113,30 @@ struct TileDma {
 struct FragAddr {   // per-lane LDS element offsets of the fragment reads (everything else is an immediate)
     int tok[2];     // token tile: block nb of sub-tile sub, d-half hf   -> tok[hf] + sub*2048 + nb*256
     int dim[2];     // dim tile:   d block nd, sub-tile sub             -> dim[sub] + nd*1024
+    int tr[4];      // token tile, transposing read: d block nd, sub-tile sub, token half t4 -> tr[nd] + sub*2048 + t4*256
     __device__ __forceinline__ FragAddr(int g, int c) {
-        const int swz = ((c >> 2) << 1) | ((c >> 1) & 1);
+        const int swz = (((c >> 1) & 1) << 1) | (((c >> 2) & 1) << 2);   // of row (c>>2)*8 + (c&3): row bit 1 = c bit 1, row bit 3 = c bit 2
         const int row = (c >> 2) * 8 + (c & 3);
         tok[0] = row * 64 + ((g ^ swz) << 3);
         tok[1] = row * 64 + (((4 + g) ^ swz) << 3);
         dim[0] = c * 64 + ((g ^ (c & 7)) << 3);
         dim[1] = c * 64 + (((4 + g) ^ (c & 7)) << 3);
+        // lane (g, m = c): token row 8g + (m >> 2), d piece m & 3 (4 values) of d block nd: chunk 2 nd + (m >> 1 & 1), half m & 1
+        const int trow = 8 * g + (c >> 2);
+        const int tswz = (((trow >> 1) & 1) << 1) | (((trow >> 3) & 1) << 2);
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) tr[nd] = trow * 64 + ((((nd << 1) | ((c >> 1) & 1)) ^ tswz) << 3) + (c & 1) * 4;
     }
 };
+// one 16 x 32 MFMA operand out of a token tile, transposed: rows = d (lane & 15 within block nd), k = tokens sub*32 + 8g .. 8g+7
+typedef short tr_v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 lds_tr16(const bf16_t* tile, int off) {
+    typedef __attribute__((address_space(3))) tr_v4s lds_v4s;
+    const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(tile + off));          // tokens 8g .. 8g+3
+    const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(tile + off + 256));    // tokens 8g+4 .. 8g+7 (4 rows on)
+    const uint2 l = __builtin_bit_cast(uint2, lo), h = __builtin_bit_cast(uint2, hi);
+    return u32x4{l.x, l.y, h.x, h.y};
+}
 __device__ __forceinline__ u32x4 lds16(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
 
 // Workgroup -> (query/key block, head, pass): a 1-D grid walked through xcd_remap so that all blocks of one
@@ -706,7 +726,7 @@ __global__ __launch_bounds__(256 * KS) void attn_fwd8_kernel(AttnArgs a, int nx)
 // epilogue of the proj dgrad GEMM that produces dO; the stand-alone C entry point runs attn_delta_kernel first).
 // dQ half: wave owns 16 queries (lane&15 = query); K, V (token tiles) and K^T (dim tile) shared via LDS.
 template <int NSUB, bool MASK>
-__device__ __forceinline__ void attn_bwd_q_tile(const bf16_t* Ks, const bf16_t* Vs, const bf16_t* KTs, const FragAddr& fa,
+__device__ __forceinline__ void attn_bwd_q_tile(const bf16_t* Ks, const bf16_t* Vs, const FragAddr& fa,
                                                 const u32x4 (&qf)[2], const u32x4 (&dof)[2], float lse_q, float del_q, f32x4 (&dq)[4],
                                                 float c2, int kt, int T, int g) {
     f32x4 s[NSUB * 2], dp[NSUB * 2];
@@ -730,7 +750,7 @@ __device__ __forceinline__ void attn_bwd_q_tile(const bf16_t* Ks, const bf16_t* 
     for (int sub = 0; sub < NSUB; ++sub) {
         const u32x4 dsb = pack8v(dp[sub * 2], dp[sub * 2 + 1]);
 #pragma unroll
-        for (int nd = 0; nd < 4; ++nd) dq[nd] = mfma16(lds16(KTs + fa.dim[sub] + nd * 1024), dsb, dq[nd]);   // dQ^T[d][q]
+        for (int nd = 0; nd < 4; ++nd) dq[nd] = mfma16(lds_tr16(Ks, fa.tr[nd] + sub * 2048), dsb, dq[nd]);   // dQ^T[d][q]: K^T out of the K tile
     }
 }
 
@@ -744,7 +764,8 @@ __device__ __forceinline__ float dot8bf(const u32x4& x, const u32x4& y) {
     return acc;
 }
 
-__device__ __forceinline__ void attn_bwd_q_body(const AttnArgs& a, int xb, int h, int b, bf16_t* smem /* [stage][K | V | K^T] */) {
+constexpr int Q_STAGE = 2 * 4096;   // bf16 elements per ring stage of the dQ half: K and V token tiles
+__device__ __forceinline__ void attn_bwd_q_body(const AttnArgs& a, int xb, int h, int b, bf16_t* smem /* [stage][K | V] */) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
     const int ld = 3 * a.D;
@@ -766,17 +787,14 @@ __device__ __forceinline__ void attn_bwd_q_body(const AttnArgs& a, int xb, int h
     const float del_q = a.delta[((size_t)b * a.H + h) * a.Tld + qc];
     const bf16_t* krow = qkv_b + a.D + h * 64;
     const bf16_t* vrow = qkv_b + 2 * a.D + h * 64;
-    const bf16_t* kT = a.qkvT + (size_t)(a.D + h * 64) * a.ldt + (size_t)b * a.Tld;
-    const uint32_t koff = dma.token_off(ld), toff = dma.dim_off(a.ldt);
+    const uint32_t koff = dma.token_off(ld);
     auto issue = [&](int kt, bf16_t* st) {
         if (kt + 64 <= a.Tld) {
             dma.fast_tile(krow + (size_t)kt * ld, koff, ld, st);
             dma.fast_tile(vrow + (size_t)kt * ld, koff, ld, st + 4096);
-            dma.fast_tile(kT + kt, toff, a.ldt, st + 8192);
         } else {
             dma.token_tile(krow, ld, kt, a.Tld - 1, st);
             dma.token_tile(vrow, ld, kt, a.Tld - 1, st + 4096);
-            dma.dim_tile(kT, a.ldt, kt, a.Tld, st + 8192);
         }
     };
     issue(0, smem);
@@ -788,19 +806,19 @@ __device__ __forceinline__ void attn_bwd_q_body(const AttnArgs& a, int xb, int h
     for (int it = 0; it < nfull; ++it) {
         dma_wait_barrier();
         const int kn = it * 64 + 64;
-        if (kn < a.Tld) issue(kn, smem + ((it + 1) & 1) * 12288);
+        if (kn < a.Tld) issue(kn, smem + ((it + 1) & 1) * Q_STAGE);
         if (active) {
-            const bf16_t* cur = smem + (it & 1) * 12288;
-            attn_bwd_q_tile<2, false>(cur, cur + 4096, cur + 8192, fa, qf, dof, lse_q, del_q, dq, c2, it * 64, a.T, g);
+            const bf16_t* cur = smem + (it & 1) * Q_STAGE;
+            attn_bwd_q_tile<2, false>(cur, cur + 4096, fa, qf, dof, lse_q, del_q, dq, c2, it * 64, a.T, g);
         }
     }
     if (nfull * 64 < a.T) {
         dma_wait_barrier();
         const int kt = nfull * 64;
         if (active) {
-            const bf16_t* cur = smem + (nfull & 1) * 12288;
-            if (kt + 32 < a.T) attn_bwd_q_tile<2, true>(cur, cur + 4096, cur + 8192, fa, qf, dof, lse_q, del_q, dq, c2, kt, a.T, g);
-            else attn_bwd_q_tile<1, true>(cur, cur + 4096, cur + 8192, fa, qf, dof, lse_q, del_q, dq, c2, kt, a.T, g);
+            const bf16_t* cur = smem + (nfull & 1) * Q_STAGE;
+            if (kt + 32 < a.T) attn_bwd_q_tile<2, true>(cur, cur + 4096, fa, qf, dof, lse_q, del_q, dq, c2, kt, a.T, g);
+            else attn_bwd_q_tile<1, true>(cur, cur + 4096, fa, qf, dof, lse_q, del_q, dq, c2, kt, a.T, g);
         }
     }
     if (active && q < a.Tld) {
@@ -813,12 +831,12 @@ __device__ __forceinline__ void attn_bwd_q_body(const AttnArgs& a, int xb, int h
 // dK / dV kernel: wave owns 16 keys (lane&15 = key); the workgroup's 4 waves share 64-query tiles of Q, dO (token
 // tiles) and Q^T, dO^T (dim tiles) plus lse / delta through LDS.  Padding keys accumulate garbage in their own
 // lanes only (MFMA output columns are independent) and are stored as exact zeros.
-#define KV_STAGE (4 * 4096 + 256)   // bf16 elements per ring stage: 4 tiles + 64 lse + 64 delta floats
+#define KV_STAGE (2 * 4096 + 256)   // bf16 elements per ring stage: the Q and dO token tiles + 64 lse + 64 delta floats
 template <int NSUB>
 __device__ __forceinline__ void attn_bwd_kv_tile(const bf16_t* st, const FragAddr& fa, const u32x4 (&kf)[2], const u32x4 (&vf)[2],
                                                  f32x4 (&dk)[4], f32x4 (&dv)[4], float c2, int g) {
-    const bf16_t *Qs = st, *Ds = st + 4096, *QTs = st + 8192, *DTs = st + 12288;
-    const float* Ls = reinterpret_cast<const float*>(st + 16384);
+    const bf16_t *Qs = st, *Ds = st + 4096;
+    const float* Ls = reinterpret_cast<const float*>(st + 8192);
     const float* Es = Ls + 64;
     f32x4 s[NSUB * 2], dp[NSUB * 2];
 #pragma unroll
@@ -845,8 +863,8 @@ __device__ __forceinline__ void attn_bwd_kv_tile(const bf16_t* st, const FragAdd
         const u32x4 pb = pack8v(s[sub * 2], s[sub * 2 + 1]), dsb = pack8v(dp[sub * 2], dp[sub * 2 + 1]);
 #pragma unroll
         for (int nd = 0; nd < 4; ++nd) {
-            dv[nd] = mfma16(lds16(DTs + fa.dim[sub] + nd * 1024), pb, dv[nd]);    // dV^T[d][key]
-            dk[nd] = mfma16(lds16(QTs + fa.dim[sub] + nd * 1024), dsb, dk[nd]);   // dK^T[d][key]
+            dv[nd] = mfma16(lds_tr16(Ds, fa.tr[nd] + sub * 2048), pb, dv[nd]);    // dV^T[d][key]: dO^T out of the dO tile
+            dk[nd] = mfma16(lds_tr16(Qs, fa.tr[nd] + sub * 2048), dsb, dk[nd]);   // dK^T[d][key]: Q^T out of the Q tile
         }
     }
 }
@@ -871,27 +889,21 @@ __device__ __forceinline__ void attn_bwd_kv_body(const AttnArgs& a, int xb, int 
     }
     const bf16_t* qrow = qkv_b + h * 64;
     const bf16_t* dorow = a.dout + (size_t)b * a.Tld * a.D + h * 64;
-    const bf16_t* qT = a.qkvT + (size_t)(h * 64) * a.ldt + (size_t)b * a.Tld;
-    const bf16_t* doT = a.doutT + (size_t)(h * 64) * a.ldt + (size_t)b * a.Tld;
     const float* lse = a.lse + ((size_t)b * a.H + h) * a.Tld;
     const float* dl = a.delta + ((size_t)b * a.H + h) * a.Tld;
-    const uint32_t qoff = dma.token_off(ld), dooff = dma.token_off(a.D), toff = dma.dim_off(a.ldt);
+    const uint32_t qoff = dma.token_off(ld), dooff = dma.token_off(a.D);
     auto issue = [&](int qt, bf16_t* st) {
         if (qt + 64 <= a.Tld) {
             dma.fast_tile(qrow + (size_t)qt * ld, qoff, ld, st);
             dma.fast_tile(dorow + (size_t)qt * a.D, dooff, a.D, st + 4096);
-            dma.fast_tile(qT + qt, toff, a.ldt, st + 8192);
-            dma.fast_tile(doT + qt, toff, a.ldt, st + 12288);
         } else {
             dma.token_tile(qrow, ld, qt, a.Tld - 1, st);
             dma.token_tile(dorow, a.D, qt, a.Tld - 1, st + 4096);
-            dma.dim_tile(qT, a.ldt, qt, a.Tld, st + 8192);
-            dma.dim_tile(doT, a.ldt, qt, a.Tld, st + 12288);
         }
         if (dma.wave < 2) {   // wave 0: 64 lse values, wave 1: 64 delta values (4 bytes per lane)
             const int qq = qt + lane < a.Tld ? qt + lane : a.Tld - 1;
             const float* src = (dma.wave == 0 ? lse : dl) + qq;
-            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(st + 16384 + dma.wave * 128), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(st + 8192 + dma.wave * 128), 4, 0, 0);
         }
     };
     issue(0, smem);
@@ -937,7 +949,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a, int nx) {
 }
 
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a, int nx) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 3 * 4096];
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * Q_STAGE];
     int xb, h, b;
     attn_block_coords(nx, a.H, a.B, xb, h, b);
     attn_bwd_q_body(a, xb, h, b, smem);
