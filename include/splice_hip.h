@@ -123,17 +123,19 @@ int splice_layernorm_bwd(const float* dy, const float* x, const float* gamma, co
                          int rows, int D, splice_stream_t stream);
 
 /* Multi-head self-attention (head dim 64), DINO Attention.forward: softmax(q k^T d^-1/2) v.
- * qkv [B*Tld][3D] bf16 (layout of models/extractor.py:136-151), qkvT its transpose [3D][ldt].
+ * qkv [B*Tld][3D] bf16 (layout of models/extractor.py:136-151).  qkvT / ldt (the transpose [3D][ldt]) are not read any more --
+ * V^T comes out of the V tile inside LDS (ds_read_b64_tr_b16) -- and may be NULL / 0; the parameters stay for ABI stability.
  * out [B*Tld][D] bf16; lse [B][H][Tld] fp32 (saved for the backward). */
 int splice_attention_fwd(const splice_bf16* qkv, const splice_bf16* qkvT, int ldt, int B, int T, int Tld,
                          int D, int H, float scale, splice_bf16* out, float* lse, splice_stream_t stream);
-/* dqkv [B*Tld][3D] bf16 from dout [B*Tld][D] (+ its transpose doutT [D][ldt]); delta is
- * [B][H][Tld] fp32 scratch (rowsum(dO * O), formed by the call). */
 /* The forward with e4m3 operands (BASELINE configs[4]): Q K^T and P V on the fp8 MFMA from UNSCALED e4m3 copies of qkv --
  * qkv8 bytes [B*Tld][3D] row-major and qkvT8 bytes [3D][ldt8] transposed (ldt8 % 16 == 0), as the fp8 QKV projection writes them
  * (SPLICE_EPI_OUT_F8 | SPLICE_EPI_OUT_F8T).  Output / lse as splice_attention_fwd; the backward runs on the bf16 tensors. */
 int splice_attention_fwd_fp8(const uint8_t* qkv8, const uint8_t* qkvT8, int ldt8, int B, int T, int Tld, int D, int H, float scale,
                              splice_bf16* out, float* lse, splice_stream_t stream);
+/* dqkv [B*Tld][3D] bf16 from dout [B*Tld][D]; delta is [B][H][Tld] fp32 scratch (rowsum(dO * O), formed by the call).
+ * qkvT / ldt / doutT are not read any more (the kernels take the transposed operands out of the token tiles with
+ * ds_read_b64_tr_b16) and may be NULL / 0: the parameters stay for ABI stability. */
 int splice_attention_bwd(const splice_bf16* qkv, const splice_bf16* qkvT, int ldt, int B, int T, int Tld,
                          int D, int H, float scale, const splice_bf16* out, const float* lse,
                          const splice_bf16* dout, const splice_bf16* doutT, float* delta,

@@ -12,7 +12,7 @@
 // Inputs: qkv  bf16 [B*Tld][3D]  (row = b*Tld + token; q | k | v column blocks, heads
 //                                 contiguous inside each block -- the layout
 //                                 models/extractor.py:136-151 reshapes)
-//         qkvT bf16 [3D][ldt]    the same matrix transposed (written by the QKV GEMM
+//         qkvT bf16 [3D][ldt]    the same matrix transposed (only the [CLS]-row kernels of vit_cls.hip still read it; written by the QKV GEMM
 //                                 epilogue) -- supplies the token-contiguous operands.
 // Tokens t >= T inside a pass are padding: masked as keys, harmless as queries.
 #include "kernels.h"
@@ -43,38 +43,38 @@ __device__ __forceinline__ float group4_sum(float v) {
 
 // ---------------------------------------------------------------------------------------
 // Tile toolkit: LDS-DMA staging (global_load_lds, 16 B per lane, no VGPR round trip) + fragment layouts that
-// need ONE ds_read_b128 per MFMA operand.
+// need ONE ds_read_b128 (or two transposing 8-byte reads) per MFMA operand.
 //
-// A wave-instruction of the DMA fills 8 rows x 128 B of LDS linearly (dest = piece base + lane*16), so every
+// A wave-instruction of the DMA fills 8 rows x 128 B of LDS linearly (dest = piece base + lane*16), so the
 // swizzle is applied on the SOURCE chunk a lane fetches.  Wave w of the 4 moves the 1-KiB pieces w and w+4 of a
 // [64][64] bf16 tile.
 //
-//   "token" tile [64 tokens][64 d] -- the operand whose rows become the ROWS of the score MFMA (keys in the
-//      forward / dQ kernels, queries in the dK/dV kernel).  Block nb (16 MFMA rows) of 32-token sub-tile `sub`
-//      takes row i = 4*j + r from token sub*32 + 8*j + 4*nb + r: lane group g then owns, over nb = 0,1, the EIGHT
-//      CONSECUTIVE tokens sub*32 + 8g .. 8g+7, which is exactly the k-slot order of the packed probabilities
-//      it feeds to the second MFMA -- whose other operand becomes a single 16-byte read of the
-//   "dim" tile [64 d][64 tokens] (transposed copy, from qkvT / doutT).
-//   16-byte chunk c of a row is stored at position c ^ swz(row): dim tile swz = row & 7; token tile
-//   swz = (row bit 1) << 1 | (row bit 3) << 2 -- conflict-free for the permuted row set above under the b128 lane groups AND for
-//   the transposing reads below (SQ_LDS_BANK_CONFLICT = 0 for both, tools/micro/tr_conflict.hip).
-//   The backward kernels take the TRANSPOSED operand of their second matrix product (dO^T, Q^T, K^T: rows = head dimension, k =
-//   token) out of the same token tile with ds_read_b64_tr_b16 instead of staging a second, d-major copy: within a 16-lane group
-//   lane m points at the 4 consecutive d values (m & 3) of token row (m >> 2), and lane i receives the column d0 + i of that
-//   4 x 16 block -- 4 consecutive tokens at one d (tools/micro/tr_read.hip); two such reads are one 16 x 32 MFMA operand.
+//   Every operand is staged ONCE, as a "token" tile [64 tokens][64 d] (rows of q / k / v / dO as they lie in memory).
+//   * Token-major fragments (the operand whose rows become the ROWS of the score MFMA: keys in the forward / dQ kernels, queries
+//     in the dK/dV kernel) are one ds_read_b128 each.  Block nb (16 MFMA rows) of 32-token sub-tile `sub` takes row i = 4*j + r
+//     from token sub*32 + 8*j + 4*nb + r: lane group g then owns, over nb = 0,1, the EIGHT CONSECUTIVE tokens sub*32 + 8g .. 8g+7,
+//     which is exactly the k-slot order of the packed probabilities it feeds to the second MFMA.
+//   * The TRANSPOSED operand of that second MFMA (V^T in the forward, K^T in the dQ half, dO^T / Q^T in the dK/dV half: rows =
+//     head dimension, k = token) comes out of the same kind of tile with ds_read_b64_tr_b16: within a 16-lane group lane m points
+//     at the 4 consecutive d values (m & 3) of token row (m >> 2), and lane i receives the column d0 + i of that 4 x 16 block --
+//     4 consecutive tokens at one d (tools/micro/tr_read.hip); two such reads are one 16 x 32 operand.  Up to round 3 these
+//     operands were staged from transposed copies (qkvT / doutT) written by the producing GEMMs: twice the LDS-DMA traffic and
+//     LDS footprint in the backward, and an extra output per GEMM.
+//   16-byte chunk c of a row is stored at position c ^ swz(row), swz = (row bit 1) << 1 | (row bit 3) << 2: conflict-free for the
+//   permuted row set above under the b128 lane groups AND for the transposing reads (SQ_LDS_BANK_CONFLICT = 0 for both,
+//   tools/micro/tr_conflict.hip, profiles/r03_tr_read_conflicts.txt).
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
 struct TileDma {
     int wave;                 // scalar
-    int lrow, tchunk, dchunk;
+    int lrow, tchunk;
     // w4 = index of the wave inside its group of 4 (a group moves one tile set; 8-wave workgroups hold two groups)
     __device__ __forceinline__ TileDma() {
         const int lane = threadIdx.x & 63;
         wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3;
         lrow = lane >> 3;
         tchunk = (lane & 7) ^ ((((lrow >> 1) & 1) << 1) | ((wave & 1) << 2));   // token tile: row = piece*8 + lrow, piece & 1 == wave & 1
-        dchunk = (lane & 7) ^ lrow;                                // dim tile:   row & 7 == lrow
     }
     __device__ __forceinline__ void piece(const bf16_t* src, bf16_t* lds, int i) const {
         __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(lds + (wave + 4 * i) * 512), 16, 0, 0);
@@ -82,8 +82,7 @@ struct TileDma {
     // Interior tiles: a uniform (scalar) tile base + per-lane byte offsets that are fixed for the whole kernel -- one
     // VALU op per DMA instead of the clamp / multiply / 64-bit add chain.
     __device__ __forceinline__ uint32_t token_off(int ld) const { return (uint32_t)(((wave * 8 + lrow) * ld + tchunk * 8) * 2); }
-    __device__ __forceinline__ uint32_t dim_off(int ldt) const { return (uint32_t)(((wave * 8 + lrow) * ldt + dchunk * 8) * 2); }
-    // tile = first element of the tile (token tile: base + tok0*ld; dim tile: baseT + tok0); stride = ld resp. ldt
+    // tile = first element of the tile (base + tok0*ld); stride = ld
     __device__ __forceinline__ void fast_tile(const bf16_t* tile, uint32_t off, int stride, bf16_t* lds) const {
         const char* b0 = reinterpret_cast<const char*>(tile);
         const char* b1 = reinterpret_cast<const char*>(tile + (size_t)32 * stride);
@@ -100,27 +99,16 @@ struct TileDma {
             piece(base + (size_t)t * ld + tchunk * 8, lds, i);
         }
     }
-    // d-major source (rows = d), 64 contiguous tokens from tok0; an 8-token chunk starting past tok_lim-8 is replaced
-    // by the last in-bounds chunk (those tokens are masked keys / skipped queries: any finite value will do)
-    __device__ __forceinline__ void dim_tile(const bf16_t* baseT, int ldt, int tok0, int tok_lim, bf16_t* lds) const {
-        int t = tok0 + dchunk * 8;
-        t = t <= tok_lim - 8 ? t : tok_lim - 8;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) piece(baseT + (size_t)((wave + 4 * i) * 8 + lrow) * ldt + t, lds, i);
-    }
 };
 
 struct FragAddr {   // per-lane LDS element offsets of the fragment reads (everything else is an immediate)
     int tok[2];     // token tile: block nb of sub-tile sub, d-half hf   -> tok[hf] + sub*2048 + nb*256
-    int dim[2];     // dim tile:   d block nd, sub-tile sub             -> dim[sub] + nd*1024
     int tr[4];      // token tile, transposing read: d block nd, sub-tile sub, token half t4 -> tr[nd] + sub*2048 + t4*256
     __device__ __forceinline__ FragAddr(int g, int c) {
         const int swz = (((c >> 1) & 1) << 1) | (((c >> 2) & 1) << 2);   // of row (c>>2)*8 + (c&3): row bit 1 = c bit 1, row bit 3 = c bit 2
         const int row = (c >> 2) * 8 + (c & 3);
         tok[0] = row * 64 + ((g ^ swz) << 3);
         tok[1] = row * 64 + (((4 + g) ^ swz) << 3);
-        dim[0] = c * 64 + ((g ^ (c & 7)) << 3);
-        dim[1] = c * 64 + (((4 + g) ^ (c & 7)) << 3);
         // lane (g, m = c): token row 8g + (m >> 2), d piece m & 3 (4 values) of d block nd: chunk 2 nd + (m >> 1 & 1), half m & 1
         const int trow = 8 * g + (c >> 2);
         const int tswz = (((trow >> 1) & 1) << 1) | (((trow >> 3) & 1) << 2);
@@ -253,7 +241,7 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
         for (int qb = 0; qb < QB; ++qb) pb[qb] = pack8v(p[qb][sub * 2], p[qb][sub * 2 + 1]);
 #pragma unroll
         for (int nd = 0; nd < 4; ++nd) {
-            const u32x4 vf = lds16(Vs + fa.dim[sub] + nd * 1024);
+            const u32x4 vf = lds_tr16(Vs, fa.tr[nd] + sub * 2048);   // V^T[d][keys sub*32 + 8g .. +7] out of the V token tile
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) o[qb][nd] = mfma16(vf, pb[qb], o[qb][nd]);
         }
@@ -282,7 +270,7 @@ __global__ __launch_bounds__(256 * KS) void attn_fwd_kernel(AttnArgs a, int nx) 
     const bool active = qbase < a.Tld;   // a wave without queries still moves its share of every tile
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.Tld * ld;
     const bf16_t* kbase = qkv_b + a.D + h * 64;
-    const bf16_t* vT = a.qkvT + (size_t)(2 * a.D + h * 64) * a.ldt + (size_t)b * a.Tld;
+    const bf16_t* vbase = qkv_b + 2 * a.D + h * 64;   // V as a token tile: P V takes V^T out of it with the transposing LDS read
     u32x4 qf[QB][2];
     int qidx[QB];
 #pragma unroll
@@ -294,14 +282,14 @@ __global__ __launch_bounds__(256 * KS) void attn_fwd_kernel(AttnArgs a, int nx) 
         qf[qb][0] = ld16v(p);
         qf[qb][1] = ld16v(p + 32);
     }
-    const uint32_t koff = dma.token_off(ld), voff = dma.dim_off(a.ldt);
+    const uint32_t koff = dma.token_off(ld);
     auto issue = [&](int kt, bf16_t* st) {
         if (kt + 64 <= a.Tld) {
             dma.fast_tile(kbase + (size_t)kt * ld, koff, ld, st);
-            dma.fast_tile(vT + kt, voff, a.ldt, st + 4096);
+            dma.fast_tile(vbase + (size_t)kt * ld, koff, ld, st + 4096);
         } else {
             dma.token_tile(kbase, ld, kt, a.Tld - 1, st);
-            dma.dim_tile(vT, a.ldt, kt, a.Tld, st + 4096);
+            dma.token_tile(vbase, ld, kt, a.Tld - 1, st + 4096);
         }
     };
     // key tiles with at least one valid key: [0, nt); group grp owns [t0, t1)
@@ -1000,7 +988,7 @@ static int g_attn_variant = 0;   // benchmarking hook (splice_attention_variant)
 void attn_set_variant(int v) { g_attn_variant = v; }
 
 int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
-    if (a->Tld % 32 || a->D % 64 || a->D / 64 != a->H || a->ldt % 4) return SPLICE_ERR_ARG;
+    if (a->Tld % 32 || a->D % 64 || a->D / 64 != a->H) return SPLICE_ERR_ARG;
     // Launch form (measured, tools/attn_bench.py at 2 / 8 / 16 passes of T = 785 and 2 passes of T = 3137, profiles/r03_attn_forms.txt):
     // 16 queries per wave and TWO wave groups per workgroup (key-range halves side by side) is the fastest form at every batch
     // size -- 13.4 / 31.6 / 60.9 us against 15.8 / 34.2 / 66.2 for one group walking both halves -- except where its 8-wave,
@@ -1036,7 +1024,7 @@ int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
 }
 
 int attn_bwd_launch(const AttnArgs* a, hipStream_t s) {
-    if (a->Tld % 32 || a->D % 64 || a->D / 64 != a->H || a->ldt % 4) return SPLICE_ERR_ARG;
+    if (a->Tld % 32 || a->D % 64 || a->D / 64 != a->H) return SPLICE_ERR_ARG;
     const int nx = cdiv(a->Tld, 64);
     if (!a->delta_ready) SPLICE_LAUNCH(attn_delta_kernel, dim3(cdiv(a->B * a->Tld * a->H, 256)), dim3(256), 0, s, *a);
     const int n = nx * a->H * a->B;

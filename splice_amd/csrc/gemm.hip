@@ -88,6 +88,7 @@ int gemm_nt_launch(unsigned flags, const bf16_t* A, int lda, const bf16_t* B, in
         CASE(EPI_OUT_BF);                                         // dgrad -> next GEMM
         CASE(EPI_OUT_BF | EPI_OUT_T);                             // proj dgrad -> attention backward
         CASE(EPI_OUT_BF | EPI_OUT_T | EPI_ROWDOT);                // same + delta = rowsum(dO * O) per head
+        CASE(EPI_OUT_BF | EPI_ROWDOT);                            // proj dgrad of the ViT engine: dO and delta (the attention backward transposes in LDS)
         CASE(EPI_GELU_GRAD | EPI_OUT_BF);                         // fc2 dgrad
         default: return SPLICE_ERR_ARG;
     }
@@ -120,7 +121,9 @@ int gemm_nt_fp8_launch(unsigned flags, const uint8_t* A, int lda, const uint8_t*
     if ((flags & (EPI_OUT_F8 | EPI_OUT_F8T)) && (flags & EPI_OUT_BF) && (N % 16 || e.ldbf % 8 || ((flags & EPI_OUT_T) && e.ldt % 8))) return SPLICE_ERR_ARG;
 #define CASE8(F) case (F): return dispatch_fp8<(F)>(A, lda, B, ldb, M, N, K, e, s)
     switch (flags) {
-        CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T);                  // qkv
+        CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF);                              // qkv
+        CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_F8 | EPI_OUT_F8T);   // qkv + e4m3 copies for the fp8 attention
+        CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T);                  // qkv with a transposed bf16 copy
         CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T | EPI_COLS_F32);   // qkv, last layer
         CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T | EPI_OUT_F8 | EPI_OUT_F8T);                  // qkv + e4m3 copies for the fp8 attention
         CASE8(EPI_SCALE_RC | EPI_BIAS | EPI_OUT_BF | EPI_OUT_T | EPI_COLS_F32 | EPI_OUT_F8 | EPI_OUT_F8T);   // the same, last layer

@@ -72,7 +72,9 @@ struct SpliceVitCtx {
     std::vector<float*> xs;                // depth+1 x [rows][D]   residual stream (block outputs)
     std::vector<float*> xmid;              // depth   x [rows][D]
     std::vector<float*> mean1, rstd1, mean2, rstd2;  // depth x [rows]
-    std::vector<bf16_t*> qkv, qkvT, attn_out, hpre;  // depth
+    std::vector<bf16_t*> qkv, attn_out, hpre;  // depth
+    bf16_t* qkvT_last = nullptr;   // [3D][rows] transpose of the LAST layer's qkv (the [CLS]-row kernels of vit_cls.hip read token-contiguous K / V);
+                                   // the attention kernels proper transpose inside LDS and need no such copy
     std::vector<float*> lse;               // depth x [B][H][Tld]
     float* qkv_last_f32 = nullptr;         // [rows][3D]
     bf16_t* ln_out = nullptr;              // [rows][D]   transient
@@ -87,7 +89,7 @@ struct SpliceVitCtx {
     bf16_t* g_bf = nullptr;
     bf16_t* dh = nullptr;                  // [rows][4D]
     float* dln = nullptr;                  // [rows][D]
-    bf16_t *dout = nullptr, *doutT = nullptr, *dqkv = nullptr;
+    bf16_t *dout = nullptr, *dqkv = nullptr;
     float* delta = nullptr;
     float* dpatches = nullptr;             // [rows][3pp]
     std::vector<void*> allocs;
@@ -284,16 +286,17 @@ int splice_vit_ctx_create(void* h, int B, int H, int W, const float* pos_TD, int
     A(c->pos_eff, (size_t)c->Tld * D);
     A(c->patches, rows * pp3);
     c->xs.resize(L + 1); c->xmid.resize(L); c->mean1.resize(L); c->rstd1.resize(L); c->mean2.resize(L); c->rstd2.resize(L);
-    c->qkv.resize(L); c->qkvT.resize(L); c->attn_out.resize(L); c->hpre.resize(L); c->lse.resize(L);
+    c->qkv.resize(L); c->attn_out.resize(L); c->hpre.resize(L); c->lse.resize(L);
     for (int l = 0; l <= L; ++l) A(c->xs[l], rows * D);
     for (int l = 0; l < L; ++l) {
         A(c->xmid[l], rows * D);
         A(c->mean1[l], rows); A(c->rstd1[l], rows); A(c->mean2[l], rows); A(c->rstd2[l], rows);
-        A(c->qkv[l], rows * 3 * D); A(c->qkvT[l], rows * 3 * D); A(c->attn_out[l], rows * D);
+        A(c->qkv[l], rows * 3 * D); A(c->attn_out[l], rows * D);
         A(c->hpre[l], rows * Hd);
         A(c->lse[l], (size_t)B * v->heads * c->Tld);
     }
     A(c->qkv_last_f32, rows * 3 * D);
+    A(c->qkvT_last, rows * 3 * D);
     A(c->ln_out, rows * D);
     A(c->cls_attn, (size_t)B * D); A(c->cls_ln, (size_t)B * D); A(c->cls_h, (size_t)B * Hd); A(c->cls_probs, (size_t)B * v->heads * c->Tld);
     A(c->cls_slabs, (size_t)16 * B * Hd);
@@ -301,7 +304,7 @@ int splice_vit_ctx_create(void* h, int B, int H, int W, const float* pos_TD, int
     A(c->hact, rows * Hd);
     if (need_grad) {
         A(c->g, rows * D); A(c->g_bf, rows * D); A(c->dh, rows * Hd); A(c->dln, rows * D * 4);   // dln: up to 4 split-K slabs
-        A(c->dout, rows * D); A(c->doutT, rows * D); A(c->dqkv, rows * 3 * D);
+        A(c->dout, rows * D); A(c->dqkv, rows * 3 * D);
         A(c->delta, (size_t)B * v->heads * c->Tld);
         A(c->dpatches, rows * pp3);
     }
@@ -423,9 +426,13 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
         else RC(layernorm_fwd_launch(x_in, W.ln1_g, W.ln1_b, ln_out, c->mean1[l] + r0, c->rstd1[l] + r0, R, D, 1e-6f, s));
         {
             GemmEpi e = {};
-            e.bias = W.qkv.b; e.out_bf = c->qkv[l] + r0 * 3 * D; e.ldbf = 3 * D; e.out_bf_t = c->qkvT[l] + r0; e.ldt = c->rows;
-            unsigned fl = EPI_BIAS | EPI_OUT_BF | EPI_OUT_T;
-            if (l == L - 1) { fl |= EPI_COLS_F32; e.out_f32_cols = c->qkv_last_f32 + r0 * 3 * D; e.ld_cols = 3 * D; e.col_lo = 0; e.col_hi = 3 * D; }
+            e.bias = W.qkv.b; e.out_bf = c->qkv[l] + r0 * 3 * D; e.ldbf = 3 * D;
+            unsigned fl = EPI_BIAS | EPI_OUT_BF;
+            if (l == L - 1) {   // + the transposed copy for the [CLS]-row kernels and the fp32 keys of the loss terms
+                fl |= EPI_OUT_T | EPI_COLS_F32;
+                e.out_bf_t = c->qkvT_last + r0; e.ldt = c->rows;
+                e.out_f32_cols = c->qkv_last_f32 + r0 * 3 * D; e.ld_cols = 3 * D; e.col_lo = 0; e.col_hi = 3 * D;
+            }
             SpliceProfScope ps(l == L - 1 ? 0 : 2);
             if (fp8) {   // e4m3 LayerNorm output (per-token scale) x e4m3 weights (per-channel scale) on the fp8 MFMA
                 e.row_scale = c->ln_scale + r0; e.col_scale = W.qkv.w8_scale;
@@ -444,7 +451,7 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
             bf16_t* cattn = c->cls_attn + (size_t)pass_begin * D;
             bf16_t* cln = c->cls_ln + (size_t)pass_begin * D;
             bf16_t* ch = c->cls_h + (size_t)pass_begin * Hd;
-            RC(attn_cls_fwd_launch(c->qkv[l] + r0 * 3 * D, c->qkvT[l] + r0, c->rows, Bp, c->T, c->Tld, D, v->heads, 0.125f, cattn,
+            RC(attn_cls_fwd_launch(c->qkv[l] + r0 * 3 * D, c->qkvT_last + r0, c->rows, Bp, c->T, c->Tld, D, v->heads, 0.125f, cattn,
                                    c->cls_probs + (size_t)pass_begin * v->heads * c->Tld, s));
             // The GEMMs of this tail have M = passes rows: their run time is the serial K walk of a workgroup, not the rows, so
             // they run split-K over many workgroups (plain fp32 slabs) and the next kernel of the chain sums the slabs.
@@ -477,7 +484,7 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
         }
         {
             AttnArgs a = {};
-            a.qkv = c->qkv[l] + r0 * 3 * D; a.qkvT = c->qkvT[l] + r0; a.ldt = c->rows; a.B = Bp; a.T = c->T; a.Tld = c->Tld; a.D = D; a.H = v->heads;
+            a.qkv = c->qkv[l] + r0 * 3 * D; a.B = Bp; a.T = c->T; a.Tld = c->Tld; a.D = D; a.H = v->heads;
             a.scale = 0.125f; a.out = c->attn_out[l] + r0 * D; a.lse = c->lse[l] + (size_t)pass_begin * v->heads * c->Tld;
             if (fp8_attn) { a.qkv8 = c->qkv8 + r0 * 3 * D; a.qkvT8 = c->qkvT8 + r0; a.ldt8 = c->rows; }
             SpliceProfScope ps(3);
@@ -541,7 +548,7 @@ int splice_vit_get_tensor(void* ctx, int kind, int layer, void** out) {
         case 3: *out = c->qkv_last_f32; break;
         case 4: *out = c->lse[layer]; break;
         case 5: *out = c->xs[0]; break;
-        case 6: *out = c->qkvT[layer]; break;
+        case 6: if (layer != c->vit->depth - 1) return SPLICE_ERR_ARG; *out = c->qkvT_last; break;   // only the last layer keeps a transposed copy
         default: return SPLICE_ERR_ARG;
     }
     return SPLICE_OK;
@@ -620,7 +627,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
                 GemmEpi e = {};
                 e.out_f32 = slabs; e.ldo = D; e.ksplit = ks_of(D); e.slab_stride = (long long)sstr;
                 RC(gemm_nt_launch(EPI_OUT_F32, g_bf, rs, W.proj.wT, D, Bp, D, D, e, s));
-                RC(attn_cls_bwd_launch(c->qkv[l] + r0 * 3 * D, c->qkvT[l] + r0, c->rows, Bp, c->T, c->Tld, D, v->heads, 0.125f,
+                RC(attn_cls_bwd_launch(c->qkv[l] + r0 * 3 * D, c->qkvT_last + r0, c->rows, Bp, c->T, c->Tld, D, v->heads, 0.125f,
                                        c->cls_probs + (size_t)pass_begin * v->heads * c->Tld, slabs, e.ksplit, sstr, dqkv, s));
             }
             g_after_mlp = g;
@@ -641,20 +648,18 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
             // attention branch
             {
                 GemmEpi e = {};
-                e.out_bf = c->dout + r0 * D; e.ldbf = D; e.out_bf_t = c->doutT; e.ldt = c->rows;
-                // transposed output is addressed by GEMM row index (0..R) -> shift the base so column = global row
-                e.out_bf_t = c->doutT + r0;
+                e.out_bf = c->dout + r0 * D; e.ldbf = D;   // (no transposed copy: the attention backward reads dO^T out of the dO tile)
                 // delta = rowsum(dO * O) per (pass, head, query) for the attention backward, formed where dO is produced
                 e.rd_other = c->attn_out[l] + r0 * D; e.ld_rd = D; e.rd_rows = c->Tld;
                 e.rowdot = c->delta + (size_t)pass_begin * v->heads * c->Tld;
-                RC(gemm_nt_launch(EPI_OUT_BF | EPI_OUT_T | EPI_ROWDOT, g_bf, D, W.proj.wT, D, R, D, D, e, s));
+                RC(gemm_nt_launch(EPI_OUT_BF | EPI_ROWDOT, g_bf, D, W.proj.wT, D, R, D, D, e, s));
             }
             {
                 AttnArgs a = {};
-                a.qkv = c->qkv[l] + r0 * 3 * D; a.qkvT = c->qkvT[l] + r0; a.ldt = c->rows; a.B = Bp; a.T = c->T; a.Tld = c->Tld;
+                a.qkv = c->qkv[l] + r0 * 3 * D; a.B = Bp; a.T = c->T; a.Tld = c->Tld;
                 a.D = D; a.H = v->heads; a.scale = 0.125f; a.out = c->attn_out[l] + r0 * D;
                 a.lse = c->lse[l] + (size_t)pass_begin * v->heads * c->Tld;
-                a.dout = c->dout + r0 * D; a.doutT = c->doutT + r0; a.delta = c->delta + (size_t)pass_begin * v->heads * c->Tld; a.delta_ready = 1; a.dqkv = dqkv;
+                a.dout = c->dout + r0 * D; a.doutT = nullptr; a.delta = c->delta + (size_t)pass_begin * v->heads * c->Tld; a.delta_ready = 1; a.dqkv = dqkv;
                 SpliceProfScope ps(6);
                 RC(attn_bwd_launch(&a, s));
             }
