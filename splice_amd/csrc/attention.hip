@@ -753,6 +753,10 @@ __device__ __forceinline__ float dot8bf(const u32x4& x, const u32x4& y) {
 }
 
 constexpr int Q_STAGE = 2 * 4096;   // bf16 elements per ring stage of the dQ half: K and V token tiles
+// (Measured and not kept, round 3: a two-wave-group form of both halves -- the tile range split over two groups of 4 waves, partial
+// sums added through LDS, as in the forward: 27.0 against 25.0 us at one pass of T = 785, 100 against 88 us at eight, equal at
+// T = 3137 -- with 33 KB of LDS the one-group workgroups already sit four to a CU; and one loop over all tiles with the partial
+// tile peeled behind it instead of in front: the same at one pair, +1.2 % step time at eight.)
 __device__ __forceinline__ void attn_bwd_q_body(const AttnArgs& a, int xb, int h, int b, bf16_t* smem /* [stage][K | V] */) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
