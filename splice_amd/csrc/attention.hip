@@ -756,7 +756,9 @@ constexpr int Q_STAGE = 2 * 4096;   // bf16 elements per ring stage of the dQ ha
 // (Measured and not kept, round 3: a two-wave-group form of both halves -- the tile range split over two groups of 4 waves, partial
 // sums added through LDS, as in the forward: 27.0 against 25.0 us at one pass of T = 785, 100 against 88 us at eight, equal at
 // T = 3137 -- with 33 KB of LDS the one-group workgroups already sit four to a CU; and one loop over all tiles with the partial
-// tile peeled behind it instead of in front: the same at one pair, +1.2 % step time at eight.)
+// tile peeled behind it instead of in front: the same at one pair, +1.2 % step time at eight; a 3-stage ring (two tiles in flight,
+// asm-issued DMA, counted waits) for the merged launch: +1.7 % step time at one pair, +1.3 % at two -- the one-pass launches are
+// not waiting on the tile feed.)
 __device__ __forceinline__ void attn_bwd_q_body(const AttnArgs& a, int xb, int h, int b, bf16_t* smem /* [stage][K | V] */) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
