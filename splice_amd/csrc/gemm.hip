@@ -18,7 +18,10 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
         // otherwise the biggest tile that still yields ~2 workgroups per CU (M = 1600: 128x64 beats 128x128 by 10 %, M = 800: 64x64)
         static const int t2min = getenv("SPLICE_GEMM_T2MIN") ? atoi(getenv("SPLICE_GEMM_T2MIN")) : 400;
         static const int t2ring = getenv("SPLICE_GEMM_T2RING") ? atoi(getenv("SPLICE_GEMM_T2RING")) : 3;
-        static const int t1min = getenv("SPLICE_GEMM_T1MIN") ? atoi(getenv("SPLICE_GEMM_T1MIN")) : 420;
+        // (t1min 420 -> 230 at the end of round 3: with the QKV epilogue down to one output the one-pair forward GEMMs of QKV / fc1
+        // (234 / 312 tiles of 128 x 128 at 1600 rows) beat their 128 x 64 ring form: -1.9 % step time at one pair, -0.6 % at two,
+        // unchanged at eight; profiles/r03_gemm_t1min_sweep.txt)
+        static const int t1min = getenv("SPLICE_GEMM_T1MIN") ? atoi(getenv("SPLICE_GEMM_T1MIN")) : 230;
         // rows of a P-pair batch (tools/gemm_sweep.py, r2): with N <= 768 the 64x64 tile stops winning at ~4800 rows (fc2 at
         // M = 6400: 688 TF on 128x64 vs 554; M = 12800: 872 vs 656); N >= 2304 takes 128x128 from 3200 rows on (t1min 640 -> 420)
         // (in-step at 2 / 3 / 4 pairs per GPU -- 3200 ... 6400 rows -- the 128x64 tile already wins from the first row count without

@@ -188,11 +188,11 @@ def test_attention_fwd_bwd(B, T, D, H, std):
     rows = B * Tld
     scale = (D // H) ** -0.5
     qkv = _bf(_rand(rows, 3 * D, seed=20, std=std))
-    qkvT = qkv.T.contiguous()
+    qkvT = None   # the transposed copies are not read any more (transposing LDS reads): the ABI allows NULL / 0 for them
     out = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
     lse = torch.zeros(B, H, Tld, device=DEV)
     L = _lib.lib()
-    _lib.check(L.splice_attention_fwd(_lib.ptr(qkv), _lib.ptr(qkvT), rows, B, T, Tld, D, H, scale, _lib.ptr(out),
+    _lib.check(L.splice_attention_fwd(_lib.ptr(qkv), _lib.ptr(qkvT), 0, B, T, Tld, D, H, scale, _lib.ptr(out),
                                       _lib.ptr(lse), _st()))
     torch.cuda.synchronize()
     ref, leaf, p = _attn_ref(qkv, B, T, Tld, D, H, scale)
@@ -217,10 +217,10 @@ def test_attention_fwd_bwd(B, T, D, H, std):
     dout = _rand(B, Tld, D, seed=21)
     dout[:, T:] = 0
     dout = _bf(dout.reshape(rows, D))
-    doutT = dout.T.contiguous()
+    doutT = None
     delta = torch.zeros(B, H, Tld, device=DEV)
     dqkv = torch.zeros(rows, 3 * D, device=DEV, dtype=torch.bfloat16)
-    _lib.check(L.splice_attention_bwd(_lib.ptr(qkv), _lib.ptr(qkvT), rows, B, T, Tld, D, H, scale, _lib.ptr(out),
+    _lib.check(L.splice_attention_bwd(_lib.ptr(qkv), _lib.ptr(qkvT), 0, B, T, Tld, D, H, scale, _lib.ptr(out),
                                       _lib.ptr(lse), _lib.ptr(dout), _lib.ptr(doutT), _lib.ptr(delta), _lib.ptr(dqkv), _st()))
     torch.cuda.synchronize()
     ref.backward(dout.float().reshape(B, Tld, D)[:, :T])

@@ -51,11 +51,11 @@ for (B, T) in shapes:
     scale = (D // H) ** -0.5
     g = torch.Generator(device="cpu").manual_seed(5)
     qkv = (torch.randn(rows, 3 * D, generator=g) * std).to(DEV).bfloat16()
-    qkvT = qkv.T.contiguous()
+    qkvT = None   # (not read any more)
     dout = torch.randn(B, Tld, D, generator=g)
     dout[:, T:] = 0
     dout = dout.reshape(rows, D).to(DEV).bfloat16()
-    doutT = dout.T.contiguous()
+    doutT = None
     ref = gref = None
     if T < 1000:
         ref, leaf = ref_attention(qkv, B, T, Tld, D, H, scale)
