@@ -16,7 +16,7 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
     else {
         // measured on MI355X (tools/gemm_bench.py): with N <= 768 the 64x64 tile wins (more workgroups on the long-K shapes);
         // otherwise the biggest tile that still yields ~2 workgroups per CU (M = 1600: 128x64 beats 128x128 by 10 %, M = 800: 64x64)
-        static const int t2min = getenv("SPLICE_GEMM_T2MIN") ? atoi(getenv("SPLICE_GEMM_T2MIN")) : 400;
+        static const int t2min = getenv("SPLICE_GEMM_T2MIN") ? atoi(getenv("SPLICE_GEMM_T2MIN")) : 300;   // (400 -> 300, end of round 3: -0.4 % step time at one pair, equal at two / eight; profiles/r03_gemm_t1min_sweep.txt)
         static const int t2ring = getenv("SPLICE_GEMM_T2RING") ? atoi(getenv("SPLICE_GEMM_T2RING")) : 3;
         // (t1min 420 -> 230 at the end of round 3: with the QKV epilogue down to one output the one-pair forward GEMMs of QKV / fc1
         // (234 / 312 tiles of 128 x 128 at 1600 rows) beat their 128 x 64 ring form: -1.9 % step time at one pair, -0.6 % at two,
