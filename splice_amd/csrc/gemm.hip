@@ -105,11 +105,13 @@ static int dispatch_fp8(const uint8_t* A, int lda, const uint8_t* B, int ldb, in
     const bf16_t* a = reinterpret_cast<const bf16_t*>(A);
     const bf16_t* b = reinterpret_cast<const bf16_t*>(B);
     const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t12864 = (long)cdiv(M, 128) * cdiv(N, 64);
+    static const int t1min8 = getenv("SPLICE_GEMM8_T1MIN") ? atoi(getenv("SPLICE_GEMM8_T1MIN")) : 230;   // (as the bf16 dispatcher: -1.3 % step time at one pair; profiles/r03_gemm_t1min_sweep.txt)
+    static const int t2min8 = getenv("SPLICE_GEMM8_T2MIN") ? atoi(getenv("SPLICE_GEMM8_T2MIN")) : 300;
     if (N <= 768) {   // fc2: as the bf16 dispatcher -- 64x64 tiles on the deep ring for the few-row shapes, 128x64 from the batched row counts on
         if (M >= 2401) launch_gemm_nt<128, 64, FLAGS, 2, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
         else launch_gemm_nt<64, 64, FLAGS, 4, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
-    } else if (t128 >= 420) launch_gemm_nt<128, 128, FLAGS, 2, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
-    else if (t12864 >= 400) launch_gemm_nt<128, 64, FLAGS, 3, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
+    } else if (t128 >= t1min8) launch_gemm_nt<128, 128, FLAGS, 2, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
+    else if (t12864 >= t2min8) launch_gemm_nt<128, 64, FLAGS, 3, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
     else launch_gemm_nt<64, 64, FLAGS, 3, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
     return SPLICE_OK;
 }
