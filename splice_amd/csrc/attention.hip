@@ -990,22 +990,25 @@ __global__ void attn_probs_kernel(AttnArgs a, float* probs) {
 }
 
 // ---------------------------------------------------------------------------------------
-static int g_attn_variant = 0;   // benchmarking hook (splice_attention_variant): forward queries per wave 16*v, 0 = automatic
+static int g_attn_variant = getenv("SPLICE_ATTN_FWD_VARIANT") ? atoi(getenv("SPLICE_ATTN_FWD_VARIANT")) : 0;   // benchmarking hook (splice_attention_variant): forward queries per wave 16*v, 0 = automatic
 void attn_set_variant(int v) { g_attn_variant = v; }
 
 int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
     if (a->Tld % 32 || a->D % 64 || a->D / 64 != a->H) return SPLICE_ERR_ARG;
-    // Launch form (measured, tools/attn_bench.py at 2 / 8 / 16 passes of T = 785 and 2 passes of T = 3137, profiles/r03_attn_forms.txt):
+    // Launch form.  Stand-alone (tools/attn_bench.py at 2 / 8 / 16 passes of T = 785 and 2 passes of T = 3137, profiles/r03_attn_forms.txt)
     // 16 queries per wave and TWO wave groups per workgroup (key-range halves side by side) is the fastest form at every batch
     // size -- 13.4 / 31.6 / 60.9 us against 15.8 / 34.2 / 66.2 for one group walking both halves -- except where its 8-wave,
-    // 64 KB workgroups just miss one round of the chip (two fit a CU: 513 .. 768 workgroups, e.g. two pairs per GPU), where the
-    // one-group form runs (three 4-wave workgroups per CU).  Both forms, and 32 queries per wave (very long batches), produce
-    // the same bits.  variant (benchmarking hook): queries per wave / 16 + 10 * (wave groups - 1); 0 = automatic.
+    // 64 KB workgroups just miss one round of the chip.  All forms, and 32 queries per wave (very long batches), produce
+    // the same bits, so the choice is free.  variant (benchmarking hook / SPLICE_ATTN_FWD_VARIANT): queries per wave / 16 + 10 * (wave groups - 1); 0 = automatic.
     const long tasks = (long)a->B * a->H * cdiv(a->Tld, 16);
     static const long qb2_tasks = getenv("SPLICE_ATTN_QB2_TASKS") ? atol(getenv("SPLICE_ATTN_QB2_TASKS")) : 60000;
     const int qb = g_attn_variant ? g_attn_variant % 10 : (tasks > qb2_tasks ? 2 : 1);
     const long wgs = (long)cdiv(a->Tld, 64 * qb) * a->H * a->B;
-    const int ks = g_attn_variant ? g_attn_variant / 10 + 1 : ((wgs > 512 && wgs <= 768) ? 1 : 2);
+    // (end of round 3, measured IN the step, where the other stream's kernels share the chip: once the launch fills the chip -- more
+    // than 512 workgroups -- one wave group per workgroup wins while the key walk is short (T = 785: -0.6 % step time at 4 / 8 pairs
+    // per GPU) and two groups keep winning on long walks (T = 3137: +0.5 % for one group); profiles/r03_attn_fwd_forms_in_step.txt)
+    static const long ks1_from = getenv("SPLICE_ATTN_KS1_FROM") ? atol(getenv("SPLICE_ATTN_KS1_FROM")) : 512;
+    const int ks = g_attn_variant ? g_attn_variant / 10 + 1 : ((wgs > ks1_from && a->T <= 2048) ? 1 : 2);
     const int nx = cdiv(a->Tld, 64 * qb);
     const dim3 grid(nx * a->H * a->B);
     if (a->qkv8) {   // e4m3 forward
