@@ -11,8 +11,8 @@ Same names, argument order and return conventions: ``attn_cosine_sim(x, eps)``, 
 * weights come from a local DINO checkpoint (``checkpoint=`` / ``state_dict=`` / env
   ``SPLICE_DINO_CHECKPOINT``) -- there is no network here; ``synthetic=True`` (or env
   ``SPLICE_SYNTHETIC_WEIGHTS=1``) draws the seeded DINO-shaped weights used by the benchmark;
-* attention probabilities (``get_attn_feature_from_input``) are materialised on request only
-  and do not carry gradients (nothing in the reference differentiates through them).
+* attention probabilities (``get_attn_feature_from_input``) are materialised on request only; they carry
+  gradients w.r.t. the input image like the hooked tensors (``models/extractor.py:97-103``).
 """
 import ctypes as C
 import os

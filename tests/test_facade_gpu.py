@@ -212,3 +212,75 @@ def test_attn_probabilities_carry_grad():
     assert rel < 6e-2 and cos > 0.995
     with torch.no_grad():                       # no graph, no saved context
         assert not ext.get_attn_feature_from_input(x0.to(DEV))[0].requires_grad
+
+
+def test_notebook_cell_runs_unchanged_after_dropin(tmp_path):
+    """Splice.ipynb cell 8, verbatim (`from train import train_model; train_model(DATAROOT, show_result)`), plus the reference-shaped
+    loop of train.py:34-80 written with the reference's OWN import lines, after the one added line `import splice_amd.dropin`
+    (VERDICT r3 #1).  Child interpreter: the aliases must not leak into this session.  The working directory holds a
+    conf/default/config.yaml, as a checkout of the reference does."""
+    import subprocess
+    import sys
+    import yaml
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    A, B = synth.smooth_image_pair(50, 0, 64, 64)
+    for name, img in (("A", A), ("B", B)):
+        d = tmp_path / "pair" / name
+        d.mkdir(parents=True)
+        Image.fromarray((img.transpose(1, 2, 0) * 255).astype(np.uint8)).save(d / "img.png")
+    cfg = yaml.safe_load(open(os.path.join(root, "splice_amd", "conf", "default", "config.yaml")))
+    cfg.update(seed=3, n_epochs=12, dino_model_name="dino_vits8", dino_global_patch_size=64, log_images_freq=6, use_augmentations=False)
+    (tmp_path / "conf" / "default").mkdir(parents=True)
+    (tmp_path / "conf" / "default" / "config.yaml").write_text(yaml.safe_dump(cfg))
+    code = f'''
+import splice_amd.dropin
+DATAROOT = {str(tmp_path / "pair")!r}
+seen = []
+def show_result(img):
+    seen.append(tuple(img.shape))
+from train import train_model
+train_model(DATAROOT, show_result)
+assert seen == [(3, 64, 64)] * 2, seen
+
+# train.py:4-7 / 34-80 with the reference's import lines
+import torch, yaml
+from data.Dataset import SingleImageDataset
+from models.model import Model
+from util.losses import LossG
+from util.util import get_scheduler, get_optimizer, save_result
+cfg = yaml.safe_load(open("conf/default/config.yaml")); cfg["dataroot"] = DATAROOT
+device = torch.device("cuda")
+dataset = SingleImageDataset(cfg)
+model = Model(cfg)
+criterion = LossG(cfg)
+optimizer = get_optimizer(cfg, model.netG.parameters())
+scheduler = get_scheduler(optimizer, lr_policy=cfg["scheduler_policy"], n_epochs=cfg["n_epochs"],
+                          n_epochs_decay=cfg["scheduler_n_epochs_decay"], lr_decay_iters=cfg["scheduler_lr_decay_iters"])
+first = last = None
+for epoch in range(1, 5):
+    inputs = dataset[0]
+    for key in inputs:
+        inputs[key] = inputs[key].to(device)
+    optimizer.zero_grad()
+    outputs = model(inputs)
+    losses = criterion(outputs, inputs)
+    loss_G = losses["loss"]
+    v = loss_G.item()
+    first = v if first is None else first
+    last = v
+    if epoch % 2 == 0:
+        with torch.no_grad():
+            output = model.netG(dataset.get_A().to(device))
+        save_result(output[0], cfg["dataroot"])
+    loss_G.backward()
+    optimizer.step()
+    scheduler.step()
+import math
+assert math.isfinite(first) and math.isfinite(last)
+print("ok")
+'''
+    env = dict(os.environ, PYTHONPATH=root, SPLICE_SYNTHETIC_WEIGHTS="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-1500:], r.stderr[-3000:])
+    assert (tmp_path / "pair" / "out" / "output.png").exists()
