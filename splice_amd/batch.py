@@ -1,12 +1,16 @@
-"""Many pairs on one node: a directory of K structure/appearance pairs -> a queue over N GPUs.
+"""Many pairs on one node: a directory of K structure/appearance pairs -> a pull queue over N GPUs.
 
 The reference optimises one pair per process invocation (``train.py:34-49,83-89``: one ``--dataroot`` with ``A/`` and
 ``B/``); K pairs are K independent runs.  Pairs share nothing but the frozen ViT weights, so the
-node-level driver is embarrassingly parallel: pair *i* goes to GPU *i mod N*, one worker PROCESS per GPU (its own HIP
-context, pinned with ``HIP_VISIBLE_DEVICES``), each worker walks its pairs in index order, no collective, no shared
-state.  The result of a pair therefore does not depend on N: ``run_batch(root, 1)`` and ``run_batch(root, 8)`` write
-bit-identical outputs (tests/test_batch_cpu.py pins that with a stub runner on CPU workers, tests/test_batch_gpu.py
-with the real engine on one GPU).
+node-level driver is embarrassingly parallel: one worker PROCESS per GPU (its own HIP context, pinned with
+``HIP_VISIBLE_DEVICES``), no collective, no shared state but ONE integer -- the head of the work list.  The work list is built
+once, by the parent, from the whole directory (``work_items``: groups of equal-size pairs when ``pairs_per_gpu`` > 1, then the
+single pairs; largest images first) and every worker PULLS the next item when it is free (round 4; rounds 1-3 assigned pair
+*i* to GPU *i mod N* statically, so one slow pair -- a 448 px image among 224 px ones -- left its GPU's other pairs waiting while the
+rest of the node idled).  The result of a pair does not depend on N, nor on which worker ran it, nor on the order: every run
+re-seeds from its config, and the grouping is a function of the directory, not of the workers.  ``run_batch(root, 1)`` and
+``run_batch(root, 8)`` write bit-identical outputs (tests/test_batch_cpu.py pins that with stub runners on CPU workers, with
+skewed run times; tests/test_batch_gpu.py with the real engine on one GPU).
 
 Layout::
 
@@ -15,7 +19,7 @@ Layout::
     root/<pair name>/out/output.png written by the run
     root/<pair name>/out/result.json {"pair", "gpu", "steps", "loss", "seconds", ...}
 
-    python -m splice_amd.batch --root pairs/ --gpus 8 [--n_epochs 2000] [--set key=value ...]
+    python -m splice_amd.batch --root pairs/ --gpus 8 [--pairs-per-gpu P] [--n_epochs 2000] [--set key=value ...]
 """
 import importlib
 import json
@@ -36,8 +40,23 @@ def discover_pairs(root):
 
 
 def assignment(n_pairs, n_gpus):
-    """pair index -> GPU: ``i mod n_gpus``; returned as one index list per GPU."""
+    """Static form ``i mod n_gpus`` of SURVEY.md section 8e, one index list per GPU -- what ``bench.py --gpus N`` uses for its
+    synthetic pairs (equal work per pair: nothing to balance).  ``run_batch`` uses the pull queue over ``work_items`` instead."""
     return [list(range(g, n_pairs, n_gpus)) for g in range(n_gpus)]
+
+
+def work_items(sizes, pairs_per_gpu=1):
+    """The node's work list: a list of index lists (a group of 2 .. ``pairs_per_gpu`` equal-size pairs that ride in the same
+    launches, or one pair), a function of the directory only.  Order = pull order: most expensive first (pixels of both images
+    x pairs of the item: longest-processing-time-first keeps the tail of the queue short), ties by first pair index."""
+    idx = list(range(len(sizes)))
+    groups, singles = group_equal_sizes(idx, sizes, pairs_per_gpu) if int(pairs_per_gpu) > 1 else ([], idx)
+    items = groups + [[i] for i in singles]
+
+    def cost(item):
+        (aw, ah), (bw, bh) = sizes[item[0]]
+        return (aw * ah + bw * bh) * len(item)
+    return sorted(items, key=lambda it: (-cost(it), it[0]))
 
 
 def train_runner(pair_dir, overrides):
@@ -102,36 +121,48 @@ def _write_result(root, name, res):
     os.replace(tmp, os.path.join(pair_dir, "out", "result.json"))
 
 
-def _worker(gpu, visible_id, root, names, indices, runner, overrides, pin_gpu, pairs_per_gpu=1, group_runner="splice_amd.batch:train_group_runner"):
+def _worker(gpu, visible_id, root, names, items, head, current, runner, overrides, pin_gpu, group_runner="splice_amd.batch:train_group_runner"):
     if pin_gpu:   # must happen before the HIP runtime starts in this process
         os.environ["HIP_VISIBLE_DEVICES"] = str(visible_id)
         os.environ.pop("CUDA_VISIBLE_DEVICES", None)
-    groups, todo = group_equal_sizes(indices, [_image_sizes(os.path.join(root, names[i])) for i in indices], pairs_per_gpu) if pairs_per_gpu > 1 else ([], list(indices))
-    run_group = _resolve(group_runner)
-    for grp in groups:   # one MultiPairEngine per group
-        for i, res in zip(grp, run_group([os.path.join(root, names[i]) for i in grp], dict(overrides))):
+    run, run_group = None, None
+    while True:
+        with head.get_lock():             # the one shared word: index of the next unclaimed work item
+            k = head.value
+            head.value = k + 1
+        if k >= len(items):
+            break
+        current[gpu] = k                  # (the parent names the item a dead worker was running)
+        item = items[k]
+        if len(item) > 1:                 # one MultiPairEngine for the group
+            run_group = run_group or _resolve(group_runner)
+            for i, res in zip(item, run_group([os.path.join(root, names[i]) for i in item], dict(overrides))):
+                _write_result(root, names[i], dict(res, pair=names[i], index=i, gpu=gpu))
+        else:
+            run = run or _resolve(runner)
+            i = item[0]
+            res = dict(run(os.path.join(root, names[i]), dict(overrides)) or {})
             _write_result(root, names[i], dict(res, pair=names[i], index=i, gpu=gpu))
-    run = _resolve(runner)
-    for i in todo:
-        res = dict(run(os.path.join(root, names[i]), dict(overrides)) or {})
-        _write_result(root, names[i], dict(res, pair=names[i], index=i, gpu=gpu))
+        current[gpu] = -1
 
 
 def run_batch(root, n_gpus=1, overrides=None, runner="splice_amd.batch:train_runner", pin_gpu=True, visible_ids=None, pairs_per_gpu=1,
-              group_runner=None):
+              group_runner=None, sizes=None):
     """Optimise every pair under ``root`` on ``n_gpus`` worker processes; returns the per-pair result dicts in pair order.
 
     ``runner``: ``"module:function"`` (or a picklable callable) ``(pair_dir, overrides) -> dict``; the default trains the
-    pair.  ``pairs_per_gpu`` > 1: a worker optimises up to that many of ITS pairs in the same launches (pairs of equal image
-    sizes only; 1.6x the pairs/hr of one pair at a time at 8 pairs per GPU) through ``group_runner``
-    ``(pair_dirs, overrides) -> [dict per pair]`` (default: ``train_group_runner`` = ``train_pairs``); pairs that fill no group
-    go through ``runner``.  A custom ``runner`` without a matching ``group_runner`` is rejected when ``pairs_per_gpu`` > 1 --
-    grouped pairs would otherwise silently run the default training.  Two things differ from K single runs in a group: the
-    pairs of a group share one crop SIZE per step (``PairBatchFeed``: positions and augmentations stay per pair), so under
-    random crops a pair's RNG stream is not the one of its single run (with deterministic full crops the results are
-    bit-identical, tests/test_batch_gpu.py); and "the result does not depend on N" holds for the grouping, which is per worker.
+    pair.  ``pairs_per_gpu`` > 1: up to that many pairs of equal image sizes are optimised in the same launches (1.6x the
+    pairs/hr of one pair at a time at 8 pairs per GPU) through ``group_runner`` ``(pair_dirs, overrides) -> [dict per pair]``
+    (default: ``train_group_runner`` = ``train_pairs``); pairs that fill no group go through ``runner``.  A custom ``runner``
+    without a matching ``group_runner`` is rejected when ``pairs_per_gpu`` > 1 -- grouped pairs would otherwise silently run the
+    default training.  The groups are formed over the WHOLE directory (``work_items``), so they do not depend on ``n_gpus``.
+    One thing differs from K single runs in a group: its pairs share one crop SIZE per step (``PairBatchFeed``: positions and
+    augmentations stay per pair), so under random crops a pair's RNG stream is not the one of its single run (with deterministic
+    full crops the results are bit-identical, tests/test_batch_gpu.py).
+    ``sizes``: per pair ``((A_w, A_h), (B_w, B_h))`` if already known (default: read from the image headers).
     ``pin_gpu=False`` leaves device visibility alone (CPU tests).  A worker that dies takes the batch down with a RuntimeError
-    naming its pairs; finished pairs keep their ``result.json``."""
+    naming the pairs it was running and the pairs left undone; the other workers drain the rest of the queue first, and
+    finished pairs keep their ``result.json``."""
     import multiprocessing as mp
     if int(pairs_per_gpu) > 1 and group_runner is None:
         if runner != "splice_amd.batch:train_runner":
@@ -141,15 +172,31 @@ def run_batch(root, n_gpus=1, overrides=None, runner="splice_amd.batch:train_run
     names = discover_pairs(root)
     if not names:
         raise ValueError(f"{root}: no <pair>/A + <pair>/B directories found")
-    n_gpus = max(1, min(int(n_gpus), len(names)))
-    plan = assignment(len(names), n_gpus)
+    if len((overrides or {}).get("dino_global_scales") or []) > 1 and int(pairs_per_gpu) > 1:
+        raise ValueError("run_batch: dino_global_scales with several entries is a single-pair option; use pairs_per_gpu=1")
+    if sizes is None:
+        try:
+            sizes = [_image_sizes(os.path.join(root, n)) for n in names]
+        except Exception:
+            if int(pairs_per_gpu) > 1:
+                raise
+            sizes = [((0, 0), (0, 0))] * len(names)    # not images (stub runners): index order, one pair per item
+    items = work_items(sizes, pairs_per_gpu)
+    n_gpus = max(1, min(int(n_gpus), len(items)))
     if visible_ids is None:
         parent = os.environ.get("HIP_VISIBLE_DEVICES")
         visible_ids = parent.split(",") if parent else [str(g) for g in range(n_gpus)]
     if pin_gpu and len(visible_ids) < n_gpus:
         raise ValueError(f"run_batch: {n_gpus} workers requested, {len(visible_ids)} visible GPUs")
+    for name in names:                      # a stale result of an earlier batch must not pass for this one's
+        try:
+            os.remove(os.path.join(root, name, "out", "result.json"))
+        except OSError:
+            pass
     ctx = mp.get_context("spawn")   # fresh interpreters: the HIP runtime must not be inherited through fork
-    procs = [ctx.Process(target=_worker, args=(g, visible_ids[g] if pin_gpu else g, root, names, plan[g], runner, dict(overrides or {}), pin_gpu, int(pairs_per_gpu), group_runner))
+    head = ctx.Value("i", 0)
+    current = ctx.Array("i", [-1] * n_gpus)
+    procs = [ctx.Process(target=_worker, args=(g, visible_ids[g] if pin_gpu else g, root, names, items, head, current, runner, dict(overrides or {}), pin_gpu, group_runner))
              for g in range(n_gpus)]
     for p in procs:
         p.start()
@@ -157,7 +204,10 @@ def run_batch(root, n_gpus=1, overrides=None, runner="splice_amd.batch:train_run
         p.join()
     failed = [g for g, p in enumerate(procs) if p.exitcode != 0]
     if failed:
-        raise RuntimeError("run_batch: worker(s) failed: " + "; ".join(f"gpu {g} (pairs {[names[i] for i in plan[g]]}, exit {procs[g].exitcode})" for g in failed))
+        undone = [n for n in names if not os.path.exists(os.path.join(root, n, "out", "result.json"))]
+        raise RuntimeError("run_batch: worker(s) failed: " + "; ".join(
+            f"gpu {g} (exit {procs[g].exitcode}) while running {[names[i] for i in items[current[g]]] if current[g] >= 0 else []}" for g in failed)
+            + f"; pairs without a result: {undone}")
     out = []
     for name in names:
         with open(os.path.join(root, name, "out", "result.json")) as f:
@@ -173,7 +223,7 @@ def _parse_value(text):
 
 
 def main(argv=None):
-    ap = ArgumentParser(description="Optimise a directory of Splice pairs over the GPUs of one node (pair i -> GPU i mod N).")
+    ap = ArgumentParser(description="Optimise a directory of Splice pairs over the GPUs of one node (one worker per GPU pulling from one work list).")
     ap.add_argument("--root", required=True, help="directory of <pair>/A, <pair>/B sub-directories")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--pairs-per-gpu", type=int, default=1, help="pairs of equal image sizes optimised in the same launches on a GPU")

@@ -114,6 +114,7 @@ struct SpliceStep {
     float* grads_b = nullptr;                        // gradient arena(s) of the B-crop plan (added to `grads` inside Adam)
     hipEvent_t ev_gb = nullptr;                      // G(B_crop) finished on the side stream
     int shape_repeats = 0;                           // consecutive steps with the same arenas and crop sizes
+    int repeat_step = -1;                            // step_idx the count above was last advanced / reset for (several partial-phase calls of ONE step count once)
     int use_graph = 1;
     int dbg_sync = 0, dbg_own_eager = 0;
     int ssim_id_on = 0;          // lambda_global_ssim / lambda_global_identity switched on (util/losses.py:35-37)
@@ -656,8 +657,13 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
             memcpy(st->graph_ptrs, ptrs, sizeof(ptrs));
             memcpy(st->graph_crops, crops, sizeof(crops));
             st->shape_repeats = 0;
-        } else if (st->shape_repeats < 2) {
-            ++st->shape_repeats;
+            st->repeat_step = step_idx;
+        } else if (step_idx != st->repeat_step) {
+            // a step split into several calls (splice_step_set_phases: MultiScaleEngine runs phases 1|2, then 4, with identical
+            // pointers and crop sizes) is ONE step: its later calls inherit the first call's eager / graph decision instead
+            // of looking like a repeat and capturing a graph that the next step's new crop sizes drop again
+            if (st->shape_repeats < 2) ++st->shape_repeats;
+            st->repeat_step = step_idx;
         }
     }
     const bool graph = st->use_graph && !splice_prof_active() && st->shape_repeats >= 1;

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib, synth
 from .generator import GeneratorEngine, GeneratorPlan
-from .vit import VitContext, VitEngine
+from .vit import VitContext, VitEngine, fp8_mode
 
 LOSS_KEYS = ["loss", "loss_global_ssim", "loss_entire_ssim", "loss_entire_cls", "loss_global_cls", "loss_global_id_B"]
 
@@ -67,10 +67,11 @@ class MultiPairEngine:
         self.device = torch.device(device)
         self.P = P = len(gen_states)
         self.vit = vit_engine or VitEngine(c["dino_model_name"], device=device).load_state_dict(vit_state)
-        # fp8=True (BASELINE configs[4]): the QKV, fc1 and fc2 forward projections (e4m3, block-scaled K = 128 MFMA), the attention
-        # forward (Q K^T and P V on the fp8 MFMA) and the key self-similarity Gram matrices; proj and the whole backward stay bf16 / fp32.  The mode is a
-        # property of THIS engine's contexts: another engine sharing the frozen ViT keeps its own.  Tolerances: tests/test_fp8_gpu.py.
-        self.fp8 = fp8 if fp8 == "gemm" else bool(fp8)   # True: projections + attention forward in e4m3; "gemm": the projections only
+        # fp8 (vit.fp8_mode; BASELINE configs[4]): True / "gemm" -- the QKV, fc1 and fc2 forward projections (e4m3, block-scaled K = 128
+        # MFMA) and the key self-similarity Gram matrices; "attention" -- the attention forward (Q K^T and P V on the fp8 MFMA) too;
+        # proj and the whole backward stay bf16 / fp32.  The mode is a property of THIS engine's contexts: another engine sharing
+        # the frozen ViT keeps its own.  Tolerances: tests/test_fp8_gpu.py.
+        self.fp8 = fp8_mode(fp8)
         if self.fp8:
             self.vit.prepare_fp8()
         self.gen = GeneratorEngine(device=device)
@@ -96,8 +97,11 @@ class MultiPairEngine:
         sa, sb = (nA, nB) if self.n_crops > 1 else (P, P)
         self.slots_ab = (sa, sb)
         batch = self.n_crops > 1
-        # (the [CLS]-only mode is a property of the context: such contexts are private, never shared with the extractor API)
-        self.ctx_g = VitContext(self.vit, 2 * (sa + sb), vh, vw, True, fp8=self.fp8) if top_cls_only else self.vit.context(2 * (sa + sb), vh, vw, need_grad=True, fp8=self.fp8)
+        # A step engine's contexts are PRIVATE, never taken from the shape-keyed cache of ``VitEngine.context()``: with an identity
+        # Resize the staged inputs, the generator outputs and their gradients live in the context's image slots, and the
+        # [CLS]-only mode is a property of the context -- two engines (or an engine and the extractor API) sharing one would
+        # overwrite each other's images.
+        self.ctx_g = VitContext(self.vit, 2 * (sa + sb), vh, vw, True, fp8=self.fp8)
         arena_stride = self.stride if P > 1 else 0
         # private plan objects (the shape-keyed plan cache could hand out one plan twice)
         self.plan_a = GeneratorPlan(self.gen, sa, ch, cw, True, arena_stride, batch_stats=batch and sa > 1)
@@ -116,8 +120,7 @@ class MultiPairEngine:
         if use_entire:
             eh, ew = entire_hw
             evh, evw = resize_output_size(eh, ew, Pz, 480)
-            self.ctx_e = (VitContext(self.vit, 2 * P, evh, evw, True, fp8=self.fp8) if top_cls_only
-                          else self.vit.context(2 * P, evh, evw, need_grad=True, fp8=self.fp8))   # (P = 1 in crops mode)
+            self.ctx_e = VitContext(self.vit, 2 * P, evh, evw, True, fp8=self.fp8)   # (P = 1 in crops mode)
             self.plan_e = GeneratorPlan(self.gen, P, eh, ew, True, arena_stride)
             sc.ent_h, sc.ent_w, sc.ent_vit_h, sc.ent_vit_w = eh, ew, evh, evw
         sc.lambda_global_cls, sc.lambda_global_ssim = c["lambda_global_cls"], c["lambda_global_ssim"]

@@ -56,6 +56,21 @@ def attn_cosine_sim(x, eps=1e-08):
     return _CosineSim.apply(x[0].contiguous().float(), float(eps))[None]
 
 
+def _release_once(ctx):
+    """Hand the node's ViT context back to the extractor's pool exactly once.  A second backward through the same node
+    (``retain_graph=True``) still finds the activations in ``ctx.vctx`` -- the context simply stays out of the pool until the
+    node dies -- but must not pool it a second time (two later forwards would then share one context)."""
+    if not getattr(ctx, "released", False):
+        ctx.released = True
+        ctx.extractor._release(ctx.vctx)
+
+
+def _check_resident(ctx):
+    if ctx.vctx.generation != ctx.generation:
+        raise RuntimeError("VitExtractor: backward through features whose ViT activations were already recycled (a second backward "
+                           "with retain_graph=True after another forward of the same image size); recompute the features instead")
+
+
 class _VitFeatures(torch.autograd.Function):
     """img [1,3,H,W] (normalised) -> (blocks [L,T,D] fp32, qkv [L,T,3D] fp32)."""
 
@@ -69,7 +84,7 @@ class _VitFeatures(torch.autograd.Function):
         blocks = torch.stack([vctx.read(KIND_BLOCK, l)[0, :T] for l in range(L)])
         qkv = torch.stack([vctx.read(KIND_QKV, l)[0, :T].float() for l in range(L - 1)] +
                           [vctx.read(KIND_QKV_LAST_F32, L - 1)[0, :T]])
-        ctx.vctx, ctx.extractor, ctx.need_grad = vctx, extractor, need_grad
+        ctx.vctx, ctx.extractor, ctx.need_grad, ctx.generation = vctx, extractor, need_grad, vctx.generation
         if not need_grad:
             extractor._release(vctx)
         return blocks, qkv
@@ -79,6 +94,7 @@ class _VitFeatures(torch.autograd.Function):
         vctx, ext = ctx.vctx, ctx.extractor
         if not ctx.need_grad:
             return None, None, None
+        _check_resident(ctx)
         eng = ext.engine
         T, Tld, D, L = vctx.T, vctx.Tld, eng.dim, eng.depth
         db, dq = {}, {}
@@ -92,7 +108,7 @@ class _VitFeatures(torch.autograd.Function):
                 t[0, :T] = d_qkv[l]
                 dq[l] = t
         d_img = vctx.backward(0, 1, db or None, dq or None, None, normalize=False)
-        ext._release(vctx)
+        _release_once(ctx)
         return d_img, None, None
 
 
@@ -118,7 +134,7 @@ class _VitProbs(torch.autograd.Function):
             lse = vctx.read(KIND_LSE, l)
             _lib.check(L.splice_attention_probs(_lib.ptr(qkv), 1, T, vctx.Tld, eng.dim, eng.heads, 0.125, _lib.ptr(lse),
                                                 _lib.ptr(probs[l]), _lib.current_stream()), "attention_probs")
-        ctx.vctx, ctx.extractor, ctx.need_grad = vctx, extractor, need_grad
+        ctx.vctx, ctx.extractor, ctx.need_grad, ctx.generation = vctx, extractor, need_grad, vctx.generation
         if need_grad:
             ctx.save_for_backward(probs)
         else:
@@ -130,6 +146,7 @@ class _VitProbs(torch.autograd.Function):
         if not ctx.need_grad:
             return None, None, None
         vctx, ext = ctx.vctx, ctx.extractor
+        _check_resident(ctx)
         (probs,) = ctx.saved_tensors
         eng = ext.engine
         T, Tld, D, H = vctx.T, vctx.Tld, eng.dim, eng.heads
@@ -148,7 +165,7 @@ class _VitProbs(torch.autograd.Function):
             g[0, :T, D:2 * D] = (0.125 * torch.bmm(dS.transpose(1, 2), q)).transpose(0, 1).reshape(T, D)
             dq_all[l] = g
         d_img = vctx.backward(0, 1, None, dq_all or None, None, normalize=False) if dq_all else torch.zeros(1, 3, vctx.H, vctx.W, device=d_probs.device)
-        ext._release(vctx)
+        _release_once(ctx)
         return d_img, None, None
 
 

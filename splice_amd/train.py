@@ -30,16 +30,12 @@ _PKG_CFG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conf", "def
 
 
 def fp8_mode(cfg):
-    """Engine ``fp8`` argument of the config key ``fp8``: False -- bf16; True / ``"gemm"`` -- e4m3 operands for the QKV / fc1 / fc2
-    projections and the self-similarity Gram matrices (the fastest measured setting); ``"attention"`` / ``"all"`` -- the attention
-    forward in e4m3 as well (BASELINE configs[4] as written; measured 0.5 - 2.8 % SLOWER than ``"gemm"``, profiles/r03_fp8_attention_ab.txt)."""
-    v = cfg.get('fp8', False)
-    if isinstance(v, str):
-        v = v.strip().lower()
-        if v in ("", "false", "0", "off", "no"):
-            return False
-        return True if v in ("attention", "all") else "gemm"
-    return "gemm" if v else False
+    """Engine ``fp8`` argument of the config key ``fp8`` (one meaning everywhere: ``splice_amd.vit.fp8_mode``): False -- bf16;
+    True / ``"gemm"`` -- e4m3 operands for the QKV / fc1 / fc2 projections and the self-similarity Gram matrices (the fastest
+    measured setting); ``"attention"`` / ``"all"`` -- the attention forward in e4m3 as well (BASELINE configs[4] as written)."""
+    from .vit import fp8_mode as _mode
+    return _mode(cfg.get('fp8', False))
+
 
 def _load_image(path, resize):
     from PIL import Image
@@ -235,6 +231,9 @@ def train_pairs(dataroots, callback=None, cfg_overrides=None, vit_state=None, pr
     cfg.update(cfg_overrides or {})
     if int(cfg['global_A_crops_n_crops']) != 1 or int(cfg['global_B_crops_n_crops']) != 1:
         raise NotImplementedError("train_pairs: several pairs per step take one global crop per image (n_crops is a single-pair option)")
+    if len(cfg.get('dino_global_scales') or []) > 1:
+        raise NotImplementedError("train_pairs: dino_global_scales with several entries is a single-pair option (train_model / MultiScaleEngine); "
+                                  "grouped pairs would silently train single-scale")
     if device.type != 'cuda':
         raise RuntimeError("train_pairs needs an MI355X: the product path has no CPU fallback")
     seed = cfg['seed']
@@ -260,6 +259,8 @@ def train_pairs(dataroots, callback=None, cfg_overrides=None, vit_state=None, pr
         gen_states.append({k: v.detach().clone() for k, v in netG.state_dict().items() if k in netG.engine.table})
         del netG
     torch.manual_seed(int(seed))
+    if cfg.get('dino_global_scales'):
+        cfg['dino_global_patch_size'] = int(cfg['dino_global_scales'][0])   # one entry: the ViT input size, as in train_model
     A0, B0 = As[0], Bs[0]
     crop_max = max(min(A0.shape[1], A0.shape[2]), min(B0.shape[1], B0.shape[2]))
     engine = MultiPairEngine(cfg, vit_state, gen_states, (crop_max, crop_max), tuple(A0.shape[1:]), device=device, vit_engine=vit_engine, fp8=fp8_mode(cfg))

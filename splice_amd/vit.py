@@ -32,26 +32,45 @@ def interpolate_pos_encoding(pos_embed, patch, h_px, w_px):
     return torch.cat((pos_embed[0, :1], grid.permute(0, 2, 3, 1).reshape(-1, D)), dim=0)
 
 
+def fp8_mode(v):
+    """The ONE meaning of an ``fp8`` argument / config value, everywhere (config key, CLI, engines, contexts):
+    falsy -> ``False`` (bf16); ``True`` / ``"gemm"`` -> ``"gemm"``: e4m3 operands for the QKV / fc1 / fc2 forward projections (and,
+    in a step engine, the key self-similarity Gram matrices) -- the fastest measured setting; ``"attention"`` / ``"all"`` ->
+    ``"attention"``: the attention forward on e4m3 operands as well (BASELINE configs[4] as written; measured 0.5 - 2.8 % slower
+    than ``"gemm"``, profiles/r03_fp8_attention_ab.txt)."""
+    if isinstance(v, str):
+        v = v.strip().lower()
+        if v in ("", "false", "0", "off", "no", "none"):
+            return False
+        if v in ("attention", "all"):
+            return "attention"
+        if v in ("gemm", "true", "1", "on", "yes"):
+            return "gemm"
+        raise ValueError(f"fp8 mode {v!r}: expected False, True / 'gemm' or 'attention'")
+    return "gemm" if v else False
+
+
 class VitContext:
     """Activations of one (batch, image-shape) forward; see splice_vit_ctx_create."""
 
     def __init__(self, engine, B, H, W, need_grad, fp8=None):
-        """``fp8``: True -- this context's QKV / fc1 / fc2 forward projections AND its attention forward on the fp8 MFMA;
-        ``"gemm"`` -- the projections only; False -- bf16.  None: the engine's default (``VitEngine.enable_fp8()`` switches it on
+        """``fp8`` (see ``fp8_mode``): True / ``"gemm"`` -- this context's QKV / fc1 / fc2 forward projections on the fp8 MFMA;
+        ``"attention"`` -- its attention forward too; False -- bf16.  None: the engine's default (``VitEngine.enable_fp8()`` switches it on
         for the contexts the engine hands out itself)."""
         self.engine, self.B, self.H, self.W, self.need_grad = engine, B, H, W, need_grad
-        self.fp8 = getattr(engine, "fp8", False) if fp8 is None else fp8
+        self.fp8 = fp8_mode(getattr(engine, "fp8", False) if fp8 is None else fp8)
         pos = interpolate_pos_encoding(engine.pos_embed, engine.patch, H, W).contiguous().float()
         h = C.c_void_p()
         _lib.check(_lib.lib().splice_vit_ctx_create(engine.handle, B, H, W, _lib.ptr(pos), int(need_grad),
                                                     _lib.current_stream(), C.byref(h)), "vit_ctx_create")
         torch.cuda.current_stream().synchronize()  # pos may be freed after this
         self.handle = h
+        self.generation = 0      # forwards run through this context (autograd nodes check theirs is still the resident one)
         t, tld, rows = C.c_int(), C.c_int(), C.c_int()
         _lib.check(_lib.lib().splice_vit_ctx_info(h, C.byref(t), C.byref(tld), C.byref(rows)))
         self.T, self.Tld, self.rows = t.value, tld.value, rows.value
         if self.fp8:
-            _lib.check(_lib.lib().splice_vit_ctx_set_fp8(h, 1 if self.fp8 == "gemm" else 3), "vit_ctx_set_fp8")
+            _lib.check(_lib.lib().splice_vit_ctx_set_fp8(h, 3 if self.fp8 == "attention" else 1), "vit_ctx_set_fp8")
 
     def __del__(self):
         try:
@@ -64,6 +83,7 @@ class VitContext:
     def forward(self, img, normalize):
         assert img.is_cuda and img.dtype == torch.float32 and img.is_contiguous()
         assert tuple(img.shape) == (self.B, 3, self.H, self.W), (img.shape, (self.B, 3, self.H, self.W))
+        self.generation += 1
         _lib.check(_lib.lib().splice_vit_forward(self.handle, _lib.ptr(img), int(normalize), _lib.current_stream()), "vit_forward")
 
     def read(self, kind, layer):
@@ -144,23 +164,25 @@ class VitEngine:
 
     def prepare_fp8(self):
         """BASELINE configs[4]: build the e4m3 copies of the QKV / fc1 / fc2 weights (once).  Contexts opt in one by one
-        (``VitContext(..., fp8=True)``), so engines that share this frozen ViT keep their own precision."""
+        (``VitContext(..., fp8="gemm" | "attention")``), so engines that share this frozen ViT keep their own precision."""
         if not getattr(self, "_fp8_ready", False):
             _lib.check(_lib.lib().splice_vit_enable_fp8(self.handle, _lib.current_stream()), "vit_enable_fp8")
             torch.cuda.current_stream().synchronize()
             self._fp8_ready = True
         return self
 
-    def enable_fp8(self):
-        """``prepare_fp8`` + make fp8 the DEFAULT of the contexts this engine hands out through ``context()`` from now on
-        (cached bf16 contexts are dropped).  Contexts built with an explicit ``fp8=`` argument are not affected."""
+    def enable_fp8(self, mode="gemm"):
+        """``prepare_fp8`` + make ``mode`` (``"gemm"``: e4m3 QKV / fc1 / fc2 projections; ``"attention"``: the attention forward too)
+        the DEFAULT of the contexts this engine hands out through ``context()`` from now on (cached contexts are dropped; this
+        includes the contexts an extractor built on this engine creates afterwards -- tolerances of the mode: tests/test_fp8_gpu.py).
+        Contexts built with an explicit ``fp8=`` argument are not affected."""
         self.prepare_fp8()
         self._ctx.clear()
-        self.fp8 = True
+        self.fp8 = fp8_mode(mode)
         return self
 
     def context(self, B, H, W, need_grad=True, fp8=None):
-        fp8 = getattr(self, "fp8", False) if fp8 is None else fp8
+        fp8 = fp8_mode(getattr(self, "fp8", False) if fp8 is None else fp8)
         key = (B, H, W, bool(need_grad), fp8)
         if key not in self._ctx:
             self._ctx[key] = VitContext(self, B, H, W, need_grad, fp8=fp8)

@@ -1,9 +1,11 @@
-"""CPU: the pair queue of splice_amd/batch.py (pair i -> worker i mod N, one process per worker, no shared state).
+"""CPU: the pair queue of splice_amd/batch.py (one process per worker pulling from ONE work list; nothing shared but its head).
 A stub runner stands in for the GPU engine: its output is a deterministic function of the pair's images and the
-overrides, so "N workers == serial" is checked bit for bit, as is the order / assignment / failure reporting."""
+overrides, so "N workers == serial" is checked bit for bit, as is the work list, the pull order under skewed run times and
+the failure reporting."""
 import hashlib
 import json
 import os
+import time
 
 import numpy as np
 import pytest
@@ -23,7 +25,13 @@ def stub_runner(pair_dir, overrides):
         f.write(h.digest())
     if overrides.get("explode") == os.path.basename(pair_dir):
         raise RuntimeError("boom")
-    return {"digest": h.hexdigest(), "steps": overrides.get("n_epochs", 0), "pid": os.getpid()}
+    t0 = time.time()
+    time.sleep(overrides.get("sleep", {}).get(os.path.basename(pair_dir), overrides.get("sleep_default", 0.0)))
+    return {"digest": h.hexdigest(), "steps": overrides.get("n_epochs", 0), "pid": os.getpid(), "t0": t0, "t1": time.time()}
+
+
+def stub_group_runner(pair_dirs, overrides):
+    return [dict(stub_runner(d, overrides), pairs_in_step=len(pair_dirs)) for d in pair_dirs]
 
 
 def _make_pairs(root, k):
@@ -48,23 +56,69 @@ def test_queue_matches_serial(tmp_path):
         root = tmp_path / tag
         root.mkdir()
         _make_pairs(root, 5)
-        res = batch.run_batch(str(root), n, {"n_epochs": 7}, runner="test_batch_cpu:stub_runner", pin_gpu=False)
+        res = batch.run_batch(str(root), n, {"n_epochs": 7, "sleep_default": 0.3}, runner="test_batch_cpu:stub_runner", pin_gpu=False)
         roots.append((root, res))
     (r1, a), (r2, b) = roots
     assert [x["pair"] for x in a] == [f"pair{i:02d}" for i in range(5)] == [x["pair"] for x in b]
     assert [x["digest"] for x in a] == [x["digest"] for x in b]                      # result independent of N
-    assert [x["gpu"] for x in b] == [0, 1, 0, 1, 0] and {x["gpu"] for x in a} == {0}   # pair i -> worker i mod N
+    assert {x["gpu"] for x in a} == {0} and {x["gpu"] for x in b} == {0, 1}           # both workers pulled work
     assert len({x["pid"] for x in b}) == 2                                           # one process per worker
     for i in range(5):
         assert (r1 / f"pair{i:02d}" / "out" / "output.png").read_bytes() == (r2 / f"pair{i:02d}" / "out" / "output.png").read_bytes()
     assert len({x["digest"] for x in a}) == 5                                        # pairs differ
 
 
+def test_pull_queue_does_not_straggle_behind_a_slow_pair(tmp_path):
+    """unequal pairs.  pair00 takes 3 s, the other five 0.25 s each.  The static `i mod N` plan gave worker 0
+    the pairs 0, 2, 4 (3.5 s) next to worker 1's 0.75 s; with the pull queue the worker that drew the slow pair runs nothing
+    else and the other one drains the rest while it is still busy."""
+    _make_pairs(tmp_path, 6)
+    over = {"sleep": {"pair00": 3.0}, "sleep_default": 0.25}
+    res = batch.run_batch(str(tmp_path), 2, over, runner="test_batch_cpu:stub_runner", pin_gpu=False)
+    slow_gpu = res[0]["gpu"]
+    assert [r["gpu"] for r in res[1:]] == [1 - slow_gpu] * 5, [r["gpu"] for r in res]
+    assert max(r["t1"] for r in res[1:]) < res[0]["t1"]             # the five short pairs were done before the slow one ended
+    # same outputs as the serial run, whatever the order the workers drew them in
+    ser = tmp_path / "serial"
+    ser.mkdir()
+    _make_pairs(ser, 6)
+    ref = batch.run_batch(str(ser), 1, over, runner="test_batch_cpu:stub_runner", pin_gpu=False)
+    assert [r["digest"] for r in ref] == [r["digest"] for r in res]
+
+
+def test_work_items_are_a_function_of_the_directory_only():
+    a, b, c = ((224, 224), (224, 224)), ((448, 448), (224, 224)), ((320, 240), (224, 224))
+    sizes = [a, b, a, a, c, a, b, a]
+    # one pair per item: most expensive images first, ties in index order
+    assert batch.work_items(sizes, 1) == [[1], [6], [4], [0], [2], [3], [5], [7]]
+    # groups of up to 4 equal-size pairs first by cost (4 x a = 401 k pixels, 2 x b = 502 k), then what fills no group
+    assert batch.work_items(sizes, 4) == [[1, 6], [0, 2, 3, 5], [4], [7]]
+    assert batch.work_items(sizes, 2) == [[1, 6], [0, 2], [3, 5], [4], [7]]
+    assert batch.work_items([a], 8) == [[0]]
+
+
+def test_groups_do_not_depend_on_the_number_of_workers(tmp_path):
+    """Round 3 grouped per worker (pairs i mod N), so the groups -- and with random crops the results -- changed with N.  Now the
+    groups come from the whole directory."""
+    sizes = [((8, 8), (8, 8))] * 5 + [((16, 8), (8, 8))]
+    seen = []
+    for n in (1, 2, 3):
+        root = tmp_path / f"n{n}"
+        root.mkdir()
+        _make_pairs(root, 6)
+        res = batch.run_batch(str(root), n, {"sleep_default": 0.05}, runner="test_batch_cpu:stub_runner", group_runner="test_batch_cpu:stub_group_runner",
+                              pin_gpu=False, pairs_per_gpu=2, sizes=sizes)
+        seen.append([(r["pair"], r.get("pairs_in_step", 1), r["digest"]) for r in res])
+    assert seen[0] == seen[1] == seen[2]
+    assert [k for _, k, _ in seen[0]] == [2, 2, 2, 2, 1, 1]
+
+
 def test_worker_failure_is_reported(tmp_path):
     _make_pairs(tmp_path, 3)
-    with pytest.raises(RuntimeError, match="gpu 1"):
-        batch.run_batch(str(tmp_path), 2, {"explode": "pair01"}, runner="test_batch_cpu:stub_runner", pin_gpu=False)
-    assert (tmp_path / "pair00" / "out" / "result.json").exists()      # the healthy worker finished its pairs
+    with pytest.raises(RuntimeError, match=r"while running \['pair01'\].*without a result: \['pair01'\]"):
+        batch.run_batch(str(tmp_path), 2, {"explode": "pair01", "sleep_default": 0.3}, runner="test_batch_cpu:stub_runner", pin_gpu=False)
+    for ok in ("pair00", "pair02"):                                     # the healthy worker drained the rest of the queue
+        assert (tmp_path / ok / "out" / "result.json").exists()
     with pytest.raises(ValueError):
         batch.run_batch(str(tmp_path / "not_a_pair"), 1, runner="test_batch_cpu:stub_runner", pin_gpu=False)
 
@@ -97,4 +151,6 @@ def test_fp8_config_key_maps_to_the_engine_mode():
     assert [fp8_mode({"fp8": v}) for v in (False, None, 0, "off", "False")] == [False] * 5
     assert fp8_mode({}) is False
     assert [fp8_mode({"fp8": v}) for v in (True, 1, "gemm", "True")] == ["gemm"] * 4
-    assert [fp8_mode({"fp8": v}) for v in ("attention", "all", " Attention ")] == [True] * 3
+    assert [fp8_mode({"fp8": v}) for v in ("attention", "all", " Attention ")] == ["attention"] * 3
+    with pytest.raises(ValueError):
+        fp8_mode({"fp8": "e5m2"})

@@ -97,7 +97,7 @@ def test_fp8_vit_features_vs_oracle():
     for fp8 in (False, True):
         eng = VitEngine(name, device=DEV).load_state_dict(vit_state)
         if fp8:
-            eng.enable_fp8()
+            eng.enable_fp8("attention")
         ctx = eng.context(1, size, size, need_grad=False)
         ctx.forward(img.to(DEV), normalize=False)
         qkv = ctx.read(KIND_QKV_LAST_F32, 11)[0, : ctx.T].cpu()
@@ -127,7 +127,7 @@ def test_fp8_step_vs_oracle_tolerance_table(name, size):
     A, B = synth.smooth_image_pair(123, 0, size, size)
     vit_state = synth.vit_params(7, name, img_size=size, w_std=0.05 if size == 64 else 0.03)
     gen_state = synth.generator_params(9, 0.02)
-    eng = SpliceEngine(cfg, vit_state, gen_state, (size, size), (size, size), fp8=True)
+    eng = SpliceEngine(cfg, vit_state, gen_state, (size, size), (size, size), fp8="attention")
     patch, dim, depth, heads = dino_vit.DINO_CONFIGS[name]
     m = dino_vit.VisionTransformer(patch, dim, depth, heads, img_size=size).eval()
     m.load_state_dict({k: torch.from_numpy(v) for k, v in vit_state.items()})
@@ -158,7 +158,7 @@ def test_fp8_step_vs_oracle_tolerance_table(name, size):
 # ---- BASELINE configs[4] at its own sizes: every loss term at the ViT input scales 224 / 320 / 448 with the fp8 operand path
 @pytest.mark.parametrize("term", ["cls", "ssim", "id"])
 def test_configs4_multiscale_224_320_448_fp8_vs_oracle(term):
-    """``MultiScaleEngine(scales=(224, 320, 448), fp8=True)`` on ViT-B/8 (T = 785 / 1601 / 3137; bilinear Resize 224 -> 320 / 448 and
+    """``MultiScaleEngine(scales=(224, 320, 448), fp8="attention")`` on ViT-B/8 (T = 785 / 1601 / 3137; bilinear Resize 224 -> 320 / 448 and
     its adjoint, interpolated position tables, 32-query attention waves and the two-launch attention backward at the large
     scales, fp8 QKV / fc1 / fc2 + fp8 self-similarity Gram): summed loss and whole-arena generator gradient of one step against
     the fp32 CPU oracle evaluated at the three ``dino_global_patch_size`` values on the same generator outputs.  One loss term per
@@ -175,7 +175,7 @@ def test_configs4_multiscale_224_320_448_fp8_vs_oracle(term):
     A, B = torch.from_numpy(A), torch.from_numpy(B)
     vit_state = synth.vit_params(7, "dino_vitb8", img_size=224, w_std=0.03)
     gen_state = synth.generator_params(9, 0.02)
-    eng = MultiScaleEngine(cfg, vit_state, gen_state, (224, 224), None, scales=scales, fp8=True)
+    eng = MultiScaleEngine(cfg, vit_state, gen_state, (224, 224), None, scales=scales, fp8="attention")
     assert [e.ctx_g.T for e in eng.engines] == [785, 1601, 3137] and all(e.ctx_g.fp8 for e in eng.engines)
     m = dino_vit.VisionTransformer(8, 768, 12, 12, img_size=224).eval()
     m.load_state_dict({k: torch.from_numpy(v) for k, v in vit_state.items()})
@@ -219,7 +219,7 @@ def test_fp8_trajectory_reaches_reference_level(golden_dir):
     g = np.load(os.path.join(golden_dir, "steps.npz"))
     A, B = synth.smooth_image_pair(32, 0, 64, 64)
     cfg = dict(dino_model_name="dino_vits8", dino_global_patch_size=64)
-    eng = SpliceEngine(cfg, synth.vit_params(7, "dino_vits8", img_size=64, w_std=0.05), synth.generator_params(31, 0.02), (64, 64), (64, 64), fp8=True)
+    eng = SpliceEngine(cfg, synth.vit_params(7, "dino_vits8", img_size=64, w_std=0.05), synth.generator_params(31, 0.02), (64, 64), (64, 64), fp8="attention")
     At, Bt = torch.from_numpy(A).to(DEV), torch.from_numpy(B).to(DEV)
     mine = []
     for _ in range(78):
@@ -250,7 +250,7 @@ def test_fp8_is_a_property_of_the_context_not_of_the_shared_vit():
         return eng.params.clone()
 
     clean = run(SpliceEngine(cfg, vit_state, gen_state, (64, 64), (64, 64)))
-    e8 = SpliceEngine(cfg, vit_state, gen_state, (64, 64), (64, 64), fp8=True)
+    e8 = SpliceEngine(cfg, vit_state, gen_state, (64, 64), (64, 64), fp8="attention")
     p8 = run(e8)
     shared = run(SpliceEngine(cfg, None, gen_state, (64, 64), (64, 64), vit_engine=e8.vit))
     assert e8.ctx_g.fp8 and not torch.equal(p8, clean)
