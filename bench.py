@@ -219,6 +219,49 @@ def time_steps(eng, A, B, K, W, barrier):
     return time.perf_counter() - t0
 
 
+MIN_TIMED_SECONDS = 1.0    # the driver's --steps 20 timed 0.07 s; a block of K steps is now repeated until >= 1 s is timed
+MAX_BLOCKS = 400
+
+
+def time_blocks(eng, A, B, K, W, barrier, rep, min_seconds=MIN_TIMED_SECONDS, max_blocks=MAX_BLOCKS):
+    """W untimed warm-up steps, then BLOCKS of exactly K steps, each bracketed by barrier + synchronize on both sides and reduced to
+    the max over ranks, repeated until at least ``min_seconds`` are timed.  Returns (local block times, max-over-ranks block times).
+    Every rank sees the same reduced times, so every rank runs the same number of blocks."""
+    for _ in range(W):
+        eng.step(A, B, A)
+    local, reduced, total = [], [], 0.0
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            eng.step(A, B, A)
+        barrier()
+        dt = time.perf_counter() - t0
+        dmax = rep.max_over_ranks(dt)
+        local.append(dt)
+        reduced.append(dmax)
+        total += dmax
+        if total >= min_seconds or len(reduced) >= max_blocks:
+            return local, reduced
+
+
+def median_block(reduced):
+    """Index of the median block (lower median for an even count: a block that was actually run)."""
+    order = sorted(range(len(reduced)), key=lambda i: reduced[i])
+    return order[(len(order) - 1) // 2]
+
+
+def timing_record(K, reduced, first_step, entire_every):
+    mid = median_block(reduced)
+    ms = [round(t / K * 1e3, 4) for t in reduced]
+    ent = [sum(1 for st in range(first_step + b * K, first_step + (b + 1) * K) if entire_every and st % entire_every == 0) for b in range(len(reduced))]
+    return mid, {"blocks": len(reduced), "steps_per_block": K, "timed_seconds": round(sum(reduced), 4), "reported_block": mid,
+                 "ms_per_step_by_block": ms if len(ms) <= 64 else ms[:64] + ["..."], "ms_per_step_min": min(ms), "ms_per_step_max": max(ms),
+                 "entire_image_steps_by_block": ent if len(ent) <= 64 else ent[:64] + ["..."],
+                 "rule": f"W warm-up steps, then blocks of exactly K steps (barrier + synchronize on both sides, max over ranks) until >= {MIN_TIMED_SECONDS} s "
+                         "are timed; value / ms_per_step are those of the MEDIAN block"}
+
+
 def train_regime_leg(eng, A, B, steps=120):
     """the headline regime (fixed full crops: identity Resize, graph replay every step) is the BASELINE config, but
     ``train_model`` with the reference's default config draws a new crop size nearly every step (data/transforms.py:21: eager
@@ -260,19 +303,20 @@ def stub_main(args, ms, world):
     rep = Replicas(backend="gloo", device=None)
     host = pin_worker(rep.local_rank, world, 0)
     eng = StubEngine(ms * (1.0 + 0.5 * rep.rank))   # rank r is slower: the max over ranks must show it
-    elapsed = time_steps(eng, None, None, args.steps, args.warmup, rep.barrier)
-    per_rank = rep.gather_floats(elapsed)
+    local, reduced = time_blocks(eng, None, None, args.steps, args.warmup, rep.barrier, rep, min_seconds=float(os.environ.get("SPLICE_BENCH_STUB_MIN_S", "0.2")))
+    mid, timing = timing_record(args.steps, reduced, args.warmup, 0)
+    per_rank = rep.gather_floats(local[mid])
+    elapsed = reduced[mid]
     hip_vis = os.environ.get("HIP_VISIBLE_DEVICES", "")
     # every rank's device binding, gathered through the same process group (as floats: device ordinals)
     devs = rep.gather_floats(float(hip_vis.split(",")[0]) if hip_vis.split(",")[0].strip().isdigit() else -1.0)
-    elapsed = rep.max_over_ranks(elapsed)
     if rep.rank == 0:
         value = aggregate_throughput(args.steps, world, elapsed)
         print(json.dumps({"metric": "stub_steps_per_sec", "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "none", "data": "stub (launcher self-test: no GPU work, SPLICE_BENCH_STUB)",
                           "config": {"workload": f"STUB: sleep {ms} ms per step (+50 % per rank)", "gpus": world, "per_rank_steps_per_s": [round(args.steps / t, 2) for t in per_rank],
-                                     "per_rank_device": [int(d) for d in devs], "host": host, "env": library_env()},
+                                     "per_rank_device": [int(d) for d in devs], "host": host, "env": library_env(), "timing": timing},
                           "roofline": None, "cpu_baseline": None}), flush=True)
     rep.close()
 
@@ -357,7 +401,9 @@ def main():
         rep.barrier()
         torch.cuda.synchronize()
 
-    elapsed = time_steps(eng, A, B, K, W, barrier)
+    local_blocks, reduced_blocks = time_blocks(eng, A, B, K, W, barrier, rep)
+    mid, timing = timing_record(K, reduced_blocks, W, eng.cfg["entire_A_every"] if not scales else eng.engines[0].cfg["entire_A_every"])
+    elapsed = local_blocks[mid]
     losses = eng.losses() if (P == 1 or scales) else eng.losses(0)
     # roofline leg: the timed region replays captured hipGraphs (event records cannot be threaded through a
     # replay), so the SAME steps continue for short instrumented stretches with every launch of one kernel family
@@ -376,10 +422,10 @@ def main():
             n_ent = sum(1 for st_ in range(eng.step_idx - nprof + 1, eng.step_idx + 1) if st_ % eng.cfg["entire_A_every"] == 0)
             prof[fam] = (ms.value, calls.value, kernels.value, nprof, n_ent)
     per_rank_elapsed = rep.gather_floats(elapsed)
-    elapsed = rep.max_over_ranks(elapsed)
+    elapsed = reduced_blocks[mid]
     T = eng.ctx_g.T if not scales else [e.ctx_g.T for e in eng.engines]
     D = eng.vit.dim
-    n_entire = sum(1 for s in range(W, W + K) if s % eng.cfg["entire_A_every"] == 0)
+    n_entire = timing["entire_image_steps_by_block"][mid] if mid < 64 else 0
     # ---- throughput form of the metric: P pairs per GPU through the shared ViT (same barrier-bracketed timing, fewer steps)
     sweep = {P: K / elapsed}
     sweep_ids = [int(x) for x in args.pairs_sweep.split(",") if x.strip()] if (world == 1 and P == 1 and not scales) else []
@@ -463,7 +509,7 @@ def main():
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("fp8-approximate(e4m3 qkv/fc1/fc2 + attention fwd + selfsim Gram)/bf16" if fp8_mode == "attention" else "fp8-approximate(e4m3 qkv/fc1/fc2 + selfsim Gram)/bf16") if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"Splice pair {hw[0]}x{hw[1]}, {args.model} (T={T}), {P} pair(s) per GPU per step, "
-                               f"{n_entire} of {K} timed steps include the entire-image branch"
+                               f"{n_entire} of the {K} steps of the reported (median) block include the entire-image branch"
                                + (f"; loss evaluated at the ViT input scales {scales} every step (configs[4])" if scales else "")
                                + ("; APPROXIMATE fp8 operand mode (per-step gradient 1e-1 off the fp32 oracle, own tolerance table: tests/test_fp8_gpu.py, DESIGN.md section 5)" if args.fp8 else ""),
                    "gpus": world, "pairs_per_gpu": P, "pair_steps_per_s": round(value * P, 3),
@@ -474,7 +520,7 @@ def main():
                                                    for k, v in sorted(sweep.items())},
                    "train_model_regime": train_leg,
                    "generator_dtype": "f32", "last_loss": round(losses["loss"], 5),
-                   "env": library_env(), "host": host},
+                   "env": library_env(), "host": host, "timing": timing},
         "roofline": roof, "cpu_baseline": cpu,
     }
     if bad:

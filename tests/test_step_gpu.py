@@ -7,8 +7,12 @@ the trajectory is CHAOTIC in the optimiser itself: Adam with beta1=0 takes ~lr-s
 sign(g), so any gradient perturbation re-routes it.  Measured with the fp32 CPU oracle (DESIGN.md
 "trajectory sensitivity"): 2 % multiplicative gradient noise moves the loss at step 72 of this very
 fixture from 99.8 to 58..84, i.e. pointwise agreement beyond ~10 steps is not a property the
-reference itself has.  So: 6-step window means within 25 % up to step 30, and the optimisation must
-end at least as low as 1.25x the reference's level.
+reference itself has.  So: 6-step window means within 25 % up to step 30; from there to the end a TWO-SIDED band on the window means
+(0.35 .. 1.30 x the reference's: the fp32 oracle with 2 % gradient noise sits at 0.58 .. 0.84 x, the bf16 engine measured 0.5 x at
+the tail) and on the level reached (0.40 .. 1.25 x); and -- what the band cannot do -- the REPORTED loss of the free-running
+engine is pinned pointwise: at steps 30, 54, 75 and 77 the fp32 oracle is evaluated at the engine's own parameters of that step
+(same point => the chaos argument does not apply) and every loss entry must agree within 3e-2.  A bug that lowers (or raises) the
+reported loss after the first steps fails that check whatever the trajectory does.
 """
 import os
 
@@ -98,13 +102,48 @@ def _teacher_forced(eng, orc, A, B, A_ent, steps, loss_tol=3e-2, grad_tol=5e-2, 
     return worst_l, worst_g
 
 
+def _run_with_spot_checks(eng, A, B, n, spots, vit_name="dino_vits8", img_size=64, vit_seed=7, rtol=3e-2):
+    """``_run`` + at every step in ``spots`` the fp32 oracle evaluated AT THE ENGINE'S PARAMETERS of that step (free-running engine,
+    no re-synchronisation of the engine): the reported loss entries must be the true ones."""
+    from oracle import losses as OL
+    vit_state = synth.vit_params(vit_seed, vit_name, img_size=img_size, w_std=0.05)
+    orc = _oracle_for(vit_name, img_size, vit_state, synth.generator_params(1, 0.02), eng.cfg)
+    rows = []
+    At, Bt = torch.from_numpy(A), torch.from_numpy(B)
+    Ad, Bd = At.to(DEV), Bt.to(DEV)
+    worst = 0.0
+    for step in range(n):
+        if step in spots:
+            snap = eng.gen.unflatten(eng.params.clone())
+        eng.step(Ad, Bd, Ad)
+        rows.append(eng.losses())
+        if step in spots:
+            with torch.no_grad():
+                for k, v in orc.params.items():
+                    v.copy_(snap[k].cpu().reshape(v.shape))
+            orc.step_idx = step - 1
+            orc.lambdas = OL.initial_lambdas(orc.cfg)
+            if step >= orc.cfg["cls_warmup"]:
+                OL.update_lambdas(orc.lambdas, orc.cfg, orc.cfg["cls_warmup"])
+            lo, _, _ = orc.step(At[None], Bt[None], At[None])
+            le = rows[-1]
+            assert set(le) == set(lo), (step, sorted(le), sorted(lo))
+            for k in lo:
+                rel = abs(le[k] - lo[k]) / abs(lo[k])
+                worst = max(worst, rel)
+                assert rel < rtol, ("reported loss != oracle loss at the engine's own parameters", step, k, le[k], lo[k])
+            print(f"    free-running step {step}: reported loss {le['loss']:.3f}, fp32 oracle at the same parameters {lo['loss']:.3f}")
+    print(f"    reported-vs-true loss along the free-running trajectory (steps {sorted(spots)}): worst rel {worst:.3e}")
+    return rows
+
+
 def test_trajectory_a_identity_resize(golden_dir):
     g = np.load(os.path.join(golden_dir, "steps.npz"))
     keys = [str(k) for k in g["loss_keys"]]
     assert keys == LOSS_KEYS
     A, B = synth.smooth_image_pair(32, 0, 64, 64)
     eng = _engine({}, A, B, 31, 64)
-    rows = _run(eng, A, B, 78)
+    rows = _run_with_spot_checks(eng, A, B, 78, spots={30, 54, 75, 77})
     _check(rows, g["a/losses"], keys, 0, 3, 3e-2)
     mine = np.array([r["loss"] for r in rows])
     ref = g["a/losses"][:, 0]
@@ -112,9 +151,13 @@ def test_trajectory_a_identity_resize(golden_dir):
         a, b = mine[lo:lo + 6].mean(), ref[lo:lo + 6].mean()
         print(f"    steps {lo}..{lo + 5}: mean loss {a:.1f} vs reference {b:.1f}")
         assert abs(a - b) / b < 0.25, (lo, a, b)
+    for lo in range(31, 73, 6):    # two-sided band to the end of the fixture (step 75 = an entire-image step, excluded like step 0)
+        a, b = mine[lo:lo + 6].mean(), ref[lo:lo + 6].mean()
+        print(f"    steps {lo}..{lo + 5}: mean loss {a:.1f} vs reference {b:.1f} (ratio {a / b:.2f})")
+        assert 0.35 < a / b < 1.30, (lo, a, b)
     tail_mine, tail_ref = np.sort(mine[60:75])[:5].mean(), np.sort(ref[60:75])[:5].mean()
-    print(f"    level reached (steps 60..74): {tail_mine:.1f} vs reference {tail_ref:.1f}")
-    assert tail_mine < 1.25 * tail_ref
+    print(f"    level reached (steps 60..74): {tail_mine:.1f} vs reference {tail_ref:.1f} (ratio {tail_mine / tail_ref:.2f})")
+    assert 0.40 * tail_ref < tail_mine < 1.25 * tail_ref
     assert np.isfinite(mine).all()
     out = eng.generate(torch.from_numpy(A)[None].to(DEV)).cpu().numpy()
     refimg = g["a/final_out"]
@@ -456,3 +499,38 @@ def test_real_dino_checkpoint_steps_vs_oracle():
     eng = SpliceEngine(cfg, vit_state, gen_state, (224, 224), (224, 224))
     orc = _oracle_for(name, 224, vit_state, gen_state, cfg)
     _teacher_forced(eng, orc, A, B, A, 3, loss_tol=2e-2, grad_tol=3e-2, tag="real checkpoint")
+
+
+def test_full_length_run_configs1_2000_steps():
+    """BASELINE configs[1] at its own length: ONE 224x224 pair, ViT-B/8 (T = 785), 2000 optimisation steps (`train.py:51-80` x 2000;
+    the paper's length, SURVEY 8d cfg 2) on the fused engine -- graph replay on ordinary steps, the entire-image branch every 75th.
+    Checks what a long run can break and a 78-step fixture cannot: every sampled loss finite, the optimisation keeps descending
+    (window means of the ordinary-step loss non-increasing within 5 %), the generated image stays inside [0, 1], device memory
+    is flat after the first 200 steps, and the step counter / Adam count agree with the number of calls."""
+    from splice_amd.engine import synthetic_engine
+    A, B = synth.smooth_image_pair(1234, 0, 224, 224)
+    eng, _, _ = synthetic_engine(dict(dino_model_name="dino_vitb8", dino_global_patch_size=224), pair_id=0, hw=(224, 224), seed=1234, device=DEV)
+    Ad, Bd = torch.from_numpy(A).to(DEV), torch.from_numpy(B).to(DEV)
+    samples, mem = {}, {}
+    for step in range(2000):
+        eng.step(Ad, Bd, Ad)
+        if step % 25 == 24 and step % 75 != 0:
+            samples[step] = eng.losses()["loss"]                  # (host sync only here)
+        if step in (199, 1999):
+            torch.cuda.synchronize()
+            free, total = torch.cuda.mem_get_info()
+            mem[step] = (total - free, torch.cuda.memory_allocated())
+    vals = np.array([samples[k] for k in sorted(samples)])
+    assert np.isfinite(vals).all() and len(vals) >= 50
+    wins = [vals[i:i + 10].mean() for i in range(0, len(vals) - 9, 10)]
+    print("    2000 steps at 224^2 / ViT-B/8: window means of the ordinary-step loss: " + ", ".join(f"{w:.2f}" for w in wins))
+    for a, b in zip(wins, wins[1:]):
+        assert b < 1.05 * a, wins
+    assert wins[-1] < 0.8 * wins[0], wins                         # and it actually went somewhere
+    out = eng.generate(Ad[None])
+    assert out.shape == (1, 3, 224, 224) and torch.isfinite(out).all() and 0.0 <= out.min().item() and out.max().item() <= 1.0
+    assert out.std().item() > 1e-3                                # not a constant image
+    assert eng.step_idx == 1999
+    used0, used1 = mem[199][0], mem[1999][0]
+    print(f"    device memory in use after 200 / 2000 steps: {used0 / 2**20:.0f} / {used1 / 2**20:.0f} MiB; torch allocator {mem[199][1] / 2**20:.0f} / {mem[1999][1] / 2**20:.0f} MiB")
+    assert abs(used1 - used0) < 64 * 2 ** 20 and mem[1999][1] == mem[199][1]
