@@ -1,0 +1,200 @@
+// 256 x 256 bf16 "NT" GEMM tile on an 8-phase schedule for gfx950 (the batched ViT shapes: M >= 6400 rows, N >= 2304):
+//   C[M][N] = sum_k A[m][k] * B[n][k], fp32 accumulate, same MFMA (16x16x32 bf16, swapped operands), same k order per
+//   accumulator and therefore the SAME BITS as the 128 x 128 / 128 x 64 / 64 x 64 tiles of gemm.h.
+//
+// Why a second main loop: the one-barrier-per-slice loops of gemm.h stop at ~35 % of the bf16 MFMA peak on these shapes -- all
+// waves of a workgroup load, wait, then compute, and the L2 -> LDS feed of a 128 x 128 tile (32 KB per 16 MFMAs per wave) is
+// exposed (profiles/r03_gemm_ablation.txt: +48 % with the DMA compiled out).  Here (CDNA4 guide, "256^2 8-phase"):
+//   * 8 waves as 2 (M) x 4 (N); a wave owns 128 x 64 of the tile = 32 accumulator fragments; half the LDS-DMA bytes per FLOP;
+//   * a K tile (BK = 64) is FOUR half-tiles of 16 KB: B rows 0..127 (q = 0), A rows 0..127 (q = 1), B rows 128..255 (q = 2),
+//     A rows 128..255 (q = 3).  A wave's 128 rows are rows wr*64..+63 of BOTH A halves and its 64 columns are columns wc*32..+31
+//     of BOTH B halves, so every half-tile is read in exactly one phase: q0 + q1 in phase 1, q2 in phase 2, q3 in phase 3,
+//     nothing in phase 4 (the B fragments of phase 1 stay in registers for quadrant (1, 0));
+//   * one half-tile is staged per phase by LDS-DMA, SEVEN half-tiles ahead of its first reader, into an 8-slot ring (128 KB);
+//     the only DMA wait is a counted vmcnt(6) in the last phase of a K tile (three half-tiles stay in flight across it);
+//   * each phase is [fragment reads + DMA issue] barrier [16 MFMAs] barrier, and the two wave halves (wr = 0 / 1: one wave of
+//     each per SIMD) run one barrier apart: while one half's MFMAs own the matrix pipe, the other half reads and stages.
+// Hazards (guide, "Read a staged buffer one phase AFTER the wait that retires it"): RAW -- the counted wait sits before the
+// first barrier of phase 4, the first read of that K tile is in the next phase; WAR -- slot of q = p - 1 is re-staged in phase
+// p: q1, q2, q3 were last read two phases earlier; q0 (read in phase 1, re-staged in phase 2) has its four reads retired by an
+// lgkmcnt(8) BEFORE phase 1's first barrier.
+#pragma once
+#include <type_traits>
+#include "gemm.h"
+
+struct Gemm8p {
+    static constexpr int BM = 256, BN = 256, NTHREADS = 512;
+    static constexpr int SLOT_ELEMS = 128 * GEMM_BK;          // one half-tile: 128 rows x 64 k (16 KB)
+    static constexpr int LDS_BYTES = 8 * SLOT_ELEMS * 2;      // 8-slot ring = 128 KB
+    f32x4 acc[8][4];                                          // [mh * 4 + i][nh * 2 + j]
+    u32x4 af[4][2];                                           // A fragments of the current 64-row sub-tile: [i][kk]
+    u32x4 bfr[2][2][2];                                       // B fragments of both 32-column sub-tiles: [nh][j][kk]
+
+    template <int N>
+    static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+    template <int N>
+    static __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+    static __device__ __forceinline__ void dma16(uint32_t lds_byte, uint32_t voff, const void* sbase) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte), "v"(voff), "s"(sbase) : "memory");
+    }
+
+    // origin of one output tile; the per-lane LDS-DMA source offsets are formed at issue time (3 VALU per DMA piece) instead of
+    // living in 8 VGPRs per tile: the accumulators leave little room
+    struct Src { int m0, n0; };
+    // PERSISTENT form: the workgroup walks `count` output tiles (tile r at coords(r) -> m0, n0) as ONE continuous stream of K
+    // tiles: the half-tile prefetch runs on into the next output tile's first two K tiles while the current tile finishes, so
+    // neither the DMA ring's fill nor the output stores of a tile (epi(m0, n0): registers -> global, asynchronous) leave the
+    // matrix pipe idle for longer than the epilogue's own instructions.  K % 128 == 0, K >= 128.
+    // (vmcnt also counts the epilogue's stores: a counted wait behind them can only wait LONGER than needed -- loads retire in
+    // order among themselves -- never shorter.)
+    template <class Coords, class Epi>
+    __device__ __forceinline__ void run_tiles(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K, int count,
+                                              Coords&& coords, Epi&& epi, bf16_t* smem) {
+        const int tid = threadIdx.x, lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wr = wave >> 2, wc = wave & 3;
+        const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) bf16_t*)smem + (uint32_t)wave * 1024u;
+        const int nt = K / GEMM_BK;
+        // a wave-instruction fills 8 rows x 128 B (dest = piece base + lane * 16); wave w moves pieces w and w + 8 of a 128-row
+        // half-tile; the XOR swizzle of the 16-byte chunks (chunk ^= row & 7) is applied on the source side; rows past the
+        // matrix are clamped (their products land in accumulator rows / columns the epilogue does not store)
+        const int prow = wave * 8 + (lane >> 3);                              // row of this lane's chunk inside piece 0
+        const uint32_t pcol = (uint32_t)(((lane & 7) ^ (lane >> 3)) * 16);   // byte offset of its (swizzled) source chunk
+        auto issue = [&](const Src& sc, int tile, auto qc, auto slotc) {
+            constexpr int q = decltype(qc)::value, slot = decltype(slotc)::value;
+            constexpr bool isA = q == 1 || q == 3;
+            constexpr int h = q >> 1;   // q0 = B half 0, q1 = A half 0, q2 = B half 1, q3 = A half 1
+            const bf16_t* src = (isA ? A : B) + (size_t)tile * GEMM_BK;
+            const uint32_t d = lds0 + (uint32_t)slot * (SLOT_ELEMS * 2);
+            const int r0 = (isA ? sc.m0 : sc.n0) + h * 128 + prow, lim = (isA ? M : N) - 1;
+            const uint32_t ld2 = (uint32_t)(isA ? lda : ldb) * 2u;
+            dma16(d, (uint32_t)min(r0, lim) * ld2 + pcol, src);
+            dma16(d + 8192u, (uint32_t)min(r0 + 64, lim) * ld2 + pcol, src);
+        };
+        const int frow = lane & 15, fchunk = lane >> 4;
+        const bf16_t* arow = smem + (wr * 64 + frow) * GEMM_BK;
+        const bf16_t* brow = smem + (wc * 32 + frow) * GEMM_BK;
+        const int ck0 = ((0 * 4 + fchunk) ^ (frow & 7)) << 3, ck1 = ((1 * 4 + fchunk) ^ (frow & 7)) << 3;
+        auto read_a = [&](auto slotc) {
+            constexpr int slot = decltype(slotc)::value;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i][0] = *reinterpret_cast<const u32x4*>(arow + slot * SLOT_ELEMS + i * 16 * GEMM_BK + ck0);
+                af[i][1] = *reinterpret_cast<const u32x4*>(arow + slot * SLOT_ELEMS + i * 16 * GEMM_BK + ck1);
+            }
+        };
+        auto read_b = [&](auto slotc, auto nhc) {
+            constexpr int slot = decltype(slotc)::value, nh = decltype(nhc)::value;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bfr[nh][j][0] = *reinterpret_cast<const u32x4*>(brow + slot * SLOT_ELEMS + j * 16 * GEMM_BK + ck0);
+                bfr[nh][j][1] = *reinterpret_cast<const u32x4*>(brow + slot * SLOT_ELEMS + j * 16 * GEMM_BK + ck1);
+            }
+        };
+        auto quadrant = [&](auto mhc, auto nhc) {
+            constexpr int mh = decltype(mhc)::value, nh = decltype(nhc)::value;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[mh * 4 + i][nh * 2 + j] = mfma16(bfr[nh][j][kk], af[i][kk], acc[mh * 4 + i][nh * 2 + j]);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        // one K tile = 4 phases.  s0 / t0: source set and K tile of the half-tile staged in phase 1 (q3), s1 / t1: of the three
+        // staged in phases 2 .. 4 (q0 .. q2); on0 / on1: whether they exist
+        auto ktile = [&](auto parc, const Src& s0, int t0, bool on0, const Src& s1, int t1, bool on1, int waitn) {
+            constexpr int PAR = decltype(parc)::value;   // waitn: vmcnt of phase 4 -- 6, 0, or -1 (no wait); wave-uniform
+            using S0 = std::integral_constant<int, PAR * 4 + 0>; using S1 = std::integral_constant<int, PAR * 4 + 1>;
+            using S2 = std::integral_constant<int, PAR * 4 + 2>; using S3 = std::integral_constant<int, PAR * 4 + 3>;
+            using O3 = std::integral_constant<int, (1 - PAR) * 4 + 3>;
+            // ---- phase 1: B sub-tile 0 (4 reads, first), A sub-tile 0 (8 reads); stage q3 of the next K tile (slot of the previous tile's q3)
+            read_b(S0{}, I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(S1{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (on0) issue(s0, t0, I3{}, O3{});
+            wait_lgkm<8>();                       // the 4 B reads are back: slot q0 may be re-staged in the next phase
+            __builtin_amdgcn_s_barrier();
+            wait_lgkm<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            quadrant(I0{}, I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 2: B sub-tile 1; stage q0 of the K tile after next (slot of this tile's q0)
+            read_b(S2{}, I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (on1) issue(s1, t1, I0{}, S0{});
+            __builtin_amdgcn_s_barrier();
+            wait_lgkm<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            quadrant(I0{}, I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 3: A sub-tile 1; stage q1
+            read_a(S3{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (on1) issue(s1, t1, I1{}, S1{});
+            __builtin_amdgcn_s_barrier();
+            wait_lgkm<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            quadrant(I1{}, I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- phase 4: no reads; stage q2; the counted wait that retires the next K tile
+            if (on1) issue(s1, t1, I2{}, S2{});
+            if (waitn == 6) wait_vm<6>();
+            else if (waitn == 0) wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            quadrant(I1{}, I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        };
+        if (count < 1) return;
+        Src cur, nxt;
+        coords(0, cur.m0, cur.n0);
+        nxt = cur;
+        if (count > 1) coords(1, nxt.m0, nxt.n0);
+        // ---- prologue: half-tiles 0 .. 6 (K tile 0 complete, q0..q2 of K tile 1), K tile 0 landed
+        issue(cur, 0, I0{}, I0{}); issue(cur, 0, I1{}, I1{}); issue(cur, 0, I2{}, I2{}); issue(cur, 0, I3{}, I3{});
+        issue(cur, 1, I0{}, std::integral_constant<int, 4>{}); issue(cur, 1, I1{}, std::integral_constant<int, 5>{}); issue(cur, 1, I2{}, std::integral_constant<int, 6>{});
+        wait_vm<6>();
+        __builtin_amdgcn_s_barrier();
+        if (wr == 1) __builtin_amdgcn_s_barrier();   // the second wave half runs one barrier behind the first
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // ONE loop over pairs of K tiles of the whole tile stream (two instances of the K-tile body in the kernel): K tile u of
+        // the current output tile while u < nt, else K tile u - nt of the next one (staged only if there is a next one)
+        int r = 0, t = 0;
+        const int pairs = count * (nt >> 1);
+#pragma unroll 1
+        for (int it = 0; it < pairs; ++it) {
+            const bool more = r + 1 < count;
+            const bool in2 = t + 2 < nt, in3 = t + 3 < nt;
+            const Src s2 = in2 ? cur : nxt, s3 = in3 ? cur : nxt;
+            const int k2 = in2 ? t + 2 : 0, k3 = in3 ? t + 3 : 1;
+            const bool on2 = in2 || more, on3 = in3 || more;
+            ktile(I0{}, cur, t + 1, true, s2, k2, on2, on2 ? 6 : 0);
+            ktile(I1{}, s2, k2, on2, s3, k3, on3, on3 ? 6 : -1);
+            t += 2;
+            if (t == nt) {
+                epi(cur.m0, cur.n0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                cur = nxt;
+                ++r;
+                t = 0;
+                if (r + 1 < count) coords(r + 1, nxt.m0, nxt.n0);
+            }
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the barrier count of the two halves
+    }
+};

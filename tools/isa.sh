@@ -1,7 +1,7 @@
 #!/bin/bash
 # dump the gfx950 ISA of one translation unit: tools/isa.sh attention  -> /tmp/isa/attention.s
 mkdir -p /tmp/isa
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -I/root/repo/include -S --cuda-device-only -o /tmp/isa/$1.s /root/repo/splice_amd/csrc/$1.hip 2>&1 | grep -v "hip-link"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -mllvm -amdgpu-kernarg-preload-count=16 -I/root/repo/include -S --cuda-device-only -o /tmp/isa/$1.s /root/repo/splice_amd/csrc/$1.hip 2>&1 | grep -v "hip-link"
 python3 - "$1" <<'PY'
 import re, sys
 s = open(f"/tmp/isa/{sys.argv[1]}.s").read()
