@@ -212,6 +212,104 @@ struct GemmTile {
         }
     }
 
+    // run_ring + the squared norms of the operand rows, taken from the bf16 fragments on their way to the MFMAs (no extra memory
+    // traffic): ssa[i] / ssb[j] = sum over k of the squares of A row (wm * WROWS + i * 16 + (lane & 15)) / B row
+    // (wn * BN / 2 + j * 16 + (lane & 15)), complete in every lane.  A row's sum is formed by the same instruction sequence
+    // whether the row is an A row or a B row (key self-similarity: K K^T with both operands the same matrix).
+    static __device__ __forceinline__ float sumsq8(const u32x4& v, float acc) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float lo = __uint_as_float(v[q] << 16), hi = __uint_as_float(v[q] & 0xFFFF0000u);
+            acc = __builtin_fmaf(lo, lo, acc);
+            acc = __builtin_fmaf(hi, hi, acc);
+        }
+        return acc;
+    }
+    template <int NS>
+    __device__ __forceinline__ void run_ring_norms(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K,
+                                                   int m0, int n0, bf16_t* smem, float (&ssa)[FM], float (&ssb)[FN]) {
+        static_assert(NS >= 3 && !FP8 && !SWAP, "bf16, unswapped, ring form");
+        constexpr int NL = A_LOADS + B_LOADS;
+        const int tid = threadIdx.x, lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            ssa[i] = 0.f;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) ssb[j] = 0.f;
+        const int lrow = lane >> 3, gchunk = (lane & 7) ^ lrow;
+        uint32_t ao[A_LOADS], bo[B_LOADS];
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            int gr = m0 + wave * 8 + 8 * NW * i + lrow;
+            gr = gr < M ? gr : M - 1;
+            ao[i] = ((uint32_t)gr * (uint32_t)lda + gchunk * 8) * 2u;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            int gr = n0 + wave * 8 + 8 * NW * i + lrow;
+            gr = gr < N ? gr : N - 1;
+            bo[i] = ((uint32_t)gr * (uint32_t)ldb + gchunk * 8) * 2u;
+        }
+        const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) bf16_t*)smem + (uint32_t)wave * (8 * GEMM_BK * 2);
+        auto issue = [&](int sl, int stage) {
+            const uint32_t st = lds0 + (uint32_t)stage * (LDS_ELEMS * 2);
+            const bf16_t* ab = A + sl * GEMM_BK;
+            const bf16_t* bb = B + sl * GEMM_BK;
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) dma16(st + i * (8 * NW * GEMM_BK * 2), ao[i], ab);
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) dma16(st + (BM + 8 * NW * i) * (GEMM_BK * 2), bo[i], bb);
+        };
+        const int nsl = K / GEMM_BK;
+#pragma unroll
+        for (int p = 0; p < NS - 1; ++p)
+            if (p < nsl) issue(p, p);
+        const int frow = lane & 15, fchunk = lane >> 4;
+        int stage = 0, nstage = NS - 1;
+        for (int t = 0; t < nsl; ++t) {
+            if (t + NS - 2 < nsl) wait_dma<(NS - 2) * NL>(); else wait_dma<0>();
+            __builtin_amdgcn_s_barrier();
+            if (t + NS - 1 < nsl) issue(t + NS - 1, nstage);
+            const bf16_t* As = smem + stage * LDS_ELEMS;
+            const bf16_t* Bs = As + BM * GEMM_BK;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                u32x4 af[FM], bf[FN];
+                const int chunk = kk * 4 + fchunk;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int row = wm * WROWS + i * 16 + frow;
+                    af[i] = *reinterpret_cast<const u32x4*>(As + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int row = wn * (BN / 2) + j * 16 + frow;
+                    bf[j] = *reinterpret_cast<const u32x4*>(Bs + row * GEMM_BK + ((chunk ^ (row & 7)) << 3));
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) ssa[i] = sumsq8(af[i], ssa[i]);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) ssb[j] = sumsq8(bf[j], ssb[j]);
+            }
+            stage = stage + 1 == NS ? 0 : stage + 1;
+            nstage = nstage + 1 == NS ? 0 : nstage + 1;
+        }
+        // a lane holds the k-values of its 16-byte chunk column (fchunk): the four lane groups of a row complete the sum
+#pragma unroll
+        for (int i = 0; i < FM; ++i) { ssa[i] += __shfl_xor(ssa[i], 16, 64); ssa[i] += __shfl_xor(ssa[i], 32, 64); }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) { ssb[j] += __shfl_xor(ssb[j], 16, 64); ssb[j] += __shfl_xor(ssb[j], 32, 64); }
+    }
+
     // SWAP layout: f(row, col0, v) where v[r] is C[row][col0 + r].
     template <class F>
     __device__ __forceinline__ void for_each_cols(int m0, int n0, F&& f) {

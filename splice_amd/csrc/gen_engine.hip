@@ -591,7 +591,7 @@ static int scale_backward(SpliceGenPlan* p, int i, const float* params, float* g
     BnUpsample up;
     up.d_src = deep.d_out; up.d_src_ns = deep.d_out_ns; up.c0 = SKIPC; up.h = p->h[i + 1]; up.w = p->w[i + 1]; up.Ho = hi; up.Wo = wi;
     RC(unit_backward(p, p->u_cat[i], params, grads, acc, s, &up));   // -> d_cat[i]
-    if (p->batch_stats || !bn_bwd_fuses_upsample(hi * wi, up.h, up.w))
+    if (p->batch_stats || !bn_bwd_fuses_upsample_ex(hi * wi, up.h, up.w, p->N, p->p_nstride, p->batch_stats))
         RC(upsample2x_bwd_launch(p->d_cat[i] + (size_t)SKIPC * hi * wi, p->u_skip[i].d_out_ns, deep.d_out, deep.d_out_ns, p->N, p->kch[i],
                                  p->h[i + 1], p->w[i + 1], hi, wi, s));
     if (i < A.n_scales - 1) RC(scale_backward(p, i + 1, params, grads, acc, s));   // leaves d x_{i+1} in u_db[i].d_out

@@ -75,6 +75,7 @@ struct BnUpsample {
     int c0 = 0, h = 0, w = 0, Ho = 0, Wo = 0;
 };
 bool bn_bwd_fuses_upsample(int HW, int h, int w);
+bool bn_bwd_fuses_upsample_ex(int HW, int h, int w, int N, size_t p_nstride, int batch);   // incl. the one-launch form of the middle planes
 int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
                   const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s, const BnUpsample* up = nullptr,
                   size_t p_nstride = 0, int batch = 0);   // batch != 0: statistics over all N images (nn.BatchNorm2d on a batch), N <= 8

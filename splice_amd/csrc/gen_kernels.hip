@@ -6,6 +6,7 @@
 // up-sampling written straight into the concat buffer, sigmoid head.  Every reduction runs
 // in a fixed order (no float atomics): replicas are bit-reproducible.
 #include "gen_kernels.h"
+#include <atomic>
 #include <cstdlib>
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -1159,6 +1160,133 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
     }
 }
 
+// ---- middle planes (BN_SMALL_HW < pixels <= BN_MID_HW: the 112 x 112 planes of a 224 x 224 image) --------------------------------
+// The two-stage form costs two launches of ~5 us each per BatchNorm in every direction.  One workgroup of 1024 threads owns a
+// whole (image, channel) plane, as for the small planes, with the plane staged in LDS instead of registers (a register tile of 49
+// elements per thread would be 18 k instructions of straight-line code): statistics + apply in ONE launch (round 4: 6 BatchNorms
+// per image and direction at 224 x 224).  Same arithmetic as the small-plane kernels up to the order of the block-wide sums.
+constexpr int BN_MID_HW = 16384;        // floats of LDS plane (64 KB)
+constexpr int BN_MID_THREADS = 1024;
+__device__ __forceinline__ void block_sum2_1024(float& a, float& b, float* red /* 32 floats */) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[w] = a; red[16 + w] = b; }
+    __syncthreads();
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { sa += red[k]; sb += red[16 + k]; }   // fixed order
+    a = sa; b = sb;
+}
+__global__ __launch_bounds__(BN_MID_THREADS) void bn_mid_fwd_kernel(const float* y, size_t y_nstride, float* __restrict__ out, size_t out_nstride, int C, int HW,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                    float* __restrict__ mean_o, float* __restrict__ rstd_o, float slope, BnUpsample up,
+                                                                    size_t p_nstride) {
+    extern __shared__ float bn_mid_plane[];   // HW floats
+    __shared__ float red[32];
+    const int c = blockIdx.x, img = blockIdx.y;
+    gamma += (size_t)img * p_nstride; beta += (size_t)img * p_nstride;
+    const float* p = y + (size_t)img * y_nstride + (size_t)c * HW;
+    float* q = out + (size_t)img * out_nstride + (size_t)c * HW;
+    float s = 0.f, dummy = 0.f;
+    if (up.src && c >= up.c0) {   // upsampled channel of the concat: produced here, stored into y for the backward
+        const float* sp = up.src + (size_t)img * up.src_ns + (size_t)(c - up.c0) * up.h * up.w;
+        float* yo = const_cast<float*>(p);
+        for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) {
+            const int oy = i / up.Wo, ox = i - oy * up.Wo;
+            const float v = up_value(sp, up.h, up.w, oy, ox);
+            yo[i] = v;
+            bn_mid_plane[i] = v;
+            s += v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) {
+            const float v = p[i];
+            bn_mid_plane[i] = v;
+            s += v;
+        }
+    }
+    block_sum2_1024(s, dummy, red);
+    const float m = s / (float)HW;
+    float sq = 0.f;
+    dummy = 0.f;
+    for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) { const float d = bn_mid_plane[i] - m; sq += d * d; }
+    block_sum2_1024(sq, dummy, red);
+    const float r = rsqrtf(sq / (float)HW + eps);
+    if (threadIdx.x == 0) { mean_o[img * C + c] = m; rstd_o[img * C + c] = r; }
+    const float sc = gamma[c] * r;
+    const float sh = beta[c] - m * sc;
+    for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) {
+        const float t = bn_mid_plane[i] * sc + sh;
+        q[i] = t > 0.f ? t : t * slope;
+    }
+}
+// backward: dz = da * act'(a) staged in LDS while s1 = sum dz and s2 = sum dz xhat are taken; second pass forms
+// dy = gamma rstd (dz - s1/HW - xhat s2/HW) (xhat from a second read of y), or -- for an upsampled channel -- sends it through
+// the x2 bilinear adjoint out of LDS.  Per-image parameter gradients (independent generators) or a single image.
+__global__ __launch_bounds__(BN_MID_THREADS) void bn_mid_bwd_kernel(const float* __restrict__ da, size_t da_nstride, const float* __restrict__ aout, size_t a_nstride,
+                                                                    const float* __restrict__ y, size_t y_nstride, float* __restrict__ dy, size_t dy_nstride, int C, int HW,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                    float slope, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, BnUpsample up,
+                                                                    size_t p_nstride) {
+    extern __shared__ float bn_mid_plane[];
+    __shared__ float red[32];
+    const int c = blockIdx.x, img = blockIdx.y;
+    gamma += (size_t)img * p_nstride;
+    const float m = mean[img * C + c], r = rstd[img * C + c];
+    const float* pd = da + (size_t)img * da_nstride + (size_t)c * HW;
+    const float* pa = aout + (size_t)img * a_nstride + (size_t)c * HW;
+    const float* py = y + (size_t)img * y_nstride + (size_t)c * HW;
+    const bool act = slope != 1.0f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) {
+        float dz = pd[i];
+        const float yv = py[i];
+        if (act && !(pa[i] > 0.f)) dz *= slope;
+        bn_mid_plane[i] = dz;
+        s1 += dz;
+        s2 += dz * ((yv - m) * r);
+    }
+    block_sum2_1024(s1, s2, red);
+    const float k1 = s1 / (float)HW, k2 = s2 / (float)HW;
+    const float gr = gamma[c] * r;
+    float* po = dy + (size_t)img * dy_nstride + (size_t)c * HW;
+    const bool through_adjoint = up.d_src && c >= up.c0;   // workgroup-uniform
+    for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) {
+        const float gv = gr * (bn_mid_plane[i] - k1 - (py[i] - m) * r * k2);
+        if (through_adjoint) bn_mid_plane[i] = gv; else po[i] = gv;
+    }
+    if (through_adjoint) {
+        __syncthreads();
+        float* qd = up.d_src + (size_t)img * up.d_src_ns + (size_t)(c - up.c0) * up.h * up.w;
+        for (int e = threadIdx.x; e < up.h * up.w; e += BN_MID_THREADS)
+            qd[e] = up_adjoint_value((const float*)bn_mid_plane, up.h, up.w, up.Ho, up.Wo, e / up.w, e % up.w);
+    }
+    if (threadIdx.x == 0) {
+        float* dg = dgamma + (size_t)img * p_nstride + c;
+        float* db = dbeta + (size_t)img * p_nstride + c;
+        *dg = accumulate ? *dg + s2 : s2;
+        *db = accumulate ? *db + s1 : s1;
+    }
+}
+static void bn_mid_allow_lds() {   // > 48 KB of dynamic LDS has to be allowed once per kernel and device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static std::atomic<unsigned long long> done{0};
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_relaxed) & bit)) {
+        (void)hipFuncSetAttribute((const void*)bn_mid_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BN_MID_HW * 4);
+        (void)hipFuncSetAttribute((const void*)bn_mid_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BN_MID_HW * 4);
+        done.fetch_or(bit, std::memory_order_relaxed);
+    }
+}
+// one image per parameter set (a single image, or independent generators) and per-image statistics: what the mid kernels cover
+static inline bool bn_mid_ok(int HW, int N, size_t p_nstride, int batch) {
+    static const int on = getenv("SPLICE_BN_MID") ? atoi(getenv("SPLICE_BN_MID")) : 1;
+    return on && HW > BN_SMALL_HW && HW <= BN_MID_HW && !batch && (N == 1 || p_nstride);
+}
+
 // the instantiation whose register tile just covers the plane (same arithmetic in the same order: the surplus elements of a
 // bigger tile only ever added zeros)
 #define BN_SMALL_DISPATCH(HW_, KERNEL, GRID, STREAM, ...)                                                         \
@@ -1180,12 +1308,21 @@ int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstri
                           (const float*)nullptr, 0, (const float*)nullptr, (float*)nullptr, u, p_nstride, batch);
         return SPLICE_OK;
     }
+    if (bn_mid_ok(HW, N, p_nstride, batch)) {
+        bn_mid_allow_lds();
+        SPLICE_LAUNCH(bn_mid_fwd_kernel, dim3(C, N), dim3(BN_MID_THREADS), (size_t)HW * 4, s, y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd, slope, u, p_nstride);
+        return SPLICE_OK;
+    }
     const int PB = plane_blocks(HW);
     SPLICE_LAUNCH(bn_stats_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, C, HW, PB, part, u);
     SPLICE_LAUNCH(bn_act_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, PB, gamma, beta, part, eps, mean, rstd, slope, p_nstride, batch);
     return SPLICE_OK;
 }
+// (middle planes fuse it too when bn_bwd_launch takes the one-launch form: the caller passes what bn_bwd_launch will see)
 bool bn_bwd_fuses_upsample(int HW, int h, int w) { return HW <= BN_SMALL_HW && h > 0 && w > 0; }
+bool bn_bwd_fuses_upsample_ex(int HW, int h, int w, int N, size_t p_nstride, int batch) {
+    return h > 0 && w > 0 && (HW <= BN_SMALL_HW || bn_mid_ok(HW, N, p_nstride, batch));
+}
 int bn_small_hw() { return BN_SMALL_HW; }
 int bn_fwd_slabs_launch(const float* slabs, int ksplit, const float* bias, float* y, size_t y_nstride, float* out, size_t out_nstride, int N,
                         int C, int HW, const float* gamma, const float* beta, float eps, float* mean, float* rstd, float slope, hipStream_t s, size_t p_nstride) {
@@ -1203,6 +1340,14 @@ int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t 
         if (!bn_bwd_fuses_upsample(HW, u.h, u.w)) u.d_src = nullptr;
         BN_SMALL_DISPATCH(HW, bn_small_bwd_kernel, dim3(C, N), s, da, da_nstride, aout, a_nstride, y, y_nstride, dy, dy_nstride, C, HW, N,
                           gamma, mean, rstd, slope, dgamma, dbeta, accumulate, u, p_nstride, batch);
+        return SPLICE_OK;
+    }
+    if (bn_mid_ok(HW, N, p_nstride, batch)) {
+        BnUpsample u = up ? *up : BnUpsample{};
+        if (!(u.h > 0 && u.w > 0)) u.d_src = nullptr;
+        bn_mid_allow_lds();
+        SPLICE_LAUNCH(bn_mid_bwd_kernel, dim3(C, N), dim3(BN_MID_THREADS), (size_t)HW * 4, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy, dy_nstride, C, HW, gamma, mean,
+                      rstd, slope, dgamma, dbeta, accumulate, u, p_nstride);
         return SPLICE_OK;
     }
     const int PB = plane_blocks(HW);

@@ -260,6 +260,21 @@ __device__ __forceinline__ void tri_tile(int t, int nt, int& tm, int& tn) {
 // upper-triangular tiles of S* = cos-sim(target keys) into the full-layout fp32 [T][T] buffer of each pair
 // FP8: the Gram matrix on the fp8 MFMA from per-row quantised keys (k8, e4m3; BASELINE configs[4]).  The cosine is scale
 // invariant per row, so the quantisation scales cancel against the norms of the QUANTISED rows (qnorm) exactly.
+// Row / column norms of a tile from the sums of squares run_ring_norms leaves in every lane (bf16 path: the norms come out of
+// the Gram kernels themselves -- the separate row-norm launch in front of each of them is gone, round 4)
+template <int FMt, int FNt>
+__device__ __forceinline__ void tile_norms(const float (&ssa)[FMt], const float (&ssb)[FNt], float (&nr)[FMt][4], float (&nc)[FNt]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < FMt; ++i) {
+        const float na = sqrtf(ssa[i]);            // A row i * 16 + (lane & 15) of this wave's sub-tile
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nr[i][r] = __shfl(na, (lane >> 4) * 4 + r, 64);   // the accumulator rows of this lane
+    }
+#pragma unroll
+    for (int j = 0; j < FNt; ++j) nc[j] = sqrtf(ssb[j]);   // B row = output column j * 16 + (lane & 15)
+}
+
 template <bool FP8>
 __global__ __launch_bounds__(256) void selfsim_tgt_kernel(SelfSimBatch b) {
     extern __shared__ __attribute__((aligned(16))) bf16_t selfsim_smem[];
@@ -267,24 +282,36 @@ __global__ __launch_bounds__(256) void selfsim_tgt_kernel(SelfSimBatch b) {
     int tm, tn;
     tri_tile(xcd_remap(blockIdx.x, gridDim.x), nt, tm, tn);
     const int m0 = tm * 64, n0 = tn * 64;
-    const float* norm = (FP8 ? b.qnorm_tgt : b.norm_tgt) + (size_t)pair * b.Tp;
     float* S = b.S_tgt + (size_t)pair * T * T;
     GemmTile<64, 64, false, FP8> tile;
-    if (FP8) {
+    if constexpr (FP8) {
+        const float* norm = b.qnorm_tgt + (size_t)pair * b.Tp;
         const bf16_t* K8 = reinterpret_cast<const bf16_t*>(b.k8_tgt + (size_t)pair * b.Tp * b.D);
         tile.template run_ring<SS_RING>(K8, b.D / 2, K8, b.D / 2, T, T, b.D / 2, m0, n0, selfsim_smem);
+        tile.for_each(m0, n0, [&](int row0, int col, f32x4 v) {
+            if (col >= T) return;
+            const float nj = norm[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (row0 + r < T) S[(size_t)(row0 + r) * T + col] = v[r] / fmaxf(norm[row0 + r] * nj, 1e-30f);
+        });
     } else {
         const bf16_t* K = b.k_tgt + (size_t)pair * b.k_pstride;
-        tile.template run_ring<SS_RING>(K, b.ldk, K, b.ldk, T, T, b.D, m0, n0, selfsim_smem);
-    }
-    const float floor_ = FP8 ? 1e-30f : b.eps;
-    tile.for_each(m0, n0, [&](int row0, int col, f32x4 v) {
-        if (col >= T) return;
-        const float nj = norm[col];
+        float ssa[2], ssb[2], nr[2][4], nc[2];
+        tile.template run_ring_norms<SS_RING>(K, b.ldk, K, b.ldk, T, T, b.D, m0, n0, selfsim_smem, ssa, ssb);
+        tile_norms<2, 2>(ssa, ssb, nr, nc);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (row0 + r < T) S[(size_t)(row0 + r) * T + col] = v[r] / fmaxf(norm[row0 + r] * nj, floor_);
-    });
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row0 = m0 + wm * 32 + i * 16 + (lane >> 4) * 4, col = n0 + wn * 32 + j * 16 + (lane & 15);
+                if (col >= T) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (row0 + r < T) S[(size_t)(row0 + r) * T + col] = tile.acc[i][j][r] / fmaxf(nr[i][r] * nc[j], b.eps);
+            }
+    }
 }
 
 template <bool FP8>
@@ -301,28 +328,42 @@ __global__ __launch_bounds__(256) void selfsim_loss_kernel(SelfSimBatch b) {
     const float* St = b.S_tgt + (size_t)pair * T * T;
     bf16_t* W = b.wmat + (size_t)pair * Tp * Tp;
     GemmTile<64, 64, false, FP8> tile;
-    if (FP8) {
-        const bf16_t* K8 = reinterpret_cast<const bf16_t*>(b.k8_x + (size_t)pair * Tp * b.D);
-        tile.template run_ring<SS_RING>(K8, b.D / 2, K8, b.D / 2, T, T, b.D / 2, m0, n0, selfsim_smem);
-    } else {
-        tile.template run_ring<SS_RING>(K, b.ldk, K, b.ldk, T, T, b.D, m0, n0, selfsim_smem);
-    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
     constexpr int FM = 2, FN = 2;
     // operands of every fragment first (clamped, always-valid addresses), arithmetic after
     float nr[FM][4], nc[FN], st[FM][FN][4], qr[FM][4], qc[FN];
-    const float* qnorm = FP8 ? b.qnorm_x + (size_t)pair * Tp : norm;
+    if constexpr (FP8) {
+        const bf16_t* K8 = reinterpret_cast<const bf16_t*>(b.k8_x + (size_t)pair * Tp * b.D);
+        tile.template run_ring<SS_RING>(K8, b.D / 2, K8, b.D / 2, T, T, b.D / 2, m0, n0, selfsim_smem);
+        const float* qnorm = b.qnorm_x + (size_t)pair * Tp;
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            nr[i][r] = norm[min(m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r, T - 1)];
-            qr[i][r] = qnorm[min(m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r, T - 1)];
+            for (int r = 0; r < 4; ++r) {
+                nr[i][r] = norm[min(m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r, T - 1)];
+                qr[i][r] = qnorm[min(m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r, T - 1)];
+            }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            nc[j] = norm[min(n0 + wn * 32 + j * 16 + (lane & 15), T - 1)];
+            qc[j] = qnorm[min(n0 + wn * 32 + j * 16 + (lane & 15), T - 1)];
+        }
+    } else {
+        // bf16: the key norms are by-products of this kernel's own operand stream (no row-norm launch in front of it); the
+        // diagonal tiles publish them for the dK kernel
+        float ssa[FM], ssb[FN];
+        tile.template run_ring_norms<SS_RING>(K, b.ldk, K, b.ldk, T, T, b.D, m0, n0, selfsim_smem, ssa, ssb);
+        tile_norms<FM, FN>(ssa, ssb, nr, nc);
+        if (!offdiag && wn == 0 && lane < 16) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) b.norm_x[(size_t)pair * Tp + m0 + wm * 32 + i * 16 + lane] = sqrtf(ssa[i]);
         }
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        nc[j] = norm[min(n0 + wn * 32 + j * 16 + (lane & 15), T - 1)];
-        qc[j] = qnorm[min(n0 + wn * 32 + j * 16 + (lane & 15), T - 1)];
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qr[i][r] = nr[i][r];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) qc[j] = nc[j];
     }
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -439,7 +480,6 @@ int selfsim_target_launch(const SelfSimBatch& b, hipStream_t s) {
         SPLICE_LAUNCH(selfsim_tgt_kernel<true>, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
         return SPLICE_OK;
     }
-    RC_SS(selfsim_norms_launch(b.k_tgt, b.ldk, b.k_pstride, b.T, b.D, b.norm_tgt, b.pairs, s));
     SPLICE_LAUNCH(selfsim_tgt_kernel<false>, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
     return SPLICE_OK;
 }
@@ -447,9 +487,9 @@ int selfsim_loss_launch(const SelfSimBatch& b, hipStream_t s) {
     SpliceProfScope prof_scope(8);
     const int nt = b.Tp / 64;
     if (nt * (nt + 1) / 2 > (int)b.part_pstride) return SPLICE_ERR_ARG;
-    RC_SS(selfsim_norms_launch(b.k_x, b.ldk, b.k_pstride, b.T, b.D, b.norm_x, b.pairs, s));   // true norms: W and r are in key units either way
     if (b.fp8) {
         if (b.D % 128) return SPLICE_ERR_ARG;
+        RC_SS(selfsim_norms_launch(b.k_x, b.ldk, b.k_pstride, b.T, b.D, b.norm_x, b.pairs, s));   // true norms: W and r are in key units either way
         RC_SS(quantize_keys_fp8_launch(b.k_x, b.ldk, b.k_pstride, b.k8_x, b.D, (size_t)b.Tp * b.D, b.qnorm_x, b.T, b.Tp, b.D, b.pairs, s));
         SPLICE_LAUNCH(selfsim_loss_kernel<true>, dim3(nt * (nt + 1) / 2, b.pairs), dim3(256), SS_LDS, s, b);
     } else {
