@@ -88,6 +88,7 @@ struct SpliceGenPlan {
     Unit u_skip[MAXS], u_da[MAXS], u_db[MAXS], u_cat[MAXS], u_up3[MAXS], u_up1[MAXS];
     float* cat[MAXS]; float* d_cat[MAXS]; // [N][skip+k][h][w]
     int kch[MAXS];
+    bool chain[MAXS];                     // scale i: the skip branch's BatchNorm runs inside the concat BatchNorm's kernels (BnPre), forward and backward
     float* pad_scratch = nullptr;         // reflection padding: padded-domain data gradient of one layer (largest layer)
     float* head_y = nullptr;              // unused (sigmoid fused)
     size_t head_w = 0, head_b = 0;
@@ -222,48 +223,81 @@ static void plan_configure(SpliceGenPlan* p, int H, int W) {
     p->forward_saved = 0;
 }
 
-static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* params, hipStream_t s, const BnUpsample* up = nullptr) {
+// the convolution of a unit as ConvArgs (ws / ws_floats: its split-K workspace)
+static ConvArgs unit_conv_args(const SpliceGenPlan* p, const Unit& u, const float* params, float* ws, size_t ws_floats) {
+    ConvArgs a = {};
+    a.in = u.in; a.w = params + u.w_off; a.bias = params + u.b_off; a.out = u.y;
+    a.in_nstride = u.in_ns; a.in_cstride = (size_t)u.Hi * u.Wi; a.out_nstride = u.y_ns; a.out_cstride = (size_t)u.Ho * u.Wo;
+    a.w_jstride = (size_t)u.Cin * u.ks * u.ks; a.w_cstride = (size_t)u.ks * u.ks; a.p_nstride = p->p_nstride;
+    a.N = p->N; a.Cin = u.Cin; a.Hi = u.Hi; a.Wi = u.Wi; a.Cout = u.Cout; a.Ho = u.Ho; a.Wo = u.Wo;
+    a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2; a.reflect = p->gen->arch.reflect && u.ks > 1;
+    a.ws = ws; a.ws_floats = ws_floats;
+    // small planes: a split-K convolution leaves its slabs for the BatchNorm kernel, which adds them while it loads the plane
+    a.defer_reduce = !p->batch_stats && u.Ho * u.Wo <= bn_small_hw();
+    return a;
+}
+// the skip unit of a scale as the BnPre of that scale's concat BatchNorm
+static BnPre skip_pre(const SpliceGenPlan* p, int i, const float* params, float* grads) {
+    const Unit& sk = p->u_skip[i];
+    BnPre pr;
+    pr.y = sk.y; pr.y_ns = sk.y_ns;
+    pr.gamma = params + sk.g_off; pr.beta = params + sk.be_off;
+    pr.mean = sk.mean; pr.rstd = sk.rstd; pr.slope = sk.slope; pr.C = sk.Cout;
+    pr.dy = sk.dy;
+    if (grads) { pr.dgamma = grads + sk.g_off; pr.dbeta = grads + sk.be_off; }
+    return pr;
+}
+// BatchNorm + activation of a unit behind its convolution (ksplit > 1 with a deferred reduction: the slabs at `slabs` are summed here)
+static int unit_bn_forward(const SpliceGenPlan* p, const Unit& u, const float* params, const float* y, size_t y_ns, const float* slabs, int ksplit,
+                           bool deferred, hipStream_t s, const BnUpsample* up, const BnPre* pre = nullptr) {
     const int N = p->N;
-    const float* y = u.in;
-    size_t y_ns = u.in_ns;
-    if (u.ks) {
-        ConvArgs a = {};
-        a.in = u.in; a.w = params + u.w_off; a.bias = params + u.b_off; a.out = u.y;
-        a.in_nstride = u.in_ns; a.in_cstride = (size_t)u.Hi * u.Wi; a.out_nstride = u.y_ns; a.out_cstride = (size_t)u.Ho * u.Wo;
-        a.w_jstride = (size_t)u.Cin * u.ks * u.ks; a.w_cstride = (size_t)u.ks * u.ks; a.p_nstride = p->p_nstride;
-        a.N = N; a.Cin = u.Cin; a.Hi = u.Hi; a.Wi = u.Wi; a.Cout = u.Cout; a.Ho = u.Ho; a.Wo = u.Wo;
-        a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2; a.reflect = p->gen->arch.reflect && u.ks > 1;
-        a.ws = p->conv_ws; a.ws_floats = p->conv_ws_floats;
-        // small planes: a split-K convolution leaves its slabs for the BatchNorm kernel, which adds them while it loads the plane
-        a.defer_reduce = !p->batch_stats && u.Ho * u.Wo <= bn_small_hw();
-        int ksplit = 1;
-        RC(conv_launch(a, s, &ksplit));
-        y = u.y; y_ns = u.y_ns;
-        if (a.defer_reduce && ksplit > 1) {
-            RC(bn_fwd_slabs_launch(p->conv_ws, ksplit, a.bias, u.y, u.y_ns, u.out, u.out_ns, N, u.Cout, u.Ho * u.Wo, params + u.g_off,
-                                   params + u.be_off, BN_EPS, u.mean, u.rstd, u.slope, s, p->p_nstride));
-            return SPLICE_OK;
-        }
+    if (deferred && ksplit > 1) {
+        RC(bn_fwd_slabs_launch(slabs, ksplit, params + u.b_off, u.y, u.y_ns, u.out, u.out_ns, N, u.Cout, u.Ho * u.Wo, params + u.g_off,
+                               params + u.be_off, BN_EPS, u.mean, u.rstd, u.slope, s, p->p_nstride));
+        return SPLICE_OK;
     }
     if (p->batch_stats && up) {   // batch statistics: the upsampled channels are materialised first (no fusion with the statistics pass)
         RC(upsample2x_fwd_launch(up->src, up->src_ns, const_cast<float*>(y) + (size_t)up->c0 * u.Ho * u.Wo, y_ns, N, u.Cout - up->c0, up->h, up->w, up->Ho, up->Wo, s));
         up = nullptr;
     }
     RC(bn_fwd_launch(y, y_ns, u.out, u.out_ns, N, u.Cout, u.Ho * u.Wo, params + u.g_off, params + u.be_off, BN_EPS, u.s1, u.mean, u.rstd, u.slope, s, up,
-                     p->p_nstride, p->batch_stats));
+                     p->p_nstride, p->batch_stats, pre));
+    return SPLICE_OK;
+}
+static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* params, hipStream_t s, const BnUpsample* up = nullptr, const BnPre* pre = nullptr) {
+    if (!u.ks) return unit_bn_forward(p, u, params, u.in, u.in_ns, nullptr, 1, false, s, up, pre);
+    const ConvArgs a = unit_conv_args(p, u, params, p->conv_ws, p->conv_ws_floats);
+    int ksplit = 1;
+    RC(conv_launch(a, s, &ksplit));
+    return unit_bn_forward(p, u, params, u.y, u.y_ns, p->conv_ws, ksplit, a.defer_reduce != 0, s, up);
+}
+// two units that read the same input and do not depend on each other (the skip branch and the first encoder convolution of a
+// scale): their convolutions share one launch (conv_pair_launch); a = the 1x1 unit
+// a_bn_later: a's BatchNorm runs inside a later kernel (BnPre of the concat BatchNorm): its convolution then writes its complete
+// output itself (no split-K: the slab workspace is reused long before that kernel runs)
+static int unit_pair_forward(const SpliceGenPlan* p, const Unit& ua, const Unit& ub, const float* params, hipStream_t s, bool a_bn_later) {
+    const size_t half = p->conv_ws_floats / 2;
+    const ConvArgs a = unit_conv_args(p, ua, params, a_bn_later ? nullptr : p->conv_ws, half), b = unit_conv_args(p, ub, params, p->conv_ws + half, half);
+    int ksa = 1, ksb = 1;
+    RC(conv_pair_launch(a, b, s, &ksa, &ksb));
+    if (!a_bn_later) RC(unit_bn_forward(p, ua, params, ua.y, ua.y_ns, a.ws, ksa, a.defer_reduce != 0, s, nullptr));
+    RC(unit_bn_forward(p, ub, params, ub.y, ub.y_ns, b.ws, ksb, b.defer_reduce != 0, s, nullptr));
     return SPLICE_OK;
 }
 
-// backward of one unit: consumes u.d_out, produces parameter grads and (optionally) u.d_in
-static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* params, float* grads, int acc, hipStream_t s,
-                         const BnUpsample* up = nullptr) {
+// backward of one unit, first part: BatchNorm backward (consumes u.d_out, leaves dy), the conv bias gradient (exact zero) and the
+// weight-gradient work item
+// bn_done: the BatchNorm backward of this unit has already run inside another kernel (BnPre)
+static int unit_backward_bn(const SpliceGenPlan* p, const Unit& u, const float* params, float* grads, int acc, hipStream_t s,
+                            const BnUpsample* up = nullptr, const BnPre* pre = nullptr, bool bn_done = false) {
     const int N = p->N, HW = u.Ho * u.Wo;
     const float* y = u.ks ? u.y : u.in;
     const size_t y_ns = u.ks ? u.y_ns : u.in_ns;
     float* dy = u.ks ? u.dy : u.d_in;          // BN-only unit: dy IS the input gradient
     const size_t dy_ns = u.ks ? u.y_ns : u.d_in_ns;
-    RC(bn_bwd_launch(u.d_out, u.d_out_ns, u.out, u.out_ns, y, y_ns, dy, dy_ns, N, u.Cout, HW, params + u.g_off, u.mean, u.rstd, u.slope,
-                     u.s1, grads + u.g_off, grads + u.be_off, acc, s, p->batch_stats ? nullptr : up, p->p_nstride, p->batch_stats));
+    if (!bn_done)
+        RC(bn_bwd_launch(u.d_out, u.d_out_ns, u.out, u.out_ns, y, y_ns, dy, dy_ns, N, u.Cout, HW, params + u.g_off, u.mean, u.rstd, u.slope,
+                         u.s1, grads + u.g_off, grads + u.be_off, acc, s, p->batch_stats ? nullptr : up, p->p_nstride, p->batch_stats, pre));
     if (!u.ks) return SPLICE_OK;
     // The bias of a conv that feeds a train-mode BatchNorm has an analytically ZERO gradient (BN subtracts the
     // per-channel mean, sum_p dy = 0); the reference's autograd returns fp32 rounding noise there.  We write the
@@ -286,18 +320,33 @@ static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* par
         const int li = r.count++;
         r.n[li] = u.Cout * u.Cin * u.ks * u.ks; r.chunks[li] = chunks; r.ws_off[li] = (long long)u.wg_off; r.dw_off[li] = (long long)u.w_off;
     }
-    if (u.d_in) {
-        ConvArgs a = {};
-        a.in = u.dy; a.w = params + u.w_off; a.bias = nullptr; a.out = u.d_in;
-        a.in_nstride = u.y_ns; a.in_cstride = (size_t)HW; a.out_nstride = u.d_in_ns; a.out_cstride = (size_t)u.Hi * u.Wi;
-        a.w_jstride = (size_t)u.ks * u.ks; a.w_cstride = (size_t)u.Cin * u.ks * u.ks; a.p_nstride = p->p_nstride;
-        a.N = N; a.Cin = u.Cout; a.Hi = u.Ho; a.Wi = u.Wo; a.Cout = u.Cin; a.Ho = u.Hi; a.Wo = u.Wi;
-        a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2; a.transposed = 1; a.accumulate = u.d_in_accumulate;
-        a.ws = p->conv_ws; a.ws_floats = p->conv_ws_floats;
-        if (p->gen->arch.reflect && u.ks > 1) RC(conv_reflect_dgrad_launch(a, p->pad_scratch, s));
-        else RC(conv_launch(a, s));
-    }
     return SPLICE_OK;
+}
+// the data-gradient convolution of a unit (dy -> d_in) in data-gradient form; accumulate: 1 = add into d_in
+static ConvArgs unit_dgrad_args(const SpliceGenPlan* p, const Unit& u, const float* params, int accumulate, float* ws, size_t ws_floats) {
+    const int HW = u.Ho * u.Wo;
+    ConvArgs a = {};
+    a.in = u.dy; a.w = params + u.w_off; a.bias = nullptr; a.out = u.d_in;
+    a.in_nstride = u.y_ns; a.in_cstride = (size_t)HW; a.out_nstride = u.d_in_ns; a.out_cstride = (size_t)u.Hi * u.Wi;
+    a.w_jstride = (size_t)u.ks * u.ks; a.w_cstride = (size_t)u.Cin * u.ks * u.ks; a.p_nstride = p->p_nstride;
+    a.N = p->N; a.Cin = u.Cout; a.Hi = u.Ho; a.Wi = u.Wo; a.Cout = u.Cin; a.Ho = u.Hi; a.Wo = u.Wi;
+    a.ks = u.ks; a.stride = u.stride; a.pad = (u.ks - 1) / 2; a.transposed = 1; a.accumulate = accumulate;
+    a.ws = ws; a.ws_floats = ws_floats;
+    return a;
+}
+// second part: the data gradient (if the unit's input needs one)
+static int unit_backward_dgrad(const SpliceGenPlan* p, const Unit& u, const float* params, int accumulate, hipStream_t s) {
+    if (!u.ks || !u.d_in) return SPLICE_OK;
+    const ConvArgs a = unit_dgrad_args(p, u, params, accumulate, p->conv_ws, p->conv_ws_floats);
+    if (p->gen->arch.reflect && u.ks > 1) RC(conv_reflect_dgrad_launch(a, p->pad_scratch, s));
+    else RC(conv_launch(a, s));
+    return SPLICE_OK;
+}
+// backward of one unit: consumes u.d_out, produces parameter grads and (optionally) u.d_in
+static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* params, float* grads, int acc, hipStream_t s,
+                         const BnUpsample* up = nullptr, const BnPre* pre = nullptr, bool bn_done = false) {
+    RC(unit_backward_bn(p, u, params, grads, acc, s, up, pre, bn_done));
+    return unit_backward_dgrad(p, u, params, u.d_in_accumulate, s);
 }
 
 static size_t wgrad_ws_need(const SpliceGenPlan* p, const Unit& u) {
@@ -441,6 +490,7 @@ int splice_gen_plan_set_arena_stride(void* plan, long long stride) {
         return SPLICE_ERR_ARG;
     }
     p->p_nstride = (size_t)stride;
+    plan_configure(p, p->H, p->W);   // (the BatchNorm launch forms depend on it)
     return SPLICE_OK;
 }
 
@@ -454,6 +504,7 @@ int splice_gen_plan_set_batch_stats(void* plan, int on) {
         return SPLICE_ERR_ARG;
     }
     p->batch_stats = on ? 1 : 0;
+    plan_configure(p, p->H, p->W);
     return SPLICE_OK;
 }
 
@@ -512,8 +563,7 @@ void splice_gen_plan_destroy(void* plan) {
 }
 
 static int scale_forward(SpliceGenPlan* p, int i, const float* params, hipStream_t s) {
-    RC(unit_forward(p, p->u_skip[i], params, s));
-    RC(unit_forward(p, p->u_da[i], params, s));
+    RC(unit_pair_forward(p, p->u_skip[i], p->u_da[i], params, s, p->chain[i]));
     RC(unit_forward(p, p->u_db[i], params, s));
     const float* deep = p->u_db[i].out;
     size_t deep_ns = p->u_db[i].out_ns;
@@ -528,7 +578,8 @@ static int scale_forward(SpliceGenPlan* p, int i, const float* params, hipStream
     // BatchNorm kernels (bn_fwd_launch with a BnUpsample), not by a launch of its own
     BnUpsample up;
     up.src = deep; up.src_ns = deep_ns; up.c0 = SKIPC; up.h = p->h[i + 1]; up.w = p->w[i + 1]; up.Ho = hi; up.Wo = wi;
-    RC(unit_forward(p, p->u_cat[i], params, s, &up));
+    const BnPre pre = skip_pre(p, i, params, nullptr);
+    RC(unit_forward(p, p->u_cat[i], params, s, &up, p->chain[i] ? &pre : nullptr));
     RC(unit_forward(p, p->u_up3[i], params, s));
     RC(unit_forward(p, p->u_up1[i], params, s));
     return SPLICE_OK;
@@ -579,9 +630,10 @@ int splice_gen_forward_borrowed(void* plan, const float* params, const float* x,
     return gen_forward_impl(plan, params, x, y, true, stream);
 }
 
-static int scale_backward(SpliceGenPlan* p, int i, const float* params, float* grads, int acc, hipStream_t s) {
+// head_done: the caller has already run the backward of u_up1[i] (paired with the shallower scale's skip branch)
+static int scale_backward(SpliceGenPlan* p, int i, const float* params, float* grads, int acc, hipStream_t s, bool head_done = false) {
     // u_up1[i].d_out holds d u_i
-    RC(unit_backward(p, p->u_up1[i], params, grads, acc, s));
+    if (!head_done) RC(unit_backward(p, p->u_up1[i], params, grads, acc, s));
     RC(unit_backward(p, p->u_up3[i], params, grads, acc, s));
     const int hi = p->h[i], wi = p->w[i];
     const GenArch& A = p->gen->arch;
@@ -590,14 +642,29 @@ static int scale_backward(SpliceGenPlan* p, int i, const float* params, float* g
     // small planes: the upsampled channels' gradient goes through the adjoint inside the concat's BatchNorm backward
     BnUpsample up;
     up.d_src = deep.d_out; up.d_src_ns = deep.d_out_ns; up.c0 = SKIPC; up.h = p->h[i + 1]; up.w = p->w[i + 1]; up.Ho = hi; up.Wo = wi;
-    RC(unit_backward(p, p->u_cat[i], params, grads, acc, s, &up));   // -> d_cat[i]
+    const BnPre pre = skip_pre(p, i, params, grads);
+    const bool chained = p->chain[i];
+    RC(unit_backward(p, p->u_cat[i], params, grads, acc, s, &up, chained ? &pre : nullptr));   // -> d_cat[i] (chained: the skip channels' gradient goes on into u_skip[i].dy)
     if (p->batch_stats || !bn_bwd_fuses_upsample_ex(hi * wi, up.h, up.w, p->N, p->p_nstride, p->batch_stats))
         RC(upsample2x_bwd_launch(p->d_cat[i] + (size_t)SKIPC * hi * wi, p->u_skip[i].d_out_ns, deep.d_out, deep.d_out_ns, p->N, p->kch[i],
                                  p->h[i + 1], p->w[i + 1], hi, wi, s));
-    if (i < A.n_scales - 1) RC(scale_backward(p, i + 1, params, grads, acc, s));   // leaves d x_{i+1} in u_db[i].d_out
+    // The skip branch's backward depends on nothing deeper: where its input needs a gradient (every scale but the first) and a
+    // deeper scale exists, it runs NOW, and its 1x1 data gradient shares a launch with the 1x1 data gradient of the deeper
+    // scale's decoder output unit (two independent convolutions, conv_pair_launch).  It is then the FIRST writer of d x_i and
+    // the encoder convolution's data gradient adds to it (a + b = b + a: the same bits as the other order).
+    const bool skip_early = i < A.n_scales - 1 && p->u_skip[i].d_in != nullptr ;
+    if (skip_early) {
+        const Unit &sk = p->u_skip[i], &h1 = p->u_up1[i + 1];
+        RC(unit_backward_bn(p, sk, params, grads, acc, s, nullptr, nullptr, chained));
+        RC(unit_backward_bn(p, h1, params, grads, acc, s));
+        const size_t half = p->conv_ws_floats / 2;
+        RC(conv_pair_launch(unit_dgrad_args(p, sk, params, 0, p->conv_ws, half), unit_dgrad_args(p, h1, params, h1.d_in_accumulate, p->conv_ws + half, half), s));
+    }
+    if (i < A.n_scales - 1) RC(scale_backward(p, i + 1, params, grads, acc, s, skip_early));   // leaves d x_{i+1} in u_db[i].d_out
     RC(unit_backward(p, p->u_db[i], params, grads, acc, s));
-    RC(unit_backward(p, p->u_da[i], params, grads, acc, s));
-    RC(unit_backward(p, p->u_skip[i], params, grads, acc, s));
+    RC(unit_backward_bn(p, p->u_da[i], params, grads, acc, s));
+    RC(unit_backward_dgrad(p, p->u_da[i], params, skip_early ? 1 : p->u_da[i].d_in_accumulate, s));
+    if (!skip_early) RC(unit_backward(p, p->u_skip[i], params, grads, acc, s, nullptr, nullptr, chained));
     return SPLICE_OK;
 }
 

@@ -22,6 +22,9 @@ struct ConvArgs {
     int defer_reduce; // split-K: leave the raw slabs in ws (ksplit_out tells how many); the consumer adds bias + slabs in slice order
 };
 int conv_launch(const ConvArgs& a, hipStream_t s, int* ksplit_out = nullptr);
+// two independent convolutions (a: 1x1, stride 1) in ONE launch where an instantiation exists, else two launches; same results
+// as two conv_launch calls up to the summation order of `a` (it adopts b's wave groups)
+int conv_pair_launch(ConvArgs a, ConvArgs b, hipStream_t s, int* ksplit_a = nullptr, int* ksplit_b = nullptr);
 // data gradient of a reflection-padded convolution (transposed conv on the padded domain + mirror fold); see gen_kernels.hip
 int conv_reflect_dgrad_launch(ConvArgs a, float* pad_scratch, hipStream_t s);
 
@@ -74,11 +77,29 @@ struct BnUpsample {
     float* d_src = nullptr; size_t d_src_ns = 0;
     int c0 = 0, h = 0, w = 0, Ho = 0, Wo = 0;
 };
+// A BatchNorm + LeakyReLU that sits in FRONT of the first `C` channels of a concat BatchNorm's input (the skip branch of a scale:
+// models/unet/skip.py:60-62 feeding the Concat + BatchNorm of :75-81).  Both BatchNorms of such a channel are reductions over the
+// SAME plane, so the workgroup that owns the plane in the concat's one-launch BatchNorm kernels runs the skip branch's first
+// (forward: statistics, normalise, activate, store into the concat buffer; backward: the adjoint behind the concat's) -- the skip
+// branch's BatchNorm has no launch of its own in either direction (round 4).
+struct BnPre {
+    const float* y = nullptr; size_t y_ns = 0;      // the skip convolution's output [N][C][HW] (forward: input; slabs != null: formed and stored here)
+    const float* slabs = nullptr; int ksplit = 0;    // split-K slabs of that convolution (deferred reduction), with its bias
+    const float* bias = nullptr;
+    const float* gamma = nullptr; const float* beta = nullptr;   // the skip BatchNorm's parameters (image n at + n * p_nstride)
+    float* mean = nullptr; float* rstd = nullptr;    // its saved statistics [N][C]
+    float slope = 0.2f;
+    int C = 0;
+    // backward only
+    float* dy = nullptr;                             // gradient w.r.t. the skip convolution's output [N][C][HW]
+    float* dgamma = nullptr; float* dbeta = nullptr;
+};
+bool bn_pre_supported(int HW, int N, size_t p_nstride, int batch);   // the concat BatchNorm of this size runs as ONE launch that can host a BnPre
 bool bn_bwd_fuses_upsample(int HW, int h, int w);
 bool bn_bwd_fuses_upsample_ex(int HW, int h, int w, int N, size_t p_nstride, int batch);   // incl. the one-launch form of the middle planes
 int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
                   const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s, const BnUpsample* up = nullptr,
-                  size_t p_nstride = 0, int batch = 0);   // batch != 0: statistics over all N images (nn.BatchNorm2d on a batch), N <= 8
+                  size_t p_nstride = 0, int batch = 0, const BnPre* pre = nullptr);   // batch != 0: statistics over all N images (nn.BatchNorm2d on a batch), N <= 8
 // same, fused with the split-K reduction of the convolution that feeds it (small planes only: HW <= bn_small_hw()):
 // y = bias + sum_k slabs[k] is formed, stored (the backward reads it) and normalised in one launch
 int bn_small_hw();
@@ -88,7 +109,7 @@ int bn_fwd_slabs_launch(const float* slabs, int ksplit, const float* bias, float
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
                   float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up = nullptr, size_t p_nstride = 0,
-                  int batch = 0);
+                  int batch = 0, const BnPre* pre = nullptr);
 int fill_zero_launch(float* p, int n, hipStream_t s);
 int channel_sum_launch(const float* dy, size_t nstride, int N, int C, int HW, float* db, int accumulate, hipStream_t s);
 int upsample2x_fwd_launch(const float* in, size_t in_nstride, float* out, size_t out_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s);

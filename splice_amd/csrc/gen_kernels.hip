@@ -24,13 +24,24 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // NG = 2: an 8-wave workgroup -- the second wave group takes the other half of every K tile's MFMA steps (and half of
 // the gather), its accumulators are added through LDS at the end.  For the layers with at most ~2 workgroups per CU the
 // run time is the serial K walk of one workgroup (fp32 MFMA: 32 cycles per 16x16x4 step), and this halves it.
+template <int KS, int FN, int CK>
+struct ConvTile {   // LDS geometry of one instantiation (shared by the kernel wrappers that carve the LDS)
+    static constexpr int T = KS * KS, KT = CK * T, BM = 64;
+    static constexpr int LDA = KS == 7 ? BM + 1 : BM + 16;   // 80: k-rows 16 banks apart -> conflict-free ds_read_b32 (7x7: 65, the 196-row tile must fit 64 KB)
+    static constexpr int LDW = KT + 2;                        // 2*odd -> conflict-free
+    static constexpr int A_FLOATS = KT * LDA, W_FLOATS = 16 * FN * LDW;
+};
+// bx / by / bz: the block coordinates of a launch of this convolution alone (m tile, n tile * ksplit + slice, image); As / Ws:
+// ConvTile<..>::A_FLOATS / W_FLOATS floats of LDS.  Called from conv_igemm_kernel (one convolution per launch) and from
+// conv_pair_kernel (two independent convolutions -- e.g. the 1x1 skip branch and the 3x3 stride-2 encoder convolution of one
+// scale, which read the same input -- sharing one launch: a launch less on a latency-bound chain).
 template <int KS, bool TRANSPOSED, int FN, int CK, int NG>
-__global__ __launch_bounds__(256 * NG) void conv_igemm_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, int bx, int by, int bz, float* As, float* Ws) {
     constexpr int T = KS * KS;
     constexpr int KT = CK * T;          // k extent of one LDS tile (multiple of 4)
     constexpr int BM = 64;
-    constexpr int LDA = KS == 7 ? BM + 1 : BM + 16;   // 80: k-rows 16 banks apart -> conflict-free ds_read_b32 (7x7: 65, the 196-row tile must fit 64 KB)
-    constexpr int LDW = KT + 2;         // 2*odd -> conflict-free
+    constexpr int LDA = ConvTile<KS, FN, CK>::LDA;
+    constexpr int LDW = ConvTile<KS, FN, CK>::LDW;
     constexpr int BN = 16 * FN;
     constexpr int NTH = 256 * NG;
     constexpr int NWV = 4 * NG;                     // waves
@@ -39,12 +50,10 @@ __global__ __launch_bounds__(256 * NG) void conv_igemm_kernel(ConvArgs a) {
     constexpr int KSTEPS = KT / 4 / NG;             // MFMA k steps per wave group per tile
     static_assert(KT % (4 * NG) == 0 && ((LDW / 2) & 1) == 1, "tile shape");
     static_assert(NG == 1 || KT * LDA >= FN * 4 * 256, "accumulator exchange reuses the A tile");
-    __shared__ float As[KT * LDA];
-    __shared__ float Ws[BN * LDW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pw = wave & 3, grp = wave >> 2;       // pixel fragment / wave group
-    const int img = blockIdx.z;
-    const int m0 = blockIdx.x * BM;
+    const int img = bz;
+    const int m0 = bx * BM;
     const int HWo = a.Ho * a.Wo;
     const float* in = a.in + (size_t)img * a.in_nstride;
     // independent images (several pairs optimised side by side): image n convolves with ITS OWN parameter arena
@@ -57,8 +66,8 @@ __global__ __launch_bounds__(256 * NG) void conv_igemm_kernel(ConvArgs a) {
     // split-K: blockIdx.y = n_tile * ksplit + slice; each slice reduces its own channel range and writes a raw
     // partial tile that conv_splitk_reduce_kernel sums in slice order (tiny deep layers: few tiles, long reductions)
     const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
-    const int kslice = blockIdx.y % ksplit;
-    const int n0 = (blockIdx.y / ksplit) * BN;
+    const int kslice = by % ksplit;
+    const int n0 = (by / ksplit) * BN;
     const int cper = ((a.Cin + ksplit - 1) / ksplit + CK - 1) / CK * CK;
     const int cbeg = kslice * cper;
     const int Kc = min(a.Cin, cbeg + cper);  // reduction channels [cbeg, Kc)
@@ -204,6 +213,28 @@ __global__ __launch_bounds__(256 * NG) void conv_igemm_kernel(ConvArgs a) {
     }
 }
 
+template <int KS, bool TRANSPOSED, int FN, int CK, int NG>
+__global__ __launch_bounds__(256 * NG) void conv_igemm_kernel(ConvArgs a) {
+    __shared__ float As[ConvTile<KS, FN, CK>::A_FLOATS];
+    __shared__ float Ws[ConvTile<KS, FN, CK>::W_FLOATS];
+    conv_igemm_body<KS, TRANSPOSED, FN, CK, NG>(a, blockIdx.x, blockIdx.y, blockIdx.z, As, Ws);
+}
+// Two independent convolutions in one launch: blocks [0, na) run convolution A (KS = KSA ...), the rest convolution B; each with
+// the block coordinates of its own grid (gxa = A's gridDim.x, gxb = B's), blockIdx.z = image for both.  NG (waves per
+// workgroup / 4) is common; LDS is the larger of the two footprints.
+template <int KSA, bool TRA, int FNA, int CKA, int KSB, bool TRB, int FNB, int CKB, int NG>
+__global__ __launch_bounds__(256 * NG) void conv_pair_kernel(ConvArgs a, ConvArgs b, int na, int gxa, int gxb) {
+    using TA = ConvTile<KSA, FNA, CKA>;
+    using TB = ConvTile<KSB, FNB, CKB>;
+    constexpr int AF = TA::A_FLOATS > TB::A_FLOATS ? TA::A_FLOATS : TB::A_FLOATS;
+    constexpr int WF = TA::W_FLOATS > TB::W_FLOATS ? TA::W_FLOATS : TB::W_FLOATS;
+    __shared__ float As[AF];
+    __shared__ float Ws[WF];
+    const int bid = blockIdx.x;
+    if (bid < na) conv_igemm_body<KSA, TRA, FNA, CKA, NG>(a, bid % gxa, bid / gxa, blockIdx.z, As, Ws);
+    else conv_igemm_body<KSB, TRB, FNB, CKB, NG>(b, (bid - na) % gxb, (bid - na) / gxb, blockIdx.z, As, Ws);
+}
+
 // out = (accumulate ? out : 0) + bias + sum_slices ws   (slice order fixed)
 __global__ void conv_splitk_reduce_kernel(ConvArgs a, int ksplit) {
     const int HWo = a.Ho * a.Wo;
@@ -227,8 +258,10 @@ __global__ void conv_splitk_reduce_kernel(ConvArgs a, int ksplit) {
     }
 }
 
-template <int KS, bool TR, int CK>
-static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
+// launch policy of one convolution (KS x KS filter, CK channels per K tile): output-channel fragments per workgroup, 8-wave
+// workgroups (NG = 2), split-K; the grid is (mt, ny, N)
+struct ConvPolicy { int fn_run, ng, ksplit, mt, ny; };
+static ConvPolicy conv_policy(const ConvArgs& a, int KS, int CK) {
     const int HWo = a.Ho * a.Wo;
     const int mt = cdiv(HWo, 64);
     // output-channel fragments per workgroup, tuned in-step with alternating runs: the 64 / 128-channel layers of the deep
@@ -259,34 +292,96 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
         if (ksplit > 16) ksplit = 16;
         if (ksplit < 2) ksplit = 1;
     }
-    a.ksplit = ksplit;
-    dim3 grid(mt, nt_run * ksplit, a.N);
     // 8-wave workgroups while the chip holds at most ~2 workgroups per CU (the serial K walk is the run time then)
+    // (K tile of 72: 9 steps per wave group; the A tile is big enough for the exchange)
+    const bool can8 = KS == 3 && CK == 8;
+    const bool ng2 = can8 && (long)mt * nt * ksplit * npol <= 2048 && cdiv(a.Cin, CK) >= 2;
+    ConvPolicy p;
+    p.fn_run = KS >= 5 ? 1 : fn_run;
+    p.ng = ng2 ? 2 : 1;
+    p.ksplit = ksplit;
+    p.mt = mt;
+    p.ny = (KS >= 5 ? cdiv(a.Cout, 16) : nt_run) * ksplit;
+    return p;
+}
+static void conv_splitk_reduce_launch(const ConvArgs& a, int ksplit, hipStream_t s) {
+    const size_t per = (size_t)a.N * a.Cout * a.Ho * a.Wo;
+    size_t g = (per + 255) / 256;
+    if (g > 1024) g = 1024;
+    SPLICE_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, a, ksplit);
+}
+
+template <int KS, bool TR, int CK>
+static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
+    const ConvPolicy pol = conv_policy(a, KS, CK);
+    a.ksplit = pol.ksplit;
+    const dim3 grid(pol.mt, pol.ny, a.N);
     constexpr bool CAN8 = KS == 3 && CK == 8;
     if constexpr (KS >= 5) {   // 5x5 / 7x7 (the inversion experiment's generator): one fragment per workgroup, 4 waves
-        SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 1, CK, 1>), dim3(mt, cdiv(a.Cout, 16) * ksplit, a.N), dim3(256), 0, s, a);
+        SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 1, CK, 1>), grid, dim3(256), 0, s, a);
     } else {
-        // (K tile of 72: 9 steps per wave group; the A tile is big enough for the exchange)
-        const bool ng2 = CAN8 && (long)mt * nt * ksplit * npol <= 2048 && cdiv(a.Cin, CK) >= 2;
-        if (ng2) {
+        if (pol.ng == 2) {
             if constexpr (CAN8) {
-                if (fn_run == 1) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 1, CK, 2>), grid, dim3(512), 0, s, a);
-                else if (fn_run == 2) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 2, CK, 2>), grid, dim3(512), 0, s, a);
+                if (pol.fn_run == 1) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 1, CK, 2>), grid, dim3(512), 0, s, a);
+                else if (pol.fn_run == 2) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 2, CK, 2>), grid, dim3(512), 0, s, a);
                 else SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 4, CK, 2>), grid, dim3(512), 0, s, a);
             }
         } else {
-            if (fn_run == 1) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 1, CK, 1>), grid, dim3(256), 0, s, a);
-            else if (fn_run == 2) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 2, CK, 1>), grid, dim3(256), 0, s, a);
+            if (pol.fn_run == 1) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 1, CK, 1>), grid, dim3(256), 0, s, a);
+            else if (pol.fn_run == 2) SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 2, CK, 1>), grid, dim3(256), 0, s, a);
             else SPLICE_LAUNCH((conv_igemm_kernel<KS, TR, 4, CK, 1>), grid, dim3(256), 0, s, a);
         }
     }
-    if (ksplit_out) *ksplit_out = ksplit;
-    if (ksplit > 1 && !a.defer_reduce) {
-        const size_t per = (size_t)a.N * a.Cout * HWo;
-        size_t g = (per + 255) / 256;
-        if (g > 1024) g = 1024;
-        SPLICE_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, a, ksplit);
+    if (ksplit_out) *ksplit_out = pol.ksplit;
+    if (pol.ksplit > 1 && !a.defer_reduce) conv_splitk_reduce_launch(a, pol.ksplit, s);
+}
+
+// channels per K tile as conv_launch picks them (deeper tiles where the reduction is long)
+static inline int conv_ck(const ConvArgs& a) { return a.ks == 3 ? (a.Cin >= 32 ? 8 : 4) : a.ks == 1 ? (a.Cin >= 64 ? 32 : 16) : 4; }
+
+// Two INDEPENDENT convolutions in one launch (conv_pair_kernel).  Forward: a = the 1x1 skip convolution of a scale, b = its 3x3
+// stride-2 encoder convolution (same input, models/unet/skip.py:60-66); backward: two 1x1 data-gradient convolutions (the skip
+// branch's and the deeper scale's last decoder convolution).  Each keeps the launch policy, the split-K workspace and the bits
+// of its own launch except that `a` adopts b's waves per workgroup.  Combinations outside the instantiated set, reflection
+// padding or 5x5 / 7x7 filters fall back to two launches.  Returns through ksplit_a / ksplit_b what conv_launch would.
+template <int KSA, bool TRA, int FNA, int CKA, int KSB, bool TRB, int FNB, int CKB, int NG>
+static void conv_pair_go(const ConvArgs& a, const ConvArgs& b, const ConvPolicy& pa, const ConvPolicy& pb, hipStream_t s) {
+    const int na = pa.mt * pa.ny, nb = pb.mt * pb.ny;
+    SPLICE_LAUNCH((conv_pair_kernel<KSA, TRA, FNA, CKA, KSB, TRB, FNB, CKB, NG>), dim3(na + nb, 1, a.N), dim3(256 * NG), 0, s, a, b, na, pa.mt, pb.mt);
+}
+int conv_pair_launch(ConvArgs a, ConvArgs b, hipStream_t s, int* ksplit_a, int* ksplit_b) {
+    static const int pair_on = getenv("SPLICE_CONV_PAIR") ? atoi(getenv("SPLICE_CONV_PAIR")) : 1;
+    const int cka = conv_ck(a), ckb = conv_ck(b);
+    bool done = false;
+    if (pair_on && a.N == b.N && !a.reflect && !b.reflect && a.ks == 1 && a.stride == 1 && (b.stride == 1 || b.stride == 2) && a.transposed == b.transposed &&
+        (size_t)a.Cin * a.in_cstride <= 0x7fffffffULL && (size_t)b.Cin * b.in_cstride <= 0x7fffffffULL) {
+        ConvPolicy pa = conv_policy(a, 1, cka), pb = conv_policy(b, b.ks, ckb);
+        pa.ng = pb.ng;     // one workgroup size per launch: the 1x1 convolution walks its K tiles with b's wave groups
+        a.ksplit = pa.ksplit; b.ksplit = pb.ksplit;
+#define PAIR(TR_, FNA_, CKA_, KSB_, FNB_, CKB_, NG_)                                                                                         \
+    if (!done && a.transposed == (TR_ ? 1 : 0) && pa.fn_run == FNA_ && cka == CKA_ && b.ks == KSB_ && pb.fn_run == FNB_ && ckb == CKB_ && pb.ng == NG_) { \
+        conv_pair_go<1, TR_, FNA_, CKA_, KSB_, TR_, FNB_, CKB_, NG_>(a, b, pa, pb, s);                                                       \
+        done = true;                                                                                                                          \
     }
+        // forward: skip (Cout = 4: one fragment) || 3x3 encoder convolution
+        PAIR(false, 1, 16, 3, 1, 4, 1) PAIR(false, 1, 16, 3, 2, 4, 1)
+        PAIR(false, 1, 16, 3, 1, 8, 1) PAIR(false, 1, 16, 3, 2, 8, 1) PAIR(false, 1, 16, 3, 1, 8, 2) PAIR(false, 1, 16, 3, 2, 8, 2)
+        PAIR(false, 1, 32, 3, 1, 8, 1) PAIR(false, 1, 32, 3, 2, 8, 1) PAIR(false, 1, 32, 3, 1, 8, 2) PAIR(false, 1, 32, 3, 2, 8, 2)
+        // backward: skip data gradient (4 -> Cin channels) || 1x1 data gradient of the deeper scale's decoder output convolution
+        PAIR(true, 1, 16, 1, 1, 16, 1) PAIR(true, 1, 16, 1, 2, 16, 1) PAIR(true, 2, 16, 1, 1, 16, 1) PAIR(true, 2, 16, 1, 2, 16, 1)
+        PAIR(true, 1, 16, 1, 1, 32, 1) PAIR(true, 1, 16, 1, 2, 32, 1) PAIR(true, 2, 16, 1, 1, 32, 1) PAIR(true, 2, 16, 1, 2, 32, 1)
+#undef PAIR
+        if (done) {
+            if (ksplit_a) *ksplit_a = pa.ksplit;
+            if (ksplit_b) *ksplit_b = pb.ksplit;
+            if (pa.ksplit > 1 && !a.defer_reduce) conv_splitk_reduce_launch(a, pa.ksplit, s);
+            if (pb.ksplit > 1 && !b.defer_reduce) conv_splitk_reduce_launch(b, pb.ksplit, s);
+            return SPLICE_OK;
+        }
+    }
+    int rc = conv_launch(a, s, ksplit_a);
+    if (rc != SPLICE_OK) return rc;
+    return conv_launch(b, s, ksplit_b);
 }
 
 int conv_launch(const ConvArgs& a, hipStream_t s, int* ksplit_out) {
@@ -905,7 +1000,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
                                                            const float* __restrict__ beta, float eps, float* __restrict__ mean_o,
                                                            float* __restrict__ rstd_o, float slope, const float* __restrict__ slabs,
                                                            int ksplit, const float* __restrict__ bias, float* __restrict__ y_out, BnUpsample up,
-                                                           size_t p_nstride, int batch) {
+                                                           size_t p_nstride, int batch, BnPre pre) {
     __shared__ float red[8];
     __shared__ float up_src_s[BN_UP_SRC];
     const int c = blockIdx.x, img = blockIdx.y;
@@ -917,7 +1012,81 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
     // is masked afterwards): lane-guarded loads compile to load + s_waitcnt per element, i.e. one memory round trip each
     float v[PER];
     float s = 0.f, dummy = 0.f;
-    if (slabs) {
+    if (pre.y && c < pre.C) {
+        // ---- the skip branch's own BatchNorm + LeakyReLU on this plane (BnPre), in front of the concat's: the plane is formed
+        // (from the skip convolution's output, or from its split-K slabs + bias), normalised with ITS statistics, activated and
+        // stored into the concat buffer (the backward reads it there); v then holds the concat BatchNorm's input
+        const float* py1 = pre.y + (size_t)img * pre.y_ns + (size_t)c * HW;
+        if (pre.slabs) {
+            const size_t per = (size_t)gridDim.y * pre.C * HW;
+            const float* sp = pre.slabs + ((size_t)img * pre.C + c) * HW;
+            float* yo = const_cast<float*>(py1);
+            const float b = pre.bias ? pre.bias[(size_t)img * p_nstride + c] : 0.f;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) v[k] = b;
+            for (int ks = 0; ks < pre.ksplit; ks += 4) {   // slice order, four slices of loads in flight (as the slabs path below)
+                float t[4][PER];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (ks + u >= pre.ksplit) continue;
+                    const float* sk = sp + (size_t)(ks + u) * per;
+#pragma unroll
+                    for (int k = 0; k < PER; ++k) {
+                        if (k * 256 >= HW) continue;
+                        const int i = threadIdx.x + k * 256;
+                        t[u][k] = sk[i < HW ? i : 0];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (ks + u >= pre.ksplit) continue;
+#pragma unroll
+                    for (int k = 0; k < PER; ++k)
+                        if (k * 256 < HW) v[k] += t[u][k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i = threadIdx.x + k * 256;
+                if (i < HW) yo[i] = v[k]; else v[k] = 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i = threadIdx.x + k * 256;
+                v[k] = k * 256 < HW ? py1[i < HW ? i : 0] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+                if (threadIdx.x + k * 256 >= HW) v[k] = 0.f;
+        }
+        float s1 = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) s1 += v[k];
+        block_sum2(s1, d1, red);
+        const float m1 = s1 / (float)HW;
+        float q1 = 0.f;
+        d1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const float d = threadIdx.x + k * 256 < HW ? v[k] - m1 : 0.f;
+            q1 += d * d;
+        }
+        block_sum2(q1, d1, red);
+        const float r1 = rsqrtf(q1 / (float)HW + eps);
+        if (threadIdx.x == 0) { pre.mean[img * pre.C + c] = m1; pre.rstd[img * pre.C + c] = r1; }
+        const float sc1 = pre.gamma[(size_t)img * p_nstride + c] * r1;
+        const float sh1 = pre.beta[(size_t)img * p_nstride + c] - m1 * sc1;
+        float* yo2 = const_cast<float*>(p);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * 256;
+            const float t = v[k] * sc1 + sh1;
+            v[k] = i < HW ? (t > 0.f ? t : t * pre.slope) : 0.f;
+            if (i < HW) yo2[i] = v[k];
+            s += v[k];
+        }
+    } else if (slabs) {
         const size_t per = (size_t)gridDim.y * C * HW;
         const float* sp = slabs + ((size_t)img * C + c) * HW;
         float* yo = y_out + (size_t)img * y_nstride + (size_t)c * HW;
@@ -1085,13 +1254,14 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
                                                            float* __restrict__ dy, size_t dy_nstride, int C, int HW, int N,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, float slope, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int accumulate, BnUpsample up, size_t p_nstride, int batch) {
+                                                           float* __restrict__ dbeta, int accumulate, BnUpsample up, size_t p_nstride, int batch, BnPre pre) {
     __shared__ float red[8];
     __shared__ float up_grad_s[BN_SMALL_HW];   // fused upsampling adjoint: this plane's input gradient
     const int c = blockIdx.x, img = blockIdx.y;
     gamma += (size_t)img * p_nstride;
     float dz[PER], xh[PER];
     float s1, s2;
+    const bool chained = pre.y && c < pre.C;   // workgroup-uniform: a skip-branch BatchNorm sits in front of this channel (BnPre)
     {
         const float m = mean[img * C + c], r = rstd[img * C + c];
         float b1 = 0.f, b2 = 0.f;   // batch statistics: sums over every image of the batch, in image order; the own plane last (dz / xh stay)
@@ -1124,7 +1294,51 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
             const int i = threadIdx.x + k * 256;
             if (i < HW) {
                 const float gv = gr * (dz[k] - k1 - xh[k] * k2);
-                if (through_adjoint) up_grad_s[i] = gv; else po[i] = gv;
+                if (through_adjoint) up_grad_s[i] = gv; else if (chained) dz[k] = gv; else po[i] = gv;
+            } else if (chained) dz[k] = 0.f;
+        }
+        if (chained) {
+            // ---- the adjoint of the skip branch's BatchNorm + LeakyReLU behind the concat's, on the same plane: dz holds the
+            // gradient w.r.t. the activated skip plane a (= this BatchNorm's input y, in the concat buffer)
+            const float m1 = pre.mean[img * pre.C + c], r1 = pre.rstd[img * pre.C + c];
+            const float* pa1 = y + (size_t)img * y_nstride + (size_t)c * HW;                   // a = act(bn1(y1)): sign selects the LeakyReLU branch
+            const float* py1 = pre.y + (size_t)img * pre.y_ns + (size_t)c * HW;
+            float va[PER], vy[PER];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                if (k * 256 >= HW) continue;
+                const int i = threadIdx.x + k * 256, j = i < HW ? i : 0;
+                va[k] = pa1[j];
+                vy[k] = py1[j];
+            }
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i = threadIdx.x + k * 256;
+                float d = 0.f, x = 0.f;
+                if (k * 256 < HW && i < HW) {
+                    d = dz[k];
+                    if (!(va[k] > 0.f)) d *= pre.slope;
+                    x = (vy[k] - m1) * r1;
+                }
+                dz[k] = d; xh[k] = x;
+                t1 += d;
+                t2 += d * x;
+            }
+            block_sum2(t1, t2, red);
+            const float j1 = t1 / (float)HW, j2 = t2 / (float)HW;
+            const float gr1 = pre.gamma[(size_t)img * p_nstride + c] * r1;
+            float* pd1 = pre.dy + (size_t)img * pre.y_ns + (size_t)c * HW;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int i = threadIdx.x + k * 256;
+                if (i < HW) pd1[i] = gr1 * (dz[k] - j1 - xh[k] * j2);
+            }
+            if (threadIdx.x == 0) {
+                float* dg = pre.dgamma + (size_t)img * p_nstride + c;
+                float* db = pre.dbeta + (size_t)img * p_nstride + c;
+                *dg = accumulate ? *dg + t2 : t2;
+                *db = accumulate ? *db + t1 : t1;
             }
         }
         if (through_adjoint) {
@@ -1179,48 +1393,87 @@ __device__ __forceinline__ void block_sum2_1024(float& a, float& b, float* red /
     for (int k = 0; k < 16; ++k) { sa += red[k]; sb += red[16 + k]; }   // fixed order
     a = sa; b = sb;
 }
+constexpr int BN_MID_SRC = 4096;        // low-resolution source plane of a fused upsampling, staged behind the plane (else read from global)
+// plane elements in groups of 4 (16-byte accesses, every thread's loads of a pass in flight together); tail elements one by one
+template <class F4, class F1>
+__device__ __forceinline__ void bn_mid_for(int HW, bool vec, F4&& f4, F1&& f1) {
+    const int n4 = vec ? HW >> 2 : 0;
+    for (int i = threadIdx.x; i < n4; i += BN_MID_THREADS) f4(i);
+    for (int i = n4 * 4 + threadIdx.x; i < HW; i += BN_MID_THREADS) f1(i);
+}
 __global__ __launch_bounds__(BN_MID_THREADS) void bn_mid_fwd_kernel(const float* y, size_t y_nstride, float* __restrict__ out, size_t out_nstride, int C, int HW,
                                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o, float slope, BnUpsample up,
-                                                                    size_t p_nstride) {
-    extern __shared__ float bn_mid_plane[];   // HW floats
+                                                                    size_t p_nstride, BnPre pre) {
+    extern __shared__ __attribute__((aligned(16))) float bn_mid_plane[];   // HW floats (+ the upsampling source)
     __shared__ float red[32];
     const int c = blockIdx.x, img = blockIdx.y;
     gamma += (size_t)img * p_nstride; beta += (size_t)img * p_nstride;
     const float* p = y + (size_t)img * y_nstride + (size_t)c * HW;
     float* q = out + (size_t)img * out_nstride + (size_t)c * HW;
+    const bool vec = !(HW & 3) && !((reinterpret_cast<size_t>(p) | reinterpret_cast<size_t>(q)) & 15);
     float s = 0.f, dummy = 0.f;
-    if (up.src && c >= up.c0) {   // upsampled channel of the concat: produced here, stored into y for the backward
+    if (pre.y && c < pre.C) {
+        // the skip branch's own BatchNorm + LeakyReLU in front of the concat's, on the same plane (BnPre; see bn_small_fwd_kernel)
+        const float* py1 = pre.y + (size_t)img * pre.y_ns + (size_t)c * HW;
+        float s1 = 0.f, d1 = 0.f;
+        for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) { const float v = py1[i]; bn_mid_plane[i] = v; s1 += v; }
+        block_sum2_1024(s1, d1, red);
+        const float m1 = s1 / (float)HW;
+        float q1 = 0.f;
+        d1 = 0.f;
+        for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) { const float d = bn_mid_plane[i] - m1; q1 += d * d; }
+        block_sum2_1024(q1, d1, red);
+        const float r1 = rsqrtf(q1 / (float)HW + eps);
+        if (threadIdx.x == 0) { pre.mean[img * pre.C + c] = m1; pre.rstd[img * pre.C + c] = r1; }
+        const float sc1 = pre.gamma[(size_t)img * p_nstride + c] * r1;
+        const float sh1 = pre.beta[(size_t)img * p_nstride + c] - m1 * sc1;
+        float* yo2 = const_cast<float*>(p);
+        for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) {
+            float t = bn_mid_plane[i] * sc1 + sh1;
+            t = t > 0.f ? t : t * pre.slope;
+            bn_mid_plane[i] = t;
+            yo2[i] = t;
+            s += t;
+        }
+    } else if (up.src && c >= up.c0) {   // upsampled channel of the concat: produced here, stored into y for the backward
         const float* sp = up.src + (size_t)img * up.src_ns + (size_t)(c - up.c0) * up.h * up.w;
         float* yo = const_cast<float*>(p);
+        const int hw = up.h * up.w;
+        const bool in_lds = hw <= BN_MID_SRC;
+        float* srcs = bn_mid_plane + ((HW + 3) & ~3);
+        if (in_lds) {
+            for (int e = threadIdx.x; e < hw; e += BN_MID_THREADS) srcs[e] = sp[e];
+            __syncthreads();
+        }
         for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) {
             const int oy = i / up.Wo, ox = i - oy * up.Wo;
-            const float v = up_value(sp, up.h, up.w, oy, ox);
+            const float v = in_lds ? up_value((const float*)srcs, up.h, up.w, oy, ox) : up_value(sp, up.h, up.w, oy, ox);
             yo[i] = v;
             bn_mid_plane[i] = v;
             s += v;
         }
     } else {
-        for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) {
-            const float v = p[i];
-            bn_mid_plane[i] = v;
-            s += v;
-        }
+        bn_mid_for(HW, vec,
+                   [&](int i) { const float4 v = reinterpret_cast<const float4*>(p)[i]; reinterpret_cast<float4*>(bn_mid_plane)[i] = v; s += (v.x + v.y) + (v.z + v.w); },
+                   [&](int i) { const float v = p[i]; bn_mid_plane[i] = v; s += v; });
     }
     block_sum2_1024(s, dummy, red);
     const float m = s / (float)HW;
     float sq = 0.f;
     dummy = 0.f;
-    for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) { const float d = bn_mid_plane[i] - m; sq += d * d; }
+    bn_mid_for(HW, vec,
+               [&](int i) { const float4 v = reinterpret_cast<const float4*>(bn_mid_plane)[i]; const float a = v.x - m, b = v.y - m, cc = v.z - m, d = v.w - m; sq += (a * a + b * b) + (cc * cc + d * d); },
+               [&](int i) { const float d = bn_mid_plane[i] - m; sq += d * d; });
     block_sum2_1024(sq, dummy, red);
     const float r = rsqrtf(sq / (float)HW + eps);
     if (threadIdx.x == 0) { mean_o[img * C + c] = m; rstd_o[img * C + c] = r; }
     const float sc = gamma[c] * r;
     const float sh = beta[c] - m * sc;
-    for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) {
-        const float t = bn_mid_plane[i] * sc + sh;
-        q[i] = t > 0.f ? t : t * slope;
-    }
+    auto act = [&](float x) { const float t = x * sc + sh; return t > 0.f ? t : t * slope; };
+    bn_mid_for(HW, vec,
+               [&](int i) { const float4 v = reinterpret_cast<const float4*>(bn_mid_plane)[i]; reinterpret_cast<float4*>(q)[i] = float4{act(v.x), act(v.y), act(v.z), act(v.w)}; },
+               [&](int i) { q[i] = act(bn_mid_plane[i]); });
 }
 // backward: dz = da * act'(a) staged in LDS while s1 = sum dz and s2 = sum dz xhat are taken; second pass forms
 // dy = gamma rstd (dz - s1/HW - xhat s2/HW) (xhat from a second read of y), or -- for an upsampled channel -- sends it through
@@ -1229,8 +1482,8 @@ __global__ __launch_bounds__(BN_MID_THREADS) void bn_mid_bwd_kernel(const float*
                                                                     const float* __restrict__ y, size_t y_nstride, float* __restrict__ dy, size_t dy_nstride, int C, int HW,
                                                                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                     float slope, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, BnUpsample up,
-                                                                    size_t p_nstride) {
-    extern __shared__ float bn_mid_plane[];
+                                                                    size_t p_nstride, BnPre pre) {
+    extern __shared__ __attribute__((aligned(16))) float bn_mid_plane[];
     __shared__ float red[32];
     const int c = blockIdx.x, img = blockIdx.y;
     gamma += (size_t)img * p_nstride;
@@ -1238,30 +1491,66 @@ __global__ __launch_bounds__(BN_MID_THREADS) void bn_mid_bwd_kernel(const float*
     const float* pd = da + (size_t)img * da_nstride + (size_t)c * HW;
     const float* pa = aout + (size_t)img * a_nstride + (size_t)c * HW;
     const float* py = y + (size_t)img * y_nstride + (size_t)c * HW;
+    float* po = dy + (size_t)img * dy_nstride + (size_t)c * HW;
     const bool act = slope != 1.0f;
+    const bool vec = !(HW & 3) && !((reinterpret_cast<size_t>(pd) | reinterpret_cast<size_t>(pa) | reinterpret_cast<size_t>(py) | reinterpret_cast<size_t>(po)) & 15);
     float s1 = 0.f, s2 = 0.f;
-    for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) {
-        float dz = pd[i];
-        const float yv = py[i];
-        if (act && !(pa[i] > 0.f)) dz *= slope;
-        bn_mid_plane[i] = dz;
-        s1 += dz;
-        s2 += dz * ((yv - m) * r);
-    }
+    auto one = [&](float d, float a, float yv) {
+        if (act && !(a > 0.f)) d *= slope;
+        s1 += d;
+        s2 += d * ((yv - m) * r);
+        return d;
+    };
+    bn_mid_for(HW, vec,
+               [&](int i) {
+                   const float4 d = reinterpret_cast<const float4*>(pd)[i], yv = reinterpret_cast<const float4*>(py)[i];
+                   const float4 a = act ? reinterpret_cast<const float4*>(pa)[i] : float4{1.f, 1.f, 1.f, 1.f};
+                   reinterpret_cast<float4*>(bn_mid_plane)[i] = float4{one(d.x, a.x, yv.x), one(d.y, a.y, yv.y), one(d.z, a.z, yv.z), one(d.w, a.w, yv.w)};
+               },
+               [&](int i) { bn_mid_plane[i] = one(pd[i], act ? pa[i] : 1.f, py[i]); });
     block_sum2_1024(s1, s2, red);
     const float k1 = s1 / (float)HW, k2 = s2 / (float)HW;
     const float gr = gamma[c] * r;
-    float* po = dy + (size_t)img * dy_nstride + (size_t)c * HW;
     const bool through_adjoint = up.d_src && c >= up.c0;   // workgroup-uniform
-    for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) {
-        const float gv = gr * (bn_mid_plane[i] - k1 - (py[i] - m) * r * k2);
-        if (through_adjoint) bn_mid_plane[i] = gv; else po[i] = gv;
-    }
-    if (through_adjoint) {
+    auto grad = [&](float dz, float yv) { return gr * (dz - k1 - (yv - m) * r * k2); };
+    if (pre.y && c < pre.C) {
+        // the adjoint of the skip branch's BatchNorm + LeakyReLU behind the concat's (BnPre): the gradient w.r.t. the activated skip
+        // plane a (= this BatchNorm's input y) stays in LDS
+        const float m1 = pre.mean[img * pre.C + c], r1 = pre.rstd[img * pre.C + c];
+        const float* py1 = pre.y + (size_t)img * pre.y_ns + (size_t)c * HW;
+        float t1 = 0.f, t2 = 0.f;
+        for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) {
+            const float a = py[i];
+            float d = grad(bn_mid_plane[i], a);
+            if (!(a > 0.f)) d *= pre.slope;
+            bn_mid_plane[i] = d;
+            t1 += d;
+            t2 += d * ((py1[i] - m1) * r1);
+        }
+        block_sum2_1024(t1, t2, red);
+        const float j1 = t1 / (float)HW, j2 = t2 / (float)HW;
+        const float gr1 = pre.gamma[(size_t)img * p_nstride + c] * r1;
+        float* pd1 = pre.dy + (size_t)img * pre.y_ns + (size_t)c * HW;
+        for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) pd1[i] = gr1 * (bn_mid_plane[i] - j1 - (py1[i] - m1) * r1 * j2);
+        if (threadIdx.x == 0) {
+            float* dg = pre.dgamma + (size_t)img * p_nstride + c;
+            float* db = pre.dbeta + (size_t)img * p_nstride + c;
+            *dg = accumulate ? *dg + t2 : t2;
+            *db = accumulate ? *db + t1 : t1;
+        }
+    } else if (through_adjoint) {
+        for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) bn_mid_plane[i] = grad(bn_mid_plane[i], py[i]);
         __syncthreads();
         float* qd = up.d_src + (size_t)img * up.d_src_ns + (size_t)(c - up.c0) * up.h * up.w;
         for (int e = threadIdx.x; e < up.h * up.w; e += BN_MID_THREADS)
             qd[e] = up_adjoint_value((const float*)bn_mid_plane, up.h, up.w, up.Ho, up.Wo, e / up.w, e % up.w);
+    } else {
+        bn_mid_for(HW, vec,
+                   [&](int i) {
+                       const float4 dz = reinterpret_cast<const float4*>(bn_mid_plane)[i], yv = reinterpret_cast<const float4*>(py)[i];
+                       reinterpret_cast<float4*>(po)[i] = float4{grad(dz.x, yv.x), grad(dz.y, yv.y), grad(dz.z, yv.z), grad(dz.w, yv.w)};
+                   },
+                   [&](int i) { po[i] = grad(bn_mid_plane[i], py[i]); });
     }
     if (threadIdx.x == 0) {
         float* dg = dgamma + (size_t)img * p_nstride + c;
@@ -1276,12 +1565,13 @@ static void bn_mid_allow_lds() {   // > 48 KB of dynamic LDS has to be allowed o
     static std::atomic<unsigned long long> done{0};
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_relaxed) & bit)) {
-        (void)hipFuncSetAttribute((const void*)bn_mid_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BN_MID_HW * 4);
+        (void)hipFuncSetAttribute((const void*)bn_mid_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (BN_MID_HW + BN_MID_SRC) * 4);
         (void)hipFuncSetAttribute((const void*)bn_mid_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BN_MID_HW * 4);
         done.fetch_or(bit, std::memory_order_relaxed);
     }
 }
 // one image per parameter set (a single image, or independent generators) and per-image statistics: what the mid kernels cover
+bool bn_pre_supported(int HW, int N, size_t p_nstride, int batch);
 static inline bool bn_mid_ok(int HW, int N, size_t p_nstride, int batch) {
     static const int on = getenv("SPLICE_BN_MID") ? atoi(getenv("SPLICE_BN_MID")) : 1;
     return on && HW > BN_SMALL_HW && HW <= BN_MID_HW && !batch && (N == 1 || p_nstride);
@@ -1298,19 +1588,25 @@ static inline bool bn_mid_ok(int HW, int N, size_t p_nstride, int batch) {
 // 512-pixel segments (tuned in-step with alternating runs: 1024 +0.45 %, 256 / 384 +0.1 %, 2048 +1.3 %)
 static inline int plane_blocks(int HW) { int b = cdiv(HW, 512); return b < 1 ? 1 : (b > MAX_PB ? MAX_PB : b); }
 int bn_part_floats(int N, int C) { return N * C * MAX_PB * 2; }
+bool bn_pre_supported(int HW, int N, size_t p_nstride, int batch) {
+    static const int on = getenv("SPLICE_BN_CHAIN") ? atoi(getenv("SPLICE_BN_CHAIN")) : 1;
+    return on && !batch && (N == 1 || p_nstride) && (HW <= BN_SMALL_HW || bn_mid_ok(HW, N, p_nstride, batch));
+}
 int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
                   const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s, const BnUpsample* up, size_t p_nstride,
-                  int batch) {
+                  int batch, const BnPre* pre) {
     const BnUpsample u = up ? *up : BnUpsample{};
+    const BnPre pr = pre ? *pre : BnPre{};
     if (batch && (N > BN_MAX_BATCH || u.src || p_nstride)) return SPLICE_ERR_ARG;
+    if (pre && !bn_pre_supported(HW, N, p_nstride, batch)) return SPLICE_ERR_ARG;
     if (HW <= BN_SMALL_HW) {
         BN_SMALL_DISPATCH(HW, bn_small_fwd_kernel, dim3(C, N), s, y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd, slope,
-                          (const float*)nullptr, 0, (const float*)nullptr, (float*)nullptr, u, p_nstride, batch);
+                          (const float*)nullptr, 0, (const float*)nullptr, (float*)nullptr, u, p_nstride, batch, pr);
         return SPLICE_OK;
     }
     if (bn_mid_ok(HW, N, p_nstride, batch)) {
         bn_mid_allow_lds();
-        SPLICE_LAUNCH(bn_mid_fwd_kernel, dim3(C, N), dim3(BN_MID_THREADS), (size_t)HW * 4, s, y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd, slope, u, p_nstride);
+        SPLICE_LAUNCH(bn_mid_fwd_kernel, dim3(C, N), dim3(BN_MID_THREADS), (size_t)(((HW + 3) & ~3) + (u.src ? BN_MID_SRC : 0)) * 4, s, y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd, slope, u, p_nstride, pr);
         return SPLICE_OK;
     }
     const int PB = plane_blocks(HW);
@@ -1328,18 +1624,20 @@ int bn_fwd_slabs_launch(const float* slabs, int ksplit, const float* bias, float
                         int C, int HW, const float* gamma, const float* beta, float eps, float* mean, float* rstd, float slope, hipStream_t s, size_t p_nstride) {
     if (HW > BN_SMALL_HW || ksplit < 2 || !slabs) return SPLICE_ERR_ARG;
     BN_SMALL_DISPATCH(HW, bn_small_fwd_kernel, dim3(C, N), s, (const float*)y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd,
-                      slope, slabs, ksplit, bias, y, BnUpsample{}, p_nstride, 0);
+                      slope, slabs, ksplit, bias, y, BnUpsample{}, p_nstride, 0, BnPre{});
     return SPLICE_OK;
 }
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
-                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up, size_t p_nstride, int batch) {
+                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up, size_t p_nstride, int batch, const BnPre* pre) {
     if (batch && (N > BN_MAX_BATCH || p_nstride)) return SPLICE_ERR_ARG;
+    if (pre && !bn_pre_supported(HW, N, p_nstride, batch)) return SPLICE_ERR_ARG;
+    const BnPre pr = pre ? *pre : BnPre{};
     if (HW <= BN_SMALL_HW) {
         BnUpsample u = up ? *up : BnUpsample{};
         if (!bn_bwd_fuses_upsample(HW, u.h, u.w)) u.d_src = nullptr;
         BN_SMALL_DISPATCH(HW, bn_small_bwd_kernel, dim3(C, N), s, da, da_nstride, aout, a_nstride, y, y_nstride, dy, dy_nstride, C, HW, N,
-                          gamma, mean, rstd, slope, dgamma, dbeta, accumulate, u, p_nstride, batch);
+                          gamma, mean, rstd, slope, dgamma, dbeta, accumulate, u, p_nstride, batch, pr);
         return SPLICE_OK;
     }
     if (bn_mid_ok(HW, N, p_nstride, batch)) {
@@ -1347,7 +1645,7 @@ int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t 
         if (!(u.h > 0 && u.w > 0)) u.d_src = nullptr;
         bn_mid_allow_lds();
         SPLICE_LAUNCH(bn_mid_bwd_kernel, dim3(C, N), dim3(BN_MID_THREADS), (size_t)HW * 4, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy, dy_nstride, C, HW, gamma, mean,
-                      rstd, slope, dgamma, dbeta, accumulate, u, p_nstride);
+                      rstd, slope, dgamma, dbeta, accumulate, u, p_nstride, pr);
         return SPLICE_OK;
     }
     const int PB = plane_blocks(HW);
