@@ -1,9 +1,10 @@
 // Instantiations + runtime dispatch of the bf16 NT GEMM (gemm.h) for the epilogues the
 // DINO-ViT forward / dgrad path uses (K3, K5, K7, K8 of SURVEY.md section 2b).
 #include "kernels.h"
+#include "gemm8p.h"
 #include <cstdlib>
 
-static int g_force_tile = 0;   // 0 auto; tile + 10 * ring: tile 1 = 128x128, 2 = 128x64, 3 = 64x64; ring 0 = 2 stages, 1 = 4 stages, 2 = 3 stages (64x64 only) (tools/gemm_bench.py)
+static int g_force_tile = 0;   // 0 auto; tile + 10 * ring: tile 1 = 128x128, 2 = 128x64, 3 = 64x64; ring 0 = 2 stages, 1 = 4 stages, 2 = 3 stages (64x64 only) (tools/gemm_bench.py); 5 = the persistent 256x256 8-phase tile where it exists (gemm8p.h), else automatic
 void gemm_force_tile(int t) { g_force_tile = t; }
 
 template <unsigned FLAGS>
@@ -11,8 +12,19 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
                          hipStream_t s) {
     const long t128 = (long)cdiv(M, 128) * cdiv(N, 128);
     const long t12864 = (long)cdiv(M, 128) * cdiv(N, 64);
+    // the batched forward projections with whole 256-column tiles (QKV of the layers without side outputs, fc1) on the persistent
+    // 256 x 256 8-phase tile where its grid quantisation is good (gemm8p.h; same bits as every other tile)
+    if constexpr (FLAGS == (EPI_BIAS | EPI_OUT_BF) || FLAGS == (EPI_BIAS | EPI_GELU | EPI_OUT_BF)) {
+        static const int on8p = getenv("SPLICE_GEMM_8P") ? atoi(getenv("SPLICE_GEMM_8P")) : 3;   // bit 0: QKV, bit 1: fc1
+        const bool want = g_force_tile == 5 || (!g_force_tile && (on8p & ((FLAGS & EPI_GELU) ? 2 : 1)) && gemm8p_shape_ok(M, N, K, lda, ldb, e, FLAGS));
+        if (want && N % 256 == 0 && K % 128 == 0 && K >= 128 && e.ldbf % 8 == 0 && !(reinterpret_cast<size_t>(e.out_bf) & 15) && !(reinterpret_cast<size_t>(e.bias) & 15) &&
+            (!(FLAGS & EPI_GELU) || !e.out_pre || (e.ldp % 8 == 0 && !(reinterpret_cast<size_t>(e.out_pre) & 15)))) {
+            launch_gemm8p<FLAGS>(s, A, lda, B, ldb, M, N, K, e);
+            return SPLICE_OK;
+        }
+    }
     int tile, ring;
-    if (g_force_tile && !(FLAGS & EPI_ROWDOT)) { tile = g_force_tile % 10; ring = g_force_tile / 10; }
+    if (g_force_tile && g_force_tile != 5 && !(FLAGS & EPI_ROWDOT)) { tile = g_force_tile % 10; ring = g_force_tile / 10; }
     else {
         // measured on MI355X (tools/gemm_bench.py): with N <= 768 the 64x64 tile wins (more workgroups on the long-K shapes);
         // otherwise the biggest tile that still yields ~2 workgroups per CU (M = 1600: 128x64 beats 128x128 by 10 %, M = 800: 64x64)

@@ -198,3 +198,87 @@ struct Gemm8p {
         if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the barrier count of the two halves
     }
 };
+
+// ---- product kernel: the persistent 8-phase tile behind two ViT forward epilogues ------------------------------------------------
+//   EPI_BIAS | EPI_OUT_BF              QKV projection (layers that need no transposed / fp32 copy)
+//   EPI_BIAS | EPI_GELU | EPI_OUT_BF   fc1: + the bf16 pre-activation of the gradient-carrying rows (e.out_pre, rows >= e.pre_row_lo)
+// Two adjacent 16-column fragments of a row leave as ONE 16-byte store per lane: v_permlane16_swap exchanges the 4-column groups of
+// lanes 16 apart, so a lane ends up with 8 consecutive columns (the epilogue has no LDS to stage through: the ring is already
+// receiving the next tile).  N % 256 == 0 (whole tiles along N; ragged M is masked), K % 128 == 0.
+template <unsigned FLAGS>
+__global__ __launch_bounds__(512) void gemm8p_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K, int gm,
+                                                     GemmEpi e) {
+    static_assert(FLAGS == (EPI_BIAS | EPI_OUT_BF) || FLAGS == (EPI_BIAS | EPI_GELU | EPI_OUT_BF), "epilogues of the 8-phase tile");
+    extern __shared__ __attribute__((aligned(16))) bf16_t gemm8p_smem[];
+    const int tiles_n = N / 256, tiles_m = (M + 255) / 256, ntiles = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    const int count = (ntiles - (int)blockIdx.x + G - 1) / G;   // tiles blockIdx.x, blockIdx.x + G, ... (G % 8 == 0: all on this workgroup's XCD)
+    Gemm8p g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 2, wc = wave & 3;
+    const int grp = lane >> 4;
+    const int c8 = ((grp & 1) << 4) | ((grp >> 1) << 3);   // first of the lane's 8 columns after the swap: {0, 16, 8, 24}[grp]
+    g.run_tiles(A, lda, B, ldb, M, N, K, count,
+                [&](int r, int& m0, int& n0) {
+                    const int t = xcd_remap(blockIdx.x + r * G, ntiles);
+                    int tm, tn;
+                    grouped_tile(t, tiles_m, tiles_n, gm, tm, tn);
+                    m0 = tm * 256; n0 = tn * 256;
+                },
+                [&](int m0, int n0) {
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh) {
+                        const int colf = n0 + nh * 128 + wc * 32 + grp * 4;   // this lane's 4 columns of fragment j = 0 (j = 1: + 16)
+                        const float4 b0 = *reinterpret_cast<const float4*>(e.bias + colf), b1 = *reinterpret_cast<const float4*>(e.bias + colf + 16);
+                        const int col = n0 + nh * 128 + wc * 32 + c8;
+#pragma unroll
+                        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                f32x4 v0 = g.acc[mh * 4 + i][nh * 2 + 0], v1 = g.acc[mh * 4 + i][nh * 2 + 1];
+                                v0[0] += b0.x; v0[1] += b0.y; v0[2] += b0.z; v0[3] += b0.w;
+                                v1[0] += b1.x; v1[1] += b1.y; v1[2] += b1.z; v1[3] += b1.w;
+                                const int row = m0 + mh * 128 + wr * 64 + i * 16 + (lane & 15);
+                                auto store8 = [&](bf16_t* base, int ld, const f32x4& x0, const f32x4& x1, bool on) {
+                                    const uint2 a = uint2{pack2bf(x0[0], x0[1]), pack2bf(x0[2], x0[3])}, b = uint2{pack2bf(x1[0], x1[1]), pack2bf(x1[2], x1[3])};
+                                    const auto rx = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+                                    const auto ry = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+                                    if (on) *reinterpret_cast<uint4*>(base + (size_t)row * ld + col) = uint4{rx[0], ry[0], rx[1], ry[1]};
+                                };
+                                if constexpr ((FLAGS & EPI_GELU) != 0) {
+                                    if (e.out_pre) store8(e.out_pre, e.ldp, v0, v1, row < M && row >= e.pre_row_lo);   // (wave-uniform pointer test; the swap runs in every lane)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) { v0[r] = gelu_f(v0[r]); v1[r] = gelu_f(v1[r]); }
+                                }
+                                store8(e.out_bf, e.ldbf, v0, v1, row < M);
+                            }
+                    }
+                },
+                gemm8p_smem);
+}
+
+// quantisation of the persistent grid: 256 workgroups walk ceil(tiles / 256) rounds; the tile pays where the last round is
+// reasonably full (tools/micro/gemm8p.hip, profiles/r04_gemm8p_micro.txt: 450 and 600 tiles win, 300 loses to the 128 x 128 tile)
+static inline bool gemm8p_shape_ok(int M, int N, int K, int lda, int ldb, const GemmEpi& e, unsigned flags) {
+    if (N % 256 || K % 128 || K < 128 || M < 256) return false;
+    if (e.ldbf % 8 || (reinterpret_cast<size_t>(e.out_bf) & 15) || (reinterpret_cast<size_t>(e.bias) & 15)) return false;
+    if ((flags & EPI_GELU) && e.out_pre && (e.ldp % 8 || (reinterpret_cast<size_t>(e.out_pre) & 15))) return false;
+    const long tiles = (long)((M + 255) / 256) * (N / 256);
+    if (tiles < 200) return false;
+    const long rounds = (tiles + 255) / 256;
+    return tiles * 100 >= rounds * 256 * 75;
+}
+template <unsigned FLAGS>
+static inline void launch_gemm8p(hipStream_t s, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, const GemmEpi& e) {
+    const int tm = (M + 255) / 256, tn = N / 256, tiles = tm * tn;
+    int gm = 1;
+    while ((gm + 1) * (gm + 1) <= (tiles / 8 + 1) && gm + 1 <= tm) ++gm;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static std::atomic<unsigned long long> done_mask{0};
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
+        (void)hipFuncSetAttribute((const void*)gemm8p_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, Gemm8p::LDS_BYTES);
+        done_mask.fetch_or(bit, std::memory_order_relaxed);
+    }
+    SPLICE_LAUNCH((gemm8p_kernel<FLAGS>), dim3(tiles < 256 ? tiles : 256), dim3(512), Gemm8p::LDS_BYTES, s, A, lda, B, ldb, M, N, K, gm, e);
+}

@@ -97,7 +97,7 @@ struct SpliceGenPlan {
     float* wgrad_ws = nullptr;
     float* conv_ws = nullptr;             // split-K scratch of the small deep convolutions
     size_t conv_ws_floats = 0;
-    size_t head_wg_off = 0;
+    size_t head_wg_off = 0, head_bias_off = 0;
     WgradReduceAll red;                   // filled during a backward, consumed by its single reduce launch
     WgradBatchPair wg;                    // every layer's weight-gradient work of a backward: launched after the dgrad chain
     float* out_copy = nullptr;            // generator output kept for the sigmoid backward
@@ -273,11 +273,13 @@ static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* para
 }
 // two units that read the same input and do not depend on each other (the skip branch and the first encoder convolution of a
 // scale): their convolutions share one launch (conv_pair_launch); a = the 1x1 unit
-// a_bn_later: a's BatchNorm runs inside a later kernel (BnPre of the concat BatchNorm): its convolution then writes its complete
-// output itself (no split-K: the slab workspace is reused long before that kernel runs)
+// a_bn_later: a's BatchNorm runs inside a later kernel (BnPre of the concat BatchNorm): a split-K convolution then sums its slabs
+// itself (same order as the BatchNorm kernel would: same bits) -- the slab workspace is reused long before that kernel runs
 static int unit_pair_forward(const SpliceGenPlan* p, const Unit& ua, const Unit& ub, const float* params, hipStream_t s, bool a_bn_later) {
     const size_t half = p->conv_ws_floats / 2;
-    const ConvArgs a = unit_conv_args(p, ua, params, a_bn_later ? nullptr : p->conv_ws, half), b = unit_conv_args(p, ub, params, p->conv_ws + half, half);
+    ConvArgs a = unit_conv_args(p, ua, params, p->conv_ws, half);
+    if (a_bn_later) a.defer_reduce = 0;
+    const ConvArgs b = unit_conv_args(p, ub, params, p->conv_ws + half, half);
     int ksa = 1, ksb = 1;
     RC(conv_pair_launch(a, b, s, &ksa, &ksb));
     if (!a_bn_later) RC(unit_bn_forward(p, ua, params, ua.y, ua.y_ns, a.ws, ksa, a.defer_reduce != 0, s, nullptr));
@@ -451,6 +453,8 @@ int splice_gen_plan_create(void* h, int N, int H, int W, int need_grad, void** o
     {
         p->head_wg_off = ws_need;
         ws_need += (size_t)N * ((H * W + 63) / 64) * A.out_channels * A.up[0];
+        p->head_bias_off = ws_need;   // per-segment partials of the head bias gradient: reduced with the weight-gradient partials
+        ws_need += (size_t)sigmoid_bias_part_floats(N, A.out_channels);
     }
     if ((rc = palloc(p, &p->x_copy, (size_t)N * A.in_channels * H * W)) != SPLICE_OK) return fail();
     if (pad_need && need_grad && (rc = palloc(p, &p->pad_scratch, pad_need)) != SPLICE_OK) return fail();
@@ -685,7 +689,13 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
     const Unit& u = p->u_up1[0];
     const int HW = p->H * p->W;
     (void)npix;
-    RC(sigmoid_bwd_bias_launch(dy, p->y_saved, p->d_head_pre, p->N, OC, HW, p->u_up1[0].s1, grads + p->head_b, accumulate, s, p->p_nstride));
+    {
+        int chunks = 0;
+        RC(sigmoid_bwd_bias_launch(dy, p->y_saved, p->d_head_pre, p->N, OC, HW, p->wgrad_ws + p->head_bias_off, s, p->p_nstride, &chunks));
+        WgradReduceAll& r = p->red;
+        const int li = r.count++;
+        r.n[li] = OC; r.chunks[li] = chunks; r.ws_off[li] = (long long)p->head_bias_off; r.dw_off[li] = (long long)p->head_b;
+    }
     {
         WgradArgs a = {};
         a.x = u.out; a.dy = p->d_head_pre;

@@ -117,8 +117,8 @@ int upsample2x_bwd_launch(const float* dout, size_t dout_nstride, float* din, si
 int sigmoid_bwd_launch(const float* dout, const float* sout, float* dpre, size_t n, hipStream_t s);
 // sigmoid backward of the [N][C][HW] head + per-channel sums of the result (the head's bias gradient) in two
 // deterministic stages; part = C * 64 floats of scratch
-int sigmoid_bwd_bias_launch(const float* dout, const float* sout, float* dpre, int N, int C, int HW, float* part, float* db,
-                            int accumulate, hipStream_t s, size_t p_nstride = 0);
+int sigmoid_bwd_bias_launch(const float* dout, const float* sout, float* dpre, int N, int C, int HW, float* part, hipStream_t s, size_t p_nstride, int* chunks);
+int sigmoid_bias_part_floats(int N, int C);   // floats of `part`: [image][segment][channel], summed by wgrad_reduce_all_launch
 int adam_launch(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step, int zero_grad, hipStream_t s);
 int adam_launch_dev(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, const int* step_dev,
                     int zero_grad, hipStream_t s, const float* g2 = nullptr);

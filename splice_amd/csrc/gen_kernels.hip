@@ -220,10 +220,11 @@ __global__ __launch_bounds__(256 * NG) void conv_igemm_kernel(ConvArgs a) {
     conv_igemm_body<KS, TRANSPOSED, FN, CK, NG>(a, blockIdx.x, blockIdx.y, blockIdx.z, As, Ws);
 }
 // Two independent convolutions in one launch: blocks [0, na) run convolution A (KS = KSA ...), the rest convolution B; each with
-// the block coordinates of its own grid (gxa = A's gridDim.x, gxb = B's), blockIdx.z = image for both.  NG (waves per
-// workgroup / 4) is common; LDS is the larger of the two footprints.
-template <int KSA, bool TRA, int FNA, int CKA, int KSB, bool TRB, int FNB, int CKB, int NG>
-__global__ __launch_bounds__(256 * NG) void conv_pair_kernel(ConvArgs a, ConvArgs b, int na, int gxa, int gxb) {
+// the block coordinates of its own grid (gxa = A's gridDim.x, gxb = B's), blockIdx.z = image for both.  Each keeps the wave
+// groups (NGA / NGB) of its own launch -- the surplus waves of the smaller one leave at once (a barrier does not wait for
+// waves that have ended) -- so a convolution's bits do not depend on whether it was paired.  LDS is the larger footprint.
+template <int KSA, bool TRA, int FNA, int CKA, int NGA, int KSB, bool TRB, int FNB, int CKB, int NGB>
+__global__ __launch_bounds__(256 * (NGA > NGB ? NGA : NGB)) void conv_pair_kernel(ConvArgs a, ConvArgs b, int na, int gxa, int gxb) {
     using TA = ConvTile<KSA, FNA, CKA>;
     using TB = ConvTile<KSB, FNB, CKB>;
     constexpr int AF = TA::A_FLOATS > TB::A_FLOATS ? TA::A_FLOATS : TB::A_FLOATS;
@@ -231,8 +232,13 @@ __global__ __launch_bounds__(256 * NG) void conv_pair_kernel(ConvArgs a, ConvArg
     __shared__ float As[AF];
     __shared__ float Ws[WF];
     const int bid = blockIdx.x;
-    if (bid < na) conv_igemm_body<KSA, TRA, FNA, CKA, NG>(a, bid % gxa, bid / gxa, blockIdx.z, As, Ws);
-    else conv_igemm_body<KSB, TRB, FNB, CKB, NG>(b, (bid - na) % gxb, (bid - na) / gxb, blockIdx.z, As, Ws);
+    if (bid < na) {
+        if (NGA < NGB && threadIdx.x >= 256 * NGA) return;
+        conv_igemm_body<KSA, TRA, FNA, CKA, NGA>(a, bid % gxa, bid / gxa, blockIdx.z, As, Ws);
+    } else {
+        if (NGB < NGA && threadIdx.x >= 256 * NGB) return;
+        conv_igemm_body<KSB, TRB, FNB, CKB, NGB>(b, (bid - na) % gxb, (bid - na) / gxb, blockIdx.z, As, Ws);
+    }
 }
 
 // out = (accumulate ? out : 0) + bias + sum_slices ws   (slice order fixed)
@@ -341,25 +347,27 @@ static inline int conv_ck(const ConvArgs& a) { return a.ks == 3 ? (a.Cin >= 32 ?
 
 // Two INDEPENDENT convolutions in one launch (conv_pair_kernel).  Forward: a = the 1x1 skip convolution of a scale, b = its 3x3
 // stride-2 encoder convolution (same input, models/unet/skip.py:60-66); backward: two 1x1 data-gradient convolutions (the skip
-// branch's and the deeper scale's last decoder convolution).  Each keeps the launch policy, the split-K workspace and the bits
-// of its own launch except that `a` adopts b's waves per workgroup.  Combinations outside the instantiated set, reflection
-// padding or 5x5 / 7x7 filters fall back to two launches.  Returns through ksplit_a / ksplit_b what conv_launch would.
-template <int KSA, bool TRA, int FNA, int CKA, int KSB, bool TRB, int FNB, int CKB, int NG>
+// branch's and the deeper scale's last decoder convolution).  Each keeps the launch policy, the split-K workspace and the BITS of
+// its own launch, so pairing is a pure launch-count choice: it pays on the latency-bound chains of few images (-0.9 % step time at
+// one pair per GPU) and not where the launches fill the chip (+0.2 % at eight: the pair runs at the larger register / LDS
+// footprint), hence only below SPLICE_CONV_PAIR_MAXN images (profiles/r04_gen_ab.txt).  Combinations outside the instantiated set,
+// reflection padding or 5x5 / 7x7 filters fall back to two launches.  Returns through ksplit_a / ksplit_b what conv_launch would.
+template <int KSA, bool TRA, int FNA, int CKA, int KSB, bool TRB, int FNB, int CKB, int NGB>
 static void conv_pair_go(const ConvArgs& a, const ConvArgs& b, const ConvPolicy& pa, const ConvPolicy& pb, hipStream_t s) {
     const int na = pa.mt * pa.ny, nb = pb.mt * pb.ny;
-    SPLICE_LAUNCH((conv_pair_kernel<KSA, TRA, FNA, CKA, KSB, TRB, FNB, CKB, NG>), dim3(na + nb, 1, a.N), dim3(256 * NG), 0, s, a, b, na, pa.mt, pb.mt);
+    SPLICE_LAUNCH((conv_pair_kernel<KSA, TRA, FNA, CKA, 1, KSB, TRB, FNB, CKB, NGB>), dim3(na + nb, 1, a.N), dim3(256 * NGB), 0, s, a, b, na, pa.mt, pb.mt);
 }
 int conv_pair_launch(ConvArgs a, ConvArgs b, hipStream_t s, int* ksplit_a, int* ksplit_b) {
     static const int pair_on = getenv("SPLICE_CONV_PAIR") ? atoi(getenv("SPLICE_CONV_PAIR")) : 1;
+    static const int pair_maxn = getenv("SPLICE_CONV_PAIR_MAXN") ? atoi(getenv("SPLICE_CONV_PAIR_MAXN")) : 4;
     const int cka = conv_ck(a), ckb = conv_ck(b);
     bool done = false;
-    if (pair_on && a.N == b.N && !a.reflect && !b.reflect && a.ks == 1 && a.stride == 1 && (b.stride == 1 || b.stride == 2) && a.transposed == b.transposed &&
-        (size_t)a.Cin * a.in_cstride <= 0x7fffffffULL && (size_t)b.Cin * b.in_cstride <= 0x7fffffffULL) {
-        ConvPolicy pa = conv_policy(a, 1, cka), pb = conv_policy(b, b.ks, ckb);
-        pa.ng = pb.ng;     // one workgroup size per launch: the 1x1 convolution walks its K tiles with b's wave groups
+    if (pair_on && a.N == b.N && a.N < pair_maxn && !a.reflect && !b.reflect && a.ks == 1 && a.stride == 1 && (b.stride == 1 || b.stride == 2) &&
+        a.transposed == b.transposed && (size_t)a.Cin * a.in_cstride <= 0x7fffffffULL && (size_t)b.Cin * b.in_cstride <= 0x7fffffffULL) {
+        const ConvPolicy pa = conv_policy(a, 1, cka), pb = conv_policy(b, b.ks, ckb);
         a.ksplit = pa.ksplit; b.ksplit = pb.ksplit;
 #define PAIR(TR_, FNA_, CKA_, KSB_, FNB_, CKB_, NG_)                                                                                         \
-    if (!done && a.transposed == (TR_ ? 1 : 0) && pa.fn_run == FNA_ && cka == CKA_ && b.ks == KSB_ && pb.fn_run == FNB_ && ckb == CKB_ && pb.ng == NG_) { \
+    if (!done && a.transposed == (TR_ ? 1 : 0) && pa.ng == 1 && pa.fn_run == FNA_ && cka == CKA_ && b.ks == KSB_ && pb.fn_run == FNB_ && ckb == CKB_ && pb.ng == NG_) { \
         conv_pair_go<1, TR_, FNA_, CKA_, KSB_, TR_, FNB_, CKB_, NG_>(a, b, pa, pb, s);                                                       \
         done = true;                                                                                                                          \
     }
@@ -1414,28 +1422,37 @@ __global__ __launch_bounds__(BN_MID_THREADS) void bn_mid_fwd_kernel(const float*
     const bool vec = !(HW & 3) && !((reinterpret_cast<size_t>(p) | reinterpret_cast<size_t>(q)) & 15);
     float s = 0.f, dummy = 0.f;
     if (pre.y && c < pre.C) {
-        // the skip branch's own BatchNorm + LeakyReLU in front of the concat's, on the same plane (BnPre; see bn_small_fwd_kernel)
+        // the skip branch's own BatchNorm + LeakyReLU in front of the concat's, on the same plane (BnPre; see bn_small_fwd_kernel).
+        // Same access pattern and summation order as a launch of this kernel on the skip unit alone: the same bits either way.
         const float* py1 = pre.y + (size_t)img * pre.y_ns + (size_t)c * HW;
+        const bool vec1 = vec && !(reinterpret_cast<size_t>(py1) & 15);
         float s1 = 0.f, d1 = 0.f;
-        for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) { const float v = py1[i]; bn_mid_plane[i] = v; s1 += v; }
+        bn_mid_for(HW, vec1,
+                   [&](int i) { const float4 v = reinterpret_cast<const float4*>(py1)[i]; reinterpret_cast<float4*>(bn_mid_plane)[i] = v; s1 += (v.x + v.y) + (v.z + v.w); },
+                   [&](int i) { const float v = py1[i]; bn_mid_plane[i] = v; s1 += v; });
         block_sum2_1024(s1, d1, red);
         const float m1 = s1 / (float)HW;
         float q1 = 0.f;
         d1 = 0.f;
-        for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) { const float d = bn_mid_plane[i] - m1; q1 += d * d; }
+        bn_mid_for(HW, vec1,
+                   [&](int i) { const float4 v = reinterpret_cast<const float4*>(bn_mid_plane)[i]; const float a = v.x - m1, b = v.y - m1, cc = v.z - m1, d = v.w - m1; q1 += (a * a + b * b) + (cc * cc + d * d); },
+                   [&](int i) { const float d = bn_mid_plane[i] - m1; q1 += d * d; });
         block_sum2_1024(q1, d1, red);
         const float r1 = rsqrtf(q1 / (float)HW + eps);
         if (threadIdx.x == 0) { pre.mean[img * pre.C + c] = m1; pre.rstd[img * pre.C + c] = r1; }
         const float sc1 = pre.gamma[(size_t)img * p_nstride + c] * r1;
         const float sh1 = pre.beta[(size_t)img * p_nstride + c] - m1 * sc1;
         float* yo2 = const_cast<float*>(p);
-        for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) {
-            float t = bn_mid_plane[i] * sc1 + sh1;
-            t = t > 0.f ? t : t * pre.slope;
-            bn_mid_plane[i] = t;
-            yo2[i] = t;
-            s += t;
-        }
+        auto act1 = [&](float x) { const float t = x * sc1 + sh1; return t > 0.f ? t : t * pre.slope; };
+        bn_mid_for(HW, vec1,
+                   [&](int i) {
+                       const float4 v = reinterpret_cast<const float4*>(bn_mid_plane)[i];
+                       const float4 a = float4{act1(v.x), act1(v.y), act1(v.z), act1(v.w)};
+                       reinterpret_cast<float4*>(bn_mid_plane)[i] = a;
+                       reinterpret_cast<float4*>(yo2)[i] = a;
+                       s += (a.x + a.y) + (a.z + a.w);
+                   },
+                   [&](int i) { const float a = act1(bn_mid_plane[i]); bn_mid_plane[i] = a; yo2[i] = a; s += a; });
     } else if (up.src && c >= up.c0) {   // upsampled channel of the concat: produced here, stored into y for the backward
         const float* sp = up.src + (size_t)img * up.src_ns + (size_t)(c - up.c0) * up.h * up.w;
         float* yo = const_cast<float*>(p);
@@ -1515,23 +1532,35 @@ __global__ __launch_bounds__(BN_MID_THREADS) void bn_mid_bwd_kernel(const float*
     auto grad = [&](float dz, float yv) { return gr * (dz - k1 - (yv - m) * r * k2); };
     if (pre.y && c < pre.C) {
         // the adjoint of the skip branch's BatchNorm + LeakyReLU behind the concat's (BnPre): the gradient w.r.t. the activated skip
-        // plane a (= this BatchNorm's input y) stays in LDS
+        // plane a (= this BatchNorm's input y) stays in LDS.  Access pattern and summation order of a launch on the skip unit alone.
         const float m1 = pre.mean[img * pre.C + c], r1 = pre.rstd[img * pre.C + c];
         const float* py1 = pre.y + (size_t)img * pre.y_ns + (size_t)c * HW;
+        float* pd1 = pre.dy + (size_t)img * pre.y_ns + (size_t)c * HW;
+        const bool vec1 = vec && !((reinterpret_cast<size_t>(py1) | reinterpret_cast<size_t>(pd1)) & 15);
         float t1 = 0.f, t2 = 0.f;
-        for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) {
-            const float a = py[i];
-            float d = grad(bn_mid_plane[i], a);
+        auto one1 = [&](float dzc, float a, float y1) {
+            float d = grad(dzc, a);
             if (!(a > 0.f)) d *= pre.slope;
-            bn_mid_plane[i] = d;
             t1 += d;
-            t2 += d * ((py1[i] - m1) * r1);
-        }
+            t2 += d * ((y1 - m1) * r1);
+            return d;
+        };
+        bn_mid_for(HW, vec1,
+                   [&](int i) {
+                       const float4 dzc = reinterpret_cast<const float4*>(bn_mid_plane)[i], a = reinterpret_cast<const float4*>(py)[i], y1 = reinterpret_cast<const float4*>(py1)[i];
+                       reinterpret_cast<float4*>(bn_mid_plane)[i] = float4{one1(dzc.x, a.x, y1.x), one1(dzc.y, a.y, y1.y), one1(dzc.z, a.z, y1.z), one1(dzc.w, a.w, y1.w)};
+                   },
+                   [&](int i) { bn_mid_plane[i] = one1(bn_mid_plane[i], py[i], py1[i]); });
         block_sum2_1024(t1, t2, red);
         const float j1 = t1 / (float)HW, j2 = t2 / (float)HW;
         const float gr1 = pre.gamma[(size_t)img * p_nstride + c] * r1;
-        float* pd1 = pre.dy + (size_t)img * pre.y_ns + (size_t)c * HW;
-        for (int i = threadIdx.x; i < HW; i += BN_MID_THREADS) pd1[i] = gr1 * (bn_mid_plane[i] - j1 - (py1[i] - m1) * r1 * j2);
+        auto grad1 = [&](float dz, float y1) { return gr1 * (dz - j1 - (y1 - m1) * r1 * j2); };
+        bn_mid_for(HW, vec1,
+                   [&](int i) {
+                       const float4 dz = reinterpret_cast<const float4*>(bn_mid_plane)[i], y1 = reinterpret_cast<const float4*>(py1)[i];
+                       reinterpret_cast<float4*>(pd1)[i] = float4{grad1(dz.x, y1.x), grad1(dz.y, y1.y), grad1(dz.z, y1.z), grad1(dz.w, y1.w)};
+                   },
+                   [&](int i) { pd1[i] = grad1(bn_mid_plane[i], py1[i]); });
         if (threadIdx.x == 0) {
             float* dg = pre.dgamma + (size_t)img * p_nstride + c;
             float* db = pre.dbeta + (size_t)img * p_nstride + c;
@@ -1588,9 +1617,13 @@ static inline bool bn_mid_ok(int HW, int N, size_t p_nstride, int batch) {
 // 512-pixel segments (tuned in-step with alternating runs: 1024 +0.45 %, 256 / 384 +0.1 %, 2048 +1.3 %)
 static inline int plane_blocks(int HW) { int b = cdiv(HW, 512); return b < 1 ? 1 : (b > MAX_PB ? MAX_PB : b); }
 int bn_part_floats(int N, int C) { return N * C * MAX_PB * 2; }
+// (chained or not, the skip branch's BatchNorm yields the same bits, so this is a pure launch-count choice: measured neutral at one
+// pair per GPU with 16 launches fewer per step, +0.3 % step time at eight pairs -- the concat kernel waits for its skip-channel
+// workgroups, which now make five block-wide reductions instead of two; hence below SPLICE_BN_CHAIN_MAXN images only)
 bool bn_pre_supported(int HW, int N, size_t p_nstride, int batch) {
     static const int on = getenv("SPLICE_BN_CHAIN") ? atoi(getenv("SPLICE_BN_CHAIN")) : 1;
-    return on && !batch && (N == 1 || p_nstride) && (HW <= BN_SMALL_HW || bn_mid_ok(HW, N, p_nstride, batch));
+    static const int maxn = getenv("SPLICE_BN_CHAIN_MAXN") ? atoi(getenv("SPLICE_BN_CHAIN_MAXN")) : 4;
+    return on && N < maxn && !batch && (N == 1 || p_nstride) && (HW <= BN_SMALL_HW || bn_mid_ok(HW, N, p_nstride, batch));
 }
 int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
                   const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s, const BnUpsample* up, size_t p_nstride,
@@ -1709,8 +1742,10 @@ __global__ void sigmoid_bwd_kernel(const float* __restrict__ dout, const float* 
         dpre[i] = dout[i] * sv * (1.f - sv);
     }
 }
-// stage 1: block (pb, c) handles segment pb of channel c over every image; stage 2: one block sums the partials in order
-// gridDim.z > 1: independent images -- blockIdx.z = image, partials per image
+// dpre = dout * s * (1 - s) and the per-segment sums of dpre for the head bias gradient: block (pb, c) handles segment pb of
+// channel c over every image (gridDim.z > 1: independent images -- blockIdx.z = image, partials per image).  The partials are laid
+// out [image][segment][channel] = the [chunk][element] layout of the weight-gradient partials, so the backward's ONE
+// wgrad_reduce_all launch sums them with everything else (round 4: the bias had a reduce launch of its own).
 __global__ __launch_bounds__(256) void sigmoid_bwd_bias_kernel(const float* __restrict__ dout, const float* __restrict__ sout,
                                                                float* __restrict__ dpre, int N, int C, int HW, int PB,
                                                                float* __restrict__ part) {
@@ -1730,25 +1765,17 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_bias_kernel(const float* __re
         }
     }
     block_sum2(acc, dummy, red);
-    if (threadIdx.x == 0) part[c * PB + pb] = acc;
+    if (threadIdx.x == 0) part[pb * C + c] = acc;
 }
-__global__ void bias_part_reduce_kernel(const float* __restrict__ part, int C, int PB, float* __restrict__ db, int accumulate, size_t p_nstride) {
-    const int c = threadIdx.x;
-    if (c >= C) return;
-    part += (size_t)blockIdx.x * C * PB;
-    db += (size_t)blockIdx.x * p_nstride;
-    float s = 0.f;
-    for (int k = 0; k < PB; ++k) s += part[c * PB + k];
-    db[c] = accumulate ? db[c] + s : s;
-}
-int sigmoid_bwd_bias_launch(const float* dout, const float* sout, float* dpre, int N, int C, int HW, float* part, float* db,
-                            int accumulate, hipStream_t s, size_t p_nstride) {
+// returns the number of partial "chunks" per parameter (for the reduce entry): PB, or N * PB for independent images
+int sigmoid_bwd_bias_launch(const float* dout, const float* sout, float* dpre, int N, int C, int HW, float* part, hipStream_t s, size_t p_nstride, int* chunks) {
     const int PB = plane_blocks(HW);
     const int nz = p_nstride ? N : 1;
     SPLICE_LAUNCH(sigmoid_bwd_bias_kernel, dim3(PB, C, nz), dim3(256), 0, s, dout, sout, dpre, N, C, HW, PB, part);
-    SPLICE_LAUNCH(bias_part_reduce_kernel, dim3(nz), dim3(64), 0, s, part, C, PB, db, accumulate, p_nstride);
+    if (chunks) *chunks = PB * nz;
     return SPLICE_OK;
 }
+int sigmoid_bias_part_floats(int N, int C) { return N * C * MAX_PB; }
 int sigmoid_bwd_launch(const float* dout, const float* sout, float* dpre, size_t n, hipStream_t s) {
     size_t g = (n + 255) / 256;
     if (g > 2048) g = 2048;

@@ -84,6 +84,37 @@ def test_gemm_forced_tiles_and_rings(force):
         L.splice_gemm_force_tile(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(700, 512, 256), (1000, 768, 128), (6400, 2304, 768)])
+def test_gemm_8phase_tile_is_bit_identical(M, N, K):
+    """The persistent 256 x 256 8-phase tile (gemm8p.h; forced with tile code 5, and selected by the dispatcher itself at the batched
+    shape 6400 x 2304 x 768 = QKV at four pairs per GPU) gives the SAME bf16 bits as the 128 x 128 tile for both of its epilogues:
+    bias -> bf16 (QKV) and bias -> [bf16 pre-activation of the rows >= pre_row_lo] -> GELU -> bf16 (fc1); ragged M, several tiles per
+    workgroup (the stream of K tiles runs on across output tiles), rows outside the matrix never stored."""
+    L = _lib.lib()
+    A, B = _bf(_rand(M, K, seed=31)), _bf(_rand(N, K, seed=32, std=0.05))
+    bias = _rand(N, seed=33)
+    lo = M // 3
+    outs = {}
+    try:
+        for force in (1, 5, 0):
+            L.splice_gemm_force_tile(force)
+            ob = torch.full((M + 64, N), -7.0, device=DEV, dtype=torch.bfloat16)       # guard rows behind the matrix
+            _gemm(_lib.EPI_BIAS | _lib.EPI_OUT_BF, A, B, M, N, K, bias=bias, out_bf=ob, ldbf=N)
+            og = torch.full((M + 64, N), -7.0, device=DEV, dtype=torch.bfloat16)
+            opre = torch.full((M + 64, N), -7.0, device=DEV, dtype=torch.bfloat16)
+            _gemm(_lib.EPI_BIAS | _lib.EPI_GELU | _lib.EPI_OUT_BF, A, B, M, N, K, bias=bias, out_bf=og, ldbf=N, out_pre=opre, ldp=N, pre_row_lo=lo)
+            outs[force] = (ob, og, opre)
+    finally:
+        L.splice_gemm_force_tile(0)
+    ref = A.float() @ B.float().T + bias
+    assert _relerr(outs[1][0][:M].float(), ref) < 3e-3
+    for force in (5, 0):
+        for a, b, name in zip(outs[force], outs[1], ("qkv", "gelu", "pre")):
+            assert torch.equal(a[:M], b[:M]), (force, name, (a[:M].float() - b[:M].float()).abs().max().item())
+            assert (a[M:] == -7.0).all(), (force, name, "rows behind the matrix were written")
+    assert (outs[5][2][:lo] == -7.0).all() and (outs[5][2][lo:M] != -7.0).any()      # pre-activation only for the gradient-carrying rows
+
+
 @pytest.mark.parametrize("K", [768, 3072])
 def test_gemm_one_wave_tiles(K):
     """2 x 785 tokens, N = 768 with the bias + residual epilogue (proj / fc2 forward): for K = 768 the dispatcher takes one
