@@ -14,11 +14,11 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
     const long t12864 = (long)cdiv(M, 128) * cdiv(N, 64);
     // the batched forward projections with whole 256-column tiles (QKV of the layers without side outputs, fc1) on the persistent
     // 256 x 256 8-phase tile where its grid quantisation is good (gemm8p.h; same bits as every other tile)
-    if constexpr (FLAGS == (EPI_BIAS | EPI_OUT_BF) || FLAGS == (EPI_BIAS | EPI_GELU | EPI_OUT_BF)) {
-        static const int on8p = getenv("SPLICE_GEMM_8P") ? atoi(getenv("SPLICE_GEMM_8P")) : 3;   // bit 0: QKV, bit 1: fc1
-        const bool want = g_force_tile == 5 || (!g_force_tile && (on8p & ((FLAGS & EPI_GELU) ? 2 : 1)) && gemm8p_shape_ok(M, N, K, lda, ldb, e, FLAGS));
-        if (want && N % 256 == 0 && K % 128 == 0 && K >= 128 && e.ldbf % 8 == 0 && !(reinterpret_cast<size_t>(e.out_bf) & 15) && !(reinterpret_cast<size_t>(e.bias) & 15) &&
-            (!(FLAGS & EPI_GELU) || !e.out_pre || (e.ldp % 8 == 0 && !(reinterpret_cast<size_t>(e.out_pre) & 15)))) {
+    if constexpr (FLAGS == (EPI_BIAS | EPI_OUT_BF) || FLAGS == (EPI_BIAS | EPI_GELU | EPI_OUT_BF) || FLAGS == (EPI_BIAS | EPI_RESID | EPI_OUT_F32)) {
+        static const int on8p = getenv("SPLICE_GEMM_8P") ? atoi(getenv("SPLICE_GEMM_8P")) : 7;   // bit 0: QKV, bit 1: fc1, bit 2: proj / fc2 forward
+        const int bit = (FLAGS & EPI_OUT_F32) ? 4 : (FLAGS & EPI_GELU) ? 2 : 1;
+        const bool want = g_force_tile == 5 ? gemm8p_operands_ok(N, K, e, FLAGS) : (!g_force_tile && (on8p & bit) && gemm8p_shape_ok(M, N, K, lda, ldb, e, FLAGS));
+        if (want) {
             launch_gemm8p<FLAGS>(s, A, lda, B, ldb, M, N, K, e);
             return SPLICE_OK;
         }

@@ -208,7 +208,8 @@ struct Gemm8p {
 template <unsigned FLAGS>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb, int M, int N, int K, int gm,
                                                      GemmEpi e) {
-    static_assert(FLAGS == (EPI_BIAS | EPI_OUT_BF) || FLAGS == (EPI_BIAS | EPI_GELU | EPI_OUT_BF), "epilogues of the 8-phase tile");
+    static_assert(FLAGS == (EPI_BIAS | EPI_OUT_BF) || FLAGS == (EPI_BIAS | EPI_GELU | EPI_OUT_BF) || FLAGS == (EPI_BIAS | EPI_RESID | EPI_OUT_F32),
+                  "epilogues of the 8-phase tile");
     extern __shared__ __attribute__((aligned(16))) bf16_t gemm8p_smem[];
     const int tiles_n = N / 256, tiles_m = (M + 255) / 256, ntiles = tiles_m * tiles_n;
     const int G = gridDim.x;
@@ -225,6 +226,36 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const bf16_t* __restrict__ 
                     m0 = tm * 256; n0 = tn * 256;
                 },
                 [&](int m0, int n0) {
+                    if constexpr ((FLAGS & EPI_OUT_F32) != 0) {
+                        // bias + residual -> fp32 (proj / fc2 forward, e.resid_mod == 0): a lane's 4 columns are one 16-byte access; the
+                        // residual rows of a 64 x 32 quadrant are requested together, ahead of their use
+#pragma unroll
+                        for (int nh = 0; nh < 2; ++nh) {
+                            const int colf = n0 + nh * 128 + wc * 32 + grp * 4;
+                            const float4 b0 = *reinterpret_cast<const float4*>(e.bias + colf), b1 = *reinterpret_cast<const float4*>(e.bias + colf + 16);
+#pragma unroll
+                            for (int mh = 0; mh < 2; ++mh) {
+                                float4 r0[4], r1[4];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const int row = min(m0 + mh * 128 + wr * 64 + i * 16 + (lane & 15), M - 1);
+                                    r0[i] = *reinterpret_cast<const float4*>(e.resid + (size_t)row * e.ldr + colf);
+                                    r1[i] = *reinterpret_cast<const float4*>(e.resid + (size_t)row * e.ldr + colf + 16);
+                                }
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const int row = m0 + mh * 128 + wr * 64 + i * 16 + (lane & 15);
+                                    const f32x4 v0 = g.acc[mh * 4 + i][nh * 2 + 0], v1 = g.acc[mh * 4 + i][nh * 2 + 1];
+                                    if (row < M) {
+                                        float* q = e.out_f32 + (size_t)row * e.ldo + colf;
+                                        *reinterpret_cast<float4*>(q) = float4{v0[0] + b0.x + r0[i].x, v0[1] + b0.y + r0[i].y, v0[2] + b0.z + r0[i].z, v0[3] + b0.w + r0[i].w};
+                                        *reinterpret_cast<float4*>(q + 16) = float4{v1[0] + b1.x + r1[i].x, v1[1] + b1.y + r1[i].y, v1[2] + b1.z + r1[i].z, v1[3] + b1.w + r1[i].w};
+                                    }
+                                }
+                            }
+                        }
+                        return;
+                    }
 #pragma unroll
                     for (int nh = 0; nh < 2; ++nh) {
                         const int colf = n0 + nh * 128 + wc * 32 + grp * 4;   // this lane's 4 columns of fragment j = 0 (j = 1: + 16)
@@ -258,11 +289,21 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const bf16_t* __restrict__ 
 
 // quantisation of the persistent grid: 256 workgroups walk ceil(tiles / 256) rounds; the tile pays where the last round is
 // reasonably full (tools/micro/gemm8p.hip, profiles/r04_gemm8p_micro.txt: 450 and 600 tiles win, 300 loses to the 128 x 128 tile)
-static inline bool gemm8p_shape_ok(int M, int N, int K, int lda, int ldb, const GemmEpi& e, unsigned flags) {
-    if (N % 256 || K % 128 || K < 128 || M < 256) return false;
-    if (e.ldbf % 8 || (reinterpret_cast<size_t>(e.out_bf) & 15) || (reinterpret_cast<size_t>(e.bias) & 15)) return false;
+// the operands' alignment the epilogue needs (16-byte accesses)
+static inline bool gemm8p_operands_ok(int N, int K, const GemmEpi& e, unsigned flags) {
+    if (N % 256 || K % 128 || K < 128 || (reinterpret_cast<size_t>(e.bias) & 15)) return false;
+    if (flags & EPI_OUT_F32)
+        return !e.resid_mod && e.ldr % 4 == 0 && e.ldo % 4 == 0 && !(reinterpret_cast<size_t>(e.resid) & 15) && !(reinterpret_cast<size_t>(e.out_f32) & 15);
+    if (e.ldbf % 8 || (reinterpret_cast<size_t>(e.out_bf) & 15)) return false;
     if ((flags & EPI_GELU) && e.out_pre && (e.ldp % 8 || (reinterpret_cast<size_t>(e.out_pre) & 15))) return false;
+    return true;
+}
+static inline bool gemm8p_shape_ok(int M, int N, int K, int lda, int ldb, const GemmEpi& e, unsigned flags) {
+    if (!gemm8p_operands_ok(N, K, e, flags) || M < 256) return false;
     const long tiles = (long)((M + 255) / 256) * (N / 256);
+    // N = 768 (proj / fc2 forward): three column tiles only -- from 128 tiles on, one round of the chip (the stand-alone loop beats
+    // the 128 x 64 tiles already on 150 of the 256 CUs: 871 against 770 TFLOP/s at 12800 x 768 x 3072)
+    if ((flags & EPI_OUT_F32) && tiles >= 128 && tiles <= 256) return true;
     if (tiles < 200) return false;
     const long rounds = (tiles + 255) / 256;
     return tiles * 100 >= rounds * 256 * 75;

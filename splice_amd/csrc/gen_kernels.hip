@@ -106,9 +106,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, int bx, int b
         a_off[i] = ok ? (int)(cl * a.in_cstride) + sy * a.Wi + sx : 0;
         if (ok) a_ok |= 1ull << i;
     }
-    static_assert(NW <= 32, "weight mask");
+    static_assert(NW <= 64, "weight mask");
     int w_off[NW], w_cl[NW], w_lds[NW];
-    unsigned w_ok = 0;
+    unsigned long long w_ok = 0;
 #pragma unroll
     for (int t = 0; t < NW; ++t) {
         const int e = tid + NTH * t;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, int bx, int b
         w_cl[t] = cl;
         w_off[t] = ok ? (int)((size_t)(n0 + j) * a.w_jstride + (size_t)cl * a.w_cstride + tap) : 0;
         w_lds[t] = e < BN * KT ? j * LDW + k : -1;
-        if (ok) w_ok |= 1u << t;
+        if (ok) w_ok |= 1ull << t;
     }
     float av[NA], wv[NW];
     auto fetch = [&](int c0) {
@@ -127,7 +127,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, int bx, int b
 #pragma unroll
         for (int i = 0; i < NA; ++i) av[i] = ((a_ok >> i) & 1ull) && (c0 + a_cl[i] < Kc) ? inc[a_off[i]] : 0.f;
 #pragma unroll
-        for (int t = 0; t < NW; ++t) wv[t] = ((w_ok >> t) & 1u) && (c0 + w_cl[t] < Kc) ? wc[w_off[t]] : 0.f;
+        for (int t = 0; t < NW; ++t) wv[t] = ((w_ok >> t) & 1ull) && (c0 + w_cl[t] < Kc) ? wc[w_off[t]] : 0.f;
     };
     f32x4 acc[FN];
 #pragma unroll
@@ -343,6 +343,9 @@ static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
 }
 
 // channels per K tile as conv_launch picks them (deeper tiles where the reduction is long)
+// (K tiles of 16 channels = 144 k-values for the 3x3 layers with >= 64 / 128 input channels -- half the barrier rounds, twice the
+// gathered loads in flight per round -- measured +2.0 % / +1.3 % step time at one pair per GPU, +2.4 % at eight: not kept,
+// profiles/r04_gen_ab.txt)
 static inline int conv_ck(const ConvArgs& a) { return a.ks == 3 ? (a.Cin >= 32 ? 8 : 4) : a.ks == 1 ? (a.Cin >= 64 ? 32 : 16) : 4; }
 
 // Two INDEPENDENT convolutions in one launch (conv_pair_kernel).  Forward: a = the 1x1 skip convolution of a scale, b = its 3x3

@@ -103,13 +103,16 @@ def test_gemm_8phase_tile_is_bit_identical(M, N, K):
             og = torch.full((M + 64, N), -7.0, device=DEV, dtype=torch.bfloat16)
             opre = torch.full((M + 64, N), -7.0, device=DEV, dtype=torch.bfloat16)
             _gemm(_lib.EPI_BIAS | _lib.EPI_GELU | _lib.EPI_OUT_BF, A, B, M, N, K, bias=bias, out_bf=og, ldbf=N, out_pre=opre, ldp=N, pre_row_lo=lo)
-            outs[force] = (ob, og, opre)
+            of = torch.full((M + 64, N), -7.0, device=DEV)
+            resid = _rand(M, N, seed=34)
+            _gemm(_lib.EPI_BIAS | _lib.EPI_RESID | _lib.EPI_OUT_F32, A, B, M, N, K, bias=bias, resid=resid, ldr=N, resid_mod=0, out_f32=of, ldo=N)
+            outs[force] = (ob, og, opre, of)
     finally:
         L.splice_gemm_force_tile(0)
     ref = A.float() @ B.float().T + bias
     assert _relerr(outs[1][0][:M].float(), ref) < 3e-3
     for force in (5, 0):
-        for a, b, name in zip(outs[force], outs[1], ("qkv", "gelu", "pre")):
+        for a, b, name in zip(outs[force], outs[1], ("qkv", "gelu", "pre", "bias + residual -> fp32 (proj / fc2)")):
             assert torch.equal(a[:M], b[:M]), (force, name, (a[:M].float() - b[:M].float()).abs().max().item())
             assert (a[M:] == -7.0).all(), (force, name, "rows behind the matrix were written")
     assert (outs[5][2][:lo] == -7.0).all() and (outs[5][2][lo:M] != -7.0).any()      # pre-activation only for the gradient-carrying rows
