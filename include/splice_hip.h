@@ -109,7 +109,9 @@ int splice_gemm_nt_fp8(unsigned flags, const uint8_t* A, int lda, const uint8_t*
 int splice_quantize_rows_fp8(const float* x, int ldx, uint8_t* q, int ldq, float* scale, int rows, int cols, splice_stream_t stream);
 /* number of slabs a split-K call with M rows leaves for its consumer: ksplit (few rows) or 1 (the sum formed in the kernel) */
 int splice_gemm_splitk_slabs(int M, int ksplit);
-/* benchmarking hook (tools/gemm_bench.py): force the tile shape, 0 = automatic */
+/* benchmarking / test hook (tools/gemm_bench.py, tests/test_ops_gpu.py): force the tile shape, 0 = automatic; tile + 10 * ring with tile 1..3 =
+ * the one-barrier tiles 128x128, 128x64, 64x64 and ring 0 / 1 / 2 = 2 / 4 / 3 LDS stages; 5 = the 8-phase 256x256 tile (gemm8p.h) wherever its operand and
+ * epilogue constraints hold (N % 256 == 0, K % 128 == 0, bias [+GELU] -> bf16 or bias + residual -> fp32) */
 int splice_gemm_force_tile(int tile);
 /* benchmarking hook (tools/attn_bench.py): pick an attention kernel variant, 0 = default */
 int splice_attention_variant(int variant);

@@ -89,6 +89,10 @@ struct SpliceGenPlan {
     float* cat[MAXS]; float* d_cat[MAXS]; // [N][skip+k][h][w]
     int kch[MAXS];
     bool chain[MAXS];                     // scale i: the skip branch's BatchNorm runs inside the concat BatchNorm's kernels (BnPre), forward and backward
+    float* skip_ws[MAXS];                 // chained skip convolution: its split-K slabs stay here until the concat BatchNorm sums them (conv_ws is reused in between)
+    size_t skip_ws_floats[MAXS];
+    int skip_ks[MAXS];                    // slabs left by the last forward (<= 1: none, u_skip.y is complete)
+    struct { const float* target = nullptr; const float* slabs = nullptr; int ksplit = 0, accumulate = 0; } pend;   // backward: slabs of the next BatchNorm's output gradient
     float* pad_scratch = nullptr;         // reflection padding: padded-domain data gradient of one layer (largest layer)
     float* head_y = nullptr;              // unused (sigmoid fused)
     size_t head_w = 0, head_b = 0;
@@ -197,6 +201,9 @@ static void plan_configure(SpliceGenPlan* p, int H, int W) {
             u.y_ns = (size_t)u.Cout * Ho * Wo;
             if (u.own_out) { u.out_ns = u.y_ns; u.d_out_ns = u.y_ns; }
         };
+        // the skip branch's BatchNorm rides in the concat BatchNorm's kernels where those own whole planes (BnPre)
+        p->chain[i] = A.skip[i] > 0 && bn_pre_supported(hi * wi, p->N, p->p_nstride, p->batch_stats);
+        p->skip_ks[i] = 1;
         dims(sk, hi, wi, hi, wi); dims(da, hi, wi, hd, wd); dims(db, hd, wd, hd, wd);
         dims(ct, hi, wi, hi, wi); dims(u3, hi, wi, hi, wi); dims(u1, hi, wi, hi, wi);
         sk.out = p->cat[i]; sk.out_ns = cat_ns;
@@ -245,6 +252,7 @@ static BnPre skip_pre(const SpliceGenPlan* p, int i, const float* params, float*
     pr.mean = sk.mean; pr.rstd = sk.rstd; pr.slope = sk.slope; pr.C = sk.Cout;
     pr.dy = sk.dy;
     if (grads) { pr.dgamma = grads + sk.g_off; pr.dbeta = grads + sk.be_off; }
+    else if (p->skip_ks[i] > 1) { pr.slabs = p->skip_ws[i]; pr.ksplit = p->skip_ks[i]; pr.bias = params + sk.b_off; }
     return pr;
 }
 // BatchNorm + activation of a unit behind its convolution (ksplit > 1 with a deferred reduction: the slabs at `slabs` are summed here)
@@ -275,13 +283,17 @@ static int unit_forward(const SpliceGenPlan* p, const Unit& u, const float* para
 // scale): their convolutions share one launch (conv_pair_launch); a = the 1x1 unit
 // a_bn_later: a's BatchNorm runs inside a later kernel (BnPre of the concat BatchNorm): a split-K convolution then sums its slabs
 // itself (same order as the BatchNorm kernel would: same bits) -- the slab workspace is reused long before that kernel runs
-static int unit_pair_forward(const SpliceGenPlan* p, const Unit& ua, const Unit& ub, const float* params, hipStream_t s, bool a_bn_later) {
+static int unit_pair_forward(SpliceGenPlan* p, int scale, const Unit& ua, const Unit& ub, const float* params, hipStream_t s, bool a_bn_later) {
     const size_t half = p->conv_ws_floats / 2;
     ConvArgs a = unit_conv_args(p, ua, params, p->conv_ws, half);
-    if (a_bn_later) a.defer_reduce = 0;
+    if (a_bn_later) {   // the slabs must outlive the deeper scales' convolutions: own workspace (none: summed here, same order, same bits)
+        if (p->skip_ws[scale] && (size_t)a.N * a.Cout * a.Ho * a.Wo * 16 <= p->skip_ws_floats[scale]) { a.ws = p->skip_ws[scale]; a.ws_floats = p->skip_ws_floats[scale]; }
+        else a.defer_reduce = 0;
+    }
     const ConvArgs b = unit_conv_args(p, ub, params, p->conv_ws + half, half);
     int ksa = 1, ksb = 1;
     RC(conv_pair_launch(a, b, s, &ksa, &ksb));
+    p->skip_ks[scale] = a_bn_later && a.defer_reduce ? ksa : 1;
     if (!a_bn_later) RC(unit_bn_forward(p, ua, params, ua.y, ua.y_ns, a.ws, ksa, a.defer_reduce != 0, s, nullptr));
     RC(unit_bn_forward(p, ub, params, ub.y, ub.y_ns, b.ws, ksb, b.defer_reduce != 0, s, nullptr));
     return SPLICE_OK;
@@ -297,9 +309,17 @@ static int unit_backward_bn(const SpliceGenPlan* p, const Unit& u, const float* 
     const size_t y_ns = u.ks ? u.y_ns : u.in_ns;
     float* dy = u.ks ? u.dy : u.d_in;          // BN-only unit: dy IS the input gradient
     const size_t dy_ns = u.ks ? u.y_ns : u.d_in_ns;
-    if (!bn_done)
+    auto& pend = const_cast<SpliceGenPlan*>(p)->pend;
+    if (pend.target && (bn_done || pend.target != u.d_out)) {
+        splice_set_error("generator backward: split-K slabs pending for a gradient that the next BatchNorm does not read");
+        return SPLICE_ERR_STATE;
+    }
+    if (!bn_done) {
+        BnSlabs sl;
+        if (pend.target) { sl.slabs = pend.slabs; sl.ksplit = pend.ksplit; sl.accumulate = pend.accumulate; pend.target = nullptr; }
         RC(bn_bwd_launch(u.d_out, u.d_out_ns, u.out, u.out_ns, y, y_ns, dy, dy_ns, N, u.Cout, HW, params + u.g_off, u.mean, u.rstd, u.slope,
-                         u.s1, grads + u.g_off, grads + u.be_off, acc, s, p->batch_stats ? nullptr : up, p->p_nstride, p->batch_stats, pre));
+                         u.s1, grads + u.g_off, grads + u.be_off, acc, s, p->batch_stats ? nullptr : up, p->p_nstride, p->batch_stats, pre, &sl));
+    }
     if (!u.ks) return SPLICE_OK;
     // The bias of a conv that feeds a train-mode BatchNorm has an analytically ZERO gradient (BN subtracts the
     // per-channel mean, sum_p dy = 0); the reference's autograd returns fp32 rounding noise there.  We write the
@@ -336,19 +356,35 @@ static ConvArgs unit_dgrad_args(const SpliceGenPlan* p, const Unit& u, const flo
     a.ws = ws; a.ws_floats = ws_floats;
     return a;
 }
+// A split-K data gradient whose result is read by exactly one kernel -- the small-plane BatchNorm backward of the unit that
+// produced this unit's input, which runs next -- leaves its slabs to that kernel (BnSlabs) instead of launching the reduction.
+// last_writer: no other convolution adds to d_in after this one.
+static bool dgrad_may_defer(const SpliceGenPlan* p, const Unit& u, bool last_writer) {
+    return last_writer && u.ks && u.d_in && !(p->gen->arch.reflect && u.ks > 1) && u.d_in_ns == (size_t)u.Cin * u.Hi * u.Wi &&
+           bn_bwd_takes_slabs(u.Hi * u.Wi, p->N, p->p_nstride, p->batch_stats);
+}
+static void dgrad_note_slabs(const SpliceGenPlan* p, const ConvArgs& a, int ksplit) {
+    if (!a.defer_reduce || ksplit <= 1) return;
+    auto& pend = const_cast<SpliceGenPlan*>(p)->pend;
+    pend.target = a.out; pend.slabs = a.ws; pend.ksplit = ksplit; pend.accumulate = a.accumulate;
+}
 // second part: the data gradient (if the unit's input needs one)
-static int unit_backward_dgrad(const SpliceGenPlan* p, const Unit& u, const float* params, int accumulate, hipStream_t s) {
+static int unit_backward_dgrad(const SpliceGenPlan* p, const Unit& u, const float* params, int accumulate, hipStream_t s, bool last_writer = false) {
     if (!u.ks || !u.d_in) return SPLICE_OK;
-    const ConvArgs a = unit_dgrad_args(p, u, params, accumulate, p->conv_ws, p->conv_ws_floats);
-    if (p->gen->arch.reflect && u.ks > 1) RC(conv_reflect_dgrad_launch(a, p->pad_scratch, s));
-    else RC(conv_launch(a, s));
+    ConvArgs a = unit_dgrad_args(p, u, params, accumulate, p->conv_ws, p->conv_ws_floats);
+    if (p->gen->arch.reflect && u.ks > 1) { RC(conv_reflect_dgrad_launch(a, p->pad_scratch, s)); return SPLICE_OK; }
+    a.defer_reduce = dgrad_may_defer(p, u, last_writer);
+    int ks = 1;
+    RC(conv_launch(a, s, &ks));
+    dgrad_note_slabs(p, a, ks);
     return SPLICE_OK;
 }
 // backward of one unit: consumes u.d_out, produces parameter grads and (optionally) u.d_in
+// last_writer: the unit's data gradient is the only (or the last) contribution to d_in and the BatchNorm backward that reads d_in runs next
 static int unit_backward(const SpliceGenPlan* p, const Unit& u, const float* params, float* grads, int acc, hipStream_t s,
-                         const BnUpsample* up = nullptr, const BnPre* pre = nullptr, bool bn_done = false) {
+                         const BnUpsample* up = nullptr, const BnPre* pre = nullptr, bool bn_done = false, bool last_writer = false) {
     RC(unit_backward_bn(p, u, params, grads, acc, s, up, pre, bn_done));
-    return unit_backward_dgrad(p, u, params, u.d_in_accumulate, s);
+    return unit_backward_dgrad(p, u, params, u.d_in_accumulate, s, last_writer);
 }
 
 static size_t wgrad_ws_need(const SpliceGenPlan* p, const Unit& u) {
@@ -430,6 +466,11 @@ int splice_gen_plan_create(void* h, int N, int H, int W, int need_grad, void** o
             const size_t pd = A.filter_down[i] / 2, pu = A.filter_up[i] / 2;
             const size_t cand[3] = {(size_t)cin * (hi + 2 * pd) * (wi + 2 * pd), (size_t)A.down[i] * (hd + 2 * pd) * (wd + 2 * pd), catC * (hi + 2 * pu) * (wi + 2 * pu)};
             for (size_t c : cand) if (N * c > pad_need) pad_need = N * c;
+        }
+        p->skip_ws[i] = nullptr; p->skip_ws_floats[i] = 0;
+        if (hi * wi <= bn_small_hw() && A.skip[i] > 0) {   // split-K slabs of a chained skip convolution (up to 16 slices)
+            p->skip_ws_floats[i] = (size_t)16 * N * A.skip[i] * hi * wi;
+            if ((rc = palloc(p, &p->skip_ws[i], p->skip_ws_floats[i])) != SPLICE_OK) break;
         }
         if ((rc = palloc(p, &p->cat[i], (size_t)N * catC * hi * wi)) != SPLICE_OK) break;
         if (need_grad && (rc = palloc(p, &p->d_cat[i], (size_t)N * catC * hi * wi)) != SPLICE_OK) break;
@@ -567,7 +608,7 @@ void splice_gen_plan_destroy(void* plan) {
 }
 
 static int scale_forward(SpliceGenPlan* p, int i, const float* params, hipStream_t s) {
-    RC(unit_pair_forward(p, p->u_skip[i], p->u_da[i], params, s, p->chain[i]));
+    RC(unit_pair_forward(p, i, p->u_skip[i], p->u_da[i], params, s, p->chain[i]));
     RC(unit_forward(p, p->u_db[i], params, s));
     const float* deep = p->u_db[i].out;
     size_t deep_ns = p->u_db[i].out_ns;
@@ -637,8 +678,9 @@ int splice_gen_forward_borrowed(void* plan, const float* params, const float* x,
 // head_done: the caller has already run the backward of u_up1[i] (paired with the shallower scale's skip branch)
 static int scale_backward(SpliceGenPlan* p, int i, const float* params, float* grads, int acc, hipStream_t s, bool head_done = false) {
     // u_up1[i].d_out holds d u_i
-    if (!head_done) RC(unit_backward(p, p->u_up1[i], params, grads, acc, s));
-    RC(unit_backward(p, p->u_up3[i], params, grads, acc, s));
+    // (up1 -> up3 -> concat: each data gradient is read by the next BatchNorm backward only, which sums its split-K slabs)
+    if (!head_done) RC(unit_backward(p, p->u_up1[i], params, grads, acc, s, nullptr, nullptr, false, true));
+    RC(unit_backward(p, p->u_up3[i], params, grads, acc, s, nullptr, nullptr, false, true));
     const int hi = p->h[i], wi = p->w[i];
     const GenArch& A = p->gen->arch;
     const int SKIPC = A.skip[i];
@@ -662,12 +704,17 @@ static int scale_backward(SpliceGenPlan* p, int i, const float* params, float* g
         RC(unit_backward_bn(p, sk, params, grads, acc, s, nullptr, nullptr, chained));
         RC(unit_backward_bn(p, h1, params, grads, acc, s));
         const size_t half = p->conv_ws_floats / 2;
-        RC(conv_pair_launch(unit_dgrad_args(p, sk, params, 0, p->conv_ws, half), unit_dgrad_args(p, h1, params, h1.d_in_accumulate, p->conv_ws + half, half), s));
+        ConvArgs db = unit_dgrad_args(p, h1, params, h1.d_in_accumulate, p->conv_ws + half, half);
+        db.defer_reduce = dgrad_may_defer(p, h1, true);   // read by up3_{i+1}'s BatchNorm backward, the next launch
+        int ksa = 1, ksb = 1;
+        RC(conv_pair_launch(unit_dgrad_args(p, sk, params, 0, p->conv_ws, half), db, s, &ksa, &ksb));
+        dgrad_note_slabs(p, db, ksb);
     }
     if (i < A.n_scales - 1) RC(scale_backward(p, i + 1, params, grads, acc, s, skip_early));   // leaves d x_{i+1} in u_db[i].d_out
-    RC(unit_backward(p, p->u_db[i], params, grads, acc, s));
+    RC(unit_backward(p, p->u_db[i], params, grads, acc, s, nullptr, nullptr, false, true));
     RC(unit_backward_bn(p, p->u_da[i], params, grads, acc, s));
-    RC(unit_backward_dgrad(p, p->u_da[i], params, skip_early ? 1 : p->u_da[i].d_in_accumulate, s));
+    // (with the skip branch's data gradient already in d x_i, the encoder's is the last writer and u_db[i-1]'s BatchNorm backward runs next)
+    RC(unit_backward_dgrad(p, p->u_da[i], params, skip_early ? 1 : p->u_da[i].d_in_accumulate, s, skip_early));
     if (!skip_early) RC(unit_backward(p, p->u_skip[i], params, grads, acc, s, nullptr, nullptr, chained));
     return SPLICE_OK;
 }

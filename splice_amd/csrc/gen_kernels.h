@@ -94,6 +94,14 @@ struct BnPre {
     float* dy = nullptr;                             // gradient w.r.t. the skip convolution's output [N][C][HW]
     float* dgamma = nullptr; float* dbeta = nullptr;
 };
+// The output gradient of a BatchNorm, left as split-K slabs by the data-gradient convolution that produces it (deferred reduction,
+// backward direction): d_out = (accumulate ? what the first writer stored at d_out : 0) + sum_k slabs[k], formed by the BatchNorm
+// backward while it loads the plane -- the arithmetic and order of conv_splitk_reduce_kernel, which then has no launch (round 4).
+struct BnSlabs {
+    const float* slabs = nullptr;   // [ksplit][N][C][HW]
+    int ksplit = 0, accumulate = 0;
+};
+bool bn_bwd_takes_slabs(int HW, int N, size_t p_nstride, int batch);
 bool bn_pre_supported(int HW, int N, size_t p_nstride, int batch);   // the concat BatchNorm of this size runs as ONE launch that can host a BnPre
 bool bn_bwd_fuses_upsample(int HW, int h, int w);
 bool bn_bwd_fuses_upsample_ex(int HW, int h, int w, int N, size_t p_nstride, int batch);   // incl. the one-launch form of the middle planes
@@ -109,7 +117,7 @@ int bn_fwd_slabs_launch(const float* slabs, int ksplit, const float* bias, float
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
                   float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up = nullptr, size_t p_nstride = 0,
-                  int batch = 0, const BnPre* pre = nullptr);
+                  int batch = 0, const BnPre* pre = nullptr, const BnSlabs* slabs = nullptr);
 int fill_zero_launch(float* p, int n, hipStream_t s);
 int channel_sum_launch(const float* dy, size_t nstride, int N, int C, int HW, float* db, int accumulate, hipStream_t s);
 int upsample2x_fwd_launch(const float* in, size_t in_nstride, float* out, size_t out_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s);

@@ -999,6 +999,30 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
 // Small planes (<= BN_SMALL_HW pixels: every layer from the 56x56 scale down at 224^2): ONE workgroup owns a whole
 // (image, channel) plane, so statistics + apply are a single launch (the plane is re-read from L1/L2).  These layers are
 // pure launch latency -- a kernel boundary costs more than the work.
+// pins a value in a register as the rounded fp32 number it is: the compiler cannot fuse the multiply that produced it into an
+// add that consumes it (-ffp-contract=fast works across statements), which keeps a fused kernel bit-identical to the two kernels
+// it replaces, where the value went through memory
+__device__ __forceinline__ void rounded(float& x) { asm volatile("" : "+v"(x)); }
+// The BatchNorm backward's per-element arithmetic, written once with every rounding pinned (products that feed a sum are rounded
+// or fused EXPLICITLY), so that the stand-alone kernels and the chained forms (BnPre) cannot be contracted differently:
+//   dz = da * (a > 0 ? 1 : slope);  xhat = (y - mean) rstd;  s1 += dz;  s2 = fma(dz, xhat, s2);
+//   dy = gamma rstd ((dz - s1/n) - xhat (s2/n))
+__device__ __forceinline__ float bn_dz(float d, float a, float slope, bool act) {
+    if (act && !(a > 0.f)) { d *= slope; rounded(d); }
+    return d;
+}
+__device__ __forceinline__ float bn_xhat(float y, float m, float r) {
+    float x = (y - m) * r;
+    rounded(x);
+    return x;
+}
+__device__ __forceinline__ float bn_dy(float gr, float dz, float k1, float xh, float k2) {
+    float t = xh * k2;
+    rounded(t);
+    float g = gr * ((dz - k1) - t);
+    rounded(g);
+    return g;
+}
 constexpr int BN_SMALL_HW = 4096;
 constexpr int BN_MAX_BATCH = 8;               // images per batch-statistics call (n_crops)
 constexpr int BN_SMALL_PER = BN_SMALL_HW / 256;   // most plane elements a thread keeps in registers (kernels are instantiated for 1, 4 and 16:
@@ -1094,6 +1118,7 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
             const int i = threadIdx.x + k * 256;
             const float t = v[k] * sc1 + sh1;
             v[k] = i < HW ? (t > 0.f ? t : t * pre.slope) : 0.f;
+            rounded(v[k]);   // the value the stand-alone kernels hand over through memory: nothing may be contracted across it
             if (i < HW) yo2[i] = v[k];
             s += v[k];
         }
@@ -1227,9 +1252,12 @@ __global__ __launch_bounds__(256) void bn_small_fwd_kernel(const float* y, size_
 // one workgroup per (channel, image); each plane is read once and kept in registers between the reduction and the apply
 // pass.  dgamma / dbeta need the sums of EVERY image: the workgroup of image 0 recomputes the other images' two sums
 // (reads only) and adds them in image order -- deterministic, no second launch, no cross-workgroup wait.
+// sl.slabs != null: the output gradient of this plane was left as split-K slabs by the data-gradient convolution that produces it
+// (BnSlabs): d = (accumulate ? the value at pd : 0) + (0 + slab 0 + slab 1 + ...), the arithmetic of conv_splitk_reduce_kernel
 template <int PER>
 __device__ __forceinline__ void bn_small_bwd_sums(const float* pd, const float* pa, const float* py, int HW, float m, float r, float slope,
-                                                  float (&dz)[PER], float (&xh)[PER], float& s1, float& s2, float* red) {
+                                                  float (&dz)[PER], float (&xh)[PER], float& s1, float& s2, float* red,
+                                                  const float* sp = nullptr, size_t per = 0, int ksplit = 0, int sl_acc = 0) {
     s1 = 0.f; s2 = 0.f;
     // branch-free loads first (see bn_small_fwd_kernel), arithmetic after
     const bool act = slope != 1.0f;
@@ -1239,23 +1267,51 @@ __device__ __forceinline__ void bn_small_bwd_sums(const float* pd, const float* 
         if (k * 256 >= HW) continue;
         const int i = threadIdx.x + k * 256;
         const int j = i < HW ? i : 0;
-        vd[k] = pd[j];
+        vd[k] = (!sp || sl_acc) ? pd[j] : 0.f;
         vy[k] = py[j];
         va[k] = act ? pa[j] : 1.f;
+    }
+    if (sp) {
+        float v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) v[k] = 0.f;
+        for (int ks = 0; ks < ksplit; ks += 4) {   // slice order, four slices of loads in flight
+            float t[4][PER];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ks + u >= ksplit) continue;
+                const float* sk = sp + (size_t)(ks + u) * per;
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    if (k * 256 >= HW) continue;
+                    const int i = threadIdx.x + k * 256;
+                    t[u][k] = sk[i < HW ? i : 0];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ks + u >= ksplit) continue;
+#pragma unroll
+                for (int k = 0; k < PER; ++k)
+                    if (k * 256 < HW) v[k] += t[u][k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (k * 256 < HW) vd[k] = sl_acc ? vd[k] + v[k] : v[k];
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int i = threadIdx.x + k * 256;
         float d = 0.f, x = 0.f;
         if (k * 256 < HW) {
-            d = vd[k];
-            if (act && !(va[k] > 0.f)) d *= slope;
-            x = (vy[k] - m) * r;
+            d = bn_dz(vd[k], va[k], slope, act);
+            x = bn_xhat(vy[k], m, r);
             if (i >= HW) { d = 0.f; x = 0.f; }
         }
         dz[k] = d; xh[k] = x;
         s1 += d;
-        s2 += d * x;
+        s2 = __builtin_fmaf(d, x, s2);
     }
     block_sum2(s1, s2, red);
 }
@@ -1265,7 +1321,8 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
                                                            float* __restrict__ dy, size_t dy_nstride, int C, int HW, int N,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, float slope, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int accumulate, BnUpsample up, size_t p_nstride, int batch, BnPre pre) {
+                                                           float* __restrict__ dbeta, int accumulate, BnUpsample up, size_t p_nstride, int batch, BnPre pre,
+                                                           BnSlabs sl) {
     __shared__ float red[8];
     __shared__ float up_grad_s[BN_SMALL_HW];   // fused upsampling adjoint: this plane's input gradient
     const int c = blockIdx.x, img = blockIdx.y;
@@ -1292,7 +1349,8 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
                 if (n < N) { b1 += n == img ? s1 : t1s[n]; b2 += n == img ? s2 : t2s[n]; }
         } else {
             bn_small_bwd_sums<PER>(da + (size_t)img * da_nstride + (size_t)c * HW, aout + (size_t)img * a_nstride + (size_t)c * HW,
-                              y + (size_t)img * y_nstride + (size_t)c * HW, HW, m, r, slope, dz, xh, s1, s2, red);
+                              y + (size_t)img * y_nstride + (size_t)c * HW, HW, m, r, slope, dz, xh, s1, s2, red,
+                              sl.slabs ? sl.slabs + ((size_t)img * C + c) * HW : nullptr, (size_t)gridDim.y * C * HW, sl.ksplit, sl.accumulate);
         }
         const float cnt = batch ? (float)HW * (float)N : (float)HW;
         const float k1 = (batch ? b1 : s1) / cnt, k2 = (batch ? b2 : s2) / cnt;
@@ -1304,7 +1362,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
         for (int k = 0; k < PER; ++k) {
             const int i = threadIdx.x + k * 256;
             if (i < HW) {
-                const float gv = gr * (dz[k] - k1 - xh[k] * k2);
+                const float gv = bn_dy(gr, dz[k], k1, xh[k], k2);
                 if (through_adjoint) up_grad_s[i] = gv; else if (chained) dz[k] = gv; else po[i] = gv;
             } else if (chained) dz[k] = 0.f;
         }
@@ -1328,13 +1386,12 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
                 const int i = threadIdx.x + k * 256;
                 float d = 0.f, x = 0.f;
                 if (k * 256 < HW && i < HW) {
-                    d = dz[k];
-                    if (!(va[k] > 0.f)) d *= pre.slope;
-                    x = (vy[k] - m1) * r1;
+                    d = bn_dz(dz[k], va[k], pre.slope, true);
+                    x = bn_xhat(vy[k], m1, r1);
                 }
                 dz[k] = d; xh[k] = x;
                 t1 += d;
-                t2 += d * x;
+                t2 = __builtin_fmaf(d, x, t2);
             }
             block_sum2(t1, t2, red);
             const float j1 = t1 / (float)HW, j2 = t2 / (float)HW;
@@ -1343,7 +1400,7 @@ __global__ __launch_bounds__(256) void bn_small_bwd_kernel(const float* __restri
 #pragma unroll
             for (int k = 0; k < PER; ++k) {
                 const int i = threadIdx.x + k * 256;
-                if (i < HW) pd1[i] = gr1 * (dz[k] - j1 - xh[k] * j2);
+                if (i < HW) pd1[i] = bn_dy(gr1, dz[k], j1, xh[k], j2);
             }
             if (threadIdx.x == 0) {
                 float* dg = pre.dgamma + (size_t)img * p_nstride + c;
@@ -1446,7 +1503,7 @@ __global__ __launch_bounds__(BN_MID_THREADS) void bn_mid_fwd_kernel(const float*
         const float sc1 = pre.gamma[(size_t)img * p_nstride + c] * r1;
         const float sh1 = pre.beta[(size_t)img * p_nstride + c] - m1 * sc1;
         float* yo2 = const_cast<float*>(p);
-        auto act1 = [&](float x) { const float t = x * sc1 + sh1; return t > 0.f ? t : t * pre.slope; };
+        auto act1 = [&](float x) { const float t = x * sc1 + sh1; float a = t > 0.f ? t : t * pre.slope; rounded(a); return a; };
         bn_mid_for(HW, vec1,
                    [&](int i) {
                        const float4 v = reinterpret_cast<const float4*>(bn_mid_plane)[i];
@@ -1516,9 +1573,9 @@ __global__ __launch_bounds__(BN_MID_THREADS) void bn_mid_bwd_kernel(const float*
     const bool vec = !(HW & 3) && !((reinterpret_cast<size_t>(pd) | reinterpret_cast<size_t>(pa) | reinterpret_cast<size_t>(py) | reinterpret_cast<size_t>(po)) & 15);
     float s1 = 0.f, s2 = 0.f;
     auto one = [&](float d, float a, float yv) {
-        if (act && !(a > 0.f)) d *= slope;
+        d = bn_dz(d, a, slope, act);
         s1 += d;
-        s2 += d * ((yv - m) * r);
+        s2 = __builtin_fmaf(d, bn_xhat(yv, m, r), s2);
         return d;
     };
     bn_mid_for(HW, vec,
@@ -1532,7 +1589,7 @@ __global__ __launch_bounds__(BN_MID_THREADS) void bn_mid_bwd_kernel(const float*
     const float k1 = s1 / (float)HW, k2 = s2 / (float)HW;
     const float gr = gamma[c] * r;
     const bool through_adjoint = up.d_src && c >= up.c0;   // workgroup-uniform
-    auto grad = [&](float dz, float yv) { return gr * (dz - k1 - (yv - m) * r * k2); };
+    auto grad = [&](float dz, float yv) { return bn_dy(gr, dz, k1, bn_xhat(yv, m, r), k2); };
     if (pre.y && c < pre.C) {
         // the adjoint of the skip branch's BatchNorm + LeakyReLU behind the concat's (BnPre): the gradient w.r.t. the activated skip
         // plane a (= this BatchNorm's input y) stays in LDS.  Access pattern and summation order of a launch on the skip unit alone.
@@ -1542,10 +1599,9 @@ __global__ __launch_bounds__(BN_MID_THREADS) void bn_mid_bwd_kernel(const float*
         const bool vec1 = vec && !((reinterpret_cast<size_t>(py1) | reinterpret_cast<size_t>(pd1)) & 15);
         float t1 = 0.f, t2 = 0.f;
         auto one1 = [&](float dzc, float a, float y1) {
-            float d = grad(dzc, a);
-            if (!(a > 0.f)) d *= pre.slope;
+            const float d = bn_dz(grad(dzc, a), a, pre.slope, true);
             t1 += d;
-            t2 += d * ((y1 - m1) * r1);
+            t2 = __builtin_fmaf(d, bn_xhat(y1, m1, r1), t2);
             return d;
         };
         bn_mid_for(HW, vec1,
@@ -1557,7 +1613,7 @@ __global__ __launch_bounds__(BN_MID_THREADS) void bn_mid_bwd_kernel(const float*
         block_sum2_1024(t1, t2, red);
         const float j1 = t1 / (float)HW, j2 = t2 / (float)HW;
         const float gr1 = pre.gamma[(size_t)img * p_nstride + c] * r1;
-        auto grad1 = [&](float dz, float y1) { return gr1 * (dz - j1 - (y1 - m1) * r1 * j2); };
+        auto grad1 = [&](float dz, float y1) { return bn_dy(gr1, dz, j1, bn_xhat(y1, m1, r1), j2); };
         bn_mid_for(HW, vec1,
                    [&](int i) {
                        const float4 dz = reinterpret_cast<const float4*>(bn_mid_plane)[i], y1 = reinterpret_cast<const float4*>(py1)[i];
@@ -1620,13 +1676,40 @@ static inline bool bn_mid_ok(int HW, int N, size_t p_nstride, int batch) {
 // 512-pixel segments (tuned in-step with alternating runs: 1024 +0.45 %, 256 / 384 +0.1 %, 2048 +1.3 %)
 static inline int plane_blocks(int HW) { int b = cdiv(HW, 512); return b < 1 ? 1 : (b > MAX_PB ? MAX_PB : b); }
 int bn_part_floats(int N, int C) { return N * C * MAX_PB * 2; }
+// (chained or not, the skip branch's BatchNorm yields the same bits -- shared arithmetic helpers with pinned roundings,
+// tests/test_generator_gpu.py::test_launch_count_forms_are_bit_neutral -- so this is a pure launch-count choice.  With the chained
+// skip convolution's split-K slabs summed inside the concat kernel it wins at every batch size: -1.3 % step time at one pair per
+// GPU, -1.0 % at four, -0.6 % at eight; profiles/r04_gen_ab.txt.  SPLICE_BN_CHAIN_MAXN limits it to fewer images per launch.)
+bool bn_pre_supported(int HW, int N, size_t p_nstride, int batch);
+static inline bool bn_mid_ok(int HW, int N, size_t p_nstride, int batch) {
+    static const int on = getenv("SPLICE_BN_MID") ? atoi(getenv("SPLICE_BN_MID")) : 1;
+    return on && HW > BN_SMALL_HW && HW <= BN_MID_HW && !batch && (N == 1 || p_nstride);
+}
+
+// the instantiation whose register tile just covers the plane (same arithmetic in the same order: the surplus elements of a
+// bigger tile only ever added zeros)
+#define BN_SMALL_DISPATCH(HW_, KERNEL, GRID, STREAM, ...)                                                         \
+    do {                                                                                                          \
+        if ((HW_) <= 256) SPLICE_LAUNCH(KERNEL<1>, GRID, dim3(256), 0, STREAM, __VA_ARGS__);                  \
+        else if ((HW_) <= 1024) SPLICE_LAUNCH(KERNEL<4>, GRID, dim3(256), 0, STREAM, __VA_ARGS__);            \
+        else SPLICE_LAUNCH(KERNEL<16>, GRID, dim3(256), 0, STREAM, __VA_ARGS__);                              \
+    } while (0)
+// 512-pixel segments (tuned in-step with alternating runs: 1024 +0.45 %, 256 / 384 +0.1 %, 2048 +1.3 %)
+static inline int plane_blocks(int HW) { int b = cdiv(HW, 512); return b < 1 ? 1 : (b > MAX_PB ? MAX_PB : b); }
+int bn_part_floats(int N, int C) { return N * C * MAX_PB * 2; }
 // (chained or not, the skip branch's BatchNorm yields the same bits, so this is a pure launch-count choice: measured neutral at one
 // pair per GPU with 16 launches fewer per step, +0.3 % step time at eight pairs -- the concat kernel waits for its skip-channel
 // workgroups, which now make five block-wide reductions instead of two; hence below SPLICE_BN_CHAIN_MAXN images only)
 bool bn_pre_supported(int HW, int N, size_t p_nstride, int batch) {
     static const int on = getenv("SPLICE_BN_CHAIN") ? atoi(getenv("SPLICE_BN_CHAIN")) : 1;
-    static const int maxn = getenv("SPLICE_BN_CHAIN_MAXN") ? atoi(getenv("SPLICE_BN_CHAIN_MAXN")) : 4;
+    static const int maxn = getenv("SPLICE_BN_CHAIN_MAXN") ? atoi(getenv("SPLICE_BN_CHAIN_MAXN")) : 1 << 30;
     return on && N < maxn && !batch && (N == 1 || p_nstride) && (HW <= BN_SMALL_HW || bn_mid_ok(HW, N, p_nstride, batch));
+}
+// the BatchNorm backward of a plane of this size can sum the split-K slabs of the data-gradient convolution that feeds it while it
+// loads the plane (one-launch small-plane kernel, every image's workgroup reads only its own plane)
+bool bn_bwd_takes_slabs(int HW, int N, size_t p_nstride, int batch) {
+    static const int on = getenv("SPLICE_BN_BWD_SLABS") ? atoi(getenv("SPLICE_BN_BWD_SLABS")) : 1;
+    return on && HW <= BN_SMALL_HW && !batch && (N == 1 || p_nstride);
 }
 int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstride, int N, int C, int HW, const float* gamma,
                   const float* beta, float eps, float* part, float* mean, float* rstd, float slope, hipStream_t s, const BnUpsample* up, size_t p_nstride,
@@ -1665,15 +1748,18 @@ int bn_fwd_slabs_launch(const float* slabs, int ksplit, const float* bias, float
 }
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
-                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up, size_t p_nstride, int batch, const BnPre* pre) {
+                  float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up, size_t p_nstride, int batch, const BnPre* pre,
+                  const BnSlabs* slabs) {
     if (batch && (N > BN_MAX_BATCH || p_nstride)) return SPLICE_ERR_ARG;
     if (pre && !bn_pre_supported(HW, N, p_nstride, batch)) return SPLICE_ERR_ARG;
+    if (slabs && slabs->slabs && !bn_bwd_takes_slabs(HW, N, p_nstride, batch)) return SPLICE_ERR_ARG;
     const BnPre pr = pre ? *pre : BnPre{};
     if (HW <= BN_SMALL_HW) {
         BnUpsample u = up ? *up : BnUpsample{};
         if (!bn_bwd_fuses_upsample(HW, u.h, u.w)) u.d_src = nullptr;
+        const BnSlabs sl = slabs ? *slabs : BnSlabs{};
         BN_SMALL_DISPATCH(HW, bn_small_bwd_kernel, dim3(C, N), s, da, da_nstride, aout, a_nstride, y, y_nstride, dy, dy_nstride, C, HW, N,
-                          gamma, mean, rstd, slope, dgamma, dbeta, accumulate, u, p_nstride, batch, pr);
+                          gamma, mean, rstd, slope, dgamma, dbeta, accumulate, u, p_nstride, batch, pr, sl);
         return SPLICE_OK;
     }
     if (bn_mid_ok(HW, N, p_nstride, batch)) {

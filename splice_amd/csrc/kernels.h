@@ -131,8 +131,8 @@ struct SelfSimBatch {
 };
 size_t selfsim_batch_ws_bytes(int T, int D, int pairs);
 void selfsim_batch_carve(void* base, int T, int D, int pairs, SelfSimBatch* b);   // fills T, Tp, D, pairs and the workspace pointers
-int selfsim_target_launch(const SelfSimBatch& b, hipStream_t s);   // norms of k_tgt + S* (2 launches)
-int selfsim_loss_launch(const SelfSimBatch& b, hipStream_t s);     // norms of k_x + fused S / loss / W + dK (3 launches)
+int selfsim_target_launch(const SelfSimBatch& b, hipStream_t s);   // S* with the row norms taken inside the Gram kernel (1 launch; 2 on the fp8 path)
+int selfsim_loss_launch(const SelfSimBatch& b, hipStream_t s);     // fused S / loss / W (norms in-kernel) + dK (2 launches; 3 on the fp8 path)
 int mse_batched_launch(const float* a, int lda, size_t a_ps, const float* b, int ldb, size_t b_ps, int rows, int cols, float loss_weight,
                        float grad_weight, float* part, size_t part_ps, float* grad, int ldg, size_t g_ps, int pairs, hipStream_t s);
 // 2-D strided MSE: loss_accum[0] += weight * mean((a-b)^2); grad (optional) = weight * 2 (a-b) / (rows*cols)

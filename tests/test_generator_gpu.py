@@ -194,3 +194,25 @@ def test_fresh_inversion_net_is_initialised_and_trainable():
     (y - torch.rand_like(y)).pow(2).mean().backward()
     live = [n for n, p in net.named_parameters() if kinds[n] == "conv_w" and p.grad.abs().sum().item() > 0]
     assert len(live) == sum(1 for k in kinds.values() if k == "conv_w"), "every conv weight must receive gradient"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(1, 224, 224), (2, 150, 200)])
+def test_launch_count_forms_are_bit_neutral(size):
+    """Round 4: paired convolutions, the skip BatchNorm chained into the concat BatchNorm's kernels and split-K slabs summed by the
+    consuming BatchNorm (both directions) only change HOW MANY launches a pass takes -- policies that may depend on the number of
+    images per launch, so they must not change a bit (the switches are read once per process: one child interpreter per setting).
+    The chained kernels share their per-element arithmetic with the stand-alone ones through helpers with pinned roundings: left to
+    the compiler, `-ffp-contract=fast` fused differently in the two code shapes (found with this test's tool)."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(__file__), "..", "tools", "gen_bits.py")
+    outs = {}
+    for tag, env in (("default", {}), ("no chain", {"SPLICE_BN_CHAIN": "0"}), ("no deferred slabs", {"SPLICE_BN_BWD_SLABS": "0"}),
+                     ("no pairs, no chain", {"SPLICE_CONV_PAIR": "0", "SPLICE_BN_CHAIN": "0"})):
+        r = subprocess.run([sys.executable, tool] + [str(v) for v in size], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = [l for l in r.stdout.splitlines() if l and not l.startswith("/")]
+        assert len(outs[tag]) > 100
+    for tag, lines in outs.items():
+        assert lines == outs["default"], (tag, [(a, b) for a, b in zip(lines, outs["default"]) if a != b][:5])
