@@ -1680,26 +1680,6 @@ int bn_part_floats(int N, int C) { return N * C * MAX_PB * 2; }
 // tests/test_generator_gpu.py::test_launch_count_forms_are_bit_neutral -- so this is a pure launch-count choice.  With the chained
 // skip convolution's split-K slabs summed inside the concat kernel it wins at every batch size: -1.3 % step time at one pair per
 // GPU, -1.0 % at four, -0.6 % at eight; profiles/r04_gen_ab.txt.  SPLICE_BN_CHAIN_MAXN limits it to fewer images per launch.)
-bool bn_pre_supported(int HW, int N, size_t p_nstride, int batch);
-static inline bool bn_mid_ok(int HW, int N, size_t p_nstride, int batch) {
-    static const int on = getenv("SPLICE_BN_MID") ? atoi(getenv("SPLICE_BN_MID")) : 1;
-    return on && HW > BN_SMALL_HW && HW <= BN_MID_HW && !batch && (N == 1 || p_nstride);
-}
-
-// the instantiation whose register tile just covers the plane (same arithmetic in the same order: the surplus elements of a
-// bigger tile only ever added zeros)
-#define BN_SMALL_DISPATCH(HW_, KERNEL, GRID, STREAM, ...)                                                         \
-    do {                                                                                                          \
-        if ((HW_) <= 256) SPLICE_LAUNCH(KERNEL<1>, GRID, dim3(256), 0, STREAM, __VA_ARGS__);                  \
-        else if ((HW_) <= 1024) SPLICE_LAUNCH(KERNEL<4>, GRID, dim3(256), 0, STREAM, __VA_ARGS__);            \
-        else SPLICE_LAUNCH(KERNEL<16>, GRID, dim3(256), 0, STREAM, __VA_ARGS__);                              \
-    } while (0)
-// 512-pixel segments (tuned in-step with alternating runs: 1024 +0.45 %, 256 / 384 +0.1 %, 2048 +1.3 %)
-static inline int plane_blocks(int HW) { int b = cdiv(HW, 512); return b < 1 ? 1 : (b > MAX_PB ? MAX_PB : b); }
-int bn_part_floats(int N, int C) { return N * C * MAX_PB * 2; }
-// (chained or not, the skip branch's BatchNorm yields the same bits, so this is a pure launch-count choice: measured neutral at one
-// pair per GPU with 16 launches fewer per step, +0.3 % step time at eight pairs -- the concat kernel waits for its skip-channel
-// workgroups, which now make five block-wide reductions instead of two; hence below SPLICE_BN_CHAIN_MAXN images only)
 bool bn_pre_supported(int HW, int N, size_t p_nstride, int batch) {
     static const int on = getenv("SPLICE_BN_CHAIN") ? atoi(getenv("SPLICE_BN_CHAIN")) : 1;
     static const int maxn = getenv("SPLICE_BN_CHAIN_MAXN") ? atoi(getenv("SPLICE_BN_CHAIN_MAXN")) : 1 << 30;
