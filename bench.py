@@ -459,9 +459,9 @@ def main():
     roofs = []
     traffic_file = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     static_traffic = {}
-    if os.path.exists(traffic_file) and args.size == 224 and args.model == "dino_vitb8" and not scales and not args.fp8:
-        try:
-            static_traffic = json.load(open(traffic_file)).get(f"P{P}", {})
+    if os.path.exists(traffic_file) and args.model == "dino_vitb8" and not scales and not args.fp8:
+        try:   # keys: "P<pairs>" at 224 x 224, "S<size>P<pairs>" otherwise; values: family id -> bytes per call
+            static_traffic = json.load(open(traffic_file)).get(f"P{P}" if args.size == 224 else f"S{args.size}P{P}", {})
         except Exception:
             static_traffic = {}
     for fam, (tot_ms, calls, kernels, steps, n_ent) in prof.items():
@@ -472,7 +472,7 @@ def main():
         traffic = static_traffic.get(str(fam))
         r = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
              "frac": round(ach / peak, 4), "traffic": traffic,
-             "traffic_source": None if traffic is None else "static: profiles/roofline_traffic.json (FETCH_SIZE x2 + WRITE_SIZE from separate --pmc passes of tools/pmc_traffic.sh on this workload, re-measured in round 3; not re-measured by this command)",
+             "traffic_source": None if traffic is None else "static: profiles/roofline_traffic.json, bytes per call of this family (FETCH_SIZE x2 + WRITE_SIZE from separate --pmc passes of tools/pmc_families.sh on this workload and build; not re-measured by this command)",
              "avg_launch_us": round(avg_ms * 1e3, 2), "calls_per_step": round(calls / steps, 1), "kernels_per_step": round(kernels / steps, 1),
              "share_of_step_ms": round(tot_ms / steps, 4)}
         if n_ent:

@@ -505,7 +505,7 @@ def test_full_length_run_configs1_2000_steps():
     """BASELINE configs[1] at its own length: ONE 224x224 pair, ViT-B/8 (T = 785), 2000 optimisation steps (`train.py:51-80` x 2000;
     the paper's length, SURVEY 8d cfg 2) on the fused engine -- graph replay on ordinary steps, the entire-image branch every 75th.
     Checks what a long run can break and a 78-step fixture cannot: every sampled loss finite, the optimisation keeps descending
-    (window means of the ordinary-step loss non-increasing within 5 %), the generated image stays inside [0, 1], device memory
+    (window means of the ordinary-step loss non-increasing within 5 % down to the plateau, within 2 x its floor there), the generated image stays inside [0, 1], device memory
     is flat after the first 200 steps, and the step counter / Adam count agree with the number of calls."""
     from splice_amd.engine import synthetic_engine
     A, B = synth.smooth_image_pair(1234, 0, 224, 224)
@@ -524,9 +524,13 @@ def test_full_length_run_configs1_2000_steps():
     assert np.isfinite(vals).all() and len(vals) >= 50
     wins = [vals[i:i + 10].mean() for i in range(0, len(vals) - 9, 10)]
     print("    2000 steps at 224^2 / ViT-B/8: window means of the ordinary-step loss: " + ", ".join(f"{w:.2f}" for w in wins))
+    # descending: every window below 1.05 x the previous one until the run has reached its plateau (<= 10 % of the first window:
+    # ~0.1 after 600 steps, where the loss of this chaotic optimisation fluctuates by tens of per cent between windows -- seen:
+    # 0.09, 0.09, 0.07, 0.10 with one build, 0.08, 0.07, 0.07, 0.06 with another); on the plateau it must stay within 2 x its floor
     for a, b in zip(wins, wins[1:]):
-        assert b < 1.05 * a, wins
-    assert wins[-1] < 0.8 * wins[0], wins                         # and it actually went somewhere
+        assert b < 1.05 * a or b <= 0.1 * wins[0], wins
+    assert all(w <= 2.0 * min(wins[:i + 1]) for i, w in enumerate(wins) if w <= 0.1 * wins[0]), wins
+    assert wins[-1] < 0.2 * wins[0], wins                         # and it actually went somewhere
     out = eng.generate(Ad[None])
     assert out.shape == (1, 3, 224, 224) and torch.isfinite(out).all() and 0.0 <= out.min().item() and out.max().item() <= 1.0
     assert out.std().item() > 1e-3                                # not a constant image
