@@ -192,10 +192,10 @@ def kernel_families(T, D, heads, P, size, depth=12, fp8=False):
     return {
         # (tile / pipeline template arguments depend on the rows of a launch: <64,64,..,4> at one pair, <128,64,..,2> from 4 pairs on)
         # (--fp8: these three run on the block-scaled K = 128 e4m3 MFMA -- priced against ITS dense peak, 5 PFLOP/s)
-        4: ("gemm_nt_kernel<BIAS|RESID|OUT_F32> fc2 forward" + (" [e4m3, scaled K=128 MFMA]" if fp8 else ""), "fp8mx" if fp8 else "bf16", 2 * P * 2.0 * T * hidden * D),
-        1: ("gemm_nt_kernel<BIAS|GELU|OUT_BF> fc1 forward" + (" [e4m3, scaled K=128 MFMA]" if fp8 else ""), "fp8mx" if fp8 else "bf16", 2 * P * 2.0 * T * hidden * D),
-        2: ("gemm_nt_kernel<BIAS|OUT_BF> qkv forward" + (" [e4m3, scaled K=128 MFMA]" if fp8 else ""), "fp8mx" if fp8 else "bf16", 2 * P * 2.0 * T * 3 * D * D),
-        9: ("gemm_nt_kernel<BIAS|RESID|OUT_F32> proj forward", "bf16", 2 * P * 2.0 * T * D * D),
+        4: ("fc2 forward GEMM, BIAS|RESID|OUT_F32 epilogue (gemm_nt_kernel; gemm8p_kernel from ~150 row tiles of 256 on)" + (" [e4m3, scaled K=128 MFMA]" if fp8 else ""), "fp8mx" if fp8 else "bf16", 2 * P * 2.0 * T * hidden * D),
+        1: ("fc1 forward GEMM, BIAS|GELU|OUT_BF epilogue (gemm_nt_kernel; gemm8p_kernel from 200 tiles of 256 x 256 on)" + (" [e4m3, scaled K=128 MFMA]" if fp8 else ""), "fp8mx" if fp8 else "bf16", 2 * P * 2.0 * T * hidden * D),
+        2: ("qkv forward GEMM, BIAS|OUT_BF epilogue (gemm_nt_kernel; gemm8p_kernel from 200 tiles of 256 x 256 on)" + (" [e4m3, scaled K=128 MFMA]" if fp8 else ""), "fp8mx" if fp8 else "bf16", 2 * P * 2.0 * T * 3 * D * D),
+        9: ("proj forward GEMM, BIAS|RESID|OUT_F32 epilogue (gemm_nt_kernel; gemm8p_kernel from ~150 row tiles of 256 on)", "bf16", 2 * P * 2.0 * T * D * D),
         3: ("attn_fwd8_kernel [e4m3 operands, k = 32 fp8 MFMA: bf16 rate]" if fp8 == "attention" else "attn_fwd_kernel", "bf16", 2 * P * 4.0 * T * T * D),
         5: ("gemm_nt_kernel<OUT_F32> split-K dgrads (fc1^T and qkv^T, mean of both)", "bf16", P * 2.0 * T * D * (hidden + 3 * D) / 2),
         6: ("attn_bwd_kernel (merged, or dQ + dK/dV launches)", "bf16", P * 10.0 * T * T * D),

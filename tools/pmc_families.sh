@@ -9,7 +9,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcf_${TAG}_$c
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcf_${TAG}_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 4 --no-cpu-baseline --prof-kernels "" --pairs-sweep "" --no-train-regime "$@" > /dev/null 2>&1
 done
-python - "$TAG" <<'PY' | tee $GRAFT_REPO_ROOT/gpurun_out/traffic_families_$1.json
+python - "$TAG" <<'PY' | tee $GRAFT_REPO_ROOT/gpurun_out/traffic_families_$TAG.json
 import csv, glob, json, sys
 tag = sys.argv[1]
 per = {}          # kernel name -> {counter: [values in dispatch order]}
