@@ -135,9 +135,7 @@ class _VitProbs(torch.autograd.Function):
             _lib.check(L.splice_attention_probs(_lib.ptr(qkv), 1, T, vctx.Tld, eng.dim, eng.heads, 0.125, _lib.ptr(lse),
                                                 _lib.ptr(probs[l]), _lib.current_stream()), "attention_probs")
         ctx.vctx, ctx.extractor, ctx.need_grad, ctx.generation = vctx, extractor, need_grad, vctx.generation
-        if need_grad:
-            ctx.save_for_backward(probs)
-        else:
+        if not need_grad:   # (with grad: nothing is saved -- the backward re-forms the matrices it needs from the resident q, k, lse)
             extractor._release(vctx)
         return probs
 
@@ -147,16 +145,19 @@ class _VitProbs(torch.autograd.Function):
             return None, None, None
         vctx, ext = ctx.vctx, ctx.extractor
         _check_resident(ctx)
-        (probs,) = ctx.saved_tensors
         eng = ext.engine
         T, Tld, D, H = vctx.T, vctx.Tld, eng.dim, eng.heads
         d = D // H
         dq_all = {}
+        L = _lib.lib()
+        live = d_probs.reshape(eng.depth, -1).any(dim=1).tolist()               # ONE host sync: which layers' probabilities were consumed
         for l in range(eng.depth):
-            dP = d_probs[l]
-            if not bool(dP.any()):
+            if not live[l]:
                 continue
-            P = probs[l]
+            dP = d_probs[l]
+            P = torch.empty(H, T, T, device=dP.device)                           # re-formed, not saved by the forward ([L, heads, T, T] is 355 MB at T = 785)
+            _lib.check(L.splice_attention_probs(_lib.ptr(vctx.read(KIND_QKV, l)), 1, T, Tld, D, H, 0.125, _lib.ptr(vctx.read(KIND_LSE, l)),
+                                                _lib.ptr(P), _lib.current_stream()), "attention_probs")
             dS = P * (dP - (dP * P).sum(-1, keepdim=True))                       # [H, T, T]
             qkv = vctx.read(KIND_QKV, l)[0, :T].float().reshape(T, 3, H, d)
             q, k = qkv[:, 0].transpose(0, 1), qkv[:, 1].transpose(0, 1)          # [H, T, d]
