@@ -61,6 +61,7 @@ struct WgradReduceAll {      // by-value kernel argument: one entry per conv lay
     int n[WGRAD_MAX_LAYERS], chunks[WGRAD_MAX_LAYERS];
     long long total;
     int count;
+    unsigned char vec[WGRAD_MAX_LAYERS];      // set by wgrad_reduce_all_launch: the layer is reduced four elements per thread (16-byte accesses); prefix then counts work items
 };
 // p_nstride > 0: independent images -- image n's chunks are summed into grads + n * p_nstride
 int wgrad_reduce_all_launch(const WgradReduceAll& d, const float* ws, float* grads, int accumulate, hipStream_t s, int n_img = 1, size_t p_nstride = 0);

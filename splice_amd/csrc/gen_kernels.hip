@@ -582,6 +582,27 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, int chunk, i
 // dw[layer][i] (+)= sum_chunk ws[layer][chunk][i] for every conv layer of a backward in one launch
 // n_img > 1 with p_nstride > 0: independent images -- blockIdx.y = image, which sums only ITS chunks (chunk index = image *
 // chunks_per_image + k) into its own gradient arena
+// one chain of a layer's chunk sum: 4 independent partial sums in a FIXED association order, 16 loads in flight
+template <class Load>
+__device__ __forceinline__ float wgrad_chunk_sum(int chunks, Load&& ld) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 15 < chunks; c += 16) {   // 16 loads in flight, added in the order of the 4-wide loop below (same bits)
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = ld(c + u);
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+    }
+    for (; c + 3 < chunks; c += 4) {
+        s0 += ld(c);
+        s1 += ld(c + 1);
+        s2 += ld(c + 2);
+        s3 += ld(c + 3);
+    }
+    for (; c < chunks; ++c) s0 += ld(c);
+    return (s0 + s1) + (s2 + s3);   // chunks == 0: an exact-zero gradient range (BN-fed conv bias)
+}
 __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(WgradReduceAll d, const float* __restrict__ ws, float* __restrict__ grads,
                                                                int accumulate, int n_img, size_t p_nstride) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -589,7 +610,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(WgradReduceAll d,
     int l = 0;
 #pragma unroll 1
     while (l + 1 < d.count && gid >= d.prefix[l + 1]) ++l;
-    const int i = (int)(gid - d.prefix[l]);
+    const bool vec = d.vec[l] != 0;
+    const int i = (int)(gid - d.prefix[l]) * (vec ? 4 : 1);
     const int n = d.n[l];
     int chunks = d.chunks[l];
     const float* p = ws + d.ws_off[l] + i;
@@ -598,24 +620,45 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all_kernel(WgradReduceAll d,
         p += (size_t)blockIdx.y * chunks * n;
         grads += (size_t)blockIdx.y * p_nstride;
     }
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // 4 independent chains in a FIXED association order
-    int c = 0;
-    for (; c + 15 < chunks; c += 16) {   // 16 loads in flight, added in the order of the 4-wide loop below (same bits)
-        float v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = p[(size_t)(c + u) * n];
-#pragma unroll
-        for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
-    }
-    for (; c + 3 < chunks; c += 4) {
-        s0 += p[(size_t)c * n];
-        s1 += p[(size_t)(c + 1) * n];
-        s2 += p[(size_t)(c + 2) * n];
-        s3 += p[(size_t)(c + 3) * n];
-    }
-    for (; c < chunks; ++c) s0 += p[(size_t)c * n];
-    const float s = (s0 + s1) + (s2 + s3);   // chunks == 0: an exact-zero gradient range (BN-fed conv bias)
     float* q = grads + d.dw_off[l] + i;
+    if (vec) {
+        // four neighbouring elements per thread through 16-byte loads (round 4: the reduction streams 15 MB of partials per image and
+        // was latency-bound on 4-byte accesses); every element still sums its chunks in the order of the scalar path: same bits
+        float4 s = {0.f, 0.f, 0.f, 0.f};
+        float4 a0 = s, a1 = s, a2 = s, a3 = s;
+        int c = 0;
+        for (; c + 7 < chunks; c += 8) {   // (8 x 16 B in flight; chains by c mod 4 as in wgrad_chunk_sum)
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(c + u) * n);
+#pragma unroll
+            for (int u = 0; u < 8; u += 4) {
+                a0.x += v[u].x; a0.y += v[u].y; a0.z += v[u].z; a0.w += v[u].w;
+                a1.x += v[u + 1].x; a1.y += v[u + 1].y; a1.z += v[u + 1].z; a1.w += v[u + 1].w;
+                a2.x += v[u + 2].x; a2.y += v[u + 2].y; a2.z += v[u + 2].z; a2.w += v[u + 2].w;
+                a3.x += v[u + 3].x; a3.y += v[u + 3].y; a3.z += v[u + 3].z; a3.w += v[u + 3].w;
+            }
+        }
+        for (; c + 3 < chunks; c += 4) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)c * n), v1 = *reinterpret_cast<const float4*>(p + (size_t)(c + 1) * n),
+                         v2 = *reinterpret_cast<const float4*>(p + (size_t)(c + 2) * n), v3 = *reinterpret_cast<const float4*>(p + (size_t)(c + 3) * n);
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+            a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+            a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        }
+        for (; c < chunks; ++c) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)c * n);
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        }
+        s.x = (a0.x + a1.x) + (a2.x + a3.x); s.y = (a0.y + a1.y) + (a2.y + a3.y);
+        s.z = (a0.z + a1.z) + (a2.z + a3.z); s.w = (a0.w + a1.w) + (a2.w + a3.w);
+        float4* q4 = reinterpret_cast<float4*>(q);
+        if (accumulate) { const float4 o = *q4; s.x = o.x + s.x; s.y = o.y + s.y; s.z = o.z + s.z; s.w = o.w + s.w; }
+        *q4 = s;
+        return;
+    }
+    const float s = wgrad_chunk_sum(chunks, [&](int c) { return p[(size_t)c * n]; });
     *q = accumulate ? *q + s : s;
 }
 
@@ -708,8 +751,19 @@ int conv_wgrad_batched_launch(const WgradBatchPair& p, hipStream_t s) {
     return SPLICE_OK;
 }
 
-int wgrad_reduce_all_launch(const WgradReduceAll& d, const float* ws, float* grads, int accumulate, hipStream_t s, int n_img, size_t p_nstride) {
-    if (d.count < 1 || d.count > WGRAD_MAX_LAYERS) return SPLICE_ERR_ARG;
+int wgrad_reduce_all_launch(const WgradReduceAll& d0, const float* ws, float* grads, int accumulate, hipStream_t s, int n_img, size_t p_nstride) {
+    if (d0.count < 1 || d0.count > WGRAD_MAX_LAYERS) return SPLICE_ERR_ARG;
+    // work items: four elements per thread wherever a layer's ranges are 16-byte aligned (every layer but the 3-channel head's bias)
+    WgradReduceAll d = d0;
+    static const int vec_on = getenv("SPLICE_WGRAD_REDUCE_VEC") ? atoi(getenv("SPLICE_WGRAD_REDUCE_VEC")) : 1;
+    const bool base_ok = vec_on && !((reinterpret_cast<size_t>(ws) | reinterpret_cast<size_t>(grads)) & 15) && p_nstride % 4 == 0;
+    d.prefix[0] = 0;
+    for (int i = 0; i < d.count; ++i) {
+        const bool v = base_ok && d.n[i] % 4 == 0 && d.ws_off[i] % 4 == 0 && d.dw_off[i] % 4 == 0;
+        d.vec[i] = v ? 1 : 0;
+        d.prefix[i + 1] = d.prefix[i] + (v ? d.n[i] / 4 : d.n[i]);
+    }
+    d.total = d.prefix[d.count];
     SPLICE_LAUNCH(wgrad_reduce_all_kernel, dim3((unsigned)((d.total + 255) / 256), p_nstride ? n_img : 1), dim3(256), 0, s, d, ws, grads, accumulate,
                        n_img, p_nstride);
     return SPLICE_OK;

@@ -209,7 +209,8 @@ def test_launch_count_forms_are_bit_neutral(size):
     tool = os.path.join(os.path.dirname(__file__), "..", "tools", "gen_bits.py")
     outs = {}
     for tag, env in (("default", {}), ("no chain", {"SPLICE_BN_CHAIN": "0"}), ("no deferred slabs", {"SPLICE_BN_BWD_SLABS": "0"}),
-                     ("no pairs, no chain", {"SPLICE_CONV_PAIR": "0", "SPLICE_BN_CHAIN": "0"})):
+                     ("no pairs, no chain", {"SPLICE_CONV_PAIR": "0", "SPLICE_BN_CHAIN": "0"}),
+                     ("scalar weight-gradient reduce", {"SPLICE_WGRAD_REDUCE_VEC": "0"})):
         r = subprocess.run([sys.executable, tool] + [str(v) for v in size], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[tag] = [l for l in r.stdout.splitlines() if l and not l.startswith("/")]
