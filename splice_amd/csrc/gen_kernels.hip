@@ -847,14 +847,40 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* y, s
     const int seg = seg_len(HW, PB), lo = pb * seg, hi = min(lo + seg, HW);
     const float* p = y + (size_t)img * nstride + (size_t)c * HW;
     float s = 0.f, dummy = 0.f;
-    if (up.src && c >= up.c0) {   // upsampled channel: the values are produced here (and stored: the second pass, the apply kernel and the backward read them)
+    // segments of up to 1024 elements (every plane up to 256 x 256) stay in registers between the two passes: the second pass
+    // used to re-read them (a dependent L2 round trip per workgroup); same values, same order of additions, same bits
+    const bool in_regs = seg <= 1024;
+    float keep[4] = {0.f, 0.f, 0.f, 0.f};
+    if (up.src && c >= up.c0) {   // upsampled channel: the values are produced here (and stored: the apply kernel and the backward read them)
         const float* sp = up.src + (size_t)img * up.src_ns + (size_t)(c - up.c0) * up.h * up.w;
         float* yo = const_cast<float*>(p);
-        for (int i = lo + threadIdx.x; i < hi; i += 256) {
-            const float v = up_value(sp, up.h, up.w, i / up.Wo, i % up.Wo);
-            yo[i] = v;
-            s += v;
+        if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = lo + threadIdx.x + k * 256;
+                if (i < hi) {
+                    const float v = up_value(sp, up.h, up.w, i / up.Wo, i % up.Wo);
+                    yo[i] = v;
+                    keep[k] = v;
+                    s += v;
+                }
+            }
+        } else {
+            for (int i = lo + threadIdx.x; i < hi; i += 256) {
+                const float v = up_value(sp, up.h, up.w, i / up.Wo, i % up.Wo);
+                yo[i] = v;
+                s += v;
+            }
         }
+    } else if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = lo + threadIdx.x + k * 256;
+            keep[k] = i < hi ? p[i] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (lo + threadIdx.x + k * 256 < hi) s += keep[k];
     } else {
         for (int i = lo + threadIdx.x; i < hi; i += 256) s += p[i];
     }
@@ -863,7 +889,13 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* y, s
     const float m = cnt > 0 ? s / (float)cnt : 0.f;
     float sq = 0.f;
     dummy = 0.f;
-    for (int i = lo + threadIdx.x; i < hi; i += 256) { const float d = p[i] - m; sq += d * d; }
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (lo + threadIdx.x + k * 256 < hi) { const float d = keep[k] - m; sq = __builtin_fmaf(d, d, sq); }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) { const float d = p[i] - m; sq = __builtin_fmaf(d, d, sq); }
+    }
     block_sum2(sq, dummy, red);
     if (threadIdx.x == 0) {
         float* o = part + (((size_t)img * C + c) * PB + pb) * 2;
