@@ -731,6 +731,7 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
     const int OC = p->gen->arch.out_channels, U0 = p->gen->arch.up[0];
     const size_t npix = (size_t)p->N * OC * p->H * p->W;
     p->red.count = 0;
+    p->pend.target = nullptr;   // (a backward that failed half-way must not leave slabs pending for this one)
     p->wg.small.count = p->wg.small.total_wgs = 0;
     p->wg.big.count = p->wg.big.total_wgs = 0;
     const Unit& u = p->u_up1[0];
@@ -764,6 +765,7 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
         RC(conv_launch(a, s));
     }
     RC(scale_backward(p, 0, params, grads, accumulate, s));
+    if (p->pend.target) { splice_set_error("splice_gen_backward: split-K slabs left without a consumer"); return SPLICE_ERR_STATE; }
     RC(conv_wgrad_batched_launch(p->wg, s));   // all layers' partials, one launch
     {   // one deterministic reduction of every layer's per-chunk weight-gradient partials
         WgradReduceAll& r = p->red;
