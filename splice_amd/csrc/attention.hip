@@ -66,18 +66,19 @@ __device__ __forceinline__ float group4_sum(float v) {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_void;
 
-struct TileDma {
+template <int NW>   // waves that move one tile set: 4 (pieces w and w + 4 each) or 8 (one piece each)
+struct TileDmaT {
     int wave;                 // scalar
     int lrow, tchunk;
-    // w4 = index of the wave inside its group of 4 (a group moves one tile set; 8-wave workgroups hold two groups)
-    __device__ __forceinline__ TileDma() {
+    // wave = index of the wave inside its group of NW (a group moves one tile set; two-group workgroups hold two groups of 4)
+    __device__ __forceinline__ TileDmaT() {
         const int lane = threadIdx.x & 63;
-        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3;
+        wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & (NW - 1);
         lrow = lane >> 3;
         tchunk = (lane & 7) ^ ((((lrow >> 1) & 1) << 1) | ((wave & 1) << 2));   // token tile: row = piece*8 + lrow, piece & 1 == wave & 1
     }
     __device__ __forceinline__ void piece(const bf16_t* src, bf16_t* lds, int i) const {
-        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(lds + (wave + 4 * i) * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(lds + (wave + NW * i) * 512), 16, 0, 0);
     }
     // Interior tiles: a uniform (scalar) tile base + per-lane byte offsets that are fixed for the whole kernel -- one
     // VALU op per DMA instead of the clamp / multiply / 64-bit add chain.
@@ -85,6 +86,11 @@ struct TileDma {
     // tile = first element of the tile (base + tok0*ld); stride = ld
     __device__ __forceinline__ void fast_tile(const bf16_t* tile, uint32_t off, int stride, bf16_t* lds) const {
         const char* b0 = reinterpret_cast<const char*>(tile);
+        if (NW == 8) {
+            asm volatile("" : "+s"(b0));   // keep the base scalar
+            piece(reinterpret_cast<const bf16_t*>(b0 + off), lds, 0);
+            return;
+        }
         const char* b1 = reinterpret_cast<const char*>(tile + (size_t)32 * stride);
         asm volatile("" : "+s"(b0), "+s"(b1));   // keep the bases scalar
         piece(reinterpret_cast<const bf16_t*>(b0 + off), lds, 0);
@@ -93,13 +99,14 @@ struct TileDma {
     // Edge tiles: token-major source, rows = tokens tok0.. (clamped to tok_max), 64 contiguous d at base + tok*ld
     __device__ __forceinline__ void token_tile(const bf16_t* base, int ld, int tok0, int tok_max, bf16_t* lds) const {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int t = tok0 + (wave + 4 * i) * 8 + lrow;
+        for (int i = 0; i < 8 / NW; ++i) {
+            int t = tok0 + (wave + NW * i) * 8 + lrow;
             t = t < tok_max ? t : tok_max;
             piece(base + (size_t)t * ld + tchunk * 8, lds, i);
         }
     }
 };
+typedef TileDmaT<4> TileDma;
 
 struct FragAddr {   // per-lane LDS element offsets of the fragment reads (everything else is an immediate)
     int tok[2];     // token tile: block nb of sub-tile sub, d-half hf   -> tok[hf] + sub*2048 + nb*256
@@ -255,18 +262,21 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
 // latencies (profiles/r02_pmc_attn_selfsim_p1.txt: 47 % of the wave cycles parked).  Two groups give every SIMD a second
 // wave and halve the serial walk.  Every launch uses the same split (it does not depend on the batch), so a pass's output
 // bits do not depend on how many passes share the launch.
-template <int QB, int KS>
-__global__ __launch_bounds__(256 * KS) void attn_fwd_kernel(AttnArgs a, int nx) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[KS * 2 * 2 * 4096 + (KS == 1 ? 4 * QB * 18 * 64 * 2 : 0)];   // [group][stage][K | V^T] tiles (+ one group: the parked first state)
+// NW = 8 (one wave group only): EIGHT waves = 128 * QB queries share one K / V ring -- half the L2 -> LDS traffic and DMA issue work per
+// query, 16 waves per CU under the LDS limit instead of 12; per query the arithmetic is that of the 4-wave forms (same bits).
+template <int QB, int KS, int NW = 4>
+__global__ __launch_bounds__(64 * NW * KS) void attn_fwd_kernel(AttnArgs a, int nx) {
+    static_assert(KS == 1 || NW == 4, "two wave groups are groups of four waves");
+    __shared__ __attribute__((aligned(16))) bf16_t smem[KS * 2 * 2 * 4096 + (KS == 1 ? NW * QB * 18 * 64 * 2 : 0)];   // [group][stage][K | V^T] tiles (+ one group: the parked first state)
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
     const int grp = KS > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
     int xb, h, b;
     attn_block_coords(nx, a.H, a.B, xb, h, b);
     const int ld = 3 * a.D;
-    const TileDma dma;
+    const TileDmaT<NW> dma;
     const FragAddr fa(g, c);
-    const int qbase = xb * (64 * QB) + dma.wave * (16 * QB);
+    const int qbase = xb * (16 * NW * QB) + dma.wave * (16 * QB);
     const bool active = qbase < a.Tld;   // a wave without queries still moves its share of every tile
     const bf16_t* qkv_b = a.qkv + (size_t)b * a.Tld * ld;
     const bf16_t* kbase = qkv_b + a.D + h * 64;
@@ -1008,7 +1018,20 @@ int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
     // than 512 workgroups -- one wave group per workgroup wins while the key walk is short (T = 785: -0.6 % step time at 4 / 8 pairs
     // per GPU) and two groups keep winning on long walks (T = 3137: +0.5 % for one group); profiles/r03_attn_fwd_forms_in_step.txt)
     static const long ks1_from = getenv("SPLICE_ATTN_KS1_FROM") ? atol(getenv("SPLICE_ATTN_KS1_FROM")) : 512;
-    const int ks = g_attn_variant ? g_attn_variant / 10 + 1 : ((wgs > ks1_from && a->T <= 2048) ? 1 : 2);
+    const int ks = g_attn_variant ? (g_attn_variant / 10 == 1 ? 2 : 1) : ((wgs > ks1_from && a->T <= 2048) ? 1 : 2);
+    // (round 4, second session) wherever one wave group per workgroup is chosen, EIGHT waves share the K / V ring (128 queries per
+    // workgroup; variant 2x): half the L2 -> LDS traffic per query and 16 instead of 12 waves per CU under the LDS limit.  Stand-alone
+    // at 16 passes of T = 785: 57.8 us against 60.1 (two groups) / 65.6 (four waves); in the step -0.5 % at 8 pairs per GPU, -0.9 % at 4
+    // (same-box alternating runs, profiles/r04_attn_w8_ab.txt).  Same bits as every other form (tests/test_ops_gpu.py).
+    static const long w8_from = getenv("SPLICE_ATTN_W8_FROM") ? atol(getenv("SPLICE_ATTN_W8_FROM")) : 512;
+    const bool w8 = !a->qkv8 && (g_attn_variant ? g_attn_variant / 10 == 2 : (w8_from >= 0 && wgs > w8_from && ks == 1));
+    if (w8) {
+        const int nx8 = cdiv(a->Tld, 128 * qb);
+        const dim3 grid8(nx8 * a->H * a->B);
+        if (qb == 2) SPLICE_LAUNCH((attn_fwd_kernel<2, 1, 8>), grid8, dim3(512), 0, s, *a, nx8);
+        else SPLICE_LAUNCH((attn_fwd_kernel<1, 1, 8>), grid8, dim3(512), 0, s, *a, nx8);
+        return SPLICE_OK;
+    }
     const int nx = cdiv(a->Tld, 64 * qb);
     const dim3 grid(nx * a->H * a->B);
     if (a->qkv8) {   // e4m3 forward

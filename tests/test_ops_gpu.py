@@ -236,7 +236,7 @@ def test_attention_fwd_bwd(B, T, D, H, std):
     # launch forms: 16 / 32 queries per wave x one / two wave groups per workgroup (the dispatcher picks by workgroup count) must
     # agree BIT FOR BIT -- a pass's attention output may not depend on how many passes share the launch
     if T <= 1601:
-        for variant in (1, 2, 11, 12):
+        for variant in (1, 2, 11, 12, 21, 22):   # 2x: eight waves (128 * x queries) on one K / V ring
             L.splice_attention_variant(variant)
             out_v, lse_v = torch.zeros_like(out), torch.zeros_like(lse)
             _lib.check(L.splice_attention_fwd(_lib.ptr(qkv), _lib.ptr(qkvT), rows, B, T, Tld, D, H, scale, _lib.ptr(out_v), _lib.ptr(lse_v), _st()))
