@@ -8,7 +8,13 @@ attention module returning a tuple whose ``[0]`` is the token tensor, and
 ``model(img)`` running the full 12-block forward.
 
 The hub source is third-party, un-vendored and un-pinned (branch ``main``): PARITY
-UNPINNED for the inside of the ViT.  The architecture below follows the published
+UNPINNED AGAINST THE REFERENCE'S OWN SOURCE for the inside of the ViT.  What stands in for it:
+``oracle/pin_vit_hf.py`` / ``tests/test_oracle_hf_pin_cpu.py`` load one seeded DINO-keyed state dict
+into this module AND into Hugging Face ``transformers.ViTModel`` (the form the public
+``facebook/dino-vit*`` checkpoints are served in; an independent implementation) and the token
+tensor behind every block agrees to the last bit; the position-table interpolation (the DINO
+recipe's +0.1 nudge) is a different recipe in transformers and stays restated-only.
+The architecture below follows the published
 DINO ViT: patch-embed Conv2d(3, D, k=p, s=p) -> flatten -> prepend cls token -> add
 (bicubically interpolated) position embedding -> depth x [x += proj(MHSA(LN(x)));
 x += fc2(GELU_erf(fc1(LN(x))))] -> LN; LayerNorm eps 1e-6; qkv bias on; no dropout.
