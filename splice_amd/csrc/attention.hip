@@ -166,9 +166,14 @@ __device__ __forceinline__ void dma_wait_barrier() {
 // reference point by a factor 2^30.  softmax is shift-invariant, so the result is the same function; P stays
 // within bf16's fp32-sized exponent range and O, l accumulate in fp32.
 #define ATTN_RESCALE_LIMIT 1073741824.0f
+#ifdef ATTN_QFOLD
+#define ATTN_M0 0.0f
+#else
+#define ATTN_M0 NEG_BIG
+#endif
 template <int QB, int NSUB, bool MASK>
 __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs, const FragAddr& fa, const u32x4 (&qf)[QB][2],
-                                              float (&m)[QB], float (&l)[QB], f32x4 (&o)[QB][4], float c2, int kt, int T, int g) {
+                                              float (&m)[QB], float (&l)[QB], f32x4 (&o)[QB][4], float c2, int kt, int T, int g, bool first = false) {
     f32x4 s[QB][NSUB * 2];
 #pragma unroll
     for (int nb = 0; nb < NSUB * 2; ++nb) {
@@ -176,7 +181,11 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
         const u32x4 k1 = lds16(Ks + fa.tok[1] + (nb >> 1) * 2048 + (nb & 1) * 256);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
+#ifdef ATTN_QFOLD   // experiment (profiles/r04_attn_qfold_experiment.txt): q carries scale * log2(e), the accumulator starts at -m
+            s[qb][nb] = mfma16(k0, qf[qb][0], f32x4{-m[qb], -m[qb], -m[qb], -m[qb]});
+#else
             s[qb][nb] = mfma16(k0, qf[qb][0], f32x4{0.f, 0.f, 0.f, 0.f});
+#endif
             s[qb][nb] = mfma16(k1, qf[qb][1], s[qb][nb]);
         }
     }
@@ -200,11 +209,19 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
 #pragma unroll
         for (int nb = 0; nb < NSUB * 2; ++nb) {
 #pragma unroll
+#ifdef ATTN_QFOLD
+            for (int r = 0; r < 4; ++r) p[qb][nb][r] = __builtin_amdgcn_exp2f(s[qb][nb][r]);
+#else
             for (int r = 0; r < 4; ++r) p[qb][nb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][nb][r], c2, -m[qb]));
+#endif
             part[nb] = (p[qb][nb][0] + p[qb][nb][1]) + (p[qb][nb][2] + p[qb][nb][3]);
         }
         ps[qb] = NSUB == 2 ? (part[0] + part[1]) + (part[NSUB * 2 - 2] + part[NSUB * 2 - 1]) : part[0] + part[1];
+#ifdef ATTN_QFOLD
+        over[qb] = first || !(ps[qb] < ATTN_RESCALE_LIMIT);   // the reference point starts at 0: the first tile of a walk always takes the exact path
+#else
         over[qb] = !(ps[qb] < ATTN_RESCALE_LIMIT);
+#endif
         redo |= over[qb];
     }
     if (__any(redo)) {
@@ -219,10 +236,16 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
             for (int nb = 0; nb < NSUB * 2; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qb][nb][r]);
+#ifdef ATTN_QFOLD
+            mx = group4_max(mx) + m[qb];   // scores are held as s * c2 - m
+#else
             mx = group4_max(mx) * c2;
+#endif
             const bool mine = group4_max(over[qb] ? 1.0f : 0.0f) > 0.f;
             const float mn = mine ? fmaxf(m[qb], mx) : m[qb];
             const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
+            const float mold = m[qb];
+            (void)mold;
             m[qb] = mn;
             l[qb] *= alpha;
 #pragma unroll
@@ -233,7 +256,11 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
 #pragma unroll
             for (int nb = 0; nb < NSUB * 2; ++nb) {
 #pragma unroll
+#ifdef ATTN_QFOLD
+                for (int r = 0; r < 4; ++r) p[qb][nb][r] = __builtin_amdgcn_exp2f(s[qb][nb][r] + (mold - mn));
+#else
                 for (int r = 0; r < 4; ++r) p[qb][nb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][nb][r], c2, -mn));
+#endif
                 part[nb] = (p[qb][nb][0] + p[qb][nb][1]) + (p[qb][nb][2] + p[qb][nb][3]);
             }
             ps[qb] = NSUB == 2 ? (part[0] + part[1]) + (part[NSUB * 2 - 2] + part[NSUB * 2 - 1]) : part[0] + part[1];
@@ -291,6 +318,15 @@ __global__ __launch_bounds__(64 * NW * KS) void attn_fwd_kernel(AttnArgs a, int 
         const bf16_t* p = qkv_b + (size_t)q * ld + h * 64 + g * 8;
         qf[qb][0] = ld16v(p);
         qf[qb][1] = ld16v(p + 32);
+#ifdef ATTN_QFOLD
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = __uint_as_float(qf[qb][hf][j] << 16) * (a.scale * LOG2E), hi = __uint_as_float(qf[qb][hf][j] & 0xFFFF0000u) * (a.scale * LOG2E);
+                qf[qb][hf][j] = pack2bf(lo, hi);
+            }
+#endif
     }
     const uint32_t koff = dma.token_off(ld);
     auto issue = [&](int kt, bf16_t* st) {
@@ -311,18 +347,18 @@ __global__ __launch_bounds__(64 * NW * KS) void attn_fwd_kernel(AttnArgs a, int 
     f32x4 o[QB][4];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        m[qb] = NEG_BIG;
+        m[qb] = ATTN_M0;
         l[qb] = 0.f;
 #pragma unroll
         for (int nd = 0; nd < 4; ++nd) o[qb][nd] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float c2 = a.scale * LOG2E;
-    auto run_tile = [&](int tile, const bf16_t* cur) {
+    auto run_tile = [&](int tile, const bf16_t* cur, bool first) {
         const int kt = tile * 64;
-        if (kt + 64 <= a.T) attn_fwd_tile<QB, 2, false>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g);
+        if (kt + 64 <= a.T) attn_fwd_tile<QB, 2, false>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g, first);
         // last tile: padding keys masked, second sub-tile skipped when it is all padding
-        else if (kt + 32 < a.T) attn_fwd_tile<QB, 2, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g);
-        else attn_fwd_tile<QB, 1, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g);
+        else if (kt + 32 < a.T) attn_fwd_tile<QB, 2, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g, first);
+        else attn_fwd_tile<QB, 1, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g, first);
     };
     if (KS == 1) {
         // One group walks BOTH key ranges, one after the other, and merges the two softmax states with the arithmetic of the
@@ -335,7 +371,7 @@ __global__ __launch_bounds__(64 * NW * KS) void attn_fwd_kernel(AttnArgs a, int 
             for (int it = tb; it < te; ++it) {
                 dma_wait_barrier();
                 if (it + 1 < nt) issue((it + 1) * 64, ring + ((it + 1) & 1) * 8192);
-                if (active) run_tile(it, ring + (it & 1) * 8192);
+                if (active) run_tile(it, ring + (it & 1) * 8192, it == tb);
             }
         };
         walk(0, per2);
@@ -345,7 +381,7 @@ __global__ __launch_bounds__(64 * NW * KS) void attn_fwd_kernel(AttnArgs a, int 
                 float* e = park + ((dma.wave * QB + qb) * 18) * 64 + lane;
                 e[0] = m[qb];
                 e[64] = l[qb];
-                m[qb] = NEG_BIG; l[qb] = 0.f;
+                m[qb] = ATTN_M0; l[qb] = 0.f;
 #pragma unroll
                 for (int nd = 0; nd < 4; ++nd) {
 #pragma unroll
@@ -373,7 +409,7 @@ __global__ __launch_bounds__(64 * NW * KS) void attn_fwd_kernel(AttnArgs a, int 
             dma_wait_barrier();   // tile `it` of every group has landed; tile it-1 fully consumed
             const int tile = t0 + it;
             if (tile + 1 < t1) issue((tile + 1) * 64, ring + ((it + 1) & 1) * 8192);
-            if (active && tile < t1) run_tile(tile, ring + (it & 1) * 8192);
+            if (active && tile < t1) run_tile(tile, ring + (it & 1) * 8192, it == 0);
         }
     }
     if (KS > 1) {   // merge the groups' partial states: lane for lane (same query, same output columns in both groups)
@@ -769,13 +805,14 @@ constexpr int Q_STAGE = 2 * 4096;   // bf16 elements per ring stage of the dQ ha
 // tile peeled behind it instead of in front: the same at one pair, +1.2 % step time at eight; a 3-stage ring (two tiles in flight,
 // asm-issued DMA, counted waits) for the merged launch: +1.7 % step time at one pair, +1.3 % at two -- the one-pass launches are
 // not waiting on the tile feed.)
+template <int NW = 4>   // waves sharing the ring: 4 (64 queries per workgroup) or 8 (128; the two-launch form of chip-filling batches)
 __device__ __forceinline__ void attn_bwd_q_body(const AttnArgs& a, int xb, int h, int b, bf16_t* smem /* [stage][K | V] */) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
     const int ld = 3 * a.D;
-    const TileDma dma;
+    const TileDmaT<NW> dma;
     const FragAddr fa(g, c);
-    const int qbase = xb * 64 + dma.wave * 16;
+    const int qbase = xb * (16 * NW) + dma.wave * 16;
     const bool active = qbase < a.Tld;
     const int q = qbase + c;
     const int qc = q < a.Tld ? q : a.Tld - 1;
@@ -873,13 +910,14 @@ __device__ __forceinline__ void attn_bwd_kv_tile(const bf16_t* st, const FragAdd
     }
 }
 
+template <int NW = 4>
 __device__ __forceinline__ void attn_bwd_kv_body(const AttnArgs& a, int xb, int h, int b, bf16_t* smem /* 2 * KV_STAGE */) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
     const int ld = 3 * a.D;
-    const TileDma dma;
+    const TileDmaT<NW> dma;
     const FragAddr fa(g, c);
-    const int kbase = xb * 64 + dma.wave * 16;
+    const int kbase = xb * (16 * NW) + dma.wave * 16;
     const bool active = kbase < a.Tld;
     const int key = kbase + c;
     const int keyc = key < a.Tld ? key : a.Tld - 1;
@@ -952,17 +990,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a, int nx) {
     else attn_bwd_q_body(a, xb, h, b, smem);
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(AttnArgs a, int nx) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_q_kernel(AttnArgs a, int nx) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * Q_STAGE];
     int xb, h, b;
     attn_block_coords(nx, a.H, a.B, xb, h, b);
-    attn_bwd_q_body(a, xb, h, b, smem);
+    attn_bwd_q_body<NW>(a, xb, h, b, smem);
 }
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(AttnArgs a, int nx) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(AttnArgs a, int nx) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * KV_STAGE];
     int xb, h, b;
     attn_block_coords(nx, a.H, a.B, xb, h, b);
-    attn_bwd_kv_body(a, xb, h, b, smem);
+    attn_bwd_kv_body<NW>(a, xb, h, b, smem);
 }
 
 __global__ void attn_delta_kernel(AttnArgs a) {
@@ -1066,8 +1106,17 @@ int attn_bwd_launch(const AttnArgs* a, hipStream_t s) {
     if (2 * n <= merge_max) {
         SPLICE_LAUNCH(attn_bwd_kernel, dim3(2 * n), dim3(256), 0, s, *a, nx);
     } else {
-        SPLICE_LAUNCH(attn_bwd_q_kernel, dim3(n), dim3(256), 0, s, *a, nx);
-        SPLICE_LAUNCH(attn_bwd_kv_kernel, dim3(n), dim3(256), 0, s, *a, nx);
+        // two-launch form: eight waves share each ring (128 queries / keys per workgroup: half the L2 -> LDS traffic; same bits per
+        // query / key -- a wave's arithmetic does not know how many waves share its tiles).  SPLICE_ATTN_BWD_W8=0: four waves.
+        static const int bwd_w8 = getenv("SPLICE_ATTN_BWD_W8") ? atoi(getenv("SPLICE_ATTN_BWD_W8")) : 1;
+        if (bwd_w8) {
+            const int nx8 = cdiv(a->Tld, 128), n8 = nx8 * a->H * a->B;
+            SPLICE_LAUNCH(attn_bwd_q_kernel<8>, dim3(n8), dim3(512), 0, s, *a, nx8);
+            SPLICE_LAUNCH(attn_bwd_kv_kernel<8>, dim3(n8), dim3(512), 0, s, *a, nx8);
+        } else {
+            SPLICE_LAUNCH(attn_bwd_q_kernel<4>, dim3(n), dim3(256), 0, s, *a, nx);
+            SPLICE_LAUNCH(attn_bwd_kv_kernel<4>, dim3(n), dim3(256), 0, s, *a, nx);
+        }
     }
     return SPLICE_OK;
 }
