@@ -20,12 +20,6 @@
 
 
 #define NEG_BIG (-1.0e30f)
-// experiment switch (tools/attn_prio_ab.sh): s_setprio 1 around the MFMA clusters -- 1 forward, 2 forward + backward
-#ifndef ATTN_PRIO
-#define ATTN_PRIO 0
-#endif
-#define PRIO_FWD(x) do { if (ATTN_PRIO >= 1) __builtin_amdgcn_s_setprio(x); } while (0)
-#define PRIO_BWD(x) do { if (ATTN_PRIO >= 2) __builtin_amdgcn_s_setprio(x); } while (0)
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 // softmax runs in base 2: scores are scaled by scale*log2(e) once, probabilities are v_exp_f32 (exp2) directly,
@@ -181,7 +175,6 @@ template <int QB, int NSUB, bool MASK>
 __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs, const FragAddr& fa, const u32x4 (&qf)[QB][2],
                                               float (&m)[QB], float (&l)[QB], f32x4 (&o)[QB][4], float c2, int kt, int T, int g, bool first = false) {
     f32x4 s[QB][NSUB * 2];
-    PRIO_FWD(1);
 #pragma unroll
     for (int nb = 0; nb < NSUB * 2; ++nb) {
         const u32x4 k0 = lds16(Ks + fa.tok[0] + (nb >> 1) * 2048 + (nb & 1) * 256);
@@ -196,7 +189,6 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
             s[qb][nb] = mfma16(k1, qf[qb][1], s[qb][nb]);
         }
     }
-    PRIO_FWD(0);
     if (MASK) {
 #pragma unroll
         for (int nb = 0; nb < NSUB * 2; ++nb)
@@ -276,7 +268,6 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
     }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) l[qb] += ps[qb];
-    PRIO_FWD(1);
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
         u32x4 pb[QB];
@@ -289,7 +280,6 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
             for (int qb = 0; qb < QB; ++qb) o[qb][nd] = mfma16(vf, pb[qb], o[qb][nd]);
         }
     }
-    PRIO_FWD(0);
 }
 
 // KS = 2: the workgroup holds TWO groups of 4 waves that own the SAME queries; group 0 walks the first half of the key tiles,
@@ -774,7 +764,6 @@ __device__ __forceinline__ void attn_bwd_q_tile(const bf16_t* Ks, const bf16_t* 
                                                 const u32x4 (&qf)[2], const u32x4 (&dof)[2], float lse_q, float del_q, f32x4 (&dq)[4],
                                                 float c2, int kt, int T, int g) {
     f32x4 s[NSUB * 2], dp[NSUB * 2];
-    PRIO_BWD(1);
 #pragma unroll
     for (int nb = 0; nb < NSUB * 2; ++nb) {
         const int off = (nb >> 1) * 2048 + (nb & 1) * 256;
@@ -783,7 +772,6 @@ __device__ __forceinline__ void attn_bwd_q_tile(const bf16_t* Ks, const bf16_t* 
         s[nb] = mfma16(lds16(Ks + fa.tok[1] + off), qf[1], s[nb]);
         dp[nb] = mfma16(lds16(Vs + fa.tok[1] + off), dof[1], dp[nb]);
     }
-    PRIO_BWD(0);
 #pragma unroll
     for (int nb = 0; nb < NSUB * 2; ++nb)
 #pragma unroll
@@ -792,14 +780,12 @@ __device__ __forceinline__ void attn_bwd_q_tile(const bf16_t* Ks, const bf16_t* 
             if (MASK) p = kt + (nb >> 1) * 32 + g * 8 + (nb & 1) * 4 + r < T ? p : 0.f;
             dp[nb][r] = p * (dp[nb][r] - del_q);
         }
-    PRIO_BWD(1);
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
         const u32x4 dsb = pack8v(dp[sub * 2], dp[sub * 2 + 1]);
 #pragma unroll
         for (int nd = 0; nd < 4; ++nd) dq[nd] = mfma16(lds_tr16(Ks, fa.tr[nd] + sub * 2048), dsb, dq[nd]);   // dQ^T[d][q]: K^T out of the K tile
     }
-    PRIO_BWD(0);
 }
 
 __device__ __forceinline__ float dot8bf(const u32x4& x, const u32x4& y) {
@@ -894,7 +880,6 @@ __device__ __forceinline__ void attn_bwd_kv_tile(const bf16_t* st, const FragAdd
     const float* Ls = reinterpret_cast<const float*>(st + 8192);
     const float* Es = Ls + 64;
     f32x4 s[NSUB * 2], dp[NSUB * 2];
-    PRIO_BWD(1);
 #pragma unroll
     for (int nb = 0; nb < NSUB * 2; ++nb) {
         const int off = (nb >> 1) * 2048 + (nb & 1) * 256;
@@ -903,7 +888,6 @@ __device__ __forceinline__ void attn_bwd_kv_tile(const bf16_t* st, const FragAdd
         s[nb] = mfma16(lds16(Qs + fa.tok[1] + off), kf[1], s[nb]);
         dp[nb] = mfma16(lds16(Ds + fa.tok[1] + off), vf[1], dp[nb]);
     }
-    PRIO_BWD(0);
 #pragma unroll
     for (int nb = 0; nb < NSUB * 2; ++nb) {
         const f32x4 ls = *reinterpret_cast<const f32x4*>(Ls + (nb >> 1) * 32 + g * 8 + (nb & 1) * 4);
@@ -915,7 +899,6 @@ __device__ __forceinline__ void attn_bwd_kv_tile(const bf16_t* st, const FragAdd
             dp[nb][r] = p * (dp[nb][r] - de[r]);
         }
     }
-    PRIO_BWD(1);
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
         const u32x4 pb = pack8v(s[sub * 2], s[sub * 2 + 1]), dsb = pack8v(dp[sub * 2], dp[sub * 2 + 1]);
@@ -925,7 +908,6 @@ __device__ __forceinline__ void attn_bwd_kv_tile(const bf16_t* st, const FragAdd
             dk[nd] = mfma16(lds_tr16(Qs, fa.tr[nd] + sub * 2048), dsb, dk[nd]);   // dK^T[d][key]: Q^T out of the Q tile
         }
     }
-    PRIO_BWD(0);
 }
 
 template <int NW = 4>
