@@ -121,7 +121,27 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, int bx, int b
         if (ok) w_ok |= 1ull << t;
     }
     float av[NA], wv[NW];
+    // Full channel tiles are fetched with RAW BUFFER loads: a thread's byte offsets are fixed for the whole kernel (an element that is
+    // padding / out of the image / out of the output-channel range carries bit 31 = out of the descriptor's range, and the hardware
+    // returns 0 for it), the channel tile enters as the SCALAR offset -- no predicate, no branch, no address arithmetic per load
+    // (the guarded global loads compiled to one exec-masked basic block per element: ~120 instructions and 13 branches per tile in
+    // front of 18 MFMAs).  Same values, same order.  The last, partial channel tile of a range keeps the guarded form.
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wgt), 0, 0x7FFFFFFF, 0x00020000);
+    int a_vo[NA], w_vo[NW];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a_vo[i] = ((a_ok >> i) & 1ull) ? a_off[i] * 4 : (int)0x80000000;
+#pragma unroll
+    for (int t = 0; t < NW; ++t) w_vo[t] = ((w_ok >> t) & 1ull) ? w_off[t] * 4 : (int)0x80000000;
     auto fetch = [&](int c0) {
+        if (c0 + CK <= Kc) {
+            const int so_a = __builtin_amdgcn_readfirstlane(c0 * (int)a.in_cstride * 4), so_w = __builtin_amdgcn_readfirstlane(c0 * (int)a.w_cstride * 4);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) av[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, a_vo[i], so_a, 0));
+#pragma unroll
+            for (int t = 0; t < NW; ++t) wv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, w_vo[t], so_w, 0));
+            return;
+        }
         const float* inc = in + (size_t)c0 * a.in_cstride;
         const float* wc = wgt + (size_t)c0 * a.w_cstride;
 #pragma unroll
@@ -509,6 +529,18 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, int chunk, i
         if (c0 + cl < a.Cin) g_cok |= 1u << i;
     }
     float xv[NA], dv[ND];
+    // raw buffer loads (see conv_igemm_body): an element outside the image / the channel range / the chunk gets an offset with bit 31
+    // set and reads as 0 -- no exec-masked block per element.  The output-gradient offsets of a thread are fixed, the fill enters as
+    // the scalar offset.
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, 0x7FFFFFFF, 0x00020000);
+    int d_vo[ND];
+#pragma unroll
+    for (int t = 0; t < ND; ++t) {
+        const int e = tid + 256 * t;
+        const int n = e / PC, q = e % PC;
+        d_vo[t] = n < a.Cout ? (int)((n * a.dy_cstride + q) * 4) : (int)0x80000000;
+    }
     auto fetch = [&](int pb) {
         const int p = pb + pl;
         const bool pvalid = p < p_end;
@@ -521,15 +553,22 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, int chunk, i
                 sy = sy < 0 ? -sy : (sy >= a.Hi ? 2 * (a.Hi - 1) - sy : sy);
                 sx = sx < 0 ? -sx : (sx >= a.Wi ? 2 * (a.Wi - 1) - sx : sx);
             }
-            const bool ok = pvalid && ((g_cok >> i) & 1u) && sy >= 0 && sy < a.Hi && sx >= 0 && sx < a.Wi;
-            xv[i] = ok ? x[g_coff[i] + sy * a.Wi + sx] : 0.f;
+            const bool ok = pvalid && ((g_cok >> i) & 1u) && (unsigned)sy < (unsigned)a.Hi && (unsigned)sx < (unsigned)a.Wi;
+            const int vo = ok ? (g_coff[i] + sy * a.Wi + sx) * 4 : (int)0x80000000;
+            xv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo, 0, 0));
         }
+        if (pb + PC <= p_end) {   // a full fill: fixed per-thread offsets + the fill as the scalar offset
+            const int so = __builtin_amdgcn_readfirstlane(pb * 4);
 #pragma unroll
-        for (int t = 0; t < ND; ++t) {
-            const int e = tid + 256 * t;
-            const int n = e / PC, q = e % PC;
-            const int pp = pb + q;
-            dv[t] = (n < a.Cout && pp < p_end) ? dy[(size_t)n * a.dy_cstride + pp] : 0.f;
+            for (int t = 0; t < ND; ++t) dv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, d_vo[t], so, 0));
+        } else {
+#pragma unroll
+            for (int t = 0; t < ND; ++t) {
+                const int e = tid + 256 * t;
+                const int n = e / PC, q = e % PC;
+                const int pp = pb + q;
+                dv[t] = (n < a.Cout && pp < p_end) ? dy[(size_t)n * a.dy_cstride + pp] : 0.f;
+            }
         }
     };
     fetch(p_begin);
