@@ -57,6 +57,21 @@ def _first_file(d):
 _VIT_ENGINES = {}
 
 
+def _release_process_caches():
+    """Interpreter exit: free the process-wide ViT engine (weights, contexts, captured graphs) while the interpreter and the HIP
+    runtime are still whole -- left to module teardown, its destructor runs in an arbitrary order against `_lib` and torch."""
+    try:
+        _VIT_ENGINES.clear()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+
+
+import atexit
+atexit.register(_release_process_caches)
+
+
 def _shared_vit_engine(model_name, who):
     """The frozen DINO ViT of this process: loaded / packed once per (weight source, model) and shared by every run that follows
     (a batch worker optimises many pairs; reading and packing 86 M parameters per pair was 2 s of a 12 s run).  Weight
