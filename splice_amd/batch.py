@@ -121,15 +121,19 @@ def _write_result(root, name, res):
     os.replace(tmp, os.path.join(pair_dir, "out", "result.json"))
 
 
-def _worker(gpu, visible_id, root, names, items, head, current, runner, overrides, pin_gpu, group_runner="splice_amd.batch:train_group_runner"):
+def _worker(gpu, visible_id, root, names, items, head, current, runner, overrides, pin_gpu, group_runner="splice_amd.batch:train_group_runner", redo=None):
     if pin_gpu:   # must happen before the HIP runtime starts in this process
         os.environ["HIP_VISIBLE_DEVICES"] = str(visible_id)
         os.environ.pop("CUDA_VISIBLE_DEVICES", None)
     run, run_group = None, None
     while True:
-        with head.get_lock():             # the one shared word: index of the next unclaimed work item
-            k = head.value
-            head.value = k + 1
+        with head.get_lock():             # the shared words: index of the next unclaimed work item, and the items handed back
+            k = next((j for j in range(len(items)) if redo[j]), None) if redo is not None else None   # (by the parent: their worker was killed)
+            if k is not None:
+                redo[k] = 0
+            else:
+                k = head.value
+                head.value = k + 1
         if k >= len(items):
             break
         current[gpu] = k                  # (the parent names the item a dead worker was running)
@@ -147,7 +151,7 @@ def _worker(gpu, visible_id, root, names, items, head, current, runner, override
 
 
 def run_batch(root, n_gpus=1, overrides=None, runner="splice_amd.batch:train_runner", pin_gpu=True, visible_ids=None, pairs_per_gpu=1,
-              group_runner=None, sizes=None):
+              group_runner=None, sizes=None, max_retries=1):
     """Optimise every pair under ``root`` on ``n_gpus`` worker processes; returns the per-pair result dicts in pair order.
 
     ``runner``: ``"module:function"`` (or a picklable callable) ``(pair_dir, overrides) -> dict``; the default trains the
@@ -160,9 +164,11 @@ def run_batch(root, n_gpus=1, overrides=None, runner="splice_amd.batch:train_run
     augmentations stay per pair), so under random crops a pair's RNG stream is not the one of its single run (with deterministic
     full crops the results are bit-identical, tests/test_batch_gpu.py).
     ``sizes``: per pair ``((A_w, A_h), (B_w, B_h))`` if already known (default: read from the image headers).
-    ``pin_gpu=False`` leaves device visibility alone (CPU tests).  A worker that dies takes the batch down with a RuntimeError
-    naming the pairs it was running and the pairs left undone; the other workers drain the rest of the queue first, and
-    finished pairs keep their ``result.json``."""
+    ``pin_gpu=False`` leaves device visibility alone (CPU tests).  A worker KILLED BY A SIGNAL (a crash below Python: the HIP
+    runtime's handler thread has done that) is replaced by a fresh process on the same GPU and the item it
+    was running goes back to the queue, at most ``max_retries`` times per item; a worker that ends with a Python error -- a
+    deterministic failure -- or an item out of retries takes the batch down with a RuntimeError naming the pairs it was running and
+    the pairs left undone; the other workers drain the rest of the queue first, and finished pairs keep their ``result.json``."""
     import multiprocessing as mp
     if int(pairs_per_gpu) > 1 and group_runner is None:
         if runner != "splice_amd.batch:train_runner":
@@ -196,18 +202,38 @@ def run_batch(root, n_gpus=1, overrides=None, runner="splice_amd.batch:train_run
     ctx = mp.get_context("spawn")   # fresh interpreters: the HIP runtime must not be inherited through fork
     head = ctx.Value("i", 0)
     current = ctx.Array("i", [-1] * n_gpus)
-    procs = [ctx.Process(target=_worker, args=(g, visible_ids[g] if pin_gpu else g, root, names, items, head, current, runner, dict(overrides or {}), pin_gpu, group_runner))
-             for g in range(n_gpus)]
-    for p in procs:
+    redo = ctx.Array("i", [0] * len(items), lock=False)   # (guarded by head's lock)
+
+    def spawn(g):
+        p = ctx.Process(target=_worker, args=(g, visible_ids[g] if pin_gpu else g, root, names, items, head, current, runner, dict(overrides or {}), pin_gpu, group_runner, redo))
         p.start()
-    for p in procs:
-        p.join()
-    failed = [g for g, p in enumerate(procs) if p.exitcode != 0]
-    if failed:
+        return p
+
+    alive = {g: spawn(g) for g in range(n_gpus)}
+    attempts, failures = [0] * len(items), []
+    while alive:
+        for g, p in list(alive.items()):
+            p.join(timeout=0.05)
+            if p.exitcode is None:
+                continue
+            del alive[g]
+            if p.exitcode == 0:
+                continue
+            k = current[g]
+            if p.exitcode < 0 and k >= 0 and attempts[k] < int(max_retries):   # killed by a signal while running item k: hand it back, new worker
+                attempts[k] += 1
+                print(f"run_batch: worker of gpu {g} was killed by signal {-p.exitcode} while running {[names[i] for i in items[k]]}; "
+                      f"restarting it (retry {attempts[k]} of {int(max_retries)} for that item)", file=sys.stderr, flush=True)
+                with head.get_lock():
+                    redo[k] = 1
+                current[g] = -1
+                alive[g] = spawn(g)
+            else:
+                failures.append((g, p.exitcode, [names[i] for i in items[k]] if k >= 0 else []))
+    if failures:
         undone = [n for n in names if not os.path.exists(os.path.join(root, n, "out", "result.json"))]
-        raise RuntimeError("run_batch: worker(s) failed: " + "; ".join(
-            f"gpu {g} (exit {procs[g].exitcode}) while running {[names[i] for i in items[current[g]]] if current[g] >= 0 else []}" for g in failed)
-            + f"; pairs without a result: {undone}")
+        raise RuntimeError("run_batch: worker(s) failed: " + "; ".join(f"gpu {g} (exit {code}) while running {running}" for g, code, running in failures)
+                           + f"; pairs without a result: {undone}")
     out = []
     for name in names:
         with open(os.path.join(root, name, "out", "result.json")) as f:
@@ -233,6 +259,7 @@ def main(argv=None):
                     help="e4m3 operands for the QKV / fc1 / fc2 projections and the self-similarity Gram matrices (config key fp8); "
                          "'--fp8 attention': the attention forward too")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="config override (conf/default/config.yaml keys)")
+    ap.add_argument("--max-retries", type=int, default=1, help="times an item goes back to the queue when the worker running it is killed by a signal")
     args = ap.parse_args(argv)
     over = {}
     if args.n_epochs is not None:
@@ -247,7 +274,7 @@ def main(argv=None):
         k, _, v = kv.partition("=")
         over[k] = _parse_value(v)
     t0 = time.perf_counter()
-    res = run_batch(args.root, args.gpus, over, pairs_per_gpu=args.pairs_per_gpu)
+    res = run_batch(args.root, args.gpus, over, pairs_per_gpu=args.pairs_per_gpu, max_retries=args.max_retries)
     dt = time.perf_counter() - t0
     print(json.dumps({"pairs": len(res), "gpus": args.gpus, "seconds": round(dt, 2), "pairs_per_hour": round(len(res) * 3600 / dt, 2), "results": res}))
 

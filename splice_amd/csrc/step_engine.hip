@@ -17,7 +17,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <deque>
 #include <map>
+#include <mutex>
 
 #include "gen_kernels.h"
 #include "kernels.h"
@@ -101,9 +104,16 @@ struct SpliceStep {
     int max_crop_h = 0, max_crop_w = 0;
     int* dev_t = nullptr;        // Adam step count on the device
     hipStream_t own_stream = nullptr;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    // Cross-stream events, a RING of sets: an eager step records its fork / join events twice and the next step records them again
+    // ~2 ms later, while waits on the previous record may still be queued; every record site has an event of its own and a set is
+    // reused only EV_RING steps later (the runtime's completion handler crashed in the release chain of such marker commands once per
+    // ~30 train_model runs, see drop_graphs)
+    enum { EV_IN, EV_OUT, EV_FORK, EV_JOIN, EV_GB, EV_FORK2, EV_JOIN2, EV_KINDS };
+    static constexpr int EV_RING = 4;
+    hipEvent_t evs[EV_RING][EV_KINDS] = {};
+    int ev_slot = 0;
+    hipEvent_t ev(int kind) const { return evs[ev_slot][kind]; }
     hipStream_t side_stream = nullptr;               // target-pass ViT forward beside the generator forward
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int overlap = 1;                                 // SPLICE_STEP_OVERLAP=0 serialises (debugging)
     int ablate = 0;                                  // always 0 in the product build.  Scratch builds (-DSPLICE_DEV_SWITCHES) read the SPLICE_STEP_ABLATE bitmask, TIMING experiments only (results are garbage):
                                                      // 1 skip G fwd, 2 skip G bwd, 4 skip ViT bwd, 8 skip target ViT fwd, 16 skip generated ViT fwd, 32 skip the y' chain of the ViT bwd
@@ -112,7 +122,6 @@ struct SpliceStep {
     float* losses_out = nullptr;                     // this step's destination of the [P][8] loss values (written by total_loss_kernel)
     int graph_crops[4] = {0, 0, 0, 0};
     float* grads_b = nullptr;                        // gradient arena(s) of the B-crop plan (added to `grads` inside Adam)
-    hipEvent_t ev_gb = nullptr;                      // G(B_crop) finished on the side stream
     int shape_repeats = 0;                           // consecutive steps with the same arenas and crop sizes
     int repeat_step = -1;                            // step_idx the count above was last advanced / reset for (several partial-phase calls of ONE step count once)
     int use_graph = 1;
@@ -126,6 +135,12 @@ struct SpliceStep {
 };
 
 static void drop_graphs(SpliceStep* st);
+static bool create_events(SpliceStep* st) {
+    for (auto& set : st->evs)
+        for (hipEvent_t& e : set)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+}
 
 template <class T>
 static int salloc(SpliceStep* st, T** p, size_t n) {
@@ -360,11 +375,7 @@ int splice_step_create(const splice_step_config* cfg, void* vit_ctx_global, void
 #endif
     if (hipStreamCreateWithFlags(&st->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&st->side_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&st->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&st->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&st->ev_gb, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&st->ev_in, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&st->ev_out, hipEventDisableTiming) != hipSuccess) {
+        !create_events(st)) {
         splice_set_error("splice_step_create: stream/event creation failed");
         return fail(SPLICE_ERR_HIP);
     }
@@ -378,11 +389,9 @@ void splice_step_destroy(void* h) {
     drop_graphs(st);
     if (st->own_stream) { (void)hipStreamSynchronize(st->own_stream); (void)hipStreamDestroy(st->own_stream); }
     if (st->side_stream) { (void)hipStreamSynchronize(st->side_stream); (void)hipStreamDestroy(st->side_stream); }
-    if (st->ev_fork) (void)hipEventDestroy(st->ev_fork);
-    if (st->ev_join) (void)hipEventDestroy(st->ev_join);
-    if (st->ev_gb) (void)hipEventDestroy(st->ev_gb);
-    if (st->ev_in) (void)hipEventDestroy(st->ev_in);
-    if (st->ev_out) (void)hipEventDestroy(st->ev_out);
+    for (auto& set : st->evs)
+        for (hipEvent_t e : set)
+            if (e) (void)hipEventDestroy(e);
     for (void* q : st->allocs) (void)hipFree(q);
     delete st;
 }
@@ -472,15 +481,15 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     const bool overlap = st->overlap && !splice_prof_active();
     hipStream_t s2 = overlap ? st->side_stream : s;
     if (overlap) {
-        HIPCHK(hipEventRecord(st->ev_fork, s));
-        HIPCHK(hipStreamWaitEvent(s2, st->ev_fork, 0));
+        HIPCHK(hipEventRecord(st->ev(SpliceStep::EV_FORK), s));
+        HIPCHK(hipStreamWaitEvent(s2, st->ev(SpliceStep::EV_FORK), 0));
     }
     // global_transform (Resize -> Normalize; the Normalize is fused into the ViT patch gather).  The generator runs as one
     // plan per crop kind (A crops | B crops: the reference draws their sizes independently, data/Dataset.py:66-67);
     // G(B_crop) goes first on the side stream so that it runs beside G(A_crop) instead of behind it
     if (do_gf && !(st->ablate & 1)) {
         RC(splice_gen_forward_borrowed(st->plan_b, params, B_crop, ip.y, s2));
-        if (overlap) HIPCHK(hipEventRecord(st->ev_gb, s2));
+        if (overlap) HIPCHK(hipEventRecord(st->ev(SpliceStep::EV_GB), s2));
     }
     float *blk_g = nullptr, *qkv_g = nullptr;
     RC(splice_vit_get_tensor(vg.ctx, 0, vg.depth - 1, (void**)&blk_g));
@@ -500,18 +509,18 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
             RC(selfsim_target_launch(sb, s2));
         }
     }
-    if (overlap) HIPCHK(hipEventRecord(st->ev_join, s2));
+    if (overlap) HIPCHK(hipEventRecord(st->ev(SpliceStep::EV_JOIN), s2));
     // ---- Model.forward: x_global = G(A_crop), y_global = G(B_crop) [, x_entire = G(A)]
     if (do_gf && !(st->ablate & 1)) {
         RC(splice_gen_forward_borrowed(st->plan_a, params, A_crop, ip.x, s));
-        if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_gb, 0));
+        if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev(SpliceStep::EV_GB), 0));
     }
     if (do_v) {
         RC(place_images(src.x, c.crop_h, c.crop_w, vg.imgs + pX * vimg, vg.H, vg.W, Pa, s));
         RC(place_images(src.y, st->cropb_h, st->cropb_w, vg.imgs + pY * vimg, vg.H, vg.W, Pb, s));
         if (!(st->ablate & 16)) RC(splice_vit_forward_passes(vg.ctx, vg.imgs, 1, pX, pX, pEnd, s));
     }
-    if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
+    if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev(SpliceStep::EV_JOIN), 0));
     // ---- losses on the global batch
     if (do_v) {
         if (l_ssim > 0.f) RC(selfsim_loss_launch(sb, s));
@@ -569,8 +578,8 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     const float* adam_g2 = nullptr;
     if (!(st->ablate & 4)) {   // (the same launches whether or not the second stream is used: results are bit-identical)
         if (overlap) {
-            HIPCHK(hipEventRecord(st->ev_fork, s));
-            HIPCHK(hipStreamWaitEvent(s2, st->ev_fork, 0));
+            HIPCHK(hipEventRecord(st->ev(SpliceStep::EV_FORK2), s));
+            HIPCHK(hipStreamWaitEvent(s2, st->ev(SpliceStep::EV_FORK2), 0));
         }
         if (do_v) {
             if (!(st->ablate & 32)) RC(splice_vit_backward(vg.ctx, pY, pEnd, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s2));
@@ -585,7 +594,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
             sum_losses(s2);
             loss_summed = true;
             RC(track_running(s2));
-            HIPCHK(hipEventRecord(st->ev_join, s2));
+            HIPCHK(hipEventRecord(st->ev(SpliceStep::EV_JOIN2), s2));
         }
         if (do_v) {
             RC(splice_vit_backward(vg.ctx, pX, pY, vg.pb.data(), nullptr, vg.pk.data(), vg.d_imgs, 1, s));
@@ -593,7 +602,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
             RC(to_leader(src.dx, ip.dx, (size_t)Pa * 3 * c.crop_h * c.crop_w, s));
         }
         if (do_gb && !(st->ablate & 2)) RC(splice_gen_backward(st->plan_a, params, ip.dx, grads, st->accumulate, s));
-        if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev_join, 0));
+        if (overlap) HIPCHK(hipStreamWaitEvent(s, st->ev(SpliceStep::EV_JOIN2), 0));
         // grads = g(A) + g(B): folded into the Adam kernel on ordinary steps; a separate add when the entire-image branch
         // still has to accumulate into the sum (same association order either way)
         if (do_gb && !(st->ablate & 2)) {
@@ -617,12 +626,40 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     return SPLICE_OK;
 }
 
+// Dropped graph executables are not destroyed on the spot.  hipStreamSynchronize returns when the last signal of a replay has
+// been reached, while the runtime's asynchronous signal-handler thread may still be walking the completion callbacks of that
+// replay's commands; hipGraphExecDestroy right behind the synchronize frees objects under it.  Measured: a segmentation fault
+// INSIDE that handler thread (libhsa-runtime64 -> libamdhip64 callback chain) once per ~15 train_model runs of 2000 steps with
+// random crop sizes (each of which captured and dropped ~14 graphs), profiles/r04_graph_drop_crash.txt.  So: executables go to a
+// process-wide graveyard and are destroyed once they have been dead for a while (what is still there at exit is left alone).
+namespace {
+struct DeadGraph { hipGraphExec_t ex; std::chrono::steady_clock::time_point t; };
+std::mutex g_dead_mu;
+std::deque<DeadGraph> g_dead;
+void reap_dead_graphs() {
+    const auto now = std::chrono::steady_clock::now();
+    std::lock_guard<std::mutex> lk(g_dead_mu);
+    while (!g_dead.empty() && now - g_dead.front().t > std::chrono::milliseconds(1500)) {
+        (void)hipGraphExecDestroy(g_dead.front().ex);
+        g_dead.pop_front();
+    }
+}
+}  // namespace
+
 static void drop_graphs(SpliceStep* st) {
+    reap_dead_graphs();
     if (st->graphs.empty()) return;
-    // a replay may still be in flight: the forked (two-branch) graphs must not be destroyed under the runtime
+    // a replay may still be in flight: the forked (two-branch) graphs must not be retired under the runtime
     if (st->own_stream) (void)hipStreamSynchronize(st->own_stream);
     if (st->side_stream) (void)hipStreamSynchronize(st->side_stream);
-    for (auto& kv : st->graphs) (void)hipGraphExecDestroy(kv.second);
+    static const int grave = getenv("SPLICE_STEP_GRAPH_GRAVE") ? atoi(getenv("SPLICE_STEP_GRAPH_GRAVE")) : 1;   // 0: destroy on the spot (the crash reproducer)
+    if (!grave) {
+        for (auto& kv : st->graphs) (void)hipGraphExecDestroy(kv.second);
+    } else {
+        const auto now = std::chrono::steady_clock::now();
+        std::lock_guard<std::mutex> lk(g_dead_mu);
+        for (auto& kv : st->graphs) g_dead.push_back(DeadGraph{kv.second, now});
+    }
     st->graphs.clear();
 }
 
@@ -640,6 +677,7 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
     hipStream_t caller = (hipStream_t)stream;
     const splice_step_config& c = st->cfg;
     const int P = st->P;
+    st->ev_slot = (st->ev_slot + 1) % SpliceStep::EV_RING;   // this call's set of cross-stream events
     // ---- lambda schedule (util/losses.py:34-44)
     if (step_idx == c.cls_warmup) st->ssim_id_on = 1;
     const bool entire = c.ent_h > 0 && c.entire_every > 0 && (step_idx % c.entire_every == 0);
@@ -647,7 +685,7 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
     // Graphs pay off only while the launch sequence repeats: with random crop sizes (data/transforms.py:21) nearly every
     // step has new shapes, and re-capturing + instantiating ~600 nodes costs as much as the step itself (9.9 vs 5.8 ms
     // measured).  So a step whose arenas / crop sizes differ from the previous step's runs eagerly (same kernels, same
-    // results) and a graph is captured only from the second consecutive step with identical shapes on.
+    // results) and a graph is captured only once the shapes have repeated (below).
     {
         void* ptrs[6] = {params, grads, m, v, losses_out, st->running};
         st->losses_out = losses_out;
@@ -666,13 +704,16 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
             st->repeat_step = step_idx;
         }
     }
-    const bool graph = st->use_graph && !splice_prof_active() && st->shape_repeats >= 1;
+    // (from the THIRD consecutive step with identical shapes on: under random crop sizes two equal steps in a row happen ~14 times
+    // per 2000 steps, each time capturing ~600 nodes for ONE replay before the next size drops the graph again)
+    static const int graph_repeats = getenv("SPLICE_STEP_GRAPH_REPEATS") ? atoi(getenv("SPLICE_STEP_GRAPH_REPEATS")) : 2;
+    const bool graph = st->use_graph && !splice_prof_active() && st->shape_repeats >= (graph_repeats < 1 ? 1 : graph_repeats > 2 ? 2 : graph_repeats);
     const bool own = graph || st->dbg_own_eager;
     hipStream_t s = caller;
     if (own) {   // graphs cannot be captured on the legacy default stream: run on the handle's own stream, fenced by events
         s = st->own_stream;
-        HIPCHK(hipEventRecord(st->ev_in, caller));
-        HIPCHK(hipStreamWaitEvent(s, st->ev_in, 0));
+        HIPCHK(hipEventRecord(st->ev(SpliceStep::EV_IN), caller));
+        HIPCHK(hipStreamWaitEvent(s, st->ev(SpliceStep::EV_IN), 0));
     }
     if (st->leader) {
         const SpliceStep* ld = st->leader;
@@ -723,8 +764,8 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
         HIPCHK(hipGraphLaunch(it->second, s));
     }
     if (own) {
-        HIPCHK(hipEventRecord(st->ev_out, s));
-        HIPCHK(hipStreamWaitEvent(caller, st->ev_out, 0));
+        HIPCHK(hipEventRecord(st->ev(SpliceStep::EV_OUT), s));
+        HIPCHK(hipStreamWaitEvent(caller, st->ev(SpliceStep::EV_OUT), 0));
     }
     if (st->dbg_sync) HIPCHK(hipStreamSynchronize(s));
     const hipError_t e = hipGetLastError();

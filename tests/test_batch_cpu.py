@@ -5,6 +5,7 @@ the failure reporting."""
 import hashlib
 import json
 import os
+import signal
 import time
 
 import numpy as np
@@ -25,6 +26,11 @@ def stub_runner(pair_dir, overrides):
         f.write(h.digest())
     if overrides.get("explode") == os.path.basename(pair_dir):
         raise RuntimeError("boom")
+    if overrides.get("segv") == os.path.basename(pair_dir):   # a crash below Python, the first `segv_times` times this pair is run
+        marks = [f for f in os.listdir(pair_dir) if f.startswith("crashed")]
+        if len(marks) < overrides.get("segv_times", 1):
+            open(os.path.join(pair_dir, f"crashed{len(marks)}"), "w").close()
+            os.kill(os.getpid(), signal.SIGSEGV)
     t0 = time.time()
     time.sleep(overrides.get("sleep", {}).get(os.path.basename(pair_dir), overrides.get("sleep_default", 0.0)))
     return {"digest": h.hexdigest(), "steps": overrides.get("n_epochs", 0), "pid": os.getpid(), "t0": t0, "t1": time.time()}
@@ -121,6 +127,29 @@ def test_worker_failure_is_reported(tmp_path):
         assert (tmp_path / ok / "out" / "result.json").exists()
     with pytest.raises(ValueError):
         batch.run_batch(str(tmp_path / "not_a_pair"), 1, runner="test_batch_cpu:stub_runner", pin_gpu=False)
+
+
+def test_killed_worker_is_replaced_and_its_item_retried(tmp_path):
+    """A worker killed by a signal (SIGSEGV inside the runner: what a crash of the HIP runtime looks like to the parent) is replaced
+    and the item it was running goes back to the queue -- once by default; results equal the crash-free run's.  An item that keeps
+    killing its workers, and Python-level failures, still take the batch down with the pair named."""
+    good, bad = tmp_path / "good", tmp_path / "bad"
+    for r in (good, bad):
+        r.mkdir()
+        _make_pairs(r, 4)
+    ref = batch.run_batch(str(good), 2, {"n_epochs": 3}, runner="test_batch_cpu:stub_runner", pin_gpu=False)
+    res = batch.run_batch(str(bad), 2, {"n_epochs": 3, "segv": "pair02", "sleep_default": 0.1}, runner="test_batch_cpu:stub_runner", pin_gpu=False)
+    # (the digest covers the overrides: compare the crash-free fields)
+    assert [r["pair"] for r in res] == [r["pair"] for r in ref] and all(r["steps"] == 3 for r in res)
+    assert (bad / "pair02" / "crashed0").exists() and not (bad / "pair02" / "crashed1").exists()
+    again = tmp_path / "again"
+    again.mkdir()
+    _make_pairs(again, 3)
+    with pytest.raises(RuntimeError, match=r"exit -11\) while running \['pair01'\].*without a result: \['pair01'\]"):
+        batch.run_batch(str(again), 2, {"segv": "pair01", "segv_times": 5, "sleep_default": 0.1}, runner="test_batch_cpu:stub_runner", pin_gpu=False)
+    assert len([f for f in os.listdir(again / "pair01") if f.startswith("crashed")]) == 2      # first run + one retry
+    with pytest.raises(RuntimeError, match=r"exit -11"):                                          # max_retries=0: the old behaviour
+        batch.run_batch(str(again), 1, {"segv": "pair00", "segv_times": 1}, runner="test_batch_cpu:stub_runner", pin_gpu=False, max_retries=0)
 
 
 def test_group_equal_sizes():

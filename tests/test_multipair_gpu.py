@@ -126,8 +126,8 @@ def test_multipair_steps_bit_identical_to_single_pair_runs():
 
 @pytest.mark.parametrize("P", [2, 4])
 def test_multipair_full_size_bit_identical_and_graph_modes(P):
-    """BASELINE configs[1] shapes (224x224, ViT-B/8, T = 785): P pairs on one engine vs the single-pair runs over 3 steps
-    (graph replay on both sides from step 2 on), and the batched engine eager/serial vs graph/overlap.  P = 4 crosses every
+    """BASELINE configs[1] shapes (224x224, ViT-B/8, T = 785): P pairs on one engine vs the single-pair runs over 4 steps
+    (graph capture at the third step, replay at the fourth, on both sides), and the batched engine eager/serial vs graph/overlap.  P = 4 crosses every
     size-dependent kernel choice (128x64 GEMM tiles, 32-query attention waves, two-launch attention backward): none of
     them may change a pair's bits."""
     cfg = dict(dino_model_name="dino_vitb8", dino_global_patch_size=224)
@@ -141,7 +141,7 @@ def test_multipair_full_size_bit_identical_and_graph_modes(P):
         vit = multi.vit
         _lib.check(_lib.lib().splice_step_use_graph(multi.handle, graph))
         _lib.check(_lib.lib().splice_step_use_overlap(multi.handle, overlap))
-        for _ in range(3):
+        for _ in range(4):
             multi.step(A, B, A)
         torch.cuda.synchronize()
         if ref is None:
@@ -152,7 +152,7 @@ def test_multipair_full_size_bit_identical_and_graph_modes(P):
     del multi
     for p in (0, P - 1):
         single = SpliceEngine(cfg, None, gens[p], (224, 224), (224, 224), vit_engine=vit)
-        for _ in range(3):
+        for _ in range(4):
             single.step(A[p], B[p], A[p])
         torch.cuda.synchronize()
         assert torch.equal(single.losses_dev[0], ref[1][p]), (p, single.losses_dev[0], ref[1][p])

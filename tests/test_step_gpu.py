@@ -304,7 +304,7 @@ def test_full_size_step_vs_oracle_and_replay_modes():
     of bench.py runs (global ssim + cls + id, two N=1 generator plans, split-K dgrads, id-loss seeds at T = 785).  Every
     loss term within 3e-2, whole-arena generator gradient within 5e-2 rel-L2 (bf16 ViT; synthetic N(0, 0.03) weights -- a
     trained checkpoint has outlier channels, see test_outlier_weights_step_vs_oracle).  Then the size-independent property:
-    graph replay == eager single-stream launches bit for bit over 3 steps."""
+    graph replay == eager single-stream launches bit for bit over 4 steps."""
     from splice_amd import _lib
     from splice_amd.engine import SpliceEngine
     cfg = dict(dino_model_name="dino_vitb8", dino_global_patch_size=224)
@@ -321,7 +321,7 @@ def test_full_size_step_vs_oracle_and_replay_modes():
         e2 = SpliceEngine(cfg, None, gen_state, (224, 224), (224, 224), vit_engine=eng.vit)
         _lib.check(_lib.lib().splice_step_use_graph(e2.handle, graph))
         _lib.check(_lib.lib().splice_step_use_overlap(e2.handle, overlap))
-        for _ in range(3):
+        for _ in range(4):   # (a graph is captured at the third step with identical shapes and replayed at the fourth)
             e2.step(Ad, Bd, Ad)
         torch.cuda.synchronize()
         if ref is None:
@@ -384,7 +384,7 @@ def test_large_size_step_replay_modes_and_vit_parity():
         _lib.check(_lib.lib().splice_step_use_graph(eng.handle, graph))
         _lib.check(_lib.lib().splice_step_use_overlap(eng.handle, overlap))
         ls = []
-        for _ in range(3):
+        for _ in range(4):   # (graph capture at the third step, replay at the fourth)
             eng.step(Ad, Bd, None)
             ls.append(eng.losses()["loss"])
         torch.cuda.synchronize()
@@ -392,7 +392,7 @@ def test_large_size_step_replay_modes_and_vit_parity():
         if ref is None:
             ref = eng.params.clone()
             # keys of pass 2 (x' = G(A)) of the last forward vs the oracle ViT applied to the same generated image
-            x = eng.generate(Ad[None])   # parameters AFTER the 3rd update: compare on a fresh forward of both sides
+            x = eng.generate(Ad[None])   # parameters AFTER the last update: compare on a fresh forward of both sides
             ctx = vit.context(1, 448, 448, need_grad=False)
             ctx.forward(x, normalize=True)
             qkv = ctx.read(KIND_QKV_LAST_F32, 11)[0, : ctx.T].cpu()

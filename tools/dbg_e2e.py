@@ -1,14 +1,19 @@
 #!/usr/bin/env python3
 """Teardown / re-entry stress of the product entry point: N train_model runs in ONE process (a batch worker's life), optionally
 under cProfile, with faulthandler on.  E2E_STEPS (300), E2E_RUNS (6), E2E_CPROFILE (0 / 1)."""
-import os, sys, time, tempfile, faulthandler, cProfile, gc
-faulthandler.enable()
+import os, sys, time, tempfile, cProfile, gc, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from PIL import Image
 from splice_amd import synth
 from splice_amd.train import train_model
 os.environ["SPLICE_SYNTHETIC_WEIGHTS"] = "1"
+_bt = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "segv_bt.so")
+if os.path.exists(_bt):   # native backtrace of a crashing thread (tools/micro/segv_bt.c)
+    ctypes.CDLL(_bt).segv_bt_install()
+else:
+    import faulthandler
+    faulthandler.enable()
 R = int(os.environ.get("E2E_RUNS", "6"))
 N = int(os.environ.get("E2E_STEPS", "300"))
 root = tempfile.mkdtemp(); dirs = []
