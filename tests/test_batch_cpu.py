@@ -30,7 +30,7 @@ def stub_runner(pair_dir, overrides):
         marks = [f for f in os.listdir(pair_dir) if f.startswith("crashed")]
         if len(marks) < overrides.get("segv_times", 1):
             open(os.path.join(pair_dir, f"crashed{len(marks)}"), "w").close()
-            os.kill(os.getpid(), signal.SIGSEGV)
+            os.kill(os.getpid(), signal.SIGKILL)   # (SIGKILL: dies by a signal like a SIGSEGV, without a core file)
     t0 = time.time()
     time.sleep(overrides.get("sleep", {}).get(os.path.basename(pair_dir), overrides.get("sleep_default", 0.0)))
     return {"digest": h.hexdigest(), "steps": overrides.get("n_epochs", 0), "pid": os.getpid(), "t0": t0, "t1": time.time()}
@@ -130,7 +130,7 @@ def test_worker_failure_is_reported(tmp_path):
 
 
 def test_killed_worker_is_replaced_and_its_item_retried(tmp_path):
-    """A worker killed by a signal (SIGSEGV inside the runner: what a crash of the HIP runtime looks like to the parent) is replaced
+    """A worker killed by a signal (the runner kills its process: what a crash of the HIP runtime looks like to the parent) is replaced
     and the item it was running goes back to the queue -- once by default; results equal the crash-free run's.  An item that keeps
     killing its workers, and Python-level failures, still take the batch down with the pair named."""
     good, bad = tmp_path / "good", tmp_path / "bad"
@@ -145,10 +145,10 @@ def test_killed_worker_is_replaced_and_its_item_retried(tmp_path):
     again = tmp_path / "again"
     again.mkdir()
     _make_pairs(again, 3)
-    with pytest.raises(RuntimeError, match=r"exit -11\) while running \['pair01'\].*without a result: \['pair01'\]"):
+    with pytest.raises(RuntimeError, match=r"exit -9\) while running \['pair01'\].*without a result: \['pair01'\]"):
         batch.run_batch(str(again), 2, {"segv": "pair01", "segv_times": 5, "sleep_default": 0.1}, runner="test_batch_cpu:stub_runner", pin_gpu=False)
     assert len([f for f in os.listdir(again / "pair01") if f.startswith("crashed")]) == 2      # first run + one retry
-    with pytest.raises(RuntimeError, match=r"exit -11"):                                          # max_retries=0: the old behaviour
+    with pytest.raises(RuntimeError, match=r"exit -9"):                                          # max_retries=0: the old behaviour
         batch.run_batch(str(again), 1, {"segv": "pair00", "segv_times": 1}, runner="test_batch_cpu:stub_runner", pin_gpu=False, max_retries=0)
 
 
