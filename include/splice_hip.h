@@ -115,6 +115,8 @@ int splice_gemm_splitk_slabs(int M, int ksplit);
 int splice_gemm_force_tile(int tile);
 /* benchmarking hook (tools/attn_bench.py): pick an attention kernel variant, 0 = default */
 int splice_attention_variant(int variant);
+/* benchmarking hook: != 0 -> the stand-alone attention entry points take q columns pre-multiplied by scale * log2(e) */
+int splice_attention_qfold(int on);
 
 /* LayerNorm(D, eps) of the DINO blocks (eps 1e-6), fp32 in -> bf16 out, and its dgrad
  * accumulated into the fp32 residual-gradient stream: g_out = g_in + dLN(dy). */
@@ -191,6 +193,10 @@ int splice_resize_bilinear_bwd(const float* dout, float* din, int planes, int h,
 int splice_vit_create(int patch, int dim, int depth, int heads, void** out_handle);
 void splice_vit_destroy(void* vit);
 int splice_vit_set_param(void* vit, const char* name, const float* data, long long numel, splice_stream_t stream);
+/* The factor the stored q columns of every layer's qkv carry (round 5: d^-1/2 * log2(e); 1 when SPLICE_VIT_QFOLD=0).  splice_vit_read_tensor
+ * kinds 1 and 3 divide it out of the copy; kind 7 (= kind 1 as stored) and the zero-copy splice_vit_get_tensor pointers do not -- attention entry
+ * points fed with stored q take scale = ln 2 instead of d^-1/2. */
+float splice_vit_qscale(void* vit);
 int splice_vit_params_complete(void* vit);
 /* BASELINE configs[4] fp8 path: prepares e4m3 copies of the QKV / fc1 / fc2 weights (per-output-channel scales).  A context
  * opts in with splice_vit_ctx_set_fp8: its three big forward projections then run on the fp8 MFMA (e4m3 LayerNorm outputs with

@@ -63,6 +63,7 @@ _SIGNATURES = {
     "splice_gemm_splitk_slabs": ([_i, _i], _i),
     "splice_gemm_force_tile": ([_i], _i),
     "splice_attention_variant": ([_i], _i),
+    "splice_attention_qfold": ([_i], _i),
     "splice_layernorm_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
     "splice_layernorm_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
     "splice_attention_fwd": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),
@@ -96,6 +97,7 @@ _SIGNATURES = {
     "splice_vit_forward_ex": ([_vp, _vp, _i, _i, _vp], _i),
     "splice_vit_forward_passes": ([_vp, _vp, _i, _i, _i, _i, _vp], _i),
     "splice_vit_get_tensor": ([_vp, _i, _i, C.POINTER(_vp)], _i),
+    "splice_vit_qscale": ([_vp], C.c_float),
     "splice_vit_read_tensor": ([_vp, _i, _i, _vp, _sz, _vp], _i),
     "splice_vit_backward": ([_vp, _i, _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp, _i, _vp], _i),
     # generator engine

@@ -458,6 +458,9 @@ __global__ __launch_bounds__(64 * NW * KS) void attn_fwd_kernel(AttnArgs a, int 
     }
 }
 
+#include "attn_pp.h"
+#include "attn_x32.h"
+
 // ---------------------------------------------------------------------------------------
 // e4m3 forward (BASELINE configs[4], "fp8 MFMA attention"): Q K^T and P V on v_mfma_f32_16x16x32_fp8_fp8 from the unscaled
 // e4m3 copies of q, k, v the fp8 QKV projection writes beside its bf16 outputs (e4m3 is a floating format: its relative
@@ -1042,6 +1045,30 @@ __global__ void attn_probs_kernel(AttnArgs a, float* probs) {
 // ---------------------------------------------------------------------------------------
 static int g_attn_variant = getenv("SPLICE_ATTN_FWD_VARIANT") ? atoi(getenv("SPLICE_ATTN_FWD_VARIANT")) : 0;   // benchmarking hook (splice_attention_variant): forward queries per wave 16*v, 0 = automatic
 void attn_set_variant(int v) { g_attn_variant = v; }
+static int g_attn_qfold = 0;
+void attn_set_qfold(int on) { g_attn_qfold = on; }
+int attn_qfold_hook() { return g_attn_qfold; }
+
+template <int NW, bool FOLD>
+static void attn_fwd_x32_go(const AttnArgs* a, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_x32_kernel<NW, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, X32<NW>::LDS_BYTES);
+        attr_done = true;
+    }
+    const int nx = cdiv(a->Tld, 32 * NW);
+    SPLICE_LAUNCH((attn_fwd_x32_kernel<NW, FOLD>), dim3(nx * a->H * a->B), dim3(64 * NW), X32<NW>::LDS_BYTES, s, *a, nx);
+}
+template <int QB, bool FOLD>
+static void attn_fwd_pp_go(const AttnArgs* a, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<QB, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+        attr_done = true;
+    }
+    const int nx = cdiv(a->Tld, 64 * QB);
+    SPLICE_LAUNCH((attn_fwd_pp_kernel<QB, FOLD>), dim3(nx * a->H * a->B), dim3(512), PP_LDS_BYTES, s, *a, nx);
+}
 
 int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
     if (a->Tld % 32 || a->D % 64 || a->D / 64 != a->H) return SPLICE_ERR_ARG;
@@ -1050,6 +1077,25 @@ int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
     // size -- 13.4 / 31.6 / 60.9 us against 15.8 / 34.2 / 66.2 for one group walking both halves -- except where its 8-wave,
     // 64 KB workgroups just miss one round of the chip.  All forms, and 32 queries per wave (very long batches), produce
     // the same bits, so the choice is free.  variant (benchmarking hook / SPLICE_ATTN_FWD_VARIANT): queries per wave / 16 + 10 * (wave groups - 1); 0 = automatic.
+    // round 5: the 32x32x16 form (attn_x32.h); variants 41 / 42 / 48 = 4 / 2 / 8 waves per workgroup
+    // Default since round 5 for the bf16 forward: four waves (128 queries) per workgroup; every form of this kernel gives a query the same
+    // bits (its arithmetic does not depend on the wave count), so a pass's output does not depend on how many passes share the launch.
+    // SPLICE_ATTN_X32=0 restores the 16x16x32 forms below (variants 1 .. 22).
+    static const int x32_mode = getenv("SPLICE_ATTN_X32") ? atoi(getenv("SPLICE_ATTN_X32")) : 4;
+    if (!a->qkv8 && (g_attn_variant / 10 == 4 || (!g_attn_variant && x32_mode))) {
+        const int nwv = g_attn_variant ? g_attn_variant % 10 : x32_mode;
+        if (a->qfold) { if (nwv == 2) attn_fwd_x32_go<2, true>(a, s); else if (nwv == 8) attn_fwd_x32_go<8, true>(a, s); else attn_fwd_x32_go<4, true>(a, s); }
+        else { if (nwv == 2) attn_fwd_x32_go<2, false>(a, s); else if (nwv == 8) attn_fwd_x32_go<8, false>(a, s); else attn_fwd_x32_go<4, false>(a, s); }
+        return SPLICE_OK;
+    }
+    // round 5: the ping-pong form (attn_pp.h); variants 31 / 32 = 16 / 32 queries per wave
+    static const int pp_mode = getenv("SPLICE_ATTN_PP") ? atoi(getenv("SPLICE_ATTN_PP")) : 0;
+    if (!a->qkv8 && (g_attn_variant / 10 == 3 || (!g_attn_variant && pp_mode))) {
+        const int qbp = g_attn_variant ? g_attn_variant % 10 : pp_mode;
+        if (a->qfold) { if (qbp == 2) attn_fwd_pp_go<2, true>(a, s); else attn_fwd_pp_go<1, true>(a, s); }
+        else { if (qbp == 2) attn_fwd_pp_go<2, false>(a, s); else attn_fwd_pp_go<1, false>(a, s); }
+        return SPLICE_OK;
+    }
     const long tasks = (long)a->B * a->H * cdiv(a->Tld, 16);
     static const long qb2_tasks = getenv("SPLICE_ATTN_QB2_TASKS") ? atol(getenv("SPLICE_ATTN_QB2_TASKS")) : 60000;
     const int qb = g_attn_variant ? g_attn_variant % 10 : (tasks > qb2_tasks ? 2 : 1);

@@ -61,6 +61,7 @@ int splice_gemm_splitk_slabs(int M, int ksplit) { return gemm_splitk_slabs(M, ks
 /* benchmarking hook: force the GEMM tile (0 auto, 1 128x128, 2 128x64, 3 64x64) */
 int splice_gemm_force_tile(int tile) { gemm_force_tile(tile); return SPLICE_OK; }
 int splice_attention_variant(int variant) { attn_set_variant(variant); return SPLICE_OK; }
+int splice_attention_qfold(int on) { attn_set_qfold(on); return SPLICE_OK; }
 
 int splice_layernorm_fwd(const float* x, const float* gamma, const float* beta, splice_bf16* y, float* mean, float* rstd,
                          int rows, int D, float eps, splice_stream_t stream) {
@@ -75,7 +76,7 @@ int splice_attention_fwd(const splice_bf16* qkv, const splice_bf16* qkvT, int ld
                          float scale, splice_bf16* out, float* lse, splice_stream_t stream) {
     AttnArgs a = {};
     a.qkv = qkv; a.qkvT = qkvT; a.ldt = ldt; a.B = B; a.T = T; a.Tld = Tld; a.D = D; a.H = H; a.scale = scale;
-    a.out = out; a.lse = lse;
+    a.out = out; a.lse = lse; a.qfold = attn_qfold_hook();
     return finish(attn_fwd_launch(&a, ST(stream)), "splice_attention_fwd");
 }
 int splice_attention_fwd_fp8(const uint8_t* qkv8, const uint8_t* qkvT8, int ldt8, int B, int T, int Tld, int D, int H, float scale,

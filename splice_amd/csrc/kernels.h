@@ -23,11 +23,14 @@ struct AttnArgs {
     const uint8_t* qkv8;   // [B*Tld][3D]
     const uint8_t* qkvT8;  // [3D][ldt8]
     int ldt8;
+    int qfold;             // != 0: the q columns of qkv hold q * scale * log2(e) (the ViT engine's packing of the QKV projection); scores are exponents as they leave the MFMA
 };
 int attn_fwd_launch(const AttnArgs* a, hipStream_t s);
 int attn_bwd_launch(const AttnArgs* a, hipStream_t s);
 int attn_probs_launch(const AttnArgs* a, float* probs, hipStream_t s);
 void attn_set_variant(int v);   // benchmarking hook
+int attn_qfold_hook();
+void attn_set_qfold(int on);    // benchmarking hook: the stand-alone entry points take pre-scaled q
 
 // ---- vit_cls.hip: the tail of the top block on the [CLS] rows only ---------------------------
 int attn_cls_fwd_launch(const bf16_t* qkv, const bf16_t* qkvT, int ldt, int B, int T, int Tld, int D, int H, float scale, bf16_t* out, float* probs,

@@ -61,7 +61,15 @@ struct SpliceVit {
     std::vector<void*> allocs;
     int n_set = 0;
     int fp8 = 0;            // e4m3 copies of the qkv / fc1 / fc2 weights exist (splice_vit_enable_fp8); contexts opt in (splice_vit_ctx_set_fp8)
+    // q folding (round 5): the q rows of every QKV projection (weight rows and bias entries [0, dim)) are packed pre-multiplied by
+    // d^-1/2 * log2(e), so the stored q IS the base-2 softmax exponent's left factor: the attention kernels skip the scale-and-shift
+    // FMA per score (attn_x32.h) and every kernel that takes "scale" gets ln 2 instead of d^-1/2 (scale * q.k == ln2 * q'.k).
+    // The dgrad uses the same packed weights, so the attention backward hands it dL/dq' (the same formulas with ln 2 for the scale).
+    // What leaves the engine is unscaled again: splice_vit_read_tensor divides the q columns, gradient seeds for qkv are divided on the way in.
+    int qfold = 1;
+    float qscale = 1.0f;    // 0.125 * log2(e) when folding
 };
+static const float kLn2 = 0.6931471805599453f, kLog2e = 1.4426950408889634f;
 
 struct SpliceVitCtx {
     SpliceVit* vit = nullptr;
@@ -121,6 +129,21 @@ static int pack_linear(SpliceVit* v, Linear& L, const float* w, int out, int in,
     RC(transpose_f32_to_bf16_launch(w, L.wT, out, in, out, s));  // wT[in][out]
     return SPLICE_OK;
 }
+__global__ void scale_f32_kernel(float* dst, const float* src, size_t n, size_t n_scaled, float f) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = i < n_scaled ? src[i] * f : src[i];
+}
+// the QKV projection with its q rows scaled (SpliceVit::qfold): fp32 product first, ONE rounding to bf16
+static int pack_qkv(SpliceVit* v, Linear& L, const float* w, int D, hipStream_t s) {
+    if (!v->qfold) return pack_linear(v, L, w, 3 * D, D, s);
+    float* tmp = nullptr;
+    const size_t n = (size_t)3 * D * D;
+    HIPCHK(hipMalloc((void**)&tmp, n * sizeof(float)));
+    hipLaunchKernelGGL(scale_f32_kernel, dim3(1024), dim3(256), 0, s, tmp, w, n, (size_t)D * D, v->qscale);
+    const int rc = pack_linear(v, L, tmp, 3 * D, D, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    return rc;
+}
 static int copy_vec(SpliceVit* v, float** dst, const float* src, size_t n, hipStream_t s) {
     RC(dev_alloc(v->allocs, dst, n));
     HIPCHK(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -128,12 +151,14 @@ static int copy_vec(SpliceVit* v, float** dst, const float* src, size_t n, hipSt
 }
 
 // add fp32 src[rows][lds] (cols columns) into bf16 dst[rows][ldd] columns [col0, col0+cols)
-__global__ void add_f32_into_bf16_kernel(bf16_t* dst, int ldd, int col0, const float* src, int lds, int rows, int cols) {
+// (the first qcols source columns are multiplied by qf: gradient seeds for q arrive as dL/dq, the engine carries dL/dq')
+__global__ void add_f32_into_bf16_kernel(bf16_t* dst, int ldd, int col0, const float* src, int lds, int rows, int cols, int qcols, float qf) {
     const size_t n = (size_t)rows * cols;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int r = i / cols, c = i % cols;
         bf16_t* p = dst + (size_t)r * ldd + col0 + c;
-        *p = f2bf(bf2f(*p) + src[(size_t)r * lds + c]);
+        const float v = src[(size_t)r * lds + c];
+        *p = f2bf(bf2f(*p) + (c < qcols ? v * qf : v));
     }
 }
 // g (+)= add ; g_bf = bf16(g).  add may be null (then just refresh g_bf); init: g = add (or 0).
@@ -144,6 +169,17 @@ __global__ void grad_stream_kernel(float* g, bf16_t* g_bf, const float* add, siz
         g[i] = v;
         g_bf[i] = f2bf(v);
     }
+}
+__global__ void scale_cols_bf16_kernel(bf16_t* x, int ld, int rows, int cols, float f) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        bf16_t* p = x + (i / cols) * ld + i % cols;
+        *p = f2bf(bf2f(*p) * f);
+    }
+}
+__global__ void scale_cols_f32_kernel(float* x, int ld, int rows, int cols, float f) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[(i / cols) * ld + i % cols] *= f;
 }
 static inline unsigned grid_n(size_t n) { size_t b = (n + 255) / 256; return (unsigned)(b > 2048 ? 2048 : (b ? b : 1)); }
 
@@ -156,6 +192,8 @@ int splice_vit_create(int patch, int dim, int depth, int heads, void** out) {
     }
     SpliceVit* v = new SpliceVit();
     v->patch = patch; v->dim = dim; v->depth = depth; v->heads = heads; v->hidden = 4 * dim;
+    v->qfold = getenv("SPLICE_VIT_QFOLD") ? atoi(getenv("SPLICE_VIT_QFOLD")) : 1;   // (0: the round-4 packing, for A/B runs)
+    v->qscale = v->qfold ? 0.125f * kLog2e : 1.0f;
     (void)hipGetDevice(&v->device);
     v->layers.resize(depth);
     *out = v;
@@ -201,8 +239,8 @@ int splice_vit_set_param(void* h, const char* name, const float* data, long long
         else if (r == "norm1.bias") { if (!expect(D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &L.ln1_b, data, D, s)); }
         else if (r == "norm2.weight") { if (!expect(D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &L.ln2_g, data, D, s)); }
         else if (r == "norm2.bias") { if (!expect(D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &L.ln2_b, data, D, s)); }
-        else if (r == "attn.qkv.weight") { if (!expect(3LL * D * D)) return SPLICE_ERR_ARG; RC(pack_linear(v, L.qkv, data, 3 * D, D, s)); }
-        else if (r == "attn.qkv.bias") { if (!expect(3 * D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &L.qkv.b, data, 3 * D, s)); }
+        else if (r == "attn.qkv.weight") { if (!expect(3LL * D * D)) return SPLICE_ERR_ARG; RC(pack_qkv(v, L.qkv, data, D, s)); }
+        else if (r == "attn.qkv.bias") { if (!expect(3 * D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &L.qkv.b, data, 3 * D, s)); if (v->qfold) hipLaunchKernelGGL(scale_f32_kernel, dim3(8), dim3(256), 0, s, L.qkv.b, L.qkv.b, (size_t)3 * D, (size_t)D, v->qscale); }
         else if (r == "attn.proj.weight") { if (!expect((long long)D * D)) return SPLICE_ERR_ARG; RC(pack_linear(v, L.proj, data, D, D, s)); }
         else if (r == "attn.proj.bias") { if (!expect(D)) return SPLICE_ERR_ARG; RC(copy_vec(v, &L.proj.b, data, D, s)); }
         else if (r == "mlp.fc1.weight") { if (!expect((long long)Hd * D)) return SPLICE_ERR_ARG; RC(pack_linear(v, L.fc1, data, Hd, D, s)); }
@@ -234,6 +272,10 @@ int splice_vit_enable_fp8(void* h, splice_stream_t stream) {
     v->fp8 = 1;
     return SPLICE_OK;
 }
+
+/* The factor the stored q columns carry (d^-1/2 log2(e), or 1 when SPLICE_VIT_QFOLD=0): splice_vit_read_tensor kinds 1 / 3 divide it out,
+ * kind 7 and the zero-copy splice_vit_get_tensor pointers do not; attention entry points fed with stored q take scale = ln 2. */
+float splice_vit_qscale(void* h) { return h ? ((SpliceVit*)h)->qscale : 1.0f; }
 
 int splice_vit_params_complete(void* h) {
     SpliceVit* v = (SpliceVit*)h;
@@ -451,7 +493,7 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
             bf16_t* cattn = c->cls_attn + (size_t)pass_begin * D;
             bf16_t* cln = c->cls_ln + (size_t)pass_begin * D;
             bf16_t* ch = c->cls_h + (size_t)pass_begin * Hd;
-            RC(attn_cls_fwd_launch(c->qkv[l] + r0 * 3 * D, c->qkvT_last + r0, c->rows, Bp, c->T, c->Tld, D, v->heads, 0.125f, cattn,
+            RC(attn_cls_fwd_launch(c->qkv[l] + r0 * 3 * D, c->qkvT_last + r0, c->rows, Bp, c->T, c->Tld, D, v->heads, v->qfold ? kLn2 : 0.125f, cattn,
                                    c->cls_probs + (size_t)pass_begin * v->heads * c->Tld, s));
             // The GEMMs of this tail have M = passes rows: their run time is the serial K walk of a workgroup, not the rows, so
             // they run split-K over many workgroups (plain fp32 slabs) and the next kernel of the chain sums the slabs.
@@ -485,7 +527,7 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
         {
             AttnArgs a = {};
             a.qkv = c->qkv[l] + r0 * 3 * D; a.B = Bp; a.T = c->T; a.Tld = c->Tld; a.D = D; a.H = v->heads;
-            a.scale = 0.125f; a.out = c->attn_out[l] + r0 * D; a.lse = c->lse[l] + (size_t)pass_begin * v->heads * c->Tld;
+            a.scale = v->qfold ? kLn2 : 0.125f; a.qfold = v->qfold; a.out = c->attn_out[l] + r0 * D; a.lse = c->lse[l] + (size_t)pass_begin * v->heads * c->Tld;
             if (fp8_attn) { a.qkv8 = c->qkv8 + r0 * 3 * D; a.qkvT8 = c->qkvT8 + r0; a.ldt8 = c->rows; }
             SpliceProfScope ps(3);
             RC(attn_fwd_launch(&a, s));
@@ -549,6 +591,7 @@ int splice_vit_get_tensor(void* ctx, int kind, int layer, void** out) {
         case 4: *out = c->lse[layer]; break;
         case 5: *out = c->xs[0]; break;
         case 6: if (layer != c->vit->depth - 1) return SPLICE_ERR_ARG; *out = c->qkvT_last; break;   // only the last layer keeps a transposed copy
+        case 7: *out = c->qkv[layer]; break;   // as kind 1; splice_vit_read_tensor copies it AS STORED (q columns pre-scaled by splice_vit_qscale)
         default: return SPLICE_ERR_ARG;
     }
     return SPLICE_OK;
@@ -559,6 +602,13 @@ int splice_vit_read_tensor(void* ctx, int kind, int layer, void* dst, size_t byt
     void* src = nullptr;
     RC(splice_vit_get_tensor(ctx, kind, layer, &src));
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    SpliceVitCtx* c = (SpliceVitCtx*)ctx;
+    if (c->vit->qfold && (kind == 1 || kind == 3)) {   // the caller sees q, not q * d^-1/2 log2(e)
+        const int D = c->vit->dim;
+        const size_t rows = bytes / ((size_t)3 * D * (kind == 1 ? 2 : 4));
+        if (kind == 1) hipLaunchKernelGGL(scale_cols_bf16_kernel, dim3(grid_n(rows * D)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dst, 3 * D, (int)rows, D, 1.0f / c->vit->qscale);
+        else hipLaunchKernelGGL(scale_cols_f32_kernel, dim3(grid_n(rows * D)), dim3(256), 0, (hipStream_t)stream, (float*)dst, 3 * D, (int)rows, D, 1.0f / c->vit->qscale);
+    }
     return SPLICE_OK;
 }
 
@@ -627,7 +677,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
                 GemmEpi e = {};
                 e.out_f32 = slabs; e.ldo = D; e.ksplit = ks_of(D); e.slab_stride = (long long)sstr;
                 RC(gemm_nt_launch(EPI_OUT_F32, g_bf, rs, W.proj.wT, D, Bp, D, D, e, s));
-                RC(attn_cls_bwd_launch(c->qkv[l] + r0 * 3 * D, c->qkvT_last + r0, c->rows, Bp, c->T, c->Tld, D, v->heads, 0.125f,
+                RC(attn_cls_bwd_launch(c->qkv[l] + r0 * 3 * D, c->qkvT_last + r0, c->rows, Bp, c->T, c->Tld, D, v->heads, v->qfold ? kLn2 : 0.125f,
                                        c->cls_probs + (size_t)pass_begin * v->heads * c->Tld, slabs, e.ksplit, sstr, dqkv, s));
             }
             g_after_mlp = g;
@@ -657,7 +707,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
             {
                 AttnArgs a = {};
                 a.qkv = c->qkv[l] + r0 * 3 * D; a.B = Bp; a.T = c->T; a.Tld = c->Tld;
-                a.D = D; a.H = v->heads; a.scale = 0.125f; a.out = c->attn_out[l] + r0 * D;
+                a.D = D; a.H = v->heads; a.scale = v->qfold ? kLn2 : 0.125f; a.qfold = v->qfold; a.out = c->attn_out[l] + r0 * D;
                 a.lse = c->lse[l] + (size_t)pass_begin * v->heads * c->Tld;
                 a.dout = c->dout + r0 * D; a.doutT = nullptr; a.delta = c->delta + (size_t)pass_begin * v->heads * c->Tld; a.delta_ready = 1; a.dqkv = dqkv;
                 SpliceProfScope ps(6);
@@ -667,8 +717,8 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
         } else {
             RC(dev_zero_launch(dqkv, (size_t)R * 3 * D * sizeof(bf16_t), s));
         }
-        if (dq) SPLICE_LAUNCH(add_f32_into_bf16_kernel, dim3(grid_n((size_t)R * 3 * D)), dim3(256), 0, s, dqkv, 3 * D, 0, dq + r0 * 3 * D, 3 * D, R, 3 * D);
-        if (dk) SPLICE_LAUNCH(add_f32_into_bf16_kernel, dim3(grid_n((size_t)R * D)), dim3(256), 0, s, dqkv, 3 * D, D, dk + r0 * D, D, R, D);
+        if (dq) SPLICE_LAUNCH(add_f32_into_bf16_kernel, dim3(grid_n((size_t)R * 3 * D)), dim3(256), 0, s, dqkv, 3 * D, 0, dq + r0 * 3 * D, 3 * D, R, 3 * D, v->qfold ? D : 0, 1.0f / v->qscale);
+        if (dk) SPLICE_LAUNCH(add_f32_into_bf16_kernel, dim3(grid_n((size_t)R * D)), dim3(256), 0, s, dqkv, 3 * D, D, dk + r0 * D, D, R, D, 0, 1.0f);
         {
             GemmEpi e = {};
             e.out_f32 = c->dln + r0 * D; e.ldo = D; e.ksplit = ks; e.slab_stride = (long long)slab;

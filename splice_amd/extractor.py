@@ -20,7 +20,7 @@ import os
 import torch
 
 from . import _lib, synth
-from .vit import KIND_BLOCK, KIND_LSE, KIND_QKV, KIND_QKV_LAST_F32, VitContext, VitEngine
+from .vit import KIND_BLOCK, KIND_LSE, KIND_QKV, KIND_QKV_LAST_F32, KIND_QKV_STORED, VitContext, VitEngine
 
 
 class _CosineSim(torch.autograd.Function):
@@ -130,9 +130,9 @@ class _VitProbs(torch.autograd.Function):
         L = _lib.lib()
         probs = torch.empty(eng.depth, eng.heads, T, T, device=img.device)
         for l in range(eng.depth):
-            qkv = vctx.read(KIND_QKV, l)
+            qkv = vctx.read(KIND_QKV_STORED, l)   # (the q the forward used, bit for bit: the rows must sum to one against ITS log-sum-exp)
             lse = vctx.read(KIND_LSE, l)
-            _lib.check(L.splice_attention_probs(_lib.ptr(qkv), 1, T, vctx.Tld, eng.dim, eng.heads, 0.125, _lib.ptr(lse),
+            _lib.check(L.splice_attention_probs(_lib.ptr(qkv), 1, T, vctx.Tld, eng.dim, eng.heads, eng.attn_scale, _lib.ptr(lse),
                                                 _lib.ptr(probs[l]), _lib.current_stream()), "attention_probs")
         ctx.vctx, ctx.extractor, ctx.need_grad, ctx.generation = vctx, extractor, need_grad, vctx.generation
         if not need_grad:   # (with grad: nothing is saved -- the backward re-forms the matrices it needs from the resident q, k, lse)
@@ -156,11 +156,12 @@ class _VitProbs(torch.autograd.Function):
                 continue
             dP = d_probs[l]
             P = torch.empty(H, T, T, device=dP.device)                           # re-formed, not saved by the forward ([L, heads, T, T] is 355 MB at T = 785)
-            _lib.check(L.splice_attention_probs(_lib.ptr(vctx.read(KIND_QKV, l)), 1, T, Tld, D, H, 0.125, _lib.ptr(vctx.read(KIND_LSE, l)),
+            stored = vctx.read(KIND_QKV_STORED, l)
+            _lib.check(L.splice_attention_probs(_lib.ptr(stored), 1, T, Tld, D, H, eng.attn_scale, _lib.ptr(vctx.read(KIND_LSE, l)),
                                                 _lib.ptr(P), _lib.current_stream()), "attention_probs")
             dS = P * (dP - (dP * P).sum(-1, keepdim=True))                       # [H, T, T]
-            qkv = vctx.read(KIND_QKV, l)[0, :T].float().reshape(T, 3, H, d)
-            q, k = qkv[:, 0].transpose(0, 1), qkv[:, 1].transpose(0, 1)          # [H, T, d]
+            qkv = stored[0, :T].float().reshape(T, 3, H, d)
+            q, k = qkv[:, 0].transpose(0, 1) / eng.qscale, qkv[:, 1].transpose(0, 1)   # [H, T, d]; seeds below are dL/dq, dL/dk (the engine rescales the q part)
             g = torch.zeros(1, Tld, 3 * D, device=dP.device)
             g[0, :T, :D] = (0.125 * torch.bmm(dS, k)).transpose(0, 1).reshape(T, D)
             g[0, :T, D:2 * D] = (0.125 * torch.bmm(dS.transpose(1, 2), q)).transpose(0, 1).reshape(T, D)

@@ -15,6 +15,7 @@ from . import _lib
 from .synth import DINO_CONFIGS
 
 KIND_BLOCK, KIND_QKV, KIND_ATTN_OUT, KIND_QKV_LAST_F32, KIND_LSE, KIND_TOKENS = 0, 1, 2, 3, 4, 5
+KIND_QKV_STORED = 7   # the layer's qkv as the engine holds it: q columns pre-multiplied by VitEngine.qscale (KIND_QKV divides it out of the copy)
 
 
 def interpolate_pos_encoding(pos_embed, patch, h_px, w_px):
@@ -92,7 +93,7 @@ class VitContext:
         D = e.dim
         if kind in (KIND_BLOCK, KIND_TOKENS):
             t = torch.empty(self.B, self.Tld, D, device=e.device)
-        elif kind == KIND_QKV:
+        elif kind in (KIND_QKV, KIND_QKV_STORED):
             t = torch.empty(self.B, self.Tld, 3 * D, device=e.device, dtype=torch.bfloat16)
         elif kind == KIND_ATTN_OUT:
             t = torch.empty(self.B, self.Tld, D, device=e.device, dtype=torch.bfloat16)
@@ -136,6 +137,9 @@ class VitEngine:
         h = C.c_void_p()
         _lib.check(_lib.lib().splice_vit_create(patch, dim, depth, heads, C.byref(h)), "vit_create")
         self.handle = h
+        # the engine stores q pre-multiplied by qscale = d^-1/2 log2(e) (1.0 with SPLICE_VIT_QFOLD=0); kernels fed with stored q take attn_scale
+        self.qscale = float(_lib.lib().splice_vit_qscale(h))
+        self.attn_scale = math.log(2.0) if self.qscale != 1.0 else (dim // heads) ** -0.5
         self.pos_embed = None
         self._ctx = {}
 

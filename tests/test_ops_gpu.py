@@ -213,6 +213,37 @@ def _attn_ref(qkv, B, T, Tld, D, H, scale):
     return o, x, p
 
 
+def test_attention_forward_score_jump_takes_the_exact_walk():
+    """The 32x32x16 forward (attn_x32.h) forms a tile's probabilities against the reference point in force and looks at the row
+    sums AFTER the tile (lazy deferred maximum).  A score that exceeds everything seen in earlier tiles by more than 2^97 inside
+    one tile overflows fp32 before that look; the kernel must notice (non-finite row sum) and recompute those queries with the
+    exact walk.  Here: one key, far into the sequence, whose score against some queries is ~18000 log2 units above the rest."""
+    B, T, D, H = 2, 785, 768, 12
+    Tld = (T + 31) // 32 * 32
+    rows = B * Tld
+    scale = (D // H) ** -0.5
+    x = _rand(rows, 3 * D, seed=77, std=1.0)
+    for (b, q, h, key) in [(0, 5, 3, 300), (1, 700, 11, 784), (1, 64, 0, 65)]:
+        x[b * Tld + q, h * 64:(h + 1) * 64] = 40.0
+        x[b * Tld + key, D + h * 64:D + (h + 1) * 64] = 40.0
+    qkv = _bf(x)
+    L = _lib.lib()
+    ref, _, _ = _attn_ref(qkv, B, T, Tld, D, H, scale)
+    for variant in (0, 42):
+        L.splice_attention_variant(variant)
+        out = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
+        lse = torch.zeros(B, H, Tld, device=DEV)
+        _lib.check(L.splice_attention_fwd(_lib.ptr(qkv), None, 0, B, T, Tld, D, H, scale, _lib.ptr(out), _lib.ptr(lse), _st()))
+        torch.cuda.synchronize()
+        L.splice_attention_variant(0)
+        got = out.float().reshape(B, Tld, D)[:, :T]
+        assert torch.isfinite(got).all() and torch.isfinite(lse[:, :, :T]).all(), variant
+        assert _relerr(got, ref.detach()) < 6e-3, (variant, _relerr(got, ref.detach()))
+        # the spiked queries attend to their key alone
+        v = qkv.float().reshape(B, Tld, 3, H, 64)
+        assert torch.allclose(got[0, 5].reshape(H, 64)[3], v[0, 300, 2, 3], atol=2e-2)
+
+
 # (1, 3137, ...) = the 448x448 sequence length of BASELINE configs[3]: 50 key tiles per query block and the
 # two-launch backward (attn_bwd_q_kernel + attn_bwd_kv_kernel), which the T <= 785 cases never reach
 @pytest.mark.parametrize("B,T,D,H,std", [(1, 17, 384, 6, 1.0), (2, 197, 768, 12, 1.0), (2, 785, 768, 12, 0.6), (1, 785, 768, 12, 2.5),
@@ -233,16 +264,25 @@ def test_attention_fwd_bwd(B, T, D, H, std):
     got = out.float().reshape(B, Tld, D)[:, :T]
     assert torch.isfinite(out.float()).all()
     assert _relerr(got, ref) < 6e-3, _relerr(got, ref)
-    # launch forms: 16 / 32 queries per wave x one / two wave groups per workgroup (the dispatcher picks by workgroup count) must
-    # agree BIT FOR BIT -- a pass's attention output may not depend on how many passes share the launch
+    # launch forms must agree BIT FOR BIT -- a pass's attention output may not depend on how many passes share the launch.  Round 5: the default
+    # is the 32x32x16 kernel (attn_x32.h; variants 41 / 42 / 48 = 4 / 2 / 8 waves per workgroup); the 16x16x32 forms (16 / 32 queries per
+    # wave x one / two wave groups x four / eight waves per K / V ring) stay selectable and agree among themselves.
     if T <= 1601:
-        for variant in (1, 2, 11, 12, 21, 22):   # 2x: eight waves (128 * x queries) on one K / V ring
+        def run(variant):
             L.splice_attention_variant(variant)
             out_v, lse_v = torch.zeros_like(out), torch.zeros_like(lse)
             _lib.check(L.splice_attention_fwd(_lib.ptr(qkv), _lib.ptr(qkvT), rows, B, T, Tld, D, H, scale, _lib.ptr(out_v), _lib.ptr(lse_v), _st()))
             torch.cuda.synchronize()
             L.splice_attention_variant(0)
+            return out_v, lse_v
+        for variant in (41, 42, 48):
+            out_v, lse_v = run(variant)
             assert torch.equal(out_v, out) and torch.equal(lse_v, lse), variant
+        out_1, lse_1 = run(1)
+        assert _relerr(out_1.float().reshape(B, Tld, D)[:, :T], ref) < 6e-3
+        for variant in (2, 11, 12, 21, 22):
+            out_v, lse_v = run(variant)
+            assert torch.equal(out_v, out_1) and torch.equal(lse_v, lse_1), variant
     # probabilities API
     probs = torch.empty(B, H, T, T, device=DEV)
     _lib.check(L.splice_attention_probs(_lib.ptr(qkv), B, T, Tld, D, H, scale, _lib.ptr(lse), _lib.ptr(probs), _st()))

@@ -10,7 +10,7 @@ if [ "$mode" = build ]; then
   mkdir -p $ROOT/build/abl
   others=$(ls $ROOT/build/csrc/*.o | grep -v attention.o)
   for m in $masks; do
-    ( /opt/rocm/bin/hipcc $FLAGS -DATTN_ABL=$m -c $ROOT/splice_amd/csrc/attention.hip -o $ROOT/build/abl/attention_$m.o &&
+    ( /opt/rocm/bin/hipcc $FLAGS -D${3:-ATTN_ABL}=$m -c $ROOT/splice_amd/csrc/attention.hip -o $ROOT/build/abl/attention_$m.o &&
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/build/abl/lib_$m.so $others $ROOT/build/abl/attention_$m.o ) &
   done
   wait; ls -la $ROOT/build/abl/*.so
@@ -23,3 +23,4 @@ else
   done
   cp /tmp/keep_abl.so $ROOT/splice_amd/libsplice_hip.so
 fi
+# round 5, the ping-pong forward (attn_pp.h):  bash tools/attn_ablate.sh build "0 1 2" PP_ABL   -- the third argument names the macro (default ATTN_ABL)

@@ -15,6 +15,7 @@ L = _lib.lib()
 DEV = "cuda"
 variants = [int(t) for t in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]
 std = float(os.environ.get("ATTN_STD", "1.0"))
+FOLD = int(os.environ.get("ATTN_FOLD", "0"))   # 1: q columns pre-multiplied by scale * log2(e) (forward only: the engine's packing of the QKV projection)
 
 
 def ref_attention(qkv, B, T, Tld, D, H, scale):
@@ -63,6 +64,10 @@ for (B, T) in shapes:
         gref = leaf.grad
     st = _lib.current_stream()
     fl_f = 4.0 * T * T * 64 * H * B
+    qkv_plain = qkv
+    if FOLD:
+        qkv = qkv.clone()
+        qkv[:, :D] = (qkv[:, :D].float() * (scale * 1.4426950408889634)).bfloat16()
     for v in variants:
         L.splice_attention_variant(v)
         out = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16)
@@ -71,10 +76,12 @@ for (B, T) in shapes:
         dqkv = torch.zeros(rows, 3 * D, device=DEV, dtype=torch.bfloat16)
 
         def fwd():
+            L.splice_attention_qfold(FOLD)
             _lib.check(L.splice_attention_fwd(_lib.ptr(qkv), _lib.ptr(qkvT), rows, B, T, Tld, D, H, scale, _lib.ptr(out), _lib.ptr(lse), st))
 
         def bwd():
-            _lib.check(L.splice_attention_bwd(_lib.ptr(qkv), _lib.ptr(qkvT), rows, B, T, Tld, D, H, scale, _lib.ptr(out), _lib.ptr(lse),
+            L.splice_attention_qfold(0)
+            _lib.check(L.splice_attention_bwd(_lib.ptr(qkv_plain), _lib.ptr(qkvT), rows, B, T, Tld, D, H, scale, _lib.ptr(out), _lib.ptr(lse),
                                               _lib.ptr(dout), _lib.ptr(doutT), _lib.ptr(delta), _lib.ptr(dqkv), st))
 
         fwd()
