@@ -117,6 +117,8 @@ int splice_gemm_force_tile(int tile);
 int splice_attention_variant(int variant);
 /* benchmarking hook: != 0 -> the stand-alone attention entry points take q columns pre-multiplied by scale * log2(e) */
 int splice_attention_qfold(int on);
+/* benchmarking hook: attention backward form, 0 automatic, 1 the 16x16x32 kernels, 2 the 32x32x16 kernels (pre-scaled q only) */
+int splice_attention_bwd_variant(int variant);
 
 /* LayerNorm(D, eps) of the DINO blocks (eps 1e-6), fp32 in -> bf16 out, and its dgrad
  * accumulated into the fp32 residual-gradient stream: g_out = g_in + dLN(dy). */

@@ -64,6 +64,7 @@ _SIGNATURES = {
     "splice_gemm_force_tile": ([_i], _i),
     "splice_attention_variant": ([_i], _i),
     "splice_attention_qfold": ([_i], _i),
+    "splice_attention_bwd_variant": ([_i], _i),
     "splice_layernorm_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp], _i),
     "splice_layernorm_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp], _i),
     "splice_attention_fwd": ([_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp], _i),

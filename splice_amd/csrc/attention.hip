@@ -460,6 +460,7 @@ __global__ __launch_bounds__(64 * NW * KS) void attn_fwd_kernel(AttnArgs a, int 
 
 #include "attn_pp.h"
 #include "attn_x32.h"
+#include "attn_bwd_x32.h"
 
 // ---------------------------------------------------------------------------------------
 // e4m3 forward (BASELINE configs[4], "fp8 MFMA attention"): Q K^T and P V on v_mfma_f32_16x16x32_fp8_fp8 from the unscaled
@@ -1141,10 +1142,41 @@ int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
     return SPLICE_OK;
 }
 
+static int g_attn_bwd_variant = getenv("SPLICE_ATTN_BWD_VARIANT") ? atoi(getenv("SPLICE_ATTN_BWD_VARIANT")) : 0;   // 1: the 16x16x32 forms, 2: the 32x32x16 forms (q pre-scaled only), 0: automatic
+void attn_set_bwd_variant(int v) { g_attn_bwd_variant = v; }
+
 int attn_bwd_launch(const AttnArgs* a, hipStream_t s) {
     if (a->Tld % 32 || a->D % 64 || a->D / 64 != a->H) return SPLICE_ERR_ARG;
     const int nx = cdiv(a->Tld, 64);
     if (!a->delta_ready) SPLICE_LAUNCH(attn_delta_kernel, dim3(cdiv(a->B * a->Tld * a->H, 256)), dim3(256), 0, s, *a);
+    if (a->qfold && g_attn_bwd_variant != 1) {   // round 5: the 32x32x16 halves (attn_bwd_x32.h); variant 2 = one launch (default), 3 = two launches
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_x32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, BX_KV_LDS);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_q_x32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, BX_Q_LDS);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_kv_x32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, BX_KV_LDS);
+            attr_done = true;
+        }
+        // small launches: two waves (64 queries / keys) per workgroup -- twice the workgroups, same bits (SPLICE_ATTN_BWD_NW2_MAX: 4-wave workgroup count up to which)
+        static const int nw2_max = getenv("SPLICE_ATTN_BWD_NW2_MAX") ? atoi(getenv("SPLICE_ATTN_BWD_NW2_MAX")) : 0;
+        if (2 * cdiv(a->Tld, 128) * a->H * a->B <= nw2_max) {
+            static bool attr2 = false;
+            if (!attr2) { (void)hipFuncSetAttribute((const void*)attn_bwd_x32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, BX_KV_LDS); attr2 = true; }
+            const int nx2 = cdiv(a->Tld, 64), n2 = nx2 * a->H * a->B;
+            SPLICE_LAUNCH((attn_bwd_x32_kernel<2>), dim3(2 * n2), dim3(128), BX_KV_LDS, s, *a, nx2);
+            return SPLICE_OK;
+        }
+        const int nx4 = cdiv(a->Tld, 128), n4 = nx4 * a->H * a->B;
+        // both forms run the same bodies (same bits): one launch while the chip is not full anyway (a dependent launch costs more than the mix of
+        // the two halves' durations), two once every CU holds several workgroups (T = 3137, 4 passes: 426 against 445 us; 2 passes of T = 785: 37.9
+        // against 32.7 us; profiles/r05_attn_bwd_x32.txt)
+        static const int merge_max4 = getenv("SPLICE_ATTN_BWD_MERGE_MAX") ? atoi(getenv("SPLICE_ATTN_BWD_MERGE_MAX")) : 1024;
+        if (g_attn_bwd_variant == 3 || (g_attn_bwd_variant != 2 && 2 * n4 > merge_max4)) {
+            SPLICE_LAUNCH((attn_bwd_q_x32_kernel<4>), dim3(n4), dim3(256), BX_Q_LDS, s, *a, nx4);
+            SPLICE_LAUNCH((attn_bwd_kv_x32_kernel<4>), dim3(n4), dim3(256), BX_KV_LDS, s, *a, nx4);
+        } else SPLICE_LAUNCH((attn_bwd_x32_kernel<4>), dim3(2 * n4), dim3(256), BX_KV_LDS, s, *a, nx4);
+        return SPLICE_OK;
+    }
     const int n = nx * a->H * a->B;
     // the two halves in one launch while the chip is not full anyway (a dependent launch costs more than the dQ half's
     // lower occupancy under the dK/dV half's LDS footprint); two launches once every CU has several workgroups

@@ -1,0 +1,448 @@
+// Attention backward on the 32x32x16 MFMA (round 5; included by attention.hip after attn_x32.h, same recipe as the forward:
+// half the MFMA instructions of the 16x16x32 forms, the softmax constants folded into MFMA accumulator seeds, every MFMA followed by
+// its share of the VALU work and LDS fragment reads of the SAME wave, LDS-DMA rings fed tiles ahead with counted waits).
+//
+// The two halves stay separate kernels (dQ: a wave owns 32 queries and walks the keys; dK/dV: a wave owns 32 keys and walks the
+// queries), each recomputing S and dP: the deterministic alternative to dQ atomics.
+//
+//   dQ half, per 32-key block:   S^T[key][q] = K q^T - lse_q      4 MFMAs  A = K rows (ds_read_b128), B = q (registers), C = -lse (constant)
+//                                dP^T[key][q] = V dO^T - delta_q  4 MFMAs  A = V rows,                B = dO (registers), C = -delta (constant)
+//                                p = exp2(S^T), dS = p * dP^T     16 v_exp + 16 v_mul + 8 v_cvt_pk per lane
+//                                dQ^T[d][q] += K^T[d][key] dS     4 MFMAs  A = K^T (two ds_read_b64_tr_b16 out of the K tile), B = packed dS
+//     a rolling two-stage pipeline over the blocks: the S / dP MFMAs of block j+1 run under the VALU work of block j.
+//   dK/dV half, per 32-query block: S[q][key] = Q k^T - lse[q]    4 MFMAs  A = Q rows, B = k (registers), C = -lse of the block's rows (4 ds_read_b128)
+//                                dP[q][key] = dO v^T - delta[q]   4 MFMAs  A = dO rows, B = v (registers), C = -delta rows
+//                                P = exp2(S), dS = P * dP
+//                                dV^T[d][key] += dO^T[d][q] P     4 MFMAs  A = dO^T (transposing reads), B = packed P
+//                                dK^T[d][key] += Q^T[d][q] dS     4 MFMAs  A = Q^T, B = packed dS
+//
+// Token tiles [64 rows][64 d] with ONE swizzle for both read forms: 16-byte chunk c of row r at c ^ swz(r),
+// swz(r) = (r bit 1) << 2 | (r bit 3) << 1 | (r bit 2): conflict-free for the b128 lane groups (32 consecutive rows at one chunk) and for
+// the transposing reads (4 rows x 64 B per half wave).
+#pragma once
+
+constexpr int BX_SLOTS = 4;
+constexpr int BX_Q_LDS = BX_SLOTS * 2 * 8192;                 // dQ half: K | V per slot
+constexpr int BX_KV_LDS = BX_SLOTS * (2 * 8192 + 512);        // dK/dV half: Q | dO | 64 lse + 64 delta floats per slot
+#ifndef BX_ABL
+#define BX_ABL 0
+#endif
+
+__device__ __forceinline__ int bx_swz(int row) { return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1); }
+
+// per-lane fragment addresses (bf16 element offsets inside a tile)
+struct BxFrag {
+    int rowa[4];      // row read (b128): row q32 (+ 32 blk), chunk 2 ks + hi            -> rowa[ks] + blk * 2048
+    int tra[2][2];    // transposing read: d block db, second read (rows + 8)            -> tra[db][sec] + blk * 2048 + kk * 1024
+    __device__ __forceinline__ BxFrag(int lane) {
+        const int q32 = lane & 31, hi = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) rowa[ks] = q32 * 64 + (((2 * ks + hi) ^ bx_swz(q32)) << 3);
+        const int m = lane & 15, dg = (lane >> 4) & 1;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int sec = 0; sec < 2; ++sec) {
+                const int row = 8 * sec + 4 * hi + (m >> 2);
+                tra[db][sec] = row * 64 + (((4 * db + 2 * dg + ((m >> 1) & 1)) ^ bx_swz(row)) << 3) + (m & 1) * 4;
+            }
+    }
+};
+__device__ __forceinline__ u32x4 bx_tr(const bf16_t* tile, const BxFrag& f, int db, int off) {   // one 32 x 16 transposed operand
+    typedef __attribute__((address_space(3))) tr_v4s lds_v4s;
+    const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(tile + f.tra[db][0] + off));
+    const tr_v4s hh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(tile + f.tra[db][1] + off));
+    const uint2 x = __builtin_bit_cast(uint2, lo), y = __builtin_bit_cast(uint2, hh);
+    return u32x4{x.x, x.y, y.x, y.y};
+}
+// seeded first MFMA of a chain: D = A B + C with D a fresh register block (the builtin's two-address form would copy C first)
+__device__ __forceinline__ void bx_mfma_seed(f32x16_t& d, const u32x4& a, const u32x4& b, const f32x16_t& c) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+}
+#define BX_SB __builtin_amdgcn_sched_barrier(0)
+
+// LDS-DMA of one [64 rows][64 d] token tile by NW waves (pieces wave + NW i), swizzled on the source side
+template <int NW>
+struct BxDma {
+    static constexpr int PIECES = 8 / NW;
+    int wave, lr, chunk;
+    uint32_t off[PIECES];
+    __device__ __forceinline__ BxDma(int lane, int wave_, int ld, int coldelta) : wave(wave_) {
+        lr = lane >> 3;
+        const int pos = lane & 7;
+        chunk = pos ^ ((((lr >> 1) & 1) << 2) | ((wave & 1) << 1) | ((lr >> 2) & 1));   // row = 8 piece + lr: bit 1 = lr bit 1, bit 2 = lr bit 2, bit 3 = piece & 1 = wave & 1
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) off[i] = (uint32_t)((((wave + NW * i) * 8 + lr) * ld + chunk * 8 + coldelta) * 2);
+    }
+    // base = first element of row 0 of the pass (column 0 of the stream's head), ld in elements
+    __device__ __forceinline__ void tile(const bf16_t* base, int ld, int coldelta, int row0, int rows_total, uint32_t dst) const {
+        if (row0 + 64 <= rows_total) {
+            const bf16_t* tb = base + (size_t)row0 * ld;
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) pp_dma16(dst + i * (NW * 1024), off[i], tb);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                int t = row0 + (wave + NW * i) * 8 + lr;
+                t = t < rows_total ? t : rows_total - 1;
+                pp_dma16(dst + i * (NW * 1024), (uint32_t)((t * ld + chunk * 8 + coldelta) * 2), base);
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int NW, bool FOLD>
+__device__ __forceinline__ void attn_bwd_q_x32_body(const AttnArgs& a, int xb, int h, int b, bf16_t* bx_smem /* [slot][K 4096 | V 4096] */) {
+    constexpr int NL = 2 * (8 / NW);
+    const int lane = threadIdx.x & 63, q32 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ld = 3 * a.D;
+    const int qbase = xb * (32 * NW) + wave * 32;
+    const bool active = qbase < a.Tld;
+    const bf16_t* pbase = a.qkv + (size_t)b * a.Tld * ld + h * 64;
+    const int nt = (a.T + 63) / 64;
+    const BxDma<NW> dk_(lane, wave, ld, a.D), dv_(lane, wave, ld, 2 * a.D);
+    const BxFrag fr(lane);
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) bf16_t*)bx_smem + (uint32_t)wave * 1024u;
+    auto issue = [&](int tile, int slot) __attribute__((always_inline)) {
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)slot * 16384u);
+        dk_.tile(pbase, ld, a.D, tile * 64, a.Tld, dst);
+        dv_.tile(pbase, ld, 2 * a.D, tile * 64, a.Tld, dst + 8192u);
+    };
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+    if (nt > 2) issue(2, 2);
+
+    const int qidx = qbase + q32;
+    const int qc = qidx < a.Tld ? qidx : a.Tld - 1;
+    u32x4 qf[4], dof[4];
+    {
+        const bf16_t* pq = pbase + (size_t)qc * ld + hi * 8;
+        const bf16_t* pd = a.dout + ((size_t)b * a.Tld + qc) * a.D + h * 64 + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qf[ks] = ld16v(pq + ks * 16); dof[ks] = ld16v(pd + ks * 16); }
+    }
+    const float lse_q = a.lse[((size_t)b * a.H + h) * a.Tld + qc];
+    const float del_q = a.delta[((size_t)b * a.H + h) * a.Tld + qc];
+    const float c2 = a.scale * LOG2E;
+    f32x16_t negl, negd, dq[2], s[2], dp[2];
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { negl[r] = -lse_q; negd[r] = -del_q; dq[0][r] = dq[1][r] = 0.f; s[0][r] = s[1][r] = dp[0][r] = dp[1][r] = 0.f; }
+    u32x4 kf[4], vf[4];   // row fragments (A operands) of the block whose S / dP comes next
+    auto read_rows = [&](const bf16_t* K, int blk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = lds16(K + fr.rowa[ks] + blk * 2048); vf[ks] = lds16(K + 4096 + fr.rowa[ks] + blk * 2048); }
+    };
+    auto sdp = [&](f32x16_t& sx, f32x16_t& dx, int ks) __attribute__((always_inline)) {   // one k step of both chains
+        if (BX_ABL & 8) { pp_opaque(sx); pp_opaque(dx); return; }
+        if (ks == 0) {
+            if (FOLD) bx_mfma_seed(sx, kf[0], qf[0], negl); else sx = mfma32(kf[0], qf[0], zero16);
+            bx_mfma_seed(dx, vf[0], dof[0], negd);
+        } else { sx = mfma32(kf[ks], qf[ks], sx); dx = mfma32(vf[ks], dof[ks], dx); }
+    };
+    pp_wait_dma<0>();
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(dof[0]), "+v"(dof[1]), "+v"(dof[2]), "+v"(dof[3]));
+    pp_barrier();
+    if (active) {
+        read_rows(bx_smem, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) sdp(s[0], dp[0], ks);
+        read_rows(bx_smem, 1);
+    }
+    // tile t: [wait: tile t+1 landed; barrier] -> issue tile t+3 -> block 0: {S, dP of block 1 | VALU of block 0 | K^T reads of block 0} {dQ of block 0 |
+    // row reads of (t+1, 0)} -> block 1: {S, dP of (t+1, 0) | VALU of block 1 | K^T reads} {dQ of block 1 | row reads of (t+1, 1)}
+    int slot = 0;
+    auto body = [&](auto TAILC, int t) __attribute__((always_inline)) {
+        constexpr bool TAIL = decltype(TAILC)::value;
+        const int s1 = (slot + 1) & 3, s3 = (slot + 3) & 3;
+        if (!TAIL || t + 2 < nt) pp_wait_dma<NL>(); else pp_wait_dma<0>();   // (t = 0: tiles 1, 2 in flight, tile 1 is needed: allow one)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pp_barrier();
+        if (!(BX_ABL & 4) && (!TAIL || t + 3 < nt)) issue(t + 3, s3);
+        if (active) {
+            const bf16_t* Kt = bx_smem + slot * 8192;
+            const bf16_t* Kn = bx_smem + s1 * 8192;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                f32x16_t& sc = s[blk];       // scores / dP of THIS block (complete)
+                f32x16_t& dc = dp[blk];
+                f32x16_t& sn = s[blk ^ 1];   // next block's, produced under this block's VALU work
+                f32x16_t& dn = dp[blk ^ 1];
+                if (TAIL && t * 64 + 64 > a.T) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[r] = t * 64 + 32 * blk + 8 * (r >> 2) + 4 * hi + (r & 3) < a.T ? sc[r] : NEG_BIG;
+                }
+                float g[16];
+                u32x4 dsb[2], ktf[2][2];
+                auto va = [&](int r0, int n) __attribute__((always_inline)) {
+                    if (BX_ABL & 1) return;
+#pragma unroll
+                    for (int r = r0; r < r0 + n; ++r) {
+                        const float p = FOLD ? __builtin_amdgcn_exp2f(sc[r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c2, -lse_q));
+                        g[r] = p * dc[r];
+                    }
+                    asm volatile("" : "+v"(g[r0]), "+v"(g[r0 + n - 1]));
+                };
+                auto cv = [&](int kk) __attribute__((always_inline)) {
+                    if (BX_ABL & 1) { pp_opaque(dsb[kk]); return; }
+                    const float* pp = &g[kk * 8];
+                    dsb[kk] = u32x4{pack2bf(pp[0], pp[1]), pack2bf(pp[2], pp[3]), pack2bf(pp[4], pp[5]), pack2bf(pp[6], pp[7])};
+                    pp_opaque(dsb[kk]);
+                };
+                auto rt = [&](int kk, int db) __attribute__((always_inline)) {
+                    if (BX_ABL & 2) { pp_opaque(ktf[kk][db]); return; }
+                    ktf[kk][db] = bx_tr(Kt, fr, db, blk * 2048 + kk * 1024);
+                };
+                // (blk 0: the next block is (t, 1), its row fragments are in kf / vf; blk 1: the next block is (t + 1, 0))
+                BX_SB;
+                sdp(sn, dn, 0); BX_SB; va(0, 4); rt(0, 0); BX_SB;
+                sdp(sn, dn, 1); BX_SB; va(4, 4); cv(0); rt(0, 1); BX_SB;
+                sdp(sn, dn, 2); BX_SB; va(8, 4); rt(1, 0); BX_SB;
+                sdp(sn, dn, 3); BX_SB; va(12, 4); cv(1); rt(1, 1); BX_SB;
+                // dQ^T += K^T dS for this block; the row fragments of the block after next (the MFMAs above have consumed kf / vf)
+                const bf16_t* Kr = blk == 0 ? Kn : Kn;            // rows of tile t + 1: block 0 after blk 0, block 1 after blk 1
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        if (!(BX_ABL & 8)) dq[db] = mfma32(ktf[kk][db], dsb[kk], dq[db]); else pp_opaque(dq[db]);
+                        BX_SB;
+                        const int ks = kk * 2 + db;
+                        if (!(BX_ABL & 2)) { kf[ks] = lds16(Kr + fr.rowa[ks] + blk * 2048); vf[ks] = lds16(Kr + 4096 + fr.rowa[ks] + blk * 2048); }
+                        else { pp_opaque(kf[ks]); pp_opaque(vf[ks]); }
+                        BX_SB;
+                    }
+            }
+        }
+        slot = s1;
+    };
+    // NOTE on the block order inside a tile: entering tile t, s[0] / dp[0] hold block (t, 0) and kf / vf the rows of (t, 1).  blk 0 produces (t, 1) into
+    // s[1] / dp[1] and then reads the rows of (t + 1, 0); blk 1 produces (t + 1, 0) into s[0] / dp[0] and reads the rows of (t + 1, 1).
+    {
+        std::false_type MAIN; std::true_type TAILT;
+        int t = 0;
+        for (; t + 4 < nt; ++t) body(MAIN, t);
+        for (; t < nt; ++t) body(TAILT, t);
+    }
+    if (!active || qidx >= a.Tld) return;
+    bf16_t* op = a.dqkv + ((size_t)b * a.Tld + qidx) * ld + h * 64 + hi * 4;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<uint2*>(op + db * 32 + j * 8) = uint2{pack2bf(dq[db][4 * j] * a.scale, dq[db][4 * j + 1] * a.scale),
+                                                                    pack2bf(dq[db][4 * j + 2] * a.scale, dq[db][4 * j + 3] * a.scale)};
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// dK / dV half (stored q pre-scaled: AttnArgs::qfold).  Per 32-query block, sixteen MFMA slots:
+//   1-4   S chain   sx = lse[row] - Q k^T   (accumulator LOADED with the block's lse rows, B = -k: the seed costs no register block and no VALU)
+//   5-8   dP chain  dx = delta[row] - dO v^T                       | p = exp2(-sx), packed P
+//   9-12  dV^T += dO^T P                                           | g = p * dx (= -dS), packed
+//   13-16 dK^T -= Q^T (-dS)  (accumulated negated, sign fixed at the store) | row fragments + seed rows of the next block
+// Queries past T inside Tld carry dO = 0 and delta = 0: they add nothing.  Keys past T are stored as exact zeros.
+template <int NW>
+__device__ __forceinline__ void attn_bwd_kv_x32_body(const AttnArgs& a, int xb, int h, int b, bf16_t* bx_smem /* [slot][Q 4096 | dO 4096 | lse 64 floats | delta 64 floats] */) {
+    constexpr int SLOT = 2 * 4096 + 256;
+    static_assert(NW >= 2, "waves 0 and 1 move the lse / delta rows");
+    const int lane = threadIdx.x & 63, k32 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ld = 3 * a.D;
+    const int kbase = xb * (32 * NW) + wave * 32;
+    const bool active = kbase < a.Tld;
+    const bf16_t* pbase = a.qkv + (size_t)b * a.Tld * ld + h * 64;           // q columns of the pass
+    const bf16_t* dobase = a.dout + (size_t)b * a.Tld * a.D + h * 64;
+    const float* lse = a.lse + ((size_t)b * a.H + h) * a.Tld;
+    const float* dl = a.delta + ((size_t)b * a.H + h) * a.Tld;
+    const int nblk = a.Tld / 32, nt = (nblk + 1) / 2;
+    const BxDma<NW> dq_(lane, wave, ld, 0), dd_(lane, wave, a.D, 0);
+    const BxFrag fr(lane);
+    const uint32_t ldsb = (uint32_t)(size_t)(__attribute__((address_space(3))) bf16_t*)bx_smem;
+    const uint32_t lds0 = ldsb + (uint32_t)wave * 1024u;
+    auto issue = [&](int tile, int slot) __attribute__((always_inline)) {
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)slot * (SLOT * 2));
+        dq_.tile(pbase, ld, 0, tile * 64, a.Tld, dst);
+        dd_.tile(dobase, a.D, 0, tile * 64, a.Tld, dst + 8192u);
+        if (wave < 2) {   // wave 0: the tile's 64 lse values, wave 1: its 64 delta values (4 bytes per lane)
+            const int r = tile * 64 + lane;
+            const uint32_t voff = (uint32_t)((r < a.Tld ? r : a.Tld - 1) * 4);
+            const uint32_t d2 = __builtin_amdgcn_readfirstlane(ldsb + (uint32_t)slot * (SLOT * 2) + 16384u + (uint32_t)wave * 256u);
+            const float* src = wave == 0 ? lse : dl;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(d2), "v"(voff), "s"(src) : "memory");
+        }
+    };
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+    if (nt > 2) issue(2, 2);
+
+    const int kidx = kbase + k32;
+    const int kc = kidx < a.Tld ? kidx : a.Tld - 1;
+    u32x4 kn[4], vn[4];   // -k, -v as B operands: lane (key, hi) holds d = 16 ks + 8 hi .. + 7
+    {
+        const bf16_t* pk = pbase + (size_t)kc * ld + a.D + hi * 8;
+        const bf16_t* pv = pbase + (size_t)kc * ld + 2 * a.D + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kn[ks] = ld16v(pk + ks * 16); vn[ks] = ld16v(pv + ks * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { kn[ks][j] ^= 0x80008000u; vn[ks][j] ^= 0x80008000u; }
+        }
+    }
+    f32x16_t dkn[2], dv[2];   // -dK^T, dV^T blocks [d][key]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkn[0][r] = dkn[1][r] = dv[0][r] = dv[1][r] = 0.f; }
+    u32x4 qr[4], dr[4];   // Q / dO row fragments (A operands) of the block that comes next
+    f32x16_t sx, dx;      // accumulators, loaded with the seed rows of the block that comes next
+    // the 128 floats of a slot: lse of the tile's 64 queries | their delta
+    auto seeds = [&](const bf16_t* st, int blk) __attribute__((always_inline)) {
+        const float* Ls = reinterpret_cast<const float*>(st + 8192);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 lv = *reinterpret_cast<const f32x4*>(Ls + 32 * blk + 8 * j + 4 * hi);
+            const f32x4 ev = *reinterpret_cast<const f32x4*>(Ls + 64 + 32 * blk + 8 * j + 4 * hi);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sx[4 * j + i] = lv[i]; dx[4 * j + i] = ev[i]; }
+        }
+    };
+    auto rows = [&](const bf16_t* st, int blk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qr[ks] = lds16(st + fr.rowa[ks] + blk * 2048); dr[ks] = lds16(st + 4096 + fr.rowa[ks] + blk * 2048); }
+    };
+    pp_wait_dma<0>();
+    asm volatile("" : "+v"(kn[0]), "+v"(kn[1]), "+v"(kn[2]), "+v"(kn[3]), "+v"(vn[0]), "+v"(vn[1]), "+v"(vn[2]), "+v"(vn[3]));
+    pp_barrier();
+    if (active) { rows(bx_smem, 0); seeds(bx_smem, 0); }
+    int slot = 0;
+    auto body = [&](auto TAILC, int t) __attribute__((always_inline)) {
+        constexpr bool TAIL = decltype(TAILC)::value;
+        const int s1 = (slot + 1) & 3, s3 = (slot + 3) & 3;
+        // waits are counted per wave: waves 0 and 1 issue one instruction more per tile (the lse / delta rows)
+        if (!TAIL || t + 2 < nt) { if (wave < 2) pp_wait_dma<2 * (8 / NW) + 1>(); else pp_wait_dma<2 * (8 / NW)>(); } else pp_wait_dma<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        pp_barrier();
+        if (!(BX_ABL & 4) && (!TAIL || t + 3 < nt)) issue(t + 3, s3);
+        if (active) {
+            const bf16_t* st = bx_smem + slot * SLOT;
+            const bf16_t* sn = bx_smem + s1 * SLOT;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                if (TAIL && 2 * t + blk >= nblk) break;   // (the half tile past Tld: clamped duplicates)
+                u32x4 dot[2][2], qt[2][2], pb[2], gb[2];
+                float p[16], g[16];
+                // slots 1-4: S chain; the transposed fragments of this block
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (!(BX_ABL & 8)) sx = mfma32(qr[ks], kn[ks], sx); else pp_opaque(sx);
+                    BX_SB;
+                    if (!(BX_ABL & 2)) {
+                        if (ks < 2) { dot[ks][0] = bx_tr(st + 4096, fr, 0, blk * 2048 + ks * 1024); dot[ks][1] = bx_tr(st + 4096, fr, 1, blk * 2048 + ks * 1024); }
+                        else { qt[ks - 2][0] = bx_tr(st, fr, 0, blk * 2048 + (ks - 2) * 1024); qt[ks - 2][1] = bx_tr(st, fr, 1, blk * 2048 + (ks - 2) * 1024); }
+                    } else if (ks < 2) { pp_opaque(dot[ks][0]); pp_opaque(dot[ks][1]); } else { pp_opaque(qt[ks - 2][0]); pp_opaque(qt[ks - 2][1]); }
+                    BX_SB;
+                }
+                // slots 5-8: dP chain; p = exp2(-(lse - s)), packed
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (!(BX_ABL & 8)) dx = mfma32(dr[ks], vn[ks], dx); else pp_opaque(dx);
+                    BX_SB;
+                    if (!(BX_ABL & 1)) {
+#pragma unroll
+                        for (int r = 4 * ks; r < 4 * ks + 4; ++r) p[r] = __builtin_amdgcn_exp2f(-sx[r]);
+                        if (ks & 1) {
+                            const float* pp = &p[(ks >> 1) * 8];
+                            pb[ks >> 1] = u32x4{pack2bf(pp[0], pp[1]), pack2bf(pp[2], pp[3]), pack2bf(pp[4], pp[5]), pack2bf(pp[6], pp[7])};
+                            pp_opaque(pb[ks >> 1]);
+                        } else asm volatile("" : "+v"(p[4 * ks]), "+v"(p[4 * ks + 3]));
+                    } else if (ks & 1) pp_opaque(pb[ks >> 1]);
+                    BX_SB;
+                }
+                // slots 9-12: dV^T += dO^T P; g = p * (delta - dP) = -dS, packed
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    const int kk = i4 >> 1, db = i4 & 1;
+                    if (!(BX_ABL & 8)) dv[db] = mfma32(dot[kk][db], pb[kk], dv[db]); else pp_opaque(dv[db]);
+                    BX_SB;
+                    if (!(BX_ABL & 1)) {
+#pragma unroll
+                        for (int r = 4 * i4; r < 4 * i4 + 4; ++r) g[r] = p[r] * dx[r];
+                        if (i4 & 1) {
+                            const float* pp = &g[(i4 >> 1) * 8];
+                            gb[i4 >> 1] = u32x4{pack2bf(pp[0], pp[1]), pack2bf(pp[2], pp[3]), pack2bf(pp[4], pp[5]), pack2bf(pp[6], pp[7])};
+                            pp_opaque(gb[i4 >> 1]);
+                        } else asm volatile("" : "+v"(g[4 * i4]), "+v"(g[4 * i4 + 3]));
+                    } else if (i4 & 1) pp_opaque(gb[i4 >> 1]);
+                    BX_SB;
+                }
+                // slots 13-16: -dK^T += Q^T (-dS); rows + seeds of the next block (this tile's block 1, or block 0 of tile t + 1)
+                const bf16_t* nx_st = blk == 0 ? st : sn;
+                const int nx_blk = blk ^ 1;
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    const int kk = i4 >> 1, db = i4 & 1;
+                    if (!(BX_ABL & 8)) dkn[db] = mfma32(qt[kk][db], gb[kk], dkn[db]); else pp_opaque(dkn[db]);
+                    BX_SB;
+                    if (!(BX_ABL & 2)) {
+                        const float* Ls = reinterpret_cast<const float*>(nx_st + 8192);
+                        qr[i4] = lds16(nx_st + fr.rowa[i4] + nx_blk * 2048);
+                        dr[i4] = lds16(nx_st + 4096 + fr.rowa[i4] + nx_blk * 2048);
+                        const f32x4 lv = *reinterpret_cast<const f32x4*>(Ls + 32 * nx_blk + 8 * i4 + 4 * hi);
+                        const f32x4 ev = *reinterpret_cast<const f32x4*>(Ls + 64 + 32 * nx_blk + 8 * i4 + 4 * hi);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { sx[4 * i4 + i] = lv[i]; dx[4 * i4 + i] = ev[i]; }
+                    } else { pp_opaque(qr[i4]); pp_opaque(dr[i4]); pp_opaque(sx); pp_opaque(dx); }
+                    BX_SB;
+                }
+            }
+        }
+        slot = s1;
+    };
+    {
+        std::false_type MAIN; std::true_type TAILT;
+        int t = 0;
+        for (; t + 4 < nt; ++t) body(MAIN, t);
+        for (; t < nt; ++t) body(TAILT, t);
+    }
+    if (!active || kidx >= a.Tld) return;
+    const float sk = kidx < a.T ? -a.scale : 0.f, sv = kidx < a.T ? 1.0f : 0.f;
+    bf16_t* pk = a.dqkv + ((size_t)b * a.Tld + kidx) * ld + a.D + h * 64 + hi * 4;
+    bf16_t* pv = a.dqkv + ((size_t)b * a.Tld + kidx) * ld + 2 * a.D + h * 64 + hi * 4;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<uint2*>(pk + db * 32 + j * 8) = uint2{pack2bf(dkn[db][4 * j] * sk, dkn[db][4 * j + 1] * sk), pack2bf(dkn[db][4 * j + 2] * sk, dkn[db][4 * j + 3] * sk)};
+            *reinterpret_cast<uint2*>(pv + db * 32 + j * 8) = uint2{pack2bf(dv[db][4 * j] * sv, dv[db][4 * j + 1] * sv), pack2bf(dv[db][4 * j + 2] * sv, dv[db][4 * j + 3] * sv)};
+        }
+}
+#undef BX_SB
+
+// One launch for the whole backward: the halves are independent given delta, their workgroups are interleaved in one grid (even logical id = dQ
+// block, odd = dK/dV block of the same (pass, head, block) triple, neighbours on one XCD).  One form for every launch size: a pass's gradient bits
+// do not depend on how many passes share the launch.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_x32_kernel(AttnArgs a, int nx) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t bx_smem[];
+    const int n = nx * a.H * a.B;
+    const int lid = xcd_remap(blockIdx.x, 2 * n);
+    const int pair = lid >> 1;
+    const int xb = pair % nx, bh = pair / nx;
+    const int h = bh % a.H, b = bh / a.H;
+    if (lid & 1) attn_bwd_kv_x32_body<NW>(a, xb, h, b, bx_smem);
+    else attn_bwd_q_x32_body<NW, true>(a, xb, h, b, bx_smem);
+}
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_q_x32_kernel(AttnArgs a, int nx) {   // (stand-alone halves: profiling / ablation)
+    extern __shared__ __attribute__((aligned(16))) bf16_t bx_smem[];
+    int xb, h, b;
+    attn_block_coords(nx, a.H, a.B, xb, h, b);
+    attn_bwd_q_x32_body<NW, true>(a, xb, h, b, bx_smem);
+}
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_kv_x32_kernel(AttnArgs a, int nx) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t bx_smem[];
+    int xb, h, b;
+    attn_block_coords(nx, a.H, a.B, xb, h, b);
+    attn_bwd_kv_x32_body<NW>(a, xb, h, b, bx_smem);
+}

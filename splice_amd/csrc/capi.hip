@@ -62,6 +62,7 @@ int splice_gemm_splitk_slabs(int M, int ksplit) { return gemm_splitk_slabs(M, ks
 int splice_gemm_force_tile(int tile) { gemm_force_tile(tile); return SPLICE_OK; }
 int splice_attention_variant(int variant) { attn_set_variant(variant); return SPLICE_OK; }
 int splice_attention_qfold(int on) { attn_set_qfold(on); return SPLICE_OK; }
+int splice_attention_bwd_variant(int variant) { attn_set_bwd_variant(variant); return SPLICE_OK; }
 
 int splice_layernorm_fwd(const float* x, const float* gamma, const float* beta, splice_bf16* y, float* mean, float* rstd,
                          int rows, int D, float eps, splice_stream_t stream) {
@@ -93,7 +94,7 @@ int splice_attention_bwd(const splice_bf16* qkv, const splice_bf16* qkvT, int ld
     AttnArgs a = {};
     a.qkv = qkv; a.qkvT = qkvT; a.ldt = ldt; a.B = B; a.T = T; a.Tld = Tld; a.D = D; a.H = H; a.scale = scale;
     a.out = const_cast<splice_bf16*>(out); a.lse = const_cast<float*>(lse);
-    a.dout = dout; a.doutT = doutT; a.delta = delta; a.dqkv = dqkv;
+    a.dout = dout; a.doutT = doutT; a.delta = delta; a.dqkv = dqkv; a.qfold = attn_qfold_hook();
     return finish(attn_bwd_launch(&a, ST(stream)), "splice_attention_bwd");
 }
 int splice_attention_probs(const splice_bf16* qkv, int B, int T, int Tld, int D, int H, float scale, const float* lse,

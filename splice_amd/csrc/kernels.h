@@ -29,6 +29,7 @@ int attn_fwd_launch(const AttnArgs* a, hipStream_t s);
 int attn_bwd_launch(const AttnArgs* a, hipStream_t s);
 int attn_probs_launch(const AttnArgs* a, float* probs, hipStream_t s);
 void attn_set_variant(int v);   // benchmarking hook
+void attn_set_bwd_variant(int v);
 int attn_qfold_hook();
 void attn_set_qfold(int on);    // benchmarking hook: the stand-alone entry points take pre-scaled q
 

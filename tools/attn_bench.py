@@ -75,13 +75,15 @@ for (B, T) in shapes:
         delta = torch.zeros(B, H, Tld, device=DEV)
         dqkv = torch.zeros(rows, 3 * D, device=DEV, dtype=torch.bfloat16)
 
+        kscale = 0.6931471805599453 if FOLD else scale   # kernels fed with pre-scaled q take ln 2 for the scale (scale * q.k == ln2 * q'.k)
+
         def fwd():
             L.splice_attention_qfold(FOLD)
-            _lib.check(L.splice_attention_fwd(_lib.ptr(qkv), _lib.ptr(qkvT), rows, B, T, Tld, D, H, scale, _lib.ptr(out), _lib.ptr(lse), st))
+            _lib.check(L.splice_attention_fwd(_lib.ptr(qkv), _lib.ptr(qkvT), rows, B, T, Tld, D, H, kscale, _lib.ptr(out), _lib.ptr(lse), st))
 
         def bwd():
-            L.splice_attention_qfold(0)
-            _lib.check(L.splice_attention_bwd(_lib.ptr(qkv_plain), _lib.ptr(qkvT), rows, B, T, Tld, D, H, scale, _lib.ptr(out), _lib.ptr(lse),
+            L.splice_attention_qfold(FOLD)
+            _lib.check(L.splice_attention_bwd(_lib.ptr(qkv), _lib.ptr(qkvT), rows, B, T, Tld, D, H, kscale, _lib.ptr(out), _lib.ptr(lse),
                                               _lib.ptr(dout), _lib.ptr(doutT), _lib.ptr(delta), _lib.ptr(dqkv), st))
 
         fwd()
@@ -90,7 +92,9 @@ for (B, T) in shapes:
         msg = ""
         if ref is not None:
             ef = relerr(out.float().reshape(B, Tld, D)[:, :T], ref)
-            gg = dqkv.float().reshape(B, Tld, 3, H, D // H)
+            gg = dqkv.float().reshape(B, Tld, 3, H, D // H).clone()
+            if FOLD:
+                gg[:, :, 0] *= scale * 1.4426950408889634   # the kernels return dL/dq'
             eb = [relerr(gg[:, :T, i], gref[:, :, i]) for i in range(3)]
             pad = gg[:, T:, 1:].abs().max().item()
             msg = f" err fwd {ef:.1e} dq {eb[0]:.1e} dk {eb[1]:.1e} dv {eb[2]:.1e} pad {pad:g}"
