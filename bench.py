@@ -14,8 +14,11 @@ optimises its OWN pair on its own GPU (independent units, no data-path collectiv
 value = total steps of all ranks / max-over-ranks time.
 
 Printed JSON (one line, rank 0) additionally carries
-  roofline     : the dominant kernel (fc2 bf16 MFMA GEMM of the ViT forward, the largest single share of the step): algorithmic
-                 FLOPs per launch / live HIP-event duration of its launches inside the timed region
+  roofline     : the live-timed kernel family with the largest share of the step (no family is excluded: at one 224 pair that is the
+                 generator chain, reported per kernel -- its three longest kernels with their own FLOPs / bytes -- and as a roll-up): algorithmic
+                 FLOPs of one call / the kernels' own begin-end time stamps; every other family under other_kernels
+  north_star   : (attention forward + backward + key self-similarity FLOPs per step) / (their kernel time per step x the dense bf16 MFMA
+                 peak) -- the figure BASELINE.json's north_star sets its 40 % target on
   cpu_baseline : the fp32 CPU oracle (a port of the reference-shaped loop: 6 ViT forwards + 3
                  backwards per step) timed on this host's cores on a bounded sample.
 
@@ -196,9 +199,9 @@ def kernel_families(T, D, heads, P, size, depth=12, fp8=False):
         1: ("fc1 forward GEMM, BIAS|GELU|OUT_BF epilogue (gemm_nt_kernel; gemm8p_kernel from 200 tiles of 256 x 256 on)" + (" [e4m3, scaled K=128 MFMA]" if fp8 else ""), "fp8mx" if fp8 else "bf16", 2 * P * 2.0 * T * hidden * D),
         2: ("qkv forward GEMM, BIAS|OUT_BF epilogue (gemm_nt_kernel; gemm8p_kernel from 200 tiles of 256 x 256 on)" + (" [e4m3, scaled K=128 MFMA]" if fp8 else ""), "fp8mx" if fp8 else "bf16", 2 * P * 2.0 * T * 3 * D * D),
         9: ("proj forward GEMM, BIAS|RESID|OUT_F32 epilogue (gemm_nt_kernel; gemm8p_kernel from ~150 row tiles of 256 on)", "bf16", 2 * P * 2.0 * T * D * D),
-        3: ("attn_fwd8_kernel [e4m3 operands, k = 32 fp8 MFMA: bf16 rate]" if fp8 == "attention" else "attn_fwd_kernel", "bf16", 2 * P * 4.0 * T * T * D),
+        3: ("attn_fwd8_kernel [e4m3 operands, k = 32 fp8 MFMA: bf16 rate]" if fp8 == "attention" else "attn_fwd_x32_kernel", "bf16", 2 * P * 4.0 * T * T * D),
         5: ("gemm_nt_kernel<OUT_F32> split-K dgrads (fc1^T and qkv^T, mean of both)", "bf16", P * 2.0 * T * D * (hidden + 3 * D) / 2),
-        6: ("attn_bwd_kernel (merged, or dQ + dK/dV launches)", "bf16", P * 10.0 * T * T * D),
+        6: ("attn_bwd_x32_kernel (one launch, or dQ + dK/dV launches)", "bf16", P * 10.0 * T * T * D),
         # generator: one call = splice_gen_forward (2.262 GFLOP per 224^2 image) or splice_gen_backward (dgrad + wgrad = 2 x forward);
         # four calls per ordinary step (A plan, B plan; forward, backward) -> mean FLOPs per call = 1.5 x forward x P images
         7: ("generator chain: conv_igemm / BatchNorm / upsample / conv_wgrad kernels of one splice_gen_forward or _backward call", "f32",
@@ -255,11 +258,13 @@ def timing_record(K, reduced, first_step, entire_every):
     mid = median_block(reduced)
     ms = [round(t / K * 1e3, 4) for t in reduced]
     ent = [sum(1 for st in range(first_step + b * K, first_step + (b + 1) * K) if entire_every and st % entire_every == 0) for b in range(len(reduced))]
-    return mid, {"blocks": len(reduced), "steps_per_block": K, "timed_seconds": round(sum(reduced), 4), "reported_block": mid,
+    return mid, {"blocks": len(reduced), "steps_per_block": K, "timed_seconds": round(sum(reduced), 4), "median_block": mid,
+                 "ms_per_step_median_block": ms[mid], "entire_image_steps_total": sum(ent),
                  "ms_per_step_by_block": ms if len(ms) <= 64 else ms[:64] + ["..."], "ms_per_step_min": min(ms), "ms_per_step_max": max(ms),
                  "entire_image_steps_by_block": ent if len(ent) <= 64 else ent[:64] + ["..."],
                  "rule": f"W warm-up steps, then blocks of exactly K steps (barrier + synchronize on both sides, max over ranks) until >= {MIN_TIMED_SECONDS} s "
-                         "are timed; value / ms_per_step are those of the MEDIAN block"}
+                         "are timed; value / ms_per_step = ALL timed steps / ALL timed seconds (the periodic entire-image steps are in it at their true "
+                         "frequency); the median block is kept as a robustness figure"}
 
 
 def train_regime_leg(eng, A, B, steps=120):
@@ -305,17 +310,18 @@ def stub_main(args, ms, world):
     eng = StubEngine(ms * (1.0 + 0.5 * rep.rank))   # rank r is slower: the max over ranks must show it
     local, reduced = time_blocks(eng, None, None, args.steps, args.warmup, rep.barrier, rep, min_seconds=float(os.environ.get("SPLICE_BENCH_STUB_MIN_S", "0.2")))
     mid, timing = timing_record(args.steps, reduced, args.warmup, 0)
-    per_rank = rep.gather_floats(local[mid])
-    elapsed = reduced[mid]
+    per_rank = rep.gather_floats(sum(local))
+    elapsed = sum(reduced)
+    k_total = args.steps * len(reduced)
     hip_vis = os.environ.get("HIP_VISIBLE_DEVICES", "")
     # every rank's device binding, gathered through the same process group (as floats: device ordinals)
     devs = rep.gather_floats(float(hip_vis.split(",")[0]) if hip_vis.split(",")[0].strip().isdigit() else -1.0)
     if rep.rank == 0:
-        value = aggregate_throughput(args.steps, world, elapsed)
+        value = aggregate_throughput(k_total, world, elapsed)
         print(json.dumps({"metric": "stub_steps_per_sec", "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "ms_per_step": round(elapsed / k_total * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "none", "data": "stub (launcher self-test: no GPU work, SPLICE_BENCH_STUB)",
-                          "config": {"workload": f"STUB: sleep {ms} ms per step (+50 % per rank)", "gpus": world, "per_rank_steps_per_s": [round(args.steps / t, 2) for t in per_rank],
+                          "config": {"workload": f"STUB: sleep {ms} ms per step (+50 % per rank)", "gpus": world, "per_rank_steps_per_s": [round(k_total / t, 2) for t in per_rank],
                                      "per_rank_device": [int(d) for d in devs], "host": host, "env": library_env(), "timing": timing},
                           "roofline": None, "cpu_baseline": None}), flush=True)
     rep.close()
@@ -329,7 +335,7 @@ def main():
     ap.add_argument("--size", type=int, default=224, help="pair height = width (configs[1]: 224)")
     ap.add_argument("--model", default="dino_vitb8")
     ap.add_argument("--pairs", type=int, default=1, help="pairs optimised side by side per GPU in the timed region (1 = the reference's unit: the latency form of the metric)")
-    ap.add_argument("--pairs-sweep", default="2,4,8", help="additional pairs-per-GPU settings timed briefly after the main region (throughput form: pairs/hr); '' = off")
+    ap.add_argument("--pairs-sweep", default="2,4,8,16,32", help="additional pairs-per-GPU settings timed briefly after the main region (throughput form: pairs/hr); '' = off")
     ap.add_argument("--fp8", nargs="?", const="gemm", default=None, choices=("gemm", "attention"),
                     help="fp8 operand path (own, looser tolerance table: an APPROXIMATE mode, tests/test_fp8_gpu.py).  '--fp8' = '--fp8 gemm': e4m3 QKV / fc1 / fc2 "
                          "projections + key self-similarity Gram on the fp8 MFMA (the fastest setting; the config key fp8: True); "
@@ -403,7 +409,8 @@ def main():
 
     local_blocks, reduced_blocks = time_blocks(eng, A, B, K, W, barrier, rep)
     mid, timing = timing_record(K, reduced_blocks, W, eng.cfg["entire_A_every"] if not scales else eng.engines[0].cfg["entire_A_every"])
-    elapsed = local_blocks[mid]
+    n_blocks = len(reduced_blocks)
+    elapsed = sum(local_blocks)          # this rank's timed seconds over all blocks
     losses = eng.losses() if (P == 1 or scales) else eng.losses(0)
     # roofline leg: the timed region replays captured hipGraphs (event records cannot be threaded through a
     # replay), so the SAME steps continue for short instrumented stretches with every launch of one kernel family
@@ -417,24 +424,30 @@ def main():
         for _ in range(nprof):
             eng.step(A, B, A)
         torch.cuda.synchronize()
-        _lib.check(_lib.lib().splice_prof_end_ex(C.byref(ms), C.byref(calls), C.byref(kernels)))
+        detail = C.create_string_buffer(16384)
+        _lib.check(_lib.lib().splice_prof_end_detail(C.byref(ms), C.byref(calls), C.byref(kernels), detail, len(detail)))
         if calls.value:
             n_ent = sum(1 for st_ in range(eng.step_idx - nprof + 1, eng.step_idx + 1) if st_ % eng.cfg["entire_A_every"] == 0)
-            prof[fam] = (ms.value, calls.value, kernels.value, nprof, n_ent)
+            per_kernel = []
+            for line in detail.value.decode(errors="replace").splitlines():
+                nm, n, tms, fl, by = line.split("\t")
+                per_kernel.append({"kernel": nm, "launches": int(n), "ms": float(tms), "flops": float(fl), "bytes": float(by)})
+            prof[fam] = (ms.value, calls.value, kernels.value, nprof, n_ent, per_kernel)
     per_rank_elapsed = rep.gather_floats(elapsed)
-    elapsed = reduced_blocks[mid]
+    elapsed = sum(reduced_blocks)        # max over ranks, block by block
+    K_total = K * n_blocks
     T = eng.ctx_g.T if not scales else [e.ctx_g.T for e in eng.engines]
     D = eng.vit.dim
-    n_entire = timing["entire_image_steps_by_block"][mid] if mid < 64 else 0
+    n_entire = timing["entire_image_steps_total"]
     # ---- throughput form of the metric: P pairs per GPU through the shared ViT (same barrier-bracketed timing, fewer steps)
-    sweep = {P: K / elapsed}
+    sweep = {P: K_total / elapsed}
     sweep_ids = [int(x) for x in args.pairs_sweep.split(",") if x.strip()] if (world == 1 and P == 1 and not scales) else []
     vit = eng.vit
     for Ps in sweep_ids:
         try:
             e2, A2, B2 = synthetic_engine(cfg, pair_id=0, hw=hw, seed=1234, device=dev, pairs=Ps, vit_engine=vit, fp8=fp8_mode, top_cls_only=not args.full_top_block)
-            k2 = max(20, K // 4)
-            sweep[Ps] = k2 / time_steps(e2, A2, B2, k2, max(5, W // 2), barrier)
+            k2 = max(20, K // 4) if Ps <= 8 else 12   # (the big batches: ~0.4 / 0.8 s of steps at 16 / 32 pairs)
+            sweep[Ps] = k2 / time_steps(e2, A2, B2, k2, max(5, W // 2) if Ps <= 8 else 4, barrier)
             del e2, A2, B2
             torch.cuda.empty_cache()
         except Exception as e:   # the sweep must never take the headline number down
@@ -464,7 +477,7 @@ def main():
             static_traffic = json.load(open(traffic_file)).get(f"P{P}" if args.size == 224 else f"S{args.size}P{P}", {})
         except Exception:
             static_traffic = {}
-    for fam, (tot_ms, calls, kernels, steps, n_ent) in prof.items():
+    for fam, (tot_ms, calls, kernels, steps, n_ent, per_kernel) in prof.items():
         kname, cls, flops = fams[fam]
         avg_ms = max(tot_ms / calls, 1e-6)
         ach = flops / (avg_ms * 1e-3) / 1e12
@@ -475,6 +488,18 @@ def main():
              "traffic_source": None if traffic is None else "static: profiles/roofline_traffic.json, bytes per call of this family (FETCH_SIZE x2 + WRITE_SIZE from separate --pmc passes of tools/pmc_families.sh on this workload and build; not re-measured by this command)",
              "avg_launch_us": round(avg_ms * 1e3, 2), "calls_per_step": round(calls / steps, 1), "kernels_per_step": round(kernels / steps, 1),
              "share_of_step_ms": round(tot_ms / steps, 4)}
+        if len(per_kernel) > 1:   # a chain of kernels: its three longest, each with its own launch count, duration and (where the launcher notes it) work
+            top = []
+            for k in per_kernel[:3]:
+                e = {"kernel": k["kernel"], "launches_per_step": round(k["launches"] / steps, 1), "avg_launch_us": round(k["ms"] / k["launches"] * 1e3, 2),
+                     "share_of_step_ms": round(k["ms"] / steps, 4)}
+                if k["flops"] > 0:
+                    tf = k["flops"] / (k["ms"] * 1e-3) / 1e12
+                    gb = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+                    e.update({"algorithmic_gflop_per_launch": round(k["flops"] / k["launches"] / 1e9, 4), "achieved_tflops": round(tf, 2), "frac_of_mfma_peak": round(tf / peak, 4),
+                              "algorithmic_mb_per_launch": round(k["bytes"] / k["launches"] / 1e6, 3), "achieved_gb_s": round(gb, 1), "frac_of_hbm_peak": round(gb / HBM_PEAK, 4)})
+                top.append(e)
+            r["kernels"] = top
         if n_ent:
             r["note_entire"] = f"{n_ent} of the {steps} instrumented steps ran the entire-image branch (its launches are in the averages)"
         if fam == 7:   # also against the HBM roofline: SURVEY 8d floor of 11.54 M fp32 activation elements per image forward, backward 2x
@@ -488,7 +513,7 @@ def main():
     if roofs:
         # dominant = the single KERNEL family with the largest total time per step (the generator entry is a chain of ~70 kernels
         # per call and is listed with the others; `furthest_below_roofline` names the family with the lowest fraction)
-        singles = [r for r in roofs if not r["kernel"].startswith("generator chain") and not r["kernel"].startswith("selfsim kernels")] or roofs
+        singles = roofs   # (no family is excluded: the largest share is the dominant one)
         roof = dict(singles[0])
         roof["note"] = ("dominant = the live-timed kernel family with the largest total time per step; achieved = algorithmic FLOPs of one "
                         "call / mean kernel duration of its launches; the duration is the kernel's own begin / end time stamp pair "
@@ -497,31 +522,41 @@ def main():
         roof["other_kernels"] = [r for r in roofs if r is not singles[0]]
         worst = min(roofs, key=lambda r: r["frac"])
         roof["furthest_below_roofline"] = {"kernel": worst["kernel"], "frac": worst["frac"], "share_of_step_ms": worst["share_of_step_ms"]}
+    north = None
+    if all(f in prof for f in (3, 6, 8)):   # BASELINE north_star: MFMA utilisation of the attention + key self-similarity kernels
+        fl = sum(fams[f][2] * prof[f][1] / prof[f][3] for f in (3, 6, 8))            # algorithmic FLOPs per step
+        ms_ = sum(prof[f][0] / prof[f][3] for f in (3, 6, 8))                         # kernel ms per step
+        north = {"what": "(attention forward + backward + key self-similarity algorithmic FLOPs per step) / (their kernel time per step x dense bf16 MFMA peak)",
+                 "gflop_per_step": round(fl / 1e9, 2), "kernel_ms_per_step": round(ms_, 4), "achieved_tflops": round(fl / (ms_ * 1e-3) / 1e12, 1),
+                 "peak_tflops": BF16_MFMA_PEAK, "frac": round(fl / (ms_ * 1e-3) / 1e12 / BF16_MFMA_PEAK, 4), "target": 0.40,
+                 "by_family": {fams[f][0].split(" ")[0]: round(fams[f][2] / (prof[f][0] / prof[f][1] * 1e-3) / 1e12 / BF16_MFMA_PEAK, 4) for f in (3, 6, 8)}}
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         try:
             cpu = cpu_baseline(dict(eng.cfg), hw, 1234)
         except Exception as e:  # the baseline must never take the product number down
             cpu = {"value": None, "unit": "steps/s", "cores": host_threads(), "kind": "port", "sample": f"failed: {e}"}
-    value = aggregate_throughput(K, world, elapsed)
+    value = aggregate_throughput(K_total, world, elapsed)
+    best_P = max((k for k, v in sweep.items() if v), key=lambda k: sweep[k] * k)
     out = {
         "metric": "opt_steps_per_sec", "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(elapsed / K_total * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("fp8-approximate(e4m3 qkv/fc1/fc2 + attention fwd + selfsim Gram)/bf16" if fp8_mode == "attention" else "fp8-approximate(e4m3 qkv/fc1/fc2 + selfsim Gram)/bf16") if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"Splice pair {hw[0]}x{hw[1]}, {args.model} (T={T}), {P} pair(s) per GPU per step, "
-                               f"{n_entire} of the {K} steps of the reported (median) block include the entire-image branch"
+                               f"{n_entire} of the {K_total} timed steps ({n_blocks} blocks of {K}) include the entire-image branch"
                                + (f"; loss evaluated at the ViT input scales {scales} every step (configs[4])" if scales else "")
                                + ("; APPROXIMATE fp8 operand mode (per-step gradient 1e-1 off the fp32 oracle, own tolerance table: tests/test_fp8_gpu.py, DESIGN.md section 5)" if args.fp8 else ""),
                    "gpus": world, "pairs_per_gpu": P, "pair_steps_per_s": round(value * P, 3),
                    "pairs_per_hour_at_2000_steps": round(value * P * 3600 / 2000, 2),
-                   "per_rank_steps_per_s": [round(K / t, 2) for t in per_rank_elapsed],
+                   "per_rank_steps_per_s": [round(K_total / t, 2) for t in per_rank_elapsed],
+                   "best_pairs_per_gpu": {"pairs": best_P, "pair_steps_per_s": round(sweep[best_P] * best_P, 2), "pairs_per_hour_at_2000_steps": round(sweep[best_P] * best_P * 3600 / 2000, 1)},
                    "throughput_by_pairs_per_gpu": {str(k): (None if v is None else {"steps_per_s": round(v, 2), "pair_steps_per_s": round(v * k, 2),
                                                                                     "pairs_per_hour_at_2000_steps": round(v * k * 3600 / 2000, 1)})
                                                    for k, v in sorted(sweep.items())},
                    "train_model_regime": train_leg,
                    "generator_dtype": "f32", "last_loss": round(losses["loss"], 5),
                    "env": library_env(), "host": host, "timing": timing},
-        "roofline": roof, "cpu_baseline": cpu,
+        "roofline": roof, "north_star": north, "cpu_baseline": cpu,
     }
     if bad:
         out["config"]["dev_env"] = bad   # --allow-dev-env: NOT a measurement of the product's step

@@ -299,6 +299,9 @@ int splice_adam_step(float* params, float* grads, float* m, float* v, long long 
 int splice_prof_begin(int which);
 int splice_prof_end(float* total_ms, int* launches);
 int splice_prof_end_ex(float* total_ms, int* calls, int* kernels);
+/* as splice_prof_end_ex, plus one text line per distinct kernel of the family in `detail` (may be NULL):
+ * "kernel\tlaunches\ttotal ms\talgorithmic FLOPs\talgorithmic bytes\n", longest first (the work columns are what the launchers noted: the convolutions) */
+int splice_prof_end_detail(float* total_ms, int* calls, int* kernels, char* detail, int detail_len);
 int splice_prof_active(void);
 int splice_vit_ctx_dims(void* ctx, int* B, int* H, int* W, int* D, int* depth, int* heads, int* patch);
 int splice_gen_plan_dims(void* plan, int* N, int* H, int* W, long long* nparams);

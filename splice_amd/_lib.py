@@ -117,6 +117,7 @@ _SIGNATURES = {
     "splice_prof_begin": ([_i], _i),
     "splice_prof_end": ([C.POINTER(_f), C.POINTER(_i)], _i),
     "splice_prof_end_ex": ([C.POINTER(_f), C.POINTER(_i), C.POINTER(_i)], _i),
+    "splice_prof_end_detail": ([C.POINTER(_f), C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i], _i),
     "splice_prof_active": ([], _i),
     "splice_step_use_graph": ([_vp, _i], _i),
     "splice_step_use_overlap": ([_vp, _i], _i),

@@ -11,7 +11,9 @@ typedef uint16_t bf16_t;  // raw bf16 storage
 // armed (splice_prof_begin) and one of its host calls is open (SpliceProfScope), the launch goes out as hipExtLaunchKernelGGL
 // with a start / stop event pair of its own: the pair carries the kernel's begin and end time stamps (what rocprofv3's
 // kernel trace reports), not the cost of two event records queued around it.  Otherwise: a plain launch.
-bool splice_prof_take(hipEvent_t* start, hipEvent_t* stop);
+bool splice_prof_take(hipEvent_t* start, hipEvent_t* stop, const char* kernel_name);
+// algorithmic work of the NEXT launch that takes an event pair (conv launchers: FLOPs and bytes of the layer); consumed by that launch
+void splice_prof_note(double flops, double bytes);
 extern int g_splice_prof_open;   // > 0: a scope of the armed family is open (prof.hip)
 struct SpliceProfScope {
     bool on;
@@ -21,7 +23,7 @@ struct SpliceProfScope {
 #define SPLICE_LAUNCH(kernel, grid, block, lds, stream, ...)                                                       \
     do {                                                                                                           \
         hipEvent_t pa_, pb_;                                                                                       \
-        if (g_splice_prof_open > 0 && splice_prof_take(&pa_, &pb_))                                                \
+        if (g_splice_prof_open > 0 && splice_prof_take(&pa_, &pb_, #kernel))                                             \
             hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, pa_, pb_, 0, __VA_ARGS__);                     \
         else                                                                                                       \
             hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                     \

@@ -337,9 +337,16 @@ static void conv_splitk_reduce_launch(const ConvArgs& a, int ksplit, hipStream_t
     SPLICE_LAUNCH(conv_splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, a, ksplit);
 }
 
+// roofline leg: the layer's algorithmic work rides with the launch (prof.hip): 2 x outputs x reduction length FLOPs; input + output + weight bytes
+static inline void conv_note_work(const ConvArgs& a) {
+    if (g_splice_prof_open <= 0) return;
+    const double outs = (double)a.N * a.Cout * a.Ho * a.Wo, red = (double)a.Cin * a.ks * a.ks;
+    splice_prof_note(2.0 * outs * red, 4.0 * (outs + (double)a.N * a.Cin * a.Hi * a.Wi + (double)a.Cout * red * (a.p_nstride ? a.N : 1)));
+}
 template <int KS, bool TR, int CK>
 static void conv_launch_fn(ConvArgs a, hipStream_t s, int* ksplit_out) {
     const ConvPolicy pol = conv_policy(a, KS, CK);
+    conv_note_work(a);
     a.ksplit = pol.ksplit;
     const dim3 grid(pol.mt, pol.ny, a.N);
     constexpr bool CAN8 = KS == 3 && CK == 8;

@@ -11,6 +11,9 @@
 // qkv^T), 6 attention bwd, 7 generator (every conv / BatchNorm / upsample / weight-gradient launch of splice_gen_forward*
 // and splice_gen_backward), 8 key self-similarity loss kernels (norms, S*, fused S / MSE / W, dK),
 // 9 proj GEMM fwd.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "common.h"
@@ -21,13 +24,21 @@ namespace {
 struct ProfState {
     int which = 0;
     std::vector<hipEvent_t> ev;   // start / stop pairs
+    std::vector<const char*> name;   // per pair: the kernel expression of its SPLICE_LAUNCH (a string literal)
+    std::vector<double> flops, bytes;   // per pair: algorithmic work noted by the launcher (0 = not noted)
     size_t used = 0;
     int calls = 0;
+    double next_flops = 0, next_bytes = 0;
 };
 ProfState g_prof;
 }   // namespace
 
-bool splice_prof_take(hipEvent_t* start, hipEvent_t* stop) {
+void splice_prof_note(double flops, double bytes) {
+    if (g_splice_prof_open <= 0) return;
+    g_prof.next_flops = flops;
+    g_prof.next_bytes = bytes;
+}
+bool splice_prof_take(hipEvent_t* start, hipEvent_t* stop, const char* kernel_name) {
     if (g_splice_prof_open <= 0) return false;
     if (g_prof.used + 2 > g_prof.ev.size()) {
         for (int i = 0; i < 512; ++i) {
@@ -38,6 +49,12 @@ bool splice_prof_take(hipEvent_t* start, hipEvent_t* stop) {
     }
     *start = g_prof.ev[g_prof.used];
     *stop = g_prof.ev[g_prof.used + 1];
+    const size_t pair = g_prof.used / 2;
+    if (g_prof.name.size() <= pair) { g_prof.name.resize(pair + 512); g_prof.flops.resize(pair + 512); g_prof.bytes.resize(pair + 512); }
+    g_prof.name[pair] = kernel_name;
+    g_prof.flops[pair] = g_prof.next_flops;
+    g_prof.bytes[pair] = g_prof.next_bytes;
+    g_prof.next_flops = g_prof.next_bytes = 0;
     g_prof.used += 2;
     return true;
 }
@@ -62,9 +79,13 @@ int splice_prof_begin(int which) {
 }
 int splice_prof_active(void) { return g_prof.which != 0; }
 
-int splice_prof_end_ex(float* total_ms, int* calls, int* kernels) {
+// detail (may be NULL): one line per distinct kernel of the family, "name\tlaunches\ttotal ms\talgorithmic FLOPs\talgorithmic bytes\n" (the last two are the
+// sums the launchers noted, 0 where none did), longest first, cut to detail_len - 1 bytes
+int splice_prof_end_detail(float* total_ms, int* calls, int* kernels, char* detail, int detail_len) {
     float tot = 0.f;
     int rc = SPLICE_OK;
+    struct Agg { const char* name; int n; double ms, flops, bytes; };
+    std::vector<Agg> agg;
     for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
         float ms = 0.f;
         if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess || hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]) != hipSuccess) {
@@ -72,6 +93,23 @@ int splice_prof_end_ex(float* total_ms, int* calls, int* kernels) {
             break;
         }
         tot += ms;
+        if (detail) {
+            const char* nm = g_prof.name[i / 2];
+            size_t k = 0;
+            while (k < agg.size() && strcmp(agg[k].name, nm) != 0) ++k;
+            if (k == agg.size()) agg.push_back(Agg{nm, 0, 0.0, 0.0, 0.0});
+            agg[k].n++; agg[k].ms += ms; agg[k].flops += g_prof.flops[i / 2]; agg[k].bytes += g_prof.bytes[i / 2];
+        }
+    }
+    if (detail && detail_len > 0) {
+        std::sort(agg.begin(), agg.end(), [](const Agg& a, const Agg& b) { return a.ms > b.ms; });
+        int pos = 0;
+        detail[0] = 0;
+        for (const Agg& g : agg) {
+            const int w = snprintf(detail + pos, (size_t)(detail_len - pos), "%s\t%d\t%.6f\t%.6g\t%.6g\n", g.name, g.n, g.ms, g.flops, g.bytes);
+            if (w < 0 || w >= detail_len - pos) { detail[pos] = 0; break; }
+            pos += w;
+        }
     }
     if (total_ms) *total_ms = tot;
     if (calls) *calls = g_prof.calls;
@@ -82,6 +120,7 @@ int splice_prof_end_ex(float* total_ms, int* calls, int* kernels) {
     g_splice_prof_open = 0;
     return rc;
 }
+int splice_prof_end_ex(float* total_ms, int* calls, int* kernels) { return splice_prof_end_detail(total_ms, calls, kernels, nullptr, 0); }
 // launches = host calls of the family (a call may launch more than one kernel, e.g. the two-launch attention backward)
 int splice_prof_end(float* total_ms, int* launches) { return splice_prof_end_ex(total_ms, launches, nullptr); }
 }
