@@ -211,13 +211,14 @@ def kernel_families(T, D, heads, P, size, depth=12, fp8=False):
     }
 
 
-def time_steps(eng, A, B, K, W, barrier):
+def time_steps(eng, A, B, K, W, barrier, E=None):
+    E = A if E is None else E
     for _ in range(W):
-        eng.step(A, B, A)
+        eng.step(A, B, E)
     barrier()
     t0 = time.perf_counter()
     for _ in range(K):
-        eng.step(A, B, A)
+        eng.step(A, B, E)
     barrier()
     return time.perf_counter() - t0
 
@@ -226,18 +227,19 @@ MIN_TIMED_SECONDS = 1.0    # the driver's --steps 20 timed 0.07 s
 MAX_BLOCKS = 400
 
 
-def time_blocks(eng, A, B, K, W, barrier, rep, min_seconds=MIN_TIMED_SECONDS, max_blocks=MAX_BLOCKS):
+def time_blocks(eng, A, B, K, W, barrier, rep, min_seconds=MIN_TIMED_SECONDS, max_blocks=MAX_BLOCKS, E=None):
     """W untimed warm-up steps, then BLOCKS of exactly K steps, each bracketed by barrier + synchronize on both sides and reduced to
     the max over ranks, repeated until at least ``min_seconds`` are timed.  Returns (local block times, max-over-ranks block times).
     Every rank sees the same reduced times, so every rank runs the same number of blocks."""
+    E = A if E is None else E
     for _ in range(W):
-        eng.step(A, B, A)
+        eng.step(A, B, E)
     local, reduced, total = [], [], 0.0
     while True:
         barrier()
         t0 = time.perf_counter()
         for _ in range(K):
-            eng.step(A, B, A)
+            eng.step(A, B, E)
         barrier()
         dt = time.perf_counter() - t0
         dmax = rep.max_over_ranks(dt)
@@ -333,6 +335,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--size", type=int, default=224, help="pair height = width (configs[1]: 224)")
+    ap.add_argument("--image", default="", help="HxW, e.g. 900x1200: the reference's DEFAULT workload shape (conf/default/config.yaml: 1200 x 900 images, A_resize -1) -- "
+                                                "square global crops of the full image height (the 855 .. 900 range of data/transforms.py:21-23 at its upper end, fixed so that "
+                                                "graphs replay), every crop resized to --size (224), the entire HxW image through Resize(224, max_size=480); one pair, no sweep")
     ap.add_argument("--model", default="dino_vitb8")
     ap.add_argument("--pairs", type=int, default=1, help="pairs optimised side by side per GPU in the timed region (1 = the reference's unit: the latency form of the metric)")
     ap.add_argument("--pairs-sweep", default="2,4,8,16,32", help="additional pairs-per-GPU settings timed briefly after the main region (throughput form: pairs/hr); '' = off")
@@ -398,8 +403,17 @@ def main():
         eng = MultiScaleEngine(cfg, synth.vit_params(1234, args.model, img_size=224), synth.generator_params(1235 + rep.pair_id(), 0.02), hw, hw,
                                scales=scales, device=dev, fp8=fp8_mode)
         A, B = torch.from_numpy(Ai).to(dev), torch.from_numpy(Bi).to(dev)
+    elif args.image:
+        ih, iw = (int(x) for x in args.image.lower().split("x"))
+        side = min(ih, iw)
+        P = 1
+        args.pairs_sweep, args.no_train_regime, args.no_cpu_baseline = "", True, True
+        eng, A, B, E_img = synthetic_engine(cfg, pair_id=rep.pair_id(), hw=(ih, iw), seed=1234, device=dev, fp8=fp8_mode, crop_hw=(side, side))
+        hw = (ih, iw)
     else:
         eng, A, B = synthetic_engine(cfg, pair_id=rep.pair_id() * P, hw=hw, seed=1234, device=dev, pairs=P, fp8=fp8_mode, top_cls_only=not args.full_top_block)
+    E_in = E_img if args.image else None   # the entire image (the crops themselves at the square BASELINE configs)
+    gen_side = min(hw) if args.image else args.size   # side of the square generator crops (the roofline leg's FLOP count)
     K, W = args.steps, args.warmup
 
     def barrier():
@@ -407,7 +421,7 @@ def main():
         rep.barrier()
         torch.cuda.synchronize()
 
-    local_blocks, reduced_blocks = time_blocks(eng, A, B, K, W, barrier, rep)
+    local_blocks, reduced_blocks = time_blocks(eng, A, B, K, W, barrier, rep, E=E_in)
     mid, timing = timing_record(K, reduced_blocks, W, eng.cfg["entire_A_every"] if not scales else eng.engines[0].cfg["entire_A_every"])
     n_blocks = len(reduced_blocks)
     elapsed = sum(local_blocks)          # this rank's timed seconds over all blocks
@@ -422,7 +436,7 @@ def main():
         _lib.check(_lib.lib().splice_prof_begin(fam))
         nprof = min(K, 20)
         for _ in range(nprof):
-            eng.step(A, B, A)
+            eng.step(A, B, A if E_in is None else E_in)
         torch.cuda.synchronize()
         detail = C.create_string_buffer(16384)
         _lib.check(_lib.lib().splice_prof_end_detail(C.byref(ms), C.byref(calls), C.byref(kernels), detail, len(detail)))
@@ -468,11 +482,11 @@ def main():
         fams = {k: (per[0][k][0] + f" (mean over the ViT input scales {scales})", per[0][k][1], sum(f[k][2] for f in per) / len(per)) for k in per[0]}
         fams[7] = per[0][7]   # (the generator works at the crop size at every scale)
     else:
-        fams = kernel_families(T, D, eng.vit.heads, P, args.size, fp8=fp8_mode)
+        fams = kernel_families(T, D, eng.vit.heads, P, gen_side, fp8=fp8_mode)
     roofs = []
     traffic_file = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     static_traffic = {}
-    if os.path.exists(traffic_file) and args.model == "dino_vitb8" and not scales and not args.fp8:
+    if os.path.exists(traffic_file) and args.model == "dino_vitb8" and not scales and not args.fp8 and not args.image:
         try:   # keys: "P<pairs>" at 224 x 224, "S<size>P<pairs>" otherwise; values: family id -> bytes per call
             static_traffic = json.load(open(traffic_file)).get(f"P{P}" if args.size == 224 else f"S{args.size}P{P}", {})
         except Exception:
@@ -503,7 +517,7 @@ def main():
         if n_ent:
             r["note_entire"] = f"{n_ent} of the {steps} instrumented steps ran the entire-image branch (its launches are in the averages)"
         if fam == 7:   # also against the HBM roofline: SURVEY 8d floor of 11.54 M fp32 activation elements per image forward, backward 2x
-            g = (args.size / 224.0) ** 2
+            g = (gen_side / 224.0) ** 2
             bytes_call = P * 1.5 * 11.54e6 * 4 * g
             r["hbm"] = {"bound": "hbm", "algorithmic_bytes_per_call": round(bytes_call), "achieved": round(bytes_call / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK,
                         "unit": "GB/s", "frac": round(bytes_call / (avg_ms * 1e-3) / 1e9 / HBM_PEAK, 4)}
@@ -542,7 +556,8 @@ def main():
         "metric": "opt_steps_per_sec", "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K_total * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("fp8-approximate(e4m3 qkv/fc1/fc2 + attention fwd + selfsim Gram)/bf16" if fp8_mode == "attention" else "fp8-approximate(e4m3 qkv/fc1/fc2 + selfsim Gram)/bf16") if args.fp8 else "bf16", "data": "synthetic",
-        "config": {"workload": f"Splice pair {hw[0]}x{hw[1]}, {args.model} (T={T}), {P} pair(s) per GPU per step, "
+        "config": {"workload": (f"Splice pair {hw[0]}x{hw[1]} (the reference's default image shape), global crops {gen_side}x{gen_side} resized to {args.size}, entire image through Resize({args.size}, max_size=480), "
+                                if args.image else f"Splice pair {hw[0]}x{hw[1]}, ") + f"{args.model} (T={T}), {P} pair(s) per GPU per step, "
                                f"{n_entire} of the {K_total} timed steps ({n_blocks} blocks of {K}) include the entire-image branch"
                                + (f"; loss evaluated at the ViT input scales {scales} every step (configs[4])" if scales else "")
                                + ("; APPROXIMATE fp8 operand mode (per-step gradient 1e-1 off the fp32 oracle, own tolerance table: tests/test_fp8_gpu.py, DESIGN.md section 5)" if args.fp8 else ""),

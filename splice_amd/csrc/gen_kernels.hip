@@ -714,6 +714,10 @@ int wgrad_chunks(int N, int Ho, int Wo, int* pix_per_chunk, int* chunks_per_img)
     int ppc = 512;
     if (HWo <= 1024) ppc = 256;
     if (HWo <= 256) ppc = 64;
+    // big planes (round 5: the reference's default 900 x 900 crops): at 512 pixels a plane of 0.81 MP made 1582 chunks, every one writing a full
+    // weight-shaped partial -- 0.84 ms of wgrad_reduce_all per step just to stream them back.  At most 128 chunks per image: a workgroup walks
+    // more 64-pixel fills before it writes (planes up to 256 x 256 keep their 512-pixel chunks, so the 224 x 224 configs keep their bits).
+    if (HWo > 128 * 512) ppc = (cdiv(HWo, 128) + 63) / 64 * 64;
     *pix_per_chunk = ppc;
     *chunks_per_img = cdiv(HWo, ppc);
     return N * *chunks_per_img;

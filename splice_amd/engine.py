@@ -293,10 +293,21 @@ class MultiScaleEngine:
         return self.engines[0].state_dict(pair)
 
 
-def synthetic_engine(cfg, pair_id=0, hw=(224, 224), seed=1234, device="cuda", vit_engine=None, entire=True, pairs=1, fp8=False, top_cls_only=True):
+def synthetic_engine(cfg, pair_id=0, hw=(224, 224), seed=1234, device="cuda", vit_engine=None, entire=True, pairs=1, fp8=False, top_cls_only=True, crop_hw=None):
     """Engine + inputs for the BASELINE benchmark configs: seeded synthetic ViT weights, xavier generator init and U[0,1)
     pairs.  ``pairs`` > 1: pairs ``pair_id .. pair_id + pairs - 1`` side by side on one engine
-    (inputs ``[P,3,h,w]``); ``pairs == 1``: the single-pair ``SpliceEngine`` with ``[3,h,w]`` inputs."""
+    (inputs ``[P,3,h,w]``); ``pairs == 1``: the single-pair ``SpliceEngine`` with ``[3,h,w]`` inputs.
+    ``crop_hw``: the global crops are the top-left ``crop_hw`` window of the ``hw`` images (the reference's default shape: 900 x 900 crops of
+    900 x 1200 images, every crop resized to ``dino_global_patch_size``); the return value then carries the entire image as a fourth entry."""
+    if crop_hw is not None:
+        if pairs != 1:
+            raise ValueError("crop_hw: one pair per engine")
+        c = dict(DEFAULT_CFG, **cfg)
+        vit_state = None if vit_engine is not None else synth.vit_params(seed, c["dino_model_name"], img_size=c["dino_global_patch_size"])
+        a, b = synth.image_pair(seed, pair_id, hw[0], hw[1])
+        eng = SpliceEngine(c, vit_state, synth.generator_params(seed + 1 + pair_id, c["init_gain"]), crop_hw, hw if entire else None, device=device, vit_engine=vit_engine, fp8=fp8)
+        A, B = torch.from_numpy(a).to(device), torch.from_numpy(b).to(device)
+        return eng, A[:, :crop_hw[0], :crop_hw[1]].contiguous(), B[:, :crop_hw[0], :crop_hw[1]].contiguous(), A
     c = dict(DEFAULT_CFG, **cfg)
     P = c["dino_global_patch_size"]
     vit_state = None
