@@ -425,3 +425,28 @@ def test_splitk_virtual_equals_real_bitwise():
         ref = (slabs[0] + slabs[1]) + slabs[2]
         assert torch.equal(big[r0:r0 + 800], ref), (r0, (big[r0:r0 + 800] - ref).abs().max().item())
     assert _relerr(big, A.float() @ B.float().T) < 1e-5
+
+
+@pytest.mark.parametrize("case,tol", [("up128", 2e-5), ("down900", 1e-4), ("cap64x150", 2e-5)])
+def test_resize_kernels_against_independent_numpy_restatement(case, tol):
+    """``resize_bilinear_fwd`` (the Resize of util/losses.py:20 inside the fused step) against oracle/resize_np.py's fixtures (torchvision 0.10
+    tensor Resize restated in numpy / float64, tests/golden/resize_np.npz): 128 -> 224, the reference's default 900 -> 224 down-scale without
+    antialias, and the 64 x 150 -> 204 x 480 max_size cap.  The adjoint kernel is pinned by the size-independent property
+    <R x, y> == <x, R^T y>."""
+    from oracle.make_resize_golden import CASES, case_input
+    shape, size = CASES[case]
+    want = torch.from_numpy(np.load(os.path.join(os.path.dirname(__file__), "golden", "resize_np.npz"))[case]).to(DEV)
+    x = torch.from_numpy(case_input(case)).to(DEV).contiguous()
+    c, h, w = x.shape
+    oh, ow = want.shape[-2:]
+    y = torch.empty(c, oh, ow, device=DEV)
+    L = _lib.lib()
+    _lib.check(L.splice_resize_bilinear_fwd(_lib.ptr(x), _lib.ptr(y), c, h, w, oh, ow, _st()))
+    torch.cuda.synchronize()
+    assert (y - want).abs().max().item() < tol, (y - want).abs().max().item()
+    dy = _rand(c, oh, ow, seed=5)
+    dx = torch.zeros(c, h, w, device=DEV)
+    _lib.check(L.splice_resize_bilinear_bwd(_lib.ptr(dy), _lib.ptr(dx), c, h, w, oh, ow, _st()))
+    torch.cuda.synchronize()
+    lhs, rhs = (y.double() * dy.double()).sum().item(), (x.double() * dx.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-5 * max(1.0, abs(lhs)), (lhs, rhs)
