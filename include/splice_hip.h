@@ -361,6 +361,9 @@ int splice_step_run(void* step, float* params, float* grads, float* m, float* v,
                     const float* A_entire, int step_idx, float* losses_out, splice_stream_t stream);
 /* generator outputs of the last step: which 0 x_global [P][3][a_h][a_w], 1 x_entire, 2 y_global */
 int splice_step_output(void* step, int which, float** out_ptr);
+/* graph bookkeeping of this handle: out[0] = captures that updated a retired executable in place (hipGraphExecUpdate; executables are pooled per
+ * step configuration and never destroyed while the process runs), out[1] = updates the runtime refused, out[2] = executables instantiated */
+int splice_step_graph_stats(void* step, long long* out);
 /* 1 (default): capture the step's launch sequence once per regime into a hipGraph and replay it;
  * 0: launch every kernel eagerly (also used automatically while splice_prof_begin is armed) */
 int splice_step_use_graph(void* step, int on);

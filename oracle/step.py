@@ -23,6 +23,7 @@ class SpliceOracle:
         c = self.cfg
         self.opt = Adam(self.params.values(), c["lr"], c["optimizer_beta1"], c["optimizer_beta2"])
         self.step_idx = -1  # data/Dataset.py:57 -- first __getitem__ makes it 0
+        self.grad_hook = None   # test infrastructure (oracle/trajectory_ensemble.py): grads -> grads before the optimizer step
 
     def model_forward(self, inputs):
         c = self.cfg
@@ -45,5 +46,7 @@ class SpliceOracle:
         losses = L.loss_g(self.vit, self.cfg, self.lambdas, outputs, inputs)
         grads = torch.autograd.grad(losses["loss"], list(self.params.values()), allow_unused=True)
         grads = [torch.zeros_like(p) if g is None else g for g, p in zip(grads, self.params.values())]
+        if self.grad_hook is not None:
+            grads = self.grad_hook(grads)
         self.opt.step(grads)
         return {k: float(v.detach()) for k, v in losses.items()}, outputs, grads

@@ -120,6 +120,7 @@ _SIGNATURES = {
     "splice_prof_end_detail": ([C.POINTER(_f), C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i], _i),
     "splice_prof_active": ([], _i),
     "splice_step_use_graph": ([_vp, _i], _i),
+    "splice_step_graph_stats": ([_vp, C.POINTER(C.c_longlong)], _i),
     "splice_step_use_overlap": ([_vp, _i], _i),
     "splice_vit_ctx_dims": ([_vp] + [C.POINTER(_i)] * 7, _i),
     "splice_gen_plan_dims": ([_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_longlong)], _i),

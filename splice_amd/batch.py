@@ -134,9 +134,10 @@ def _worker(gpu, visible_id, root, names, items, head, current, runner, override
             else:
                 k = head.value
                 head.value = k + 1
+            if k < len(items):
+                current[gpu] = k          # inside the locked section: a worker killed right after its claim is still attributed
         if k >= len(items):
             break
-        current[gpu] = k                  # (the parent names the item a dead worker was running)
         item = items[k]
         if len(item) > 1:                 # one MultiPairEngine for the group
             run_group = run_group or _resolve(group_runner)
@@ -184,9 +185,9 @@ def run_batch(root, n_gpus=1, overrides=None, runner="splice_amd.batch:train_run
         try:
             sizes = [_image_sizes(os.path.join(root, n)) for n in names]
         except Exception:
-            if int(pairs_per_gpu) > 1:
-                raise
-            sizes = [((0, 0), (0, 0))] * len(names)    # not images (stub runners): index order, one pair per item
+            if int(pairs_per_gpu) > 1 or runner == "splice_amd.batch:train_runner":
+                raise                                  # the default runner trains IMAGES: an unreadable one is an error here, not later in a worker
+            sizes = [((0, 0), (0, 0))] * len(names)    # custom (stub) runners on directories without images: index order, one pair per item
     items = work_items(sizes, pairs_per_gpu)
     n_gpus = max(1, min(int(n_gpus), len(items)))
     if visible_ids is None:
@@ -220,6 +221,33 @@ def run_batch(root, n_gpus=1, overrides=None, runner="splice_amd.batch:train_run
             if p.exitcode == 0:
                 continue
             k = current[g]
+            if p.exitcode < 0:
+                # a worker killed INSIDE the claim section leaves the shared lock held: every other worker would block on it for ever
+                lk = head.get_lock()
+                if lk.acquire(timeout=10.0):
+                    lk.release()
+                else:
+                    for q in alive.values():
+                        q.terminate()
+                    undone = [n for n in names if not os.path.exists(os.path.join(root, n, "out", "result.json"))]
+                    raise RuntimeError(f"run_batch: worker of gpu {g} was killed by signal {-p.exitcode} while holding the work-list lock; "
+                                       f"the batch cannot continue; pairs without a result: {undone}")
+                if k < 0:
+                    # killed between two items (or before its first claim was visible): hand back whatever was claimed, is unfinished and is not
+                    # some live worker's current item
+                    with lk:
+                        claimed = min(head.value, len(items))
+                        busy = {current[h] for h in alive}
+                        lost = [j for j in range(claimed) if not redo[j] and j not in busy and attempts[j] < int(max_retries)
+                                and any(not os.path.exists(os.path.join(root, names[i], "out", "result.json")) for i in items[j])]
+                        for j in lost:
+                            redo[j] = 1
+                            attempts[j] += 1
+                    if lost or head.value < len(items):
+                        print(f"run_batch: worker of gpu {g} was killed by signal {-p.exitcode} between items; re-queued {[[names[i] for i in items[j]] for j in lost]}, "
+                              "restarting it", file=sys.stderr, flush=True)
+                        alive[g] = spawn(g)
+                        continue
             if p.exitcode < 0 and k >= 0 and attempts[k] < int(max_retries):   # killed by a signal while running item k: hand it back, new worker
                 attempts[k] += 1
                 print(f"run_batch: worker of gpu {g} was killed by signal {-p.exitcode} while running {[names[i] for i in items[k]]}; "

@@ -118,7 +118,11 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     p = __builtin_fmaf(p, u, 5.937872082e-02f);
     p = __builtin_fmaf(p, u, -2.656380534e-01f);
     p = __builtin_fmaf(p, u, 7.978171706e-01f);
-    return __builtin_fmaf(xc, p, 0.5f);   // (outside [-4, 4]: the value at the clamp, 1 + 5e-4 / -5e-4 -- the true derivative there, which decays to 1 / 0)
+    const float d = __builtin_fmaf(xc, p, 0.5f);
+    // Outside [-4, 4] the derivative of gelu_f AS IMPLEMENTED: 0 below -4 (the forward is constant there), Phi(4) above 4 (the forward is x * Phi(4)).
+    // Round 4 returned the fit's values at the clamp (-5e-4 / 1 + 5e-4): a small systematic gradient on every strongly negative fc1
+    // pre-activation; the two selects sit in the backward epilogue only, not in the fc1-forward hot spot the diet was for.
+    return x < -4.0f ? 0.0f : (x > 4.0f ? 0.99997f : d);
 }
 
 // D = A(16xK32) * B(K32x16) + C on one wave.  Operand layout (gfx950, 16x16x32 bf16):

@@ -118,6 +118,7 @@ struct SpliceStep {
     int ablate = 0;                                  // always 0 in the product build.  Scratch builds (-DSPLICE_DEV_SWITCHES) read the SPLICE_STEP_ABLATE bitmask, TIMING experiments only (results are garbage):
                                                      // 1 skip G fwd, 2 skip G bwd, 4 skip ViT bwd, 8 skip target ViT fwd, 16 skip generated ViT fwd, 32 skip the y' chain of the ViT bwd
     std::map<int, hipGraphExec_t> graphs;
+    long graph_updates = 0, graph_update_refusals = 0, graph_instantiations = 0;
     void* graph_ptrs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // arenas + the caller's losses / running buffers a captured graph is bound to
     float* losses_out = nullptr;                     // this step's destination of the [P][8] loss values (written by total_loss_kernel)
     int graph_crops[4] = {0, 0, 0, 0};
@@ -646,9 +647,37 @@ void reap_dead_graphs() {
 }
 }  // namespace
 
+// Round 5: a dropped executable is not retired at all while the PROCESS lives.  It moves to a process-wide spare pool keyed by what fixes the launch
+// SEQUENCE of a step (regime, pairs, crops per pair, phases, ViT depth ...) and the next capture with that key -- by this handle or by the next pair's
+// handle of a batch worker -- UPDATES it in place (hipGraphExecUpdate: same node sequence, new kernel parameters) instead of instantiating a new one:
+// no hipGraphExecDestroy in a running loop (the call the crash above sat behind), no hipGraphInstantiate per capture (the larger part of a capture's
+// cost), and the number of executables a process ever owns is bounded by the step configurations it has run.  An update the runtime refuses (the
+// launch sequence itself changed: another kernel choice at the new sizes) falls back to instantiate; the refused executable goes to the graveyard.
+// SPLICE_STEP_GRAPH_REUSE=0 restores the round-4 policy.
+static bool graph_reuse_on() {
+    static const int on = getenv("SPLICE_STEP_GRAPH_REUSE") ? atoi(getenv("SPLICE_STEP_GRAPH_REUSE")) : 1;
+    return on != 0;
+}
+namespace {
+std::map<unsigned long long, std::vector<hipGraphExec_t>> g_spare;   // guarded by g_dead_mu
+}
+static unsigned long long graph_key(const SpliceStep* st, int variant) {
+    unsigned long long k = (unsigned long long)(unsigned)variant;
+    k = k * 131 + (unsigned)st->P; k = k * 131 + (unsigned)st->Pa; k = k * 131 + (unsigned)st->Pb; k = k * 131 + (unsigned)st->Pe;
+    k = k * 131 + (unsigned)st->overlap; k = k * 131 + (unsigned)st->cfg.top_cls_only; k = k * 131 + (unsigned)st->cfg.fp8_selfsim;
+    k = k * 131 + (unsigned)(st->cfg.ent_h > 0); k = k * 131 + (unsigned)st->skip_adam; k = k * 131 + (unsigned)st->vg.depth; k = k * 131 + (unsigned)st->vg.D;
+    return k;
+}
 static void drop_graphs(SpliceStep* st) {
     reap_dead_graphs();
     if (st->graphs.empty()) return;
+    if (graph_reuse_on()) {
+        // (no synchronize needed here: nothing is destroyed; the update itself waits for the executable's last launch)
+        std::lock_guard<std::mutex> lk(g_dead_mu);
+        for (auto& kv : st->graphs) g_spare[graph_key(st, kv.first)].push_back(kv.second);
+        st->graphs.clear();
+        return;
+    }
     // a replay may still be in flight: the forked (two-branch) graphs must not be retired under the runtime
     if (st->own_stream) (void)hipStreamSynchronize(st->own_stream);
     if (st->side_stream) (void)hipStreamSynchronize(st->side_stream);
@@ -756,9 +785,34 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
                 fprintf(stderr, "[splice graph] variant %d (pairs %d): nodes %zu edges %zu roots %zu\n", variant, P, nn, ne, nr);
             }
             hipGraphExec_t ex = nullptr;
-            const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+            hipGraphExec_t spare = nullptr;
+            if (graph_reuse_on()) {
+                std::lock_guard<std::mutex> lk(g_dead_mu);
+                auto sp = g_spare.find(graph_key(st, variant));
+                if (sp != g_spare.end() && !sp->second.empty()) { spare = sp->second.back(); sp->second.pop_back(); }
+            }
+            if (spare) {   // a retired executable of this step configuration: update it in place
+                hipGraphNode_t bad_node = nullptr;
+                hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
+                // (its last launch -- possibly by another handle -- is long finished when its regime captures again; the device-wide wait is for the
+                // case of a worker that destroys and re-creates engines back to back)
+                (void)hipDeviceSynchronize();
+                if (hipGraphExecUpdate(spare, g, &bad_node, &res) == hipSuccess && res == hipGraphExecUpdateSuccess) {
+                    ex = spare;
+                    ++st->graph_updates;
+                } else {
+                    (void)hipGetLastError();
+                    std::lock_guard<std::mutex> lk(g_dead_mu);
+                    g_dead.push_back(DeadGraph{spare, std::chrono::steady_clock::now()});
+                    ++st->graph_update_refusals;
+                }
+            }
+            if (!ex) {
+                const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+                if (ei != hipSuccess) { (void)hipGraphDestroy(g); splice_set_error("splice_step_run: hipGraphInstantiate: %s", hipGetErrorString(ei)); return SPLICE_ERR_HIP; }
+                ++st->graph_instantiations;
+            }
             (void)hipGraphDestroy(g);
-            if (ei != hipSuccess) { splice_set_error("splice_step_run: hipGraphInstantiate: %s", hipGetErrorString(ei)); return SPLICE_ERR_HIP; }
             it = st->graphs.emplace(variant, ex).first;
         }
         HIPCHK(hipGraphLaunch(it->second, s));
@@ -770,6 +824,14 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
     if (st->dbg_sync) HIPCHK(hipStreamSynchronize(s));
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { splice_set_error("splice_step_run: %s", hipGetErrorString(e)); return SPLICE_ERR_HIP; }
+    return SPLICE_OK;
+}
+
+// out[0..2] = captures that updated a retired executable in place / updates the runtime refused / executables instantiated, by this handle
+int splice_step_graph_stats(void* h, long long* out) {
+    SpliceStep* st = (SpliceStep*)h;
+    if (!st || !out) return SPLICE_ERR_ARG;
+    out[0] = st->graph_updates; out[1] = st->graph_update_refusals; out[2] = st->graph_instantiations;
     return SPLICE_OK;
 }
 

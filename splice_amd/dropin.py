@@ -133,34 +133,47 @@ def _ours(mod):
     return getattr(mod, _MARK, False) or getattr(mod, "__name__", "").startswith("splice_amd")
 
 
+_built = {}        # alias -> module object: built ONCE, so that a second install() binds the same objects (module identity is stable)
+_displaced = {}    # alias -> the foreign module install(force=True) replaced; uninstall() puts it back
+
+
 def install(force=False):
-    """Register the aliases (idempotent).  Raises ImportError if a name is already bound to a module that is not ours."""
-    table = {name: None for name in _PACKAGES}
-    table.update({alias: target for alias, target in _ALIASES.items()})
-    table.update({"models.unet.skip": None, "data.Dataset": None, "data.transforms": None})
-    taken = [n for n in table if n in sys.modules and not _ours(sys.modules[n])]
+    """Register the aliases.  Idempotent: the alias modules are built once and a name already bound to ours is left alone, so module
+    identity does not change between calls.  Raises ImportError if a name is already bound to a module that is not ours; with
+    ``force=True`` the foreign module is remembered and ``uninstall()`` restores it."""
+    names = list(_PACKAGES) + list(_ALIASES) + ["models.unet.skip", "data.Dataset", "data.transforms"]
+    taken = [n for n in names if n in sys.modules and not _ours(sys.modules[n])]
     if taken and not force:
         raise ImportError("splice_amd.dropin: these module names are already imported from elsewhere (a reference checkout on "
                           f"sys.path?): {taken}; import splice_amd.dropin first, or call splice_amd.dropin.install(force=True)")
-    built = {name: _package(name) for name in _PACKAGES}
-    built.update({alias: importlib.import_module(target) for alias, target in _ALIASES.items()})
-    built["models.unet.skip"] = _skip_module()
-    built.update(_data_modules())
-    for name, mod in built.items():
-        if sys.modules.get(name) is not mod and not (name in sys.modules and _ours(sys.modules[name]) and name in _PACKAGES):
-            sys.modules[name] = mod
-            _installed.append(name)
+    if not _built:
+        _built.update({name: _package(name) for name in _PACKAGES})
+        _built.update({alias: importlib.import_module(target) for alias, target in _ALIASES.items()})
+        _built["models.unet.skip"] = _skip_module()
+        _built.update(_data_modules())
+    for name, mod in _built.items():
+        cur = sys.modules.get(name)
+        if cur is mod or (cur is not None and _ours(cur)):
+            continue                      # already ours (this call is a repeat, or the package itself was imported under that name)
+        if cur is not None:
+            _displaced[name] = cur        # force=True: a foreign module gives way, and comes back at uninstall()
+        sys.modules[name] = mod
+        _installed.append(name)
     # attribute access through the parent (`import models.extractor; models.extractor.VitExtractor`)
-    for name in built:
+    for name in _built:
         parent, _, leaf = name.rpartition(".")
         if parent:
             setattr(sys.modules[parent], leaf, sys.modules[name])
-    return sorted(built)
+    return sorted(_built)
 
 
 def uninstall():
+    """Remove what install() bound; foreign modules displaced by ``install(force=True)`` are restored."""
     while _installed:
-        sys.modules.pop(_installed.pop(), None)
+        name = _installed.pop()
+        sys.modules.pop(name, None)
+        if name in _displaced:
+            sys.modules[name] = _displaced.pop(name)
 
 
 install(force=os.environ.get("SPLICE_DROPIN_FORCE") == "1")

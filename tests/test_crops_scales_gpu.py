@@ -71,7 +71,7 @@ def test_n_crops_step_vs_oracle(n_crops):
     """global_A_crops_n_crops = global_B_crops_n_crops = n (conf/default/config.yaml): A_global / B_global are [n,3,s,s] stacks
     (data/transforms.py:27), netG normalises over the stack, util/losses.py:74-105 sums each term over the crops, the entire
     branch stays one image and takes its [CLS] target from the FIRST B crop (zip).  Teacher-forced steps 0..3 (entire +
-    cls; ssim + cls + id; ...; entire again at step 3) against the oracle: losses 3e-2, gradient 5e-2."""
+    cls; ssim + cls + id; ...; entire again at step 3) against the oracle: losses 1e-2, gradient 6e-2 (measured r5: 2.3e-3 / 4.1e-2 -- batch statistics over the crops make the gradient the noisier one)."""
     cfg = dict(dino_model_name="dino_vits8", dino_global_patch_size=64, entire_A_every=3)
     vit_state = synth.vit_params(7, "dino_vits8", img_size=64, w_std=0.05)
     gen_state = synth.generator_params(41, 0.02)
@@ -92,10 +92,10 @@ def test_n_crops_step_vs_oracle(n_crops):
         le = eng.losses()
         assert set(le) == set(lo), (step, sorted(le), sorted(lo))
         for k in lo:
-            assert abs(le[k] - lo[k]) / abs(lo[k]) < 3e-2, (step, k, le[k], lo[k])
+            assert abs(le[k] - lo[k]) / abs(lo[k]) < 1e-2, (step, k, le[k], lo[k])
         rel = _rel_grad(eng, og)
         print(f"    n_crops={n_crops} step {step}: loss {le['loss']:.4f} vs oracle {lo['loss']:.4f}; gradient rel err {rel:.3e}")
-        assert rel < 5e-2, (step, rel)
+        assert rel < 6e-2, (step, rel)
 
 
 def test_multiscale_step_vs_oracle():
@@ -126,13 +126,13 @@ def test_multiscale_step_vs_oracle():
         eng.step(A.to(DEV), B.to(DEV), A.to(DEV))
         le = eng.losses()
         total_f = float(total.detach())
-        assert abs(le["loss"] - total_f) / abs(total_f) < 3e-2, (step, le["loss"], total_f)
+        assert abs(le["loss"] - total_f) / abs(total_f) < 1e-2, (step, le["loss"], total_f)
         for sz, d in zip(scales, per):
             for k, v in d.items():
-                assert abs(le["scales"][sz][k] - float(v.detach())) / abs(float(v.detach())) < 3e-2, (step, sz, k)
+                assert abs(le["scales"][sz][k] - float(v.detach())) / abs(float(v.detach())) < 1e-2, (step, sz, k)
         rel = _rel_grad(eng, og)
         print(f"    multi-scale step {step}: loss {le['loss']:.4f} vs oracle {total_f:.4f}; gradient rel err {rel:.3e}")
-        assert rel < 5e-2, (step, rel)
+        assert rel < 3e-2, (step, rel)
         orcs[0].opt.step(og)
     # the update itself: parameters after the last fused Adam against the oracle's Adam on the oracle gradient
     ref = eng.gen.flatten({k: v.detach() for k, v in orcs[0].params.items()})

@@ -98,3 +98,34 @@ def test_single_image_dataset_contract(tmp_path):
         print('ok')
     """)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_install_is_idempotent_and_uninstall_restores_foreign_modules():
+    """a second install() must bind the SAME module objects; install(force=True) over a foreign ``train`` module must be undone
+    by uninstall().  Child interpreter: the aliases are process-global."""
+    code = r"""
+import sys, types
+import splice_amd.dropin as d
+import train as t1
+skip = sys.modules['models.unet.skip']
+d.install()
+assert sys.modules['models.unet.skip'] is skip and sys.modules['train'] is t1 and sys.modules['data.Dataset'] is sys.modules['data'].Dataset
+d.uninstall()
+assert 'train' not in sys.modules
+foreign = types.ModuleType('train')
+sys.modules['train'] = foreign
+try:
+    d.install()
+    raise SystemExit('install() over a foreign module must raise')
+except ImportError:
+    pass
+d.install(force=True)
+assert sys.modules['train'] is not foreign
+d.uninstall()
+assert sys.modules['train'] is foreign
+print('OK')
+"""
+    import subprocess, sys as _sys, os as _os
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    r = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=dict(_os.environ, PYTHONPATH=root), timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout, r.stderr)

@@ -284,3 +284,31 @@ print("ok")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-1500:], r.stderr[-3000:])
     assert (tmp_path / "pair" / "out" / "output.png").exists()
+
+
+def test_second_backward_with_retain_graph_gives_the_same_gradients():
+    """``_release_once`` / ``_check_resident`` promise that a second backward through the same extractor node
+    (``retain_graph=True``) works.  The engine's backward re-forms what it needs from the RESIDENT activations (qkv, log-sum-exp, block
+    outputs) and sums into its own buffers: a second pass must find them intact.  Block, keys and probability facets, each twice."""
+    from splice_amd.extractor import VitExtractor
+    name, S = "dino_vits8", 32
+    sd = synth.vit_params(7, name, img_size=S, w_std=0.05)
+    ext = VitExtractor(name, DEV, state_dict=sd)
+    x0 = torch.from_numpy(synth.normal(15, "img32b", (1, 3, S, S))).to(DEV)
+    for facet in ("block", "keys", "attn"):
+        x = x0.clone().requires_grad_(True)
+        if facet == "block":
+            f = ext.get_block_feature_from_input(x)
+            loss = (f[11] ** 2).sum() + f[5].sum()
+        elif facet == "keys":
+            loss = (ext.get_keys_from_input(x, 11) ** 2).sum() + ext.get_keys_self_sim_from_input(x, 11).sum()
+        else:
+            p = ext.get_attn_feature_from_input(x)
+            loss = (p[3] ** 2).sum() + (p[11] ** 2).sum()
+        loss.backward(retain_graph=True)
+        g1 = x.grad.clone()
+        x.grad = None
+        loss.backward()
+        g2 = x.grad.clone()
+        assert torch.isfinite(g1).all() and g1.abs().sum() > 0
+        assert torch.equal(g1, g2), (facet, (g1 - g2).abs().max().item())

@@ -183,14 +183,14 @@ def test_top_block_modes_vs_oracle_and_batching(mode):
         le = eng.losses(0)
         assert set(le) == set(lo)
         for k in lo:
-            assert abs(le[k] - lo[k]) / abs(lo[k]) < 3e-2, (step, k, le[k], lo[k])
+            assert abs(le[k] - lo[k]) / abs(lo[k]) < 1e-2, (step, k, le[k], lo[k])
         num = den = 0.0
         for (name, gt), go in zip(eng.gen.unflatten(eng.grads).items(), og):
             if name.endswith("0.bias") and name != "9.0.bias":
                 continue
             num += (gt.cpu().double() - go.reshape(-1).double()).norm().item() ** 2
             den += go.double().norm().item() ** 2
-        assert (num / den) ** 0.5 < 5e-2, (step, (num / den) ** 0.5)
+        assert (num / den) ** 0.5 < 3e-2, (step, (num / den) ** 0.5)
     multi = MultiPairEngine(cfg, None, gens, (64, 64), (64, 64), vit_engine=eng.vit, top_cls_only=mode)
     for _ in range(4):
         multi.step(A, B, A)

@@ -17,3 +17,9 @@ for phase in range(4):
             eng.step(A[:, :sa, :sa].contiguous(), B[:, :sb, :sb].contiguous(), A)
     m = mem()
     print(f"phase {phase} ({'fixed' if phase % 2 == 0 else 'random'} crops): {1500 / (time.perf_counter() - t0):.1f} steps/s, device memory in use {m:.0f} MiB, loss {eng.losses()['loss']:.4f}", flush=True)
+
+import ctypes as C
+from splice_amd import _lib
+st = (C.c_longlong * 3)()
+_lib.check(_lib.lib().splice_step_graph_stats(eng.handle, st))
+print("graph executables of this handle: updated in place %d, updates refused %d, instantiated %d" % tuple(st), flush=True)
