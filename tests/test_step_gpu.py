@@ -3,18 +3,19 @@ recorded from the REFERENCE loop (Model + LossG + Adam, oracle/make_golden.py) a
 
 Tolerances (bf16 ViT, fp32 generator/losses/Adam; round 5: 2-3 x the measured deviations, profiles/r05_step_tests_verbose.txt --
 teacher-forced losses 1.4e-3 .. 2.8e-3 measured, bar 1e-2; whole-arena generator gradient 4e-3 .. 1.8e-2 measured, bar 3e-2; the
-outlier-weight / real-checkpoint tests keep 2e-2 / 3e-2, the n_crops batches 3e-2 / 6e-2): every entry of the loss dict within 1e-2
-relative at steps 0-2 (identical parameters on both sides up to one or two updates).  After that
-the trajectory is CHAOTIC in the optimiser itself: Adam with beta1=0 takes ~lr-sized steps along
-sign(g), so any gradient perturbation re-routes it.  Measured with the fp32 CPU oracle (DESIGN.md
-"trajectory sensitivity"): 2 % multiplicative gradient noise moves the loss at step 72 of this very
-fixture from 99.8 to 58..84, i.e. pointwise agreement beyond ~10 steps is not a property the
-reference itself has.  So: 6-step window means within 25 % up to step 30; from there to the end a TWO-SIDED band on the window means
-(0.35 .. 1.30 x the reference's: the fp32 oracle with 2 % gradient noise sits at 0.58 .. 0.84 x, the bf16 engine measured 0.5 x at
-the tail) and on the level reached (0.40 .. 1.25 x); and -- what the band cannot do -- the REPORTED loss of the free-running
-engine is pinned pointwise: at steps 30, 54, 75 and 77 the fp32 oracle is evaluated at the engine's own parameters of that step
-(same point => the chaos argument does not apply) and every loss entry must agree within 1e-2 (measured 2.2e-3).  A bug that lowers (or raises) the
-reported loss after the first steps fails that check whatever the trajectory does.
+outlier-weight / real-checkpoint tests keep 2e-2 / 3e-2, the n_crops batches 1e-2 / 6e-2): every entry of the loss dict within 1e-2
+relative at steps 0-2 (identical parameters on both sides up to one or two updates).
+
+After that NO implementation can be compared pointwise, the reference included: Adam with beta1 = 0 moves every parameter by ~lr whatever
+the size of its gradient component, so rounding-level differences in near-zero components re-route the run.  Measured with the fp32 CPU
+oracle (oracle/trajectory_ensemble.py, tests/golden/trajectory_ensemble.json): the SAME fp32 code with one thread against many threads is
+above 2 % from step 6, up to 84 % apart, 20.7 dB between the two final images.  So the free run is checked two ways:
+  * as a member of a family -- its 6-step window means, the level it reaches and its final image (PSNR, channel statistics) must lie inside
+    the range of that ensemble (the fp32 loop with another thread count and with gradient noise of relative size 1e-2 / 2e-2, 8 seeds each;
+    the engine's measured gradient error along the run is 1e-2 .. 6e-2), widened by 10 %;
+  * pointwise where pointwise MEANS something -- at 15 steps of the free run the fp32 oracle is evaluated at the engine's own parameters of
+    that step: every reported loss entry within 1e-2 (measured 3.8e-3) and the gradient the engine descended along is recorded against the
+    oracle's (1e-2 .. 6e-2 whole-arena relative L2).  A bias in a loss term or in the direction of descent fails there whatever the trajectory does.
 """
 import os
 
@@ -27,8 +28,6 @@ from splice_amd.engine import LOSS_KEYS, SpliceEngine
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-# bars of the output-pixel check in test_trajectory_a (set from the measured values)
-PIX_MEAN_TOL, PIX_STD_TOL, PIX_PSNR_FLOOR = 0.05, 0.6, 15.0   # measured r2 (two engine versions): <= 0.034, <= 0.45, 17.0 / 18.5 dB
 
 
 def _engine(cfg_over, A, B, gen_seed, img_size):
