@@ -298,7 +298,7 @@ def test_second_backward_with_retain_graph_gives_the_same_gradients():
     for facet in ("block", "keys", "attn"):
         x = x0.clone().requires_grad_(True)
         if facet == "block":
-            f = ext.get_block_feature_from_input(x)
+            f = ext.get_feature_from_input(x)
             loss = (f[11] ** 2).sum() + f[5].sum()
         elif facet == "keys":
             loss = (ext.get_keys_from_input(x, 11) ** 2).sum() + ext.get_keys_self_sim_from_input(x, 11).sum()
