@@ -836,7 +836,44 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
 // chip: stage 1 = PB workgroups per (image, channel) plane write partials; stage 2 = the consuming
 // element-wise kernel recombines the <= 64 partials in a fixed order in its prologue.
 constexpr int MAX_PB = 64;
-__host__ __device__ inline int seg_len(int HW, int PB) { return (HW + PB - 1) / PB; }
+// Planes of more than 64 x 1024 pixels (every 448^2 / 512^2 / 900^2 layer; round 5): up to MAX_PB_V segments of <= BN_V_CH x 1024 pixels whose
+// length is a multiple of 4, so that a thread owns runs of 4 consecutive pixels and moves them as ONE 16-byte access (4-byte aligned:
+// gfx950's global accesses need dword alignment only, so odd plane sizes -- the random 855 .. 900 crops -- need no peeling).  A segment
+// count above MAX_PB is what selects that layout everywhere (seg_len, the combines); the 224^2 layers keep theirs, bit for bit.
+constexpr int MAX_PB_V = 256;
+constexpr int BN_V_CH = 5;   // 16-byte runs a thread holds: 5 x 4 x 256 = 5120 pixels per segment at most (1.31 M pixel planes)
+__host__ __device__ inline int seg_len(int HW, int PB) {
+    const int s = (HW + PB - 1) / PB;
+    return PB > MAX_PB ? (s + 3) & ~3 : s;
+}
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+// run k of this thread inside the segment [lo, hi): pixels i .. i + 3, i = lo + 4 (threadIdx.x + 256 k); pixels behind `hi` read as 0
+__device__ __forceinline__ void ld_run(const float* __restrict__ p, int i, int hi, float (&v)[4]) {
+    if (i + 3 < hi) {
+        const f4u t = *(const f4u*)(p + i);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = i + j < hi ? p[i + j] : 0.f;
+    }
+}
+__device__ __forceinline__ void st_run(float* __restrict__ p, int i, int hi, const float (&v)[4]) {
+    if (i + 3 < hi) {
+        f4u t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+        *(f4u*)(p + i) = t;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i + j < hi) p[i + j] = v[j];
+    }
+}
+// fixed-order sum of component `comp` of the PB per-segment pairs of a plane by one wave (PB <= 64: lane b holds segment b, as before)
+__device__ __forceinline__ float part_sum(const float* __restrict__ pp, int PB, int comp, int lane) {
+    if (PB <= MAX_PB) return wave_sum(lane < PB ? pp[2 * lane + comp] : 0.f);
+    float a = 0.f;
+    for (int b = lane; b < PB; b += 64) a += pp[2 * b + comp];
+    return wave_sum(a);
+}
 
 // x2 bilinear (align_corners=False) source coordinates of output o, and one upsampled value from a plane p[h][w] (global
 // or LDS): the expression order of upsample2x_fwd_kernel
@@ -954,6 +991,56 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* y, s
     }
 }
 
+// the same stage for the big planes (PB > MAX_PB): the segment sits in registers as BN_V_CH runs of 4 pixels per thread, loaded (or, for an
+// upsampled channel, produced and stored) with 16-byte accesses that are all in flight before the first sum
+__global__ __launch_bounds__(256) void bn_stats_partial_v_kernel(const float* y, size_t nstride, int C, int HW, int PB,
+                                                                 float* __restrict__ part /* [N][C][PB][2] */, BnUpsample up) {
+    __shared__ float red[8];
+    const int pb = blockIdx.x, c = blockIdx.y, img = blockIdx.z;
+    const int seg = seg_len(HW, PB), lo = pb * seg, hi = min(lo + seg, HW);
+    const float* p = y + (size_t)img * nstride + (size_t)c * HW;
+    float keep[BN_V_CH][4];
+    if (up.src && c >= up.c0) {
+        const float* sp = up.src + (size_t)img * up.src_ns + (size_t)(c - up.c0) * up.h * up.w;
+        float* yo = const_cast<float*>(p);
+#pragma unroll
+        for (int k = 0; k < BN_V_CH; ++k) {
+            const int i = lo + 4 * (threadIdx.x + 256 * k);
+            int oy = i / up.Wo, ox = i - oy * up.Wo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                keep[k][j] = i + j < hi ? up_value(sp, up.h, up.w, oy, ox) : 0.f;
+                if (++ox == up.Wo) { ox = 0; ++oy; }
+            }
+            if (i < hi) st_run(yo, i, hi, keep[k]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < BN_V_CH; ++k) ld_run(p, lo + 4 * (threadIdx.x + 256 * k), hi, keep[k]);
+    }
+    float s = 0.f, dummy = 0.f;
+#pragma unroll
+    for (int k = 0; k < BN_V_CH; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += keep[k][j];   // (pixels behind `hi` are zeros)
+    block_sum2(s, dummy, red);
+    const int cnt = hi - lo;
+    const float m = cnt > 0 ? s / (float)cnt : 0.f;
+    float sq = 0.f;
+    dummy = 0.f;
+#pragma unroll
+    for (int k = 0; k < BN_V_CH; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lo + 4 * ((int)threadIdx.x + 256 * k) + j < hi) { const float d = keep[k][j] - m; sq = __builtin_fmaf(d, d, sq); }
+    block_sum2(sq, dummy, red);
+    if (threadIdx.x == 0) {
+        float* o = part + (((size_t)img * C + c) * PB + pb) * 2;
+        o[0] = m;
+        o[1] = sq;
+    }
+}
+
 // Chan et al. pairwise combination of the <= 64 segment statistics by ONE wave: lane b holds segment b, a fixed
 // binary tree (lane l absorbs lane l + off, off = 32 .. 1) leaves the plane's (mean, M2) in lane 0.  Deterministic, and
 // ~100 cycles instead of a 49-step dependent chain in front of every workgroup of the apply kernel.
@@ -970,6 +1057,21 @@ __device__ __forceinline__ void bn_combine_wave_raw(const float* part, int PB, i
     int cnt = lane < PB ? min(lo + seg, HW) - lo : 0;
     cnt = cnt > 0 ? cnt : 0;
     float n = (float)cnt, m = cnt > 0 ? part[2 * lane] : 0.f, M2 = cnt > 0 ? part[2 * lane + 1] : 0.f;
+    if (PB > MAX_PB) {   // big planes: lane l first merges its G consecutive segments l G .. l G + G - 1 in order, then the same tree
+        const int G = (PB + 63) >> 6;
+        n = 0.f; m = 0.f; M2 = 0.f;
+        for (int g = 0; g < G; ++g) {
+            const int b = lane * G + g, blo = b * seg;
+            const int bc = b < PB ? min(blo + seg, HW) - blo : 0;
+            if (bc > 0) {
+                const float nb = (float)bc, mb = part[2 * b], Mb = part[2 * b + 1];
+                const float nt = n + nb, d = mb - m, w = nb / nt;
+                m += d * w;
+                M2 += Mb + d * d * n * w;
+                n = nt;
+            }
+        }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float nb = __shfl_down(n, off, 64), mb = __shfl_down(m, off, 64), Mb = __shfl_down(M2, off, 64);
@@ -1023,6 +1125,23 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y
     const float sh = beta[c] - st[0] * sc;
     const float* p = y + (size_t)img * y_nstride + (size_t)c * HW;
     float* q = out + (size_t)img * out_nstride + (size_t)c * HW;
+    if (PB > MAX_PB) {   // big planes: the workgroup's own segment as 16-byte runs, all loads in flight before the first store
+        const int seg = seg_len(HW, PB), lo = blockIdx.x * seg, hi = min(lo + seg, HW);
+        float v[BN_V_CH][4];
+#pragma unroll
+        for (int k = 0; k < BN_V_CH; ++k) ld_run(p, lo + 4 * (threadIdx.x + 256 * k), hi, v[k]);
+#pragma unroll
+        for (int k = 0; k < BN_V_CH; ++k) {
+            const int i = lo + 4 * (threadIdx.x + 256 * k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = v[k][j] * sc + sh;
+                v[k][j] = t > 0.f ? t : t * slope;
+            }
+            if (i < hi) st_run(q, i, hi, v[k]);
+        }
+        return;
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
         const float v = p[i] * sc + sh;
         q[i] = v > 0.f ? v : v * slope;
@@ -1042,6 +1161,26 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     const float* pa = aout + (size_t)img * a_nstride + (size_t)c * HW;
     const float* py = y + (size_t)img * y_nstride + (size_t)c * HW;
     float s1 = 0.f, s2 = 0.f;
+    if (PB > MAX_PB) {
+        const bool act = slope != 1.0f;
+        float d[BN_V_CH][4], a[BN_V_CH][4], yy[BN_V_CH][4];
+#pragma unroll
+        for (int k = 0; k < BN_V_CH; ++k) {
+            const int i = lo + 4 * (threadIdx.x + 256 * k);
+            ld_run(pd, i, hi, d[k]);
+            ld_run(py, i, hi, yy[k]);
+            if (act) ld_run(pa, i, hi, a[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < BN_V_CH; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {   // (pixels behind `hi`: dz = 0 adds nothing to either sum)
+                float dz = d[k][j];
+                if (act && !(a[k][j] > 0.f)) dz *= slope;
+                s1 += dz;
+                s2 += dz * (yy[k][j] - m) * r;
+            }
+    } else
     for (int i = lo + threadIdx.x; i < hi; i += 256) {
         float dz = pd[i];
         if (slope != 1.0f && !(pa[i] > 0.f)) dz *= slope;
@@ -1069,7 +1208,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     if (threadIdx.x < 64) {   // one wave: lane k holds segment k (PB <= 64), fixed-order tree sums
         const int lane = threadIdx.x;
         const float* pp = part + ((size_t)img * C + c) * PB * 2;
-        const float a = wave_sum(lane < PB ? pp[2 * lane] : 0.f), b = wave_sum(lane < PB ? pp[2 * lane + 1] : 0.f);
+        const float a = part_sum(pp, PB, 0, lane), b = part_sum(pp, PB, 1, lane);
         if (lane == 0) { st[0] = a; st[1] = b; }
         if (p_nstride) {   // independent images: every image owns its parameter gradients (the sums of the N = 1 path: 0 + x)
             if (blockIdx.x == 0 && lane == 0) {
@@ -1083,8 +1222,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             float g = 0.f, be = 0.f;
             for (int n = 0; n < N; ++n) {
                 const float* pn = part + ((size_t)n * C + c) * PB * 2;
-                be += wave_sum(lane < PB ? pn[2 * lane] : 0.f);
-                g += wave_sum(lane < PB ? pn[2 * lane + 1] : 0.f);
+                be += part_sum(pn, PB, 0, lane);
+                g += part_sum(pn, PB, 1, lane);
             }
             if (lane == 0) {
                 dgamma[c] = accumulate ? dgamma[c] + g : g;
@@ -1097,8 +1236,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         float a = 0.f, b = 0.f;
         for (int n = 0; n < N; ++n) {
             const float* pn = part + ((size_t)n * C + c) * PB * 2;
-            a += wave_sum(lane < PB ? pn[2 * lane] : 0.f);
-            b += wave_sum(lane < PB ? pn[2 * lane + 1] : 0.f);
+            a += part_sum(pn, PB, 0, lane);
+            b += part_sum(pn, PB, 1, lane);
         }
         if (lane == 0) { st[0] = a; st[1] = b; }
     }
@@ -1111,6 +1250,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const float* pa = aout + (size_t)img * a_nstride + (size_t)c * HW;
     const float* py = y + (size_t)img * y_nstride + (size_t)c * HW;
     float* po = dy + (size_t)img * dy_nstride + (size_t)c * HW;
+    if (PB > MAX_PB) {
+        const int seg = seg_len(HW, PB), lo = blockIdx.x * seg, hi = min(lo + seg, HW);
+        const bool act = slope != 1.0f;
+        float d[BN_V_CH][4], a[BN_V_CH][4], yy[BN_V_CH][4];
+#pragma unroll
+        for (int k = 0; k < BN_V_CH; ++k) {
+            const int i = lo + 4 * (threadIdx.x + 256 * k);
+            ld_run(pd, i, hi, d[k]);
+            ld_run(py, i, hi, yy[k]);
+            if (act) ld_run(pa, i, hi, a[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < BN_V_CH; ++k) {
+            const int i = lo + 4 * (threadIdx.x + 256 * k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float dz = d[k][j];
+                if (act && !(a[k][j] > 0.f)) dz *= slope;
+                d[k][j] = gr * (dz - k1 - (yy[k][j] - m) * r * k2);
+            }
+            if (i < hi) st_run(po, i, hi, d[k]);
+        }
+        return;
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
         float dz = pd[i];
         if (slope != 1.0f && !(pa[i] > 0.f)) dz *= slope;
@@ -1811,7 +1974,17 @@ static inline bool bn_mid_ok(int HW, int N, size_t p_nstride, int batch) {
     } while (0)
 // 512-pixel segments (tuned in-step with alternating runs: 1024 +0.45 %, 256 / 384 +0.1 %, 2048 +1.3 %)
 static inline int plane_blocks(int HW) { int b = cdiv(HW, 512); return b < 1 ? 1 : (b > MAX_PB ? MAX_PB : b); }
-int bn_part_floats(int N, int C) { return N * C * MAX_PB * 2; }
+int bn_part_floats(int N, int C) { return N * C * MAX_PB_V * 2; }
+// big planes (round 5): segments of <= 4096 pixels moved in 16-byte runs; SPLICE_BN_VEC=0 keeps the 64-segment scalar layout everywhere
+static inline bool bn_vec_ok(int HW) {
+    static const int on = getenv("SPLICE_BN_VEC") ? atoi(getenv("SPLICE_BN_VEC")) : 1;
+    return on && HW > MAX_PB * 1024 && (long long)HW <= (long long)MAX_PB_V * BN_V_CH * 1024;
+}
+static inline int bn_plane_blocks(int HW) {
+    if (!bn_vec_ok(HW)) return plane_blocks(HW);
+    const int b = cdiv(HW, 4096);
+    return b <= MAX_PB ? MAX_PB + 1 : (b > MAX_PB_V ? MAX_PB_V : b);
+}
 // (chained or not, the skip branch's BatchNorm yields the same bits -- shared arithmetic helpers with pinned roundings,
 // tests/test_generator_gpu.py::test_launch_count_forms_are_bit_neutral -- so this is a pure launch-count choice.  With the chained
 // skip convolution's split-K slabs summed inside the concat kernel it wins at every batch size: -1.3 % step time at one pair per
@@ -1844,8 +2017,9 @@ int bn_fwd_launch(const float* y, size_t y_nstride, float* out, size_t out_nstri
         SPLICE_LAUNCH(bn_mid_fwd_kernel, dim3(C, N), dim3(BN_MID_THREADS), (size_t)(((HW + 3) & ~3) + (u.src ? BN_MID_SRC : 0)) * 4, s, y, y_nstride, out, out_nstride, C, HW, gamma, beta, eps, mean, rstd, slope, u, p_nstride, pr);
         return SPLICE_OK;
     }
-    const int PB = plane_blocks(HW);
-    SPLICE_LAUNCH(bn_stats_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, C, HW, PB, part, u);
+    const int PB = bn_plane_blocks(HW);
+    if (PB > MAX_PB) SPLICE_LAUNCH(bn_stats_partial_v_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, C, HW, PB, part, u);
+    else SPLICE_LAUNCH(bn_stats_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, C, HW, PB, part, u);
     SPLICE_LAUNCH(bn_act_kernel, dim3(PB, C, N), dim3(256), 0, s, y, y_nstride, out, out_nstride, C, HW, PB, gamma, beta, part, eps, mean, rstd, slope, p_nstride, batch);
     return SPLICE_OK;
 }
@@ -1886,7 +2060,7 @@ int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t 
                       rstd, slope, dgamma, dbeta, accumulate, u, p_nstride, pr);
         return SPLICE_OK;
     }
-    const int PB = plane_blocks(HW);
+    const int PB = bn_plane_blocks(HW);
     SPLICE_LAUNCH(bn_bwd_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, C, HW, PB, mean, rstd, slope, part);
     SPLICE_LAUNCH(bn_bwd_apply_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy,
                        dy_nstride, C, HW, N, PB, gamma, mean, rstd, slope, part, dgamma, dbeta, accumulate, p_nstride, batch);
