@@ -318,7 +318,7 @@ static int unit_backward_bn(const SpliceGenPlan* p, const Unit& u, const float* 
         BnSlabs sl;
         if (pend.target) { sl.slabs = pend.slabs; sl.ksplit = pend.ksplit; sl.accumulate = pend.accumulate; pend.target = nullptr; }
         RC(bn_bwd_launch(u.d_out, u.d_out_ns, u.out, u.out_ns, y, y_ns, dy, dy_ns, N, u.Cout, HW, params + u.g_off, u.mean, u.rstd, u.slope,
-                         u.s1, grads + u.g_off, grads + u.be_off, acc, s, p->batch_stats ? nullptr : up, p->p_nstride, p->batch_stats, pre, &sl));
+                         u.s1, grads + u.g_off, grads + u.be_off, acc, s, p->batch_stats ? nullptr : up, p->p_nstride, p->batch_stats, pre, &sl, params + u.be_off));
     }
     if (!u.ks) return SPLICE_OK;
     // The bias of a conv that feeds a train-mode BatchNorm has an analytically ZERO gradient (BN subtracts the

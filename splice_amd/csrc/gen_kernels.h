@@ -118,7 +118,7 @@ int bn_fwd_slabs_launch(const float* slabs, int ksplit, const float* bias, float
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
                   float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up = nullptr, size_t p_nstride = 0,
-                  int batch = 0, const BnPre* pre = nullptr, const BnSlabs* slabs = nullptr);
+                  int batch = 0, const BnPre* pre = nullptr, const BnSlabs* slabs = nullptr, const float* beta = nullptr);
 int fill_zero_launch(float* p, int n, hipStream_t s);
 int channel_sum_launch(const float* dy, size_t nstride, int N, int C, int HW, float* db, int accumulate, hipStream_t s);
 int upsample2x_fwd_launch(const float* in, size_t in_nstride, float* out, size_t out_nstride, int N, int C, int h, int w, int Ho, int Wo, hipStream_t s);

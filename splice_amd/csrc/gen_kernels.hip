@@ -7,6 +7,12 @@
 // in a fixed order (no float atomics): replicas are bit-reproducible.
 #include "gen_kernels.h"
 #include <atomic>
+#ifndef CONV_KB
+#define CONV_KB 6   // k steps per LDS fragment batch of conv_igemm_body at one output-channel fragment per workgroup (0: the whole tile at once); 3 at 2 or 4 fragments
+#endif
+#ifndef CONV_ABL
+#define CONV_ABL 0   // timing ablations of conv_igemm_body (tools/conv_ablate.sh): 1 = no MFMA, 2 = no gather after the first tile, 3 = one k step per tile
+#endif
 #include <cstdlib>
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -50,7 +56,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, int bx, int b
     constexpr int KSTEPS = KT / 4 / NG;             // MFMA k steps per wave group per tile
     static_assert(KT % (4 * NG) == 0 && ((LDW / 2) & 1) == 1, "tile shape");
     static_assert(NG == 1 || KT * LDA >= FN * 4 * 256, "accumulator exchange reuses the A tile");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: what depends only on it stays out of the VGPRs)
     const int pw = wave & 3, grp = wave >> 2;       // pixel fragment / wave group
     const int img = bz;
     const int m0 = bx * BM;
@@ -131,11 +137,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, int bx, int b
     int a_vo[NA], w_vo[NW];
 #pragma unroll
     for (int i = 0; i < NA; ++i) a_vo[i] = ((a_ok >> i) & 1ull) ? a_off[i] * 4 : (int)0x80000000;
+#if CONV_ABL == 4   // prologue ablation: one cheap offset per element instead of the descriptor arithmetic above (which becomes dead code)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a_vo[i] = (pl + 64 * i) * 4;
+#endif
 #pragma unroll
     for (int t = 0; t < NW; ++t) w_vo[t] = ((w_ok >> t) & 1ull) ? w_off[t] * 4 : (int)0x80000000;
     auto fetch = [&](int c0) {
         if (c0 + CK <= Kc) {
             const int so_a = __builtin_amdgcn_readfirstlane(c0 * (int)a.in_cstride * 4), so_w = __builtin_amdgcn_readfirstlane(c0 * (int)a.w_cstride * 4);
+#if CONV_ABL == 2
+            if (c0 != cbeg) return;
+#endif
 #pragma unroll
             for (int i = 0; i < NA; ++i) av[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, a_vo[i], so_a, 0));
 #pragma unroll
@@ -145,32 +158,66 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, int bx, int b
         const float* inc = in + (size_t)c0 * a.in_cstride;
         const float* wc = wgt + (size_t)c0 * a.w_cstride;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) av[i] = ((a_ok >> i) & 1ull) && (c0 + a_cl[i] < Kc) ? inc[a_off[i]] : 0.f;
+        for (int i = 0; i < NA; ++i) av[i] = a_vo[i] >= 0 && (c0 + a_cl[i] < Kc) ? inc[a_vo[i] >> 2] : 0.f;
 #pragma unroll
-        for (int t = 0; t < NW; ++t) wv[t] = ((w_ok >> t) & 1ull) && (c0 + w_cl[t] < Kc) ? wc[w_off[t]] : 0.f;
+        for (int t = 0; t < NW; ++t) wv[t] = w_vo[t] >= 0 && (c0 + w_cl[t] < Kc) ? wc[w_vo[t] >> 2] : 0.f;
     };
     f32x4 acc[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     fetch(cbeg);
+    // LDS addresses as ONE base per access family + compile-time offsets (the instruction's offset field).  The bases are re-defined (an empty asm) in
+    // every trip: hoisted out of the loop as invariants, the 18 + 18 + 18 sums each sat in a register of their own (167 -> 188 VGPRs with the batches)
+    // (integer indices, not pointers: a pointer that went through an asm loses its LDS address space and the accesses become flat)
+    int a_wr = wave * LDA + pl;
+    int a_rd = (grp * KSTEPS * 4 + (lane >> 4)) * LDA + pw * 16 + (lane & 15);
+    int w_rd = (lane & 15) * LDW + grp * KSTEPS * 4 + (lane >> 4);
     for (int c0 = cbeg; c0 < Kc; c0 += CK) {
+        asm volatile("" : "+v"(a_wr), "+v"(a_rd), "+v"(w_rd));
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < NA; ++i) As[(wave + NWV * i) * LDA + pl] = av[i];
+        for (int i = 0; i < NA; ++i) As[a_wr + NWV * i * LDA] = av[i];
 #pragma unroll
         for (int t = 0; t < NW; ++t)
             if (w_lds[t] >= 0) Ws[w_lds[t]] = wv[t];
         __syncthreads();
         if (c0 + CK < Kc) fetch(c0 + CK);
+        // The fragments of KB k steps are read from LDS as one batch, and the NEXT batch is on its way while this one feeds the MFMAs (round 5:
+        // the compiler's own order was read -> wait -> MFMA per k step, an exposed LDS round trip in front of every one of the 18 MFMAs of a tile;
+        // same operands in the same order, same bits).
+        constexpr int KB0 = FN == 1 ? CONV_KB : 3;
+        constexpr int KB = KB0 > 0 ? (KB0 < KSTEPS ? KB0 : KSTEPS) : KSTEPS;
+        float af[2][KB], bf[2][FN][KB];
+        auto frag = [&](int buf, int k0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const int kk = grp * KSTEPS + ks;
-            const float a_ = As[(kk * 4 + (lane >> 4)) * LDA + pw * 16 + (lane & 15)];
+            for (int t = 0; t < KB; ++t) {
+                if (k0 + t >= KSTEPS) break;
+                af[buf][t] = As[a_rd + (k0 + t) * 4 * LDA];
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const float b_ = Ws[(j * 16 + (lane & 15)) * LDW + kk * 4 + (lane >> 4)];
-                acc[j] = mfma4(a_, b_, acc[j]);
+                for (int j = 0; j < FN; ++j) bf[buf][j][t] = Ws[w_rd + j * 16 * LDW + (k0 + t) * 4];
             }
+        };
+        frag(0, 0);
+#pragma unroll
+        for (int k0 = 0, cur = 0; k0 < KSTEPS; k0 += KB, cur ^= 1) {
+            if (k0 + KB < KSTEPS) frag(cur ^ 1, k0 + KB);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < KB; ++t) {
+                if (k0 + t >= KSTEPS) break;
+#if CONV_ABL == 3
+                if (k0 + t) continue;
+#endif
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+#if CONV_ABL == 1
+                    acc[j][0] += af[cur][t] * bf[cur][j][t];
+#else
+                    acc[j] = mfma4(af[cur][t], bf[cur][j][t], acc[j]);
+#endif
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (NG == 2) {   // second wave group -> first, through the (now idle) A tile
@@ -302,7 +349,15 @@ static ConvPolicy conv_policy(const ConvArgs& a, int KS, int CK) {
     // summation order) keeps using the one-image fragment count.
     static const int batch_fn = getenv("SPLICE_CONV_BATCH_FN") ? atoi(getenv("SPLICE_CONV_BATCH_FN")) : 2;
     static const int batch_min = getenv("SPLICE_CONV_BATCH_MIN") ? atoi(getenv("SPLICE_CONV_BATCH_MIN")) : 4;
-    const int fn_run = (KS < 5 && fn == 1 && a.Cout >= 64 && a.N >= batch_min && (batch_fn == 2 || batch_fn == 4)) ? batch_fn : fn;
+    int fn_run = (KS < 5 && fn == 1 && a.Cout >= 64 && a.N >= batch_min && (batch_fn == 2 || batch_fn == 4)) ? batch_fn : fn;
+    // Big planes (round 5; the reference's default 855 .. 900 crops, 448^2, 512^2): thousands of pixel tiles per layer fill the chip whatever the
+    // channel split, and every 16-channel fragment a workgroup does NOT own is a second gather of the same input tile by another workgroup
+    static const int big_fn = getenv("SPLICE_CONV_BIG_FN") ? atoi(getenv("SPLICE_CONV_BIG_FN")) : 4;   // same-box A/B at 900 x 1200: 0 -> 10.14, 2 -> 10.12, 4 -> 10.10 ms per step
+    static const int big_mt = getenv("SPLICE_CONV_BIG_MT") ? atoi(getenv("SPLICE_CONV_BIG_MT")) : 512;
+    if (KS < 5 && (big_fn == 2 || big_fn == 4) && mt >= big_mt && a.Cout > 16) {
+        const int want = a.Cout > 32 ? big_fn : 2;
+        if (want > fn_run) fn_run = want;
+    }
     const int nt_run = cdiv(a.Cout, 16 * fn_run);
     // launch policy (split-K, 8-wave workgroups) from the workgroups of ONE image when the images are independent pairs:
     // split-K changes the summation order, and a pair's result must not depend on how many pairs share the launch
@@ -579,7 +634,13 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, int chunk, i
         }
     };
     fetch(p_begin);
+    // fragment reads in batches of WB pixel steps, the next batch in flight under this one's MFMAs (round 5, as in conv_igemm_body: the compiler's
+    // order was read -> wait -> MFMA per step); one LDS base per operand + compile-time offsets, re-defined per fill so that they are not hoisted
+    // into a register each.  Same operands, same order, same bits.
+    constexpr int WB = 4, NB = PC / 4 / WB;
+    [[maybe_unused]] int lds_rd = (lane & 15) * LD + (lane >> 4);
     for (int pb = p_begin; pb < p_end; pb += PC) {
+        if constexpr (NI < 4) asm volatile("" : "+v"(lds_rd));
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NA; ++i) Xs[(wave + 4 * i) * LD + pl] = xv[i];
@@ -595,11 +656,29 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, int chunk, i
             const int pair = wave + 4 * q;
             if (pair < NI * NJ) {
                 const int fi = pair / NJ, fj = pair % NJ;
+                if constexpr (NI >= 4) {   // the 64- and 128-channel bodies sit at the 2-waves-per-SIMD register limit: they keep the plain order
 #pragma unroll
-                for (int s4 = 0; s4 < PC / 4; ++s4) {
-                    const float av = Ds[(fi * 16 + (lane & 15)) * LD + s4 * 4 + (lane >> 4)];
-                    const float bv = Xs[(fj * 16 + (lane & 15)) * LD + s4 * 4 + (lane >> 4)];
-                    acc[q] = mfma4(av, bv, acc[q]);
+                    for (int s4 = 0; s4 < PC / 4; ++s4) {
+                        const float av = Ds[(fi * 16 + (lane & 15)) * LD + s4 * 4 + (lane >> 4)];
+                        const float bv = Xs[(fj * 16 + (lane & 15)) * LD + s4 * 4 + (lane >> 4)];
+                        acc[q] = mfma4(av, bv, acc[q]);
+                    }
+                } else {
+                    const int d_rd = lds_rd + fi * 16 * LD, x_rd = lds_rd + fj * 16 * LD;
+                    float af[2][WB], bf[2][WB];
+#pragma unroll
+                    for (int t = 0; t < WB; ++t) { af[0][t] = Ds[d_rd + t * 4]; bf[0][t] = Xs[x_rd + t * 4]; }
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        if (b + 1 < NB) {
+#pragma unroll
+                            for (int t = 0; t < WB; ++t) { af[(b + 1) & 1][t] = Ds[d_rd + ((b + 1) * WB + t) * 4]; bf[(b + 1) & 1][t] = Xs[x_rd + ((b + 1) * WB + t) * 4]; }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 0; t < WB; ++t) acc[q] = mfma4(af[b & 1][t], bf[b & 1][t], acc[q]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
         }
@@ -732,7 +811,7 @@ int wgrad_chunks(int N, int Ho, int Wo, int* pix_per_chunk, int* chunks_per_img)
 // several workgroups per CU -- these are the layers with thousands of workgroups), BIG = true the 64 / 128-channel ones
 // (up to 229 VGPRs).  One kernel for everything ran the small layers at the big variant's occupancy.
 template <bool BIG>
-__global__ __launch_bounds__(256) void conv_wgrad_batched_kernel(WgradBatch b) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_batched_kernel(WgradBatch b) {
     __shared__ float Xs[WG_XS_FLOATS];
     __shared__ float Ds[(BIG ? 8 : 2) * 16 * WG_LD];
     int l = 0;
@@ -1103,6 +1182,10 @@ __device__ __forceinline__ void bn_combine_batch(const float* part_c0 /* image 0
     rstd = rsqrtf(M2 / n + eps);
 }
 
+// the affine map of the big-plane forward with its two roundings pinned (one fma each), so that the backward can re-form the pre-activation
+// value from y, mean, rstd, gamma, beta to the bit and read the activation's sign off it instead of loading the activated tensor
+__device__ __forceinline__ float bn_shift(float beta, float mean, float sc) { return __builtin_fmaf(-mean, sc, beta); }
+__device__ __forceinline__ float bn_affine(float y, float sc, float sh) { return __builtin_fmaf(y, sc, sh); }
 // stage 2 + apply: a = act(gamma * (y - mean) * rstd + beta), written to a channel slice of `out`
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y, size_t y_nstride, float* __restrict__ out,
                                                      size_t out_nstride, int C, int HW, int PB, const float* __restrict__ gamma,
@@ -1130,12 +1213,13 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y
         float v[BN_V_CH][4];
 #pragma unroll
         for (int k = 0; k < BN_V_CH; ++k) ld_run(p, lo + 4 * (threadIdx.x + 256 * k), hi, v[k]);
+        const float shv = bn_shift(beta[c], st[0], sc);
 #pragma unroll
         for (int k = 0; k < BN_V_CH; ++k) {
             const int i = lo + 4 * (threadIdx.x + 256 * k);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float t = v[k][j] * sc + sh;
+                const float t = bn_affine(v[k][j], sc, shv);   // (the backward of these planes re-forms t from y to get the activation's sign)
                 v[k][j] = t > 0.f ? t : t * slope;
             }
             if (i < hi) st_run(q, i, hi, v[k]);
@@ -1152,7 +1236,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ da, size_t da_nstride, const float* __restrict__ aout,
                                                              size_t a_nstride, const float* __restrict__ y, size_t y_nstride, int C, int HW,
                                                              int PB, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                             float slope, float* __restrict__ part /* [N][C][PB][2] */) {
+                                                             float slope, float* __restrict__ part /* [N][C][PB][2] */,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, size_t p_nstride) {
     __shared__ float red[8];
     const int pb = blockIdx.x, c = blockIdx.y, img = blockIdx.z;
     const int seg = seg_len(HW, PB), lo = pb * seg, hi = min(lo + seg, HW);
@@ -1162,21 +1247,24 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     const float* py = y + (size_t)img * y_nstride + (size_t)c * HW;
     float s1 = 0.f, s2 = 0.f;
     if (PB > MAX_PB) {
-        const bool act = slope != 1.0f;
+        const bool act = slope != 1.0f, from_y = act && beta != nullptr;   // the activation's sign from y (bn_affine): one tensor less to read
         float d[BN_V_CH][4], a[BN_V_CH][4], yy[BN_V_CH][4];
 #pragma unroll
         for (int k = 0; k < BN_V_CH; ++k) {
             const int i = lo + 4 * (threadIdx.x + 256 * k);
             ld_run(pd, i, hi, d[k]);
             ld_run(py, i, hi, yy[k]);
-            if (act) ld_run(pa, i, hi, a[k]);
+            if (act && !from_y) ld_run(pa, i, hi, a[k]);
         }
+        float sc = 0.f, sh = 0.f;
+        if (from_y) { sc = gamma[(size_t)img * p_nstride + c] * r; sh = bn_shift(beta[(size_t)img * p_nstride + c], m, sc); }
 #pragma unroll
         for (int k = 0; k < BN_V_CH; ++k)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {   // (pixels behind `hi`: dz = 0 adds nothing to either sum)
                 float dz = d[k][j];
-                if (act && !(a[k][j] > 0.f)) dz *= slope;
+                const float av = from_y ? bn_affine(yy[k][j], sc, sh) : a[k][j];
+                if (act && !(av > 0.f)) dz *= slope;
                 s1 += dz;
                 s2 += dz * (yy[k][j] - m) * r;
             }
@@ -1201,7 +1289,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dy, size_t dy_nstride, int C, int HW, int N, int PB,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, float slope, const float* __restrict__ part,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, size_t p_nstride, int batch) {
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, size_t p_nstride, int batch,
+                                                           const float* __restrict__ beta) {
     __shared__ float st[2];
     const int c = blockIdx.y, img = blockIdx.z;
     gamma += (size_t)img * p_nstride;
@@ -1252,22 +1341,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     float* po = dy + (size_t)img * dy_nstride + (size_t)c * HW;
     if (PB > MAX_PB) {
         const int seg = seg_len(HW, PB), lo = blockIdx.x * seg, hi = min(lo + seg, HW);
-        const bool act = slope != 1.0f;
+        const bool act = slope != 1.0f, from_y = act && beta != nullptr;
         float d[BN_V_CH][4], a[BN_V_CH][4], yy[BN_V_CH][4];
 #pragma unroll
         for (int k = 0; k < BN_V_CH; ++k) {
             const int i = lo + 4 * (threadIdx.x + 256 * k);
             ld_run(pd, i, hi, d[k]);
             ld_run(py, i, hi, yy[k]);
-            if (act) ld_run(pa, i, hi, a[k]);
+            if (act && !from_y) ld_run(pa, i, hi, a[k]);
         }
+        const float sc = gr, sh = from_y ? bn_shift(beta[(size_t)img * p_nstride + c], m, sc) : 0.f;
 #pragma unroll
         for (int k = 0; k < BN_V_CH; ++k) {
             const int i = lo + 4 * (threadIdx.x + 256 * k);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float dz = d[k][j];
-                if (act && !(a[k][j] > 0.f)) dz *= slope;
+                const float av = from_y ? bn_affine(yy[k][j], sc, sh) : a[k][j];
+                if (act && !(av > 0.f)) dz *= slope;
                 d[k][j] = gr * (dz - k1 - (yy[k][j] - m) * r * k2);
             }
             if (i < hi) st_run(po, i, hi, d[k]);
@@ -2039,7 +2130,7 @@ int bn_fwd_slabs_launch(const float* slabs, int ksplit, const float* bias, float
 int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t a_nstride, const float* y, size_t y_nstride, float* dy,
                   size_t dy_nstride, int N, int C, int HW, const float* gamma, const float* mean, const float* rstd, float slope,
                   float* part, float* dgamma, float* dbeta, int accumulate, hipStream_t s, const BnUpsample* up, size_t p_nstride, int batch, const BnPre* pre,
-                  const BnSlabs* slabs) {
+                  const BnSlabs* slabs, const float* beta) {
     if (batch && (N > BN_MAX_BATCH || p_nstride)) return SPLICE_ERR_ARG;
     if (pre && !bn_pre_supported(HW, N, p_nstride, batch)) return SPLICE_ERR_ARG;
     if (slabs && slabs->slabs && !bn_bwd_takes_slabs(HW, N, p_nstride, batch)) return SPLICE_ERR_ARG;
@@ -2061,9 +2152,13 @@ int bn_bwd_launch(const float* da, size_t da_nstride, const float* aout, size_t 
         return SPLICE_OK;
     }
     const int PB = bn_plane_blocks(HW);
-    SPLICE_LAUNCH(bn_bwd_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, C, HW, PB, mean, rstd, slope, part);
+    // big planes: the activation's sign is re-formed from y (needs beta; batch statistics keep reading the activated tensor: their mean / rstd arrays
+    // are per image while the forward normalised with the batch's)
+    static const int sign_from_y = getenv("SPLICE_BN_SIGN_FROM_Y") ? atoi(getenv("SPLICE_BN_SIGN_FROM_Y")) : 1;
+    const float* be = (sign_from_y && !batch && PB > MAX_PB) ? beta : nullptr;
+    SPLICE_LAUNCH(bn_bwd_partial_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, C, HW, PB, mean, rstd, slope, part, gamma, be, p_nstride);
     SPLICE_LAUNCH(bn_bwd_apply_kernel, dim3(PB, C, N), dim3(256), 0, s, da, da_nstride, aout, a_nstride, y, y_nstride, dy,
-                       dy_nstride, C, HW, N, PB, gamma, mean, rstd, slope, part, dgamma, dbeta, accumulate, p_nstride, batch);
+                       dy_nstride, C, HW, N, PB, gamma, mean, rstd, slope, part, dgamma, dbeta, accumulate, p_nstride, batch, be);
     return SPLICE_OK;
 }
 __global__ void fill_zero_kernel(float* p, int n) {

@@ -660,6 +660,7 @@ static bool graph_reuse_on() {
 }
 namespace {
 std::map<unsigned long long, std::vector<hipGraphExec_t>> g_spare;   // guarded by g_dead_mu
+std::vector<hipGraphExec_t> g_parked;                                 // executables whose update the runtime refused (guarded by g_dead_mu)
 }
 static unsigned long long graph_key(const SpliceStep* st, int variant) {
     unsigned long long k = (unsigned long long)(unsigned)variant;
@@ -802,8 +803,11 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
                     ++st->graph_updates;
                 } else {
                     (void)hipGetLastError();
+                    // a refused executable is parked, not destroyed (no hipGraphExecDestroy in a running loop); only past 64 parked ones -- a regime that
+                    // keeps changing its kernel choices, never seen with the reference's crop ranges -- the oldest goes to the graveyard
                     std::lock_guard<std::mutex> lk(g_dead_mu);
-                    g_dead.push_back(DeadGraph{spare, std::chrono::steady_clock::now()});
+                    g_parked.push_back(spare);
+                    if (g_parked.size() > 64) { g_dead.push_back(DeadGraph{g_parked.front(), std::chrono::steady_clock::now()}); g_parked.erase(g_parked.begin()); }
                     ++st->graph_update_refusals;
                 }
             }
