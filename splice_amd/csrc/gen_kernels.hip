@@ -20,6 +20,29 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// 16-byte accesses at 4-byte alignment (gfx950's global accesses need dword alignment only): runs of 4 consecutive pixels of odd-sized planes
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+// run k of this thread inside the segment [lo, hi): pixels i .. i + 3, i = lo + 4 (threadIdx.x + 256 k); pixels behind `hi` read as 0
+__device__ __forceinline__ void ld_run(const float* __restrict__ p, int i, int hi, float (&v)[4]) {
+    if (i + 3 < hi) {
+        const f4u t = *(const f4u*)(p + i);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = i + j < hi ? p[i + j] : 0.f;
+    }
+}
+__device__ __forceinline__ void st_run(float* __restrict__ p, int i, int hi, const float (&v)[4]) {
+    if (i + 3 < hi) {
+        f4u t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+        *(f4u*)(p + i) = t;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i + j < hi) p[i + j] = v[j];
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Implicit-GEMM convolution.  M = output pixels of one image (64 per workgroup),
 // N = output channels (16*FN per workgroup), K = (channel, ky, kx) in the weight's own
@@ -477,6 +500,174 @@ int conv_pair_launch(ConvArgs a, ConvArgs b, hipStream_t s, int* ksplit_a, int* 
     return conv_launch(b, s, ksplit_b);
 }
 
+// ---------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution of BIG planes (round 5: the reference's default 855 .. 900 crops, 448^2, 512^2): a 2-D pixel tile with the input halo
+// staged in LDS.  conv_igemm_body gathers 64 pixels x 72 k-values per channel tile for 18 MFMAs per wave -- every input element is fetched 9 times
+// per 16 output channels, each behind its own descriptor -- and the instruction stream around the MFMAs costs twice the matrix pipe's time on
+// these layers (profiles/r05_conv_big_planes.txt).  Here a workgroup owns 8 rows x 64 columns of output; per channel chunk it stages the
+// (8 + 2) x (64 + 2) input patch ONCE (padding / reflection resolved while staging, row-contiguous loads), a wave owns two rows = 8 pixel fragments,
+// and one weight fragment + one address add serve 8 MFMAs.  The k order inside a chunk, the chunk size (conv_ck) and the operand layout are those
+// of conv_igemm_body: the same bits (tools/gen_bits.py under SPLICE_CONV_TILE=0 / 1).
+constexpr int CT_TH = 8, CT_TW = 64, CT_PH = CT_TH + 2, CT_PW = CT_TW + 2, CT_PLANE = CT_PH * CT_PW;
+template <bool TRANSPOSED, int FN, int CK>
+__global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a, int tiles_x) {
+    constexpr int KT = CK * 9, KSTEPS = KT / 4, LDW = KT + 2, BN = 16 * FN;
+    constexpr int PE = CK * CT_PLANE;                 // patch elements per chunk
+    constexpr int NP = (PE + 255) / 256;              // ... per thread
+    constexpr int NW = (BN * KT + 255) / 256;         // weight elements per thread per chunk
+    __shared__ float Ps[PE];
+    __shared__ float Ws[BN * LDW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int img = blockIdx.z;
+    const int x0 = (blockIdx.x % tiles_x) * CT_TW, y0 = (blockIdx.x / tiles_x) * CT_TH;
+    const int n0 = blockIdx.y * BN;
+    const float* in = a.in + (size_t)img * a.in_nstride;
+    const float* wgt = a.w + (size_t)img * a.p_nstride;
+    const float* bias = a.bias ? a.bias + (size_t)img * a.p_nstride : nullptr;
+    // source coordinates of the patch origin: forward sy = oy - pad + ky, data gradient sy = oy + pad - ky (ky = 0 .. 2)
+    const int sy0 = TRANSPOSED ? y0 + a.pad - 2 : y0 - a.pad, sx0 = TRANSPOSED ? x0 + a.pad - 2 : x0 - a.pad;
+    // ---- staging descriptors: patch element e = tid + 256 j = (channel, patch row, patch column); fixed for the kernel, the chunk enters as the scalar offset
+    int p_vo[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int e = tid + 256 * j;
+        const int c = e / CT_PLANE, rem = e % CT_PLANE, r = rem / CT_PW, x = rem % CT_PW;
+        int sy = sy0 + r, sx = sx0 + x;
+        if (!TRANSPOSED && a.reflect) {   // nn.ReflectionPad2d in front of the convolution: mirror without the edge
+            sy = sy < 0 ? -sy : (sy >= a.Hi ? 2 * (a.Hi - 1) - sy : sy);
+            sx = sx < 0 ? -sx : (sx >= a.Wi ? 2 * (a.Wi - 1) - sx : sx);
+        }
+        const bool ok = e < PE && sy >= 0 && sy < a.Hi && sx >= 0 && sx < a.Wi;
+        p_vo[j] = ok ? (int)(c * a.in_cstride + (size_t)sy * a.Wi + sx) * 4 : (int)0x80000000;
+    }
+    int w_vo[NW], w_lds[NW];
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+        const int e = tid + 256 * t;
+        const int j = e / KT, k = e % KT;
+        const int cl = k / 9, tap = k % 9;
+        const bool ok = e < BN * KT && (n0 + j) < a.Cout;
+        w_vo[t] = ok ? (int)((size_t)(n0 + j) * a.w_jstride + (size_t)cl * a.w_cstride + tap) * 4 : (int)0x80000000;
+        w_lds[t] = e < BN * KT ? j * LDW + k : -1;
+    }
+    // ---- fragment addressing: lane (pixel i = lane & 15, k group g = lane >> 4); k = kk * 4 + g = (channel, ky, kx) -> offset inside the patch
+    int koff[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+        const int k = kk * 4 + (lane >> 4);
+        const int c = k / 9, tap = k % 9, ky = tap / 3, kx = tap % 3;
+        koff[kk] = c * CT_PLANE + (TRANSPOSED ? 2 - ky : ky) * CT_PW + (TRANSPOSED ? 2 - kx : kx);
+    }
+    int a_rd = (2 * wave) * CT_PW + (lane & 15);                 // pixel (row 2 wave, column lane & 15) of the tile, in patch coordinates without the tap
+    int w_rd = (lane & 15) * LDW + (lane >> 4);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wgt), 0, 0x7FFFFFFF, 0x00020000);
+    const int Kc = a.Cin;
+    float pv[NP], wv[NW];
+    auto fetch = [&](int c0) __attribute__((always_inline)) {
+        const int so_a = __builtin_amdgcn_readfirstlane(c0 * (int)a.in_cstride * 4), so_w = __builtin_amdgcn_readfirstlane(c0 * (int)a.w_cstride * 4);
+        if (c0 + CK <= Kc) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) pv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, p_vo[j], so_a, 0));
+#pragma unroll
+            for (int t = 0; t < NW; ++t) wv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, w_vo[t], so_w, 0));
+        } else {   // the last, partial chunk of the reduction: channels behind Kc read as 0
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const bool cok = c0 + (tid + 256 * j) / CT_PLANE < Kc;
+                pv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, cok ? p_vo[j] : (int)0x80000000, so_a, 0));
+            }
+#pragma unroll
+            for (int t = 0; t < NW; ++t) {
+                const bool cok = c0 + ((tid + 256 * t) % KT) / 9 < Kc;
+                wv[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, cok ? w_vo[t] : (int)0x80000000, so_w, 0));
+            }
+        }
+    };
+    const int fn_live = __builtin_amdgcn_readfirstlane(min(FN, (a.Cout - n0 + 15) / 16));   // fragments of this workgroup that hold output channels
+    f32x4 acc[8][FN];
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    fetch(0);
+    for (int c0 = 0; c0 < Kc; c0 += CK) {
+        asm volatile("" : "+v"(a_rd), "+v"(w_rd));   // (LDS bases re-defined per trip: base + instruction offset instead of one register per address)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            if (tid + 256 * j < PE) Ps[tid + 256 * j] = pv[j];
+#pragma unroll
+        for (int t = 0; t < NW; ++t)
+            if (w_lds[t] >= 0) Ws[w_lds[t]] = wv[t];
+        __syncthreads();
+        if (c0 + CK < Kc) fetch(c0 + CK);
+        // fragments of k step kk + 1 are on their way while step kk feeds 8 x FN MFMAs
+        float af[2][8], bf[2][FN];
+        auto frag = [&](int buf, int kk) __attribute__((always_inline)) {
+            const int ao = a_rd + koff[kk];
+#pragma unroll
+            for (int f = 0; f < 8; ++f) af[buf][f] = Ps[ao + (f >> 2) * CT_PW + (f & 3) * 16];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bf[buf][j] = Ws[w_rd + j * 16 * LDW + kk * 4];
+        };
+        frag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            if (kk + 1 < KSTEPS) frag((kk + 1) & 1, kk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                if (j > 0 && j >= fn_live) continue;   // a 16-channel fragment wholly behind Cout (36 = 32 + 4, 68, 132 output channels): no MFMAs for it
+#pragma unroll
+                for (int f = 0; f < 8; ++f) acc[f][j] = mfma4(af[kk & 1][f], bf[kk & 1][j], acc[f][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- epilogue: acc[f][j][r] = out[n = n0 + j*16 + (lane & 15)][row y0 + 2 wave + (f >> 2)][column x0 + (f & 3) * 16 + (lane >> 4) * 4 + r]
+    float* out = a.out + (size_t)img * a.out_nstride;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + j * 16 + (lane & 15);
+        if (n >= a.Cout) continue;
+        const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const int row = y0 + 2 * wave + (f >> 2), col = x0 + (f & 3) * 16 + (lane >> 4) * 4;
+            if (row >= a.Ho || col >= a.Wo) continue;
+            float* q = out + (size_t)n * a.out_cstride + (size_t)row * a.Wo + col;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[f][j][r] + b;   // (no activation in this kernel: the generator's only sigmoid sits behind a 1x1 convolution; conv_tile_ok)
+            }
+            if (a.accumulate) {
+                float pr[4];
+                ld_run(q, 0, a.Wo - col, pr);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = pr[r] + v[r];
+            }
+            st_run(q, 0, a.Wo - col, v);
+        }
+    }
+}
+static bool conv_tile_ok(const ConvArgs& a) {
+    static const int on = getenv("SPLICE_CONV_TILE") ? atoi(getenv("SPLICE_CONV_TILE")) : 1;
+    // planes above 40000 pixels (same-box A/B, ms per step at min 65536 / 40000 / 12000: one pair at 224^2 3.630 / 3.609 / 3.717, eight pairs 16.40 / 16.25 / 16.12,
+    // 900 x 1200 9.42 / 9.23 / 9.41: the 112^2 planes are 28 tiles -- too few for one image, and the policy must not depend on the images per launch)
+    static const int min_px = getenv("SPLICE_CONV_TILE_MIN") ? atoi(getenv("SPLICE_CONV_TILE_MIN")) : 40000;
+    return on && a.ks == 3 && a.stride == 1 && !a.act && a.Wo >= 64 && (long long)a.Ho * a.Wo > min_px && !(a.reflect && a.transposed) &&
+           (size_t)a.Cin * a.in_cstride <= 0x1fffffffULL;
+}
+template <bool TR, int CK>
+static void conv_tile_launch(const ConvArgs& a, hipStream_t s) {
+    conv_note_work(a);
+    const int tiles_x = cdiv(a.Wo, CT_TW), tiles_y = cdiv(a.Ho, CT_TH);
+    if (a.Cout <= 16) SPLICE_LAUNCH((conv3x3_tile_kernel<TR, 1, CK>), dim3(tiles_x * tiles_y, 1, a.N), dim3(256), 0, s, a, tiles_x);
+    else SPLICE_LAUNCH((conv3x3_tile_kernel<TR, 2, CK>), dim3(tiles_x * tiles_y, cdiv(a.Cout, 32), a.N), dim3(256), 0, s, a, tiles_x);
+}
+
 int conv_launch(const ConvArgs& a, hipStream_t s, int* ksplit_out) {
     if (a.ks != 1 && a.ks != 3 && a.ks != 5 && a.ks != 7) return SPLICE_ERR_ARG;
     if (a.reflect && a.transposed) return SPLICE_ERR_ARG;   // the data gradient of a reflection-padded conv goes through conv_reflect_dgrad_launch
@@ -488,6 +679,12 @@ int conv_launch(const ConvArgs& a, hipStream_t s, int* ksplit_out) {
     if (a.stride != 1 && a.stride != 2) return SPLICE_ERR_ARG;
     if ((size_t)a.Cin * a.in_cstride > 0x7fffffffULL) return SPLICE_ERR_ARG;   // 32-bit gather offsets
     // deeper channel tiles where the reduction is long (fewer barrier rounds on the small, deep layers)
+    if (conv_tile_ok(a)) {   // big planes: the LDS-halo tile (no split-K there)
+        if (a.Cin >= 32) { if (a.transposed) conv_tile_launch<true, 8>(a, s); else conv_tile_launch<false, 8>(a, s); }
+        else { if (a.transposed) conv_tile_launch<true, 4>(a, s); else conv_tile_launch<false, 4>(a, s); }
+        if (ksplit_out) *ksplit_out = 1;
+        return SPLICE_OK;
+    }
     if (a.ks == 3) {
         if (a.Cin >= 32) { if (a.transposed) conv_launch_fn<3, true, 8>(a, s, ksplit_out); else conv_launch_fn<3, false, 8>(a, s, ksplit_out); }
         else { if (a.transposed) conv_launch_fn<3, true, 4>(a, s, ksplit_out); else conv_launch_fn<3, false, 4>(a, s, ksplit_out); }
@@ -924,27 +1121,6 @@ constexpr int BN_V_CH = 5;   // 16-byte runs a thread holds: 5 x 4 x 256 = 5120 
 __host__ __device__ inline int seg_len(int HW, int PB) {
     const int s = (HW + PB - 1) / PB;
     return PB > MAX_PB ? (s + 3) & ~3 : s;
-}
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-// run k of this thread inside the segment [lo, hi): pixels i .. i + 3, i = lo + 4 (threadIdx.x + 256 k); pixels behind `hi` read as 0
-__device__ __forceinline__ void ld_run(const float* __restrict__ p, int i, int hi, float (&v)[4]) {
-    if (i + 3 < hi) {
-        const f4u t = *(const f4u*)(p + i);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = i + j < hi ? p[i + j] : 0.f;
-    }
-}
-__device__ __forceinline__ void st_run(float* __restrict__ p, int i, int hi, const float (&v)[4]) {
-    if (i + 3 < hi) {
-        f4u t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
-        *(f4u*)(p + i) = t;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i + j < hi) p[i + j] = v[j];
-    }
 }
 // fixed-order sum of component `comp` of the PB per-segment pairs of a plane by one wave (PB <= 64: lane b holds segment b, as before)
 __device__ __forceinline__ float part_sum(const float* __restrict__ pp, int PB, int comp, int lane) {

@@ -217,3 +217,28 @@ def test_launch_count_forms_are_bit_neutral(size):
         assert len(outs[tag]) > 100
     for tag, lines in outs.items():
         assert lines == outs["default"], (tag, [(a, b) for a, b in zip(lines, outs["default"]) if a != b][:5])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(1, 500, 470), (2, 400, 384)])
+def test_big_plane_kernels_are_bit_neutral(size):
+    """Round 5 (the reference's default 855 .. 900 crops, 448^2, 512^2): on big planes the 3x3 stride-1 convolutions run a 2-D pixel tile with the
+    input halo staged in LDS (conv3x3_tile_kernel) -- same k order, same chunking, same operand layout as the implicit-GEMM kernel, so where that one
+    runs a single wave group without split-K (every plane of these sizes above 2048 pixel tiles) the two must agree bit for bit; the BatchNorm backward
+    of big planes re-forms the activation's sign from y instead of loading the activated tensor (same comparison, same bits).  Sizes with ragged tiles in
+    both directions and with two images per launch; one child interpreter per setting.  (The tile kernel's own threshold is 40000 pixels; below 2048 pixel
+    tiles = 131072 pixels the implicit-GEMM kernel splits the k steps over two wave groups -- another summation order -- so the comparison raises the
+    threshold to that for every arm.)"""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(__file__), "..", "tools", "gen_bits.py")
+    outs = {}
+    base = dict(os.environ, SPLICE_CONV_TILE_MIN="131072")
+    for tag, env in (("default", {}), ("implicit-GEMM convolutions only", {"SPLICE_CONV_TILE": "0"}), ("activation sign from the activated tensor", {"SPLICE_BN_SIGN_FROM_Y": "0"}),
+                     ("one channel fragment per workgroup", {"SPLICE_CONV_BIG_FN": "0", "SPLICE_CONV_TILE": "0"})):
+        r = subprocess.run([sys.executable, tool] + [str(v) for v in size], env=dict(base, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = [l for l in r.stdout.splitlines() if l and not l.startswith("/")]
+        assert len(outs[tag]) > 100
+    for tag, lines in outs.items():
+        assert lines == outs["default"], (tag, [(a, b) for a, b in zip(lines, outs["default"]) if a != b][:5])
