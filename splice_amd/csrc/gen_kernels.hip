@@ -508,9 +508,12 @@ int conv_pair_launch(ConvArgs a, ConvArgs b, hipStream_t s, int* ksplit_a, int* 
 // (8 + 2) x (64 + 2) input patch ONCE (padding / reflection resolved while staging, row-contiguous loads), a wave owns two rows = 8 pixel fragments,
 // and one weight fragment + one address add serve 8 MFMAs.  The k order inside a chunk, the chunk size (conv_ck) and the operand layout are those
 // of conv_igemm_body: the same bits (tools/gen_bits.py under SPLICE_CONV_TILE=0 / 1).
-constexpr int CT_TH = 8, CT_TW = 64, CT_PH = CT_TH + 2, CT_PW = CT_TW + 2, CT_PLANE = CT_PH * CT_PW;
-template <bool TRANSPOSED, int FN, int CK>
+constexpr int CT_TW = 64, CT_PW = CT_TW + 2;
+// RW = output rows per wave (2: the 8-row tile described above; 1: a 4-row tile -- twice the workgroups, 1.5 x instead of 1.25 x the halo -- for planes that
+// would make too few 8-row tiles to fill the chip)
+template <bool TRANSPOSED, int FN, int CK, int RW>
 __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a, int tiles_x) {
+    constexpr int CT_TH = 4 * RW, CT_PH = CT_TH + 2, CT_PLANE = CT_PH * CT_PW, NF = 4 * RW;   // NF = 16-pixel fragments per wave
     constexpr int KT = CK * 9, KSTEPS = KT / 4, LDW = KT + 2, BN = 16 * FN;
     constexpr int PE = CK * CT_PLANE;                 // patch elements per chunk
     constexpr int NP = (PE + 255) / 256;              // ... per thread
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a, int tiles
         const int c = k / 9, tap = k % 9, ky = tap / 3, kx = tap % 3;
         koff[kk] = c * CT_PLANE + (TRANSPOSED ? 2 - ky : ky) * CT_PW + (TRANSPOSED ? 2 - kx : kx);
     }
-    int a_rd = (2 * wave) * CT_PW + (lane & 15);                 // pixel (row 2 wave, column lane & 15) of the tile, in patch coordinates without the tap
+    int a_rd = (RW * wave) * CT_PW + (lane & 15);                 // pixel (row 2 wave, column lane & 15) of the tile, in patch coordinates without the tap
     int w_rd = (lane & 15) * LDW + (lane >> 4);
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, 0x7FFFFFFF, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wgt), 0, 0x7FFFFFFF, 0x00020000);
@@ -585,9 +588,9 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a, int tiles
         }
     };
     const int fn_live = __builtin_amdgcn_readfirstlane(min(FN, (a.Cout - n0 + 15) / 16));   // fragments of this workgroup that hold output channels
-    f32x4 acc[8][FN];
+    f32x4 acc[NF][FN];
 #pragma unroll
-    for (int f = 0; f < 8; ++f)
+    for (int f = 0; f < NF; ++f)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     fetch(0);
@@ -603,11 +606,11 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a, int tiles
         __syncthreads();
         if (c0 + CK < Kc) fetch(c0 + CK);
         // fragments of k step kk + 1 are on their way while step kk feeds 8 x FN MFMAs
-        float af[2][8], bf[2][FN];
+        float af[2][NF], bf[2][FN];
         auto frag = [&](int buf, int kk) __attribute__((always_inline)) {
             const int ao = a_rd + koff[kk];
 #pragma unroll
-            for (int f = 0; f < 8; ++f) af[buf][f] = Ps[ao + (f >> 2) * CT_PW + (f & 3) * 16];
+            for (int f = 0; f < NF; ++f) af[buf][f] = Ps[ao + (f >> 2) * CT_PW + (f & 3) * 16];
 #pragma unroll
             for (int j = 0; j < FN; ++j) bf[buf][j] = Ws[w_rd + j * 16 * LDW + kk * 4];
         };
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a, int tiles
             for (int j = 0; j < FN; ++j) {
                 if (j > 0 && j >= fn_live) continue;   // a 16-channel fragment wholly behind Cout (36 = 32 + 4, 68, 132 output channels): no MFMAs for it
 #pragma unroll
-                for (int f = 0; f < 8; ++f) acc[f][j] = mfma4(af[kk & 1][f], bf[kk & 1][j], acc[f][j]);
+                for (int f = 0; f < NF; ++f) acc[f][j] = mfma4(af[kk & 1][f], bf[kk & 1][j], acc[f][j]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -633,8 +636,8 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a, int tiles
         if (n >= a.Cout) continue;
         const float b = bias ? bias[n] : 0.f;
 #pragma unroll
-        for (int f = 0; f < 8; ++f) {
-            const int row = y0 + 2 * wave + (f >> 2), col = x0 + (f & 3) * 16 + (lane >> 4) * 4;
+        for (int f = 0; f < NF; ++f) {
+            const int row = y0 + RW * wave + (f >> 2), col = x0 + (f & 3) * 16 + (lane >> 4) * 4;
             if (row >= a.Ho || col >= a.Wo) continue;
             float* q = out + (size_t)n * a.out_cstride + (size_t)row * a.Wo + col;
             float v[4];
@@ -663,9 +666,16 @@ static bool conv_tile_ok(const ConvArgs& a) {
 template <bool TR, int CK>
 static void conv_tile_launch(const ConvArgs& a, hipStream_t s) {
     conv_note_work(a);
-    const int tiles_x = cdiv(a.Wo, CT_TW), tiles_y = cdiv(a.Ho, CT_TH);
-    if (a.Cout <= 16) SPLICE_LAUNCH((conv3x3_tile_kernel<TR, 1, CK>), dim3(tiles_x * tiles_y, 1, a.N), dim3(256), 0, s, a, tiles_x);
-    else SPLICE_LAUNCH((conv3x3_tile_kernel<TR, 2, CK>), dim3(tiles_x * tiles_y, cdiv(a.Cout, 32), a.N), dim3(256), 0, s, a, tiles_x);
+    static const int rw1_max = getenv("SPLICE_CONV_TILE_RW1_MAX") ? atoi(getenv("SPLICE_CONV_TILE_RW1_MAX")) : 0x7fffffff;   // planes up to this many pixels take the 4-row tile: all of them (same-box A/B against the 8-row tile: 900 x 1200 9.20 -> 9.07 ms, one pair at 224^2 3.594 -> 3.574, eight pairs 16.33 -> 16.30: 118 .. 133 instead of 167 .. 183 VGPRs)
+    const bool rw1 = (long long)a.Ho * a.Wo <= rw1_max;
+    const int tiles_x = cdiv(a.Wo, CT_TW), tiles_y = cdiv(a.Ho, rw1 ? 4 : 8);
+    if (rw1) {
+        if (a.Cout <= 16) SPLICE_LAUNCH((conv3x3_tile_kernel<TR, 1, CK, 1>), dim3(tiles_x * tiles_y, 1, a.N), dim3(256), 0, s, a, tiles_x);
+        else SPLICE_LAUNCH((conv3x3_tile_kernel<TR, 2, CK, 1>), dim3(tiles_x * tiles_y, cdiv(a.Cout, 32), a.N), dim3(256), 0, s, a, tiles_x);
+        return;
+    }
+    if (a.Cout <= 16) SPLICE_LAUNCH((conv3x3_tile_kernel<TR, 1, CK, 2>), dim3(tiles_x * tiles_y, 1, a.N), dim3(256), 0, s, a, tiles_x);
+    else SPLICE_LAUNCH((conv3x3_tile_kernel<TR, 2, CK, 2>), dim3(tiles_x * tiles_y, cdiv(a.Cout, 32), a.N), dim3(256), 0, s, a, tiles_x);
 }
 
 int conv_launch(const ConvArgs& a, hipStream_t s, int* ksplit_out) {
