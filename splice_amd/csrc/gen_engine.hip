@@ -734,6 +734,7 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
     p->pend.target = nullptr;   // (a backward that failed half-way must not leave slabs pending for this one)
     p->wg.small.count = p->wg.small.total_wgs = 0;
     p->wg.big.count = p->wg.big.total_wgs = 0;
+    p->wg.tile.count = p->wg.tile.total_wgs = 0;
     const Unit& u = p->u_up1[0];
     const int HW = p->H * p->W;
     (void)npix;

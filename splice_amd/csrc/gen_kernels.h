@@ -49,7 +49,7 @@ struct WgradDesc {           // compact per-layer descriptor of the batched weig
     uint32_t reflect;
 };
 struct WgradBatch { int count; int total_wgs; WgradDesc d[WGRAD_BATCH_MAX]; };   // by-value kernel argument
-struct WgradBatchPair { WgradBatch small, big; };   // layers with <= 32 / > 32 output channels (different kernel occupancy)
+struct WgradBatchPair { WgradBatch small, big, tile; };   // layers with <= 32 / > 32 output channels (different kernel occupancy); 3x3 layers of big planes (conv_wgrad_tile_kernel)
 int conv_wgrad_add(WgradBatchPair* b, WgradArgs a, int* chunks_out);       // queue one layer; partials go to a.ws
 int conv_wgrad_batched_launch(const WgradBatchPair& b, hipStream_t s);     // one launch per class for every queued layer
 

@@ -1058,15 +1058,184 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_batched_kernel(WgradBatch b
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Weight gradient of the 3x3 stride-1 layers of BIG planes (round 5), the counterpart of conv3x3_tile_kernel: a workgroup = (strip of 4 x 64-pixel tiles,
+// 8-channel K tile).  Per tile the (4 + 2) x (64 + 2) x 8 input patch is staged in LDS once (interior tiles: fixed per-thread offsets + the tile as the
+// scalar offset; border tiles resolve padding / reflection per element); a wave owns one pixel row, takes its output-gradient operand STRAIGHT from
+// global memory (16-byte loads: lane (n, g) holds dy[n][16 q + 4 g .. + 3], four MFMA steps per load) and its input operand from the patch at
+// [per-lane (channel, tap) offset + 4 g] + [compile-time pixel offset]; the 72 (channel, tap) columns are 5 fragments, the accumulators stay in registers
+// over the whole strip, the four waves' sums are added in wave order through LDS at the end.  conv_wgrad_body fills LDS with 64 pixels x 36 k-values and
+// 64 x Cout gradients for 16 MFMA steps per fragment pair (and leaves one wave idle at 16 output channels).
+constexpr int WT_CK = 8, WT_NJ = 5, WT_PH = 6, WT_PLANE = WT_PH * CT_PW, WT_PE = WT_CK * WT_PLANE, WT_NP = (WT_PE + 255) / 256;
+template <int NI>
+__device__ __forceinline__ void conv_wgrad_tile_body(const WgradDesc& d, int chunk, int ktile, int nb /* first output channel of this workgroup */, float* Ps) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Cin = d.Cin, Cout = d.Cout, Hi = d.Hi, Wi = d.Wi, Ho = d.Ho, Wo = d.Wo, pad = d.pad;
+    const int img = chunk / d.chunks_per_img, strip = chunk % d.chunks_per_img;
+    const int tiles_x = (Wo + CT_TW - 1) / CT_TW, tiles_y = (Ho + 3) / 4, T = tiles_x * tiles_y;
+    const int t_begin = (int)((long long)strip * T / d.chunks_per_img), t_end = (int)((long long)(strip + 1) * T / d.chunks_per_img);
+    const int c0 = ktile * WT_CK;
+    const float* x = d.x + (size_t)img * d.x_nstride + (size_t)c0 * d.x_cstride;
+    const float* dy = d.dy + (size_t)img * d.dy_nstride;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, 0x7FFFFFFF, 0x00020000);
+    // patch element e = tid + 256 j = (channel, patch row, patch column), relative to the tile's patch origin
+    int p_rel[WT_NP];
+#pragma unroll
+    for (int j = 0; j < WT_NP; ++j) {
+        const int e = tid + 256 * j;
+        const int c = e / WT_PLANE, rem = e % WT_PLANE, r = rem / CT_PW, xx = rem % CT_PW;
+        p_rel[j] = (e < WT_PE && c0 + c < Cin) ? (int)(c * d.x_cstride + (unsigned)(r * Wi + xx)) * 4 : (int)0x80000000;
+    }
+    // input operand: column j = jf * 16 + (lane & 15) = (channel, tap) -> offset inside the patch (+ this wave's row, + the lane's pixel group)
+    int b_base[WT_NJ];
+#pragma unroll
+    for (int jf = 0; jf < WT_NJ; ++jf) {
+        const int j = jf * 16 + (lane & 15);
+        const int cl = j / 9, tap = j % 9;
+        b_base[jf] = (j < WT_CK * 9 ? cl * WT_PLANE + (tap / 3) * CT_PW + tap % 3 : 0) + wave * CT_PW + 4 * (lane >> 4);
+    }
+    int dy_off[NI];
+#pragma unroll
+    for (int fi = 0; fi < NI; ++fi) {
+        const int n = nb + fi * 16 + (lane & 15);
+        dy_off[fi] = n < Cout ? (int)(n * d.dy_cstride) * 4 : (int)0x80000000;
+    }
+    f32x4 acc[NI][WT_NJ];
+#pragma unroll
+    for (int fi = 0; fi < NI; ++fi)
+#pragma unroll
+        for (int jf = 0; jf < WT_NJ; ++jf) acc[fi][jf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float pv[WT_NP];
+    float dyn[NI][4][4], dyc[NI][4][4];
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int y0 = ty * 4, x0 = tx * CT_TW, sy0 = y0 - pad, sx0 = x0 - pad;
+        const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + WT_PH <= Hi && sx0 + CT_PW <= Wi;
+        if (interior) {
+            const int so = __builtin_amdgcn_readfirstlane((sy0 * Wi + sx0) * 4);
+#pragma unroll
+            for (int j = 0; j < WT_NP; ++j) pv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, p_rel[j], so, 0));
+        } else {
+#pragma unroll
+            for (int j = 0; j < WT_NP; ++j) {
+                const int e = tid + 256 * j;
+                const int c = e / WT_PLANE, rem = e % WT_PLANE, r = rem / CT_PW, xx = rem % CT_PW;
+                int sy = sy0 + r, sx = sx0 + xx;
+                if (d.reflect) {
+                    sy = sy < 0 ? -sy : (sy >= Hi ? 2 * (Hi - 1) - sy : sy);
+                    sx = sx < 0 ? -sx : (sx >= Wi ? 2 * (Wi - 1) - sx : sx);
+                }
+                const bool ok = p_rel[j] >= 0 && sy >= 0 && sy < Hi && sx >= 0 && sx < Wi;
+                pv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? (int)(c * d.x_cstride + (unsigned)(sy * Wi + sx)) * 4 : (int)0x80000000, 0, 0));
+            }
+        }
+        // this wave's row of the output gradient: 16-byte runs (4-byte aligned); pixels behind the row end / rows behind the plane read as 0
+        const int row = y0 + wave;
+        const int col0 = x0 + 4 * (lane >> 4);
+#pragma unroll
+        for (int fi = 0; fi < NI; ++fi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = col0 + 16 * q;
+                const bool ok = row < Ho && col < Wo && dy_off[fi] >= 0;
+                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, ok ? dy_off[fi] + (row * Wo + col) * 4 : (int)0x80000000, 0, 0));
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) dyn[fi][q][tt] = col + tt < Wo ? __uint_as_float(v[tt]) : 0.f;
+            }
+    };
+    if (t_begin < t_end) fetch(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        asm volatile("" : "+v"(b_base[0]), "+v"(b_base[1]), "+v"(b_base[2]), "+v"(b_base[3]), "+v"(b_base[4]));   // (LDS bases re-defined per trip: base + instruction offset)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < WT_NP; ++j)
+            if (tid + 256 * j < WT_PE) Ps[tid + 256 * j] = pv[j];
+#pragma unroll
+        for (int fi = 0; fi < NI; ++fi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) dyc[fi][q][tt] = dyn[fi][q][tt];
+        __syncthreads();
+        if (t + 1 < t_end) fetch(t + 1);
+        float bv[2][WT_NJ];
+#pragma unroll
+        for (int jf = 0; jf < WT_NJ; ++jf) bv[0][jf] = Ps[b_base[jf]];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {   // pixel step: column 16 (st / 4) + 4 g + st % 4 of the wave's row
+            if (st + 1 < 16) {
+#pragma unroll
+                for (int jf = 0; jf < WT_NJ; ++jf) bv[(st + 1) & 1][jf] = Ps[b_base[jf] + 16 * ((st + 1) >> 2) + ((st + 1) & 3)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int fi = 0; fi < NI; ++fi)
+#pragma unroll
+                for (int jf = 0; jf < WT_NJ; ++jf) acc[fi][jf] = mfma4(dyc[fi][st >> 2][st & 3], bv[st & 1][jf], acc[fi][jf]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- the four waves' sums, added in wave order (fixed: bit-reproducible), then the partial of this (chunk, K tile): layout of the weight tensor
+    __syncthreads();
+    constexpr int NV = NI * WT_NJ * 4;
+    if (wave > 0) {
+#pragma unroll
+        for (int fi = 0; fi < NI; ++fi)
+#pragma unroll
+            for (int jf = 0; jf < WT_NJ; ++jf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ps[((wave - 1) * NV + (fi * WT_NJ + jf) * 4 + r) * 64 + lane] = acc[fi][jf][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    float* ws = d.ws + (size_t)chunk * Cout * Cin * 9;
+#pragma unroll
+    for (int fi = 0; fi < NI; ++fi)
+#pragma unroll
+        for (int jf = 0; jf < WT_NJ; ++jf) {
+            const int j = jf * 16 + (lane & 15);
+            const int cl = j / 9, tap = j % 9;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[fi][jf][r];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v += Ps[(w * NV + (fi * WT_NJ + jf) * 4 + r) * 64 + lane];
+                const int n = nb + fi * 16 + (lane >> 4) * 4 + r;
+                if (j < WT_CK * 9 && c0 + cl < Cin && n < Cout) ws[((size_t)n * Cin + c0 + cl) * 9 + tap] = v;
+            }
+        }
+}
+constexpr int WT_LDS_FLOATS = 3 * 2 * WT_NJ * 4 * 64 > WT_PE ? 3 * 2 * WT_NJ * 4 * 64 : WT_PE;
+__global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(WgradBatch b) {
+    __shared__ float Ps[WT_LDS_FLOATS];
+    int l = 0;
+#pragma unroll 1
+    while (l + 1 < b.count && blockIdx.x >= b.d[l + 1].wg_begin) ++l;
+    const WgradDesc& d = b.d[l];
+    const int local = blockIdx.x - d.wg_begin;
+    // (chunk, K tile, block of 32 output channels): layers with 64 / 128 output channels are 2 / 4 passes over the same patches
+    const int chunk = local % d.chunks, kt_all = local / d.chunks, ktiles_c = (d.Cin + WT_CK - 1) / WT_CK;
+    const int ktile = kt_all % ktiles_c, nb = (kt_all / ktiles_c) * 32;
+    if (d.variant == 1) conv_wgrad_tile_body<1>(d, chunk, ktile, nb, Ps);
+    else conv_wgrad_tile_body<2>(d, chunk, ktile, nb, Ps);
+}
+static bool wgrad_tile_ok(const WgradArgs& a) {
+    static const int on = getenv("SPLICE_WGRAD_TILE") ? atoi(getenv("SPLICE_WGRAD_TILE")) : 1;
+    static const int min_px = getenv("SPLICE_WGRAD_TILE_MIN") ? atoi(getenv("SPLICE_WGRAD_TILE_MIN")) : 40000;
+    return on && a.ks == 3 && a.stride == 1 && a.Wo >= 64 && (long long)a.Ho * a.Wo > min_px && a.Hi == a.Ho && a.Wi == a.Wo && a.pad == 1;
+}
+
 // append one layer to a batch (partial sums only: ws gets chunks * Cout*Cin*ks*ks floats); returns the number of chunks
 int conv_wgrad_add(WgradBatchPair* pair, WgradArgs a, int* chunks_out) {
-    WgradBatch* b = a.Cout > 32 ? &pair->big : &pair->small;
+    const bool tile = wgrad_tile_ok(a);
+    WgradBatch* b = tile ? &pair->tile : a.Cout > 32 ? &pair->big : &pair->small;
     if (a.Cout > 128 || (a.ks != 1 && a.ks != 3 && a.ks != 5 && a.ks != 7) || b->count >= WGRAD_BATCH_MAX) return SPLICE_ERR_ARG;
     if ((size_t)a.Cin * a.x_cstride > 0x7fffffffULL || a.x_nstride > 0xffffffffULL || a.dy_nstride > 0xffffffffULL) return SPLICE_ERR_ARG;
     if (a.Hi > 65535 || a.Wi > 65535 || a.Cin > 65535) return SPLICE_ERR_ARG;
     const int chunks = wgrad_chunks(a.N, a.Ho, a.Wo, &a.pix_per_chunk, &a.chunks_per_img);
-    const int CK = a.ks == 1 ? 16 : 4;
-    const int ktiles = cdiv(a.Cin, CK) * (a.ks >= 5 ? a.ks : 1);   // 5x5 / 7x7: one K tile per (channel tile, filter row)
+    const int CK = tile ? WT_CK : a.ks == 1 ? 16 : 4;
+    const int ktiles = cdiv(a.Cin, CK) * (a.ks >= 5 ? a.ks : 1) * (tile ? cdiv(a.Cout, 32) : 1);   // 5x5 / 7x7: one K tile per (channel tile, filter row); tile kernel: x blocks of 32 output channels
     const int ni = cdiv(a.Cout, 16);
     WgradDesc& d = b->d[b->count++];
     d.x = a.x; d.dy = a.dy; d.ws = a.ws;
@@ -1074,6 +1243,7 @@ int conv_wgrad_add(WgradBatchPair* pair, WgradArgs a, int* chunks_out) {
     d.Cin = (uint16_t)a.Cin; d.Cout = (uint16_t)a.Cout; d.Hi = (uint16_t)a.Hi; d.Wi = (uint16_t)a.Wi; d.Ho = (uint16_t)a.Ho; d.Wo = (uint16_t)a.Wo;
     d.ks = (uint8_t)a.ks; d.stride = (uint8_t)a.stride; d.pad = (uint8_t)a.pad;
     d.variant = (uint8_t)((a.ks == 3 ? 4 : a.ks == 5 ? 8 : a.ks == 7 ? 12 : 0) + (ni <= 1 ? 0 : ni <= 2 ? 1 : ni <= 4 ? 2 : 3));
+    if (tile) d.variant = (uint8_t)(ni < 2 ? 1 : 2);   // 1 or 2 fragments of output channels per workgroup
     d.reflect = (uint32_t)(a.reflect ? 1 : 0);
     d.pix_per_chunk = (uint16_t)a.pix_per_chunk; d.chunks_per_img = (uint16_t)a.chunks_per_img;
     d.wg_begin = (uint32_t)b->total_wgs; d.chunks = (uint32_t)chunks;
@@ -1084,6 +1254,7 @@ int conv_wgrad_add(WgradBatchPair* pair, WgradArgs a, int* chunks_out) {
 int conv_wgrad_batched_launch(const WgradBatchPair& p, hipStream_t s) {
     if (p.big.count > 0) SPLICE_LAUNCH(conv_wgrad_batched_kernel<true>, dim3((unsigned)p.big.total_wgs), dim3(256), 0, s, p.big);
     if (p.small.count > 0) SPLICE_LAUNCH(conv_wgrad_batched_kernel<false>, dim3((unsigned)p.small.total_wgs), dim3(256), 0, s, p.small);
+    if (p.tile.count > 0) SPLICE_LAUNCH(conv_wgrad_tile_kernel, dim3((unsigned)p.tile.total_wgs), dim3(256), 0, s, p.tile);
     return SPLICE_OK;
 }
 

@@ -28,6 +28,8 @@ def dig(t):
     return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16]
 
 
+if os.environ.get("GEN_BITS_DUMP"):   # tensors themselves, for numeric comparison of two builds / switch settings (tools/gen_num_ab.sh)
+    torch.save({"forward": y.cpu(), **{k: v.cpu() for k, v in eng.unflatten(grads).items()}}, os.environ["GEN_BITS_DUMP"])
 print("forward", dig(y))
 for name, g in eng.unflatten(grads).items():
     print(name, dig(g))
