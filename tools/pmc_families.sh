@@ -48,10 +48,11 @@ dg = launches(lambda n: "gemm_nt_kernel<" in n and ", 4u," in n)
 mx = max((b for b, _ in dg), default=0.0)
 dg = [x for x in dg if x[0] > 0.25 * mx]          # (drops the patch-embedding dgrad, a 192-column GEMM with the same flags)
 res["5"] = mean(dg); detail["5"] = sorted({n[:60] for _, n in dg})
-af = launches(lambda n: "attn_fwd_kernel" in n or "attn_fwd8_kernel" in n)
+af = launches(lambda n: "attn_fwd_kernel" in n or "attn_fwd8_kernel" in n or "attn_fwd_x32_kernel" in n)
 res["3"] = mean(af); detail["3"] = sorted({n[:40] for _, n in af})
-ab = launches(lambda n: n.startswith("attn_bwd_kernel") or "attn_bwd_q_kernel" in n or "attn_bwd_kv_kernel" in n)
-calls = count(lambda n: n.startswith("attn_bwd_kernel")) + count(lambda n: "attn_bwd_kv_kernel" in n)
+ab = launches(lambda n: "attn_bwd_kernel" in n or "attn_bwd_q_kernel" in n or "attn_bwd_kv_kernel" in n or "attn_bwd_x32_kernel" in n or "attn_bwd_q_x32_kernel" in n or "attn_bwd_kv_x32_kernel" in n)
+# one call = one merged launch, or the dQ + dK/dV pair (counted by its dK/dV launch)
+calls = count(lambda n: "attn_bwd_kernel" in n or "attn_bwd_x32_kernel" in n) + count(lambda n: "attn_bwd_kv_kernel" in n or "attn_bwd_kv_x32_kernel" in n)
 res["6"] = sum(b for b, _ in ab) / calls if calls else None; detail["6"] = sorted({n[:40] for _, n in ab})
 gen = launches(lambda n: any(k in n for k in GEN))
 calls = 2 * count(lambda n: "conv_wgrad_batched_kernel<false>" in n)     # one such launch per backward call; as many forward calls
