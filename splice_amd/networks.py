@@ -7,7 +7,7 @@ VIEWS into one flat fp32 arena, so ``torch.optim`` / ``state_dict`` / ``load_sta
 unchanged while the engine reads and writes the arena directly.  The fused engine implements the reference's
 default architecture (``skip()`` with its default arguments, which is all ``define_G`` ever builds) and every other
 architecture its kernels cover (e.g. the 6-scale reflection-padded net of ``inversion.py``); what they do not cover returns a
-stock-PyTorch module (``unet_general.GeneralSkip``).  A fresh ``skip()`` carries PyTorch's constructor initialisation.
+stock-PyTorch module (``unet_general.GeneralSkip``) -- only on request (``SPLICE_ALLOW_STOCK_TORCH=1``), an error otherwise.  A fresh ``skip()`` carries PyTorch's constructor initialisation.
 """
 import math
 
@@ -143,15 +143,17 @@ def skip(num_input_channels=3, num_output_channels=3, num_channels_down=[16, 32,
               and all(0 < c <= 128 for c in arch["num_channels_down"] + arch["num_channels_up"] + arch["num_channels_skip"])
               and 0 < num_input_channels <= 128 and 0 < num_output_channels <= 16)
     if not on_hip:
-        # what the kernels do not cover (other down-samplers / activations / no sigmoid, or a CPU device): stock PyTorch modules --
-        # said out loud, so that nobody mistakes such a net for the HIP engine (SPLICE_STRICT_HIP=1 turns the notice into an error)
+        # what the kernels do not cover (other down-samplers / activations / no sigmoid, or a CPU device).  Round 5: this FAILS by default -- the
+        # package has one backend; a net built from stock PyTorch modules (splice_amd.unet_general, the architecture restated for tests and for
+        # experiments outside the engine) has to be asked for by name: SPLICE_ALLOW_STOCK_TORCH=1, and it still announces itself.
         import os
         import warnings
         msg = ("splice_amd.networks.skip: this architecture / device is outside the HIP generator engine "
                f"(device={device!r}, scales={n}, pad={pad!r}, act_fun={act_fun!r}, downsample_mode={downsample_mode!r}, "
-               f"upsample_mode={upsample_mode!r}, need_sigmoid={need_sigmoid}): building stock PyTorch modules instead")
-        if os.environ.get("SPLICE_STRICT_HIP") == "1":
-            raise RuntimeError(msg)
+               f"upsample_mode={upsample_mode!r}, need_sigmoid={need_sigmoid})")
+        if os.environ.get("SPLICE_ALLOW_STOCK_TORCH") != "1" or os.environ.get("SPLICE_STRICT_HIP") == "1":
+            raise RuntimeError(msg + "; set SPLICE_ALLOW_STOCK_TORCH=1 to build it from stock PyTorch modules instead (not the HIP engine)")
+        msg += ": building stock PyTorch modules instead"
         warnings.warn(msg, RuntimeWarning, stacklevel=2)
         from .unet_general import GeneralSkip
         return GeneralSkip(num_input_channels, num_output_channels, num_channels_down, num_channels_up, num_channels_skip,

@@ -148,14 +148,14 @@ def test_general_skip_matches_reference_inversion_net(golden_dir):
     from splice_amd.networks import skip
     from oracle.fixtures import INVERSION_NET, sample, stats
     g = np.load(os.path.join(golden_dir, "inversion_net.npz"))
-    with pytest.warns(RuntimeWarning, match="outside the HIP generator engine"):   # the stock-PyTorch net announces itself
-        net = skip(8, 3, device="cpu", **INVERSION_NET)
-    os.environ["SPLICE_STRICT_HIP"] = "1"
+    with pytest.raises(RuntimeError, match="outside the HIP generator engine"):     # round 5: one backend -- outside the engine is an error by default
+        skip(8, 3, device="cpu", **INVERSION_NET)
+    os.environ["SPLICE_ALLOW_STOCK_TORCH"] = "1"
     try:
-        with pytest.raises(RuntimeError, match="outside the HIP generator engine"):
-            skip(8, 3, device="cpu", **INVERSION_NET)
+        with pytest.warns(RuntimeWarning, match="outside the HIP generator engine"):   # asked for by name, the stock-PyTorch net still announces itself
+            net = skip(8, 3, device="cpu", **INVERSION_NET)
     finally:
-        del os.environ["SPLICE_STRICT_HIP"]
+        del os.environ["SPLICE_ALLOW_STOCK_TORCH"]
     params = list(net.named_parameters())
     assert len(params) == int(g["n_tensors"]) and sum(p.numel() for _, p in params) == int(g["n_params"])
     with torch.no_grad():
