@@ -1223,7 +1223,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(WgradBatch b) {
 static bool wgrad_tile_ok(const WgradArgs& a) {
     static const int on = getenv("SPLICE_WGRAD_TILE") ? atoi(getenv("SPLICE_WGRAD_TILE")) : 1;
     static const int min_px = getenv("SPLICE_WGRAD_TILE_MIN") ? atoi(getenv("SPLICE_WGRAD_TILE_MIN")) : 40000;
-    return on && a.ks == 3 && a.stride == 1 && a.Wo >= 64 && (long long)a.Ho * a.Wo > min_px && a.Hi == a.Ho && a.Wi == a.Wo && a.pad == 1;
+    return on && a.ks == 3 && a.stride == 1 && a.Wo >= 64 && (long long)a.Ho * a.Wo > min_px && a.Hi == a.Ho && a.Wi == a.Wo && a.pad == 1 &&
+           (size_t)a.Cin * a.x_cstride <= 0x1fffffffULL && (size_t)a.Cout * a.dy_cstride <= 0x1fffffffULL;   // (32-bit byte offsets)
 }
 
 // append one layer to a batch (partial sums only: ws gets chunks * Cout*Cin*ks*ks floats); returns the number of chunks
