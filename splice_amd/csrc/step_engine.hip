@@ -19,6 +19,7 @@
 
 #include <chrono>
 #include <deque>
+#include <array>
 #include <map>
 #include <mutex>
 
@@ -118,6 +119,13 @@ struct SpliceStep {
     int ablate = 0;                                  // always 0 in the product build.  Scratch builds (-DSPLICE_DEV_SWITCHES) read the SPLICE_STEP_ABLATE bitmask, TIMING experiments only (results are garbage):
                                                      // 1 skip G fwd, 2 skip G bwd, 4 skip ViT bwd, 8 skip target ViT fwd, 16 skip generated ViT fwd, 32 skip the y' chain of the ViT bwd
     std::map<int, hipGraphExec_t> graphs;
+    // steps whose shapes differ from the previous step's (random crop sizes): captured anyway and launched through a rotation of executables that are
+    // UPDATED in place -- the host records ~600 nodes and patches their parameters instead of issuing ~600 launches (round 5; SPLICE_STEP_GRAPH_EVERY)
+    struct RotExec { hipGraphExec_t ex = nullptr; hipEvent_t done = nullptr; };
+    static constexpr int ROT = 3;
+    std::map<int, std::array<RotExec, ROT>> rot;
+    std::map<int, int> rot_pos;
+    long long rot_launches = 0;
     long graph_updates = 0, graph_update_refusals = 0, graph_instantiations = 0;
     void* graph_ptrs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // arenas + the caller's losses / running buffers a captured graph is bound to
     float* losses_out = nullptr;                     // this step's destination of the [P][8] loss values (written by total_loss_kernel)
@@ -136,6 +144,7 @@ struct SpliceStep {
 };
 
 static void drop_graphs(SpliceStep* st);
+static void retire_rotation(SpliceStep* st);
 static bool create_events(SpliceStep* st) {
     for (auto& set : st->evs)
         for (hipEvent_t& e : set)
@@ -388,6 +397,7 @@ void splice_step_destroy(void* h) {
     SpliceStep* st = (SpliceStep*)h;
     if (!st) return;
     drop_graphs(st);
+    retire_rotation(st);
     if (st->own_stream) { (void)hipStreamSynchronize(st->own_stream); (void)hipStreamDestroy(st->own_stream); }
     if (st->side_stream) { (void)hipStreamSynchronize(st->side_stream); (void)hipStreamDestroy(st->side_stream); }
     for (auto& set : st->evs)
@@ -693,6 +703,19 @@ static void drop_graphs(SpliceStep* st) {
     st->graphs.clear();
 }
 
+// the rotation's executables of a handle that goes away: into the process-wide pool (the next handle's captures update them in place), never destroyed
+static void retire_rotation(SpliceStep* st) {
+    if (st->own_stream) (void)hipStreamSynchronize(st->own_stream);
+    std::lock_guard<std::mutex> lk(g_dead_mu);
+    for (auto& kv : st->rot)
+        for (auto& r : kv.second) {
+            if (r.ex) g_spare[graph_key(st, kv.first)].push_back(r.ex);
+            if (r.done) (void)hipEventDestroy(r.done);
+            r.ex = nullptr; r.done = nullptr;
+        }
+    st->rot.clear();
+}
+
 // One step of every pair.  step_idx is the reference's data step counter (0-based, data/Dataset.py:57,63).
 // params/grads/m/v: the generator arenas, [P][arena_stride] (one flat arena when P = 1).  A_crop / B_crop: [P][3][h][w]
 // at the current crop sizes; A_entire [P][3][ent_h][ent_w] (may be NULL on steps where step_idx % entire_every != 0).
@@ -763,7 +786,71 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
         sa.ip = st->dev_t; sa.iv = step_idx + 1;
         SPLICE_LAUNCH(stage_inputs_kernel, dim3(128 * (P > 4 ? 4 : P)), dim3(256), 0, s, sa);
     }
-    if (!graph) {
+    // Changing shapes (round 5): the step is still captured, and an executable of the handle's rotation for this regime is updated in place from the capture
+    // and launched.  Eager, the host issues ~600 launches of ~6.6 us per step -- 3.96 ms against 3.6 ms of GPU time, train_model was HOST-bound
+    // (tools/e2e_cprofile.py); recording the nodes and patching their parameters costs less than launching them.  The rotation (3 executables per regime)
+    // keeps the update off an executable that may still be running: slot i was launched three steps ago, its completion event is waited for (normally
+    // already signalled).  An update the runtime refuses (another kernel choice at the new sizes) re-instantiates that slot; the old executable is parked.
+    // MEASURED (round 5, same box): correct (bit-equal to eager, tests/test_step_gpu.py) and SLOWER -- the train_model regime 272.1 -> 265.9 steps/s, a 2000-step
+    // pair end to end 8.14 -> 8.93 s: recording ~600 nodes + hipGraphExecUpdate costs more host time per step than ~600 eager launches.  Kept behind
+    // SPLICE_STEP_GRAPH_EVERY=1 as the record; the default stays eager launches for changing shapes.
+    static const int graph_every = getenv("SPLICE_STEP_GRAPH_EVERY") ? atoi(getenv("SPLICE_STEP_GRAPH_EVERY")) : 0;   // OFF: measured slower (below)
+    const bool rotate = !graph && graph_every && st->use_graph && !splice_prof_active() && !st->dbg_own_eager && graph_reuse_on();
+    if (rotate) {
+        hipStream_t rs = st->own_stream;
+        HIPCHK(hipEventRecord(st->ev(SpliceStep::EV_IN), s));     // (the staged inputs were written on s)
+        HIPCHK(hipStreamWaitEvent(rs, st->ev(SpliceStep::EV_IN), 0));
+        const int variant = (st->ssim_id_on ? 1 : 0) | (entire ? 2 : 0) | (st->phases << 2);
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(rs, hipStreamCaptureModeThreadLocal));
+        const int rc = step_body(st, params, grads, m, v, st->ssim_id_on != 0, entire, rs);
+        const hipError_t ee = hipStreamEndCapture(rs, &g);
+        if (rc != SPLICE_OK || ee != hipSuccess || !g) {
+            if (g) (void)hipGraphDestroy(g);
+            if (rc == SPLICE_OK) splice_set_error("splice_step_run: graph capture failed (%s)", hipGetErrorString(ee));
+            return rc != SPLICE_OK ? rc : SPLICE_ERR_HIP;
+        }
+        auto& ring = st->rot[variant];
+        int& pos = st->rot_pos[variant];
+        SpliceStep::RotExec& slot = ring[pos];
+        pos = (pos + 1) % SpliceStep::ROT;
+        if (!slot.done) HIPCHK(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+        bool ready = false;
+        if (!slot.ex) {   // an empty slot first looks for a retired executable of this step configuration (a previous pair's rotation): bounded executable count per process
+            std::lock_guard<std::mutex> lk(g_dead_mu);
+            auto sp = g_spare.find(graph_key(st, variant));
+            if (sp != g_spare.end() && !sp->second.empty()) { slot.ex = sp->second.back(); sp->second.pop_back(); }
+            if (slot.ex) (void)hipDeviceSynchronize();   // (its last launch belonged to another handle: no event of ours to wait for)
+        } else {
+            HIPCHK(hipEventSynchronize(slot.done));
+        }
+        if (slot.ex) {
+            hipGraphNode_t bad_node = nullptr;
+            hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
+            if (hipGraphExecUpdate(slot.ex, g, &bad_node, &res) == hipSuccess && res == hipGraphExecUpdateSuccess) {
+                ready = true;
+                ++st->graph_updates;
+            } else {
+                (void)hipGetLastError();
+                std::lock_guard<std::mutex> lk(g_dead_mu);
+                g_parked.push_back(slot.ex);
+                if (g_parked.size() > 64) { g_dead.push_back(DeadGraph{g_parked.front(), std::chrono::steady_clock::now()}); g_parked.erase(g_parked.begin()); }
+                slot.ex = nullptr;
+                ++st->graph_update_refusals;
+            }
+        }
+        if (!ready) {
+            const hipError_t ei = hipGraphInstantiate(&slot.ex, g, nullptr, nullptr, 0);
+            if (ei != hipSuccess) { (void)hipGraphDestroy(g); slot.ex = nullptr; splice_set_error("splice_step_run: hipGraphInstantiate: %s", hipGetErrorString(ei)); return SPLICE_ERR_HIP; }
+            ++st->graph_instantiations;
+        }
+        (void)hipGraphDestroy(g);
+        HIPCHK(hipGraphLaunch(slot.ex, rs));
+        HIPCHK(hipEventRecord(slot.done, rs));
+        ++st->rot_launches;
+        HIPCHK(hipEventRecord(st->ev(SpliceStep::EV_OUT), rs));
+        HIPCHK(hipStreamWaitEvent(s, st->ev(SpliceStep::EV_OUT), 0));
+    } else if (!graph) {
         RC(step_body(st, params, grads, m, v, st->ssim_id_on != 0, entire, s));
     } else {
         const int variant = (st->ssim_id_on ? 1 : 0) | (entire ? 2 : 0) | (st->phases << 2);

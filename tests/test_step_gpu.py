@@ -629,3 +629,43 @@ def test_full_length_run_configs1_2000_steps():
     used0, used1 = mem[199][0], mem[1999][0]
     print(f"    device memory in use after 200 / 2000 steps: {used0 / 2**20:.0f} / {used1 / 2**20:.0f} MiB; torch allocator {mem[199][1] / 2**20:.0f} / {mem[1999][1] / 2**20:.0f} MiB")
     assert abs(used1 - used0) < 64 * 2 ** 20 and mem[1999][1] == mem[199][1]
+
+
+@pytest.mark.gpu
+def test_changing_crop_sizes_run_through_updated_executables_bit_equal_to_eager():
+    """Round 5 (an OPTION, off by default: SPLICE_STEP_GRAPH_EVERY=1): a step whose crop sizes differ from the previous step's (the reference's default regime:
+    a new random size nearly every step) is captured anyway and launched through a rotation of three executables per regime that are updated in place -- the
+    host records the nodes instead of issuing ~600 launches.  A new size at EVERY step, the cls warm-up, ordinary and entire-image regimes in the run: parameters bit-equal to eager launches, every capture
+    after the rotation has filled is an update, a second handle starts from the first one's executables."""
+    import ctypes as C
+    from splice_amd import _lib
+    A, B = synth.smooth_image_pair(79, 0, 64, 64)
+    At, Bt = torch.from_numpy(A).to(DEV), torch.from_numpy(B).to(DEV)
+    sizes = [64, 63, 62, 64, 61, 63, 62, 60, 64, 63, 61, 62, 64, 60, 63, 62, 61, 64]
+    import subprocess, sys, textwrap
+    if os.environ.get("SPLICE_STEP_GRAPH_EVERY") != "1":
+        # the switch is read once per process and is OFF by default (the form measured slower than eager launches: profiles/r05_graph_every_step.txt):
+        # the test body runs in a child interpreter with it on
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-s", "-k", "changing_crop_sizes_run_through_updated"],
+                           env=dict(os.environ, SPLICE_STEP_GRAPH_EVERY="1"), capture_output=True, text=True, timeout=600)
+        print(textwrap.indent("\n".join(l for l in r.stdout.splitlines() if "rotation:" in l), "    "))
+        assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+        return
+    def run(graph):
+        eng = _engine(dict(cls_warmup=2, entire_A_every=5), A, B, gen_seed=6, img_size=64)
+        _lib.check(_lib.lib().splice_step_use_graph(eng.handle, graph))
+        for sz in sizes:
+            eng.step(At[:, :sz, :sz].contiguous(), Bt[:, :sz, :sz].contiguous(), At)
+        torch.cuda.synchronize()
+        st = (C.c_longlong * 3)()
+        _lib.check(_lib.lib().splice_step_graph_stats(eng.handle, st))
+        return eng.params.clone(), list(st)
+    p_eager, st0 = run(0)
+    p_rot, st1 = run(1)
+    assert st0 == [0, 0, 0], st0
+    assert torch.equal(p_rot, p_eager)
+    p_rot2, st2 = run(1)
+    assert torch.equal(p_rot2, p_eager)
+    print(f"    rotation: first engine updates / refusals / instantiations {st1}, second engine {st2}")
+    assert st1[0] + st1[2] == len(sizes) and st1[0] >= len(sizes) // 2, st1     # every step captured; most of them updates (refusals re-instantiate)
+    assert st2[0] >= st1[0], st2                                                 # the second engine's empty slots start from the first one's executables
