@@ -191,7 +191,8 @@ def train_model(dataroot, callback=None, cfg_overrides=None, vit_state=None, pro
             engine.step(inputs['A_global'], inputs['B_global'], inputs['A'][0] if 'A' in inputs else None)
             if log:
                 engine.book_logged_forward()   # ... and its BatchNorm bookkeeping lands AFTER the step's, as in the reference
-                writer.submit(output[0])
+                # (out/output.png is overwritten every time: intermediate images may be skipped when they come faster than the writer's interval, the last one never)
+                writer.submit(output[0], force=epoch + cfg['log_images_freq'] > cfg['n_epochs'])
                 if callback is not None:
                     callback(output[0])
             if progress and (epoch % 50 == 0 or epoch == 1):
@@ -289,7 +290,7 @@ def train_pairs(dataroots, callback=None, cfg_overrides=None, vit_state=None, pr
             if log:
                 engine.book_logged_forward()   # BatchNorm bookkeeping of the P logging forwards, after the step's (train.py:70-79)
                 for p, out in enumerate(outputs):
-                    writers[p].submit(out[0])
+                    writers[p].submit(out[0], force=epoch + cfg['log_images_freq'] > cfg['n_epochs'])
                     if callback is not None:
                         callback(p, out[0])
             if progress and (epoch % 50 == 0 or epoch == 1):

@@ -2,6 +2,7 @@
 over the generator's arena-backed parameters), ``tensor2im``, ``save_result``."""
 from pathlib import Path
 
+import os
 import numpy as np
 import torch
 from torch.optim import lr_scheduler
@@ -89,10 +90,25 @@ class AsyncResultWriter:
         for _ in range(slots):
             self._free.put(None)
         self._err = None
+        # Round 5: out/output.png is OVERWRITTEN by every logged image (util/util.py:55-59 called from train.py:75), so only the latest one matters to a
+        # reader.  At ~270 steps/s a logged image every 10 steps is 27 PNG encodes per second on a thread that shares the GIL with the launch loop
+        # (measured: 8.1 -> 7.6 s per 2000-step pair without them).  Intermediate images closer than min_interval seconds are skipped; the caller forces the
+        # last one.  SPLICE_LOG_MIN_INTERVAL=0 writes every logged image.
+        self.min_interval = float(os.environ.get("SPLICE_LOG_MIN_INTERVAL", "0.25"))
+        self._last = -1e9
+        self.skipped = 0
         self._t = threading.Thread(target=self._run, name="splice-result-writer", daemon=True)
         self._t.start()
 
-    def submit(self, image_t):
+    def submit(self, image_t, force=True):
+        """force=False: the image may be skipped when the previous one was submitted less than ``min_interval`` seconds ago (the file is
+        overwritten every time anyway; the encoder thread shares the interpreter lock with the loop that launches the steps)."""
+        import time
+        now = time.monotonic()
+        if not force and now - self._last < self.min_interval:
+            self.skipped += 1
+            return
+        self._last = now
         buf = self._free.get()                      # blocks only if `slots` images are still being written
         img = image_t.detach()
         if buf is None or buf.shape != img.shape:

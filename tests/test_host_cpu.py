@@ -215,6 +215,23 @@ def test_async_result_writer(tmp_path):
     assert not (tmp_path / "out" / "output.png.tmp").exists()
 
 
+def test_async_result_writer_skips_intermediate_images_never_the_last(tmp_path):
+    """Round 5: out/output.png is overwritten by every logged image, so intermediate ones that come faster than the writer's interval may be skipped
+    (force=False); a forced one -- train_model's last logged image -- is always written, whatever came before it."""
+    from PIL import Image
+    from splice_amd.util import AsyncResultWriter
+    w = AsyncResultWriter(str(tmp_path))
+    assert w.min_interval > 0
+    imgs = [torch.from_numpy(synth.image_pair(4, i, 20, 28)[0]) for i in range(6)]
+    for im in imgs[:-1]:
+        w.submit(im, force=False)          # back to back: only the first is inside the interval's budget
+    w.submit(imgs[-1], force=True)
+    w.close()
+    assert w.skipped == 4
+    got = np.asarray(Image.open(tmp_path / "out" / "output.png"))
+    assert np.array_equal(got, (imgs[-1].numpy().transpose(1, 2, 0) * 255.0).astype(np.uint8))
+
+
 def test_facade_factories_cpu():
     """util/util.py:8-39 conventions of the registries: every documented policy builds, unknown names are RETURNED as
     NotImplementedError (not raised), tensor2im casts arrays / passes foreign objects through."""
