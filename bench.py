@@ -407,8 +407,10 @@ def main():
         ih, iw = (int(x) for x in args.image.lower().split("x"))
         side = min(ih, iw)
         P = 1
-        args.pairs_sweep, args.no_train_regime, args.no_cpu_baseline = "", True, True
+        args.pairs_sweep, args.no_cpu_baseline = "", True
         eng, A, B, E_img = synthetic_engine(cfg, pair_id=rep.pair_id(), hw=(ih, iw), seed=1234, device=dev, fp8=fp8_mode, crop_hw=(side, side))
+        from splice_amd import synth as _synth
+        B_full = torch.from_numpy(_synth.image_pair(1234, rep.pair_id(), ih, iw)[1]).to(dev)   # (the train_model regime draws its random 95 .. 100 % crops from the full images)
         hw = (ih, iw)
     else:
         eng, A, B = synthetic_engine(cfg, pair_id=rep.pair_id() * P, hw=hw, seed=1234, device=dev, pairs=P, fp8=fp8_mode, top_cls_only=not args.full_top_block)
@@ -470,7 +472,7 @@ def main():
     train_leg = None
     if world == 1 and P == 1 and args.size >= 64 and not args.no_train_regime:
         try:
-            train_leg = train_regime_leg(eng, A, B)
+            train_leg = train_regime_leg(eng, E_img, B_full) if args.image else train_regime_leg(eng, A, B)
         except Exception as e:
             train_leg = {"steps_per_s": None, "regime": f"failed: {e}"}
     if rank != 0:

@@ -11,7 +11,7 @@ timeout 300 python bench.py --pairs 8 --steps 60 --warmup 10 --no-cpu-baseline -
 timeout 300 python bench.py --fp8 gemm --no-cpu-baseline --no-train-regime --prof-kernels 4,1,2,3 > gpurun_out/${TAG}_bench_fp8_gemm.json 2> gpurun_out/${TAG}_bench_fp8_gemm.err
 timeout 300 python bench.py --pairs 8 --fp8 gemm --steps 60 --warmup 10 --no-cpu-baseline --no-train-regime --pairs-sweep "" > gpurun_out/${TAG}_bench_pairs8_fp8_gemm.json 2> gpurun_out/${TAG}_bench_pairs8_fp8_gemm.err
 timeout 300 python bench.py --size 512 --steps 60 --warmup 10 --no-cpu-baseline --no-train-regime --pairs-sweep "" > gpurun_out/${TAG}_bench_512.json 2> gpurun_out/${TAG}_bench_512.err
-timeout 300 python bench.py --image 900x1200 --steps 30 --warmup 5 --no-cpu-baseline --no-train-regime --pairs-sweep "" > gpurun_out/${TAG}_bench_900_1200.json 2> gpurun_out/${TAG}_bench_900_1200.err
+timeout 300 python bench.py --image 900x1200 --steps 30 --warmup 5 --no-cpu-baseline --pairs-sweep "" > gpurun_out/${TAG}_bench_900_1200.json 2> gpurun_out/${TAG}_bench_900_1200.err
 timeout 300 python bench.py --scales 224,320,448 --steps 60 --warmup 10 > gpurun_out/${TAG}_bench_scales.json 2> gpurun_out/${TAG}_bench_scales.err
 timeout 300 python bench.py --scales 224,320,448 --fp8 gemm --steps 60 --warmup 10 > gpurun_out/${TAG}_bench_scales_fp8_gemm.json 2> gpurun_out/${TAG}_bench_scales_fp8_gemm.err
 bash tools/prof_step.sh ${TAG}_p1 --steps 60 --warmup 10 > /dev/null 2>&1
