@@ -96,6 +96,7 @@ class AsyncResultWriter:
         # last one.  SPLICE_LOG_MIN_INTERVAL=0 writes every logged image.
         self.min_interval = float(os.environ.get("SPLICE_LOG_MIN_INTERVAL", "0.25"))
         self._last = -1e9
+        self._gap = 0.0         # 10 x the duration of the last convert + encode + write (a 1200 x 900 image takes ~60 ms: the writer thread stays under 10 % duty)
         self.skipped = 0
         self._t = threading.Thread(target=self._run, name="splice-result-writer", daemon=True)
         self._t.start()
@@ -105,7 +106,7 @@ class AsyncResultWriter:
         overwritten every time anyway; the encoder thread shares the interpreter lock with the loop that launches the steps)."""
         import time
         now = time.monotonic()
-        if not force and now - self._last < self.min_interval:
+        if not force and now - self._last < max(self.min_interval, self._gap):
             self.skipped += 1
             return
         self._last = now
@@ -130,10 +131,14 @@ class AsyncResultWriter:
             try:
                 if ev is not None:
                     ev.synchronize()
+                import time
+                t0 = time.monotonic()
                 arr = (buf.clamp(0.0, 1.0).numpy().transpose(1, 2, 0) * 255.0).astype(np.uint8)
                 tmp = self.dir / "output.png.tmp"
                 Image.fromarray(arr).save(tmp, format="PNG")
                 tmp.replace(self.dir / "output.png")      # readers never see a half-written file
+                if self.min_interval > 0:
+                    self._gap = 10.0 * (time.monotonic() - t0)
             except Exception as e:                         # surfaced by close()
                 self._err = e
             self._free.put(buf)
