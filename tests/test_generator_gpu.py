@@ -56,7 +56,8 @@ def test_generator_vs_reference_golden(golden_dir, tag, h, w):
     np.testing.assert_allclose(got[:, 2], ref[:, 2], rtol=3e-2, atol=1e-13)
 
 
-@pytest.mark.parametrize("N,h,w", [(2, 75, 102), (1, 213, 213), (2, 160, 160)])
+@pytest.mark.parametrize("N,h,w", [(2, 75, 102), (1, 213, 213), (2, 160, 160), (1, 300, 282), (2, 264, 330)])   # (the last two: planes above 40000 / 65536 pixels --
+# round 5's LDS-halo tile convolutions and weight gradients, ragged tiles in both directions, the register-resident BatchNorm segments with odd plane sizes)
 def test_generator_batch_vs_fp64_oracle_and_accumulate(N, h, w):
     """N side-by-side calls == N independent oracle calls (per-call BN statistics); parameter
     gradients sum over calls; accumulate adds.  Gradients vs the fp64 oracle (see module docstring)."""
