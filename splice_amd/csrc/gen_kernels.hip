@@ -504,13 +504,13 @@ int conv_pair_launch(ConvArgs a, ConvArgs b, hipStream_t s, int* ksplit_a, int* 
 // 3x3 stride-1 convolution of BIG planes (round 5: the reference's default 855 .. 900 crops, 448^2, 512^2): a 2-D pixel tile with the input halo
 // staged in LDS.  conv_igemm_body gathers 64 pixels x 72 k-values per channel tile for 18 MFMAs per wave -- every input element is fetched 9 times
 // per 16 output channels, each behind its own descriptor -- and the instruction stream around the MFMAs costs twice the matrix pipe's time on
-// these layers (profiles/r05_conv_big_planes.txt).  Here a workgroup owns 8 rows x 64 columns of output; per channel chunk it stages the
-// (8 + 2) x (64 + 2) input patch ONCE (padding / reflection resolved while staging, row-contiguous loads), a wave owns two rows = 8 pixel fragments,
-// and one weight fragment + one address add serve 8 MFMAs.  The k order inside a chunk, the chunk size (conv_ck) and the operand layout are those
+// these layers (profiles/r05_conv_big_planes.txt).  Here a workgroup owns 4 RW rows x 64 columns of output (RW = 1 is what runs: 4 rows); per channel
+// chunk it stages the (4 RW + 2) x (64 + 2) input patch ONCE (padding / reflection resolved while staging, row-contiguous loads), a wave owns RW rows =
+// 4 RW pixel fragments, and one weight fragment + one address add serve 4 RW MFMAs per output-channel fragment.  The k order inside a chunk, the chunk size (conv_ck) and the operand layout are those
 // of conv_igemm_body: the same bits (tools/gen_bits.py under SPLICE_CONV_TILE=0 / 1).
 constexpr int CT_TW = 64, CT_PW = CT_TW + 2;
-// RW = output rows per wave (2: the 8-row tile described above; 1: a 4-row tile -- twice the workgroups, 1.5 x instead of 1.25 x the halo -- for planes that
-// would make too few 8-row tiles to fill the chip)
+// RW = output rows per wave (1: the 4-row tile, the default on every plane -- 118 .. 133 VGPRs, 3 - 4 waves per SIMD; 2: an 8-row tile with 1.25 x instead of
+// 1.5 x the halo and 167 .. 183 VGPRs, measured slower everywhere: SPLICE_CONV_TILE_RW1_MAX)
 template <bool TRANSPOSED, int FN, int CK, int RW>
 __global__ __launch_bounds__(256) void conv3x3_tile_kernel(ConvArgs a, int tiles_x) {
     constexpr int CT_TH = 4 * RW, CT_PH = CT_TH + 2, CT_PLANE = CT_PH * CT_PW, NF = 4 * RW;   // NF = 16-pixel fragments per wave
