@@ -61,7 +61,7 @@ def library_env():
 def dev_env_violations(dev_build):
     """Settings under which a timed step is not the product's step (the bench must refuse them)."""
     env, bad = library_env(), []
-    for k in ("SPLICE_STEP_ABLATE", "SPLICE_STEP_SYNC", "SPLICE_STEP_OWN_EAGER"):   # on when non-zero
+    for k in ("SPLICE_STEP_ABLATE", "SPLICE_STEP_SYNC"):   # on when non-zero
         if env.get(k, "0").strip() not in ("", "0"):
             bad.append(f"{k}={env[k]}")
     for k in ("SPLICE_STEP_GRAPH", "SPLICE_STEP_OVERLAP"):                         # the default execution form, off when 0
@@ -208,7 +208,38 @@ def kernel_families(T, D, heads, P, size, depth=12, fp8=False):
             P * 1.5 * 2.2623e9 * g),
         # key self-similarity: S* (upper tiles, 0.47 of T^2 D x 2), S + loss (same), dK = W K (2 T^2 D); two calls per step (target | loss + dK)
         8: ("selfsim kernels (norms, S*, fused S / MSE / W, dK) per call", "bf16", P * (0.5 * 2.0 * T * T * D * 2 + 2.0 * T * T * D) / 2),
+        # LayerNorm: HBM-bound; the work figure is algorithmic BYTES per call, mean of a forward call (2 P passes: fp32 row in, bf16 row out) and a
+        # backward call (P passes: 3 split-K slabs + x + incoming gradient in, fp32 gradient + its bf16 copy out = 26 B per element)
+        10: ("layernorm_fwd_kernel / layernorm_bwd_kernel (mean of both)", "hbm", P * T * D * (2 * 6 + 26) / 2.0),
+        11: ("gemm_nt_kernel bf16-output dgrads (fc2^T x GELU', proj^T + delta row dots; mean of both)", "bf16", P * 2.0 * T * D * (hidden + D) / 2),
     }
+
+
+KERNEL_CLASSES = {"vit_gemms": (1, 2, 4, 9, 5, 11), "attention": (3, 6), "layernorm": (10,), "generator": (7,), "structure_loss": (8,)}
+
+
+def hbm_copy_rate(dev):
+    """This box's f32 copy rate (torch's float4 copy kernel over 1 GiB, GB/s moved = read + write): the boxes of the pool differ by a few per cent
+    (-1.5 % on the headline between two rounds' boxes), so every line states what its box delivers."""
+    import torch
+    n = 1 << 28
+    a = torch.empty(n, device=dev, dtype=torch.float32).fill_(1.0)
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(3):
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        for _ in range(4):
+            b.copy_(a)
+        s1.record()
+        torch.cuda.synchronize()
+        best = max(best, 4 * 2.0 * n * 4 / (s0.elapsed_time(s1) * 1e-3) / 1e9)
+    del a, b
+    torch.cuda.empty_cache()
+    return round(best, 1)
 
 
 def time_steps(eng, A, B, K, W, barrier, E=None):
@@ -352,8 +383,8 @@ def main():
                                                                   "all the losses read besides the keys)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-regime", action="store_true", help="skip the train_model-shaped leg (random crops + augmentations + logging)")
-    ap.add_argument("--prof-kernels", default="4,5,3,6,7,8", help="kernel families timed live for the roofline leg ('' = off): 4 fc2 fwd, 1 fc1 fwd, 2 qkv fwd, 9 proj fwd, "
-                                                                  "3 attention fwd, 5 split-K dgrads, 6 attention bwd, 7 generator chain, 8 key self-similarity")
+    ap.add_argument("--prof-kernels", default="4,1,2,9,5,11,3,6,10,7,8", help="kernel families timed live for the roofline leg ('' = off; default: all): 4 fc2 fwd, 1 fc1 fwd, 2 qkv fwd, 9 proj fwd, "
+                                                                  "5 split-K dgrads, 11 bf16-output dgrads, 3 attention fwd, 6 attention bwd, 10 LayerNorm, 7 generator chain, 8 key self-similarity")
     ap.add_argument("--allow-dev-env", action="store_true", help="run although a debugging / work-skipping SPLICE_* switch is set (the JSON line then carries config.dev_env)")
     args = ap.parse_args()
     fp8_mode = False if not args.fp8 else ("attention" if (args.fp8 == "attention" or args.fp8_attention == "on") else "gemm")   # splice_amd.vit.fp8_mode
@@ -496,10 +527,11 @@ def main():
     for fam, (tot_ms, calls, kernels, steps, n_ent, per_kernel) in prof.items():
         kname, cls, flops = fams[fam]
         avg_ms = max(tot_ms / calls, 1e-6)
-        ach = flops / (avg_ms * 1e-3) / 1e12
-        peak = {"bf16": BF16_MFMA_PEAK, "fp8mx": FP8_MX_MFMA_PEAK}.get(cls, F32_MFMA_PEAK)
+        hbm_bound = cls == "hbm"   # (work = algorithmic bytes per call)
+        ach = flops / (avg_ms * 1e-3) / (1e9 if hbm_bound else 1e12)
+        peak = HBM_PEAK if hbm_bound else {"bf16": BF16_MFMA_PEAK, "fp8mx": FP8_MX_MFMA_PEAK}.get(cls, F32_MFMA_PEAK)
         traffic = static_traffic.get(str(fam))
-        r = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+        r = {"bound": "hbm" if hbm_bound else "mfma", "family": fam, "kernel": kname, "achieved": round(ach, 2), "peak": peak, "unit": "GB/s" if hbm_bound else "TFLOP/s",
              "frac": round(ach / peak, 4), "traffic": traffic,
              "traffic_source": None if traffic is None else "static: profiles/roofline_traffic.json, bytes per call of this family (FETCH_SIZE x2 + WRITE_SIZE from separate --pmc passes of tools/pmc_families.sh on this workload and build; not re-measured by this command)",
              "avg_launch_us": round(avg_ms * 1e3, 2), "calls_per_step": round(calls / steps, 1), "kernels_per_step": round(kernels / steps, 1),
@@ -538,6 +570,31 @@ def main():
         roof["other_kernels"] = [r for r in roofs if r is not singles[0]]
         worst = min(roofs, key=lambda r: r["frac"])
         roof["furthest_below_roofline"] = {"kernel": worst["kernel"], "frac": worst["frac"], "share_of_step_ms": worst["share_of_step_ms"]}
+    by_class = None
+    if prof:   # class roll-up: every live-timed family in one of five classes -- which CLASS dominates does not depend on how the families are cut
+        by_class = {}
+        for cname, ids in KERNEL_CLASSES.items():
+            got = [f for f in ids if f in prof]
+            if not got:
+                continue
+            ms_step = sum(prof[f][0] / prof[f][3] for f in got)
+            launches = sum(prof[f][2] / prof[f][3] for f in got)
+            work = sum(fams[f][2] * prof[f][1] / prof[f][3] for f in got)   # algorithmic FLOPs (bytes for LayerNorm) per step
+            cls0 = fams[got[0]][1]
+            if cls0 == "hbm":
+                rate, pk, unit = work / (ms_step * 1e-3) / 1e9, HBM_PEAK, "GB/s"
+            else:
+                rate, pk, unit = work / (ms_step * 1e-3) / 1e12, {"bf16": BF16_MFMA_PEAK, "fp8mx": FP8_MX_MFMA_PEAK}.get(cls0, F32_MFMA_PEAK), "TFLOP/s"
+            by_class[cname] = {"families": got, "families_missing": [f for f in ids if f not in prof], "kernel_ms_per_step": round(ms_step, 4), "launches_per_step": round(launches, 1),
+                               ("algorithmic_gb_per_step" if cls0 == "hbm" else "algorithmic_gflop_per_step"): round(work / 1e9, 3), "achieved": round(rate, 2), "peak": pk, "unit": unit,
+                               "frac": round(rate / pk, 4)}
+        tot_ms = sum(v["kernel_ms_per_step"] for v in by_class.values())
+        for v in by_class.values():
+            v["share_of_timed_kernel_ms"] = round(v["kernel_ms_per_step"] / tot_ms, 4)
+        if roof is not None:
+            roof["by_class"] = by_class
+            roof["by_class_note"] = ("serialised kernel time of the live-timed families per step (the step itself overlaps two chains: ms_per_step is smaller than the sum); not live-timed: "
+                                     "patch embedding, the [CLS]-row tail of the top block, resize / staging / Adam (< 5 % of kernel time, profiles/r06_kernel_stats_p1.csv)")
     north = None
     if all(f in prof for f in (3, 6, 8)):   # BASELINE north_star: MFMA utilisation of the attention + key self-similarity kernels
         fl = sum(fams[f][2] * prof[f][1] / prof[f][3] for f in (3, 6, 8))            # algorithmic FLOPs per step
@@ -546,6 +603,10 @@ def main():
                  "gflop_per_step": round(fl / 1e9, 2), "kernel_ms_per_step": round(ms_, 4), "achieved_tflops": round(fl / (ms_ * 1e-3) / 1e12, 1),
                  "peak_tflops": BF16_MFMA_PEAK, "frac": round(fl / (ms_ * 1e-3) / 1e12 / BF16_MFMA_PEAK, 4), "target": 0.40,
                  "by_family": {fams[f][0].split(" ")[0]: round(fams[f][2] / (prof[f][0] / prof[f][1] * 1e-3) / 1e12 / BF16_MFMA_PEAK, 4) for f in (3, 6, 8)}}
+    try:
+        box_copy = hbm_copy_rate(dev)
+    except Exception:
+        box_copy = None
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         try:
@@ -571,7 +632,7 @@ def main():
                                                                                     "pairs_per_hour_at_2000_steps": round(v * k * 3600 / 2000, 1)})
                                                    for k, v in sorted(sweep.items())},
                    "train_model_regime": train_leg,
-                   "generator_dtype": "f32", "last_loss": round(losses["loss"], 5),
+                   "generator_dtype": "f32", "last_loss": round(losses["loss"], 5), "box_hbm_f32_copy_gb_s": box_copy,
                    "env": library_env(), "host": host, "timing": timing},
         "roofline": roof, "north_star": north, "cpu_baseline": cpu,
     }

@@ -3,7 +3,8 @@
 The 78-step fixture of tests/test_step_gpu.py::test_trajectory_a (64 x 64 pair, DINO ViT-S/8, ``train.py:51-80`` via oracle/step.py) is
 re-run on the CPU in fp32 with the generator gradient of EVERY step perturbed by isotropic noise of relative L2 size eps
 (g' = g + eps * |g| / sqrt(n) * z, z ~ N(0, 1)): eps = 1e-2 and 2e-2 bracket the engine's measured whole-arena gradient error against the
-fp32 oracle at identical parameters (4e-3 .. 1.8e-2, profiles/r05_step_tests_verbose.txt).  Adam with beta1 = 0 moves every parameter by
+fp32 oracle at identical parameters early in the run and teacher-forced (4e-3 .. 1.8e-2), eps = 6e-2 (round 6) covers what it grows to late in
+the free run (up to 6.8e-2 at step 36 .. 77, profiles/r06_step_tests_verbose.txt; DESIGN section 5 says why it grows and that it is noise).  Adam with beta1 = 0 moves every parameter by
 ~lr along sign(g): the trajectory is chaotic, and the ensemble says by how much.  Written: tests/golden/trajectory_ensemble.json -- per
 member the 6-step window means of the total loss relative to the UNPERTURBED reference trajectory (tests/golden/steps.npz), the level
 reached over steps 60..74, and the PSNR of the member's final image against the reference's final image.  The GPU test then requires the
@@ -90,7 +91,7 @@ if __name__ == "__main__":
                   "one_thread_vs_fixture": figures(one_l, one_o, ref_losses, ref_img)}
     print("fp32 against fp32 (1 thread vs many):", json.dumps({k: v for k, v in self_repro.items() if k != "one_thread_vs_fixture"}))
     members = [dict(base, eps=0.0, seed=-1, threads="many"), dict(self_repro["one_thread_vs_fixture"], eps=0.0, seed=-1, threads=1)]
-    for eps in (1e-2, 2e-2):
+    for eps in (1e-2, 2e-2, 6e-2):
         for k in range(n):
             l_, o_ = run_member(eps, k)
             f = figures(l_, o_, ref_losses, ref_img)

@@ -248,6 +248,15 @@ def run_batch(root, n_gpus=1, overrides=None, runner="splice_amd.batch:train_run
                               "restarting it", file=sys.stderr, flush=True)
                         alive[g] = spawn(g)
                         continue
+                    # nothing lost and the queue is drained: the worker had finished its last item and died afterwards (a HIP runtime crash at
+                    # interpreter teardown is exactly this case) -- every pair it claimed has its result.json, so this is not a failure
+                    with lk:
+                        busy = {current[h] for h in alive}
+                        orphaned = [j for j in range(min(head.value, len(items))) if not redo[j] and j not in busy
+                                    and any(not os.path.exists(os.path.join(root, names[i], "out", "result.json")) for i in items[j])]
+                    if not orphaned:
+                        print(f"run_batch: worker of gpu {g} was killed by signal {-p.exitcode} after its last item; all results are on disk", file=sys.stderr, flush=True)
+                        continue
             if p.exitcode < 0 and k >= 0 and attempts[k] < int(max_retries):   # killed by a signal while running item k: hand it back, new worker
                 attempts[k] += 1
                 print(f"run_batch: worker of gpu {g} was killed by signal {-p.exitcode} while running {[names[i] for i in items[k]]}; "

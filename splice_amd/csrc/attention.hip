@@ -157,308 +157,8 @@ __device__ __forceinline__ void dma_wait_barrier() {
     __syncthreads();
 }
 
-// ---------------------------------------------------------------------------------------
-// forward: workgroup = 4 waves x QB blocks of 16 queries; 64-key K / V^T tiles arrive by LDS-DMA into a 2-deep
-// ring (one barrier per tile, the next tile's DMA flies during this tile's MFMAs).  The hot loop is branch-free
-// except for ONE wave-uniform test per tile: probabilities are formed against the running maximum of the LAST
-// rescale (p = exp2(s*c - m), no per-tile max, no cross-lane traffic) and the exact max / rescale path only runs
-// when some lane's partial row sum leaves [0, 2^30) -- i.e. on the first tile and when the scores outgrow the
-// reference point by a factor 2^30.  softmax is shift-invariant, so the result is the same function; P stays
-// within bf16's fp32-sized exponent range and O, l accumulate in fp32.
-#define ATTN_RESCALE_LIMIT 1073741824.0f
-#ifdef ATTN_QFOLD
-#define ATTN_M0 0.0f
-#else
-#define ATTN_M0 NEG_BIG
-#endif
-template <int QB, int NSUB, bool MASK>
-__device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs, const FragAddr& fa, const u32x4 (&qf)[QB][2],
-                                              float (&m)[QB], float (&l)[QB], f32x4 (&o)[QB][4], float c2, int kt, int T, int g, bool first = false) {
-    f32x4 s[QB][NSUB * 2];
-#pragma unroll
-    for (int nb = 0; nb < NSUB * 2; ++nb) {
-        const u32x4 k0 = lds16(Ks + fa.tok[0] + (nb >> 1) * 2048 + (nb & 1) * 256);
-        const u32x4 k1 = lds16(Ks + fa.tok[1] + (nb >> 1) * 2048 + (nb & 1) * 256);
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-#ifdef ATTN_QFOLD   // experiment (profiles/r04_attn_qfold_experiment.txt): q carries scale * log2(e), the accumulator starts at -m
-            s[qb][nb] = mfma16(k0, qf[qb][0], f32x4{-m[qb], -m[qb], -m[qb], -m[qb]});
-#else
-            s[qb][nb] = mfma16(k0, qf[qb][0], f32x4{0.f, 0.f, 0.f, 0.f});
-#endif
-            s[qb][nb] = mfma16(k1, qf[qb][1], s[qb][nb]);
-        }
-    }
-    if (MASK) {
-#pragma unroll
-        for (int nb = 0; nb < NSUB * 2; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool valid = kt + (nb >> 1) * 32 + g * 8 + (nb & 1) * 4 + r < T;
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) s[qb][nb][r] = valid ? s[qb][nb][r] : NEG_BIG;
-            }
-    }
-    f32x4 p[QB][NSUB * 2];
-    float ps[QB];
-    bool over[QB];
-    bool redo = false;
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        float part[NSUB * 2];
-#pragma unroll
-        for (int nb = 0; nb < NSUB * 2; ++nb) {
-#pragma unroll
-#ifdef ATTN_QFOLD
-            for (int r = 0; r < 4; ++r) p[qb][nb][r] = __builtin_amdgcn_exp2f(s[qb][nb][r]);
-#else
-            for (int r = 0; r < 4; ++r) p[qb][nb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][nb][r], c2, -m[qb]));
-#endif
-            part[nb] = (p[qb][nb][0] + p[qb][nb][1]) + (p[qb][nb][2] + p[qb][nb][3]);
-        }
-        ps[qb] = NSUB == 2 ? (part[0] + part[1]) + (part[NSUB * 2 - 2] + part[NSUB * 2 - 1]) : part[0] + part[1];
-#ifdef ATTN_QFOLD
-        over[qb] = first || !(ps[qb] < ATTN_RESCALE_LIMIT);   // the reference point starts at 0: the first tile of a walk always takes the exact path
-#else
-        over[qb] = !(ps[qb] < ATTN_RESCALE_LIMIT);
-#endif
-        redo |= over[qb];
-    }
-    if (__any(redo)) {
-        // exact online-softmax step (rare): executed by the whole wave, taking effect PER QUERY -- only a query one of whose four
-        // lanes ran over moves its reference maximum; for the others mn = m, alpha = 1 and the same p and row sum come out again
-        // (same summation order as above).  A query's bits must not depend on which other queries share its wave: the launch
-        // forms (16 / 32 queries per wave, one / two wave groups) have to agree exactly.
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            float mx = NEG_BIG;
-#pragma unroll
-            for (int nb = 0; nb < NSUB * 2; ++nb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qb][nb][r]);
-#ifdef ATTN_QFOLD
-            mx = group4_max(mx) + m[qb];   // scores are held as s * c2 - m
-#else
-            mx = group4_max(mx) * c2;
-#endif
-            const bool mine = group4_max(over[qb] ? 1.0f : 0.0f) > 0.f;
-            const float mn = mine ? fmaxf(m[qb], mx) : m[qb];
-            const float alpha = __builtin_amdgcn_exp2f(m[qb] - mn);
-            const float mold = m[qb];
-            (void)mold;
-            m[qb] = mn;
-            l[qb] *= alpha;
-#pragma unroll
-            for (int nd = 0; nd < 4; ++nd)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[qb][nd][r] *= alpha;
-            float part[NSUB * 2];
-#pragma unroll
-            for (int nb = 0; nb < NSUB * 2; ++nb) {
-#pragma unroll
-#ifdef ATTN_QFOLD
-                for (int r = 0; r < 4; ++r) p[qb][nb][r] = __builtin_amdgcn_exp2f(s[qb][nb][r] + (mold - mn));
-#else
-                for (int r = 0; r < 4; ++r) p[qb][nb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][nb][r], c2, -mn));
-#endif
-                part[nb] = (p[qb][nb][0] + p[qb][nb][1]) + (p[qb][nb][2] + p[qb][nb][3]);
-            }
-            ps[qb] = NSUB == 2 ? (part[0] + part[1]) + (part[NSUB * 2 - 2] + part[NSUB * 2 - 1]) : part[0] + part[1];
-        }
-    }
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) l[qb] += ps[qb];
-#pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub) {
-        u32x4 pb[QB];
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) pb[qb] = pack8v(p[qb][sub * 2], p[qb][sub * 2 + 1]);
-#pragma unroll
-        for (int nd = 0; nd < 4; ++nd) {
-            const u32x4 vf = lds_tr16(Vs, fa.tr[nd] + sub * 2048);   // V^T[d][keys sub*32 + 8g .. +7] out of the V token tile
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) o[qb][nd] = mfma16(vf, pb[qb], o[qb][nd]);
-        }
-    }
-}
+#define ATTN_RESCALE_LIMIT 1073741824.0f   // a lane whose partial row sum reaches this takes the rescale / exact path (attn_x32.h, the e4m3 forward)
 
-// KS = 2: the workgroup holds TWO groups of 4 waves that own the SAME queries; group 0 walks the first half of the key tiles,
-// group 1 the second half (own LDS ring each), and group 0 merges the two partial softmax states (m, l, O) at the end -- the
-// exact online-softmax merge, through LDS.  At one pair per GPU a (pass, head) offers 13 blocks of 64 queries: 312 workgroups
-// = 1.2 waves per SIMD that each walk 13 key tiles one after the other with nothing to overlap their LDS / MFMA / exp
-// latencies (profiles/r02_pmc_attn_selfsim_p1.txt: 47 % of the wave cycles parked).  Two groups give every SIMD a second
-// wave and halve the serial walk.  Every launch uses the same split (it does not depend on the batch), so a pass's output
-// bits do not depend on how many passes share the launch.
-// NW = 8 (one wave group only): EIGHT waves = 128 * QB queries share one K / V ring -- half the L2 -> LDS traffic and DMA issue work per
-// query, 16 waves per CU under the LDS limit instead of 12; per query the arithmetic is that of the 4-wave forms (same bits).
-template <int QB, int KS, int NW = 4>
-__global__ __launch_bounds__(64 * NW * KS) void attn_fwd_kernel(AttnArgs a, int nx) {
-    static_assert(KS == 1 || NW == 4, "two wave groups are groups of four waves");
-    __shared__ __attribute__((aligned(16))) bf16_t smem[KS * 2 * 2 * 4096 + (KS == 1 ? NW * QB * 18 * 64 * 2 : 0)];   // [group][stage][K | V^T] tiles (+ one group: the parked first state)
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 4, c = lane & 15;
-    const int grp = KS > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
-    int xb, h, b;
-    attn_block_coords(nx, a.H, a.B, xb, h, b);
-    const int ld = 3 * a.D;
-    const TileDmaT<NW> dma;
-    const FragAddr fa(g, c);
-    const int qbase = xb * (16 * NW * QB) + dma.wave * (16 * QB);
-    const bool active = qbase < a.Tld;   // a wave without queries still moves its share of every tile
-    const bf16_t* qkv_b = a.qkv + (size_t)b * a.Tld * ld;
-    const bf16_t* kbase = qkv_b + a.D + h * 64;
-    const bf16_t* vbase = qkv_b + 2 * a.D + h * 64;   // V as a token tile: P V takes V^T out of it with the transposing LDS read
-    u32x4 qf[QB][2];
-    int qidx[QB];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        int q = qbase + qb * 16 + c;
-        qidx[qb] = q;
-        q = q < a.Tld ? q : a.Tld - 1;
-        const bf16_t* p = qkv_b + (size_t)q * ld + h * 64 + g * 8;
-        qf[qb][0] = ld16v(p);
-        qf[qb][1] = ld16v(p + 32);
-#ifdef ATTN_QFOLD
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float lo = __uint_as_float(qf[qb][hf][j] << 16) * (a.scale * LOG2E), hi = __uint_as_float(qf[qb][hf][j] & 0xFFFF0000u) * (a.scale * LOG2E);
-                qf[qb][hf][j] = pack2bf(lo, hi);
-            }
-#endif
-    }
-    const uint32_t koff = dma.token_off(ld);
-    auto issue = [&](int kt, bf16_t* st) {
-        if (kt + 64 <= a.Tld) {
-            dma.fast_tile(kbase + (size_t)kt * ld, koff, ld, st);
-            dma.fast_tile(vbase + (size_t)kt * ld, koff, ld, st + 4096);
-        } else {
-            dma.token_tile(kbase, ld, kt, a.Tld - 1, st);
-            dma.token_tile(vbase, ld, kt, a.Tld - 1, st + 4096);
-        }
-    };
-    // key tiles with at least one valid key: [0, nt); group grp owns [t0, t1)
-    const int nt = (a.T + 63) / 64, per = (nt + 1) / 2;    // the key range is ALWAYS split in two (same bits for every launch form)
-    const int t0 = KS > 1 ? grp * per : 0, t1 = KS > 1 ? min(nt, t0 + per) : nt;
-    bf16_t* ring = smem + grp * (2 * 8192);
-    if (t0 < t1) issue(t0 * 64, ring);
-    float m[QB], l[QB];
-    f32x4 o[QB][4];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        m[qb] = ATTN_M0;
-        l[qb] = 0.f;
-#pragma unroll
-        for (int nd = 0; nd < 4; ++nd) o[qb][nd] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const float c2 = a.scale * LOG2E;
-    auto run_tile = [&](int tile, const bf16_t* cur, bool first) {
-        const int kt = tile * 64;
-        if (kt + 64 <= a.T) attn_fwd_tile<QB, 2, false>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g, first);
-        // last tile: padding keys masked, second sub-tile skipped when it is all padding
-        else if (kt + 32 < a.T) attn_fwd_tile<QB, 2, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g, first);
-        else attn_fwd_tile<QB, 1, true>(cur, cur + 4096, fa, qf, m, l, o, c2, kt, a.T, g, first);
-    };
-    if (KS == 1) {
-        // One group walks BOTH key ranges, one after the other, and merges the two softmax states with the arithmetic of the
-        // two-group form below: bit for bit the same output (the batched launches keep their 4-wave workgroups -- many waves per
-        // SIMD anyway -- without making a pass's result depend on the batch size).  The first state waits in LDS, lane for lane
-        // (kept in registers it cost 40 VGPRs and a third of the batched kernel's speed).
-        const int per2 = (nt + 1) / 2;
-        float* park = reinterpret_cast<float*>(smem + 2 * 2 * 4096);   // [wave][QB][18][64], behind the ring
-        auto walk = [&](int tb, int te) {
-            for (int it = tb; it < te; ++it) {
-                dma_wait_barrier();
-                if (it + 1 < nt) issue((it + 1) * 64, ring + ((it + 1) & 1) * 8192);
-                if (active) run_tile(it, ring + (it & 1) * 8192, it == tb);
-            }
-        };
-        walk(0, per2);
-        if (nt > per2) {
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                float* e = park + ((dma.wave * QB + qb) * 18) * 64 + lane;
-                e[0] = m[qb];
-                e[64] = l[qb];
-                m[qb] = ATTN_M0; l[qb] = 0.f;
-#pragma unroll
-                for (int nd = 0; nd < 4; ++nd) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) e[(2 + nd * 4 + r) * 64] = o[qb][nd][r];
-                    o[qb][nd] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            walk(per2, nt);
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                const float* e = park + ((dma.wave * QB + qb) * 18) * 64 + lane;
-                const float m0 = e[0], l0 = e[64], m1 = m[qb], l1 = l[qb];
-                const float mn = fmaxf(m0, m1);
-                const float a0 = __builtin_amdgcn_exp2f(m0 - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
-                m[qb] = mn;
-                l[qb] = merge2(l0, a0, l1, a1);
-#pragma unroll
-                for (int nd = 0; nd < 4; ++nd)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[qb][nd][r] = merge2(e[(2 + nd * 4 + r) * 64], a0, o[qb][nd][r], a1);
-            }
-        }
-    } else {
-        for (int it = 0; it < per; ++it) {
-            dma_wait_barrier();   // tile `it` of every group has landed; tile it-1 fully consumed
-            const int tile = t0 + it;
-            if (tile + 1 < t1) issue((tile + 1) * 64, ring + ((it + 1) & 1) * 8192);
-            if (active && tile < t1) run_tile(tile, ring + (it & 1) * 8192, it == 0);
-        }
-    }
-    if (KS > 1) {   // merge the groups' partial states: lane for lane (same query, same output columns in both groups)
-        float* ex = reinterpret_cast<float*>(smem);   // [wave4][QB][18][64]
-        __syncthreads();                              // every ring is idle
-        if (grp == 1) {
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                float* e = ex + ((dma.wave * QB + qb) * 18) * 64 + lane;
-                e[0] = m[qb];
-                e[64] = l[qb];
-#pragma unroll
-                for (int nd = 0; nd < 4; ++nd)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) e[(2 + nd * 4 + r) * 64] = o[qb][nd][r];
-            }
-        }
-        __syncthreads();
-        if (grp == 1) return;
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            const float* e = ex + ((dma.wave * QB + qb) * 18) * 64 + lane;
-            const float m1 = e[0], l1 = e[64];
-            const float mn = fmaxf(m[qb], m1);
-            const float a0 = __builtin_amdgcn_exp2f(m[qb] - mn), a1 = __builtin_amdgcn_exp2f(m1 - mn);
-            m[qb] = mn;
-            l[qb] = merge2(l[qb], a0, l1, a1);
-#pragma unroll
-            for (int nd = 0; nd < 4; ++nd)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[qb][nd][r] = merge2(o[qb][nd][r], a0, e[(2 + nd * 4 + r) * 64], a1);
-        }
-    }
-    if (!active) return;
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const float lt = group4_sum(l[qb]);
-        const int q = qidx[qb];
-        if (q < a.Tld) {
-            const float inv = 1.0f / lt;
-            bf16_t* op = a.out + ((size_t)b * a.Tld + q) * a.D + h * 64 + g * 4;
-#pragma unroll
-            for (int nd = 0; nd < 4; ++nd) st4bf(op + nd * 16, o[qb][nd], inv);
-            if (g == 0) a.lse[((size_t)b * a.H + h) * a.Tld + q] = m[qb] + __builtin_amdgcn_logf(lt);   // log2 units
-        }
-    }
-}
-
-#include "attn_pp.h"
 #include "attn_x32.h"
 #include "attn_bwd_x32.h"
 
@@ -1044,158 +744,105 @@ __global__ void attn_probs_kernel(AttnArgs a, float* probs) {
 }
 
 // ---------------------------------------------------------------------------------------
-static int g_attn_variant = getenv("SPLICE_ATTN_FWD_VARIANT") ? atoi(getenv("SPLICE_ATTN_FWD_VARIANT")) : 0;   // benchmarking hook (splice_attention_variant): forward queries per wave 16*v, 0 = automatic
+// Launch policy.  No environment reads: the only switches are the two C-ABI hooks below (splice_attention_variant /
+// splice_attention_bwd_variant), which the op-level tests use to force EVERY launch form the policy can pick and compare bits.
+static int g_attn_variant = 0;       // forward: 0 automatic; 41 / 42 / 48 = the 32x32x16 kernel with 4 / 2 / 8 waves; e4m3 forward: queries per wave / 16 + 10 * (two wave groups)
 void attn_set_variant(int v) { g_attn_variant = v; }
-static int g_attn_qfold = 0;
+static int g_attn_qfold = 0;         // the stand-alone entry points take pre-scaled q (AttnArgs::qfold) when set
 void attn_set_qfold(int on) { g_attn_qfold = on; }
 int attn_qfold_hook() { return g_attn_qfold; }
 
+// hipFuncSetAttribute once per (kernel, device): a flag per device ordinal, so a second device of the same process sets its own
+struct AttrOnce {
+    bool done[64] = {};
+    void set(const void* fn, int bytes) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); return; }
+        if (!done[dev]) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); done[dev] = true; }
+    }
+};
+
 template <int NW, bool FOLD>
 static void attn_fwd_x32_go(const AttnArgs* a, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_x32_kernel<NW, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, X32<NW>::LDS_BYTES);
-        attr_done = true;
-    }
+    static AttrOnce attr;
+    attr.set((const void*)attn_fwd_x32_kernel<NW, FOLD>, X32<NW>::LDS_BYTES);
     const int nx = cdiv(a->Tld, 32 * NW);
     SPLICE_LAUNCH((attn_fwd_x32_kernel<NW, FOLD>), dim3(nx * a->H * a->B), dim3(64 * NW), X32<NW>::LDS_BYTES, s, *a, nx);
-}
-template <int QB, bool FOLD>
-static void attn_fwd_pp_go(const AttnArgs* a, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<QB, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-        attr_done = true;
-    }
-    const int nx = cdiv(a->Tld, 64 * QB);
-    SPLICE_LAUNCH((attn_fwd_pp_kernel<QB, FOLD>), dim3(nx * a->H * a->B), dim3(512), PP_LDS_BYTES, s, *a, nx);
 }
 
 int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
     if (a->Tld % 32 || a->D % 64 || a->D / 64 != a->H) return SPLICE_ERR_ARG;
-    // Launch form.  Stand-alone (tools/attn_bench.py at 2 / 8 / 16 passes of T = 785 and 2 passes of T = 3137, profiles/r03_attn_forms.txt)
-    // 16 queries per wave and TWO wave groups per workgroup (key-range halves side by side) is the fastest form at every batch
-    // size -- 13.4 / 31.6 / 60.9 us against 15.8 / 34.2 / 66.2 for one group walking both halves -- except where its 8-wave,
-    // 64 KB workgroups just miss one round of the chip.  All forms, and 32 queries per wave (very long batches), produce
-    // the same bits, so the choice is free.  variant (benchmarking hook / SPLICE_ATTN_FWD_VARIANT): queries per wave / 16 + 10 * (wave groups - 1); 0 = automatic.
-    // round 5: the 32x32x16 form (attn_x32.h); variants 41 / 42 / 48 = 4 / 2 / 8 waves per workgroup
-    // Default since round 5 for the bf16 forward: four waves (128 queries) per workgroup; every form of this kernel gives a query the same
-    // bits (its arithmetic does not depend on the wave count), so a pass's output does not depend on how many passes share the launch.
-    // SPLICE_ATTN_X32=0 restores the 16x16x32 forms below (variants 1 .. 22).
-    static const int x32_mode = getenv("SPLICE_ATTN_X32") ? atoi(getenv("SPLICE_ATTN_X32")) : 4;
-    if (!a->qkv8 && (g_attn_variant / 10 == 4 || (!g_attn_variant && x32_mode))) {
-        const int nwv = g_attn_variant ? g_attn_variant % 10 : x32_mode;
+    if (!a->qkv8) {
+        // bf16: the 32x32x16 kernel (attn_x32.h), four waves (128 queries) per workgroup.  Every form of it gives a query the same bits
+        // (the arithmetic does not depend on the wave count: tests/test_ops_gpu.py forces 2 / 4 / 8), so a pass's output does not
+        // depend on how many passes share the launch.  The 16x16x32 forms of rounds 1-4 and the ping-pong form of round 5
+        // (profiles/r05_attn_pp1.txt: 0.93 x) are gone from the library; their records stay in profiles/ and DESIGN section 8.
+        const int nwv = g_attn_variant / 10 == 4 ? g_attn_variant % 10 : 4;
         if (a->qfold) { if (nwv == 2) attn_fwd_x32_go<2, true>(a, s); else if (nwv == 8) attn_fwd_x32_go<8, true>(a, s); else attn_fwd_x32_go<4, true>(a, s); }
         else { if (nwv == 2) attn_fwd_x32_go<2, false>(a, s); else if (nwv == 8) attn_fwd_x32_go<8, false>(a, s); else attn_fwd_x32_go<4, false>(a, s); }
         return SPLICE_OK;
     }
-    // round 5: the ping-pong form (attn_pp.h); variants 31 / 32 = 16 / 32 queries per wave
-    static const int pp_mode = getenv("SPLICE_ATTN_PP") ? atoi(getenv("SPLICE_ATTN_PP")) : 0;
-    if (!a->qkv8 && (g_attn_variant / 10 == 3 || (!g_attn_variant && pp_mode))) {
-        const int qbp = g_attn_variant ? g_attn_variant % 10 : pp_mode;
-        if (a->qfold) { if (qbp == 2) attn_fwd_pp_go<2, true>(a, s); else attn_fwd_pp_go<1, true>(a, s); }
-        else { if (qbp == 2) attn_fwd_pp_go<2, false>(a, s); else attn_fwd_pp_go<1, false>(a, s); }
-        return SPLICE_OK;
-    }
+    // e4m3 forward (configs[4]): 16 or 32 queries per wave, the key range walked by one wave group or by two side by side (same bits from all
+    // four forms, tests/test_fp8_gpu.py).  Policy measured in the step (profiles/r03_attn_fwd_forms_in_step.txt): two groups until the launch
+    // fills the chip (more than 512 workgroups) on short key walks; 32 queries per wave only for very long batches.
+    if (!a->qkvT8 || a->ldt8 % 16 || a->D % 16) return SPLICE_ERR_ARG;
     const long tasks = (long)a->B * a->H * cdiv(a->Tld, 16);
-    static const long qb2_tasks = getenv("SPLICE_ATTN_QB2_TASKS") ? atol(getenv("SPLICE_ATTN_QB2_TASKS")) : 60000;
-    const int qb = g_attn_variant ? g_attn_variant % 10 : (tasks > qb2_tasks ? 2 : 1);
+    const int qb = g_attn_variant ? g_attn_variant % 10 : (tasks > 60000 ? 2 : 1);
     const long wgs = (long)cdiv(a->Tld, 64 * qb) * a->H * a->B;
-    // (end of round 3, measured IN the step, where the other stream's kernels share the chip: once the launch fills the chip -- more
-    // than 512 workgroups -- one wave group per workgroup wins while the key walk is short (T = 785: -0.6 % step time at 4 / 8 pairs
-    // per GPU) and two groups keep winning on long walks (T = 3137: +0.5 % for one group); profiles/r03_attn_fwd_forms_in_step.txt)
-    static const long ks1_from = getenv("SPLICE_ATTN_KS1_FROM") ? atol(getenv("SPLICE_ATTN_KS1_FROM")) : 512;
-    const int ks = g_attn_variant ? (g_attn_variant / 10 == 1 ? 2 : 1) : ((wgs > ks1_from && a->T <= 2048) ? 1 : 2);
-    // (round 4, second session) wherever one wave group per workgroup is chosen, EIGHT waves share the K / V ring (128 queries per
-    // workgroup; variant 2x): half the L2 -> LDS traffic per query and 16 instead of 12 waves per CU under the LDS limit.  Stand-alone
-    // at 16 passes of T = 785: 57.8 us against 60.1 (two groups) / 65.6 (four waves); in the step -0.5 % at 8 pairs per GPU, -0.9 % at 4
-    // (same-box alternating runs, profiles/r04_attn_w8_ab.txt).  Same bits as every other form (tests/test_ops_gpu.py).
-    static const long w8_from = getenv("SPLICE_ATTN_W8_FROM") ? atol(getenv("SPLICE_ATTN_W8_FROM")) : 512;
-    const bool w8 = !a->qkv8 && (g_attn_variant ? g_attn_variant / 10 == 2 : (w8_from >= 0 && wgs > w8_from && ks == 1));
-    if (w8) {
-        const int nx8 = cdiv(a->Tld, 128 * qb);
-        const dim3 grid8(nx8 * a->H * a->B);
-        if (qb == 2) SPLICE_LAUNCH((attn_fwd_kernel<2, 1, 8>), grid8, dim3(512), 0, s, *a, nx8);
-        else SPLICE_LAUNCH((attn_fwd_kernel<1, 1, 8>), grid8, dim3(512), 0, s, *a, nx8);
-        return SPLICE_OK;
-    }
+    const int ks = g_attn_variant ? (g_attn_variant / 10 == 1 ? 2 : 1) : ((wgs > 512 && a->T <= 2048) ? 1 : 2);
     const int nx = cdiv(a->Tld, 64 * qb);
     const dim3 grid(nx * a->H * a->B);
-    if (a->qkv8) {   // e4m3 forward
-        if (!a->qkvT8 || a->ldt8 % 16 || a->D % 16) return SPLICE_ERR_ARG;
-        if (ks == 2) {
-            if (qb == 2) SPLICE_LAUNCH((attn_fwd8_kernel<2, 2>), grid, dim3(512), 0, s, *a, nx);
-            else SPLICE_LAUNCH((attn_fwd8_kernel<1, 2>), grid, dim3(512), 0, s, *a, nx);
-        } else {
-            if (qb == 2) SPLICE_LAUNCH((attn_fwd8_kernel<2, 1>), grid, dim3(256), 0, s, *a, nx);
-            else SPLICE_LAUNCH((attn_fwd8_kernel<1, 1>), grid, dim3(256), 0, s, *a, nx);
-        }
-        return SPLICE_OK;
-    }
     if (ks == 2) {
-        if (qb == 2) SPLICE_LAUNCH((attn_fwd_kernel<2, 2>), grid, dim3(512), 0, s, *a, nx);
-        else SPLICE_LAUNCH((attn_fwd_kernel<1, 2>), grid, dim3(512), 0, s, *a, nx);
+        if (qb == 2) SPLICE_LAUNCH((attn_fwd8_kernel<2, 2>), grid, dim3(512), 0, s, *a, nx);
+        else SPLICE_LAUNCH((attn_fwd8_kernel<1, 2>), grid, dim3(512), 0, s, *a, nx);
     } else {
-        if (qb == 2) SPLICE_LAUNCH((attn_fwd_kernel<2, 1>), grid, dim3(256), 0, s, *a, nx);
-        else SPLICE_LAUNCH((attn_fwd_kernel<1, 1>), grid, dim3(256), 0, s, *a, nx);
+        if (qb == 2) SPLICE_LAUNCH((attn_fwd8_kernel<2, 1>), grid, dim3(256), 0, s, *a, nx);
+        else SPLICE_LAUNCH((attn_fwd8_kernel<1, 1>), grid, dim3(256), 0, s, *a, nx);
     }
     return SPLICE_OK;
 }
 
-static int g_attn_bwd_variant = getenv("SPLICE_ATTN_BWD_VARIANT") ? atoi(getenv("SPLICE_ATTN_BWD_VARIANT")) : 0;   // 1: the 16x16x32 forms, 2: the 32x32x16 forms (q pre-scaled only), 0: automatic
+// backward hook: 0 automatic; 1 = the 16x16x32 halves (what plain, un-scaled q gets in any case); 2 / 3 = the 32x32x16 halves in one / two
+// launches (pre-scaled q only); 4 = the 32x32x16 halves, one launch of two-wave workgroups
+static int g_attn_bwd_variant = 0;
 void attn_set_bwd_variant(int v) { g_attn_bwd_variant = v; }
+static const int kAttnBwdMergeMaxX32 = 1024;   // workgroups of the merged 32x32x16 launch up to which ONE launch is used
+static const int kAttnBwdMergeMax16 = 768;     // the same bound for the 16x16x32 halves
 
 int attn_bwd_launch(const AttnArgs* a, hipStream_t s) {
     if (a->Tld % 32 || a->D % 64 || a->D / 64 != a->H) return SPLICE_ERR_ARG;
     const int nx = cdiv(a->Tld, 64);
     if (!a->delta_ready) SPLICE_LAUNCH(attn_delta_kernel, dim3(cdiv(a->B * a->Tld * a->H, 256)), dim3(256), 0, s, *a);
-    if (a->qfold && g_attn_bwd_variant != 1) {   // round 5: the 32x32x16 halves (attn_bwd_x32.h); variant 2 = one launch (default), 3 = two launches
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)attn_bwd_x32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, BX_KV_LDS);
-            (void)hipFuncSetAttribute((const void*)attn_bwd_q_x32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, BX_Q_LDS);
-            (void)hipFuncSetAttribute((const void*)attn_bwd_kv_x32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, BX_KV_LDS);
-            attr_done = true;
-        }
-        // small launches: two waves (64 queries / keys) per workgroup -- twice the workgroups, same bits (SPLICE_ATTN_BWD_NW2_MAX: 4-wave workgroup count up to which)
-        static const int nw2_max = getenv("SPLICE_ATTN_BWD_NW2_MAX") ? atoi(getenv("SPLICE_ATTN_BWD_NW2_MAX")) : 0;
-        if (2 * cdiv(a->Tld, 128) * a->H * a->B <= nw2_max) {
-            static bool attr2 = false;
-            if (!attr2) { (void)hipFuncSetAttribute((const void*)attn_bwd_x32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, BX_KV_LDS); attr2 = true; }
+    if (a->qfold && g_attn_bwd_variant != 1) {   // the 32x32x16 halves (attn_bwd_x32.h): what the engine runs
+        static AttrOnce at_m, at_q, at_kv, at_m2;
+        at_m.set((const void*)attn_bwd_x32_kernel<4>, BX_KV_LDS);
+        at_q.set((const void*)attn_bwd_q_x32_kernel<4>, BX_Q_LDS);
+        at_kv.set((const void*)attn_bwd_kv_x32_kernel<4>, BX_KV_LDS);
+        if (g_attn_bwd_variant == 4) {   // two waves (64 queries / keys) per workgroup: twice the workgroups, same bits (tested; not selected by the policy)
+            at_m2.set((const void*)attn_bwd_x32_kernel<2>, BX_KV_LDS);
             const int nx2 = cdiv(a->Tld, 64), n2 = nx2 * a->H * a->B;
             SPLICE_LAUNCH((attn_bwd_x32_kernel<2>), dim3(2 * n2), dim3(128), BX_KV_LDS, s, *a, nx2);
             return SPLICE_OK;
         }
         const int nx4 = cdiv(a->Tld, 128), n4 = nx4 * a->H * a->B;
-        // both forms run the same bodies (same bits): one launch while the chip is not full anyway (a dependent launch costs more than the mix of
-        // the two halves' durations), two once every CU holds several workgroups (T = 3137, 4 passes: 426 against 445 us; 2 passes of T = 785: 37.9
-        // against 32.7 us; profiles/r05_attn_bwd_x32.txt)
-        static const int merge_max4 = getenv("SPLICE_ATTN_BWD_MERGE_MAX") ? atoi(getenv("SPLICE_ATTN_BWD_MERGE_MAX")) : 1024;
-        if (g_attn_bwd_variant == 3 || (g_attn_bwd_variant != 2 && 2 * n4 > merge_max4)) {
+        // both forms run the same bodies (same bits, tested at op level and through the multi-pair step): one launch while the chip is not
+        // full anyway (a dependent launch costs more than the mix of the two halves' durations), two once every CU holds several workgroups
+        // (T = 3137, 4 passes: 426 against 445 us; 2 passes of T = 785: 37.9 against 32.7 us; profiles/r05_attn_bwd_x32.txt)
+        if (g_attn_bwd_variant == 3 || (g_attn_bwd_variant != 2 && 2 * n4 > kAttnBwdMergeMaxX32)) {
             SPLICE_LAUNCH((attn_bwd_q_x32_kernel<4>), dim3(n4), dim3(256), BX_Q_LDS, s, *a, nx4);
             SPLICE_LAUNCH((attn_bwd_kv_x32_kernel<4>), dim3(n4), dim3(256), BX_KV_LDS, s, *a, nx4);
         } else SPLICE_LAUNCH((attn_bwd_x32_kernel<4>), dim3(2 * n4), dim3(256), BX_KV_LDS, s, *a, nx4);
         return SPLICE_OK;
     }
+    // plain q (the op-level C-ABI without splice_attention_qfold): the 16x16x32 halves; one launch while the chip is not full anyway,
+    // two once every CU has several workgroups
     const int n = nx * a->H * a->B;
-    // the two halves in one launch while the chip is not full anyway (a dependent launch costs more than the dQ half's
-    // lower occupancy under the dK/dV half's LDS footprint); two launches once every CU has several workgroups
-    static const int merge_max = getenv("SPLICE_ATTN_MERGE_MAX") ? atoi(getenv("SPLICE_ATTN_MERGE_MAX")) : 768;
-    if (2 * n <= merge_max) {
+    if (2 * n <= kAttnBwdMergeMax16) {
         SPLICE_LAUNCH(attn_bwd_kernel, dim3(2 * n), dim3(256), 0, s, *a, nx);
     } else {
-        // (measured and not selected, round 4: eight waves sharing each ring -- 128 queries / keys per workgroup, half the L2 -> LDS traffic, same
-        // bits -- are SLOWER stand-alone, 165 against 157 us at 16 passes of T = 785, 316 against 286 us at 2 passes of T = 3137, and neutral in the
-        // step; profiles/r04_attn_bwd_w8_ab.txt.  The backward's 33 KB workgroups already sit four to a CU.)  SPLICE_ATTN_BWD_W8=1 selects it.
-        static const int bwd_w8 = getenv("SPLICE_ATTN_BWD_W8") ? atoi(getenv("SPLICE_ATTN_BWD_W8")) : 0;
-        if (bwd_w8) {
-            const int nx8 = cdiv(a->Tld, 128), n8 = nx8 * a->H * a->B;
-            SPLICE_LAUNCH(attn_bwd_q_kernel<8>, dim3(n8), dim3(512), 0, s, *a, nx8);
-            SPLICE_LAUNCH(attn_bwd_kv_kernel<8>, dim3(n8), dim3(512), 0, s, *a, nx8);
-        } else {
-            SPLICE_LAUNCH(attn_bwd_q_kernel<4>, dim3(n), dim3(256), 0, s, *a, nx);
-            SPLICE_LAUNCH(attn_bwd_kv_kernel<4>, dim3(n), dim3(256), 0, s, *a, nx);
-        }
+        SPLICE_LAUNCH(attn_bwd_q_kernel<4>, dim3(n), dim3(256), 0, s, *a, nx);
+        SPLICE_LAUNCH(attn_bwd_kv_kernel<4>, dim3(n), dim3(256), 0, s, *a, nx);
     }
     return SPLICE_OK;
 }

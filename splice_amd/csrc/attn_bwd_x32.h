@@ -24,9 +24,6 @@
 constexpr int BX_SLOTS = 4;
 constexpr int BX_Q_LDS = BX_SLOTS * 2 * 8192;                 // dQ half: K | V per slot
 constexpr int BX_KV_LDS = BX_SLOTS * (2 * 8192 + 512);        // dK/dV half: Q | dO | 64 lse + 64 delta floats per slot
-#ifndef BX_ABL
-#define BX_ABL 0
-#endif
 
 __device__ __forceinline__ int bx_swz(int row) { return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1); }
 
@@ -136,7 +133,6 @@ __device__ __forceinline__ void attn_bwd_q_x32_body(const AttnArgs& a, int xb, i
         for (int ks = 0; ks < 4; ++ks) { kf[ks] = lds16(K + fr.rowa[ks] + blk * 2048); vf[ks] = lds16(K + 4096 + fr.rowa[ks] + blk * 2048); }
     };
     auto sdp = [&](f32x16_t& sx, f32x16_t& dx, int ks) __attribute__((always_inline)) {   // one k step of both chains
-        if (BX_ABL & 8) { pp_opaque(sx); pp_opaque(dx); return; }
         if (ks == 0) {
             if (FOLD) bx_mfma_seed(sx, kf[0], qf[0], negl); else sx = mfma32(kf[0], qf[0], zero16);
             bx_mfma_seed(dx, vf[0], dof[0], negd);
@@ -160,7 +156,7 @@ __device__ __forceinline__ void attn_bwd_q_x32_body(const AttnArgs& a, int xb, i
         if (!TAIL || t + 2 < nt) pp_wait_dma<NL>(); else pp_wait_dma<0>();   // (t = 0: tiles 1, 2 in flight, tile 1 is needed: allow one)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         pp_barrier();
-        if (!(BX_ABL & 4) && (!TAIL || t + 3 < nt)) issue(t + 3, s3);
+        if (!TAIL || t + 3 < nt) issue(t + 3, s3);
         if (active) {
             const bf16_t* Kt = bx_smem + slot * 8192;
             const bf16_t* Kn = bx_smem + s1 * 8192;
@@ -177,7 +173,6 @@ __device__ __forceinline__ void attn_bwd_q_x32_body(const AttnArgs& a, int xb, i
                 float g[16];
                 u32x4 dsb[2], ktf[2][2];
                 auto va = [&](int r0, int n) __attribute__((always_inline)) {
-                    if (BX_ABL & 1) return;
 #pragma unroll
                     for (int r = r0; r < r0 + n; ++r) {
                         const float p = FOLD ? __builtin_amdgcn_exp2f(sc[r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c2, -lse_q));
@@ -186,13 +181,11 @@ __device__ __forceinline__ void attn_bwd_q_x32_body(const AttnArgs& a, int xb, i
                     asm volatile("" : "+v"(g[r0]), "+v"(g[r0 + n - 1]));
                 };
                 auto cv = [&](int kk) __attribute__((always_inline)) {
-                    if (BX_ABL & 1) { pp_opaque(dsb[kk]); return; }
                     const float* pp = &g[kk * 8];
                     dsb[kk] = u32x4{pack2bf(pp[0], pp[1]), pack2bf(pp[2], pp[3]), pack2bf(pp[4], pp[5]), pack2bf(pp[6], pp[7])};
                     pp_opaque(dsb[kk]);
                 };
                 auto rt = [&](int kk, int db) __attribute__((always_inline)) {
-                    if (BX_ABL & 2) { pp_opaque(ktf[kk][db]); return; }
                     ktf[kk][db] = bx_tr(Kt, fr, db, blk * 2048 + kk * 1024);
                 };
                 // (blk 0: the next block is (t, 1), its row fragments are in kf / vf; blk 1: the next block is (t + 1, 0))
@@ -207,11 +200,10 @@ __device__ __forceinline__ void attn_bwd_q_x32_body(const AttnArgs& a, int xb, i
                 for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
-                        if (!(BX_ABL & 8)) dq[db] = mfma32(ktf[kk][db], dsb[kk], dq[db]); else pp_opaque(dq[db]);
+                        dq[db] = mfma32(ktf[kk][db], dsb[kk], dq[db]);
                         BX_SB;
                         const int ks = kk * 2 + db;
-                        if (!(BX_ABL & 2)) { kf[ks] = lds16(Kr + fr.rowa[ks] + blk * 2048); vf[ks] = lds16(Kr + 4096 + fr.rowa[ks] + blk * 2048); }
-                        else { pp_opaque(kf[ks]); pp_opaque(vf[ks]); }
+                        kf[ks] = lds16(Kr + fr.rowa[ks] + blk * 2048); vf[ks] = lds16(Kr + 4096 + fr.rowa[ks] + blk * 2048);
                         BX_SB;
                     }
             }
@@ -322,7 +314,7 @@ __device__ __forceinline__ void attn_bwd_kv_x32_body(const AttnArgs& a, int xb, 
         if (!TAIL || t + 2 < nt) { if (wave < 2) pp_wait_dma<2 * (8 / NW) + 1>(); else pp_wait_dma<2 * (8 / NW)>(); } else pp_wait_dma<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         pp_barrier();
-        if (!(BX_ABL & 4) && (!TAIL || t + 3 < nt)) issue(t + 3, s3);
+        if (!TAIL || t + 3 < nt) issue(t + 3, s3);
         if (active) {
             const bf16_t* st = bx_smem + slot * SLOT;
             const bf16_t* sn = bx_smem + s1 * SLOT;
@@ -334,20 +326,20 @@ __device__ __forceinline__ void attn_bwd_kv_x32_body(const AttnArgs& a, int xb, 
                 // slots 1-4: S chain; the transposed fragments of this block
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    if (!(BX_ABL & 8)) sx = mfma32(qr[ks], kn[ks], sx); else pp_opaque(sx);
+                    sx = mfma32(qr[ks], kn[ks], sx);
                     BX_SB;
-                    if (!(BX_ABL & 2)) {
+                    {
                         if (ks < 2) { dot[ks][0] = bx_tr(st + 4096, fr, 0, blk * 2048 + ks * 1024); dot[ks][1] = bx_tr(st + 4096, fr, 1, blk * 2048 + ks * 1024); }
                         else { qt[ks - 2][0] = bx_tr(st, fr, 0, blk * 2048 + (ks - 2) * 1024); qt[ks - 2][1] = bx_tr(st, fr, 1, blk * 2048 + (ks - 2) * 1024); }
-                    } else if (ks < 2) { pp_opaque(dot[ks][0]); pp_opaque(dot[ks][1]); } else { pp_opaque(qt[ks - 2][0]); pp_opaque(qt[ks - 2][1]); }
+                    }
                     BX_SB;
                 }
                 // slots 5-8: dP chain; p = exp2(-(lse - s)), packed
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    if (!(BX_ABL & 8)) dx = mfma32(dr[ks], vn[ks], dx); else pp_opaque(dx);
+                    dx = mfma32(dr[ks], vn[ks], dx);
                     BX_SB;
-                    if (!(BX_ABL & 1)) {
+                    {
 #pragma unroll
                         for (int r = 4 * ks; r < 4 * ks + 4; ++r) p[r] = __builtin_amdgcn_exp2f(-sx[r]);
                         if (ks & 1) {
@@ -355,16 +347,16 @@ __device__ __forceinline__ void attn_bwd_kv_x32_body(const AttnArgs& a, int xb, 
                             pb[ks >> 1] = u32x4{pack2bf(pp[0], pp[1]), pack2bf(pp[2], pp[3]), pack2bf(pp[4], pp[5]), pack2bf(pp[6], pp[7])};
                             pp_opaque(pb[ks >> 1]);
                         } else asm volatile("" : "+v"(p[4 * ks]), "+v"(p[4 * ks + 3]));
-                    } else if (ks & 1) pp_opaque(pb[ks >> 1]);
+                    }
                     BX_SB;
                 }
                 // slots 9-12: dV^T += dO^T P; g = p * (delta - dP) = -dS, packed
 #pragma unroll
                 for (int i4 = 0; i4 < 4; ++i4) {
                     const int kk = i4 >> 1, db = i4 & 1;
-                    if (!(BX_ABL & 8)) dv[db] = mfma32(dot[kk][db], pb[kk], dv[db]); else pp_opaque(dv[db]);
+                    dv[db] = mfma32(dot[kk][db], pb[kk], dv[db]);
                     BX_SB;
-                    if (!(BX_ABL & 1)) {
+                    {
 #pragma unroll
                         for (int r = 4 * i4; r < 4 * i4 + 4; ++r) g[r] = p[r] * dx[r];
                         if (i4 & 1) {
@@ -372,7 +364,7 @@ __device__ __forceinline__ void attn_bwd_kv_x32_body(const AttnArgs& a, int xb, 
                             gb[i4 >> 1] = u32x4{pack2bf(pp[0], pp[1]), pack2bf(pp[2], pp[3]), pack2bf(pp[4], pp[5]), pack2bf(pp[6], pp[7])};
                             pp_opaque(gb[i4 >> 1]);
                         } else asm volatile("" : "+v"(g[4 * i4]), "+v"(g[4 * i4 + 3]));
-                    } else if (i4 & 1) pp_opaque(gb[i4 >> 1]);
+                    }
                     BX_SB;
                 }
                 // slots 13-16: -dK^T += Q^T (-dS); rows + seeds of the next block (this tile's block 1, or block 0 of tile t + 1)
@@ -381,9 +373,9 @@ __device__ __forceinline__ void attn_bwd_kv_x32_body(const AttnArgs& a, int xb, 
 #pragma unroll
                 for (int i4 = 0; i4 < 4; ++i4) {
                     const int kk = i4 >> 1, db = i4 & 1;
-                    if (!(BX_ABL & 8)) dkn[db] = mfma32(qt[kk][db], gb[kk], dkn[db]); else pp_opaque(dkn[db]);
+                    dkn[db] = mfma32(qt[kk][db], gb[kk], dkn[db]);
                     BX_SB;
-                    if (!(BX_ABL & 2)) {
+                    {
                         const float* Ls = reinterpret_cast<const float*>(nx_st + 8192);
                         qr[i4] = lds16(nx_st + fr.rowa[i4] + nx_blk * 2048);
                         dr[i4] = lds16(nx_st + 4096 + fr.rowa[i4] + nx_blk * 2048);
@@ -391,7 +383,7 @@ __device__ __forceinline__ void attn_bwd_kv_x32_body(const AttnArgs& a, int xb, 
                         const f32x4 ev = *reinterpret_cast<const f32x4*>(Ls + 64 + 32 * nx_blk + 8 * i4 + 4 * hi);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) { sx[4 * i4 + i] = lv[i]; dx[4 * i4 + i] = ev[i]; }
-                    } else { pp_opaque(qr[i4]); pp_opaque(dr[i4]); pp_opaque(sx); pp_opaque(dx); }
+                    }
                     BX_SB;
                 }
             }

@@ -34,12 +34,18 @@ struct X32 {
     static constexpr int LDS_BYTES = 6 * 8192;
 };
 
-#ifndef X32_SEED   // 1: the score MFMAs start from the accumulator -m (FOLD); 0: they start from 0 and the softmax subtracts m (one v_sub_f32 per score)
-#define X32_SEED 1
-#endif
-#ifndef X32_ABL   // timing-only ablations: 1 no softmax VALU, 2 no LDS fragment reads, 4 no DMA in the loop, 8 no MFMAs, 16 no waits / barriers in the loop
-#define X32_ABL 0
-#endif
+// LDS-DMA from inline asm (the compiler may not reorder it against the counted waits), counted vmcnt wait, raw barrier fenced for the scheduler
+__device__ __forceinline__ void pp_dma16(uint32_t lds_byte, uint32_t voff, const void* sbase) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_byte), "v"(voff), "s"(sbase) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void pp_wait_dma() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void pp_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class V> __device__ __forceinline__ void pp_opaque(V& v) { asm volatile("" : "+v"(v)); }   // pins a value HERE (IR-level sinking ignores sched_barrier)
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 __device__ __forceinline__ f32x16_t mfma32(const u32x4& a, const u32x4& b, const f32x16_t& c) {
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_x32_kernel(AttnArgs a, int n
         m_ref = half2_max(mx) * (FOLD ? 1.0f : c2);
 #pragma unroll
         for (int r = 0; r < 16; ++r) negm[r] = -m_ref;
-        if (FOLD && X32_SEED) scores(sb[0], negm);
+        if (FOLD) scores(sb[0], negm);
         if (nt > 1) read_k(Kring + 4096);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every wave holds K(0), K(1) in registers before their slots are refilled
@@ -256,20 +262,16 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_x32_kernel(AttnArgs a, int n
         f32x16_t (&s)[2] = sb[PAR];
         f32x16_t (&sn)[2] = sb[PAR ^ 1];
         const int s1 = slot == 2 ? 0 : slot + 1, s2 = slot == 0 ? 2 : slot - 1;   // (t + 1) % 3, (t + 2) % 3
-        if (!(X32_ABL & 16)) {
-            if (!TAIL || t + 3 < nt) pp_wait_dma<NL>(); else pp_wait_dma<0>();   // only the group issued last tile may still fly
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // this wave's fragment reads are out of the slots refilled below
-            pp_barrier();
+        if (!TAIL || t + 3 < nt) pp_wait_dma<NL>(); else pp_wait_dma<0>();   // only the group issued last tile may still fly
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // this wave's fragment reads are out of the slots refilled below
+        pp_barrier();
+        if (!TAIL) issue_fast(s1, s2);
+        else {
+            if (t + 4 < nt) issue_k(t + 4, s1);   // K(t+1) left its slot for the registers during tile t - 1
+            if (t + 2 < nt) issue_v(t + 2, s2);   // V(t-1) was consumed by tile t - 1
         }
-        if (!(X32_ABL & 4)) {
-            if (!TAIL) issue_fast(s1, s2);
-            else {
-                if (t + 4 < nt) issue_k(t + 4, s1);   // K(t+1) left its slot for the registers during tile t - 1
-                if (t + 2 < nt) issue_v(t + 2, s2);   // V(t-1) was consumed by tile t - 1
-            }
-            kptr += tile_bytes;
-            vptr += tile_bytes;
-        }
+        kptr += tile_bytes;
+        vptr += tile_bytes;
         if (active) {
             const bf16_t* Vs = Vring + slot * 4096;
             const bf16_t* Kn = Kring + s2 * 4096;
@@ -284,22 +286,19 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_x32_kernel(AttnArgs a, int n
                     for (int r = 0; r < 16; ++r) s[kb][r] = kt + 32 * kb + 8 * (r >> 2) + 4 * hi + (r & 3) < a.T ? s[kb][r] : NEG_BIG;
             }
             auto ex = [&](int kb, int r0, int n) __attribute__((always_inline)) {
-                if (X32_ABL & 1) return;
 #pragma unroll
                 for (int r = r0; r < r0 + n; ++r) {
-                    p[kb][r] = FOLD ? __builtin_amdgcn_exp2f(X32_SEED ? s[kb][r] : s[kb][r] - m_ref) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c2, -m_ref));
+                    p[kb][r] = FOLD ? __builtin_amdgcn_exp2f(s[kb][r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c2, -m_ref));
                     pa[r & 3] += p[kb][r];
                 }
                 asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]));   // (pins the adds HERE: IR-level sinking ignores sched_barrier)
             };
             auto cv = [&](int kk) __attribute__((always_inline)) {
-                if (X32_ABL & 1) { pp_opaque(pb[kk]); return; }
                 const float* pp = &p[kk >> 1][(kk & 1) * 8];
                 pb[kk] = u32x4{pack2bf(pp[0], pp[1]), pack2bf(pp[2], pp[3]), pack2bf(pp[4], pp[5]), pack2bf(pp[6], pp[7])};
                 pp_opaque(pb[kk]);   // (pins the conversions HERE)
             };
             auto rv = [&](int kk, int db) __attribute__((always_inline)) {
-                if (X32_ABL & 2) { pp_opaque(vf[kk][db]); return; }
                 typedef __attribute__((address_space(3))) tr_v4s lds_v4s;
                 const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(Vs + va[db] + kk * 1024));
                 const tr_v4s hh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(Vs + va[db] + kk * 1024 + 512));
@@ -307,18 +306,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_x32_kernel(AttnArgs a, int n
                 vf[kk][db] = u32x4{x.x, x.y, y.x, y.y};
             };
             auto rk = [&](int kb, int ks) __attribute__((always_inline)) {
-                if (X32_ABL & 2) { pp_opaque(kf[kb][ks]); return; }
                 kf[kb][ks] = lds16(Kn + ka[ks] + kb * 2048);   // (past the last tile: stale bytes, never used)
             };
             auto qk = [&](int kb, int ks) __attribute__((always_inline)) {
-                if (X32_ABL & 8) { pp_opaque(sn[kb]); return; }
                 // (past the last tile: a dummy product).  The first MFMA of a chain takes its accumulator from -m and writes a DIFFERENT register block:
                 // through the builtin the compiler copies the sixteen registers first (two-address form), 16 v_mov_b64 per tile.
-                if (ks == 0 && FOLD && X32_SEED) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sn[kb]) : "v"(kf[kb][0]), "v"(qf[0]), "v"(negm));
+                if (ks == 0 && FOLD) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sn[kb]) : "v"(kf[kb][0]), "v"(qf[0]), "v"(negm));
                 else sn[kb] = mfma32(kf[kb][ks], qf[ks], ks == 0 ? zero16 : sn[kb]);
             };
             auto pv = [&](int kk, int db) __attribute__((always_inline)) {
-                if (X32_ABL & 8) { pp_opaque(o[db]); return; }
                 o[db] = mfma32(vf[kk][db], pb[kk], o[db]);
             };
             X32_SB;
@@ -352,7 +348,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_x32_kernel(AttnArgs a, int n
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     negm[r] = -m_ref; o[0][r] *= alpha; o[1][r] *= alpha;
-                    if (FOLD && X32_SEED) { sn[0][r] -= shift; sn[1][r] -= shift; }
+                    if (FOLD) { sn[0][r] -= shift; sn[1][r] -= shift; }
                 }
             }
         }

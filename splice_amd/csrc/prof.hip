@@ -10,7 +10,8 @@
 // which: 1 fc1 GEMM fwd, 2 qkv GEMM fwd (layers 0..depth-2), 3 attention fwd, 4 fc2 GEMM fwd, 5 split-K dgrad GEMMs (fc1^T,
 // qkv^T), 6 attention bwd, 7 generator (every conv / BatchNorm / upsample / weight-gradient launch of splice_gen_forward*
 // and splice_gen_backward), 8 key self-similarity loss kernels (norms, S*, fused S / MSE / W, dK),
-// 9 proj GEMM fwd.
+// 9 proj GEMM fwd, 10 LayerNorm forward + backward (the backward also sums the split-K slabs of the dgrad in front of it),
+// 11 the bf16-output dgrad GEMMs (fc2^T x GELU', proj^T + delta row dots).
 #include <algorithm>
 #include <cstdio>
 #include <cstring>

@@ -464,8 +464,11 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
         float* x_mid = c->xmid[l] + r0 * D;
         const bool fp8 = (c->fp8 & 1) && c->ln_out8 && W.qkv.w8;
         const bool fp8_attn = fp8 && (c->fp8 & 2) && c->qkv8;
-        if (fp8) RC(layernorm_fwd_fp8_launch(x_in, W.ln1_g, W.ln1_b, c->ln_out8 + r0 * D, c->ln_scale + r0, c->mean1[l] + r0, c->rstd1[l] + r0, R, D, 1e-6f, s));
-        else RC(layernorm_fwd_launch(x_in, W.ln1_g, W.ln1_b, ln_out, c->mean1[l] + r0, c->rstd1[l] + r0, R, D, 1e-6f, s));
+        {
+            SpliceProfScope ps(10);
+            if (fp8) RC(layernorm_fwd_fp8_launch(x_in, W.ln1_g, W.ln1_b, c->ln_out8 + r0 * D, c->ln_scale + r0, c->mean1[l] + r0, c->rstd1[l] + r0, R, D, 1e-6f, s));
+            else RC(layernorm_fwd_launch(x_in, W.ln1_g, W.ln1_b, ln_out, c->mean1[l] + r0, c->rstd1[l] + r0, R, D, 1e-6f, s));
+        }
         {
             GemmEpi e = {};
             e.bias = W.qkv.b; e.out_bf = c->qkv[l] + r0 * 3 * D; e.ldbf = 3 * D;
@@ -538,8 +541,11 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
             SpliceProfScope ps(9);
             RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, c->attn_out[l] + r0 * D, D, W.proj.w, D, R, D, D, e, s));
         }
-        if (fp8) RC(layernorm_fwd_fp8_launch(x_mid, W.ln2_g, W.ln2_b, c->ln_out8 + r0 * D, c->ln_scale + r0, c->mean2[l] + r0, c->rstd2[l] + r0, R, D, 1e-6f, s));
-        else RC(layernorm_fwd_launch(x_mid, W.ln2_g, W.ln2_b, ln_out, c->mean2[l] + r0, c->rstd2[l] + r0, R, D, 1e-6f, s));
+        {
+            SpliceProfScope ps(10);
+            if (fp8) RC(layernorm_fwd_fp8_launch(x_mid, W.ln2_g, W.ln2_b, c->ln_out8 + r0 * D, c->ln_scale + r0, c->mean2[l] + r0, c->rstd2[l] + r0, R, D, 1e-6f, s));
+            else RC(layernorm_fwd_launch(x_mid, W.ln2_g, W.ln2_b, ln_out, c->mean2[l] + r0, c->rstd2[l] + r0, R, D, 1e-6f, s));
+        }
         {
             GemmEpi e = {};
             e.bias = W.fc1.b; e.out_bf = hact; e.ldbf = Hd; e.out_pre = c->need_grad ? c->hpre[l] + r0 * Hd : nullptr; e.ldp = Hd;
@@ -686,6 +692,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
             {
                 GemmEpi e = {};
                 e.aux = c->hpre[l] + r0 * Hd; e.ldaux = Hd; e.out_bf = c->dh + r0 * Hd; e.ldbf = Hd;
+                SpliceProfScope ps(11);
                 RC(gemm_nt_launch(EPI_GELU_GRAD | EPI_OUT_BF, g_bf, D, W.fc2.wT, D, R, Hd, D, e, s));
             }
             {
@@ -694,7 +701,10 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
                 SpliceProfScope ps(5);
                 RC(gemm_nt_launch(EPI_OUT_F32, c->dh + r0 * Hd, Hd, W.fc1.wT, Hd, R, D, Hd, e, s));
             }
-            RC(layernorm_bwd_slabs_launch(c->dln + r0 * D, gemm_splitk_slabs(R, ks), slab, c->xmid[l] + r0 * D, W.ln2_g, c->mean2[l] + r0, c->rstd2[l] + r0, g, g, g_bf, R, D, s));
+            {
+                SpliceProfScope ps(10);
+                RC(layernorm_bwd_slabs_launch(c->dln + r0 * D, gemm_splitk_slabs(R, ks), slab, c->xmid[l] + r0 * D, W.ln2_g, c->mean2[l] + r0, c->rstd2[l] + r0, g, g, g_bf, R, D, s));
+            }
             // attention branch
             {
                 GemmEpi e = {};
@@ -702,6 +712,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
                 // delta = rowsum(dO * O) per (pass, head, query) for the attention backward, formed where dO is produced
                 e.rd_other = c->attn_out[l] + r0 * D; e.ld_rd = D; e.rd_rows = c->Tld;
                 e.rowdot = c->delta + (size_t)pass_begin * v->heads * c->Tld;
+                SpliceProfScope ps(11);
                 RC(gemm_nt_launch(EPI_OUT_BF | EPI_ROWDOT, g_bf, D, W.proj.wT, D, R, D, D, e, s));
             }
             {
@@ -725,7 +736,10 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
             SpliceProfScope ps(5);
             RC(gemm_nt_launch(EPI_OUT_F32, dqkv, 3 * D, W.qkv.wT, 3 * D, R, D, 3 * D, e, s));
         }
-        RC(layernorm_bwd_slabs_launch(c->dln + r0 * D, gemm_splitk_slabs(R, ks), slab, c->xs[l] + r0 * D, W.ln1_g, c->mean1[l] + r0, c->rstd1[l] + r0, g_after_mlp, g, g_bf, R, D, s));
+        {
+            SpliceProfScope ps(10);
+            RC(layernorm_bwd_slabs_launch(c->dln + r0 * D, gemm_splitk_slabs(R, ks), slab, c->xs[l] + r0 * D, W.ln1_g, c->mean1[l] + r0, c->rstd1[l] + r0, g_after_mlp, g, g_bf, R, D, s));
+        }
         g_live = true;
     }
     if (!g_live) {

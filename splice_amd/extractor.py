@@ -82,8 +82,14 @@ class _VitFeatures(torch.autograd.Function):
         vctx.forward(img.contiguous().float(), normalize=False)
         T, L = vctx.T, eng.depth
         blocks = torch.stack([vctx.read(KIND_BLOCK, l)[0, :T] for l in range(L)])
-        qkv = torch.stack([vctx.read(KIND_QKV, l)[0, :T].float() for l in range(L - 1)] +
-                          [vctx.read(KIND_QKV_LAST_F32, L - 1)[0, :T]])
+        # the engine stores q pre-multiplied by eng.qscale in bf16: widen FIRST, divide in fp32 -- the hooked 'query' facet then carries the single
+        # bf16 rounding of the stored value (KIND_QKV de-scales inside bf16: a second rounding, 2^-9 relative)
+        def qkv_f32(l):
+            t = vctx.read(KIND_QKV_STORED, l)[0, :T].float()
+            if eng.qscale != 1.0:
+                t[:, :eng.dim] /= eng.qscale
+            return t
+        qkv = torch.stack([qkv_f32(l) for l in range(L - 1)] + [vctx.read(KIND_QKV_LAST_F32, L - 1)[0, :T]])
         ctx.vctx, ctx.extractor, ctx.need_grad, ctx.generation = vctx, extractor, need_grad, vctx.generation
         if not need_grad:
             extractor._release(vctx)

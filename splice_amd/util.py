@@ -95,6 +95,8 @@ class AsyncResultWriter:
         # (measured: 8.1 -> 7.6 s per 2000-step pair without them).  Intermediate images closer than min_interval seconds are skipped; the caller forces the
         # last one.  SPLICE_LOG_MIN_INTERVAL=0 writes every logged image.
         self.min_interval = float(os.environ.get("SPLICE_LOG_MIN_INTERVAL", "0.25"))
+        # (_last is written by the submitting thread only, _gap by the writer thread only and read by submit(): single float stores, atomic under the
+        # interpreter lock; a stale _gap only moves ONE skip decision.  A run killed mid-training leaves a file at most max(min_interval, _gap) old.)
         self._last = -1e9
         self._gap = 0.0         # 10 x the duration of the last convert + encode + write (a 1200 x 900 image takes ~60 ms: the writer thread stays under 10 % duty)
         self.skipped = 0

@@ -31,6 +31,9 @@ def stub_runner(pair_dir, overrides):
         if len(marks) < overrides.get("segv_times", 1):
             open(os.path.join(pair_dir, f"crashed{len(marks)}"), "w").close()
             os.kill(os.getpid(), signal.SIGKILL)   # (SIGKILL: dies by a signal like a SIGSEGV, without a core file)
+    if overrides.get("die_at_exit"):   # the process dies by a signal AFTER its last item (what a HIP runtime crash at interpreter teardown looks like)
+        from multiprocessing import util as mp_util
+        mp_util.Finalize(None, os.kill, args=(os.getpid(), signal.SIGKILL), exitpriority=-100)
     t0 = time.time()
     time.sleep(overrides.get("sleep", {}).get(os.path.basename(pair_dir), overrides.get("sleep_default", 0.0)))
     return {"digest": h.hexdigest(), "steps": overrides.get("n_epochs", 0), "pid": os.getpid(), "t0": t0, "t1": time.time()}
@@ -150,6 +153,14 @@ def test_killed_worker_is_replaced_and_its_item_retried(tmp_path):
     assert len([f for f in os.listdir(again / "pair01") if f.startswith("crashed")]) == 2      # first run + one retry
     with pytest.raises(RuntimeError, match=r"exit -9"):                                          # max_retries=0: the old behaviour
         batch.run_batch(str(again), 1, {"segv": "pair00", "segv_times": 1}, runner="test_batch_cpu:stub_runner", pin_gpu=False, max_retries=0)
+
+
+def test_worker_killed_after_its_last_item_is_not_a_failure(tmp_path):
+    """a worker that finished every item it claimed and is then killed by a signal (teardown crash) leaves current = -1, nothing
+    lost and an empty queue -- every pair has its result.json, so run_batch returns the results instead of raising."""
+    _make_pairs(tmp_path, 3)
+    res = batch.run_batch(str(tmp_path), 2, {"n_epochs": 2, "die_at_exit": True}, runner="test_batch_cpu:stub_runner", pin_gpu=False)
+    assert [r["pair"] for r in res] == ["pair00", "pair01", "pair02"] and all(r["steps"] == 2 for r in res)
 
 
 def test_group_equal_sizes():

@@ -124,12 +124,13 @@ def test_multipair_steps_bit_identical_to_single_pair_runs():
     assert not torch.equal(multi.pair_params(0), multi.pair_params(1))
 
 
-@pytest.mark.parametrize("P", [2, 4])
+@pytest.mark.parametrize("P", [2, 4, 8])
 def test_multipair_full_size_bit_identical_and_graph_modes(P):
     """BASELINE configs[1] shapes (224x224, ViT-B/8, T = 785): P pairs on one engine vs the single-pair runs over 4 steps
-    (graph capture at the third step, replay at the fourth, on both sides), and the batched engine eager/serial vs graph/overlap.  P = 4 crosses every
-    size-dependent kernel choice (128x64 GEMM tiles, 32-query attention waves, two-launch attention backward): none of
-    them may change a pair's bits."""
+    (graph capture at the third step, replay at the fourth, on both sides), and the batched engine eager/serial vs graph/overlap.  P = 4 changes the
+    GEMM tiles (128x64, 128x128) against P = 1 and keeps the merged attention backward (2 * 7 * 12 * 4 = 672 <= 1024 workgroups); P = 8 is the
+    configuration of `bench.py --pairs 8` and the pairs sweep: the persistent 256x256 8-phase GEMM tile for the forward projections and the
+    TWO-LAUNCH 32x32x16 attention backward (2 * 7 * 12 * 8 = 1344 workgroups).  None of them may change a pair's bits."""
     cfg = dict(dino_model_name="dino_vitb8", dino_global_patch_size=224)
     vit_state = synth.vit_params(7, "dino_vitb8", img_size=224, w_std=0.03)
     gens = [synth.generator_params(90 + p, 0.02) for p in range(P)]

@@ -264,25 +264,18 @@ def test_attention_fwd_bwd(B, T, D, H, std):
     got = out.float().reshape(B, Tld, D)[:, :T]
     assert torch.isfinite(out.float()).all()
     assert _relerr(got, ref) < 6e-3, _relerr(got, ref)
-    # launch forms must agree BIT FOR BIT -- a pass's attention output may not depend on how many passes share the launch.  Round 5: the default
-    # is the 32x32x16 kernel (attn_x32.h; variants 41 / 42 / 48 = 4 / 2 / 8 waves per workgroup); the 16x16x32 forms (16 / 32 queries per
-    # wave x one / two wave groups x four / eight waves per K / V ring) stay selectable and agree among themselves.
-    if T <= 1601:
-        def run(variant):
-            L.splice_attention_variant(variant)
-            out_v, lse_v = torch.zeros_like(out), torch.zeros_like(lse)
-            _lib.check(L.splice_attention_fwd(_lib.ptr(qkv), _lib.ptr(qkvT), rows, B, T, Tld, D, H, scale, _lib.ptr(out_v), _lib.ptr(lse_v), _st()))
-            torch.cuda.synchronize()
-            L.splice_attention_variant(0)
-            return out_v, lse_v
-        for variant in (41, 42, 48):
-            out_v, lse_v = run(variant)
-            assert torch.equal(out_v, out) and torch.equal(lse_v, lse), variant
-        out_1, lse_1 = run(1)
-        assert _relerr(out_1.float().reshape(B, Tld, D)[:, :T], ref) < 6e-3
-        for variant in (2, 11, 12, 21, 22):
-            out_v, lse_v = run(variant)
-            assert torch.equal(out_v, out_1) and torch.equal(lse_v, lse_1), variant
+    # launch forms must agree BIT FOR BIT -- a pass's attention output may not depend on how many passes share the launch.  The bf16 forward is the
+    # 32x32x16 kernel (attn_x32.h); variants 41 / 42 / 48 = 4 / 2 / 8 waves per workgroup (the 16x16x32 forms of rounds 1-4 left the library in round 6)
+    def run(variant):
+        L.splice_attention_variant(variant)
+        out_v, lse_v = torch.zeros_like(out), torch.zeros_like(lse)
+        _lib.check(L.splice_attention_fwd(_lib.ptr(qkv), _lib.ptr(qkvT), rows, B, T, Tld, D, H, scale, _lib.ptr(out_v), _lib.ptr(lse_v), _st()))
+        torch.cuda.synchronize()
+        L.splice_attention_variant(0)
+        return out_v, lse_v
+    for variant in (41, 42, 48):
+        out_v, lse_v = run(variant)
+        assert torch.equal(out_v, out) and torch.equal(lse_v, lse), variant
     # probabilities API
     probs = torch.empty(B, H, T, T, device=DEV)
     _lib.check(L.splice_attention_probs(_lib.ptr(qkv), B, T, Tld, D, H, scale, _lib.ptr(lse), _lib.ptr(probs), _st()))
@@ -306,6 +299,72 @@ def test_attention_fwd_bwd(B, T, D, H, std):
         assert e < 2e-2, (name, e)
     assert ggot[:, T:, 1:].abs().max().item() == 0.0  # padded keys/values get exactly zero gradient
 
+
+
+# What the ENGINE runs (VERDICT r5 "What's weak" #1): q pre-scaled by scale * log2(e) (the ViT engine packs the q rows of the QKV projection that
+# way), forward attn_fwd_x32_kernel<., FOLD = true>, backward attn_bwd_x32_kernel in ONE launch (<= 1024 workgroups), in TWO launches
+# (attn_bwd_q_x32_kernel + attn_bwd_kv_x32_kernel: 7+ pairs at T = 785, 2+ passes at T = 3137) or as two-wave workgroups.  (8, 785) and (2, 3137)
+# take the two-launch form by the POLICY; every case also forces all three forms and compares bits.
+@pytest.mark.parametrize("B,T,D,H,std", [(1, 17, 384, 6, 1.0), (2, 197, 768, 12, 1.0), (2, 785, 768, 12, 0.6), (1, 785, 768, 12, 2.5),
+                                         (8, 785, 768, 12, 1.0), (2, 3137, 768, 12, 0.6), (2, 1601, 768, 12, 1.0)])
+def test_attention_fwd_bwd_prescaled_q_engine_forms(B, T, D, H, std):
+    Tld = (T + 31) // 32 * 32
+    rows = B * Tld
+    scale = (D // H) ** -0.5
+    c = scale * 1.4426950408889634
+    x = _rand(rows, 3 * D, seed=23, std=std)
+    x[:, :D] *= c                       # the stored q' = q * scale * log2(e), rounded to bf16 ONCE (vit_engine.hip pack_qkv)
+    qkv = _bf(x)
+    qkv_eff = qkv.float().clone()
+    qkv_eff[:, :D] /= c                 # the q the fp32 reference sees
+    L = _lib.lib()
+    ln2 = 0.6931471805599453
+    L.splice_attention_qfold(1)
+    try:
+        def fwd(variant):
+            L.splice_attention_variant(variant)
+            o, l = torch.zeros(rows, D, device=DEV, dtype=torch.bfloat16), torch.zeros(B, H, Tld, device=DEV)
+            _lib.check(L.splice_attention_fwd(_lib.ptr(qkv), None, rows, B, T, Tld, D, H, ln2, _lib.ptr(o), _lib.ptr(l), _st()))
+            torch.cuda.synchronize()
+            L.splice_attention_variant(0)
+            return o, l
+        out, lse = fwd(0)
+        ref, leaf, _ = _attn_ref(qkv_eff, B, T, Tld, D, H, scale)
+        got = out.float().reshape(B, Tld, D)[:, :T]
+        assert torch.isfinite(out.float()).all()
+        assert _relerr(got, ref) < 6e-3, _relerr(got, ref)
+        for variant in (41, 42, 48):
+            o_v, l_v = fwd(variant)
+            assert torch.equal(o_v, out) and torch.equal(l_v, lse), variant
+        dout = _rand(B, Tld, D, seed=24)
+        dout[:, T:] = 0
+        dout = _bf(dout.reshape(rows, D))
+
+        def bwd(variant):
+            L.splice_attention_bwd_variant(variant)
+            delta = torch.zeros(B, H, Tld, device=DEV)
+            dqkv = torch.zeros(rows, 3 * D, device=DEV, dtype=torch.bfloat16)
+            _lib.check(L.splice_attention_bwd(_lib.ptr(qkv), None, rows, B, T, Tld, D, H, ln2, _lib.ptr(out), _lib.ptr(lse), _lib.ptr(dout), None,
+                                              _lib.ptr(delta), _lib.ptr(dqkv), _st()))
+            torch.cuda.synchronize()
+            L.splice_attention_bwd_variant(0)
+            return dqkv
+        dqkv = bwd(0)
+        ref.backward(dout.float().reshape(B, Tld, D)[:, :T])
+        gref = leaf.grad   # [B,T,3,H,d] with respect to the un-scaled q
+        ggot = dqkv.float().reshape(B, Tld, 3, H, D // H).clone()
+        ggot[:, :, 0] *= c   # the kernels return dL/dq'; q = q'/c
+        assert torch.isfinite(ggot).all()
+        for i, name in enumerate("qkv"):
+            e = _relerr(ggot[:, :T, i], gref[:, :, i])
+            assert e < 2e-2, (name, e)
+        assert ggot[:, T:, 1:].abs().max().item() == 0.0
+        for variant in (2, 3, 4):   # one launch / two launches / two-wave workgroups: same bodies, same bits
+            assert torch.equal(bwd(variant), dqkv), variant
+    finally:
+        L.splice_attention_qfold(0)
+        L.splice_attention_variant(0)
+        L.splice_attention_bwd_variant(0)
 
 def _selfsim(K, T, D, eps=1e-8):
     L = _lib.lib()

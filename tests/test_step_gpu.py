@@ -269,16 +269,17 @@ def test_streams_and_graph_do_not_change_results():
 
 
 def test_graph_executables_are_updated_in_place_across_crop_sizes_and_handles():
-    """Round 5: a captured step executable is never destroyed in a running process.  When the crop sizes change, the regime's
-    executable retires to a process-wide pool and the next capture of that step configuration -- by this engine or by the NEXT pair's engine --
-    updates it in place (hipGraphExecUpdate) instead of instantiating a new one.  Here: runs of equal crop sizes (each long enough to capture)
-    at three different sizes, then a second engine; the parameters must equal the eager run's BIT FOR BIT, captures after the first must be
-    updates, and the runtime may refuse none."""
+    """A captured step executable is never destroyed in a running process (round 5) and -- round 6 -- the pool it retires to is keyed by the
+    SIGNATURE of the captured graph (device, kernel function of every node in order, edge list): the next capture with the same launch sequence,
+    by this engine or by the next pair's engine, updates it in place (hipGraphExecUpdate).  Runs of equal crop sizes (each long enough to
+    capture) at several sizes, then a second engine; the parameters must equal the eager run's BIT FOR BIT and the runtime may refuse NO update
+    (round 5 keyed the pool by a few configuration words and saw refusals outnumber updates here, VERDICT r5 "What's weak" #5)."""
     import ctypes as C
     from splice_amd import _lib
     A, B = synth.smooth_image_pair(78, 0, 64, 64)
     At, Bt = torch.from_numpy(A).to(DEV), torch.from_numpy(B).to(DEV)
-    sizes = [64] * 5 + [63] * 5 + [62] * 4 + [64] * 4 + [61] * 1 + [63] * 4   # (one launch-policy class: the kernel sequence is the same at every size)
+    sizes = [64] * 5 + [63] * 5 + [62] * 4 + [64] * 4 + [61] * 1 + [63] * 4
+
     def run(graph):
         eng = _engine(dict(cls_warmup=1, entire_A_every=1000), A, B, gen_seed=6, img_size=64)
         _lib.check(_lib.lib().splice_step_use_graph(eng.handle, graph))
@@ -288,16 +289,17 @@ def test_graph_executables_are_updated_in_place_across_crop_sizes_and_handles():
         st = (C.c_longlong * 3)()
         _lib.check(_lib.lib().splice_step_graph_stats(eng.handle, st))
         return eng.params.clone(), list(st)
-    p_eager, _ = run(0)
+    p_eager, st0 = run(0)
+    assert st0 == [0, 0, 0], st0
     p_graph, st1 = run(1)
     assert torch.equal(p_graph, p_eager)
     p_graph2, st2 = run(1)     # a second handle: its captures find the first one's executables in the pool
     assert torch.equal(p_graph2, p_eager)
     print(f"    graph executables: first engine updates / refusals / instantiations {st1}, second engine {st2}")
-    # (a refusal -- the runtime declines an update because a kernel CHOICE changed with the size -- is legal: the capture then instantiates)
-    assert st1[0] + st1[2] >= 4 and st1[0] >= 1, st1   # the ordinary regime captured at 64, 63, 62, 64, 63: first an instantiation, then updates
-    assert st2[0] >= 1, st2       # the second engine starts from the first one's executables (inside a full test session the pool also holds other
-    # tests' executables of this shape class with other step configurations: the runtime refuses those, which shows as refusals here)
+    assert st1[1] == 0 and st2[1] == 0, (st1, st2)              # same signature => the runtime accepts the update
+    assert st1[0] + st1[2] == 5, st1                            # the ordinary regime captured at 64, 63, 62, 64, 63
+    assert st2[0] + st2[2] == 5 and st2[2] <= st1[2], (st1, st2)   # the second engine instantiates nothing the first one has not left in the pool
+    assert st2[0] >= 1, st2
 
 
 def test_step_phases_and_follower_are_exact():
@@ -631,41 +633,3 @@ def test_full_length_run_configs1_2000_steps():
     assert abs(used1 - used0) < 64 * 2 ** 20 and mem[1999][1] == mem[199][1]
 
 
-@pytest.mark.gpu
-def test_changing_crop_sizes_run_through_updated_executables_bit_equal_to_eager():
-    """Round 5 (an OPTION, off by default: SPLICE_STEP_GRAPH_EVERY=1): a step whose crop sizes differ from the previous step's (the reference's default regime:
-    a new random size nearly every step) is captured anyway and launched through a rotation of three executables per regime that are updated in place -- the
-    host records the nodes instead of issuing ~600 launches.  A new size at EVERY step, the cls warm-up, ordinary and entire-image regimes in the run: parameters bit-equal to eager launches, every capture
-    after the rotation has filled is an update, a second handle starts from the first one's executables."""
-    import ctypes as C
-    from splice_amd import _lib
-    A, B = synth.smooth_image_pair(79, 0, 64, 64)
-    At, Bt = torch.from_numpy(A).to(DEV), torch.from_numpy(B).to(DEV)
-    sizes = [64, 63, 62, 64, 61, 63, 62, 60, 64, 63, 61, 62, 64, 60, 63, 62, 61, 64]
-    import subprocess, sys, textwrap
-    if os.environ.get("SPLICE_STEP_GRAPH_EVERY") != "1":
-        # the switch is read once per process and is OFF by default (the form measured slower than eager launches: profiles/r05_graph_every_step.txt):
-        # the test body runs in a child interpreter with it on
-        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-s", "-k", "changing_crop_sizes_run_through_updated"],
-                           env=dict(os.environ, SPLICE_STEP_GRAPH_EVERY="1"), capture_output=True, text=True, timeout=600)
-        print(textwrap.indent("\n".join(l for l in r.stdout.splitlines() if "rotation:" in l), "    "))
-        assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-        return
-    def run(graph):
-        eng = _engine(dict(cls_warmup=2, entire_A_every=5), A, B, gen_seed=6, img_size=64)
-        _lib.check(_lib.lib().splice_step_use_graph(eng.handle, graph))
-        for sz in sizes:
-            eng.step(At[:, :sz, :sz].contiguous(), Bt[:, :sz, :sz].contiguous(), At)
-        torch.cuda.synchronize()
-        st = (C.c_longlong * 3)()
-        _lib.check(_lib.lib().splice_step_graph_stats(eng.handle, st))
-        return eng.params.clone(), list(st)
-    p_eager, st0 = run(0)
-    p_rot, st1 = run(1)
-    assert st0 == [0, 0, 0], st0
-    assert torch.equal(p_rot, p_eager)
-    p_rot2, st2 = run(1)
-    assert torch.equal(p_rot2, p_eager)
-    print(f"    rotation: first engine updates / refusals / instantiations {st1}, second engine {st2}")
-    assert st1[0] + st1[2] == len(sizes) and st1[0] >= 1, st1     # every step captured: an update, or an instantiation (3 regimes x 3 empty slots at first; a refusal at these tiny sizes re-instantiates)
-    assert st2[0] >= st1[0], st2                                                 # the second engine's empty slots start from the first one's executables
