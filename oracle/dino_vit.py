@@ -138,6 +138,26 @@ class VisionTransformer(nn.Module):
         return self.norm(x)[:, 0]
 
 
+def round_weights_bf16(state, dim, head_dim=64):
+    """TEST INFRASTRUCTURE: the ViT state dict with every Linear / patch-embedding WEIGHT rounded to bf16 the way the HIP engine packs it
+    (splice_amd/csrc/vit_engine.hip pack_linear: one rounding; pack_qkv: the q rows are scaled by head_dim^-1/2 * log2(e) in fp32 FIRST and
+    rounded once).  Biases, LayerNorm parameters, class token and position embedding stay fp32 in the engine, and so here.  An fp32 oracle on
+    these weights is "the model the engine actually holds": comparing against it separates the engine's input-independent deviation (a fixed
+    perturbation of the frozen weights) from the rounding of its activations (tests/test_step_gpu.py, tools/traj_grad_error.py)."""
+    import numpy as np
+    c = (head_dim ** -0.5) * 1.4426950408889634
+    out = {}
+    for k, v in state.items():
+        t = torch.from_numpy(np.asarray(v)).clone() if not torch.is_tensor(v) else v.clone()
+        if k.endswith("attn.qkv.weight"):
+            t[:dim] = (t[:dim] * c).bfloat16().float() / c
+            t[dim:] = t[dim:].bfloat16().float()
+        elif k.endswith(".weight") and t.dim() >= 2:
+            t = t.bfloat16().float()
+        out[k] = t
+    return out
+
+
 def build_vit(model_name=None, patch=None, dim=None, depth=None, heads=None, img_size=224):
     if model_name is not None:
         patch, dim, depth, heads = DINO_CONFIGS[model_name]

@@ -2,7 +2,6 @@
 // DINO-ViT forward / dgrad path uses (K3, K5, K7, K8 of SURVEY.md section 2b).
 #include "kernels.h"
 #include "gemm8p.h"
-#include <cstdlib>
 
 static int g_force_tile = 0;   // 0 auto; tile + 10 * ring: tile 1 = 128x128, 2 = 128x64, 3 = 64x64; ring 0 = 2 stages, 1 = 4 stages, 2 = 3 stages (64x64 only) (tools/gemm_bench.py); 5 = the persistent 256x256 8-phase tile where it exists (gemm8p.h), else automatic
 void gemm_force_tile(int t) { g_force_tile = t; }
@@ -15,7 +14,7 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
     // the batched forward projections with whole 256-column tiles (QKV of the layers without side outputs, fc1) on the persistent
     // 256 x 256 8-phase tile where its grid quantisation is good (gemm8p.h; same bits as every other tile)
     if constexpr (FLAGS == (EPI_BIAS | EPI_OUT_BF) || FLAGS == (EPI_BIAS | EPI_GELU | EPI_OUT_BF) || FLAGS == (EPI_BIAS | EPI_RESID | EPI_OUT_F32)) {
-        static const int on8p = getenv("SPLICE_GEMM_8P") ? atoi(getenv("SPLICE_GEMM_8P")) : 7;   // bit 0: QKV, bit 1: fc1, bit 2: proj / fc2 forward
+        constexpr int on8p = 7;   // bit 0: QKV, bit 1: fc1, bit 2: proj / fc2 forward
         const int bit = (FLAGS & EPI_OUT_F32) ? 4 : (FLAGS & EPI_GELU) ? 2 : 1;
         const bool want = g_force_tile == 5 ? gemm8p_operands_ok(N, K, e, FLAGS) : (!g_force_tile && (on8p & bit) && gemm8p_shape_ok(M, N, K, lda, ldb, e, FLAGS));
         if (want) {
@@ -28,31 +27,46 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
     else {
         // measured on MI355X (tools/gemm_bench.py): with N <= 768 the 64x64 tile wins (more workgroups on the long-K shapes);
         // otherwise the biggest tile that still yields ~2 workgroups per CU (M = 1600: 128x64 beats 128x128 by 10 %, M = 800: 64x64)
-        static const int t2min = getenv("SPLICE_GEMM_T2MIN") ? atoi(getenv("SPLICE_GEMM_T2MIN")) : 300;   // (400 -> 300, end of round 3: -0.4 % step time at one pair, equal at two / eight; profiles/r03_gemm_t1min_sweep.txt)
-        static const int t2ring = getenv("SPLICE_GEMM_T2RING") ? atoi(getenv("SPLICE_GEMM_T2RING")) : 3;
+        constexpr int t2min = 300;   // (400 -> 300, end of round 3: -0.4 % step time at one pair, equal at two / eight; profiles/r03_gemm_t1min_sweep.txt)
+        constexpr int t2ring = 3;
         // (t1min 420 -> 230 at the end of round 3: with the QKV epilogue down to one output the one-pair forward GEMMs of QKV / fc1
         // (234 / 312 tiles of 128 x 128 at 1600 rows) beat their 128 x 64 ring form: -1.9 % step time at one pair, -0.6 % at two,
         // unchanged at eight; profiles/r03_gemm_t1min_sweep.txt)
-        static const int t1min = getenv("SPLICE_GEMM_T1MIN") ? atoi(getenv("SPLICE_GEMM_T1MIN")) : 230;
+        constexpr int t1min = 230;
         // rows of a P-pair batch (tools/gemm_sweep.py, r2): with N <= 768 the 64x64 tile stops winning at ~4800 rows (fc2 at
         // M = 6400: 688 TF on 128x64 vs 554; M = 12800: 872 vs 656); N >= 2304 takes 128x128 from 3200 rows on (t1min 640 -> 420)
         // (in-step at 2 / 3 / 4 pairs per GPU -- 3200 ... 6400 rows -- the 128x64 tile already wins from the first row count without
         // a ring on: +0.9 / +0.3 / +0.8 % pair-steps/s against the stand-alone sweep's 4800, tools/gemm_thresh_sweep.sh)
-        static const int bigm = getenv("SPLICE_GEMM_BIGM") ? atoi(getenv("SPLICE_GEMM_BIGM")) : 2401;
+        constexpr int bigm = 2401;
         tile = (FLAGS & EPI_ROWDOT) ? 3 : N <= 768 ? (M >= bigm ? 2 : 3) : t128 >= t1min ? 1 : t12864 >= t2min ? 2 : 3;
+#ifdef SPLICE_EXP_T160   // experiment build (tools/ab_libs.sh): the 128 x 160 tile where it turns 1.2 rounds of 128 x 128 tiles into one
+        if constexpr (FLAGS == (EPI_BIAS | EPI_GELU | EPI_OUT_BF) || FLAGS == (EPI_GELU_GRAD | EPI_OUT_BF)) {
+            const long t160 = (long)cdiv(M, 128) * cdiv(N, 160);
+            if (N > 768 && tile == 1 && t128 > 272 && t160 <= 272) tile = 4;
+        }
+#endif
         // few workgroups walking a long K (fc2, the fc1 / qkv dgrads): the per-slice DMA latency is exposed with 2 stages,
         // the 4-stage ring keeps 3 slices in flight (fc1T 800x768x3072: 23.4 -> 15.3 us); elsewhere its LDS footprint costs occupancy
         const int ks = (FLAGS == EPI_OUT_F32 && e.ksplit > 1 && K % (e.ksplit * GEMM_BK) == 0) ? e.ksplit : 1;
-        static const int ringk = getenv("SPLICE_GEMM_RINGK") ? atoi(getenv("SPLICE_GEMM_RINGK")) : 768;
-        static const int ringwg = getenv("SPLICE_GEMM_RINGWG") ? atoi(getenv("SPLICE_GEMM_RINGWG")) : 640;
+        constexpr int ringk = 768;
+        constexpr int ringwg = 640;
         // (the rings pay while a launch is a single wave of latency-bound workgroups: M <= 2400 rows; beyond that the plain
         // 2-stage pipeline is faster -- fc2 at M = 3200: 557 vs 460 TF, 128x64 at M = 6400: 688 vs 626)
         ring = (tile == 3 && M <= 2400 && K / ks >= (ks > 1 ? 768 : ringk) && (long)cdiv(M, 64) * cdiv(N, 64) * ks <= ringwg) ? 1 : 0;
         if (tile == 2 && t2ring && M <= 2400) ring = t2ring == 3 ? 2 : 1;
         // the short-K ring shapes (proj, projT: 12 slices) run the 3-stage form -- its own instantiation, so profiles keep
         // them apart from the long-K launches of the same epilogue (fc2)
-        static const int shortns = getenv("SPLICE_GEMM_SHORTNS") ? atoi(getenv("SPLICE_GEMM_SHORTNS")) : 3;
+        constexpr int shortns = 3;
         if (ring && tile == 3 && ks == 1 && K < 1536 && shortns == 3) ring = 2;
+    }
+    if constexpr (FLAGS == (EPI_BIAS | EPI_GELU | EPI_OUT_BF) || FLAGS == (EPI_GELU_GRAD | EPI_OUT_BF) || FLAGS == EPI_OUT_BF) {
+        // 128 x 160 (wave tile 64 x 80): N = 3072 at 1600 rows = 13 x 20 = 260 tiles -- one round of the chip, where 128 x 128 takes 312 (hipBLASLt's choice for
+        // this shape: MT128x160x64, profiles/r06_hipblaslt_kernel_names.txt).  Same k order per accumulator: same bits.
+        if (tile == 4) {
+            if (ring == 2) launch_gemm_nt<128, 160, FLAGS, 3>(s, A, lda, B, ldb, M, N, K, e);
+            else launch_gemm_nt<128, 160, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e);
+            return SPLICE_OK;
+        }
     }
     if constexpr ((FLAGS & EPI_ROWDOT) != 0) {   // only instantiated for the 64-column tile
         if (ring == 2) launch_gemm_nt<64, 64, FLAGS, 3>(s, A, lda, B, ldb, M, N, K, e);
@@ -60,8 +74,8 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
         else launch_gemm_nt<64, 64, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e);
     } else {
         if constexpr (FLAGS == (EPI_BIAS | EPI_RESID | EPI_OUT_F32)) {   // proj forward at M = 2 x 800 (K = 768): one wave of 64x96 tiles (200 workgroups) instead of 300 64x64 ones, in-step -0.4 %;
-            // the same tile for fc2 (K = 3072) measured equal or worse (SPLICE_GEMM_T96: 0 off, 3 both, 5 long-K only, 6 short-K only)
-            static const int t96 = getenv("SPLICE_GEMM_T96") ? atoi(getenv("SPLICE_GEMM_T96")) : 6;
+            // the same tile for fc2 (K = 3072) measured equal or worse (t96: 0 off, 3 both, 5 long-K only, 6 short-K only)
+            constexpr int t96 = 6;
             const long wg64 = (long)cdiv(M, 64) * cdiv(N, 64), wg96 = (long)cdiv(M, 64) * (N / 96);
             if (t96 && !(t96 == 5 && K < 1536) && !(t96 == 6 && K >= 1536) && tile == 3 && N % 96 == 0 && wg64 > 256 && wg96 <= 256) {
                 if (K >= 1536 && t96 != 3) launch_gemm_nt<64, 96, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e);
@@ -117,8 +131,8 @@ static int dispatch_fp8(const uint8_t* A, int lda, const uint8_t* B, int ldb, in
     const bf16_t* a = reinterpret_cast<const bf16_t*>(A);
     const bf16_t* b = reinterpret_cast<const bf16_t*>(B);
     const long t128 = (long)cdiv(M, 128) * cdiv(N, 128), t12864 = (long)cdiv(M, 128) * cdiv(N, 64);
-    static const int t1min8 = getenv("SPLICE_GEMM8_T1MIN") ? atoi(getenv("SPLICE_GEMM8_T1MIN")) : 230;   // (as the bf16 dispatcher: -1.3 % step time at one pair; profiles/r03_gemm_t1min_sweep.txt)
-    static const int t2min8 = getenv("SPLICE_GEMM8_T2MIN") ? atoi(getenv("SPLICE_GEMM8_T2MIN")) : 300;
+    constexpr int t1min8 = 230;   // (as the bf16 dispatcher: -1.3 % step time at one pair; profiles/r03_gemm_t1min_sweep.txt)
+    constexpr int t2min8 = 300;
     if (N <= 768) {   // fc2: as the bf16 dispatcher -- 64x64 tiles on the deep ring for the few-row shapes, 128x64 from the batched row counts on
         if (M >= 2401) launch_gemm_nt<128, 64, FLAGS, 2, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);
         else launch_gemm_nt<64, 64, FLAGS, 4, true>(s, a, lda / 2, b, ldb / 2, M, N, K / 2, e);

@@ -370,13 +370,13 @@ static ConvPolicy conv_policy(const ConvArgs& a, int KS, int CK) {
     // -0.75 % step time, 4 fragments -0.3 % / 0; profiles/r03_conv_fn_ab.txt).  Which output channels share a workgroup does not
     // touch any sum, so a pair's bits do not depend on it -- the split-K / wave-group policy below (which does change the
     // summation order) keeps using the one-image fragment count.
-    static const int batch_fn = getenv("SPLICE_CONV_BATCH_FN") ? atoi(getenv("SPLICE_CONV_BATCH_FN")) : 2;
-    static const int batch_min = getenv("SPLICE_CONV_BATCH_MIN") ? atoi(getenv("SPLICE_CONV_BATCH_MIN")) : 4;
+    constexpr int batch_fn = 2;
+    constexpr int batch_min = 4;
     int fn_run = (KS < 5 && fn == 1 && a.Cout >= 64 && a.N >= batch_min && (batch_fn == 2 || batch_fn == 4)) ? batch_fn : fn;
     // Big planes (round 5; the reference's default 855 .. 900 crops, 448^2, 512^2): thousands of pixel tiles per layer fill the chip whatever the
     // channel split, and every 16-channel fragment a workgroup does NOT own is a second gather of the same input tile by another workgroup
     static const int big_fn = getenv("SPLICE_CONV_BIG_FN") ? atoi(getenv("SPLICE_CONV_BIG_FN")) : 4;   // same-box A/B at 900 x 1200: 0 -> 10.14, 2 -> 10.12, 4 -> 10.10 ms per step
-    static const int big_mt = getenv("SPLICE_CONV_BIG_MT") ? atoi(getenv("SPLICE_CONV_BIG_MT")) : 512;
+    constexpr int big_mt = 512;
     if (KS < 5 && (big_fn == 2 || big_fn == 4) && mt >= big_mt && a.Cout > 16) {
         const int want = a.Cout > 32 ? big_fn : 2;
         if (want > fn_run) fn_run = want;
@@ -467,7 +467,7 @@ static void conv_pair_go(const ConvArgs& a, const ConvArgs& b, const ConvPolicy&
 }
 int conv_pair_launch(ConvArgs a, ConvArgs b, hipStream_t s, int* ksplit_a, int* ksplit_b) {
     static const int pair_on = getenv("SPLICE_CONV_PAIR") ? atoi(getenv("SPLICE_CONV_PAIR")) : 1;
-    static const int pair_maxn = getenv("SPLICE_CONV_PAIR_MAXN") ? atoi(getenv("SPLICE_CONV_PAIR_MAXN")) : 4;
+    constexpr int pair_maxn = 4;
     const int cka = conv_ck(a), ckb = conv_ck(b);
     bool done = false;
     if (pair_on && a.N == b.N && a.N < pair_maxn && !a.reflect && !b.reflect && a.ks == 1 && a.stride == 1 && (b.stride == 1 || b.stride == 2) &&
@@ -666,7 +666,7 @@ static bool conv_tile_ok(const ConvArgs& a) {
 template <bool TR, int CK>
 static void conv_tile_launch(const ConvArgs& a, hipStream_t s) {
     conv_note_work(a);
-    static const int rw1_max = getenv("SPLICE_CONV_TILE_RW1_MAX") ? atoi(getenv("SPLICE_CONV_TILE_RW1_MAX")) : 0x7fffffff;   // planes up to this many pixels take the 4-row tile: all of them (same-box A/B against the 8-row tile: 900 x 1200 9.20 -> 9.07 ms, one pair at 224^2 3.594 -> 3.574, eight pairs 16.33 -> 16.30: 118 .. 133 instead of 167 .. 183 VGPRs)
+    constexpr int rw1_max = 0x7fffffff;   // planes up to this many pixels take the 4-row tile: all of them (same-box A/B against the 8-row tile: 900 x 1200 9.20 -> 9.07 ms, one pair at 224^2 3.594 -> 3.574, eight pairs 16.33 -> 16.30: 118 .. 133 instead of 167 .. 183 VGPRs)
     const bool rw1 = (long long)a.Ho * a.Wo <= rw1_max;
     const int tiles_x = cdiv(a.Wo, CT_TW), tiles_y = cdiv(a.Ho, rw1 ? 4 : 8);
     if (rw1) {
@@ -1222,7 +1222,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tile_kernel(WgradBatch b) {
 }
 static bool wgrad_tile_ok(const WgradArgs& a) {
     static const int on = getenv("SPLICE_WGRAD_TILE") ? atoi(getenv("SPLICE_WGRAD_TILE")) : 1;
-    static const int min_px = getenv("SPLICE_WGRAD_TILE_MIN") ? atoi(getenv("SPLICE_WGRAD_TILE_MIN")) : 40000;
+    constexpr int min_px = 40000;
     return on && a.ks == 3 && a.stride == 1 && a.Wo >= 64 && (long long)a.Ho * a.Wo > min_px && a.Hi == a.Ho && a.Wi == a.Wo && a.pad == 1 &&
            (size_t)a.Cin * a.x_cstride <= 0x1fffffffULL && (size_t)a.Cout * a.dy_cstride <= 0x1fffffffULL;   // (32-bit byte offsets)
 }
@@ -2409,7 +2409,7 @@ static void bn_mid_allow_lds() {   // > 48 KB of dynamic LDS has to be allowed o
 // one image per parameter set (a single image, or independent generators) and per-image statistics: what the mid kernels cover
 bool bn_pre_supported(int HW, int N, size_t p_nstride, int batch);
 static inline bool bn_mid_ok(int HW, int N, size_t p_nstride, int batch) {
-    static const int on = getenv("SPLICE_BN_MID") ? atoi(getenv("SPLICE_BN_MID")) : 1;
+    constexpr int on = 1;
     return on && HW > BN_SMALL_HW && HW <= BN_MID_HW && !batch && (N == 1 || p_nstride);
 }
 
@@ -2426,7 +2426,7 @@ static inline int plane_blocks(int HW) { int b = cdiv(HW, 512); return b < 1 ? 1
 int bn_part_floats(int N, int C) { return N * C * MAX_PB_V * 2; }
 // big planes (round 5): segments of <= 4096 pixels moved in 16-byte runs; SPLICE_BN_VEC=0 keeps the 64-segment scalar layout everywhere
 static inline bool bn_vec_ok(int HW) {
-    static const int on = getenv("SPLICE_BN_VEC") ? atoi(getenv("SPLICE_BN_VEC")) : 1;
+    constexpr int on = 1;
     return on && HW > MAX_PB * 1024 && (long long)HW <= (long long)MAX_PB_V * BN_V_CH * 1024;
 }
 static inline int bn_plane_blocks(int HW) {
@@ -2440,7 +2440,7 @@ static inline int bn_plane_blocks(int HW) {
 // GPU, -1.0 % at four, -0.6 % at eight; profiles/r04_gen_ab.txt.  SPLICE_BN_CHAIN_MAXN limits it to fewer images per launch.)
 bool bn_pre_supported(int HW, int N, size_t p_nstride, int batch) {
     static const int on = getenv("SPLICE_BN_CHAIN") ? atoi(getenv("SPLICE_BN_CHAIN")) : 1;
-    static const int maxn = getenv("SPLICE_BN_CHAIN_MAXN") ? atoi(getenv("SPLICE_BN_CHAIN_MAXN")) : 1 << 30;
+    constexpr int maxn = 1 << 30;
     return on && N < maxn && !batch && (N == 1 || p_nstride) && (HW <= BN_SMALL_HW || bn_mid_ok(HW, N, p_nstride, batch));
 }
 // the BatchNorm backward of a plane of this size can sum the split-K slabs of the data-gradient convolution that feeds it while it

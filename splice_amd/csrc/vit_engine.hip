@@ -192,7 +192,7 @@ int splice_vit_create(int patch, int dim, int depth, int heads, void** out) {
     }
     SpliceVit* v = new SpliceVit();
     v->patch = patch; v->dim = dim; v->depth = depth; v->heads = heads; v->hidden = 4 * dim;
-    v->qfold = getenv("SPLICE_VIT_QFOLD") ? atoi(getenv("SPLICE_VIT_QFOLD")) : 1;   // (0: the round-4 packing, for A/B runs)
+    v->qfold = 1;   // (the plain packing of rounds 1-4 is gone with its kernels; the field stays: the kernels below are written for either)
     v->qscale = v->qfold ? 0.125f * kLog2e : 1.0f;
     (void)hipGetDevice(&v->device);
     v->layers.resize(depth);

@@ -137,7 +137,7 @@ class VitEngine:
         h = C.c_void_p()
         _lib.check(_lib.lib().splice_vit_create(patch, dim, depth, heads, C.byref(h)), "vit_create")
         self.handle = h
-        # the engine stores q pre-multiplied by qscale = d^-1/2 log2(e) (1.0 with SPLICE_VIT_QFOLD=0); kernels fed with stored q take attn_scale
+        # the engine stores q pre-multiplied by qscale = d^-1/2 log2(e) (always since round 6); kernels fed with stored q take attn_scale
         self.qscale = float(_lib.lib().splice_vit_qscale(h))
         self.attn_scale = math.log(2.0) if self.qscale != 1.0 else (dim // heads) ** -0.5
         self.pos_embed = None

@@ -19,7 +19,7 @@ def _run(extra_env, *argv):
 
 
 def test_spawn_two_workers_stub():
-    r = _run({"SPLICE_BENCH_STUB": "20", "SPLICE_BENCH_STUB_GPUS": "4", "HIP_VISIBLE_DEVICES": "3,5,6,7", "SPLICE_GEMM_T96": "6"},
+    r = _run({"SPLICE_BENCH_STUB": "20", "SPLICE_BENCH_STUB_GPUS": "4", "HIP_VISIBLE_DEVICES": "3,5,6,7", "SPLICE_CONV_TILE": "1"},
              "--gpus", "2", "--steps", "6", "--warmup", "1")
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -36,7 +36,7 @@ def test_spawn_two_workers_stub():
     assert abs(out["value"] - 2 * min(r0, r1)) / out["value"] < 0.05
     assert 29.0 < out["ms_per_step"] < 45.0
     assert cfg["host"]["threads"] >= 1
-    assert cfg["env"] == {"SPLICE_GEMM_T96": "6"}   # library switches are echoed, bench plumbing is not
+    assert cfg["env"] == {"SPLICE_CONV_TILE": "1"}   # library switches are echoed, bench plumbing is not
     # blocks of exactly K steps repeated until the minimum timed duration (0.2 s for the stub; 1 s for real runs),
     # round 5: value / ms_per_step are ALL timed steps over ALL timed seconds; the median block is a robustness figure
     t = cfg["timing"]
@@ -65,8 +65,8 @@ def test_dev_switches_are_refused(monkeypatch):
         if k.startswith("SPLICE_"):
             monkeypatch.delenv(k)
     assert bench.dev_env_violations(False) == []
-    monkeypatch.setenv("SPLICE_GEMM_T2MIN", "400")            # a launch-policy knob: echoed, not refused
-    assert bench.dev_env_violations(False) == [] and bench.library_env() == {"SPLICE_GEMM_T2MIN": "400"}
+    monkeypatch.setenv("SPLICE_CONV_TILE_MIN", "40000")            # a launch-policy knob: echoed, not refused
+    assert bench.dev_env_violations(False) == [] and bench.library_env() == {"SPLICE_CONV_TILE_MIN": "40000"}
     monkeypatch.setenv("SPLICE_STEP_ABLATE", "3")
     monkeypatch.setenv("SPLICE_STEP_GRAPH", "0")
     monkeypatch.setenv("SPLICE_STEP_OVERLAP", "1")

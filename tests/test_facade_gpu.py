@@ -87,7 +87,7 @@ def test_reference_loop_through_facade(golden_dir):
             if np.isnan(ref):
                 assert k not in losses
             else:
-                assert abs(losses[k].item() - ref) / abs(ref) < 3e-2, (step, k, losses[k].item(), ref)
+                assert abs(losses[k].item() - ref) / abs(ref) < 2e-2, (step, k, losses[k].item(), ref)   # measured 1.8e-3 .. 9.5e-3 (steps 0 .. 2 of the fixture)
         optimizer.step()
         scheduler.step()
     with torch.no_grad():

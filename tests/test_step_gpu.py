@@ -1,7 +1,7 @@
 """GPU parity of the fused optimisation step (C ABI splice_step_*) against the loss trajectories
 recorded from the REFERENCE loop (Model + LossG + Adam, oracle/make_golden.py) and the fp32 oracle.
 
-Tolerances (bf16 ViT, fp32 generator/losses/Adam; round 5: 2-3 x the measured deviations, profiles/r05_step_tests_verbose.txt --
+Tolerances (bf16 ViT, fp32 generator/losses/Adam; 2-3 x the measured deviations, profiles/r06_step_tests_verbose.txt --
 teacher-forced losses 1.4e-3 .. 2.8e-3 measured, bar 1e-2; whole-arena generator gradient 4e-3 .. 1.8e-2 measured, bar 3e-2; the
 outlier-weight / real-checkpoint tests keep 2e-2 / 3e-2, the n_crops batches 1e-2 / 6e-2): every entry of the loss dict within 1e-2
 relative at steps 0-2 (identical parameters on both sides up to one or two updates).
@@ -11,11 +11,14 @@ the size of its gradient component, so rounding-level differences in near-zero c
 oracle (oracle/trajectory_ensemble.py, tests/golden/trajectory_ensemble.json): the SAME fp32 code with one thread against many threads is
 above 2 % from step 6, up to 84 % apart, 20.7 dB between the two final images.  So the free run is checked two ways:
   * as a member of a family -- its 6-step window means, the level it reaches and its final image (PSNR, channel statistics) must lie inside
-    the range of that ensemble (the fp32 loop with another thread count and with gradient noise of relative size 1e-2 / 2e-2, 8 seeds each;
-    the engine's measured gradient error along the run is 1e-2 .. 6e-2), widened by 10 %;
+    the range of that ensemble: the fp32 loop with another thread count, with gradient noise of relative size 1e-2 / 2e-2 / 6e-2 (8 seeds each:
+    the engine's measured error along the run is 0.7e-2 .. 6.8e-2) and -- since half of that error is no noise but the bf16 rounding of the
+    frozen ViT weights -- the fp32 loop run ON the rounded weights; widened by 10 %;
   * pointwise where pointwise MEANS something -- at 15 steps of the free run the fp32 oracle is evaluated at the engine's own parameters of
-    that step: every reported loss entry within 1e-2 (measured 3.8e-3) and the gradient the engine descended along is recorded against the
-    oracle's (1e-2 .. 6e-2 whole-arena relative L2).  A bias in a loss term or in the direction of descent fails there whatever the trajectory does.
+    that step: every reported loss entry within 1e-2 (measured 4.3e-3), and the gradient the engine descended along within 1.4e-1 (cosine
+    above 0.996) of the fp32 oracle's and within 6e-2 of the fp32 oracle's on the engine's rounded weights -- ASSERTED (round 5 only recorded
+    them); see the comment above TRAJ_GRAD_BAR_FP32 for why the relative error grows along the run.  A bias in a loss term or in the direction
+    of descent fails there whatever the trajectory does.
 """
 import os
 
@@ -59,24 +62,30 @@ def _check(rows, gl, keys, lo, hi, rtol):
     print(f"    steps {lo}..{hi - 1}: worst rel loss deviation {worst:.3e}")
 
 
-def _oracle_for(name, img_size, vit_state, gen_state, cfg):
+def _oracle_for(name, img_size, vit_state, gen_state, cfg, bf16_weights=False):
     from oracle import dino_vit
     from oracle.step import SpliceOracle
     patch, dim, depth, heads = dino_vit.DINO_CONFIGS[name]
     m = dino_vit.VisionTransformer(patch, dim, depth, heads, img_size=img_size).eval()
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in vit_state.items()})
+    if bf16_weights:   # the fp32 oracle on the bf16-rounded weights the engine holds (oracle/dino_vit.py round_weights_bf16)
+        m.load_state_dict(dino_vit.round_weights_bf16(vit_state, dim))
+    else:
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in vit_state.items()})
     return SpliceOracle(m, {k: torch.from_numpy(v) for k, v in gen_state.items()}, cfg)
 
 
-def _grad_rel_err(eng, og):
-    """whole-arena relative L2 distance of the engine's generator gradient to the oracle's autograd gradient"""
-    num = den = 0.0
+def _grad_rel_err(eng, og, with_cos=False):
+    """whole-arena relative L2 distance of the engine's generator gradient to the oracle's autograd gradient (with_cos: and their cosine)"""
+    num = den = dot = ne = 0.0
     for (name, gt), go in zip(eng.gen.unflatten(eng.grads).items(), og):
         if name.endswith("0.bias") and name != "9.0.bias":
             continue   # conv biases that feed a train-mode BatchNorm: analytically zero (the oracle holds rounding noise)
-        d = (gt.cpu().double() - go.reshape(-1).double()).norm().item()
-        num, den = num + d * d, den + go.double().norm().item() ** 2
-    return (num / den) ** 0.5
+        a, b = gt.cpu().double(), go.reshape(-1).double()
+        d = (a - b).norm().item()
+        num, den = num + d * d, den + b.norm().item() ** 2
+        dot, ne = dot + float(a @ b), ne + a.norm().item() ** 2
+    rel = (num / den) ** 0.5
+    return (rel, dot / (ne * den) ** 0.5) if with_cos else rel
 
 
 def _teacher_forced(eng, orc, A, B, A_ent, steps, loss_tol=1e-2, grad_tol=3e-2, tag=""):
@@ -103,45 +112,65 @@ def _teacher_forced(eng, orc, A, B, A_ent, steps, loss_tol=1e-2, grad_tol=3e-2, 
     return worst_l, worst_g
 
 
+# Bars of the spot checks along the free run (round 6; measured: profiles/r06_traj_grad_error.txt, r06_step_tests_verbose.txt).  The engine's
+# gradient error against the fp32 oracle is a FLOOR, not a fraction: |g_e - g_o| stays at 7 .. 15 (absolute, this fixture) while |g_o| falls
+# from 1470 to 135 along the run (log-log slope 0.24), so the RELATIVE error grows from 0.7e-2 to 6.8e-2 where the gradient is smallest (step 36).
+# The floor has two parts of similar size: the bf16 rounding of the frozen ViT WEIGHTS -- a fixed perturbation of the model, the same at every
+# step (which is why the error vectors of neighbouring steps are correlated, cosine up to 0.87: it is not isotropic noise) -- 0.3e-2 .. 5.7e-2,
+# and the rounding of activations / probabilities, 0.4e-2 .. 2.5e-2, measured against the fp32 oracle evaluated ON the rounded weights.
+TRAJ_GRAD_BAR_FP32 = 1.4e-1       # 2 x 6.8e-2: against the fp32 oracle (fp32 weights)
+TRAJ_GRAD_BAR_BF16W = 6e-2        # 2 x 2.8e-2 (step 75, an entire-image step; 2.5e-2 at step 36): against the fp32 oracle on the engine's bf16-rounded weights
+TRAJ_GRAD_COS = 0.996             # measured >= 0.99809
+
+
 def _run_with_spot_checks(eng, A, B, n, spots, vit_name="dino_vits8", img_size=64, vit_seed=7, rtol=1e-2):
     """``_run`` + at every step in ``spots`` the fp32 oracle evaluated AT THE ENGINE'S PARAMETERS of that step (free-running engine,
-    no re-synchronisation of the engine): the reported loss entries must be the true ones, and (round 5) so must the GRADIENT the engine
-    took its step along -- the engine's gradient arena after the step against the oracle's autograd gradient at the same point, whole-arena
-    relative L2 (bar 3e-2).  A bias anywhere along the run -- in a loss term or in the direction of descent -- fails here whatever the
-    chaotic trajectory does."""
+    no re-synchronisation of the engine): the reported loss entries must be the true ones, and so must the GRADIENT the engine took its step
+    along -- the engine's gradient arena after the step against the oracle's autograd gradient at the same point, whole-arena relative L2 and
+    cosine, against BOTH oracles (fp32 weights: bar 1.4e-1 / cos 0.996; the bf16-rounded weights the engine holds: bar 6e-2).  A bias anywhere
+    along the run -- in a loss term or in the direction of descent -- fails here whatever the chaotic trajectory does."""
     from oracle import losses as OL
     vit_state = synth.vit_params(vit_seed, vit_name, img_size=img_size, w_std=0.05)
     orc = _oracle_for(vit_name, img_size, vit_state, synth.generator_params(1, 0.02), eng.cfg)
+    orc_w = _oracle_for(vit_name, img_size, vit_state, synth.generator_params(1, 0.02), eng.cfg, bf16_weights=True)
     rows = []
     At, Bt = torch.from_numpy(A), torch.from_numpy(B)
     Ad, Bd = At.to(DEV), Bt.to(DEV)
-    worst = worst_g = 0.0
+    worst = worst_g = worst_w = 0.0
+    worst_cos = 1.0
+
+    def at_snapshot(o, snap, step):
+        with torch.no_grad():
+            for k, v in o.params.items():
+                v.copy_(snap[k].cpu().reshape(v.shape))
+        o.step_idx = step - 1
+        o.lambdas = OL.initial_lambdas(o.cfg)
+        if step >= o.cfg["cls_warmup"]:
+            OL.update_lambdas(o.lambdas, o.cfg, o.cfg["cls_warmup"])
+        return o.step(At[None], Bt[None], At[None])
     for step in range(n):
         if step in spots:
             snap = eng.gen.unflatten(eng.params.clone())
         eng.step(Ad, Bd, Ad)
         rows.append(eng.losses())
         if step in spots:
-            with torch.no_grad():
-                for k, v in orc.params.items():
-                    v.copy_(snap[k].cpu().reshape(v.shape))
-            orc.step_idx = step - 1
-            orc.lambdas = OL.initial_lambdas(orc.cfg)
-            if step >= orc.cfg["cls_warmup"]:
-                OL.update_lambdas(orc.lambdas, orc.cfg, orc.cfg["cls_warmup"])
-            lo, _, og = orc.step(At[None], Bt[None], At[None])
+            lo, _, og = at_snapshot(orc, snap, step)
             le = rows[-1]
             assert set(le) == set(lo), (step, sorted(le), sorted(lo))
             for k in lo:
                 rel = abs(le[k] - lo[k]) / abs(lo[k])
                 worst = max(worst, rel)
                 assert rel < rtol, ("reported loss != oracle loss at the engine's own parameters", step, k, le[k], lo[k])
-            grel = _grad_rel_err(eng, og)
-            worst_g = max(worst_g, grel)
-            gbar = float(os.environ.get("SPLICE_TEST_TRAJ_GRAD_BAR", "1e9"))
-            assert grel < gbar, ("gradient != oracle gradient at the engine's own parameters", step, grel)
-            print(f"    free-running step {step}: reported loss {le['loss']:.3f}, fp32 oracle at the same parameters {lo['loss']:.3f}; gradient rel err {grel:.3e}")
-    print(f"    along the free-running trajectory (steps {sorted(spots)}): reported-vs-true loss worst rel {worst:.3e}, gradient worst rel {worst_g:.3e}")
+            grel, gcos = _grad_rel_err(eng, og, with_cos=True)
+            _, _, ogw = at_snapshot(orc_w, snap, step)
+            grel_w = _grad_rel_err(eng, ogw)
+            worst_g, worst_w, worst_cos = max(worst_g, grel), max(worst_w, grel_w), min(worst_cos, gcos)
+            print(f"    free-running step {step}: reported loss {le['loss']:.3f}, fp32 oracle at the same parameters {lo['loss']:.3f}; gradient rel err {grel:.3e} "
+                  f"(cos {gcos:.5f}); against the oracle on the bf16-rounded weights {grel_w:.3e}")
+            assert grel < TRAJ_GRAD_BAR_FP32 and gcos > TRAJ_GRAD_COS, ("gradient != fp32 oracle gradient at the engine's own parameters", step, grel, gcos)
+            assert grel_w < TRAJ_GRAD_BAR_BF16W, ("gradient != gradient of the fp32 oracle on the engine's bf16-rounded weights", step, grel_w)
+    print(f"    along the free-running trajectory (steps {sorted(spots)}): reported-vs-true loss worst rel {worst:.3e}, gradient worst rel {worst_g:.3e} "
+          f"(cos >= {worst_cos:.5f}), against the bf16-weight oracle {worst_w:.3e}")
     return rows
 
 
@@ -202,8 +231,8 @@ def test_trajectory_b_resize_nonsquare(golden_dir):
     eng = _engine({}, A, B, 33, 64)
     assert eng.vit_hw == (64, 106)
     rows = _run(eng, A, B, 4)
-    _check(rows, g["b/losses"], keys, 0, 2, 3e-2)
-    _check(rows, g["b/losses"], keys, 2, 4, 2.5e-1)
+    _check(rows, g["b/losses"], keys, 0, 2, 1e-2)     # measured 1.9e-3
+    _check(rows, g["b/losses"], keys, 2, 4, 3e-2)     # measured 9.9e-3 (two and three free-running updates behind the fixture; round 5 carried 2.5e-1 here)
 
 
 def test_step_gradients_vs_oracle_teacher_forced():

@@ -27,28 +27,11 @@ DEV = "cuda"
 SPOTS = [1, 6, 12, 18, 24, 30, 36, 42, 48, 54, 60, 66, 72, 77]
 
 
-def bf16_weights(vit_state, dim):
-    """The engine's ONE deviation from the fp32 model that does not depend on the input: the Linear / patch-embedding weights are rounded to bf16 once
-    (vit_engine.hip pack_linear; the q rows of the QKV projection after scaling by d^-1/2 log2(e), pack_qkv).  Biases, LayerNorm parameters, the
-    class token and the position embedding stay fp32 in the engine."""
-    c = (64 ** -0.5) * 1.4426950408889634
-    out = {}
-    for k, v in vit_state.items():
-        t = torch.from_numpy(v).clone()
-        if k.endswith("attn.qkv.weight"):
-            t[:dim] = (t[:dim] * c).bfloat16().float() / c
-            t[dim:] = t[dim:].bfloat16().float()
-        elif k.endswith(".weight") and t.dim() >= 2:
-            t = t.bfloat16().float()
-        out[k] = t
-    return out
-
-
 def oracle_for(cfg, vit_state, round_weights=False):
     patch, dim, depth, heads = dino_vit.DINO_CONFIGS["dino_vits8"]
     m = dino_vit.VisionTransformer(patch, dim, depth, heads, img_size=64).eval()
     if round_weights:
-        m.load_state_dict(bf16_weights(vit_state, dim))
+        m.load_state_dict(dino_vit.round_weights_bf16(vit_state, dim))
         return SpliceOracle(m, {k: torch.from_numpy(v) for k, v in synth.generator_params(1, 0.02).items()}, cfg)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in vit_state.items()})
     return SpliceOracle(m, {k: torch.from_numpy(v) for k, v in synth.generator_params(1, 0.02).items()}, cfg)
