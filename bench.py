@@ -371,7 +371,7 @@ def main():
                                                 "graphs replay), every crop resized to --size (224), the entire HxW image through Resize(224, max_size=480); one pair, no sweep")
     ap.add_argument("--model", default="dino_vitb8")
     ap.add_argument("--pairs", type=int, default=1, help="pairs optimised side by side per GPU in the timed region (1 = the reference's unit: the latency form of the metric)")
-    ap.add_argument("--pairs-sweep", default="2,4,8,16,32", help="additional pairs-per-GPU settings timed briefly after the main region (throughput form: pairs/hr); '' = off")
+    ap.add_argument("--pairs-sweep", default="2,4,8,12,16,32", help="additional pairs-per-GPU settings timed briefly after the main region (throughput form: pairs/hr); '' = off")
     ap.add_argument("--fp8", nargs="?", const="gemm", default=None, choices=("gemm", "attention"),
                     help="fp8 operand path (own, looser tolerance table: an APPROXIMATE mode, tests/test_fp8_gpu.py).  '--fp8' = '--fp8 gemm': e4m3 QKV / fc1 / fc2 "
                          "projections + key self-similarity Gram on the fp8 MFMA (the fastest setting; the config key fp8: True); "
@@ -519,9 +519,10 @@ def main():
     roofs = []
     traffic_file = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     static_traffic = {}
-    if os.path.exists(traffic_file) and args.model == "dino_vitb8" and not scales and not args.fp8 and not args.image:
-        try:   # keys: "P<pairs>" at 224 x 224, "S<size>P<pairs>" otherwise; values: family id -> bytes per call
-            static_traffic = json.load(open(traffic_file)).get(f"P{P}" if args.size == 224 else f"S{args.size}P{P}", {})
+    if os.path.exists(traffic_file) and args.model == "dino_vitb8" and not scales and not args.fp8:
+        try:   # keys: "P<pairs>" at 224 x 224, "S<size>P<pairs>" otherwise, "IMG<h>x<w>" for --image; values: family id -> bytes per call
+            tkey = f"IMG{hw[0]}x{hw[1]}" if args.image else (f"P{P}" if args.size == 224 else f"S{args.size}P{P}")
+            static_traffic = json.load(open(traffic_file)).get(tkey, {})
         except Exception:
             static_traffic = {}
     for fam, (tot_ms, calls, kernels, steps, n_ent, per_kernel) in prof.items():

@@ -113,11 +113,14 @@ int splice_gemm_splitk_slabs(int M, int ksplit);
  * the one-barrier tiles 128x128, 128x64, 64x64 and ring 0 / 1 / 2 = 2 / 4 / 3 LDS stages; 5 = the 8-phase 256x256 tile (gemm8p.h) wherever its operand and
  * epilogue constraints hold (N % 256 == 0, K % 128 == 0, bias [+GELU] -> bf16 or bias + residual -> fp32) */
 int splice_gemm_force_tile(int tile);
-/* benchmarking hook (tools/attn_bench.py): pick an attention kernel variant, 0 = default */
+/* test / benchmarking hook: attention forward launch form, 0 = automatic.  bf16: 41 / 42 / 48 = the 32x32x16 kernel with 4 / 2 / 8 waves per workgroup
+ * (same bits from all three, tests/test_ops_gpu.py); e4m3 forward: queries per wave / 16 + 10 * (two wave groups) */
 int splice_attention_variant(int variant);
-/* benchmarking hook: != 0 -> the stand-alone attention entry points take q columns pre-multiplied by scale * log2(e) */
+/* test / benchmarking hook: != 0 -> the stand-alone attention entry points take q columns pre-multiplied by scale * log2(e) and scale = ln 2
+ * (what the ViT engine runs: attn_fwd_x32_kernel<., FOLD>, attn_bwd_x32_kernel); 0 -> plain q and scale = d^-1/2 */
 int splice_attention_qfold(int on);
-/* benchmarking hook: attention backward form, 0 automatic, 1 the 16x16x32 kernels, 2 the 32x32x16 kernels (pre-scaled q only) */
+/* test / benchmarking hook: attention backward form, 0 automatic; 1 = the 16x16x32 halves (what plain q gets in any case); pre-scaled q only:
+ * 2 / 3 = the 32x32x16 halves in one / two launches, 4 = one launch of two-wave workgroups (same bits from 2, 3 and 4) */
 int splice_attention_bwd_variant(int variant);
 
 /* LayerNorm(D, eps) of the DINO blocks (eps 1e-6), fp32 in -> bf16 out, and its dgrad
@@ -195,7 +198,7 @@ int splice_resize_bilinear_bwd(const float* dout, float* din, int planes, int h,
 int splice_vit_create(int patch, int dim, int depth, int heads, void** out_handle);
 void splice_vit_destroy(void* vit);
 int splice_vit_set_param(void* vit, const char* name, const float* data, long long numel, splice_stream_t stream);
-/* The factor the stored q columns of every layer's qkv carry (round 5: d^-1/2 * log2(e); 1 when SPLICE_VIT_QFOLD=0).  splice_vit_read_tensor
+/* The factor the stored q columns of every layer's qkv carry (d^-1/2 * log2(e)).  splice_vit_read_tensor
  * kinds 1 and 3 divide it out of the copy; kind 7 (= kind 1 as stored) and the zero-copy splice_vit_get_tensor pointers do not -- attention entry
  * points fed with stored q take scale = ln 2 instead of d^-1/2. */
 float splice_vit_qscale(void* vit);

@@ -3,11 +3,11 @@
 // `self.model(input_img)` (models/extractor.py:83,91,99): softmax(q k^T / sqrt(d)) v,
 // without materialising the [h,T,T] probability tensors the reference's hooks keep.
 //
-// All products are "swapped" 16x16x32 bf16 MFMAs so that every lane owns ONE query (or
-// one key) column of the score tile: softmax statistics are per-lane scalars, the
-// probabilities feed the second MFMA straight from registers (no LDS round trip, no
-// cross-lane traffic in the hot loop), and the rows of the score MFMA are permuted so that
-// a lane's 8 probabilities are 8 CONSECUTIVE tokens (see the tile toolkit below).
+// This file: the tile toolkit shared by the kernels below, the e4m3 forward of BASELINE configs[4] (16x16x32 fp8 MFMAs), the 16x16x32 bf16
+// backward halves that serve plain (un-scaled) q at the op-level C-ABI, the small delta / probability kernels, and the launch policy.  The
+// kernels the ViT engine runs -- q pre-scaled, 32x32x16 bf16 MFMAs -- live in attn_x32.h (forward) and attn_bwd_x32.h (backward).  In every
+// kernel the products are "swapped" so that a lane owns ONE query (or one key) column of the score tile: softmax statistics are per-lane
+// scalars and the probabilities feed the second MFMA straight from registers (no LDS round trip, no cross-lane traffic in the hot loop).
 //
 // Inputs: qkv  bf16 [B*Tld][3D]  (row = b*Tld + token; q | k | v column blocks, heads
 //                                 contiguous inside each block -- the layout

@@ -32,19 +32,19 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
         // (t1min 420 -> 230 at the end of round 3: with the QKV epilogue down to one output the one-pair forward GEMMs of QKV / fc1
         // (234 / 312 tiles of 128 x 128 at 1600 rows) beat their 128 x 64 ring form: -1.9 % step time at one pair, -0.6 % at two,
         // unchanged at eight; profiles/r03_gemm_t1min_sweep.txt)
-        constexpr int t1min = 230;
+#ifndef SPLICE_T1MIN   // (compile-time defaults; variant builds for tools/ab_libs.sh override them with -D)
+#define SPLICE_T1MIN 230
+#endif
+#ifndef SPLICE_T96
+#define SPLICE_T96 6
+#endif
+        constexpr int t1min = SPLICE_T1MIN;
         // rows of a P-pair batch (tools/gemm_sweep.py, r2): with N <= 768 the 64x64 tile stops winning at ~4800 rows (fc2 at
         // M = 6400: 688 TF on 128x64 vs 554; M = 12800: 872 vs 656); N >= 2304 takes 128x128 from 3200 rows on (t1min 640 -> 420)
         // (in-step at 2 / 3 / 4 pairs per GPU -- 3200 ... 6400 rows -- the 128x64 tile already wins from the first row count without
         // a ring on: +0.9 / +0.3 / +0.8 % pair-steps/s against the stand-alone sweep's 4800, tools/gemm_thresh_sweep.sh)
         constexpr int bigm = 2401;
         tile = (FLAGS & EPI_ROWDOT) ? 3 : N <= 768 ? (M >= bigm ? 2 : 3) : t128 >= t1min ? 1 : t12864 >= t2min ? 2 : 3;
-#ifdef SPLICE_EXP_T160   // experiment build (tools/ab_libs.sh): the 128 x 160 tile where it turns 1.2 rounds of 128 x 128 tiles into one
-        if constexpr (FLAGS == (EPI_BIAS | EPI_GELU | EPI_OUT_BF) || FLAGS == (EPI_GELU_GRAD | EPI_OUT_BF)) {
-            const long t160 = (long)cdiv(M, 128) * cdiv(N, 160);
-            if (N > 768 && tile == 1 && t128 > 272 && t160 <= 272) tile = 4;
-        }
-#endif
         // few workgroups walking a long K (fc2, the fc1 / qkv dgrads): the per-slice DMA latency is exposed with 2 stages,
         // the 4-stage ring keeps 3 slices in flight (fc1T 800x768x3072: 23.4 -> 15.3 us); elsewhere its LDS footprint costs occupancy
         const int ks = (FLAGS == EPI_OUT_F32 && e.ksplit > 1 && K % (e.ksplit * GEMM_BK) == 0) ? e.ksplit : 1;
@@ -59,15 +59,9 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
         constexpr int shortns = 3;
         if (ring && tile == 3 && ks == 1 && K < 1536 && shortns == 3) ring = 2;
     }
-    if constexpr (FLAGS == (EPI_BIAS | EPI_GELU | EPI_OUT_BF) || FLAGS == (EPI_GELU_GRAD | EPI_OUT_BF) || FLAGS == EPI_OUT_BF) {
-        // 128 x 160 (wave tile 64 x 80): N = 3072 at 1600 rows = 13 x 20 = 260 tiles -- one round of the chip, where 128 x 128 takes 312 (hipBLASLt's choice for
-        // this shape: MT128x160x64, profiles/r06_hipblaslt_kernel_names.txt).  Same k order per accumulator: same bits.
-        if (tile == 4) {
-            if (ring == 2) launch_gemm_nt<128, 160, FLAGS, 3>(s, A, lda, B, ldb, M, N, K, e);
-            else launch_gemm_nt<128, 160, FLAGS, 2>(s, A, lda, B, ldb, M, N, K, e);
-            return SPLICE_OK;
-        }
-    }
+    // (round 6: hipBLASLt runs fc1 at 1600 rows on 128 x 160 tiles -- 260 tiles, one round of the chip -- and is 10 % faster there than our 128 x 128
+    // (312 tiles).  The same shape on THIS tile engine (wave tile 64 x 80, five fragment columns) measured 17.1 us against 14.6 stand-alone and +0.5 % step
+    // time in the alternating in-step A/B: not kept.  profiles/r06_gemm_t160.txt)
     if constexpr ((FLAGS & EPI_ROWDOT) != 0) {   // only instantiated for the 64-column tile
         if (ring == 2) launch_gemm_nt<64, 64, FLAGS, 3>(s, A, lda, B, ldb, M, N, K, e);
         else if (ring) launch_gemm_nt<64, 64, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e);
@@ -75,7 +69,7 @@ static int dispatch_tile(const bf16_t* A, int lda, const bf16_t* B, int ldb, int
     } else {
         if constexpr (FLAGS == (EPI_BIAS | EPI_RESID | EPI_OUT_F32)) {   // proj forward at M = 2 x 800 (K = 768): one wave of 64x96 tiles (200 workgroups) instead of 300 64x64 ones, in-step -0.4 %;
             // the same tile for fc2 (K = 3072) measured equal or worse (t96: 0 off, 3 both, 5 long-K only, 6 short-K only)
-            constexpr int t96 = 6;
+            constexpr int t96 = SPLICE_T96;
             const long wg64 = (long)cdiv(M, 64) * cdiv(N, 64), wg96 = (long)cdiv(M, 64) * (N / 96);
             if (t96 && !(t96 == 5 && K < 1536) && !(t96 == 6 && K >= 1536) && tile == 3 && N % 96 == 0 && wg64 > 256 && wg96 <= 256) {
                 if (K >= 1536 && t96 != 3) launch_gemm_nt<64, 96, FLAGS, 4>(s, A, lda, B, ldb, M, N, K, e);

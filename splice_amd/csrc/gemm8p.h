@@ -304,6 +304,9 @@ static inline bool gemm8p_shape_ok(int M, int N, int K, int lda, int ldb, const 
     // N = 768 (proj / fc2 forward): three column tiles only -- from 128 tiles on, one round of the chip (the stand-alone loop beats
     // the 128 x 64 tiles already on 150 of the 256 CUs: 871 against 770 TFLOP/s at 12800 x 768 x 3072)
     if ((flags & EPI_OUT_F32) && tiles >= 128 && tiles <= 256) return true;
+    // ... and beyond one round the same fill is as good as it was inside one: 300 tiles (16 pairs) = two rounds at 59 % -- the fill eight pairs run at (150 tiles).
+    // Round 6: 467 -> 497 pair-steps/s at 16 pairs per GPU against the 128 x 64 tile the 75 % rule below sent them to (profiles/r06_gemm8p_fill_ab.txt)
+    if ((flags & EPI_OUT_F32) && tiles > 256 && tiles * 100 >= ((tiles + 255) / 256) * 256 * 55) return true;
     if (tiles < 200) return false;
     const long rounds = (tiles + 255) / 256;
     return tiles * 100 >= rounds * 256 * 75;

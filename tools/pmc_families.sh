@@ -44,6 +44,19 @@ GEN = ("conv_", "bn_", "wgrad", "upsample2x", "sigmoid_bwd", "reflect_fold")
 res, detail = {}, {}
 fc2 = top_cluster(launches(lambda n: ("gemm_nt_kernel<" in n and ", 7u," in n) or "gemm8p_kernel<7u>" in n))
 res["4"] = mean(fc2); detail["4"] = sorted({n[:60] for _, n in fc2})
+# proj forward shares fc2's epilogue flags (7u): the launches BELOW fc2's cluster, above the patch embedding's (K = 192)
+p7 = launches(lambda n: ("gemm_nt_kernel<" in n and ", 7u," in n) or "gemm8p_kernel<7u>" in n)
+m7 = max((b for b, _ in p7), default=0.0)
+pj = [x for x in p7 if 0.12 * m7 < x[0] <= 0.6 * m7]
+res["9"] = mean(pj); detail["9"] = sorted({n[:60] for _, n in pj})
+f1 = top_cluster(launches(lambda n: ("gemm_nt_kernel<" in n and ", 41u," in n) or "gemm8p_kernel<41u>" in n))
+res["1"] = mean(f1); detail["1"] = sorted({n[:60] for _, n in f1})
+qk = top_cluster(launches(lambda n: ("gemm_nt_kernel<" in n and ", 9u," in n) or "gemm8p_kernel<9u>" in n))
+res["2"] = mean(qk); detail["2"] = sorted({n[:60] for _, n in qk})
+bd = launches(lambda n: "gemm_nt_kernel<" in n and (", 72u," in n or ", 520u," in n))
+res["11"] = mean(bd); detail["11"] = sorted({n[:60] for _, n in bd})
+ln = launches(lambda n: "layernorm_fwd_kernel" in n or "layernorm_bwd_kernel" in n)
+res["10"] = mean(ln); detail["10"] = sorted({n[:40] for _, n in ln})
 dg = launches(lambda n: "gemm_nt_kernel<" in n and ", 4u," in n)
 mx = max((b for b, _ in dg), default=0.0)
 dg = [x for x in dg if x[0] > 0.25 * mx]          # (drops the patch-embedding dgrad, a 192-column GEMM with the same flags)
