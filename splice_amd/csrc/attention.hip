@@ -807,7 +807,8 @@ int attn_fwd_launch(const AttnArgs* a, hipStream_t s) {
 // launches (pre-scaled q only); 4 = the 32x32x16 halves, one launch of two-wave workgroups
 static int g_attn_bwd_variant = 0;
 void attn_set_bwd_variant(int v) { g_attn_bwd_variant = v; }
-static const int kAttnBwdMergeMaxX32 = 1024;   // workgroups of the merged 32x32x16 launch up to which ONE launch is used
+static const int kAttnBwdMergeMaxX32 = 1400;   // workgroups of the merged 32x32x16 launch up to which ONE launch is used (round 6: 1024 -> 1400, profiles/r06_attn_bwd_merge.txt:
+                                               // 8 passes of T = 785 = 1344 workgroups 84.2 us merged against 90.8 in two launches, 2 passes of T = 3137 = 1200: 234.6 against 254.4; beyond ~2000 a wash)
 static const int kAttnBwdMergeMax16 = 768;     // the same bound for the 16x16x32 halves
 
 int attn_bwd_launch(const AttnArgs* a, hipStream_t s) {
@@ -828,7 +829,7 @@ int attn_bwd_launch(const AttnArgs* a, hipStream_t s) {
         const int nx4 = cdiv(a->Tld, 128), n4 = nx4 * a->H * a->B;
         // both forms run the same bodies (same bits, tested at op level and through the multi-pair step): one launch while the chip is not
         // full anyway (a dependent launch costs more than the mix of the two halves' durations), two once every CU holds several workgroups
-        // (T = 3137, 4 passes: 426 against 445 us; 2 passes of T = 785: 37.9 against 32.7 us; profiles/r05_attn_bwd_x32.txt)
+        // (T = 3137, 4 passes = 2400 workgroups: 426 against 445 us; 2 passes of T = 785: 37.9 against 32.7 us; profiles/r05_attn_bwd_x32.txt)
         if (g_attn_bwd_variant == 3 || (g_attn_bwd_variant != 2 && 2 * n4 > kAttnBwdMergeMaxX32)) {
             SPLICE_LAUNCH((attn_bwd_q_x32_kernel<4>), dim3(n4), dim3(256), BX_Q_LDS, s, *a, nx4);
             SPLICE_LAUNCH((attn_bwd_kv_x32_kernel<4>), dim3(n4), dim3(256), BX_KV_LDS, s, *a, nx4);

@@ -129,8 +129,9 @@ def test_multipair_full_size_bit_identical_and_graph_modes(P):
     """BASELINE configs[1] shapes (224x224, ViT-B/8, T = 785): P pairs on one engine vs the single-pair runs over 4 steps
     (graph capture at the third step, replay at the fourth, on both sides), and the batched engine eager/serial vs graph/overlap.  P = 4 changes the
     GEMM tiles (128x64, 128x128) against P = 1 and keeps the merged attention backward (2 * 7 * 12 * 4 = 672 <= 1024 workgroups); P = 8 is the
-    configuration of `bench.py --pairs 8` and the pairs sweep: the persistent 256x256 8-phase GEMM tile for the forward projections and the
-    TWO-LAUNCH 32x32x16 attention backward (2 * 7 * 12 * 8 = 1344 workgroups).  None of them may change a pair's bits."""
+    configuration of `bench.py --pairs 8` and the pairs sweep: the persistent 256x256 8-phase GEMM tile for the forward projections (and 1344
+    workgroups in the merged attention backward; the two-launch form, taken above 1400, is compared bit for bit at op level:
+    tests/test_ops_gpu.py::test_attention_fwd_bwd_prescaled_q_engine_forms).  None of them may change a pair's bits."""
     cfg = dict(dino_model_name="dino_vitb8", dino_global_patch_size=224)
     vit_state = synth.vit_params(7, "dino_vitb8", img_size=224, w_std=0.03)
     gens = [synth.generator_params(90 + p, 0.02) for p in range(P)]

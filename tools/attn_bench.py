@@ -15,6 +15,7 @@ L = _lib.lib()
 DEV = "cuda"
 variants = [int(t) for t in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]
 std = float(os.environ.get("ATTN_STD", "1.0"))
+BWD_VARIANT = int(os.environ.get("ATTN_BWD_VARIANT", "0"))   # splice_attention_bwd_variant: 0 policy, 2 one launch, 3 two launches, 4 two-wave workgroups (pre-scaled q)
 FOLD = int(os.environ.get("ATTN_FOLD", "0"))   # 1: q columns pre-multiplied by scale * log2(e) (forward only: the engine's packing of the QKV projection)
 
 
@@ -83,6 +84,7 @@ for (B, T) in shapes:
 
         def bwd():
             L.splice_attention_qfold(FOLD)
+            L.splice_attention_bwd_variant(BWD_VARIANT)
             _lib.check(L.splice_attention_bwd(_lib.ptr(qkv), _lib.ptr(qkvT), rows, B, T, Tld, D, H, kscale, _lib.ptr(out), _lib.ptr(lse),
                                               _lib.ptr(dout), _lib.ptr(doutT), _lib.ptr(delta), _lib.ptr(dqkv), st))
 
@@ -96,7 +98,7 @@ for (B, T) in shapes:
             if FOLD:
                 gg[:, :, 0] *= scale * 1.4426950408889634   # the kernels return dL/dq'
             eb = [relerr(gg[:, :T, i], gref[:, :, i]) for i in range(3)]
-            pad = gg[:, T:, 1:].abs().max().item()
+            pad = gg[:, T:, 1:].abs().max().item() if Tld > T else 0.0
             msg = f" err fwd {ef:.1e} dq {eb[0]:.1e} dk {eb[1]:.1e} dv {eb[2]:.1e} pad {pad:g}"
         tf, tb = timed(fwd), timed(bwd)
         print(f"B{B} T{T} variant {v:3d}: fwd {tf:6.1f} us {fl_f / tf / 1e6:5.0f} TF | bwd {tb:6.1f} us {2.5 * fl_f / tb / 1e6:5.0f} TF(alg 2.5x){msg}", flush=True)
