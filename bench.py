@@ -209,8 +209,9 @@ def kernel_families(T, D, heads, P, size, depth=12, fp8=False):
         # key self-similarity: S* (upper tiles, 0.47 of T^2 D x 2), S + loss (same), dK = W K (2 T^2 D); two calls per step (target | loss + dK)
         8: ("selfsim kernels (norms, S*, fused S / MSE / W, dK) per call", "bf16", P * (0.5 * 2.0 * T * T * D * 2 + 2.0 * T * T * D) / 2),
         # LayerNorm: HBM-bound; the work figure is algorithmic BYTES per call, mean of a forward call (2 P passes: fp32 row in, bf16 row out) and a
-        # backward call (P passes: 3 split-K slabs + x + incoming gradient in, fp32 gradient + its bf16 copy out = 26 B per element)
-        10: ("layernorm_fwd_kernel / layernorm_bwd_kernel (mean of both)", "hbm", P * T * D * (2 * 6 + 26) / 2.0),
+        # backward call (P passes: the split-K slabs of the dgrad in front of it -- three below 2401 rows per call, one from there on (gemm.h
+        # GEMM_VSPLIT_ROWS: the sum is formed inside the GEMM) -- + x + incoming gradient in, fp32 gradient + its bf16 copy out = 14 + 4 x slabs B per element)
+        10: ("layernorm_fwd_kernel / layernorm_bwd_kernel (mean of both)", "hbm", P * T * D * (2 * 6 + (14 + 4 * (3 if P * 800 < 2401 else 1))) / 2.0),
         11: ("gemm_nt_kernel bf16-output dgrads (fc2^T x GELU', proj^T + delta row dots; mean of both)", "bf16", P * 2.0 * T * D * (hidden + D) / 2),
     }
 

@@ -303,6 +303,8 @@ static inline bool gemm8p_shape_ok(int M, int N, int K, int lda, int ldb, const 
     const long tiles = (long)((M + 255) / 256) * (N / 256);
     // N = 768 (proj / fc2 forward): three column tiles only -- from 128 tiles on, one round of the chip (the stand-alone loop beats
     // the 128 x 64 tiles already on 150 of the 256 CUs: 871 against 770 TFLOP/s at 12800 x 768 x 3072)
+    // (round 6: proj, K = 768, moves 100 MB of fp32 residual in + out per call at eight pairs and is HBM-bound on 150 workgroups -- but sending it back to
+    // the many-workgroup 128 x 64 tile was slower in the step at 8 / 16 / 32 pairs: -0.3 / -0.7 / -1.3 %, profiles/r06_proj_tile_ab.txt)
     if ((flags & EPI_OUT_F32) && tiles >= 128 && tiles <= 256) return true;
     // ... and beyond one round the same fill is as good as it was inside one: 300 tiles (16 pairs) = two rounds at 59 % -- the fill eight pairs run at (150 tiles).
     // Round 6: 467 -> 497 pair-steps/s at 16 pairs per GPU against the 128 x 64 tile the 75 % rule below sent them to (profiles/r06_gemm8p_fill_ab.txt)

@@ -11,6 +11,8 @@ shapes = [("fc2T8", 800, 3072, 768), ("fc1_16", 1600, 3072, 768)] if os.environ.
           ("qkv", 3200, 2304, 768), ("proj", 3200, 768, 768), ("fc1", 3200, 3072, 768), ("fc2", 3200, 768, 3072),
           ("fc2T", 1600, 3072, 768), ("fc1T", 1600, 768, 3072), ("projT", 1600, 768, 768), ("qkvT", 1600, 768, 2304),
           ("patch", 3200, 768, 192)]
+if os.environ.get("GEMM_SHAPES"):   # e.g. GEMM_SHAPES=fc1T:6400x768x3072,qkvT:6400x768x2304
+    shapes = [(t.split(":")[0],) + tuple(int(x) for x in t.split(":")[1].split("x")) for t in os.environ["GEMM_SHAPES"].split(",")]
 names = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 11: "128x128r4", 12: "128x64r4", 13: "64x64r4", 23: "64x64r3", 33: "64x64r6x2", 43: "64x96r7", 53: "64x96r4", 63: "64x64r8", 21: "128x128r3", 73: "128x192r3", 83: "64x192r4", 93: "128x96r5"}   # tile + 10 * (4-stage ring)
 tiles = [int(t) for t in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3]
 for name, M, N, K in shapes:
