@@ -10,9 +10,6 @@
 #ifndef CONV_KB
 #define CONV_KB 6   // k steps per LDS fragment batch of conv_igemm_body at one output-channel fragment per workgroup (0: the whole tile at once); 3 at 2 or 4 fragments
 #endif
-#ifndef CONV_ABL
-#define CONV_ABL 0   // timing ablations of conv_igemm_body (tools/conv_ablate.sh): 1 = no MFMA, 2 = no gather after the first tile, 3 = one k step per tile
-#endif
 #include <cstdlib>
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -160,18 +157,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, int bx, int b
     int a_vo[NA], w_vo[NW];
 #pragma unroll
     for (int i = 0; i < NA; ++i) a_vo[i] = ((a_ok >> i) & 1ull) ? a_off[i] * 4 : (int)0x80000000;
-#if CONV_ABL == 4   // prologue ablation: one cheap offset per element instead of the descriptor arithmetic above (which becomes dead code)
-#pragma unroll
-    for (int i = 0; i < NA; ++i) a_vo[i] = (pl + 64 * i) * 4;
-#endif
 #pragma unroll
     for (int t = 0; t < NW; ++t) w_vo[t] = ((w_ok >> t) & 1ull) ? w_off[t] * 4 : (int)0x80000000;
     auto fetch = [&](int c0) {
         if (c0 + CK <= Kc) {
             const int so_a = __builtin_amdgcn_readfirstlane(c0 * (int)a.in_cstride * 4), so_w = __builtin_amdgcn_readfirstlane(c0 * (int)a.w_cstride * 4);
-#if CONV_ABL == 2
-            if (c0 != cbeg) return;
-#endif
 #pragma unroll
             for (int i = 0; i < NA; ++i) av[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, a_vo[i], so_a, 0));
 #pragma unroll
@@ -228,16 +218,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, int bx, int b
 #pragma unroll
             for (int t = 0; t < KB; ++t) {
                 if (k0 + t >= KSTEPS) break;
-#if CONV_ABL == 3
-                if (k0 + t) continue;
-#endif
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
-#if CONV_ABL == 1
-                    acc[j][0] += af[cur][t] * bf[cur][j][t];
-#else
                     acc[j] = mfma4(af[cur][t], bf[cur][j][t], acc[j]);
-#endif
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
