@@ -266,3 +266,27 @@ def test_extractor_arch_table_matches_reference_substring_rules():
         return (patch, 6 if small else 12, 384 if small else 768)
     for name in ("dino_vits8", "dino_vits16", "dino_vitb8", "dino_vitb16", "vit_small_patch8_224", "vit_base_patch16_224", "dino_xcit_s8"):
         assert _arch_of(name) == rule(name), name
+
+
+def test_round_weights_bf16_matches_the_engine_packing_rules():
+    """oracle/dino_vit.py round_weights_bf16 (the "model the engine holds" of the free-run spot checks): every Linear / patch-embedding weight goes
+    through bf16 once, the q rows of the QKV projection AFTER their scaling by d^-1/2 log2(e) (vit_engine.hip pack_qkv), everything else stays fp32."""
+    import numpy as np
+    import torch
+    from oracle import dino_vit
+    from splice_amd import synth
+    st = synth.vit_params(3, "dino_vits8", img_size=32, w_std=0.05)
+    dim = 384
+    out = dino_vit.round_weights_bf16(st, dim)
+    assert set(out) == set(st)
+    c = (64 ** -0.5) * 1.4426950408889634
+    for k, v in st.items():
+        a, b = torch.from_numpy(np.asarray(v)), out[k]
+        if k.endswith("attn.qkv.weight"):
+            assert torch.equal(b[dim:], a[dim:].bfloat16().float())
+            assert torch.equal((b[:dim] * c).bfloat16().float(), (a[:dim] * c).bfloat16().float())   # the scaled q rows are bf16 values
+            assert not torch.equal(b[:dim], a[:dim].bfloat16().float())                               # ... which is NOT the rounding of the unscaled rows
+        elif k.endswith(".weight") and a.dim() >= 2:
+            assert torch.equal(b, a.bfloat16().float()), k
+        else:
+            assert torch.equal(b, a), k   # biases, LayerNorm parameters, class token, position embedding: untouched
