@@ -235,7 +235,10 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
                               splice_stream_t stream);
 /* kind 0: block output l fp32 [rows][D] (models/extractor.py:56-60) | 1: raw qkv l bf16
  * [rows][3D] (:68-72) | 2: attention output l bf16 [rows][D] | 3: last-layer qkv fp32
- * [rows][3D] | 4: lse l fp32 [B][H][Tld] | 5: embedded tokens fp32 [rows][D] | 6: raw qkv l transposed, bf16 [3D][rows] */
+ * [rows][3D] | 4: lse l fp32 [B][H][Tld] | 5: embedded tokens fp32 [rows][D] | 6: raw qkv l transposed, bf16 [3D][rows] | 7: as 1.
+ * ZERO-COPY: the pointers are the engine's own buffers, so the q columns of kinds 1 / 3 / 6 / 7 carry the factor splice_vit_qscale()
+ * (a C caller that wants the reference's q divides it out, or calls splice_vit_read_tensor, whose copies of kinds 1 and 3
+ * are un-scaled -- in bf16 for kind 1: one more rounding; Python's VitExtractor reads kind 7 and divides in fp32). */
 int splice_vit_get_tensor(void* ctx, int kind, int layer, void** out_ptr);
 int splice_vit_read_tensor(void* ctx, int kind, int layer, void* dst, size_t bytes, splice_stream_t stream);
 /* dgrad-only backward over passes [pass_begin, pass_end): gradients may be injected at
