@@ -20,8 +20,26 @@ struct SpliceProfScope {
     explicit SpliceProfScope(int which);
     ~SpliceProfScope();
 };
+// Scratch builds only (make DEV=1, -DSPLICE_DEV_SWITCHES; bench.py refuses such a library): a launch inside a SPLICE_DEV_REGION(id) whose bit is set
+// in the environment mask SPLICE_DEV_SKIP is NOT issued once two steps have run (buffers then hold finite data of those steps) -- TIMING ONLY, the
+// results are garbage: what the step loses when a region's launches vanish is that region's cost on the critical path (tools/critical_path_map.sh).
+#ifdef SPLICE_DEV_SWITCHES
+extern unsigned long long g_splice_dev_skip;   // prof.hip
+extern int g_splice_dev_region, g_splice_dev_steps;
+struct SpliceDevRegion {
+    int prev;
+    explicit SpliceDevRegion(int id) : prev(g_splice_dev_region) { g_splice_dev_region = id; }
+    ~SpliceDevRegion() { g_splice_dev_region = prev; }
+};
+#define SPLICE_DEV_REGION(id) SpliceDevRegion splice_dev_region_##id(id)
+#define SPLICE_DEV_SKIPPED() (g_splice_dev_steps > 2 && ((g_splice_dev_skip >> g_splice_dev_region) & 1ull))
+#else
+#define SPLICE_DEV_REGION(id) do { } while (0)
+#define SPLICE_DEV_SKIPPED() false
+#endif
 #define SPLICE_LAUNCH(kernel, grid, block, lds, stream, ...)                                                       \
     do {                                                                                                           \
+        if (SPLICE_DEV_SKIPPED()) break;                                                                           \
         hipEvent_t pa_, pb_;                                                                                       \
         if (g_splice_prof_open > 0 && splice_prof_take(&pa_, &pb_, #kernel))                                             \
             hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, pa_, pb_, 0, __VA_ARGS__);                     \

@@ -258,6 +258,7 @@ static BnPre skip_pre(const SpliceGenPlan* p, int i, const float* params, float*
 // BatchNorm + activation of a unit behind its convolution (ksplit > 1 with a deferred reduction: the slabs at `slabs` are summed here)
 static int unit_bn_forward(const SpliceGenPlan* p, const Unit& u, const float* params, const float* y, size_t y_ns, const float* slabs, int ksplit,
                            bool deferred, hipStream_t s, const BnUpsample* up, const BnPre* pre = nullptr) {
+    SPLICE_DEV_REGION(13);
     const int N = p->N;
     if (deferred && ksplit > 1) {
         RC(bn_fwd_slabs_launch(slabs, ksplit, params + u.b_off, u.y, u.y_ns, u.out, u.out_ns, N, u.Cout, u.Ho * u.Wo, params + u.g_off,
@@ -317,6 +318,7 @@ static int unit_backward_bn(const SpliceGenPlan* p, const Unit& u, const float* 
     if (!bn_done) {
         BnSlabs sl;
         if (pend.target) { sl.slabs = pend.slabs; sl.ksplit = pend.ksplit; sl.accumulate = pend.accumulate; pend.target = nullptr; }
+        SPLICE_DEV_REGION(14);
         RC(bn_bwd_launch(u.d_out, u.d_out_ns, u.out, u.out_ns, y, y_ns, dy, dy_ns, N, u.Cout, HW, params + u.g_off, u.mean, u.rstd, u.slope,
                          u.s1, grads + u.g_off, grads + u.be_off, acc, s, p->batch_stats ? nullptr : up, p->p_nstride, p->batch_stats, pre, &sl, params + u.be_off));
     }
@@ -635,7 +637,7 @@ static int gen_forward_impl(void* plan, const float* params, const float* x, flo
     SpliceGenPlan* p = (SpliceGenPlan*)plan;
     if (!p || !params || !x || !y) return SPLICE_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    SpliceProfScope prof_scope(7);
+    SpliceProfScope prof_scope(7); SPLICE_DEV_REGION(15);
     if (borrowed) {
         p->x_in = x;
     } else {
@@ -727,7 +729,7 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
         return SPLICE_ERR_STATE;
     }
     hipStream_t s = (hipStream_t)stream;
-    SpliceProfScope prof_scope(7);
+    SpliceProfScope prof_scope(7); SPLICE_DEV_REGION(16);
     const int OC = p->gen->arch.out_channels, U0 = p->gen->arch.up[0];
     const size_t npix = (size_t)p->N * OC * p->H * p->W;
     p->red.count = 0;
@@ -767,6 +769,7 @@ int splice_gen_backward(void* plan, const float* params, const float* dy, float*
     }
     RC(scale_backward(p, 0, params, grads, accumulate, s));
     if (p->pend.target) { splice_set_error("splice_gen_backward: split-K slabs left without a consumer"); return SPLICE_ERR_STATE; }
+    SPLICE_DEV_REGION(17);
     RC(conv_wgrad_batched_launch(p->wg, s));   // all layers' partials, one launch
     {   // one deterministic reduction of every layer's per-chunk weight-gradient partials
         WgradReduceAll& r = p->red;

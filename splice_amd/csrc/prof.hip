@@ -14,12 +14,17 @@
 // 11 the bf16-output dgrad GEMMs (fc2^T x GELU', proj^T + delta row dots).
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "common.h"
 
 int g_splice_prof_open = 0;
+#ifdef SPLICE_DEV_SWITCHES
+unsigned long long g_splice_dev_skip = getenv("SPLICE_DEV_SKIP") ? strtoull(getenv("SPLICE_DEV_SKIP"), nullptr, 0) : 0ull;
+int g_splice_dev_region = 0, g_splice_dev_steps = 0;
+#endif
 
 namespace {
 struct ProfState {

@@ -472,7 +472,7 @@ int selfsim_norms_launch(const bf16_t* k, int ldk, size_t k_pstride, int T, int 
     return SPLICE_OK;
 }
 int selfsim_target_launch(const SelfSimBatch& b, hipStream_t s) {
-    SpliceProfScope prof_scope(8);
+    SpliceProfScope prof_scope(8); SPLICE_DEV_REGION(18);
     const int nt = b.Tp / 64;
     if (b.fp8) {
         if (b.D % 128) return SPLICE_ERR_ARG;
@@ -484,7 +484,7 @@ int selfsim_target_launch(const SelfSimBatch& b, hipStream_t s) {
     return SPLICE_OK;
 }
 int selfsim_loss_launch(const SelfSimBatch& b, hipStream_t s) {
-    SpliceProfScope prof_scope(8);
+    SpliceProfScope prof_scope(8); SPLICE_DEV_REGION(18);
     const int nt = b.Tp / 64;
     if (nt * (nt + 1) / 2 > (int)b.part_pstride) return SPLICE_ERR_ARG;
     if (b.fp8) {

@@ -632,6 +632,7 @@ static int step_body(SpliceStep* st, float* params, float* grads, float* m, floa
     }
     if (!loss_summed) { sum_losses(s); RC(track_running(s)); }
     // ---- optimizer.step() (train.py:79) over every pair's arena; Adam's step count (>= 1) is read from the device at execution time
+    SPLICE_DEV_REGION(21);
     if (do_gb && !st->skip_adam) RC(adam_launch_dev(params, grads, m, v, st->astride ? P * st->astride : (size_t)st->nparams, c.lr, c.beta1, c.beta2, c.eps, st->dev_t, 0, s, adam_g2));
     return SPLICE_OK;
 }
@@ -706,6 +707,9 @@ int splice_step_run(void* h, float* params, float* grads, float* m, float* v, co
                     const float* A_entire, int step_idx, float* losses_out, splice_stream_t stream) {
     SpliceStep* st = (SpliceStep*)h;
     if (!st || !params || !grads || !m || !v || !A_crop || !B_crop || step_idx < 0) return SPLICE_ERR_ARG;
+#ifdef SPLICE_DEV_SWITCHES
+    ++g_splice_dev_steps;
+#endif
     hipStream_t caller = (hipStream_t)stream;
     const splice_step_config& c = st->cfg;
     const int P = st->P;

@@ -465,7 +465,7 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
         const bool fp8 = (c->fp8 & 1) && c->ln_out8 && W.qkv.w8;
         const bool fp8_attn = fp8 && (c->fp8 & 2) && c->qkv8;
         {
-            SpliceProfScope ps(10);
+            SpliceProfScope ps(10); SPLICE_DEV_REGION(1);
             if (fp8) RC(layernorm_fwd_fp8_launch(x_in, W.ln1_g, W.ln1_b, c->ln_out8 + r0 * D, c->ln_scale + r0, c->mean1[l] + r0, c->rstd1[l] + r0, R, D, 1e-6f, s));
             else RC(layernorm_fwd_launch(x_in, W.ln1_g, W.ln1_b, ln_out, c->mean1[l] + r0, c->rstd1[l] + r0, R, D, 1e-6f, s));
         }
@@ -478,7 +478,7 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
                 e.out_bf_t = c->qkvT_last + r0; e.ldt = c->rows;
                 e.out_f32_cols = c->qkv_last_f32 + r0 * 3 * D; e.ld_cols = 3 * D; e.col_lo = 0; e.col_hi = 3 * D;
             }
-            SpliceProfScope ps(l == L - 1 ? 0 : 2);
+            SpliceProfScope ps(l == L - 1 ? 0 : 2); SPLICE_DEV_REGION(2);
             if (fp8) {   // e4m3 LayerNorm output (per-token scale) x e4m3 weights (per-channel scale) on the fp8 MFMA
                 e.row_scale = c->ln_scale + r0; e.col_scale = W.qkv.w8_scale;
                 if (fp8_attn && !(l == L - 1 && c->top_cls_only)) {   // e4m3 copies of q, k, v for the fp8 attention forward of this layer
@@ -491,6 +491,7 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
             }
         }
         if (l == L - 1 && c->top_cls_only) {
+            SPLICE_DEV_REGION(19);
             // the tail of the top block on the [CLS] row of every pass only (vit_cls.hip): M = passes, rows Tld apart
             const int rs = c->Tld * D, hs = c->Tld * Hd;   // element strides between the [CLS] rows of consecutive passes
             bf16_t* cattn = c->cls_attn + (size_t)pass_begin * D;
@@ -532,17 +533,17 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
             a.qkv = c->qkv[l] + r0 * 3 * D; a.B = Bp; a.T = c->T; a.Tld = c->Tld; a.D = D; a.H = v->heads;
             a.scale = v->qfold ? kLn2 : 0.125f; a.qfold = v->qfold; a.out = c->attn_out[l] + r0 * D; a.lse = c->lse[l] + (size_t)pass_begin * v->heads * c->Tld;
             if (fp8_attn) { a.qkv8 = c->qkv8 + r0 * 3 * D; a.qkvT8 = c->qkvT8 + r0; a.ldt8 = c->rows; }
-            SpliceProfScope ps(3);
+            SpliceProfScope ps(3); SPLICE_DEV_REGION(3);
             RC(attn_fwd_launch(&a, s));
         }
         {
             GemmEpi e = {};
             e.bias = W.proj.b; e.resid = x_in; e.ldr = D; e.out_f32 = x_mid; e.ldo = D;
-            SpliceProfScope ps(9);
+            SpliceProfScope ps(9); SPLICE_DEV_REGION(4);
             RC(gemm_nt_launch(EPI_BIAS | EPI_RESID | EPI_OUT_F32, c->attn_out[l] + r0 * D, D, W.proj.w, D, R, D, D, e, s));
         }
         {
-            SpliceProfScope ps(10);
+            SpliceProfScope ps(10); SPLICE_DEV_REGION(1);
             if (fp8) RC(layernorm_fwd_fp8_launch(x_mid, W.ln2_g, W.ln2_b, c->ln_out8 + r0 * D, c->ln_scale + r0, c->mean2[l] + r0, c->rstd2[l] + r0, R, D, 1e-6f, s));
             else RC(layernorm_fwd_launch(x_mid, W.ln2_g, W.ln2_b, ln_out, c->mean2[l] + r0, c->rstd2[l] + r0, R, D, 1e-6f, s));
         }
@@ -551,7 +552,7 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
             e.bias = W.fc1.b; e.out_bf = hact; e.ldbf = Hd; e.out_pre = c->need_grad ? c->hpre[l] + r0 * Hd : nullptr; e.ldp = Hd;
             const long lo = (long)c->grad_pass_begin * c->Tld - (long)r0;   // first local row whose pre-activation is kept
             e.pre_row_lo = lo > 0 ? (int)lo : 0;
-            SpliceProfScope ps(1);
+            SpliceProfScope ps(1); SPLICE_DEV_REGION(5);
             if (fp8) {   // e4m3 LayerNorm output x e4m3 weights; GELU(x) leaves as e4m3 (the operand of fc2), the pre-activation as bf16
                 e.out_bf = nullptr; e.out_f8 = c->hact8 + r0 * Hd; e.ld8 = Hd;
                 e.row_scale = c->ln_scale + r0; e.col_scale = W.fc1.w8_scale;
@@ -563,7 +564,7 @@ int splice_vit_forward_passes(void* ctx, const float* img, int normalize, int gr
         {
             GemmEpi e = {};
             e.bias = W.fc2.b; e.resid = x_mid; e.ldr = D; e.out_f32 = c->xs[l + 1] + r0 * D; e.ldo = D;
-            SpliceProfScope ps(4);
+            SpliceProfScope ps(4); SPLICE_DEV_REGION(6);
             if (fp8) {
                 e.row_scale = nullptr; e.col_scale = W.fc2.w8_scale;
                 RC(gemm_nt_fp8_launch(EPI_SCALE_RC | EPI_BIAS | EPI_RESID | EPI_OUT_F32, c->hact8 + r0 * Hd, Hd, W.fc2.w8, Hd, R, D, Hd, e, s));
@@ -660,6 +661,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
         bf16_t* dqkv = c->dqkv + r0 * 3 * D;
         const float* g_after_mlp = nullptr;  // g_in for LN1 backward
         if (g_live && l == L - 1 && c->top_cls_only) {
+            SPLICE_DEV_REGION(20);
             // the forward ran the tail of this block on the [CLS] rows only: so does the backward (the gradient injected at the
             // block output must be zero outside the [CLS] rows -- the Splice appearance term, util/losses.py:90)
             const int rs = c->Tld * D, hs = c->Tld * Hd;
@@ -692,17 +694,17 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
             {
                 GemmEpi e = {};
                 e.aux = c->hpre[l] + r0 * Hd; e.ldaux = Hd; e.out_bf = c->dh + r0 * Hd; e.ldbf = Hd;
-                SpliceProfScope ps(11);
+                SpliceProfScope ps(11); SPLICE_DEV_REGION(7);
                 RC(gemm_nt_launch(EPI_GELU_GRAD | EPI_OUT_BF, g_bf, D, W.fc2.wT, D, R, Hd, D, e, s));
             }
             {
                 GemmEpi e = {};
                 e.out_f32 = c->dln + r0 * D; e.ldo = D; e.ksplit = ks; e.slab_stride = (long long)slab;
-                SpliceProfScope ps(5);
+                SpliceProfScope ps(5); SPLICE_DEV_REGION(8);
                 RC(gemm_nt_launch(EPI_OUT_F32, c->dh + r0 * Hd, Hd, W.fc1.wT, Hd, R, D, Hd, e, s));
             }
             {
-                SpliceProfScope ps(10);
+                SpliceProfScope ps(10); SPLICE_DEV_REGION(9);
                 RC(layernorm_bwd_slabs_launch(c->dln + r0 * D, gemm_splitk_slabs(R, ks), slab, c->xmid[l] + r0 * D, W.ln2_g, c->mean2[l] + r0, c->rstd2[l] + r0, g, g, g_bf, R, D, s));
             }
             // attention branch
@@ -712,7 +714,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
                 // delta = rowsum(dO * O) per (pass, head, query) for the attention backward, formed where dO is produced
                 e.rd_other = c->attn_out[l] + r0 * D; e.ld_rd = D; e.rd_rows = c->Tld;
                 e.rowdot = c->delta + (size_t)pass_begin * v->heads * c->Tld;
-                SpliceProfScope ps(11);
+                SpliceProfScope ps(11); SPLICE_DEV_REGION(10);
                 RC(gemm_nt_launch(EPI_OUT_BF | EPI_ROWDOT, g_bf, D, W.proj.wT, D, R, D, D, e, s));
             }
             {
@@ -721,7 +723,7 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
                 a.D = D; a.H = v->heads; a.scale = v->qfold ? kLn2 : 0.125f; a.qfold = v->qfold; a.out = c->attn_out[l] + r0 * D;
                 a.lse = c->lse[l] + (size_t)pass_begin * v->heads * c->Tld;
                 a.dout = c->dout + r0 * D; a.doutT = nullptr; a.delta = c->delta + (size_t)pass_begin * v->heads * c->Tld; a.delta_ready = 1; a.dqkv = dqkv;
-                SpliceProfScope ps(6);
+                SpliceProfScope ps(6); SPLICE_DEV_REGION(11);
                 RC(attn_bwd_launch(&a, s));
             }
             g_after_mlp = g;
@@ -733,11 +735,11 @@ int splice_vit_backward(void* ctx, int pass_begin, int pass_end, const float* co
         {
             GemmEpi e = {};
             e.out_f32 = c->dln + r0 * D; e.ldo = D; e.ksplit = ks; e.slab_stride = (long long)slab;
-            SpliceProfScope ps(5);
+            SpliceProfScope ps(5); SPLICE_DEV_REGION(12);
             RC(gemm_nt_launch(EPI_OUT_F32, dqkv, 3 * D, W.qkv.wT, 3 * D, R, D, 3 * D, e, s));
         }
         {
-            SpliceProfScope ps(10);
+            SpliceProfScope ps(10); SPLICE_DEV_REGION(9);
             RC(layernorm_bwd_slabs_launch(c->dln + r0 * D, gemm_splitk_slabs(R, ks), slab, c->xs[l] + r0 * D, W.ln1_g, c->mean1[l] + r0, c->rstd1[l] + r0, g_after_mlp, g, g_bf, R, D, s));
         }
         g_live = true;
